@@ -1,0 +1,194 @@
+"""oracle -- ctypes binding of the CPU parity oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package; the product (ark_vrf_amd) never does.  The C sources under oracle/
+restate the reference path (each function cites /root/reference file:line) and are
+pinned to the reference's known-answer vectors by tests/test_oracle_golden.py.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_DIR, "_build", "liborc.so")
+
+BANDERSNATCH = 0
+BABYJUBJUB = 1
+
+OK, VERIFICATION_FAILURE, INVALID_DATA = 0, 1, 2
+
+
+def build(force=False):
+    srcs = [os.path.join(_DIR, f) for f in os.listdir(_DIR) if f.endswith((".c", ".h"))]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", _DIR, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _buf(n):
+    return (C.c_uint8 * n)()
+
+
+def _b(x):
+    return bytes(x)
+
+
+def _u8(data):
+    data = bytes(data)
+    return (C.c_uint8 * max(1, len(data))).from_buffer_copy(data.ljust(1, b"\0"))
+
+
+def _u32(vals):
+    vals = list(vals)
+    return (C.c_uint32 * max(1, len(vals)))(*vals)
+
+
+def from_seed(suite, seed):
+    sk, pk = _buf(32), _buf(32)
+    assert lib().orc_from_seed(suite, _u8(seed), sk, pk) == 0
+    return _b(sk), _b(pk)
+
+
+def sk_to_pk(suite, sk):
+    pk = _buf(32)
+    assert lib().orc_sk_to_pk(suite, _u8(sk), pk) == 0
+    return _b(pk)
+
+
+def hash_to_curve(suite, data):
+    out = _buf(32)
+    st = lib().orc_hash_to_curve(suite, _u8(data), C.c_size_t(len(data)), out)
+    assert st == 0, st
+    return _b(out)
+
+
+def vrf_output(suite, sk, inp):
+    out = _buf(32)
+    assert lib().orc_vrf_output(suite, _u8(sk), _u8(inp), out) == 0
+    return _b(out)
+
+
+def point_to_hash(suite, pt, n=32):
+    out = _buf(n)
+    assert lib().orc_point_to_hash(suite, _u8(pt), out, C.c_size_t(n)) == 0
+    return _b(out)
+
+
+def thin_prove(suite, sk, ios, ad):
+    """ios: list of (input32, output32)."""
+    iob = b"".join(i + o for i, o in ios)
+    proof = _buf(64)
+    st = lib().orc_thin_prove(suite, _u8(sk), _u8(iob), C.c_size_t(len(ios)), _u8(ad), C.c_size_t(len(ad)), proof)
+    assert st == 0, st
+    return _b(proof)
+
+
+def thin_verify(suite, pk, ios, ad, proof):
+    iob = b"".join(i + o for i, o in ios)
+    return lib().orc_thin_verify(suite, _u8(pk), _u8(iob), C.c_size_t(len(ios)), _u8(ad), C.c_size_t(len(ad)), _u8(proof))
+
+
+def _batch_args(items_ios, ads):
+    iob = b"".join(i + o for ios in items_ios for i, o in ios)
+    counts = [len(ios) for ios in items_ios]
+    adb = b"".join(ads)
+    adl = [len(a) for a in ads]
+    return _u8(iob), _u32(counts), _u8(adb), _u32(adl), sum(counts)
+
+
+def thin_batch_verify(suite, pks, items_ios, ads, proofs):
+    n = len(pks)
+    iob, cnt, adb, adl, _ = _batch_args(items_ios, ads)
+    return lib().orc_thin_batch_verify(suite, C.c_size_t(n), _u8(b"".join(pks)), iob, cnt, adb, adl, _u8(b"".join(proofs)))
+
+
+def thin_batch_terms(suite, pks, items_ios, ads, proofs):
+    """Returns (status, bases_xy bytes, scalars bytes) of the batch MSM (src/thin.rs:282-317)."""
+    n = len(pks)
+    iob, cnt, adb, adl, tot = _batch_args(items_ios, ads)
+    cap = 2 * n + 2 * tot + 1
+    bases, sc = _buf(cap * 64), _buf(cap * 32)
+    k = C.c_size_t(0)
+    st = lib().orc_thin_batch_terms(suite, C.c_size_t(n), _u8(b"".join(pks)), iob, cnt, adb, adl,
+                                    _u8(b"".join(proofs)), bases, sc, C.byref(k))
+    return st, _b(bases)[: 64 * k.value], _b(sc)[: 32 * k.value]
+
+
+def pedersen_prove(suite, sk, ios, ad):
+    iob = b"".join(i + o for i, o in ios)
+    proof, bl = _buf(160), _buf(32)
+    st = lib().orc_pedersen_prove(suite, _u8(sk), _u8(iob), C.c_size_t(len(ios)), _u8(ad), C.c_size_t(len(ad)), proof, bl)
+    assert st == 0, st
+    return _b(proof), _b(bl)
+
+
+def pedersen_verify(suite, ios, ad, proof):
+    iob = b"".join(i + o for i, o in ios)
+    return lib().orc_pedersen_verify(suite, _u8(iob), C.c_size_t(len(ios)), _u8(ad), C.c_size_t(len(ad)), _u8(proof))
+
+
+def pedersen_batch_verify(suite, items_ios, ads, proofs):
+    n = len(proofs)
+    iob, cnt, adb, adl, _ = _batch_args(items_ios, ads)
+    return lib().orc_pedersen_batch_verify(suite, C.c_size_t(n), iob, cnt, adb, adl, _u8(b"".join(proofs)))
+
+
+def pedersen_batch_terms(suite, items_ios, ads, proofs):
+    n = len(proofs)
+    iob, cnt, adb, adl, _ = _batch_args(items_ios, ads)
+    cap = 5 * n + 2
+    bases, sc = _buf(cap * 64), _buf(cap * 32)
+    k = C.c_size_t(0)
+    st = lib().orc_pedersen_batch_terms(suite, C.c_size_t(n), iob, cnt, adb, adl, _u8(b"".join(proofs)),
+                                        bases, sc, C.byref(k))
+    return st, _b(bases)[: 64 * k.value], _b(sc)[: 32 * k.value]
+
+
+def msm(suite, bases_xy, scalars, algo=1):
+    n = len(scalars) // 32
+    assert len(bases_xy) == 64 * n
+    out = _buf(64)
+    st = lib().orc_msm(suite, C.c_size_t(n), _u8(bases_xy), _u8(scalars), out, algo)
+    assert st == 0, st
+    return _b(out)
+
+
+def point_decompress(suite, pt, validate=False):
+    out = _buf(64)
+    st = lib().orc_point_decompress(suite, _u8(pt), out, int(validate))
+    return st, _b(out)
+
+
+def point_compress(suite, xy):
+    out = _buf(32)
+    assert lib().orc_point_compress(suite, _u8(xy), out) == 0
+    return _b(out)
+
+
+def suite_point(suite, which):
+    out = _buf(32)
+    lib().orc_suite_point(suite, which, out)
+    return _b(out)
+
+
+def smul(suite, k, pt):
+    out = _buf(32)
+    assert lib().orc_smul(suite, _u8(k), _u8(pt), out) == 0
+    return _b(out)
+
+
+def sha512(data):
+    out = _buf(64)
+    lib().orc_sha512(_u8(data), C.c_size_t(len(data)), out)
+    return _b(out)

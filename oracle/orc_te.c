@@ -1,0 +1,213 @@
+/*
+ * oracle/orc_te.c -- suites and twisted-Edwards group arithmetic (TEST ORACLE).
+ *
+ * Restates, from the published formulas, what the reference gets from arkworks
+ * `ark_ec::twisted_edwards::{Affine, Projective}` (ark-ec 0.6, third-party):
+ * extended coordinates (X:Y:T:Z), add-2008-hwcd / dbl-2008-hwcd for general `a`.
+ * Call sites in the reference: src/lib.rs:332,392 (sk*G, sk*I), src/thin.rs:119,158,
+ * src/pedersen.rs:148-167,229-245, src/utils/common.rs:400-404,414.
+ * Suite constants: src/suites/bandersnatch.rs:13-14,62-105, src/suites/baby_jubjub.rs:12-13,56-95.
+ * Any correct group law yields the same group element; parity is defined on the
+ * normalised affine result / its encoding.
+ */
+#include "orc.h"
+#include <stdlib.h>
+#include <string.h>
+
+static suite_t g_suites[2];
+static int g_init = 0;
+
+static void fq_dec(u256 *o, const char *dec, const mont_t *m) {
+    u256 t; u256_from_dec(&t, dec); mont_to(o, &t, m);
+}
+static void fq_small(u256 *o, uint64_t v, const mont_t *m) {
+    u256 t = {{v, 0, 0, 0}}; mont_to(o, &t, m);
+}
+
+static void init_suites(void) {
+    u256 p;
+    /* ---- Bandersnatch-SHA512-ELL2-v1 (src/suites/bandersnatch.rs:62-105) ---- */
+    suite_t *s = &g_suites[0];
+    memset(s, 0, sizeof *s);
+    s->id = ORC_SUITE_BANDERSNATCH;
+    s->suite_id = "Bandersnatch-SHA512-ELL2-v1"; s->suite_id_len = 27;
+    u256_from_dec(&p, "52435875175126190479447740508185965837690552500527637822603658699938581184513");
+    mont_init(&s->fq, &p);
+    u256_from_dec(&p, "13108968793781547619861935127046491459309155893440570251786403306729687672801");
+    mont_init(&s->fr, &p);
+    { u256 five; fq_small(&five, 5, &s->fq); mont_neg(&s->a, &five, &s->fq); }
+    s->a_is_minus5 = 1;
+    fq_dec(&s->d, "45022363124591815672509500913686876175488063829319466900776701791074614335719", &s->fq);
+    s->cofactor = 4; s->h2c = ORC_H2C_ELL2;
+    fq_dec(&s->G.x, "18886178867200960497001835917649091219057080094937609519140440539760939937304", &s->fq);
+    fq_dec(&s->G.y, "19188667384257783945677642223292697773471335439753913231509108946878080696678", &s->fq);
+    fq_dec(&s->B.x, "23335687741101763108036518445642207119627658113885888016488710494487028845889", &s->fq);
+    fq_dec(&s->B.y, "5552214580375038693022409684979828600325210968745774080859660443337357929963", &s->fq);
+    fq_dec(&s->ACC.x, "14056632001415368875257708737821299882600475929746323097150942355715730684350", &s->fq);
+    fq_dec(&s->ACC.y, "10322661992765989500407719465917595459409463902187386706652408883505670839210", &s->fq);
+    fq_dec(&s->PAD.x, "26913883415342152801331916189968962157924271221160514298872262294143390094043", &s->fq);
+    fq_dec(&s->PAD.y, "30874728313203001508631936119690348239461579770372782660098261717479009115354", &s->fq);
+    /* Elligator2 Montgomery-model constants: src/suites/bandersnatch_sw.rs:104-111 (J = A, K = B), Z = 5 */
+    fq_dec(&s->ell2_j, "29978822694968839326280996386011761570173833766074948509196803838190355340952", &s->fq);
+    fq_dec(&s->ell2_k, "25465760566081946422412445027709227188579564747101592991722834452325077642517", &s->fq);
+    fq_small(&s->ell2_z, 5, &s->fq);
+
+    /* ---- BabyJubJub-SHA512-TAI-v1 (src/suites/baby_jubjub.rs:56-95) ---- */
+    s = &g_suites[1];
+    memset(s, 0, sizeof *s);
+    s->id = ORC_SUITE_BABYJUBJUB;
+    s->suite_id = "BabyJubJub-SHA512-TAI-v1"; s->suite_id_len = 24;
+    u256_from_dec(&p, "21888242871839275222246405745257275088548364400416034343698204186575808495617");
+    mont_init(&s->fq, &p);
+    u256_from_dec(&p, "2736030358979909402780800718157159386076813972158567259200215660948447373041");
+    mont_init(&s->fr, &p);
+    fq_small(&s->a, 1, &s->fq);
+    fq_dec(&s->d, "9706598848417545097372247223557719406784115219466060233080913168975159366771", &s->fq);
+    s->cofactor = 8; s->h2c = ORC_H2C_TAI;
+    fq_dec(&s->G.x, "19698561148652590122159747500897617769866003486955115824547446575314762165298", &s->fq);
+    fq_dec(&s->G.y, "19298250018296453272277890825869354524455968081175474282777126169995084727839", &s->fq);
+    fq_dec(&s->B.x, "15549380791300914366206471199568039679131690710803662429646809536753521087193", &s->fq);
+    fq_dec(&s->B.y, "15218614024055502695611547593111691164731001864276292210438920202280814188379", &s->fq);
+    fq_dec(&s->ACC.x, "6402374321243162085389111671722843560682527921646684137786768606010797479351", &s->fq);
+    fq_dec(&s->ACC.y, "9735581299071570006712034490635195155689931359428941496570758703259384062170", &s->fq);
+    fq_dec(&s->PAD.x, "11167490195257431015694161063225325511805242064780376648595733691987293447528", &s->fq);
+    fq_dec(&s->PAD.y, "18403369502642103292159933062507105566469227524991433735553439433605496057425", &s->fq);
+    g_init = 1;
+}
+
+const suite_t *orc_suite(int id) {
+    if (!g_init) init_suites();
+    if (id < 0 || id > 1) return NULL;
+    return &g_suites[id];
+}
+
+/* ---- group law ---- */
+#define FQ (&s->fq)
+
+void te_identity(te_ext *o, const suite_t *s) {
+    memset(o, 0, sizeof *o); o->y = s->fq.r1; o->z = s->fq.r1;
+}
+void te_from_aff(te_ext *o, const te_aff *a, const suite_t *s) {
+    o->x = a->x; o->y = a->y; o->z = s->fq.r1; mont_mul(&o->t, &a->x, &a->y, FQ);
+}
+/* add-2008-hwcd (general a): 9M + 1*a + 1*d */
+void te_add(te_ext *o, const te_ext *p, const te_ext *q, const suite_t *s) {
+    u256 A, B, C, D, E, F, G, H, t0, t1;
+    mont_mul(&A, &p->x, &q->x, FQ);
+    mont_mul(&B, &p->y, &q->y, FQ);
+    mont_mul(&C, &p->t, &q->t, FQ); mont_mul(&C, &C, &s->d, FQ);
+    mont_mul(&D, &p->z, &q->z, FQ);
+    mont_add(&t0, &p->x, &p->y, FQ); mont_add(&t1, &q->x, &q->y, FQ);
+    mont_mul(&E, &t0, &t1, FQ); mont_sub(&E, &E, &A, FQ); mont_sub(&E, &E, &B, FQ);
+    mont_sub(&F, &D, &C, FQ); mont_add(&G, &D, &C, FQ);
+    mont_mul(&t0, &s->a, &A, FQ); mont_sub(&H, &B, &t0, FQ);
+    mont_mul(&o->x, &E, &F, FQ); mont_mul(&o->y, &G, &H, FQ);
+    mont_mul(&o->t, &E, &H, FQ); mont_mul(&o->z, &F, &G, FQ);
+}
+void te_madd(te_ext *o, const te_ext *p, const te_aff *q, const suite_t *s) {
+    te_ext e; te_from_aff(&e, q, s); te_add(o, p, &e, s);
+}
+/* dbl-2008-hwcd */
+void te_dbl(te_ext *o, const te_ext *p, const suite_t *s) {
+    u256 A, B, C, D, E, F, G, H, t0;
+    mont_sqr(&A, &p->x, FQ); mont_sqr(&B, &p->y, FQ);
+    mont_sqr(&C, &p->z, FQ); mont_add(&C, &C, &C, FQ);
+    mont_mul(&D, &s->a, &A, FQ);
+    mont_add(&t0, &p->x, &p->y, FQ); mont_sqr(&E, &t0, FQ); mont_sub(&E, &E, &A, FQ); mont_sub(&E, &E, &B, FQ);
+    mont_add(&G, &D, &B, FQ); mont_sub(&F, &G, &C, FQ); mont_sub(&H, &D, &B, FQ);
+    mont_mul(&o->x, &E, &F, FQ); mont_mul(&o->y, &G, &H, FQ);
+    mont_mul(&o->t, &E, &H, FQ); mont_mul(&o->z, &F, &G, FQ);
+}
+void te_neg_aff(te_aff *o, const te_aff *p, const suite_t *s) { mont_neg(&o->x, &p->x, FQ); o->y = p->y; }
+
+void te_to_aff(te_aff *o, const te_ext *p, const suite_t *s) {
+    u256 zi; mont_inv(&zi, &p->z, FQ);
+    mont_mul(&o->x, &p->x, &zi, FQ); mont_mul(&o->y, &p->y, &zi, FQ);
+}
+/* CurveGroup::normalize_batch (Montgomery's trick), src/utils/common.rs:414 */
+void te_batch_to_aff(te_aff *o, const te_ext *p, size_t n, const suite_t *s) {
+    if (!n) return;
+    u256 *pre = (u256 *)malloc(n * sizeof(u256));
+    u256 acc = s->fq.r1;
+    for (size_t i = 0; i < n; i++) { pre[i] = acc; mont_mul(&acc, &acc, &p[i].z, FQ); }
+    u256 inv; mont_inv(&inv, &acc, FQ);
+    for (size_t i = n; i-- > 0;) {
+        u256 zi; mont_mul(&zi, &inv, &pre[i], FQ);
+        mont_mul(&inv, &inv, &p[i].z, FQ);
+        mont_mul(&o[i].x, &p[i].x, &zi, FQ); mont_mul(&o[i].y, &p[i].y, &zi, FQ);
+    }
+    free(pre);
+}
+int te_is_identity_ext(const te_ext *p, const suite_t *s) {
+    (void)s; return u256_is_zero(&p->x) && u256_cmp(&p->y, &p->z) == 0;
+}
+int te_is_identity_aff(const te_aff *p, const suite_t *s) {
+    return u256_is_zero(&p->x) && u256_cmp(&p->y, &s->fq.r1) == 0;
+}
+int te_eq_ext(const te_ext *p, const te_ext *q, const suite_t *s) {
+    u256 a, b;
+    mont_mul(&a, &p->x, &q->z, FQ); mont_mul(&b, &q->x, &p->z, FQ);
+    if (u256_cmp(&a, &b)) return 0;
+    mont_mul(&a, &p->y, &q->z, FQ); mont_mul(&b, &q->y, &p->z, FQ);
+    return u256_cmp(&a, &b) == 0;
+}
+int te_on_curve(const te_aff *p, const suite_t *s) {
+    u256 x2, y2, l, r;
+    mont_sqr(&x2, &p->x, FQ); mont_sqr(&y2, &p->y, FQ);
+    mont_mul(&l, &s->a, &x2, FQ); mont_add(&l, &l, &y2, FQ);
+    mont_mul(&r, &x2, &y2, FQ); mont_mul(&r, &r, &s->d, FQ); mont_add(&r, &r, &s->fq.r1, FQ);
+    return u256_cmp(&l, &r) == 0;
+}
+/* double-and-add, MSB first; scalar is a plain (non-Montgomery) integer */
+void te_smul(te_ext *o, const te_aff *p, const u256 *k, const suite_t *s) {
+    te_ext acc, pe; te_identity(&acc, s); te_from_aff(&pe, p, s);
+    int started = 0;
+    for (int i = 255; i >= 0; i--) {
+        if (started) te_dbl(&acc, &acc, s);
+        if ((k->l[i / 64] >> (i % 64)) & 1) { te_add(&acc, &acc, &pe, s); started = 1; }
+    }
+    *o = acc;
+}
+/* is_in_correct_subgroup_assuming_on_curve: r * P == 0 */
+int te_in_subgroup(const te_aff *p, const suite_t *s) {
+    te_ext e; te_smul(&e, p, &s->fr.p, s); return te_is_identity_ext(&e, s);
+}
+
+/* ---- codecs (ark-serialize CanonicalSerialize for TE affine) ---- */
+static int fq_is_negative(const u256 *x_mont, const suite_t *s) { /* x > (q-1)/2 */
+    u256 x; mont_from(&x, x_mont, FQ); return u256_cmp(&x, &s->fq.pm1_half) > 0;
+}
+void te_encode(uint8_t out[32], const te_aff *p, const suite_t *s) {
+    u256 y; mont_from(&y, &p->y, FQ); u256_to_le(out, &y);
+    if (fq_is_negative(&p->x, s)) out[31] |= 0x80;
+}
+int te_decode(te_aff *o, const uint8_t in[32], const suite_t *s) {
+    uint8_t b[32]; memcpy(b, in, 32);
+    int neg = b[31] >> 7; b[31] &= 0x7f;
+    u256 y; u256_from_le(&y, b);
+    if (u256_cmp(&y, &s->fq.p) >= 0) return ORC_INVALID_DATA;
+    mont_to(&o->y, &y, FQ);
+    /* x^2 = (1 - y^2) / (a - d y^2) */
+    u256 y2, num, den, x2, x;
+    mont_sqr(&y2, &o->y, FQ);
+    mont_sub(&num, &s->fq.r1, &y2, FQ);
+    mont_mul(&den, &s->d, &y2, FQ); mont_sub(&den, &s->a, &den, FQ);
+    if (u256_is_zero(&den)) return ORC_INVALID_DATA;
+    mont_inv(&den, &den, FQ); mont_mul(&x2, &num, &den, FQ);
+    if (!mont_sqrt(&x, &x2, FQ)) return ORC_INVALID_DATA;
+    if (fq_is_negative(&x, s) != neg) mont_neg(&x, &x, FQ);
+    /* x == 0 with the negative flag set is a non-canonical encoding */
+    if (u256_is_zero(&x) && neg) return ORC_INVALID_DATA;
+    o->x = x;
+    return ORC_OK;
+}
+void te_encode_xy(uint8_t out[64], const te_aff *p, const suite_t *s) {
+    u256 t; mont_from(&t, &p->x, FQ); u256_to_le(out, &t);
+    mont_from(&t, &p->y, FQ); u256_to_le(out + 32, &t);
+}
+int te_decode_xy(te_aff *o, const uint8_t in[64], const suite_t *s) {
+    u256 x, y; u256_from_le(&x, in); u256_from_le(&y, in + 32);
+    if (u256_cmp(&x, &s->fq.p) >= 0 || u256_cmp(&y, &s->fq.p) >= 0) return ORC_INVALID_DATA;
+    mont_to(&o->x, &x, FQ); mont_to(&o->y, &y, FQ);
+    return ORC_OK;
+}

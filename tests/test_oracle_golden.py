@@ -1,0 +1,109 @@
+"""Pins the CPU oracle to the reference's own known-answer vectors.
+
+Vectors: tests/golden/*.json are verbatim copies of /root/reference/data/vectors/
+{bandersnatch_sha-512_ell2,baby-jubjub_sha-512_tai}_{thin,pedersen}.json -- the files the
+reference asserts in src/testing.rs:263-280, src/thin.rs:635-648, src/pedersen.rs:793-809.
+Seeds per src/testing.rs:291-299.
+"""
+import hashlib
+import json
+import os
+
+import pytest
+
+import oracle as orc
+
+SUITES = {
+    "bandersnatch_sha-512_ell2": orc.BANDERSNATCH,
+    "baby-jubjub_sha-512_tai": orc.BABYJUBJUB,
+}
+SEEDS = [1, 2, 3, 4, 5, 5, 6]
+
+
+def load(golden_dir, name, scheme):
+    with open(os.path.join(golden_dir, f"{name}_{scheme}.json")) as f:
+        return json.load(f)
+
+
+def test_sha512_matches_hashlib():
+    for n in [0, 1, 55, 111, 112, 113, 127, 128, 129, 255, 256, 1000]:
+        d = bytes((i * 7 + n) & 0xFF for i in range(n))
+        assert orc.sha512(d) == hashlib.sha512(d).digest()
+
+
+@pytest.mark.parametrize("name", list(SUITES))
+@pytest.mark.parametrize("scheme", ["thin", "pedersen"])
+def test_base_fields(golden_dir, name, scheme):
+    s = SUITES[name]
+    for i, v in enumerate(load(golden_dir, name, scheme)):
+        sk, pk = bytes.fromhex(v["sk"]), bytes.fromhex(v["pk"])
+        seed = bytes([SEEDS[i]]) + bytes(31)
+        assert orc.from_seed(s, seed) == (sk, pk)                      # src/lib.rs:346-369
+        assert orc.sk_to_pk(s, sk) == pk
+        h = orc.hash_to_curve(s, bytes.fromhex(v["alpha"]))           # src/testing.rs:271
+        assert h.hex() == v["h"]
+        gamma = orc.vrf_output(s, sk, h)                               # src/testing.rs:275
+        assert gamma.hex() == v["gamma"]
+        assert orc.point_to_hash(s, gamma).hex() == v["beta"]          # src/testing.rs:278
+
+
+@pytest.mark.parametrize("name", list(SUITES))
+def test_thin_vectors(golden_dir, name):
+    s = SUITES[name]
+    vs = load(golden_dir, name, "thin")
+    pks, ios, ads, proofs = [], [], [], []
+    for v in vs:
+        sk, pk = bytes.fromhex(v["sk"]), bytes.fromhex(v["pk"])
+        io = [(bytes.fromhex(v["h"]), bytes.fromhex(v["gamma"]))]
+        ad = bytes.fromhex(v["ad"])
+        proof = orc.thin_prove(s, sk, io, ad)                          # src/thin.rs:635-648
+        assert proof.hex() == v["proof_r"] + v["proof_s"]
+        assert orc.thin_verify(s, pk, io, ad, proof) == orc.OK
+        bad = bytearray(proof); bad[40] ^= 1
+        assert orc.thin_verify(s, pk, io, ad, bytes(bad)) == orc.VERIFICATION_FAILURE
+        assert orc.thin_verify(s, pk, io, ad + b"x", proof) == orc.VERIFICATION_FAILURE
+        pks.append(pk); ios.append(io); ads.append(ad); proofs.append(proof)
+    # batch equation on the reference's 7 proofs: 29-term MSM == identity
+    st, bases, sc = orc.thin_batch_terms(s, pks, ios, ads, proofs)
+    assert st == orc.OK and len(sc) == 32 * 29
+    ident = bytes(32) + (1).to_bytes(32, "little")
+    assert orc.msm(s, bases, sc, algo=1) == ident
+    assert orc.msm(s, bases, sc, algo=0) == ident
+    assert orc.thin_batch_verify(s, pks, ios, ads, proofs) == orc.OK
+    bad = bytearray(proofs[3]); bad[33] ^= 4
+    assert orc.thin_batch_verify(s, pks, ios, ads, proofs[:3] + [bytes(bad)] + proofs[4:]) == orc.VERIFICATION_FAILURE
+
+
+@pytest.mark.parametrize("name", list(SUITES))
+def test_pedersen_vectors(golden_dir, name):
+    s = SUITES[name]
+    vs = load(golden_dir, name, "pedersen")
+    ios, ads, proofs = [], [], []
+    for v in vs:
+        sk = bytes.fromhex(v["sk"])
+        io = [(bytes.fromhex(v["h"]), bytes.fromhex(v["gamma"]))]
+        ad = bytes.fromhex(v["ad"])
+        proof, blinding = orc.pedersen_prove(s, sk, io, ad)            # src/pedersen.rs:793-809
+        assert blinding.hex() == v["blinding"]
+        assert proof.hex() == v["proof_pk_com"] + v["proof_r"] + v["proof_ok"] + v["proof_s"] + v["proof_sb"]
+        assert orc.pedersen_verify(s, io, ad, proof) == orc.OK
+        bad = bytearray(proof); bad[100] ^= 1
+        assert orc.pedersen_verify(s, io, ad, bytes(bad)) == orc.VERIFICATION_FAILURE
+        ios.append(io); ads.append(ad); proofs.append(proof)
+    st, bases, sc = orc.pedersen_batch_terms(s, ios, ads, proofs)
+    assert st == orc.OK and len(sc) == 32 * 37
+    ident = bytes(32) + (1).to_bytes(32, "little")
+    assert orc.msm(s, bases, sc, algo=1) == ident
+    assert orc.pedersen_batch_verify(s, ios, ads, proofs) == orc.OK
+    bad = bytearray(proofs[2]); bad[130] ^= 4
+    assert orc.pedersen_batch_verify(s, ios, ads, proofs[:2] + [bytes(bad)] + proofs[3:]) == orc.VERIFICATION_FAILURE
+
+
+@pytest.mark.parametrize("name", list(SUITES))
+def test_suite_constants(golden_dir, name):
+    """BLINDING_BASE / ACCUMULATOR_BASE / PADDING are hash-to-curve outputs
+    (src/pedersen.rs:39,568-579 `blinding_base_check`; src/ring.rs:66-69 `padding_check`, `accumulator_base_check`)."""
+    s = SUITES[name]
+    assert orc.hash_to_curve(s, b"pedersen-blinding") == orc.suite_point(s, 1)
+    assert orc.hash_to_curve(s, b"ring-accumulator") == orc.suite_point(s, 2)
+    assert orc.hash_to_curve(s, b"ring-padding") == orc.suite_point(s, 3)
