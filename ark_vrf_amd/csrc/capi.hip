@@ -1,0 +1,258 @@
+// capi.hip -- the C ABI of libavrf.so (include/avrf.h): contexts, staging, orchestration.
+//
+// Host-side counterpart of the reference's scheme layer for the accelerated path
+// (src/thin.rs:188-326 BatchVerifier; src/pedersen.rs:303-426).  All group/field work is
+// launched on the context's HIP stream; the host only (1) runs the sequential weight
+// transcript (host_sha512.h), (2) finishes the MSM's O(256)-step window Horner (host_te.h).
+#include "../../include/avrf.h"
+#include "host_sha512.h"
+#include "host_te.h"
+#include "msm.h"
+#include "vrf_batch.h"
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+using namespace avrf;
+
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "avrf: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return AVRF_ERR_NO_DEVICE; } } while (0)
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr; size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return (T *)p; }
+};
+struct PinBuf {
+  void *p = nullptr; size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    hipError_t e = hipHostMalloc(&p, bytes + 256);
+    if (e == hipSuccess) cap = bytes + 256;
+    return e;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct avrf_ctx {
+  int suite = 0, device = 0;
+  hipStream_t stream = nullptr;
+  MsmWorkspace ws;
+  // staged batch
+  int staged_kind = 0;            // 0 none, 1 thin, 2 pedersen
+  size_t n = 0, tot_io = 0, n_terms = 0;
+  DevBuf d_pks, d_ios, d_io_off, d_ads, d_ad_off, d_proofs;
+  std::vector<uint8_t> h_resp;    // host copy of the response scalars (s [, sb]) for the weight transcript
+  DevBuf d_c, d_z, d_flags, d_scalars, d_pre, d_gpart, d_misc;
+  PinBuf h_c, h_flags, h_io;
+  double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+extern "C" {
+
+const char *avrf_version(void) { return "avrf 0.1 (gfx950; thin/pedersen batch; te-msm)"; }
+
+int avrf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int avrf_ctx_create(int suite, int device, avrf_ctx **out) {
+  if (!out || suite < 0 || suite > 1) return AVRF_ERR_BAD_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return AVRF_ERR_NO_DEVICE;
+  HIP_TRY(hipSetDevice(device));
+  avrf_ctx *c = new avrf_ctx();
+  c->suite = suite; c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return AVRF_ERR_NO_DEVICE; }
+  *out = c;
+  return AVRF_OK;
+}
+
+void avrf_ctx_destroy(avrf_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  c->ws.release();
+  DevBuf *bufs[] = {&c->d_pks, &c->d_ios, &c->d_io_off, &c->d_ads, &c->d_ad_off, &c->d_proofs, &c->d_c, &c->d_z,
+                    &c->d_flags, &c->d_scalars, &c->d_pre, &c->d_gpart, &c->d_misc};
+  for (DevBuf *b : bufs) b->release();
+  c->h_c.release(); c->h_flags.release(); c->h_io.release();
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static int finish_point(avrf_ctx *c, const HostExt &r, uint8_t out_xy[64]) {
+  if (c->suite == 0) HostTe<SuiteBandersnatch>::to_affine_bytes(r, out_xy);
+  else HostTe<SuiteBabyJubJub>::to_affine_bytes(r, out_xy);
+  return AVRF_OK;
+}
+static bool point_is_identity(avrf_ctx *c, const HostExt &r) {
+  return c->suite == 0 ? HostTe<SuiteBandersnatch>::is_identity(r) : HostTe<SuiteBabyJubJub>::is_identity(r);
+}
+static bool scalar_in_range(int suite, const uint8_t *s) {
+  H256 v; memcpy(v.l, s, 32);
+  return suite == 0 ? !HostField<FrBandersnatch>::geq_p(v) : !HostField<FrBabyJubJub>::geq_p(v);
+}
+
+int avrf_msm_te(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *scalars, uint8_t out_xy[64]) {
+  if (!c || !out_xy || (n && (!bases_xy || !scalars))) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  for (size_t i = 0; i < n; i++) if (!scalar_in_range(c->suite, scalars + 32 * i)) return AVRF_INVALID_DATA;
+  HostExt r;
+  if (n) {
+    HIP_TRY(c->d_misc.ensure(n * 64)); HIP_TRY(c->d_scalars.ensure(n * 32)); HIP_TRY(c->d_pre.ensure(n * sizeof(te_pre_raw)));
+    HIP_TRY(c->d_flags.ensure(16)); HIP_TRY(c->h_flags.ensure(16));
+    HIP_TRY(hipMemcpyAsync(c->d_misc.p, bases_xy, n * 64, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+    launch_pre_from_affine(c->suite, c->d_misc.as<uint8_t>(), n, c->d_pre.as<te_pre_raw>(), c->d_flags.as<uint32_t>(), 0, c->stream);
+    HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  if (msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), n, c->ws, c->stream, &r)) return AVRF_ERR_BAD_ARG;
+  if (n && *c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;
+  return finish_point(c, r, out_xy);
+}
+
+// ---------------------------------------------------------------- staging
+
+static int stage_common(avrf_ctx *c, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,
+                        const uint8_t *ads, const uint32_t *ad_lens) {
+  HIP_TRY(c->h_io.ensure((n + 1) * 8));
+  uint32_t *io_off = c->h_io.as<uint32_t>(), *ad_off = io_off + (n + 1);
+  uint64_t a = 0, b = 0;
+  for (size_t j = 0; j < n; j++) { io_off[j] = (uint32_t)a; ad_off[j] = (uint32_t)b; a += io_counts[j]; b += ad_lens[j]; }
+  if (a > 0x3fffffffULL || b > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
+  io_off[n] = (uint32_t)a; ad_off[n] = (uint32_t)b;
+  c->tot_io = (size_t)a;
+  HIP_TRY(c->d_io_off.ensure((n + 1) * 4)); HIP_TRY(c->d_ad_off.ensure((n + 1) * 4));
+  HIP_TRY(c->d_ios.ensure(a * 128 + 16)); HIP_TRY(c->d_ads.ensure(b + 16));
+  HIP_TRY(hipMemcpyAsync(c->d_io_off.p, io_off, (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_ad_off.p, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  if (a) HIP_TRY(hipMemcpyAsync(c->d_ios.p, ios_xy, a * 128, hipMemcpyHostToDevice, c->stream));
+  if (b) HIP_TRY(hipMemcpyAsync(c->d_ads.p, ads, b, hipMemcpyHostToDevice, c->stream));
+  return AVRF_OK;
+}
+
+int avrf_thin_batch_stage(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
+                          const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
+  if (!c) return AVRF_ERR_BAD_ARG;
+  if (n && (!pks_xy || !io_counts || !ad_lens || !proofs)) return AVRF_ERR_BAD_ARG;
+  if (n > 0x0fffffffULL) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  c->staged_kind = 0; c->n = n;
+  if (n == 0) { c->staged_kind = 1; c->tot_io = 0; c->n_terms = 0; return AVRF_OK; }
+  int st = stage_common(c, n, ios_xy, io_counts, ads, ad_lens);
+  if (st) return st;
+  HIP_TRY(c->d_pks.ensure(n * 64)); HIP_TRY(c->d_proofs.ensure(n * 96));
+  HIP_TRY(hipMemcpyAsync(c->d_pks.p, pks_xy, n * 64, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_proofs.p, proofs, n * 96, hipMemcpyHostToDevice, c->stream));
+  c->h_resp.resize(n * 32);
+  for (size_t j = 0; j < n; j++) memcpy(&c->h_resp[32 * j], proofs + 96 * j + 64, 32);
+  c->n_terms = 2 * n + 2 * c->tot_io + 1;
+  HIP_TRY(c->d_c.ensure(n * 16)); HIP_TRY(c->d_z.ensure(c->tot_io * 16 + 16)); HIP_TRY(c->d_flags.ensure(16));
+  HIP_TRY(c->h_c.ensure(n * 16)); HIP_TRY(c->h_flags.ensure(16));
+  HIP_TRY(c->d_scalars.ensure(c->n_terms * 32)); HIP_TRY(c->d_pre.ensure(c->n_terms * sizeof(te_pre_raw)));
+  HIP_TRY(c->d_gpart.ensure(((n + 127) / 128) * 32));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->staged_kind = 1;
+  return AVRF_OK;
+}
+
+int avrf_thin_batch_run(avrf_ctx *c) {
+  if (!c || c->staged_kind != 1) return AVRF_ERR_BAD_ARG;
+  if (c->n == 0) return AVRF_OK;                                       // src/thin.rs:262-264
+  HIP_TRY(hipSetDevice(c->device));
+  double t0 = now_us();
+  const size_t n = c->n;
+  BatchDev b;
+  b.pks_xy = c->d_pks.as<uint8_t>(); b.ios_xy = c->d_ios.as<uint8_t>(); b.io_off = c->d_io_off.as<uint32_t>();
+  b.ads = c->d_ads.as<uint8_t>(); b.ad_off = c->d_ad_off.as<uint32_t>(); b.proofs = c->d_proofs.as<uint8_t>(); b.n = (uint32_t)n;
+  HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  launch_thin_prepare(c->suite, b, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_flags.as<uint32_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(c->h_c.p, c->d_c.p, n * 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  double t1 = now_us();
+  if (*c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;            // src/thin.rs:266-271 (+ malformed encodings)
+  // weight transcript, src/thin.rs:274-279: new(SUITE_ID); absorb [0x50]; for each item absorb LE32(c), LE32(s)
+  HostSha512 h;
+  if (c->suite == 0) h.update(SuiteBandersnatch::SUITE_ID, SuiteBandersnatch::SUITE_ID_LEN);
+  else h.update(SuiteBabyJubJub::SUITE_ID, SuiteBabyJubJub::SUITE_ID_LEN);
+  const uint8_t tag = 0x50; h.update(&tag, 1);
+  {
+    const uint8_t *cs = c->h_c.as<uint8_t>();
+    uint8_t rec[64];
+    memset(rec, 0, sizeof rec);
+    for (size_t j = 0; j < n; j++) { memcpy(rec, cs + 16 * j, 16); memcpy(rec + 32, &c->h_resp[32 * j], 32); h.update(rec, 64); }
+  }
+  uint8_t dg[64]; h.final(dg);
+  Seed64 seed;
+  for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, dg + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
+  double t2 = now_us();
+  launch_thin_terms(c->suite, b, seed, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_scalars.as<uint32_t>(),
+                    c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
+  double t3 = now_us();
+  HostExt r;
+  if (msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r)) return AVRF_ERR_BAD_ARG;
+  double t4 = now_us();
+  int st = point_is_identity(c, r) ? AVRF_OK : AVRF_VERIFICATION_FAILURE;   // src/thin.rs:319-322
+  double t5 = now_us();
+  c->timing[0] = t5 - t0; c->timing[1] = t1 - t0; c->timing[2] = t2 - t1; c->timing[3] = t3 - t2; c->timing[4] = t4 - t3; c->timing[5] = t5 - t4;
+  return st;
+}
+
+int avrf_thin_batch_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
+                           const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
+  int st = avrf_thin_batch_stage(c, n, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs);
+  if (st) return st;
+  return avrf_thin_batch_run(c);
+}
+
+size_t avrf_batch_last_terms(avrf_ctx *c, uint8_t *bases_xy, uint8_t *scalars) {
+  if (!c || !c->staged_kind || !c->n_terms) return 0;
+  if (hipSetDevice(c->device) != hipSuccess) return 0;
+  size_t k = c->n_terms;
+  if (scalars) { if (hipMemcpy(scalars, c->d_scalars.p, k * 32, hipMemcpyDeviceToHost) != hipSuccess) return 0; }
+  if (bases_xy) {
+    std::vector<te_pre_raw> pre(k);
+    if (hipMemcpy(pre.data(), c->d_pre.p, k * sizeof(te_pre_raw), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    for (size_t i = 0; i < k; i++) {
+      H256 x, y; memcpy(x.l, pre[i].w, 32); memcpy(y.l, pre[i].w + 8, 32);
+      if (c->suite == 0) { x = HostField<FqBandersnatch>::from_mont(x); y = HostField<FqBandersnatch>::from_mont(y); }
+      else { x = HostField<FqBabyJubJub>::from_mont(x); y = HostField<FqBabyJubJub>::from_mont(y); }
+      memcpy(bases_xy + 64 * i, x.l, 32); memcpy(bases_xy + 64 * i + 32, y.l, 32);
+    }
+  }
+  return k;
+}
+
+void avrf_last_timing(avrf_ctx *c, double out[8]) {
+  if (!c || !out) return;
+  for (int i = 0; i < 8; i++) out[i] = c->timing[i];
+}
+
+}  // extern "C"

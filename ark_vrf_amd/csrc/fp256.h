@@ -1,0 +1,188 @@
+// fp256.h -- 256-bit prime-field arithmetic for gfx950 VALU (8 x u32 limbs, Montgomery R = 2^256).
+//
+// Device counterpart of what the reference gets from arkworks `Fp<MontBackend<_,4>>`
+// (third-party ark-ff 0.6; reached from src/thin.rs:289-311, src/pedersen.rs:373-410 for the
+// scalar field and from every group operation for the base field).  One field element per
+// lane, limbs in VGPRs; products through v_mad_u64_u32.  All moduli on the path have their
+// top bit clear (253..255 bits), which admits the carry-free CIOS form used below.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "consts_gen.h"
+
+namespace avrf {
+
+#define AVRF_DI __device__ __forceinline__
+
+struct fp { uint32_t v[8]; };
+
+template <class F> AVRF_DI fp fp_const(const uint32_t (&c)[8]) {
+  fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = c[i];
+  return r;
+}
+template <class F> AVRF_DI fp fp_one() { return fp_const<F>(F::ONE); }
+AVRF_DI fp fp_zero() { fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = 0;
+  return r; }
+
+AVRF_DI bool fp_is_zero(const fp &a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.v[i];
+  return o == 0;
+}
+AVRF_DI bool fp_eq(const fp &a, const fp &b) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i];
+  return o == 0;
+}
+
+// r = a + b, returns carry
+AVRF_DI uint32_t add8(fp &r, const fp &a, const fp &b) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c += (uint64_t)a.v[i] + b.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+  return (uint32_t)c;
+}
+// r = a - b, returns borrow (0/1)
+AVRF_DI uint32_t sub8(fp &r, const fp &a, const fp &b) {
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c += (int64_t)a.v[i] - (int64_t)b.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+  return (uint32_t)(c & 1);
+}
+template <class F> AVRF_DI uint32_t sub_p(fp &r, const fp &a) {
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c += (int64_t)a.v[i] - (int64_t)F::P[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+  return (uint32_t)(c & 1);
+}
+// a >= p ?  (plain integer compare)
+template <class F> AVRF_DI bool ge_p(const fp &a) { fp t; return sub_p<F>(t, a) == 0; }
+
+template <class F> AVRF_DI fp fp_add(const fp &a, const fp &b) {
+  fp t, u; add8(t, a, b);               // < 2p < 2^256: no carry out
+  uint32_t br = sub_p<F>(u, t);
+#pragma unroll
+  for (int i = 0; i < 8; i++) t.v[i] = br ? t.v[i] : u.v[i];
+  return t;
+}
+template <class F> AVRF_DI fp fp_sub(const fp &a, const fp &b) {
+  fp t; uint32_t br = sub8(t, a, b);
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c += (uint64_t)t.v[i] + (br ? F::P[i] : 0u); t.v[i] = (uint32_t)c; c >>= 32; }
+  return t;
+}
+template <class F> AVRF_DI fp fp_neg(const fp &a) {
+  fp t; int64_t c = 0; bool z = fp_is_zero(a);
+#pragma unroll
+  for (int i = 0; i < 8; i++) { c += (int64_t)F::P[i] - (int64_t)a.v[i]; t.v[i] = z ? 0u : (uint32_t)c; c >>= 32; }
+  return t;
+}
+template <class F> AVRF_DI fp fp_dbl(const fp &a) { return fp_add<F>(a, a); }
+
+// Montgomery product a*b/R mod p.  Carry-free CIOS (top bit of p clear).
+template <class F> AVRF_DI fp fp_mul(const fp &a, const fp &b) {
+  uint32_t t[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t A = (uint64_t)a.v[0] * b.v[i] + t[0];
+    uint32_t m = (uint32_t)A * F::NINV;
+    uint64_t C = (uint64_t)m * F::P[0] + (uint32_t)A;
+    A >>= 32; C >>= 32;
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+      A += (uint64_t)a.v[j] * b.v[i] + t[j];
+      C += (uint64_t)m * F::P[j] + (uint32_t)A;
+      t[j - 1] = (uint32_t)C;
+      A >>= 32; C >>= 32;
+    }
+    t[7] = (uint32_t)(A + C);
+  }
+  fp r, u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  uint32_t br = sub_p<F>(u, r);
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = br ? r.v[i] : u.v[i];
+  return r;
+}
+template <class F> AVRF_DI fp fp_sqr(const fp &a) { return fp_mul<F>(a, a); }
+
+template <class F> AVRF_DI fp fp_to_mont(const fp &a) { return fp_mul<F>(a, fp_const<F>(F::R2)); }
+template <class F> AVRF_DI fp fp_from_mont(const fp &a) {
+  fp one = fp_zero(); one.v[0] = 1; return fp_mul<F>(a, one);
+}
+
+// a^e for a constant exponent (plain 256-bit integer), square-and-multiply MSB first.
+template <class F> AVRF_DI fp fp_pow_const(const fp &a, const uint32_t (&e)[8]) {
+  fp r = fp_one<F>();
+  bool started = false;
+  for (int i = 255; i >= 0; i--) {
+    if (started) r = fp_sqr<F>(r);
+    if ((e[i >> 5] >> (i & 31)) & 1) { r = started ? fp_mul<F>(r, a) : a; started = true; }
+  }
+  return r;
+}
+template <class F> AVRF_DI fp fp_inv(const fp &a) { return fp_pow_const<F>(a, F::PM2); }
+
+// x > (p-1)/2 on the canonical value of a Montgomery-form element ("negative" in ark-serialize)
+template <class F> AVRF_DI bool fp_is_negative_mont(const fp &a_mont) {
+  fp a = fp_from_mont<F>(a_mont), t;
+  // a > HALF  <=>  HALF - a borrows
+  return sub8(t, fp_const<F>(F::HALF), a) != 0;
+}
+template <class F> AVRF_DI bool fp_is_negative_plain(const fp &a) {
+  fp t; return sub8(t, fp_const<F>(F::HALF), a) != 0;
+}
+
+// little-endian bytes <-> limbs (global or local memory)
+AVRF_DI fp fp_load_le(const uint8_t *p) {
+  fp r;
+  if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = w[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      r.v[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+  }
+  return r;
+}
+AVRF_DI void fp_store_le(uint8_t *p, const fp &a) {
+  if ((reinterpret_cast<uintptr_t>(p) & 3) == 0) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = a.v[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) { p[4 * i] = (uint8_t)a.v[i]; p[4 * i + 1] = (uint8_t)(a.v[i] >> 8); p[4 * i + 2] = (uint8_t)(a.v[i] >> 16); p[4 * i + 3] = (uint8_t)(a.v[i] >> 24); }
+  }
+}
+
+// value of `nbytes` little-endian bytes (nbytes <= 64) reduced mod p, Montgomery form.
+// Mirrors PrimeField::from_le_bytes_mod_order as used by src/utils/common.rs:65-76.
+template <class F> AVRF_DI fp fp_from_le_bytes_mod_order_16(const uint32_t w[4]) {
+  // 128-bit value < p for every field on the path (p > 2^250): just convert.
+  fp a = fp_zero();
+#pragma unroll
+  for (int i = 0; i < 4; i++) a.v[i] = w[i];
+  return fp_to_mont<F>(a);
+}
+// 512-bit (lo + hi*2^256): lo*R2/R + hi*R3/R... computed as mont(lo,R2) + mont(mont(hi,R2),R2)
+template <class F> AVRF_DI fp fp_from_wide_mont(const fp &lo, const fp &hi) {
+  fp r2 = fp_const<F>(F::R2);
+  fp l = fp_mul<F>(lo, r2);              // lo * R        (lo may be >= p: mont mul handles any a < 2^256 with b < p)
+  fp h = fp_mul<F>(fp_mul<F>(hi, r2), r2); // hi * R^2 = (hi * 2^256) * R
+  return fp_add<F>(l, h);
+}
+
+}  // namespace avrf

@@ -1,0 +1,46 @@
+// msm.h -- Pippenger bucket MSM over twisted-Edwards curves for gfx950: kernel declarations
+// and the host-side engine.  Takes over `VariableBaseMSM::msm_unchecked` at
+// src/thin.rs:319, src/pedersen.rs:420, src/utils/common.rs:410-411.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "host_te.h"
+
+namespace avrf {
+
+struct te_pre_raw { uint32_t w[24]; };   // x | y | k, Montgomery, 8 x u32 each
+struct te_ext_raw { uint32_t w[32]; };   // x | y | t | z
+
+struct MsmPlan {
+  int c;         // window bits
+  int nwin;      // number of windows: nwin * c >= scalar bits + 1
+  int nb;        // buckets per window = 2^(c-1) (signed digits)
+  int lpb;       // lanes cooperating on one bucket
+};
+MsmPlan msm_plan(size_t n, int scalar_bits);
+
+// Device workspace owned by a context; grows on demand, never shrinks.
+struct MsmWorkspace {
+  uint32_t *keys = nullptr;      // nwin * n
+  uint32_t *counts = nullptr;    // nwin * nb   (histogram, then reused as cursors)
+  uint32_t *offsets = nullptr;   // nwin * nb + 1
+  uint32_t *sorted = nullptr;    // nwin * n
+  te_ext_raw *buckets = nullptr; // nwin * nb
+  te_ext_raw *bits = nullptr;    // nwin * c
+  te_ext_raw *bits_host = nullptr; // pinned
+  size_t cap_n = 0, cap_buckets = 0, cap_bits = 0;
+  void ensure(size_t n, const MsmPlan &p);
+  void release();
+};
+
+// MSM of n precomputed device points (Montgomery form) with n plain 256-bit scalars (8 x u32 LE,
+// already < r), on `stream`.  Result: extended point on the host.  suite: 0 Bandersnatch, 1 Baby-JubJub.
+int msm_te_device(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n,
+                  MsmWorkspace &ws, hipStream_t stream, HostExt *out);
+
+// canonical affine bytes (x||y LE32) -> te_pre (device); flags[i] |= 1 if a coordinate >= q, |= 2 if off-curve (when check_curve)
+void launch_pre_from_affine(int suite, const uint8_t *d_xy, size_t n, te_pre_raw *d_pre, uint32_t *d_flag,
+                            int check_curve, hipStream_t stream);
+
+}  // namespace avrf

@@ -1,0 +1,186 @@
+// vrf_batch.hip -- per-item Fiat-Shamir hashing and MSM term construction on the device.
+//
+//   k_thin_prepare : thin::BatchVerifier::prepare, src/thin.rs:209-226
+//                    (vrf_transcript_scalars_with_schnorr src/utils/common.rs:251-258,
+//                     vrf_transcript_base :159-173, DelinearizeScalars :335-369, challenge :270-280)
+//   k_thin_terms   : the per-item part of thin::BatchVerifier::verify, src/thin.rs:287-313
+//   k_g_final      : the shared-generator term, src/thin.rs:303,316-317
+// One lane per batch item; SHA-512 state in VGPRs (sha512_dev.h); scalar-field products in
+// 8 x u32 Montgomery form (fp256.h).
+#include "vrf_batch.h"
+#include "sha512_dev.h"
+#include "te.h"
+
+namespace avrf {
+
+enum : uint8_t { DS_THIN = 0x01, DS_PEDERSEN = 0x02, DS_DELINEARIZE = 0x30, DS_CHALLENGE = 0x40 };
+
+// absorb the ark-serialize compressed encoding of an affine point given as canonical x||y
+// (LE32 each): LE32(y) with bit 255 set iff x > (q-1)/2   
+template <class S> AVRF_DI void absorb_point_xy(Sha512 &h, const fp &x, const fp &y) {
+  using Fq = typename S::Fq;
+  uint32_t sign = fp_is_negative_plain<Fq>(x) ? 0x80000000u : 0u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) sha512_u32le(h, y.v[i] | (i == 7 ? sign : 0u));
+}
+template <class S> AVRF_DI uint32_t point_flags(const fp &x, const fp &y) {
+  using Fq = typename S::Fq;
+  uint32_t f = 0;
+  if (ge_p<Fq>(x) || ge_p<Fq>(y)) f |= FLAG_RANGE;
+  fp one = fp_zero(); one.v[0] = 1;
+  if (fp_is_zero(x) && fp_eq(y, one)) f |= FLAG_IDENTITY;
+  return f;
+}
+
+template <class S>
+__global__ void __launch_bounds__(128)
+k_thin_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint32_t *__restrict__ z_out, uint32_t *__restrict__ flags) {
+  using Fr = typename S::Fr;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b.n) return;
+  uint32_t io0 = b.io_off[j], io1 = b.io_off[j + 1], m = io1 - io0;
+  uint32_t ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  uint32_t f = 0;
+  Sha512 h; sha512_init(h);
+  for (int i = 0; i < S::SUITE_ID_LEN; i++) sha512_byte(h, S::SUITE_ID[i]);   // Transcript::new(SUITE_ID)
+  sha512_byte(h, DS_THIN);                                                     // common.rs:166
+  sha512_u64le(h, (uint64_t)m + 1);                                            // absorb_ios :377-383, Schnorr pair first
+#pragma unroll
+  for (int i = 0; i < 8; i++) sha512_u32le(h, S::G_C[i]);                      // chain_ios :231-240: (G, pk)
+  {
+    fp x = fp_load_le(b.pks_xy + 64 * (size_t)j), y = fp_load_le(b.pks_xy + 64 * (size_t)j + 32);
+    f |= point_flags<S>(x, y);                                                 // thin.rs:266-271
+    absorb_point_xy<S>(h, x, y);
+  }
+  for (uint32_t i = 0; i < m; i++) {
+    const uint8_t *p = b.ios_xy + 128 * (size_t)(io0 + i);
+    fp x = fp_load_le(p), y = fp_load_le(p + 32);
+    f |= point_flags<S>(x, y); absorb_point_xy<S>(h, x, y);
+    x = fp_load_le(p + 64); y = fp_load_le(p + 96);
+    f |= point_flags<S>(x, y); absorb_point_xy<S>(h, x, y);
+  }
+  sha512_u64le(h, (uint64_t)adl);                                              // common.rs:169-170
+  sha512_bytes(h, b.ads + ad0, adl);
+  uint64_t seed[8], blk[8];
+  if (m) {                                                                     // DelinearizeScalars :345-363
+    Sha512 hd = h; sha512_byte(hd, DS_DELINEARIZE);
+    sha512_final(hd, seed);
+    for (uint32_t i = 0; i < m; i++) {
+      if ((i & 3) == 0) sha512_xof_block(seed, i >> 2, blk);
+      uint32_t w[4]; digest_le128(blk, i & 3, w);
+      uint4 *o = reinterpret_cast<uint4 *>(z_out + 4 * (size_t)(io0 + i));
+      *o = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+  {                                                                            // challenge :270-280
+    const uint8_t *pr = b.proofs + 96 * (size_t)j;
+    fp x = fp_load_le(pr), y = fp_load_le(pr + 32), s = fp_load_le(pr + 64);
+    if (point_flags<S>(x, y) & FLAG_RANGE) f |= FLAG_RANGE;                    // R may be the identity (thin.rs:95-99)
+    if (ge_p<Fr>(s)) f |= FLAG_SCALAR;
+    sha512_byte(h, DS_CHALLENGE);
+    absorb_point_xy<S>(h, x, y);
+    sha512_final(h, seed);
+    sha512_xof_block(seed, 0, blk);
+    uint32_t w[4]; digest_le128(blk, 0, w);
+    uint4 *o = reinterpret_cast<uint4 *>(c_out + 4 * (size_t)j);
+    *o = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  if (f) atomicOr(flags, f);
+}
+
+AVRF_DI fp fp_from_u128(const uint32_t *w) {
+  fp a = fp_zero(); uint4 v = *reinterpret_cast<const uint4 *>(w);
+  a.v[0] = v.x; a.v[1] = v.y; a.v[2] = v.z; a.v[3] = v.w; return a;
+}
+template <class S> AVRF_DI void emit_term(uint32_t *scalars, te_pre *pre, uint32_t t, const fp &scalar_plain, const uint8_t *xy) {
+  using Fq = typename S::Fq;
+  store_fp(scalars + 8 * (size_t)t, scalar_plain);
+  fp x = fp_to_mont<Fq>(fp_load_le(xy)), y = fp_to_mont<Fq>(fp_load_le(xy + 32));
+  store_pre(pre + t, te_make_pre<S>(x, y));
+}
+
+template <class S>
+__global__ void __launch_bounds__(128)
+k_thin_terms(BatchDev b, Seed64 seed, const uint32_t *__restrict__ c_in, const uint32_t *__restrict__ z_in,
+             uint32_t *__restrict__ scalars, te_pre *__restrict__ pre, uint32_t *__restrict__ gpart) {
+  using Fr = typename S::Fr;
+  __shared__ fp red[128];
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  fp ws = fp_zero();
+  if (j < b.n) {
+    uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0;
+    // w_j = challenge_scalar(&mut t): 16 bytes of the weight stream (thin.rs:289, common.rs:72-76)
+    uint64_t blk[8]; sha512_xof_block(seed.w, j >> 2, blk);
+    uint32_t ww[4]; digest_le128(blk, j & 3, ww);
+    fp w_plain = fp_zero(); w_plain.v[0] = ww[0]; w_plain.v[1] = ww[1]; w_plain.v[2] = ww[2]; w_plain.v[3] = ww[3];
+    fp w = fp_to_mont<Fr>(w_plain);
+    fp c = fp_to_mont<Fr>(fp_from_u128(c_in + 4 * (size_t)j));
+    const uint8_t *pr = b.proofs + 96 * (size_t)j;
+    fp s = fp_to_mont<Fr>(fp_load_le(pr + 64));
+    fp wc = fp_mul<Fr>(w, c);                               // thin.rs:291-292
+    ws = fp_mul<Fr>(w, s);
+    uint32_t t = 2 * j + 2 * io0;
+    emit_term<S>(scalars, pre, t, w_plain, pr);                                           // (R_j, w_j)        :295-296
+    emit_term<S>(scalars, pre, t + 1, fp_from_mont<Fr>(wc), b.pks_xy + 64 * (size_t)j);   // (pk_j, w c z0)    :299-300, z0 = 1
+    for (uint32_t i = 0; i < m; i++) {                                                    // :306-312
+      fp z = fp_to_mont<Fr>(fp_from_u128(z_in + 4 * (size_t)(io0 + i)));
+      const uint8_t *p = b.ios_xy + 128 * (size_t)(io0 + i);
+      emit_term<S>(scalars, pre, t + 2 + 2 * i, fp_from_mont<Fr>(fp_mul<Fr>(wc, z)), p + 64);             // (O_i, w c z_i)
+      emit_term<S>(scalars, pre, t + 3 + 2 * i, fp_from_mont<Fr>(fp_neg<Fr>(fp_mul<Fr>(ws, z))), p);      // (I_i, -w s z_i)
+    }
+  }
+  // block sum of w_j s_j z0 (Montgomery form), thin.rs:303
+  red[threadIdx.x] = ws;
+  __syncthreads();
+  for (int s2 = 64; s2 >= 1; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) red[threadIdx.x] = fp_add<Fr>(red[threadIdx.x], red[threadIdx.x + s2]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_fp(gpart + 8 * (size_t)blockIdx.x, red[0]);
+}
+
+// g = -(sum of partials); last term (G, g)   (thin.rs:303,316-317)
+template <class S>
+__global__ void __launch_bounds__(256)
+k_g_final(const uint32_t *__restrict__ gpart, uint32_t nparts, uint32_t *__restrict__ scalars, te_pre *__restrict__ pre,
+          uint32_t t_last, int which_base) {
+  using Fr = typename S::Fr; using Fq = typename S::Fq;
+  __shared__ fp red[256];
+  fp acc = fp_zero();
+  for (uint32_t i = threadIdx.x; i < nparts; i += 256) acc = fp_add<Fr>(acc, load_fp(gpart + 8 * (size_t)i));
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s2 = 128; s2 >= 1; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) red[threadIdx.x] = fp_add<Fr>(red[threadIdx.x], red[threadIdx.x + s2]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    store_fp(scalars + 8 * (size_t)t_last, fp_from_mont<Fr>(fp_neg<Fr>(red[0])));
+    te_pre g;
+    if (which_base == 0) { g.x = fp_const<Fq>(S::G_X); g.y = fp_const<Fq>(S::G_Y); g.k = fp_const<Fq>(S::G_K); }
+    else { g.x = fp_const<Fq>(S::B_X); g.y = fp_const<Fq>(S::B_Y); g.k = fp_const<Fq>(S::B_K); }
+    store_pre(pre + t_last, g);
+  }
+}
+
+void launch_thin_prepare(int suite, const BatchDev &b, uint32_t *d_c, uint32_t *d_z, uint32_t *d_flags, hipStream_t st) {
+  if (!b.n) return;
+  dim3 g((b.n + 127) / 128), blk(128);
+  if (suite == 0) hipLaunchKernelGGL(k_thin_prepare<SuiteBandersnatch>, g, blk, 0, st, b, d_c, d_z, d_flags);
+  else hipLaunchKernelGGL(k_thin_prepare<SuiteBabyJubJub>, g, blk, 0, st, b, d_c, d_z, d_flags);
+}
+
+void launch_thin_terms(int suite, const BatchDev &b, const Seed64 &seed, const uint32_t *d_c, const uint32_t *d_z,
+                       uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st) {
+  if (!b.n) return;
+  dim3 g((b.n + 127) / 128), blk(128);
+  if (suite == 0) {
+    hipLaunchKernelGGL(k_thin_terms<SuiteBandersnatch>, g, blk, 0, st, b, seed, d_c, d_z, d_scalars, (te_pre *)d_pre, d_gpart);
+    hipLaunchKernelGGL(k_g_final<SuiteBandersnatch>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 0);
+  } else {
+    hipLaunchKernelGGL(k_thin_terms<SuiteBabyJubJub>, g, blk, 0, st, b, seed, d_c, d_z, d_scalars, (te_pre *)d_pre, d_gpart);
+    hipLaunchKernelGGL(k_g_final<SuiteBabyJubJub>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 0);
+  }
+}
+
+}  // namespace avrf

@@ -1,0 +1,132 @@
+/*
+ * avrf.h -- C ABI of the MI355X-native batched VRF engine (libavrf.so).
+ *
+ * Drop-in boundary for the hot path of davxy/ark-vrf.  The reference has no
+ * FFI of its own (`#![deny(unsafe_code)]`, src/lib.rs:95); each entry point below names the
+ * reference interface it replaces (paths relative to the reference repo).  A Rust shim
+ * re-implementing `thin::{Prover,Verifier,BatchVerifier}` / `pedersen::{...}` for
+ * `Secret<S>` / `Public<S>` binds exactly these symbols.
+ *
+ * Conventions
+ *  - plain pointers and sizes; the caller owns every buffer; handles are opaque.
+ *  - scalars: 32-byte little-endian canonical integers (< group order), as
+ *    `CanonicalSerialize` writes `ScalarField` (src/testing.rs:25-34).
+ *  - "xy" points: 64 bytes, LE32(x) || LE32(y), canonical (non-Montgomery) affine
+ *    twisted-Edwards coordinates, identity = (0, 1).  This is what a caller holding
+ *    arkworks `Affine { x, y }` values has after deserialisation.
+ *  - "compressed" points: 32 bytes, ark-serialize compressed form (LE32(y), bit 255 = x sign).
+ *  - status codes mirror `ark_vrf::Error` (src/lib.rs:135-147).
+ *  - every call runs on the context's own HIP stream; one context per host thread.
+ *  - no CPU fallback: creating a context fails (AVRF_ERR_NO_DEVICE) without a gfx950 device.
+ */
+#ifndef AVRF_H
+#define AVRF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  AVRF_OK = 0,                     /* Ok(())                                   */
+  AVRF_VERIFICATION_FAILURE = 1,   /* Error::VerificationFailure               */
+  AVRF_INVALID_DATA = 2,           /* Error::InvalidData                       */
+  AVRF_RING_CAPACITY_EXCEEDED = 3, /* Error::RingCapacityExceeded              */
+  AVRF_SRS_LOOKUP_FAILED = 4,      /* Error::SrsLookupFailed                   */
+  AVRF_ERR_NO_DEVICE = -1,         /* no HIP device / kernels not loadable     */
+  AVRF_ERR_BAD_ARG = -2
+};
+
+enum {
+  AVRF_SUITE_BANDERSNATCH_SHA512_ELL2 = 0, /* src/suites/bandersnatch.rs:62-105 */
+  AVRF_SUITE_BABYJUBJUB_SHA512_TAI = 1     /* src/suites/baby_jubjub.rs:56-95   */
+};
+
+typedef struct avrf_ctx avrf_ctx;
+
+/* Library / build identification (no GPU needed). */
+const char *avrf_version(void);
+/* Number of visible HIP devices (0 when there is none; never initialises a context). */
+int avrf_device_count(void);
+
+/* One engine instance: suite parameterisation (trait Suite, src/lib.rs:177-250) + one HIP
+ * stream + device workspace on `device`. */
+int avrf_ctx_create(int suite, int device, avrf_ctx **out);
+void avrf_ctx_destroy(avrf_ctx *ctx);
+
+/* <S::Affine as AffineRepr>::Group::msm_unchecked(&bases, &scalars)
+ * (call sites src/thin.rs:319, src/pedersen.rs:420, src/utils/common.rs:410-411).
+ * bases_xy: n x 64, scalars: n x 32, out_xy: normalised result (64 bytes).
+ * "unchecked": no subgroup check; off-range coordinates / scalars give AVRF_INVALID_DATA. */
+int avrf_msm_te(avrf_ctx *ctx, size_t n, const uint8_t *bases_xy, const uint8_t *scalars, uint8_t out_xy[64]);
+
+/* thin::BatchVerifier::{new, push*, verify}  (src/thin.rs:188-326).
+ * n items; item j has io_counts[j] VRF I/O pairs; ios_xy holds sum(io_counts) pairs as
+ * input_xy(64) || output_xy(64); ads holds the concatenated additional-data strings with
+ * lengths ad_lens[j]; proofs: R_xy(64) || s(32) per item.
+ * Returns AVRF_OK, AVRF_INVALID_DATA (identity pk / io point, or malformed encodings),
+ * or AVRF_VERIFICATION_FAILURE.  Empty batch => AVRF_OK (src/thin.rs:262-264). */
+int avrf_thin_batch_verify(avrf_ctx *ctx, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy,
+                           const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens,
+                           const uint8_t *proofs);
+
+/* Two-phase form of the same call for callers that keep a batch resident in HBM
+ * (bench.py times avrf_thin_batch_run only): stage copies the batch to the device,
+ * run performs prepare + verify on the staged batch and may be called repeatedly. */
+int avrf_thin_batch_stage(avrf_ctx *ctx, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy,
+                          const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens,
+                          const uint8_t *proofs);
+int avrf_thin_batch_run(avrf_ctx *ctx);
+
+/* Exposes the MSM the last avrf_thin_batch_run / avrf_pedersen_batch_run built
+ * (bases_xy: n_terms x 64, scalars: n_terms x 32) so tests can compare weights and terms with
+ * the oracle bit for bit.  Either output pointer may be NULL; returns the number of terms. */
+size_t avrf_batch_last_terms(avrf_ctx *ctx, uint8_t *bases_xy, uint8_t *scalars);
+
+/* Last-call timing breakdown in microseconds (host wall clock):
+ * [0] total, [1] device prepare (hash), [2] host weight transcript, [3] scalars, [4] msm, [5] finish */
+void avrf_last_timing(avrf_ctx *ctx, double out[8]);
+
+/* thin::Prover::prove for a batch of independent (sk, ios, ad)  (src/thin.rs:111-129).
+ * sks: n x 32; ios as above; proofs_out: n x 96 (R_xy || s). */
+int avrf_thin_prove(avrf_ctx *ctx, size_t n, const uint8_t *sks, const uint8_t *ios_xy, const uint32_t *io_counts,
+                    const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out);
+
+/* thin::Verifier::verify for a batch of independent items (src/thin.rs:131-165);
+ * status_out[j] receives the per-item status.  Returns AVRF_OK when the call itself ran. */
+int avrf_thin_verify(avrf_ctx *ctx, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
+                     const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, int32_t *status_out);
+
+/* pedersen::BatchVerifier::{new, push*, verify} (src/pedersen.rs:303-426).
+ * proofs: Yb_xy(64) || R_xy(64) || Ok_xy(64) || s(32) || sb(32) = 256 bytes per item. */
+int avrf_pedersen_batch_verify(avrf_ctx *ctx, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,
+                               const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs);
+int avrf_pedersen_batch_stage(avrf_ctx *ctx, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,
+                              const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs);
+int avrf_pedersen_batch_run(avrf_ctx *ctx);
+
+/* pedersen::Prover::prove (src/pedersen.rs:136-186) for a batch; proofs_out: n x 256,
+ * blindings_out: n x 32 (may be NULL). */
+int avrf_pedersen_prove(avrf_ctx *ctx, size_t n, const uint8_t *sks, const uint8_t *ios_xy, const uint32_t *io_counts,
+                        const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out, uint8_t *blindings_out);
+
+/* pedersen::Verifier::verify (src/pedersen.rs:188-249) for a batch of independent items. */
+int avrf_pedersen_verify(avrf_ctx *ctx, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,
+                         const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, int32_t *status_out);
+
+/* CanonicalSerialize / CanonicalDeserialize of curve points, batched on the device
+ * (ark-serialize compressed form; checked constructors src/lib.rs:410-494).
+ * decompress: in n x 32 -> out n x 64; status_out[j] = AVRF_OK / AVRF_INVALID_DATA.
+ * validate != 0 additionally requires prime-order-subgroup membership and non-identity. */
+int avrf_points_decompress(avrf_ctx *ctx, size_t n, const uint8_t *in, uint8_t *out_xy, int validate, int32_t *status_out);
+int avrf_points_compress(avrf_ctx *ctx, size_t n, const uint8_t *in_xy, uint8_t *out);
+
+/* Secret::from_scalar / Secret::output: sk*G and sk*I for a batch (src/lib.rs:331-334,391-393). */
+int avrf_scalar_mul_base(avrf_ctx *ctx, size_t n, const uint8_t *sks, uint8_t *out_xy);
+int avrf_scalar_mul(avrf_ctx *ctx, size_t n, const uint8_t *scalars, const uint8_t *points_xy, uint8_t *out_xy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -192,3 +192,47 @@ def sha512(data):
     out = _buf(64)
     lib().orc_sha512(_u8(data), C.c_size_t(len(data)), out)
     return _b(out)
+
+
+def gen_batch(suite, kind, n, run_seed=bytes(32), start=0, threads=8):
+    """Deterministic synthetic batch (SURVEY.md §8d recipe), generated by the oracle's prover on
+    `threads` host threads.  Returns a dict of bytes in the C-ABI layouts of include/avrf.h:
+    sks, pks_xy, ios_xy, ads, ad_lens (list), proofs; io_counts is all ones."""
+    from concurrent.futures import ThreadPoolExecutor
+    L = lib()
+    psz = 96 if kind == 0 else 256
+    chunks = []
+    per = max(1, (n + threads - 1) // threads)
+    for lo in range(0, n, per):
+        chunks.append((lo, min(per, n - lo)))
+
+    def work(ch):
+        lo, cnt = ch
+        sks, pks, ios = _buf(32 * cnt), _buf(64 * cnt), _buf(128 * cnt)
+        ads, adl, prf = _buf(24 * cnt), (C.c_uint32 * cnt)(), _buf(psz * cnt)
+        st = L.orc_gen_batch(suite, kind, _u8(run_seed), C.c_uint64(start + lo), C.c_size_t(cnt), sks, pks, ios, ads, adl, prf)
+        assert st == 0, st
+        lens = list(adl)
+        return _b(sks), _b(pks), _b(ios), _b(ads)[: sum(lens)], lens, _b(prf)
+
+    if n == 0:
+        return dict(n=0, sks=b"", pks_xy=b"", ios_xy=b"", ads=b"", ad_lens=[], io_counts=[], proofs=b"")
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        parts = list(ex.map(work, chunks))
+    return dict(n=n, sks=b"".join(p[0] for p in parts), pks_xy=b"".join(p[1] for p in parts),
+                ios_xy=b"".join(p[2] for p in parts), ads=b"".join(p[3] for p in parts),
+                ad_lens=[x for p in parts for x in p[4]], io_counts=[1] * n, proofs=b"".join(p[5] for p in parts))
+
+
+def thin_batch_verify_raw(suite, b):
+    """orc_thin_batch_verify on a gen_batch dict: converts xy -> compressed first."""
+    n = b["n"]
+    pks = [point_compress(suite, b["pks_xy"][64 * j: 64 * j + 64]) for j in range(n)]
+    ios, ads, proofs, off = [], [], [], 0
+    for j in range(n):
+        i = point_compress(suite, b["ios_xy"][128 * j: 128 * j + 64]); o = point_compress(suite, b["ios_xy"][128 * j + 64: 128 * j + 128])
+        ios.append([(i, o)])
+        ads.append(b["ads"][off: off + b["ad_lens"][j]]); off += b["ad_lens"][j]
+        pr = b["proofs"][96 * j: 96 * j + 96]
+        proofs.append(point_compress(suite, pr[:64]) + pr[64:])
+    return pks, ios, ads, proofs

@@ -559,3 +559,53 @@ int orc_smul(int suite, const uint8_t k_b[32], const uint8_t pt[32], uint8_t out
 void orc_sha512(const uint8_t *d, size_t n, uint8_t out[64]) {
     sha512_t h; sha512_init(&h); sha512_update(&h, d, n); sha512_final(&h, out);
 }
+
+/* ------------------------------------------------------------------ synthetic batches
+ * Deterministic benchmark/test inputs derived from the item index j and a 32-byte run seed, through
+ * the suite's own hash functions (recipe modelled on benches/thin.rs:46-63, README.md:161-182):
+ *   sk_j    = Secret::from_seed(run_seed XOR (LE64(j) || 0...))        (src/lib.rs:346-369)
+ *   input_j = Input::new("avrf-bench-input" || LE64(j))                (src/lib.rs:503-505)
+ *   ad_j    = "ad-<j>"
+ * Outputs use the C-ABI layouts of include/avrf.h ("xy" = LE32(x)||LE32(y)).
+ * kind 0: thin   -> pks_xy n*64, ios_xy n*128, proofs n*96  (R_xy || s)
+ * kind 1: pedersen -> ios_xy n*128, proofs n*256 (Yb_xy || R_xy || Ok_xy || s || sb), pks_xy unused (may be NULL)
+ * sks (n*32) is always written.  ads: concatenated, ad_lens[n]; caller provides >= 16 bytes per item. */
+int orc_gen_batch(int suite, int kind, const uint8_t run_seed[32], uint64_t start, size_t count,
+                  uint8_t *sks, uint8_t *pks_xy, uint8_t *ios_xy, uint8_t *ads, uint32_t *ad_lens, uint8_t *proofs) {
+    const suite_t *s = orc_suite(suite); if (!s) return -1;
+    size_t ad_off = 0;
+    for (size_t q = 0; q < count; q++) {
+        uint64_t j = start + q;
+        uint8_t seed[32], sk[32], pk[32], msg[24], in_c[32], out_c[32], io_c[64];
+        memcpy(seed, run_seed, 32);
+        for (int i = 0; i < 8; i++) seed[i] ^= (uint8_t)(j >> (8 * i));
+        if (orc_from_seed(suite, seed, sk, pk)) return -1;
+        memcpy(msg, "avrf-bench-input", 16);
+        for (int i = 0; i < 8; i++) msg[16 + i] = (uint8_t)(j >> (8 * i));
+        if (orc_hash_to_curve(suite, msg, 24, in_c)) return -1;
+        if (orc_vrf_output(suite, sk, in_c, out_c)) return -1;
+        memcpy(io_c, in_c, 32); memcpy(io_c + 32, out_c, 32);
+        /* "ad-<j>" */
+        char adb[24]; int al = 0; { char tmp[24]; int tl = 0; uint64_t v = j; do { tmp[tl++] = (char)('0' + v % 10); v /= 10; } while (v);
+            adb[al++] = 'a'; adb[al++] = 'd'; adb[al++] = '-'; while (tl) adb[al++] = tmp[--tl]; }
+        memcpy(ads + ad_off, adb, (size_t)al); ad_lens[q] = (uint32_t)al; ad_off += (size_t)al;
+        memcpy(sks + 32 * q, sk, 32);
+        te_aff p;
+        te_decode(&p, in_c, s); te_encode_xy(ios_xy + 128 * q, &p, s);
+        te_decode(&p, out_c, s); te_encode_xy(ios_xy + 128 * q + 64, &p, s);
+        if (kind == 0) {
+            uint8_t pr[64];
+            if (orc_thin_prove(suite, sk, io_c, 1, (const uint8_t *)adb, (size_t)al, pr)) return -1;
+            te_decode(&p, pk, s); te_encode_xy(pks_xy + 64 * q, &p, s);
+            te_decode(&p, pr, s); te_encode_xy(proofs + 96 * q, &p, s);
+            memcpy(proofs + 96 * q + 64, pr + 32, 32);
+        } else {
+            uint8_t pr[160];
+            if (orc_pedersen_prove(suite, sk, io_c, 1, (const uint8_t *)adb, (size_t)al, pr, NULL)) return -1;
+            if (pks_xy) { te_decode(&p, pk, s); te_encode_xy(pks_xy + 64 * q, &p, s); }
+            for (int k = 0; k < 3; k++) { te_decode(&p, pr + 32 * k, s); te_encode_xy(proofs + 256 * q + 64 * k, &p, s); }
+            memcpy(proofs + 256 * q + 192, pr + 96, 64);
+        }
+    }
+    return 0;
+}

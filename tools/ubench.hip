@@ -1,0 +1,121 @@
+// tools/ubench.hip -- integer-ALU micro-benchmarks for gfx950 (the local guides list no
+// integer-multiply rates; SURVEY.md §7 "Hard parts").  Measures what bounds the field
+// arithmetic: v_mad_u64_u32 / v_mul_lo / v_mul_hi / v_add_co issue rates, f64 FMA rate,
+// Montgomery-multiplication and mixed-addition throughput per chip at several occupancies.
+// Build: hipcc -O3 --offload-arch=gfx950 -o /tmp/ubench tools/ubench.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "../ark_vrf_amd/csrc/te.h"
+
+using namespace avrf;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <int OP> __global__ void k_op(uint32_t *out, int iters, uint32_t seed) {
+  uint32_t a = seed + threadIdx.x, b = seed * 3 + blockIdx.x;
+  uint64_t c0 = a, c1 = b, c2 = a ^ b, c3 = a + b, c4 = 5, c5 = 6, c6 = 7, c7 = 8;
+  double d0 = a, d1 = b, d2 = 1.5, d3 = 2.5, d4 = 3.5, d5 = 4.5, d6 = 5.5, d7 = 6.5, dm = 1.0000001, da = 0.5;
+  for (int i = 0; i < iters; i++) {
+    if (OP == 0) {  // mad_u64_u32, 8 independent chains
+      c0 = (uint64_t)(uint32_t)c0 * b + c0; c1 = (uint64_t)(uint32_t)c1 * b + c1; c2 = (uint64_t)(uint32_t)c2 * b + c2; c3 = (uint64_t)(uint32_t)c3 * b + c3;
+      c4 = (uint64_t)(uint32_t)c4 * b + c4; c5 = (uint64_t)(uint32_t)c5 * b + c5; c6 = (uint64_t)(uint32_t)c6 * b + c6; c7 = (uint64_t)(uint32_t)c7 * b + c7;
+    } else if (OP == 1) {  // mul_lo
+      uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, x4 = c4, x5 = c5, x6 = c6, x7 = c7;
+      x0 *= b; x1 *= b; x2 *= b; x3 *= b; x4 *= b; x5 *= b; x6 *= b; x7 *= b;
+      c0 = x0; c1 = x1; c2 = x2; c3 = x3; c4 = x4; c5 = x5; c6 = x6; c7 = x7;
+    } else if (OP == 2) {  // mul_hi
+      c0 = __umulhi((uint32_t)c0, b) + 1; c1 = __umulhi((uint32_t)c1, b) + 1; c2 = __umulhi((uint32_t)c2, b) + 1; c3 = __umulhi((uint32_t)c3, b) + 1;
+      c4 = __umulhi((uint32_t)c4, b) + 1; c5 = __umulhi((uint32_t)c5, b) + 1; c6 = __umulhi((uint32_t)c6, b) + 1; c7 = __umulhi((uint32_t)c7, b) + 1;
+    } else if (OP == 3) {  // 64-bit add (add_co + addc)
+      c0 += c1; c1 += c2; c2 += c3; c3 += c4; c4 += c5; c5 += c6; c6 += c7; c7 += c0;
+    } else if (OP == 4) {  // f64 fma
+      d0 = fma(d0, dm, da); d1 = fma(d1, dm, da); d2 = fma(d2, dm, da); d3 = fma(d3, dm, da);
+      d4 = fma(d4, dm, da); d5 = fma(d5, dm, da); d6 = fma(d6, dm, da); d7 = fma(d7, dm, da);
+    } else if (OP == 5) {  // mad_u32_u24
+      uint32_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, x4 = c4, x5 = c5, x6 = c6, x7 = c7;
+      x0 = __umul24(x0, b) + x1; x1 = __umul24(x1, b) + x2; x2 = __umul24(x2, b) + x3; x3 = __umul24(x3, b) + x4;
+      x4 = __umul24(x4, b) + x5; x5 = __umul24(x5, b) + x6; x6 = __umul24(x6, b) + x7; x7 = __umul24(x7, b) + x0;
+      c0 = x0; c1 = x1; c2 = x2; c3 = x3; c4 = x4; c5 = x5; c6 = x6; c7 = x7;
+    }
+  }
+  uint64_t r = c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7;
+  double dr = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32) ^ (uint32_t)dr;
+}
+
+template <class F> __global__ void k_fmul(uint32_t *out, int iters, uint32_t seed) {
+  fp a, b;
+  for (int i = 0; i < 8; i++) { a.v[i] = seed * (i + 1) + threadIdx.x; b.v[i] = seed * (i + 7) + blockIdx.x; }
+  a.v[7] &= 0x0fffffff; b.v[7] &= 0x0fffffff;
+  for (int i = 0; i < iters; i++) { a = fp_mul<F>(a, b); b = fp_mul<F>(b, a); }
+  uint32_t r = 0;
+  for (int i = 0; i < 8; i++) r ^= a.v[i] ^ b.v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <class F> __global__ void k_fadd(uint32_t *out, int iters, uint32_t seed) {
+  fp a, b;
+  for (int i = 0; i < 8; i++) { a.v[i] = seed * (i + 1) + threadIdx.x; b.v[i] = seed * (i + 7) + blockIdx.x; }
+  a.v[7] &= 0x0fffffff; b.v[7] &= 0x0fffffff;
+  for (int i = 0; i < iters; i++) { a = fp_add<F>(a, b); b = fp_sub<F>(b, a); }
+  uint32_t r = 0;
+  for (int i = 0; i < 8; i++) r ^= a.v[i] ^ b.v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <class S> __global__ void k_madd(uint32_t *out, int iters, uint32_t seed) {
+  using Fq = typename S::Fq;
+  te_ext p = te_identity<S>();
+  te_pre q; q.x = fp_const<Fq>(S::G_X); q.y = fp_const<Fq>(S::G_Y); q.k = fp_const<Fq>(S::G_K);
+  q.x.v[0] ^= (threadIdx.x & 1);  // keep the compiler from hoisting everything
+  for (int i = 0; i < iters; i++) p = te_madd<S>(p, q);
+  uint32_t r = 0;
+  for (int i = 0; i < 8; i++) r ^= p.x.v[i] ^ p.y.v[i] ^ p.z.v[i] ^ p.t.v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r + seed;
+}
+
+template <class K> double time_kernel(K launch, int reps = 3) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  launch();  // warm-up
+  CK(hipDeviceSynchronize());
+  float best = 1e30f;
+  for (int r = 0; r < reps; r++) {
+    CK(hipEventRecord(e0, 0)); launch(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+  }
+  return best * 1e-3;
+}
+
+int main() {
+  hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+  printf("device: %s, CUs %d, clock %d MHz\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000);
+  uint32_t *out; CK(hipMalloc(&out, 256 * 32 * 256 * 4 * 4));
+  const char *names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "add64 (add_co+addc)", "v_fma_f64", "mul24+add"};
+  int iters = 4096;
+  for (int wpc = 4; wpc <= 32; wpc *= 2) {   // waves per CU
+    int blocks = 256 * wpc / 4, threads = 256;
+    printf("--- %d waves/CU (%d blocks x %d)\n", wpc, blocks, threads);
+    for (int op = 0; op < 6; op++) {
+      double t;
+      switch (op) {
+        case 0: t = time_kernel([&] { hipLaunchKernelGGL(k_op<0>, dim3(blocks), dim3(threads), 0, 0, out, iters, 12345u); }); break;
+        case 1: t = time_kernel([&] { hipLaunchKernelGGL(k_op<1>, dim3(blocks), dim3(threads), 0, 0, out, iters, 12345u); }); break;
+        case 2: t = time_kernel([&] { hipLaunchKernelGGL(k_op<2>, dim3(blocks), dim3(threads), 0, 0, out, iters, 12345u); }); break;
+        case 3: t = time_kernel([&] { hipLaunchKernelGGL(k_op<3>, dim3(blocks), dim3(threads), 0, 0, out, iters, 12345u); }); break;
+        case 4: t = time_kernel([&] { hipLaunchKernelGGL(k_op<4>, dim3(blocks), dim3(threads), 0, 0, out, iters, 12345u); }); break;
+        default: t = time_kernel([&] { hipLaunchKernelGGL(k_op<5>, dim3(blocks), dim3(threads), 0, 0, out, iters, 12345u); }); break;
+      }
+      double ops = (double)blocks * threads * iters * 8;
+      printf("  %-22s %8.2f Gop/s  (%.2f lane-ops/clk/CU @2.4GHz)\n", names[op], ops / t * 1e-9, ops / t / 2.4e9 / 256);
+    }
+    int fit = 512;
+    double t = time_kernel([&] { hipLaunchKernelGGL(k_fmul<FqBandersnatch>, dim3(blocks), dim3(threads), 0, 0, out, fit, 777u); });
+    printf("  %-22s %8.2f Gmul/s\n", "fp_mul<FqBandersnatch>", (double)blocks * threads * fit * 2 / t * 1e-9);
+    t = time_kernel([&] { hipLaunchKernelGGL(k_fmul<FqBabyJubJub>, dim3(blocks), dim3(threads), 0, 0, out, fit, 777u); });
+    printf("  %-22s %8.2f Gmul/s\n", "fp_mul<FqBabyJubJub>", (double)blocks * threads * fit * 2 / t * 1e-9);
+    t = time_kernel([&] { hipLaunchKernelGGL(k_fadd<FqBandersnatch>, dim3(blocks), dim3(threads), 0, 0, out, fit * 4, 777u); });
+    printf("  %-22s %8.2f Gop/s\n", "fp_add/sub", (double)blocks * threads * fit * 4 * 2 / t * 1e-9);
+    t = time_kernel([&] { hipLaunchKernelGGL(k_madd<SuiteBandersnatch>, dim3(blocks), dim3(threads), 0, 0, out, 128, 777u); });
+    printf("  %-22s %8.3f Gadd/s  (%.1f us per add per lane)\n", "te_madd<Bandersnatch>", (double)blocks * threads * 128 / t * 1e-9, t / 128 * 1e6);
+  }
+  return 0;
+}
