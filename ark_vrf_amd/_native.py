@@ -16,6 +16,9 @@ ERR_NO_DEVICE, ERR_BAD_ARG = -1, -2
 BANDERSNATCH_SHA512_ELL2 = 0
 BABYJUBJUB_SHA512_TAI = 1
 
+THIN_PROOF_LEN = 96       # R_xy || s
+PEDERSEN_PROOF_LEN = 256  # Yb_xy || R_xy || Ok_xy || s || sb
+
 
 class AvrfError(RuntimeError):
     pass
@@ -38,17 +41,39 @@ def lib():
 
 
 def _u8(data):
+    if isinstance(data, C.Array):
+        return data
     data = bytes(data)
     return (C.c_uint8 * max(1, len(data))).from_buffer_copy(data.ljust(1, b"\0"))
 
 
 def _u32(vals):
+    if isinstance(vals, C.Array):
+        return vals
     vals = list(vals)
     return (C.c_uint32 * max(1, len(vals)))(*vals)
 
 
 def device_count():
     return lib().avrf_device_count()
+
+
+class Batch:
+    """Host-side packed batch in the C-ABI layout (see include/avrf.h)."""
+
+    def __init__(self, n, ios_xy, io_counts, ads, ad_lens, pks_xy=None, proofs=None, sks=None):
+        self.n = n
+        self.ios_xy, self.io_counts, self.ads, self.ad_lens = _u8(ios_xy), _u32(io_counts), _u8(ads), _u32(ad_lens)
+        self.pks_xy = _u8(pks_xy) if pks_xy is not None else None
+        self.proofs = _u8(proofs) if proofs is not None else None
+        self.sks = _u8(sks) if sks is not None else None
+
+    @classmethod
+    def from_items(cls, items_ios_xy, ads, pks_xy=None, proofs=None, sks=None):
+        iob = b"".join(i + o for ios in items_ios_xy for i, o in ios)
+        j = lambda v: None if v is None else b"".join(v)
+        return cls(len(ads), iob, [len(x) for x in items_ios_xy], b"".join(ads), [len(a) for a in ads],
+                   j(pks_xy), j(proofs), j(sks))
 
 
 class Context:
@@ -82,29 +107,26 @@ class Context:
             raise AvrfError(f"avrf_msm_te -> {st}")
         return bytes(out)
 
-    # -- thin batch
-    @staticmethod
-    def _pack(items_ios, ads):
-        iob = b"".join(i + o for ios in items_ios for i, o in ios)
-        return _u8(iob), _u32(len(ios) for ios in items_ios), _u8(b"".join(ads)), _u32(len(a) for a in ads)
-
+    # -- batch verifiers
     def thin_batch_verify(self, pks_xy, items_ios_xy, ads, proofs):
-        iob, cnt, adb, adl = self._pack(items_ios_xy, ads)
-        return lib().avrf_thin_batch_verify(self._h, C.c_size_t(len(pks_xy)), _u8(b"".join(pks_xy)), iob, cnt, adb, adl,
-                                            _u8(b"".join(proofs)))
+        b = Batch.from_items(items_ios_xy, ads, pks_xy=pks_xy, proofs=proofs)
+        return lib().avrf_thin_batch_verify(self._h, C.c_size_t(b.n), b.pks_xy, b.ios_xy, b.io_counts, b.ads, b.ad_lens, b.proofs)
 
-    def thin_batch_stage(self, pks_xy, items_ios_xy, ads, proofs):
-        iob, cnt, adb, adl = self._pack(items_ios_xy, ads)
-        return lib().avrf_thin_batch_stage(self._h, C.c_size_t(len(pks_xy)), _u8(b"".join(pks_xy)), iob, cnt, adb, adl,
-                                           _u8(b"".join(proofs)))
-
-    def thin_batch_stage_raw(self, n, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs):
-        """Same as thin_batch_stage with pre-packed buffers (bytes / numpy arrays)."""
-        return lib().avrf_thin_batch_stage(self._h, C.c_size_t(n), _u8(pks_xy), _u8(ios_xy), _u32(io_counts), _u8(ads),
-                                           _u32(ad_lens), _u8(proofs))
+    def thin_batch_stage(self, b):
+        return lib().avrf_thin_batch_stage(self._h, C.c_size_t(b.n), b.pks_xy, b.ios_xy, b.io_counts, b.ads, b.ad_lens, b.proofs)
 
     def thin_batch_run(self):
         return lib().avrf_thin_batch_run(self._h)
+
+    def pedersen_batch_verify(self, items_ios_xy, ads, proofs):
+        b = Batch.from_items(items_ios_xy, ads, proofs=proofs)
+        return lib().avrf_pedersen_batch_verify(self._h, C.c_size_t(b.n), b.ios_xy, b.io_counts, b.ads, b.ad_lens, b.proofs)
+
+    def pedersen_batch_stage(self, b):
+        return lib().avrf_pedersen_batch_stage(self._h, C.c_size_t(b.n), b.ios_xy, b.io_counts, b.ads, b.ad_lens, b.proofs)
+
+    def pedersen_batch_run(self):
+        return lib().avrf_pedersen_batch_run(self._h)
 
     def last_terms(self):
         k = lib().avrf_batch_last_terms(self._h, None, None)
@@ -117,3 +139,64 @@ class Context:
         out = (C.c_double * 8)()
         lib().avrf_last_timing(self._h, out)
         return list(out)
+
+    # -- independent per-item calls
+    def thin_prove(self, b):
+        out = (C.c_uint8 * max(1, 96 * b.n))()
+        st = lib().avrf_thin_prove(self._h, C.c_size_t(b.n), b.sks, b.pks_xy, b.ios_xy, b.io_counts, b.ads, b.ad_lens, out)
+        if st != OK:
+            raise AvrfError(f"avrf_thin_prove -> {st}")
+        return bytes(out)[: 96 * b.n]
+
+    def thin_verify(self, b):
+        out = (C.c_int32 * max(1, b.n))()
+        st = lib().avrf_thin_verify(self._h, C.c_size_t(b.n), b.pks_xy, b.ios_xy, b.io_counts, b.ads, b.ad_lens, b.proofs, out)
+        if st != OK:
+            raise AvrfError(f"avrf_thin_verify -> {st}")
+        return list(out)[: b.n]
+
+    def pedersen_prove(self, b):
+        out, bl = (C.c_uint8 * max(1, 256 * b.n))(), (C.c_uint8 * max(1, 32 * b.n))()
+        st = lib().avrf_pedersen_prove(self._h, C.c_size_t(b.n), b.sks, b.pks_xy, b.ios_xy, b.io_counts, b.ads, b.ad_lens, out, bl)
+        if st != OK:
+            raise AvrfError(f"avrf_pedersen_prove -> {st}")
+        return bytes(out)[: 256 * b.n], bytes(bl)[: 32 * b.n]
+
+    def pedersen_verify(self, b):
+        out = (C.c_int32 * max(1, b.n))()
+        st = lib().avrf_pedersen_verify(self._h, C.c_size_t(b.n), b.ios_xy, b.io_counts, b.ads, b.ad_lens, b.proofs, out)
+        if st != OK:
+            raise AvrfError(f"avrf_pedersen_verify -> {st}")
+        return list(out)[: b.n]
+
+    def scalar_mul_base(self, scalars):
+        n = len(scalars) // 32
+        out = (C.c_uint8 * max(1, 64 * n))()
+        st = lib().avrf_scalar_mul_base(self._h, C.c_size_t(n), _u8(scalars), out)
+        if st != OK:
+            raise AvrfError(f"avrf_scalar_mul_base -> {st}")
+        return bytes(out)[: 64 * n]
+
+    def scalar_mul(self, scalars, points_xy):
+        n = len(scalars) // 32
+        out = (C.c_uint8 * max(1, 64 * n))()
+        st = lib().avrf_scalar_mul(self._h, C.c_size_t(n), _u8(scalars), _u8(points_xy), out)
+        if st != OK:
+            raise AvrfError(f"avrf_scalar_mul -> {st}")
+        return bytes(out)[: 64 * n]
+
+    def points_decompress(self, comp, validate=False):
+        n = len(comp) // 32
+        out, st_out = (C.c_uint8 * max(1, 64 * n))(), (C.c_int32 * max(1, n))()
+        st = lib().avrf_points_decompress(self._h, C.c_size_t(n), _u8(comp), out, int(validate), st_out)
+        if st != OK:
+            raise AvrfError(f"avrf_points_decompress -> {st}")
+        return bytes(out)[: 64 * n], list(st_out)[:n]
+
+    def points_compress(self, xy):
+        n = len(xy) // 64
+        out = (C.c_uint8 * max(1, 32 * n))()
+        st = lib().avrf_points_compress(self._h, C.c_size_t(n), _u8(xy), out)
+        if st != OK:
+            raise AvrfError(f"avrf_points_compress -> {st}")
+        return bytes(out)[: 32 * n]

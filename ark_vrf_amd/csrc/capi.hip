@@ -8,6 +8,7 @@
 #include "host_sha512.h"
 #include "host_te.h"
 #include "msm.h"
+#include "proto_dev.h"
 #include "vrf_batch.h"
 #include <chrono>
 #include <stdio.h>
@@ -24,7 +25,7 @@ namespace {
 struct DevBuf {
   void *p = nullptr; size_t cap = 0;
   hipError_t ensure(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
+    if (bytes <= cap && p) return hipSuccess;
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
     size_t want = bytes + bytes / 8 + 256;
@@ -38,7 +39,7 @@ struct DevBuf {
 struct PinBuf {
   void *p = nullptr; size_t cap = 0;
   hipError_t ensure(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
+    if (bytes <= cap && p) return hipSuccess;
     if (p) (void)hipHostFree(p);
     p = nullptr; cap = 0;
     hipError_t e = hipHostMalloc(&p, bytes + 256);
@@ -62,16 +63,24 @@ struct avrf_ctx {
   // staged batch
   int staged_kind = 0;            // 0 none, 1 thin, 2 pedersen
   size_t n = 0, tot_io = 0, n_terms = 0;
-  DevBuf d_pks, d_ios, d_io_off, d_ads, d_ad_off, d_proofs;
+  DevBuf d_pks, d_ios, d_io_off, d_ads, d_ad_off, d_proofs, d_sks;
   std::vector<uint8_t> h_resp;    // host copy of the response scalars (s [, sb]) for the weight transcript
-  DevBuf d_c, d_z, d_flags, d_scalars, d_pre, d_gpart, d_misc;
+  DevBuf d_c, d_z, d_flags, d_scalars, d_pre, d_gpart, d_misc, d_out, d_status;
   PinBuf h_c, h_flags, h_io;
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+static BatchDev batch_of(avrf_ctx *c) {
+  BatchDev b;
+  b.pks_xy = c->d_pks.as<uint8_t>(); b.ios_xy = c->d_ios.as<uint8_t>(); b.io_off = c->d_io_off.as<uint32_t>();
+  b.ads = c->d_ads.as<uint8_t>(); b.ad_off = c->d_ad_off.as<uint32_t>(); b.proofs = c->d_proofs.as<uint8_t>();
+  b.sks = c->d_sks.as<uint8_t>(); b.n = (uint32_t)c->n;
+  return b;
+}
+
 extern "C" {
 
-const char *avrf_version(void) { return "avrf 0.1 (gfx950; thin/pedersen batch; te-msm)"; }
+const char *avrf_version(void) { return "avrf 0.2 (gfx950; te-msm, thin/pedersen prove+verify+batch)"; }
 
 int avrf_device_count(void) {
   int n = 0;
@@ -88,6 +97,7 @@ int avrf_ctx_create(int suite, int device, avrf_ctx **out) {
   avrf_ctx *c = new avrf_ctx();
   c->suite = suite; c->device = device;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return AVRF_ERR_NO_DEVICE; }
+  if (c->d_flags.ensure(64) != hipSuccess || c->h_flags.ensure(64) != hipSuccess) { avrf_ctx_destroy(c); return AVRF_ERR_NO_DEVICE; }
   *out = c;
   return AVRF_OK;
 }
@@ -97,8 +107,8 @@ void avrf_ctx_destroy(avrf_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   c->ws.release();
-  DevBuf *bufs[] = {&c->d_pks, &c->d_ios, &c->d_io_off, &c->d_ads, &c->d_ad_off, &c->d_proofs, &c->d_c, &c->d_z,
-                    &c->d_flags, &c->d_scalars, &c->d_pre, &c->d_gpart, &c->d_misc};
+  DevBuf *bufs[] = {&c->d_pks, &c->d_ios, &c->d_io_off, &c->d_ads, &c->d_ad_off, &c->d_proofs, &c->d_sks, &c->d_c, &c->d_z,
+                    &c->d_flags, &c->d_scalars, &c->d_pre, &c->d_gpart, &c->d_misc, &c->d_out, &c->d_status};
   for (DevBuf *b : bufs) b->release();
   c->h_c.release(); c->h_flags.release(); c->h_io.release();
   (void)hipStreamDestroy(c->stream);
@@ -125,13 +135,13 @@ int avrf_msm_te(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *s
   HostExt r;
   if (n) {
     HIP_TRY(c->d_misc.ensure(n * 64)); HIP_TRY(c->d_scalars.ensure(n * 32)); HIP_TRY(c->d_pre.ensure(n * sizeof(te_pre_raw)));
-    HIP_TRY(c->d_flags.ensure(16)); HIP_TRY(c->h_flags.ensure(16));
     HIP_TRY(hipMemcpyAsync(c->d_misc.p, bases_xy, n * 64, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
     launch_pre_from_affine(c->suite, c->d_misc.as<uint8_t>(), n, c->d_pre.as<te_pre_raw>(), c->d_flags.as<uint32_t>(), 0, c->stream);
     HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
   }
+  c->staged_kind = 0;
   if (msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), n, c->ws, c->stream, &r)) return AVRF_ERR_BAD_ARG;
   if (n && *c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;
   return finish_point(c, r, out_xy);
@@ -139,13 +149,21 @@ int avrf_msm_te(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *s
 
 // ---------------------------------------------------------------- staging
 
-static int stage_common(avrf_ctx *c, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,
-                        const uint8_t *ads, const uint32_t *ad_lens) {
+// kind: 1 thin (pks + 96-byte proofs), 2 pedersen (256-byte proofs); proofs/pks/sks may be NULL for provers
+static int stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy,
+                 const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
+  if (!c) return AVRF_ERR_BAD_ARG;
+  if (n && (!io_counts || !ad_lens)) return AVRF_ERR_BAD_ARG;
+  if (n > 0x0fffffffULL) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  c->staged_kind = 0; c->n = n; c->tot_io = 0; c->n_terms = 0;
+  if (n == 0) { c->staged_kind = kind; return AVRF_OK; }
   HIP_TRY(c->h_io.ensure((n + 1) * 8));
   uint32_t *io_off = c->h_io.as<uint32_t>(), *ad_off = io_off + (n + 1);
   uint64_t a = 0, b = 0;
   for (size_t j = 0; j < n; j++) { io_off[j] = (uint32_t)a; ad_off[j] = (uint32_t)b; a += io_counts[j]; b += ad_lens[j]; }
-  if (a > 0x3fffffffULL || b > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
+  if (a > 0x1fffffffULL || b > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
+  if ((a && !ios_xy) || (b && !ads)) return AVRF_ERR_BAD_ARG;
   io_off[n] = (uint32_t)a; ad_off[n] = (uint32_t)b;
   c->tot_io = (size_t)a;
   HIP_TRY(c->d_io_off.ensure((n + 1) * 4)); HIP_TRY(c->d_ad_off.ensure((n + 1) * 4));
@@ -154,82 +172,96 @@ static int stage_common(avrf_ctx *c, size_t n, const uint8_t *ios_xy, const uint
   HIP_TRY(hipMemcpyAsync(c->d_ad_off.p, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
   if (a) HIP_TRY(hipMemcpyAsync(c->d_ios.p, ios_xy, a * 128, hipMemcpyHostToDevice, c->stream));
   if (b) HIP_TRY(hipMemcpyAsync(c->d_ads.p, ads, b, hipMemcpyHostToDevice, c->stream));
+  const size_t psz = kind == 1 ? 96 : 256;
+  if (pks_xy) { HIP_TRY(c->d_pks.ensure(n * 64)); HIP_TRY(hipMemcpyAsync(c->d_pks.p, pks_xy, n * 64, hipMemcpyHostToDevice, c->stream)); }
+  if (sks) { HIP_TRY(c->d_sks.ensure(n * 32)); HIP_TRY(hipMemcpyAsync(c->d_sks.p, sks, n * 32, hipMemcpyHostToDevice, c->stream)); }
+  if (proofs) {
+    HIP_TRY(c->d_proofs.ensure(n * psz)); HIP_TRY(hipMemcpyAsync(c->d_proofs.p, proofs, n * psz, hipMemcpyHostToDevice, c->stream));
+    const size_t rsz = kind == 1 ? 32 : 64, roff = kind == 1 ? 64 : 192;
+    c->h_resp.resize(n * rsz);
+    for (size_t j = 0; j < n; j++) memcpy(&c->h_resp[rsz * j], proofs + psz * j + roff, rsz);
+    c->n_terms = kind == 1 ? 2 * n + 2 * c->tot_io + 1 : 5 * n + 2;
+    HIP_TRY(c->d_c.ensure(n * 16)); HIP_TRY(c->h_c.ensure(n * 16));
+    HIP_TRY(c->d_z.ensure(kind == 1 ? c->tot_io * 16 + 16 : n * 128));
+    HIP_TRY(c->d_scalars.ensure(c->n_terms * 32)); HIP_TRY(c->d_pre.ensure(c->n_terms * sizeof(te_pre_raw)));
+    HIP_TRY(c->d_gpart.ensure(((n + 127) / 128) * 64 + 64));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->staged_kind = kind;
   return AVRF_OK;
 }
 
 int avrf_thin_batch_stage(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
                           const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
-  if (!c) return AVRF_ERR_BAD_ARG;
-  if (n && (!pks_xy || !io_counts || !ad_lens || !proofs)) return AVRF_ERR_BAD_ARG;
-  if (n > 0x0fffffffULL) return AVRF_ERR_BAD_ARG;
-  HIP_TRY(hipSetDevice(c->device));
-  c->staged_kind = 0; c->n = n;
-  if (n == 0) { c->staged_kind = 1; c->tot_io = 0; c->n_terms = 0; return AVRF_OK; }
-  int st = stage_common(c, n, ios_xy, io_counts, ads, ad_lens);
-  if (st) return st;
-  HIP_TRY(c->d_pks.ensure(n * 64)); HIP_TRY(c->d_proofs.ensure(n * 96));
-  HIP_TRY(hipMemcpyAsync(c->d_pks.p, pks_xy, n * 64, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->d_proofs.p, proofs, n * 96, hipMemcpyHostToDevice, c->stream));
-  c->h_resp.resize(n * 32);
-  for (size_t j = 0; j < n; j++) memcpy(&c->h_resp[32 * j], proofs + 96 * j + 64, 32);
-  c->n_terms = 2 * n + 2 * c->tot_io + 1;
-  HIP_TRY(c->d_c.ensure(n * 16)); HIP_TRY(c->d_z.ensure(c->tot_io * 16 + 16)); HIP_TRY(c->d_flags.ensure(16));
-  HIP_TRY(c->h_c.ensure(n * 16)); HIP_TRY(c->h_flags.ensure(16));
-  HIP_TRY(c->d_scalars.ensure(c->n_terms * 32)); HIP_TRY(c->d_pre.ensure(c->n_terms * sizeof(te_pre_raw)));
-  HIP_TRY(c->d_gpart.ensure(((n + 127) / 128) * 32));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  c->staged_kind = 1;
-  return AVRF_OK;
+  if (n && (!pks_xy || !proofs)) return AVRF_ERR_BAD_ARG;
+  return stage(c, 1, n, nullptr, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs);
+}
+int avrf_pedersen_batch_stage(avrf_ctx *c, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,
+                              const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
+  if (n && !proofs) return AVRF_ERR_BAD_ARG;
+  return stage(c, 2, n, nullptr, nullptr, ios_xy, io_counts, ads, ad_lens, proofs);
 }
 
-int avrf_thin_batch_run(avrf_ctx *c) {
-  if (!c || c->staged_kind != 1) return AVRF_ERR_BAD_ARG;
-  if (c->n == 0) return AVRF_OK;                                       // src/thin.rs:262-264
+// shared tail of both batch verifiers: weight transcript on the host, terms + MSM on the device
+static int batch_run(avrf_ctx *c, int kind) {
+  if (!c || c->staged_kind != kind) return AVRF_ERR_BAD_ARG;
+  if (c->n == 0) return AVRF_OK;                                       // src/thin.rs:262-264, src/pedersen.rs:343-345
+  if (!c->n_terms) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
   double t0 = now_us();
   const size_t n = c->n;
-  BatchDev b;
-  b.pks_xy = c->d_pks.as<uint8_t>(); b.ios_xy = c->d_ios.as<uint8_t>(); b.io_off = c->d_io_off.as<uint32_t>();
-  b.ads = c->d_ads.as<uint8_t>(); b.ad_off = c->d_ad_off.as<uint32_t>(); b.proofs = c->d_proofs.as<uint8_t>(); b.n = (uint32_t)n;
+  BatchDev b = batch_of(c);
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
-  launch_thin_prepare(c->suite, b, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_flags.as<uint32_t>(), c->stream);
+  if (kind == 1) launch_thin_prepare(c->suite, b, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_flags.as<uint32_t>(), c->stream);
+  else launch_ped_prepare(c->suite, b, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream);
   HIP_TRY(hipMemcpyAsync(c->h_c.p, c->d_c.p, n * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   double t1 = now_us();
-  if (*c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;            // src/thin.rs:266-271 (+ malformed encodings)
-  // weight transcript, src/thin.rs:274-279: new(SUITE_ID); absorb [0x50]; for each item absorb LE32(c), LE32(s)
+  if (*c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;            // src/thin.rs:266-271, src/pedersen.rs:348-353
+  // weight transcript (src/thin.rs:274-279, src/pedersen.rs:361-367):
+  //   new(SUITE_ID); absorb [0x50]; per item absorb LE32(c) || LE32(s) [|| LE32(sb)]
   HostSha512 h;
   if (c->suite == 0) h.update(SuiteBandersnatch::SUITE_ID, SuiteBandersnatch::SUITE_ID_LEN);
   else h.update(SuiteBabyJubJub::SUITE_ID, SuiteBabyJubJub::SUITE_ID_LEN);
-  const uint8_t tag = 0x50; h.update(&tag, 1);
+  const uint8_t tag = DS_BATCH_VERIFY; h.update(&tag, 1);
   {
     const uint8_t *cs = c->h_c.as<uint8_t>();
-    uint8_t rec[64];
+    const size_t rsz = kind == 1 ? 32 : 64;
+    uint8_t rec[96];
     memset(rec, 0, sizeof rec);
-    for (size_t j = 0; j < n; j++) { memcpy(rec, cs + 16 * j, 16); memcpy(rec + 32, &c->h_resp[32 * j], 32); h.update(rec, 64); }
+    for (size_t j = 0; j < n; j++) { memcpy(rec, cs + 16 * j, 16); memcpy(rec + 32, &c->h_resp[rsz * j], rsz); h.update(rec, 32 + rsz); }
   }
   uint8_t dg[64]; h.final(dg);
   Seed64 seed;
   for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, dg + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
   double t2 = now_us();
-  launch_thin_terms(c->suite, b, seed, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_scalars.as<uint32_t>(),
-                    c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
+  if (kind == 1) launch_thin_terms(c->suite, b, seed, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_scalars.as<uint32_t>(),
+                                   c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
+  else launch_ped_terms(c->suite, b, seed, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_scalars.as<uint32_t>(),
+                        c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
   double t3 = now_us();
   HostExt r;
   if (msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r)) return AVRF_ERR_BAD_ARG;
   double t4 = now_us();
-  int st = point_is_identity(c, r) ? AVRF_OK : AVRF_VERIFICATION_FAILURE;   // src/thin.rs:319-322
+  int st = point_is_identity(c, r) ? AVRF_OK : AVRF_VERIFICATION_FAILURE;   // src/thin.rs:319-322, src/pedersen.rs:420-423
   double t5 = now_us();
   c->timing[0] = t5 - t0; c->timing[1] = t1 - t0; c->timing[2] = t2 - t1; c->timing[3] = t3 - t2; c->timing[4] = t4 - t3; c->timing[5] = t5 - t4;
   return st;
 }
 
+int avrf_thin_batch_run(avrf_ctx *c) { return batch_run(c, 1); }
+int avrf_pedersen_batch_run(avrf_ctx *c) { return batch_run(c, 2); }
+
 int avrf_thin_batch_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
                            const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
   int st = avrf_thin_batch_stage(c, n, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs);
-  if (st) return st;
-  return avrf_thin_batch_run(c);
+  return st ? st : avrf_thin_batch_run(c);
+}
+int avrf_pedersen_batch_verify(avrf_ctx *c, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,
+                               const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
+  int st = avrf_pedersen_batch_stage(c, n, ios_xy, io_counts, ads, ad_lens, proofs);
+  return st ? st : avrf_pedersen_batch_run(c);
 }
 
 size_t avrf_batch_last_terms(avrf_ctx *c, uint8_t *bases_xy, uint8_t *scalars) {
@@ -253,6 +285,130 @@ size_t avrf_batch_last_terms(avrf_ctx *c, uint8_t *bases_xy, uint8_t *scalars) {
 void avrf_last_timing(avrf_ctx *c, double out[8]) {
   if (!c || !out) return;
   for (int i = 0; i < 8; i++) out[i] = c->timing[i];
+}
+
+// ---------------------------------------------------------------- independent per-item calls
+
+static int read_flags(avrf_ctx *c) {
+  if (hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+  if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) return -1;
+  return (int)*c->h_flags.as<uint32_t>();
+}
+
+int avrf_thin_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
+                    const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out) {
+  if (n && (!sks || !proofs_out)) return AVRF_ERR_BAD_ARG;
+  int st = stage(c, 1, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, nullptr);
+  if (st || !n) return st;
+  c->staged_kind = 0;
+  BatchDev b = batch_of(c); if (!pks_xy) b.pks_xy = nullptr;
+  HIP_TRY(c->d_out.ensure(n * 96));
+  HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  double t0 = now_us();
+  launch_thin_prove(c->suite, b, c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, n * 96, hipMemcpyDeviceToHost, c->stream));
+  int f = read_flags(c);
+  c->timing[0] = now_us() - t0;
+  if (f < 0) return AVRF_ERR_NO_DEVICE;
+  return f ? AVRF_INVALID_DATA : AVRF_OK;
+}
+
+int avrf_thin_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
+                     const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, int32_t *status_out) {
+  if (n && (!pks_xy || !proofs || !status_out)) return AVRF_ERR_BAD_ARG;
+  int st = stage(c, 1, n, nullptr, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs);
+  if (st || !n) return st;
+  HIP_TRY(c->d_status.ensure(n * 4));
+  double t0 = now_us();
+  launch_thin_verify(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
+  c->timing[0] = now_us() - t0;
+  return AVRF_OK;
+}
+
+int avrf_pedersen_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
+                        const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out, uint8_t *blindings_out) {
+  if (n && (!sks || !proofs_out)) return AVRF_ERR_BAD_ARG;
+  int st = stage(c, 2, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, nullptr);
+  if (st || !n) return st;
+  c->staged_kind = 0;
+  BatchDev b = batch_of(c); if (!pks_xy) b.pks_xy = nullptr;
+  HIP_TRY(c->d_out.ensure(n * 256)); HIP_TRY(c->d_misc.ensure(n * 32));
+  HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  double t0 = now_us();
+  launch_ped_prove(c->suite, b, c->d_out.as<uint8_t>(), c->d_misc.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, n * 256, hipMemcpyDeviceToHost, c->stream));
+  if (blindings_out) HIP_TRY(hipMemcpyAsync(blindings_out, c->d_misc.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+  int f = read_flags(c);
+  c->timing[0] = now_us() - t0;
+  if (f < 0) return AVRF_ERR_NO_DEVICE;
+  return f ? AVRF_INVALID_DATA : AVRF_OK;
+}
+
+int avrf_pedersen_verify(avrf_ctx *c, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,
+                         const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, int32_t *status_out) {
+  if (n && (!proofs || !status_out)) return AVRF_ERR_BAD_ARG;
+  int st = stage(c, 2, n, nullptr, nullptr, ios_xy, io_counts, ads, ad_lens, proofs);
+  if (st || !n) return st;
+  HIP_TRY(c->d_status.ensure(n * 4));
+  double t0 = now_us();
+  launch_ped_verify(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
+  c->timing[0] = now_us() - t0;
+  return AVRF_OK;
+}
+
+static int smul_common(avrf_ctx *c, size_t n, const uint8_t *scalars, const uint8_t *points_xy, uint8_t *out_xy) {
+  if (!c || (n && (!scalars || !out_xy))) return AVRF_ERR_BAD_ARG;
+  if (!n) return AVRF_OK;
+  if (n > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  c->staged_kind = 0;
+  HIP_TRY(c->d_sks.ensure(n * 32)); HIP_TRY(c->d_out.ensure(n * 64));
+  HIP_TRY(hipMemcpyAsync(c->d_sks.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  if (points_xy) { HIP_TRY(c->d_misc.ensure(n * 64)); HIP_TRY(hipMemcpyAsync(c->d_misc.p, points_xy, n * 64, hipMemcpyHostToDevice, c->stream)); }
+  HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  launch_smul(c->suite, c->d_sks.as<uint8_t>(), points_xy ? c->d_misc.as<uint8_t>() : nullptr, (uint32_t)n, c->d_out.as<uint8_t>(),
+              c->d_flags.as<uint32_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(out_xy, c->d_out.p, n * 64, hipMemcpyDeviceToHost, c->stream));
+  int f = read_flags(c);
+  if (f < 0) return AVRF_ERR_NO_DEVICE;
+  return f ? AVRF_INVALID_DATA : AVRF_OK;
+}
+int avrf_scalar_mul_base(avrf_ctx *c, size_t n, const uint8_t *sks, uint8_t *out_xy) { return smul_common(c, n, sks, nullptr, out_xy); }
+int avrf_scalar_mul(avrf_ctx *c, size_t n, const uint8_t *scalars, const uint8_t *points_xy, uint8_t *out_xy) {
+  if (n && !points_xy) return AVRF_ERR_BAD_ARG;
+  return smul_common(c, n, scalars, points_xy, out_xy);
+}
+
+int avrf_points_decompress(avrf_ctx *c, size_t n, const uint8_t *in, uint8_t *out_xy, int validate, int32_t *status_out) {
+  if (!c || (n && (!in || !out_xy || !status_out))) return AVRF_ERR_BAD_ARG;
+  if (!n) return AVRF_OK;
+  if (n > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  c->staged_kind = 0;
+  HIP_TRY(c->d_misc.ensure(n * 32)); HIP_TRY(c->d_out.ensure(n * 64)); HIP_TRY(c->d_status.ensure(n * 4));
+  HIP_TRY(hipMemcpyAsync(c->d_misc.p, in, n * 32, hipMemcpyHostToDevice, c->stream));
+  launch_decompress(c->suite, c->d_misc.as<uint8_t>(), (uint32_t)n, c->d_out.as<uint8_t>(), validate, c->d_status.as<int32_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(out_xy, c->d_out.p, n * 64, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
+  return AVRF_OK;
+}
+int avrf_points_compress(avrf_ctx *c, size_t n, const uint8_t *in_xy, uint8_t *out) {
+  if (!c || (n && (!in_xy || !out))) return AVRF_ERR_BAD_ARG;
+  if (!n) return AVRF_OK;
+  if (n > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  c->staged_kind = 0;
+  HIP_TRY(c->d_misc.ensure(n * 64)); HIP_TRY(c->d_out.ensure(n * 32));
+  HIP_TRY(hipMemcpyAsync(c->d_misc.p, in_xy, n * 64, hipMemcpyHostToDevice, c->stream));
+  launch_compress(c->suite, c->d_misc.as<uint8_t>(), (uint32_t)n, c->d_out.as<uint8_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(out, c->d_out.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
+  return AVRF_OK;
 }
 
 }  // extern "C"

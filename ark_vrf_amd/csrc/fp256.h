@@ -133,6 +133,32 @@ template <class F> AVRF_DI fp fp_pow_const(const fp &a, const uint32_t (&e)[8]) 
 }
 template <class F> AVRF_DI fp fp_inv(const fp &a) { return fp_pow_const<F>(a, F::PM2); }
 
+
+// Square root by Tonelli-Shanks (p - 1 = 2^s * t, ROOT = g^t for a non-residue g).  Returns
+// false when `a` is a non-residue.  Which of the two roots is returned is unspecified; callers
+// choose by sign (ark-serialize's x-sign flag).
+template <class F> AVRF_DI bool fp_sqrt(const fp &a, fp &out) {
+  if (fp_is_zero(a)) { out = a; return true; }
+  const fp one = fp_one<F>();
+  fp z = fp_const<F>(F::ROOT);
+  fp w = fp_pow_const<F>(a, F::T_MINUS1_HALF);
+  fp x = fp_mul<F>(w, a);          // a^((t+1)/2)
+  fp b = fp_mul<F>(x, w);          // a^t
+  int v = F::TWO_ADICITY;
+  while (!fp_eq(b, one)) {
+    int k = 0; fp b2k = b;
+    while (!fp_eq(b2k, one)) { b2k = fp_sqr<F>(b2k); k++; if (k >= v) return false; }
+    fp ww = z;
+    for (int j = 0; j < v - k - 1; j++) ww = fp_sqr<F>(ww);
+    z = fp_sqr<F>(ww);
+    b = fp_mul<F>(b, z);
+    x = fp_mul<F>(x, ww);
+    v = k;
+  }
+  if (!fp_eq(fp_sqr<F>(x), a)) return false;
+  out = x; return true;
+}
+
 // x > (p-1)/2 on the canonical value of a Montgomery-form element ("negative" in ark-serialize)
 template <class F> AVRF_DI bool fp_is_negative_mont(const fp &a_mont) {
   fp a = fp_from_mont<F>(a_mont), t;
@@ -183,6 +209,63 @@ template <class F> AVRF_DI fp fp_from_wide_mont(const fp &lo, const fp &hi) {
   fp l = fp_mul<F>(lo, r2);              // lo * R        (lo may be >= p: mont mul handles any a < 2^256 with b < p)
   fp h = fp_mul<F>(fp_mul<F>(hi, r2), r2); // hi * R^2 = (hi * 2^256) * R
   return fp_add<F>(l, h);
+}
+
+
+// ---- out-of-line variants for the per-item protocol kernels (code size / compile time);
+// the MSM hot loops keep the force-inlined forms above.
+#define AVRF_DN __device__ __noinline__ static
+template <class F> AVRF_DN fp fp_mul_nf(fp a, fp b) { return fp_mul<F>(a, b); }
+template <class F> AVRF_DI fp fp_sqr_nf(const fp &a) { return fp_mul_nf<F>(a, a); }
+template <class F> AVRF_DI fp fp_to_mont_nf(const fp &a) { return fp_mul_nf<F>(a, fp_const<F>(F::R2)); }
+template <class F> AVRF_DI fp fp_from_mont_nf(const fp &a) { fp one = fp_zero(); one.v[0] = 1; return fp_mul_nf<F>(a, one); }
+template <class F> AVRF_DI bool fp_is_negative_mont_nf(const fp &a_mont) {
+  fp a = fp_from_mont_nf<F>(a_mont), t; return sub8(t, fp_const<F>(F::HALF), a) != 0;
+}
+template <class F> AVRF_DI fp fp_from_wide_mont_nf(const fp &lo, const fp &hi) {
+  fp r2 = fp_const<F>(F::R2);
+  return fp_add<F>(fp_mul_nf<F>(lo, r2), fp_mul_nf<F>(fp_mul_nf<F>(hi, r2), r2));
+}
+template <class F> AVRF_DN fp fp_inv_nf(fp a) {
+  fp r = fp_one<F>();
+  bool started = false;
+  for (int i = 255; i >= 0; i--) {
+    if (started) r = fp_mul_nf<F>(r, r);
+    if ((F::PM2[i >> 5] >> (i & 31)) & 1) { r = started ? fp_mul_nf<F>(r, a) : a; started = true; }
+  }
+  return r;
+}
+template <class F> AVRF_DN fp fp_pow_nf(fp a, int which) {   // which: 0 -> T_MINUS1_HALF
+  fp r = fp_one<F>();
+  bool started = false;
+  for (int i = 255; i >= 0; i--) {
+    if (started) r = fp_mul_nf<F>(r, r);
+    uint32_t bit = which == 0 ? (F::T_MINUS1_HALF[i >> 5] >> (i & 31)) & 1 : (F::PM2[i >> 5] >> (i & 31)) & 1;
+    if (bit) { r = started ? fp_mul_nf<F>(r, a) : a; started = true; }
+  }
+  return r;
+}
+// Tonelli-Shanks, out-of-line (see fp_sqrt)
+template <class F> AVRF_DN bool fp_sqrt_nf(fp a, fp *out) {
+  if (fp_is_zero(a)) { *out = a; return true; }
+  const fp one = fp_one<F>();
+  fp z = fp_const<F>(F::ROOT);
+  fp w = fp_pow_nf<F>(a, 0);
+  fp x = fp_mul_nf<F>(w, a);
+  fp b = fp_mul_nf<F>(x, w);
+  int v = F::TWO_ADICITY;
+  while (!fp_eq(b, one)) {
+    int k = 0; fp b2k = b;
+    while (!fp_eq(b2k, one)) { b2k = fp_mul_nf<F>(b2k, b2k); k++; if (k >= v) return false; }
+    fp ww = z;
+    for (int j = 0; j < v - k - 1; j++) ww = fp_mul_nf<F>(ww, ww);
+    z = fp_mul_nf<F>(ww, ww);
+    b = fp_mul_nf<F>(b, z);
+    x = fp_mul_nf<F>(x, ww);
+    v = k;
+  }
+  if (!fp_eq(fp_mul_nf<F>(x, x), a)) return false;
+  *out = x; return true;
 }
 
 }  // namespace avrf

@@ -1,0 +1,196 @@
+// proto_dev.h -- device-side restatement of the reference's Fiat-Shamir protocol glue
+// (src/utils/common.rs) on top of sha512_dev.h / fp256.h / te.h.  One lane = one VRF item.
+//
+//   vrf_transcript_base   common.rs:159-173   -> tr_base()
+//   chain_ios             common.rs:231-240   -> schnorr argument of tr_base()
+//   DelinearizeScalars    common.rs:335-369   -> delin_seed() + xof128()
+//   challenge             common.rs:270-280   -> challenge_begin()/challenge_finish()
+//   nonce                 common.rs:313-328   -> nonce()
+//   challenge_scalar      common.rs:72-76, nonce_scalar :57-70
+#pragma once
+#include "sha512_dev.h"
+#include "te.h"
+
+// Everything that includes this header is a per-item protocol kernel: route the field / curve
+// calls to their out-of-line forms (fp256.h, te.h) so that each kernel holds ONE copy of the
+// Montgomery multiplier and of each point operation instead of hundreds of inlined ones.
+// (The MSM hot loops in msm.hip do not include this header and stay fully inlined.)
+#define fp_mul fp_mul_nf
+#define fp_sqr fp_sqr_nf
+#define fp_inv fp_inv_nf
+#define fp_to_mont fp_to_mont_nf
+#define fp_from_mont fp_from_mont_nf
+#define fp_is_negative_mont fp_is_negative_mont_nf
+#define fp_from_wide_mont fp_from_wide_mont_nf
+#define te_madd te_madd_nf
+#define te_add te_add_nf
+#define te_dbl te_dbl_nf
+#define te_to_aff te_to_aff_nf
+#define te_make_pre te_make_pre_nf
+
+namespace avrf {
+
+enum : uint8_t {
+  DS_THIN = 0x01, DS_PEDERSEN = 0x02, DS_NONCE_EXPAND = 0x10, DS_NONCE = 0x11, DS_PEDERSEN_BLINDING = 0x12,
+  DS_POINT_TO_HASH = 0x20, DS_DELINEARIZE = 0x30, DS_CHALLENGE = 0x40, DS_BATCH_VERIFY = 0x50
+};
+enum { FLAG_RANGE = 1, FLAG_IDENTITY = 2, FLAG_SCALAR = 4, FLAG_CURVE = 8 };
+
+// A staged batch in HBM.  Offsets are exclusive prefix sums (n + 1 entries).
+struct BatchDev {
+  const uint8_t *pks_xy;    // n x 64 (thin only)
+  const uint8_t *ios_xy;    // tot_io x 128 (input_xy || output_xy)
+  const uint32_t *io_off;   // n + 1
+  const uint8_t *ads;       // concatenated additional data
+  const uint32_t *ad_off;   // n + 1
+  const uint8_t *proofs;    // thin: n x 96 (R_xy || s); pedersen: n x 256
+  const uint8_t *sks;       // n x 32 (provers only)
+  uint32_t n;
+};
+struct Seed64 { uint64_t w[8]; };  // a SHA-512 digest as big-endian words
+
+// absorb the ark-serialize compressed encoding of an affine point given as canonical x||y
+// (LE32 each): LE32(y) with bit 255 set iff x > (q-1)/2   
+template <class S> AVRF_DI void absorb_point_xy(Sha512 &h, const fp &x, const fp &y) {
+  using Fq = typename S::Fq;
+  uint32_t sign = fp_is_negative_plain<Fq>(x) ? 0x80000000u : 0u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) sha512_u32le(h, y.v[i] | (i == 7 ? sign : 0u));
+}
+AVRF_DI void absorb_fp_le(Sha512 &h, const fp &a) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) sha512_u32le(h, a.v[i]);
+}
+template <class S> AVRF_DI uint32_t point_flags(const fp &x, const fp &y) {
+  using Fq = typename S::Fq;
+  uint32_t f = 0;
+  if (ge_p<Fq>(x) || ge_p<Fq>(y)) f |= FLAG_RANGE;
+  fp one = fp_zero(); one.v[0] = 1;
+  if (fp_is_zero(x) && fp_eq(y, one)) f |= FLAG_IDENTITY;
+  return f;
+}
+
+// Transcript after vrf_transcript_base: SUITE_ID, scheme tag, io count + pairs (optionally the
+// Schnorr pair (G, pk) first), ad length + ad.  Accumulates point flags of pk / ios into *flags.
+template <class S> AVRF_DI void tr_base(Sha512 &h, uint8_t scheme, bool schnorr, const uint8_t *pk_xy,
+                                        const uint8_t *ios_xy, uint32_t m, const uint8_t *ad, uint32_t adl, uint32_t *flags) {
+  sha512_init(h);
+  for (int i = 0; i < S::SUITE_ID_LEN; i++) sha512_byte(h, S::SUITE_ID[i]);
+  sha512_byte(h, scheme);
+  sha512_u64le(h, (uint64_t)m + (schnorr ? 1 : 0));
+  uint32_t f = 0;
+  if (schnorr) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) sha512_u32le(h, S::G_C[i]);
+    fp x = fp_load_le(pk_xy), y = fp_load_le(pk_xy + 32);
+    f |= point_flags<S>(x, y);
+    absorb_point_xy<S>(h, x, y);
+  }
+  for (uint32_t i = 0; i < m; i++) {
+    const uint8_t *p = ios_xy + 128 * (size_t)i;
+    fp x = fp_load_le(p), y = fp_load_le(p + 32);
+    f |= point_flags<S>(x, y); absorb_point_xy<S>(h, x, y);
+    x = fp_load_le(p + 64); y = fp_load_le(p + 96);
+    f |= point_flags<S>(x, y); absorb_point_xy<S>(h, x, y);
+  }
+  sha512_u64le(h, (uint64_t)adl);
+  sha512_bytes(h, ad, adl);
+  *flags |= f;
+}
+// seed of the delinearisation stream: fork + [0x30] + finalize
+AVRF_DI void delin_seed(const Sha512 &h, uint64_t (&seed)[8]) {
+  Sha512 hd = h; sha512_byte(hd, DS_DELINEARIZE); sha512_final(hd, seed);
+}
+// i-th 16-byte chunk of a squeeze stream as a 128-bit plain integer
+AVRF_DI fp xof128(const uint64_t (&seed)[8], uint32_t i) {
+  uint64_t blk[8]; sha512_xof_block(seed, i >> 2, blk);
+  uint32_t w[4]; digest_le128(blk, i & 3, w);
+  fp a = fp_zero(); a.v[0] = w[0]; a.v[1] = w[1]; a.v[2] = w[2]; a.v[3] = w[3]; return a;
+}
+// challenge_scalar of a finished transcript: first 16 squeezed bytes (plain 128-bit integer < r)
+AVRF_DI fp challenge_finish(const Sha512 &h) {
+  uint64_t seed[8]; sha512_final(h, seed); return xof128(seed, 0);
+}
+// first `nbytes` (<= 64) squeezed bytes as little-endian integer pieces lo (bytes 0..31), hi (32..63)
+AVRF_DI void squeeze64(const Sha512 &h, fp &lo, fp &hi, uint64_t (&blk)[8]) {
+  uint64_t seed[8]; sha512_final(h, seed); sha512_xof_block(seed, 0, blk);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint64_t b = __builtin_bswap64(blk[i]); lo.v[2 * i] = (uint32_t)b; lo.v[2 * i + 1] = (uint32_t)(b >> 32);
+    uint64_t c = __builtin_bswap64(blk[4 + i]); hi.v[2 * i] = (uint32_t)c; hi.v[2 * i + 1] = (uint32_t)(c >> 32);
+  }
+}
+// nonce(sk, transcript): returns the nonce in Montgomery form over Fr.  `sk_plain` canonical.
+template <class S> AVRF_DN fp nonce(fp sk_plain, Sha512 t) {
+  using Fr = typename S::Fr;
+  Sha512 te = t; sha512_byte(te, DS_NONCE_EXPAND); absorb_fp_le(te, sk_plain);
+  fp lo, hi; uint64_t skh[8];
+  squeeze64(te, lo, hi, skh);                       // sk_hash = 64 squeezed bytes = block 0
+  Sha512 tn = t; sha512_byte(tn, DS_NONCE);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {                     // absorb the 64 bytes of sk_hash in order
+    uint64_t w = skh[i];
+#pragma unroll
+    for (int k = 0; k < 8; k++) sha512_byte(tn, (uint8_t)(w >> (56 - 8 * k)));
+  }
+  uint64_t blk[8]; squeeze64(tn, lo, hi, blk);
+  // nonce_scalar: ceil((bits+128)/8) = 48 bytes for both suites (253 / 251 bits)
+  static_assert((Fr::BITS + 128 + 7) / 8 == 48, "nonce length");
+#pragma unroll
+  for (int i = 4; i < 8; i++) hi.v[i] = 0;           // keep bytes 32..47 only
+  return fp_from_wide_mont<Fr>(lo, hi);
+}
+
+// ---- group helpers for the per-item kernels
+
+template <class S> AVRF_DI te_pre pre_from_xy(const uint8_t *xy) {
+  using Fq = typename S::Fq;
+  return te_make_pre<S>(fp_to_mont<Fq>(fp_load_le(xy)), fp_to_mont<Fq>(fp_load_le(xy + 32)));
+}
+// k * P, k a plain integer of `nbits` bits, binary double-and-add (MSB first)
+template <class S> AVRF_DN te_ext te_smul(te_pre p, fp k, int nbits) {
+  te_ext acc = te_identity<S>();
+  for (int i = nbits - 1; i >= 0; i--) {
+    acc = te_dbl<S>(acc);
+    if ((k.v[i >> 5] >> (i & 31)) & 1) acc = te_madd<S>(acc, p);
+  }
+  return acc;
+}
+// a*P + b*Q (Shamir's trick), a/b plain integers of nbits bits
+template <class S> AVRF_DN te_ext te_smul2(te_pre p, fp a, te_pre q, fp b, int nbits) {
+  using Fq = typename S::Fq;
+  te_ext pq = te_madd<S>(te_from_pre<S>(p), q);
+  te_aff pqa = te_to_aff<S>(pq);
+  te_pre pqp = te_make_pre<S>(pqa.x, pqa.y);
+  te_ext acc = te_identity<S>();
+  for (int i = nbits - 1; i >= 0; i--) {
+    acc = te_dbl<S>(acc);
+    uint32_t ba = (a.v[i >> 5] >> (i & 31)) & 1, bb = (b.v[i >> 5] >> (i & 31)) & 1;
+    if (ba | bb) {
+      te_pre sel;
+#pragma unroll
+      for (int w = 0; w < 8; w++) {
+        sel.x.v[w] = (ba & bb) ? pqp.x.v[w] : (ba ? p.x.v[w] : q.x.v[w]);
+        sel.y.v[w] = (ba & bb) ? pqp.y.v[w] : (ba ? p.y.v[w] : q.y.v[w]);
+        sel.k.v[w] = (ba & bb) ? pqp.k.v[w] : (ba ? p.k.v[w] : q.k.v[w]);
+      }
+      acc = te_madd<S>(acc, sel);
+    }
+  }
+  (void)sizeof(Fq);
+  return acc;
+}
+template <class S> AVRF_DI void store_xy(uint8_t *out, const te_aff &a) {
+  using Fq = typename S::Fq;
+  fp_store_le(out, fp_from_mont<Fq>(a.x)); fp_store_le(out + 32, fp_from_mont<Fq>(a.y));
+}
+template <class S> AVRF_DI void absorb_point_mont(Sha512 &h, const te_aff &a) {
+  using Fq = typename S::Fq;
+  absorb_point_xy<S>(h, fp_from_mont<Fq>(a.x), fp_from_mont<Fq>(a.y));
+}
+template <class S> AVRF_DI bool ext_eq_aff(const te_ext &p, const te_pre &q) {   // p == q ?
+  using Fq = typename S::Fq;
+  return fp_eq(p.x, fp_mul<Fq>(q.x, p.z)) && fp_eq(p.y, fp_mul<Fq>(q.y, p.z));
+}
+
+}  // namespace avrf

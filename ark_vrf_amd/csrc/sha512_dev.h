@@ -46,8 +46,16 @@ struct Sha512 {
   uint32_t total;   // total bytes absorbed (messages here are far below 2^32 bytes)
 };
 
-AVRF_DI void sha512_compress(uint64_t (&h)[8], uint64_t (&w)[16]) {
-  uint64_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+struct ShaH { uint64_t v[8]; };
+struct ShaW { uint64_t v[16]; };
+
+// One compression; deliberately NOT inlined (it is ~2k instructions and is reached from dozens of
+// absorb sites; arguments and result travel in VGPRs).
+__device__ __noinline__ static ShaH sha512_compress_nf(ShaH hin, ShaW win) {
+  uint64_t a = hin.v[0], b = hin.v[1], c = hin.v[2], d = hin.v[3], e = hin.v[4], f = hin.v[5], g = hin.v[6], hh = hin.v[7];
+  uint64_t w[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) w[i] = win.v[i];
 #pragma unroll 1
   for (int r = 0; r < 80; r += 16) {
 #pragma unroll
@@ -67,7 +75,20 @@ AVRF_DI void sha512_compress(uint64_t (&h)[8], uint64_t (&w)[16]) {
       hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
   }
-  h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  ShaH o;
+  o.v[0] = hin.v[0] + a; o.v[1] = hin.v[1] + b; o.v[2] = hin.v[2] + c; o.v[3] = hin.v[3] + d;
+  o.v[4] = hin.v[4] + e; o.v[5] = hin.v[5] + f; o.v[6] = hin.v[6] + g; o.v[7] = hin.v[7] + hh;
+  return o;
+}
+AVRF_DI void sha512_compress(uint64_t (&h)[8], uint64_t (&w)[16]) {
+  ShaH hi; ShaW wi;
+#pragma unroll
+  for (int i = 0; i < 8; i++) hi.v[i] = h[i];
+#pragma unroll
+  for (int i = 0; i < 16; i++) wi.v[i] = w[i];
+  ShaH o = sha512_compress_nf(hi, wi);
+#pragma unroll
+  for (int i = 0; i < 8; i++) h[i] = o.v[i];
 }
 
 AVRF_DI void sha512_init(Sha512 &s) {

@@ -98,6 +98,17 @@ template <class S> AVRF_DI bool te_on_curve(const fp &x, const fp &y) {
   return fp_eq(l, r);
 }
 
+// out-of-line forms (per-item protocol kernels)
+template <class S> AVRF_DN te_ext te_madd_nf(te_ext p, te_pre q) { return te_madd<S>(p, q); }
+template <class S> AVRF_DN te_ext te_add_nf(te_ext p, te_ext q) { return te_add<S>(p, q); }
+template <class S> AVRF_DN te_ext te_dbl_nf(te_ext p) { return te_dbl<S>(p); }
+template <class S> AVRF_DN te_aff te_to_aff_nf(te_ext p) {
+  using Fq = typename S::Fq;
+  fp zi = fp_inv_nf<Fq>(p.z);
+  te_aff r; r.x = fp_mul_nf<Fq>(p.x, zi); r.y = fp_mul_nf<Fq>(p.y, zi); return r;
+}
+template <class S> AVRF_DN te_pre te_make_pre_nf(fp x_mont, fp y_mont) { return te_make_pre<S>(x_mont, y_mont); }
+
 // raw load/store of points as 32-bit words (global memory, 16-byte vectorised)
 AVRF_DI void load_words(uint32_t *dst, const uint32_t *src, int nwords) {
   const uint4 *s4 = reinterpret_cast<const uint4 *>(src);

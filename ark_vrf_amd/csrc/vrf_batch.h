@@ -6,20 +6,8 @@
 
 namespace avrf {
 
-// A staged batch in HBM.  Offsets are exclusive prefix sums (n + 1 entries).
-struct BatchDev {
-  const uint8_t *pks_xy;    // n x 64 (thin only)
-  const uint8_t *ios_xy;    // tot_io x 128 (input_xy || output_xy)
-  const uint32_t *io_off;   // n + 1
-  const uint8_t *ads;       // concatenated additional data
-  const uint32_t *ad_off;   // n + 1
-  const uint8_t *proofs;    // thin: n x 96 (R_xy || s); pedersen: n x 256
-  uint32_t n;
-};
-
-struct Seed64 { uint64_t w[8]; };  // a SHA-512 digest as big-endian words
-
-enum { FLAG_RANGE = 1, FLAG_IDENTITY = 2, FLAG_SCALAR = 4 };
+struct BatchDev;
+struct Seed64;
 
 // thin::BatchVerifier::prepare (src/thin.rs:209-226) for every item: c_j (4 x u32 LE) and
 // z_{j,i} for i >= 1 (4 x u32 each, indexed by io_off[j] + i - 1); plus the identity / range
@@ -30,5 +18,20 @@ void launch_thin_prepare(int suite, const BatchDev &b, uint32_t *d_c, uint32_t *
 // given the weight-transcript seed.  n_terms = 2 n + 2 tot_io + 1.
 void launch_thin_terms(int suite, const BatchDev &b, const Seed64 &seed, const uint32_t *d_c, const uint32_t *d_z,
                        uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st);
+
+// pedersen::BatchItem::new (src/pedersen.rs:276-293) and the (5N+2)-term MSM of :369-418.
+void launch_ped_prepare(int suite, const BatchDev &b, uint32_t *d_c, uint8_t *d_merged, uint32_t *d_flags, hipStream_t st);
+void launch_ped_terms(int suite, const BatchDev &b, const Seed64 &seed, const uint32_t *d_c, const uint8_t *d_merged,
+                      uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st);
+
+// independent per-item kernels (vrf_single.hip)
+void launch_smul(int suite, const uint8_t *d_scalars, const uint8_t *d_points_xy, uint32_t n, uint8_t *d_out, uint32_t *d_flags, hipStream_t st);
+void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st);
+void launch_thin_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
+void launch_ped_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st);
+void launch_ped_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
+
+void launch_decompress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st);
+void launch_compress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st);
 
 }  // namespace avrf

@@ -8,29 +8,9 @@
 // One lane per batch item; SHA-512 state in VGPRs (sha512_dev.h); scalar-field products in
 // 8 x u32 Montgomery form (fp256.h).
 #include "vrf_batch.h"
-#include "sha512_dev.h"
-#include "te.h"
+#include "proto_dev.h"
 
 namespace avrf {
-
-enum : uint8_t { DS_THIN = 0x01, DS_PEDERSEN = 0x02, DS_DELINEARIZE = 0x30, DS_CHALLENGE = 0x40 };
-
-// absorb the ark-serialize compressed encoding of an affine point given as canonical x||y
-// (LE32 each): LE32(y) with bit 255 set iff x > (q-1)/2   
-template <class S> AVRF_DI void absorb_point_xy(Sha512 &h, const fp &x, const fp &y) {
-  using Fq = typename S::Fq;
-  uint32_t sign = fp_is_negative_plain<Fq>(x) ? 0x80000000u : 0u;
-#pragma unroll
-  for (int i = 0; i < 8; i++) sha512_u32le(h, y.v[i] | (i == 7 ? sign : 0u));
-}
-template <class S> AVRF_DI uint32_t point_flags(const fp &x, const fp &y) {
-  using Fq = typename S::Fq;
-  uint32_t f = 0;
-  if (ge_p<Fq>(x) || ge_p<Fq>(y)) f |= FLAG_RANGE;
-  fp one = fp_zero(); one.v[0] = 1;
-  if (fp_is_zero(x) && fp_eq(y, one)) f |= FLAG_IDENTITY;
-  return f;
-}
 
 template <class S>
 __global__ void __launch_bounds__(128)
@@ -160,6 +140,115 @@ k_g_final(const uint32_t *__restrict__ gpart, uint32_t nparts, uint32_t *__restr
     if (which_base == 0) { g.x = fp_const<Fq>(S::G_X); g.y = fp_const<Fq>(S::G_Y); g.k = fp_const<Fq>(S::G_K); }
     else { g.x = fp_const<Fq>(S::B_X); g.y = fp_const<Fq>(S::B_Y); g.k = fp_const<Fq>(S::B_K); }
     store_pre(pre + t_last, g);
+  }
+}
+
+
+// ---------------------------------------------------------------- Pedersen batch
+
+// pedersen::BatchItem::new (src/pedersen.rs:276-293): challenge c_j and the merged I/O pair
+// (written as canonical xy to merged_xy[j], 128 bytes) for every item.
+template <class S>
+__global__ void __launch_bounds__(128)
+k_ped_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint8_t *__restrict__ merged_xy, uint32_t *__restrict__ flags) {
+  using Fr = typename S::Fr;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b.n) return;
+  uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pr = b.proofs + 256 * (size_t)j;
+  Sha512 t; uint32_t f = 0;
+  tr_base<S>(t, DS_PEDERSEN, false, nullptr, ios, m, b.ads + ad0, adl, &f);   // io identity -> io_identity flag (:278)
+  uint8_t *mo = merged_xy + 128 * (size_t)j;
+  if (m == 1) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(ios); uint4 *dst = reinterpret_cast<uint4 *>(mo);
+#pragma unroll
+    for (int i = 0; i < 8; i++) dst[i] = src[i];
+  } else if (m == 0) {
+    fp zero = fp_zero(), one = fp_zero(); one.v[0] = 1;
+    fp_store_le(mo, zero); fp_store_le(mo + 32, one); fp_store_le(mo + 64, zero); fp_store_le(mo + 96, one);
+  } else {                                                                     // merge_ios, common.rs:389-419
+    uint64_t dseed[8]; delin_seed(t, dseed);
+    te_ext im = te_identity<S>(), om = te_identity<S>();
+    for (uint32_t i = 0; i < m; i++) {
+      te_pre pi = pre_from_xy<S>(ios + 128 * (size_t)i), po = pre_from_xy<S>(ios + 128 * (size_t)i + 64);
+      if (i == 0) { im = te_madd<S>(im, pi); om = te_madd<S>(om, po); }
+      else { fp z = xof128(dseed, i - 1); im = te_add<S>(im, te_smul<S>(pi, z, 128)); om = te_add<S>(om, te_smul<S>(po, z, 128)); }
+    }
+    te_aff ia = te_to_aff<S>(im), oa = te_to_aff<S>(om);
+    store_xy<S>(mo, ia); store_xy<S>(mo + 64, oa);
+  }
+  fp ybx = fp_load_le(pr), yby = fp_load_le(pr + 32), rx = fp_load_le(pr + 64), ry = fp_load_le(pr + 96);
+  fp okx = fp_load_le(pr + 128), oky = fp_load_le(pr + 160);
+  f |= point_flags<S>(ybx, yby);                                               // pk_com.is_zero() (:348-353)
+  f |= (point_flags<S>(rx, ry) | point_flags<S>(okx, oky)) & FLAG_RANGE;
+  if (ge_p<Fr>(fp_load_le(pr + 192)) || ge_p<Fr>(fp_load_le(pr + 224))) f |= FLAG_SCALAR;
+  absorb_point_xy<S>(t, ybx, yby);                                             // :280
+  sha512_byte(t, DS_CHALLENGE); absorb_point_xy<S>(t, rx, ry); absorb_point_xy<S>(t, okx, oky);
+  fp c = challenge_finish(t);                                                  // :281
+  *reinterpret_cast<uint4 *>(c_out + 4 * (size_t)j) = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
+  if (f) atomicOr(flags, f);
+}
+
+// per-item part of pedersen::BatchVerifier::verify, src/pedersen.rs:369-410
+template <class S>
+__global__ void __launch_bounds__(128)
+k_ped_terms(BatchDev b, Seed64 seed, const uint32_t *__restrict__ c_in, const uint8_t *__restrict__ merged_xy,
+            uint32_t *__restrict__ scalars, te_pre *__restrict__ pre, uint32_t *__restrict__ gpart, uint32_t *__restrict__ bpart) {
+  using Fr = typename S::Fr;
+  __shared__ fp red[128];
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  fp us = fp_zero(), usb = fp_zero();
+  if (j < b.n) {
+    // 32 squeezed bytes per item: t = bytes[0..16], u = bytes[16..32]   (:373-381)
+    fp t_plain = xof128(seed.w, 2 * j), u_plain = xof128(seed.w, 2 * j + 1);
+    fp tt = fp_to_mont<Fr>(t_plain), uu = fp_to_mont<Fr>(u_plain);
+    fp c = fp_to_mont<Fr>(fp_from_u128(c_in + 4 * (size_t)j));
+    const uint8_t *pr = b.proofs + 256 * (size_t)j, *mo = merged_xy + 128 * (size_t)j;
+    fp s = fp_to_mont<Fr>(fp_load_le(pr + 192)), sb = fp_to_mont<Fr>(fp_load_le(pr + 224));
+    uint32_t k = 5 * j;
+    emit_term<S>(scalars, pre, k, fp_from_mont<Fr>(fp_mul<Fr>(tt, c)), mo + 64);                    // (O, t c)      :388-389
+    emit_term<S>(scalars, pre, k + 1, t_plain, pr + 128);                                            // (Ok, t)       :391-392
+    emit_term<S>(scalars, pre, k + 2, fp_from_mont<Fr>(fp_neg<Fr>(fp_mul<Fr>(tt, s))), mo);         // (I, -t s)     :394-395
+    emit_term<S>(scalars, pre, k + 3, fp_from_mont<Fr>(fp_mul<Fr>(uu, c)), pr);                     // (Yb, u c)     :398-399
+    emit_term<S>(scalars, pre, k + 4, u_plain, pr + 64);                                             // (R, u)        :401-402
+    us = fp_mul<Fr>(uu, s); usb = fp_mul<Fr>(uu, sb);                                                // :405-406
+  }
+  red[threadIdx.x] = us;
+  __syncthreads();
+  for (int s2 = 64; s2 >= 1; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) red[threadIdx.x] = fp_add<Fr>(red[threadIdx.x], red[threadIdx.x + s2]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_fp(gpart + 8 * (size_t)blockIdx.x, red[0]);
+  __syncthreads();
+  red[threadIdx.x] = usb;
+  __syncthreads();
+  for (int s2 = 64; s2 >= 1; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) red[threadIdx.x] = fp_add<Fr>(red[threadIdx.x], red[threadIdx.x + s2]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) store_fp(bpart + 8 * (size_t)blockIdx.x, red[0]);
+}
+
+void launch_ped_prepare(int suite, const BatchDev &b, uint32_t *d_c, uint8_t *d_merged, uint32_t *d_flags, hipStream_t st) {
+  if (!b.n) return;
+  dim3 g((b.n + 127) / 128), blk(128);
+  if (suite == 0) hipLaunchKernelGGL(k_ped_prepare<SuiteBandersnatch>, g, blk, 0, st, b, d_c, d_merged, d_flags);
+  else hipLaunchKernelGGL(k_ped_prepare<SuiteBabyJubJub>, g, blk, 0, st, b, d_c, d_merged, d_flags);
+}
+void launch_ped_terms(int suite, const BatchDev &b, const Seed64 &seed, const uint32_t *d_c, const uint8_t *d_merged,
+                      uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st) {
+  if (!b.n) return;
+  dim3 g((b.n + 127) / 128), blk(128);
+  uint32_t *bp = d_gpart + 8 * (size_t)g.x;
+  if (suite == 0) {
+    hipLaunchKernelGGL(k_ped_terms<SuiteBandersnatch>, g, blk, 0, st, b, seed, d_c, d_merged, d_scalars, (te_pre *)d_pre, d_gpart, bp);
+    hipLaunchKernelGGL(k_g_final<SuiteBandersnatch>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 2, 0);
+    hipLaunchKernelGGL(k_g_final<SuiteBandersnatch>, dim3(1), dim3(256), 0, st, bp, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 1);
+  } else {
+    hipLaunchKernelGGL(k_ped_terms<SuiteBabyJubJub>, g, blk, 0, st, b, seed, d_c, d_merged, d_scalars, (te_pre *)d_pre, d_gpart, bp);
+    hipLaunchKernelGGL(k_g_final<SuiteBabyJubJub>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 2, 0);
+    hipLaunchKernelGGL(k_g_final<SuiteBabyJubJub>, dim3(1), dim3(256), 0, st, bp, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 1);
   }
 }
 

@@ -1,0 +1,321 @@
+// vrf_single.hip -- batches of INDEPENDENT per-item proofs / verifications, one lane per item
+// (SURVEY.md §7.1 K7): every lane runs its own Fiat-Shamir transcript and its own scalar
+// multiplications; there is no cross-lane dependency, so the kernels are pure VALU streams.
+//
+//   k_thin_prove     thin::Prover::prove      src/thin.rs:111-129
+//   k_thin_verify    thin::Verifier::verify   src/thin.rs:131-165
+//   k_ped_prove      pedersen::Prover::prove  src/pedersen.rs:136-186
+//   k_ped_verify     pedersen::Verifier::verify src/pedersen.rs:188-249
+//   k_smul           Secret::from_scalar / Secret::output  src/lib.rs:331-334,391-393
+// The merged I/O pair follows vrf_transcript_from_iter / merge_ios (src/utils/common.rs:181-202,
+// 389-419); any summation order gives the same group element.
+#include "proto_dev.h"
+
+namespace avrf {
+
+// (I_m, O_m) = sum_i z_i * (I_i, O_i) over `m` caller pairs; z stream from `dseed`.
+// first_is_one: the first caller pair takes z = 1 (Pedersen); otherwise pair i takes chunk i (Thin,
+// whose z_0 = 1 belongs to the Schnorr pair handled by the caller).
+template <class S>
+AVRF_DI void merge_pairs(const uint8_t *ios_xy, uint32_t m, const uint64_t (&dseed)[8], bool first_is_one,
+                         te_ext &im, te_ext &om) {
+  for (uint32_t i = 0; i < m; i++) {
+    te_pre pi = pre_from_xy<S>(ios_xy + 128 * (size_t)i), po = pre_from_xy<S>(ios_xy + 128 * (size_t)i + 64);
+    if (first_is_one && i == 0) { im = te_madd<S>(im, pi); om = te_madd<S>(om, po); continue; }
+    fp z = xof128(dseed, first_is_one ? i - 1 : i);
+    im = te_add<S>(im, te_smul<S>(pi, z, 128));
+    om = te_add<S>(om, te_smul<S>(po, z, 128));
+  }
+}
+template <class S> AVRF_DI te_pre g_pre() {
+  using Fq = typename S::Fq; te_pre g; g.x = fp_const<Fq>(S::G_X); g.y = fp_const<Fq>(S::G_Y); g.k = fp_const<Fq>(S::G_K); return g;
+}
+template <class S> AVRF_DI te_pre b_pre() {
+  using Fq = typename S::Fq; te_pre g; g.x = fp_const<Fq>(S::B_X); g.y = fp_const<Fq>(S::B_Y); g.k = fp_const<Fq>(S::B_K); return g;
+}
+template <class S> AVRF_DI te_pre pre_from_aff(const te_aff &a) { return te_make_pre<S>(a.x, a.y); }
+// normalise two points with one inversion
+template <class S> AVRF_DI void to_aff2(const te_ext &p, const te_ext &q, te_aff &pa, te_aff &qa) {
+  using Fq = typename S::Fq;
+  fp zz = fp_mul<Fq>(p.z, q.z), inv = fp_inv<Fq>(zz);
+  fp pi = fp_mul<Fq>(inv, q.z), qi = fp_mul<Fq>(inv, p.z);
+  pa.x = fp_mul<Fq>(p.x, pi); pa.y = fp_mul<Fq>(p.y, pi); qa.x = fp_mul<Fq>(q.x, qi); qa.y = fp_mul<Fq>(q.y, qi);
+}
+
+// ---------------------------------------------------------------- scalar multiplication
+
+// out = k * P (P = G when points_xy == nullptr)
+template <class S>
+__global__ void __launch_bounds__(128)
+k_smul(const uint8_t *__restrict__ scalars, const uint8_t *__restrict__ points_xy, uint32_t n, uint8_t *__restrict__ out_xy,
+       uint32_t *__restrict__ flags) {
+  using Fr = typename S::Fr;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  fp k = fp_load_le(scalars + 32 * (size_t)j);
+  uint32_t f = ge_p<Fr>(k) ? FLAG_SCALAR : 0;
+  te_pre p;
+  if (points_xy) {
+    fp x = fp_load_le(points_xy + 64 * (size_t)j), y = fp_load_le(points_xy + 64 * (size_t)j + 32);
+    f |= point_flags<S>(x, y) & FLAG_RANGE;
+    p = pre_from_xy<S>(points_xy + 64 * (size_t)j);
+  } else p = g_pre<S>();
+  te_aff r = te_to_aff<S>(te_smul<S>(p, k, Fr::BITS));
+  store_xy<S>(out_xy + 64 * (size_t)j, r);
+  if (f) atomicOr(flags, f);
+}
+
+// ---------------------------------------------------------------- Thin VRF
+
+template <class S>
+__global__ void __launch_bounds__(128)
+k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict__ flags) {
+  using Fr = typename S::Fr;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b.n) return;
+  uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0;
+  fp sk = fp_load_le(b.sks + 32 * (size_t)j);
+  uint32_t f = ge_p<Fr>(sk) ? FLAG_SCALAR : 0;
+  // public key: cached by Secret in the reference (src/lib.rs:331-334)
+  uint8_t pk_xy[64];
+  if (b.pks_xy) { for (int i = 0; i < 64; i++) pk_xy[i] = b.pks_xy[64 * (size_t)j + i]; }
+  else { te_aff pk = te_to_aff<S>(te_smul<S>(g_pre<S>(), sk, Fr::BITS)); store_xy<S>(pk_xy, pk); }
+  Sha512 t; uint32_t pf = 0;
+  tr_base<S>(t, DS_THIN, true, pk_xy, ios, m, b.ads + ad0, adl, &pf);          // thin.rs:112
+  f |= pf & FLAG_RANGE;
+  // merged input I_m = G + sum z_i I_i  (only the input is needed by the prover)
+  te_pre im_pre = g_pre<S>();
+  if (m) {
+    uint64_t dseed[8]; delin_seed(t, dseed);
+    te_ext im = te_from_pre<S>(g_pre<S>()), om = te_identity<S>();
+    for (uint32_t i = 0; i < m; i++) {
+      te_pre pi = pre_from_xy<S>(ios + 128 * (size_t)i);
+      im = te_add<S>(im, te_smul<S>(pi, xof128(dseed, i), 128));
+    }
+    (void)om;
+    im_pre = pre_from_aff<S>(te_to_aff<S>(im));
+  }
+  fp k = nonce<S>(sk, t);                                                       // thin.rs:115
+  te_aff r = te_to_aff<S>(te_smul<S>(im_pre, fp_from_mont<Fr>(k), Fr::BITS));   // thin.rs:119
+  Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);    // thin.rs:122
+  fp c = fp_to_mont<Fr>(challenge_finish(tc));
+  fp s = fp_add<Fr>(k, fp_mul<Fr>(c, fp_to_mont<Fr>(sk)));                      // thin.rs:125
+  store_xy<S>(proofs_out + 96 * (size_t)j, r);
+  fp_store_le(proofs_out + 96 * (size_t)j + 64, fp_from_mont<Fr>(s));
+  if (f) atomicOr(flags, f);
+}
+
+template <class S>
+__global__ void __launch_bounds__(128)
+k_thin_verify(BatchDev b, int32_t *__restrict__ status) {
+  using Fr = typename S::Fr; using Fq = typename S::Fq;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b.n) return;
+  uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pk_xy = b.pks_xy + 64 * (size_t)j, *pr = b.proofs + 96 * (size_t)j;
+  Sha512 t; uint32_t f = 0;
+  tr_base<S>(t, DS_THIN, true, pk_xy, ios, m, b.ads + ad0, adl, &f);
+  fp rx = fp_load_le(pr), ry = fp_load_le(pr + 32), s = fp_load_le(pr + 64);
+  if (point_flags<S>(rx, ry) & FLAG_RANGE) f |= FLAG_RANGE;
+  if (ge_p<Fr>(s)) f |= FLAG_SCALAR;
+  if (f) { status[j] = 2; return; }                                             // InvalidData, thin.rs:140-149
+  te_pre ip = g_pre<S>(), op = pre_from_xy<S>(pk_xy);
+  if (m) {
+    uint64_t dseed[8]; delin_seed(t, dseed);
+    te_ext im = te_from_pre<S>(ip), om = te_from_pre<S>(op);
+    merge_pairs<S>(ios, m, dseed, false, im, om);
+    te_aff ia, oa; to_aff2<S>(im, om, ia, oa);
+    ip = pre_from_aff<S>(ia); op = pre_from_aff<S>(oa);
+  }
+  Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_xy<S>(tc, rx, ry);
+  fp c = challenge_finish(tc);                                                  // plain, 128 bits
+  // s*I_m - c*O_m == R   (thin.rs:158-161)
+  te_ext lhs = te_smul2<S>(ip, s, te_pre_neg<S>(op), c, Fr::BITS);
+  te_pre rp = te_make_pre<S>(fp_to_mont<Fq>(rx), fp_to_mont<Fq>(ry));
+  status[j] = ext_eq_aff<S>(lhs, rp) ? 0 : 1;
+}
+
+// ---------------------------------------------------------------- Pedersen VRF
+
+template <class S>
+__global__ void __launch_bounds__(128)
+k_ped_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ blindings_out, uint32_t *__restrict__ flags) {
+  using Fr = typename S::Fr;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b.n) return;
+  uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0;
+  fp sk = fp_load_le(b.sks + 32 * (size_t)j);
+  uint32_t f = ge_p<Fr>(sk) ? FLAG_SCALAR : 0, pf = 0;
+  Sha512 t;
+  tr_base<S>(t, DS_PEDERSEN, false, nullptr, ios, m, b.ads + ad0, adl, &pf);   // pedersen.rs:142
+  f |= pf & FLAG_RANGE;
+  // merged input (common.rs:186-199): identity for m = 0, the pair itself for m = 1
+  te_pre ip; bool have_input = m > 0;
+  if (m == 1) ip = pre_from_xy<S>(ios);
+  else if (m > 1) {
+    uint64_t dseed[8]; delin_seed(t, dseed);
+    te_ext im = te_identity<S>(), om = te_identity<S>();
+    for (uint32_t i = 0; i < m; i++) {
+      te_pre pi = pre_from_xy<S>(ios + 128 * (size_t)i);
+      if (i == 0) im = te_madd<S>(im, pi); else im = te_add<S>(im, te_smul<S>(pi, xof128(dseed, i - 1), 128));
+    }
+    (void)om;
+    ip = pre_from_aff<S>(te_to_aff<S>(im));
+  }
+  Sha512 tb = t; sha512_byte(tb, DS_PEDERSEN_BLINDING);
+  fp bl = nonce<S>(sk, tb);                                                     // pedersen.rs:51-54,145
+  fp bl_plain = fp_from_mont<Fr>(bl);
+  te_pre pkp;
+  if (b.pks_xy) pkp = pre_from_xy<S>(b.pks_xy + 64 * (size_t)j);
+  else pkp = pre_from_aff<S>(te_to_aff<S>(te_smul<S>(g_pre<S>(), sk, Fr::BITS)));
+  te_aff yb = te_to_aff<S>(te_madd<S>(te_smul<S>(b_pre<S>(), bl_plain, Fr::BITS), pkp));   // :148-149
+  absorb_point_mont<S>(t, yb);                                                  // :152
+  fp k = nonce<S>(sk, t), kb = nonce<S>(bl_plain, t);                           // :155-156
+  fp k_plain = fp_from_mont<Fr>(k);
+  te_ext R = te_smul2<S>(g_pre<S>(), k_plain, b_pre<S>(), fp_from_mont<Fr>(kb), Fr::BITS);   // :159-161
+  te_ext OK = have_input ? te_smul<S>(ip, k_plain, Fr::BITS) : te_identity<S>();             // :164
+  te_aff ra, oka; to_aff2<S>(R, OK, ra, oka);                                   // :166-167
+  Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, ra); absorb_point_mont<S>(tc, oka);
+  fp c = fp_to_mont<Fr>(challenge_finish(tc));                                  // :170
+  fp s = fp_add<Fr>(k, fp_mul<Fr>(c, fp_to_mont<Fr>(sk)));                      // :173
+  fp sb = fp_add<Fr>(kb, fp_mul<Fr>(c, bl));                                    // :175
+  uint8_t *o = proofs_out + 256 * (size_t)j;
+  store_xy<S>(o, yb); store_xy<S>(o + 64, ra); store_xy<S>(o + 128, oka);
+  fp_store_le(o + 192, fp_from_mont<Fr>(s)); fp_store_le(o + 224, fp_from_mont<Fr>(sb));
+  if (blindings_out) fp_store_le(blindings_out + 32 * (size_t)j, bl_plain);
+  if (f) atomicOr(flags, f);
+}
+
+template <class S>
+__global__ void __launch_bounds__(128)
+k_ped_verify(BatchDev b, int32_t *__restrict__ status) {
+  using Fr = typename S::Fr; using Fq = typename S::Fq;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b.n) return;
+  uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pr = b.proofs + 256 * (size_t)j;
+  Sha512 t; uint32_t f = 0;
+  tr_base<S>(t, DS_PEDERSEN, false, nullptr, ios, m, b.ads + ad0, adl, &f);
+  fp ybx = fp_load_le(pr), yby = fp_load_le(pr + 32), rx = fp_load_le(pr + 64), ry = fp_load_le(pr + 96);
+  fp okx = fp_load_le(pr + 128), oky = fp_load_le(pr + 160), s = fp_load_le(pr + 192), sb = fp_load_le(pr + 224);
+  f |= point_flags<S>(ybx, yby);                                               // Yb == 0 rejected, pedersen.rs:204-206
+  f |= (point_flags<S>(rx, ry) | point_flags<S>(okx, oky)) & FLAG_RANGE;
+  if (ge_p<Fr>(s) || ge_p<Fr>(sb)) f |= FLAG_SCALAR;
+  if (f) { status[j] = 2; return; }
+  te_pre ip, op; bool have_io = m > 0;
+  if (m == 1) { ip = pre_from_xy<S>(ios); op = pre_from_xy<S>(ios + 64); }
+  else if (m > 1) {
+    uint64_t dseed[8]; delin_seed(t, dseed);
+    te_ext im = te_identity<S>(), om = te_identity<S>();
+    merge_pairs<S>(ios, m, dseed, true, im, om);
+    te_aff ia, oa; to_aff2<S>(im, om, ia, oa);
+    ip = pre_from_aff<S>(ia); op = pre_from_aff<S>(oa);
+  }
+  absorb_point_xy<S>(t, ybx, yby);                                             // :219
+  sha512_byte(t, DS_CHALLENGE); absorb_point_xy<S>(t, rx, ry); absorb_point_xy<S>(t, okx, oky);
+  fp c = challenge_finish(t);                                                  // :222
+  // Eq1: s*I - c*O == Ok   (:229-232)
+  te_ext lhs1 = have_io ? te_smul2<S>(ip, s, te_pre_neg<S>(op), c, Fr::BITS) : te_identity<S>();
+  te_pre okp = te_make_pre<S>(fp_to_mont<Fq>(okx), fp_to_mont<Fq>(oky));
+  if (!ext_eq_aff<S>(lhs1, okp)) { status[j] = 1; return; }
+  // Eq2: s*G + sb*B - c*Yb == R   (:238-245)
+  te_pre ybp = te_make_pre<S>(fp_to_mont<Fq>(ybx), fp_to_mont<Fq>(yby));
+  te_ext lhs2 = te_smul2<S>(g_pre<S>(), s, b_pre<S>(), sb, Fr::BITS);
+  lhs2 = te_add<S>(lhs2, te_smul<S>(te_pre_neg<S>(ybp), c, 128));
+  te_pre rp = te_make_pre<S>(fp_to_mont<Fq>(rx), fp_to_mont<Fq>(ry));
+  status[j] = ext_eq_aff<S>(lhs2, rp) ? 0 : 1;
+}
+
+
+// ---------------------------------------------------------------- point codecs
+
+// CanonicalDeserialize for TE affine points, compressed form: y = LE32 with the
+// top bit cleared, x recovered from x^2 = (1 - y^2) / (a - d y^2), sign chosen by the flag.
+// validate: additionally require the prime-order subgroup and non-identity (src/lib.rs:410-433).
+template <class S>
+__global__ void __launch_bounds__(128)
+k_decompress(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ out_xy, int validate, int32_t *__restrict__ status) {
+  using Fq = typename S::Fq; using Fr = typename S::Fr;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  fp y = fp_load_le(in + 32 * (size_t)j);
+  bool neg = (y.v[7] >> 31) != 0; y.v[7] &= 0x7fffffffu;
+  int32_t st = 0;
+  fp x = fp_zero();
+  if (ge_p<Fq>(y)) st = 2;
+  else {
+    fp ym = fp_to_mont<Fq>(y), y2 = fp_sqr<Fq>(ym), one = fp_one<Fq>();
+    fp num = fp_sub<Fq>(one, y2);
+    fp a_const = S::A_KIND == 1 ? fp_neg<Fq>(fp_add<Fq>(fp_dbl<Fq>(fp_dbl<Fq>(one)), one)) : one;
+    fp den = fp_sub<Fq>(a_const, fp_mul<Fq>(fp_const<Fq>(S::D), y2));
+    fp xm;
+    if (fp_is_zero(den) || !fp_sqrt_nf<Fq>(fp_mul<Fq>(num, fp_inv<Fq>(den)), &xm)) st = 2;
+    else {
+      if (fp_is_negative_mont<Fq>(xm) != neg) xm = fp_neg<Fq>(xm);
+      if (fp_is_zero(xm) && neg) st = 2;
+      x = fp_from_mont<Fq>(xm);
+      if (!st && validate) {
+        fp onep = fp_zero(); onep.v[0] = 1;
+        if (fp_is_zero(x) && fp_eq(y, onep)) st = 2;                       // identity
+        else {
+          te_ext rp = te_smul<S>(te_make_pre<S>(xm, ym), fp_const<Fr>(Fr::P), Fr::BITS);   // r * P == 0
+          if (!te_is_identity<S>(rp)) st = 2;
+        }
+      }
+    }
+  }
+  fp_store_le(out_xy + 64 * (size_t)j, x); fp_store_le(out_xy + 64 * (size_t)j + 32, y);
+  status[j] = st;
+}
+template <class S>
+__global__ void __launch_bounds__(256)
+k_compress(const uint8_t *__restrict__ in_xy, uint32_t n, uint8_t *__restrict__ out) {
+  using Fq = typename S::Fq;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  fp x = fp_load_le(in_xy + 64 * (size_t)j), y = fp_load_le(in_xy + 64 * (size_t)j + 32);
+  if (fp_is_negative_plain<Fq>(x)) y.v[7] |= 0x80000000u;
+  fp_store_le(out + 32 * (size_t)j, y);
+}
+
+// ---------------------------------------------------------------- launchers
+
+#define AVRF_DISPATCH(suite, KERNEL, grid, block, st, ...)                                          \
+  do {                                                                                              \
+    if ((suite) == 0) hipLaunchKernelGGL(KERNEL<SuiteBandersnatch>, grid, block, 0, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<SuiteBabyJubJub>, grid, block, 0, st, __VA_ARGS__);                \
+  } while (0)
+
+void launch_smul(int suite, const uint8_t *d_scalars, const uint8_t *d_points_xy, uint32_t n, uint8_t *d_out, uint32_t *d_flags, hipStream_t st) {
+  if (!n) return;
+  AVRF_DISPATCH(suite, k_smul, dim3((n + 127) / 128), dim3(128), st, d_scalars, d_points_xy, n, d_out, d_flags);
+}
+void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st) {
+  if (!b.n) return;
+  AVRF_DISPATCH(suite, k_thin_prove, dim3((b.n + 127) / 128), dim3(128), st, b, d_proofs_out, d_flags);
+}
+void launch_thin_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st) {
+  if (!b.n) return;
+  AVRF_DISPATCH(suite, k_thin_verify, dim3((b.n + 127) / 128), dim3(128), st, b, d_status);
+}
+void launch_ped_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st) {
+  if (!b.n) return;
+  AVRF_DISPATCH(suite, k_ped_prove, dim3((b.n + 127) / 128), dim3(128), st, b, d_proofs_out, d_blind, d_flags);
+}
+void launch_ped_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st) {
+  if (!b.n) return;
+  AVRF_DISPATCH(suite, k_ped_verify, dim3((b.n + 127) / 128), dim3(128), st, b, d_status);
+}
+
+void launch_decompress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st) {
+  if (!n) return;
+  AVRF_DISPATCH(suite, k_decompress, dim3((n + 127) / 128), dim3(128), st, d_in, n, d_out, validate, d_status);
+}
+void launch_compress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st) {
+  if (!n) return;
+  AVRF_DISPATCH(suite, k_compress, dim3((n + 255) / 256), dim3(256), st, d_in, n, d_out);
+}
+
+}  // namespace avrf

@@ -89,9 +89,10 @@ size_t avrf_batch_last_terms(avrf_ctx *ctx, uint8_t *bases_xy, uint8_t *scalars)
 void avrf_last_timing(avrf_ctx *ctx, double out[8]);
 
 /* thin::Prover::prove for a batch of independent (sk, ios, ad)  (src/thin.rs:111-129).
- * sks: n x 32; ios as above; proofs_out: n x 96 (R_xy || s). */
-int avrf_thin_prove(avrf_ctx *ctx, size_t n, const uint8_t *sks, const uint8_t *ios_xy, const uint32_t *io_counts,
-                    const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out);
+ * sks: n x 32; pks_xy: the cached `Secret::public` (n x 64) or NULL to derive sk*G on the device;
+ * ios as above; proofs_out: n x 96 (R_xy || s). */
+int avrf_thin_prove(avrf_ctx *ctx, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy,
+                    const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out);
 
 /* thin::Verifier::verify for a batch of independent items (src/thin.rs:131-165);
  * status_out[j] receives the per-item status.  Returns AVRF_OK when the call itself ran. */
@@ -106,10 +107,11 @@ int avrf_pedersen_batch_stage(avrf_ctx *ctx, size_t n, const uint8_t *ios_xy, co
                               const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs);
 int avrf_pedersen_batch_run(avrf_ctx *ctx);
 
-/* pedersen::Prover::prove (src/pedersen.rs:136-186) for a batch; proofs_out: n x 256,
- * blindings_out: n x 32 (may be NULL). */
-int avrf_pedersen_prove(avrf_ctx *ctx, size_t n, const uint8_t *sks, const uint8_t *ios_xy, const uint32_t *io_counts,
-                        const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out, uint8_t *blindings_out);
+/* pedersen::Prover::prove (src/pedersen.rs:136-186) for a batch; pks_xy as for avrf_thin_prove;
+ * proofs_out: n x 256, blindings_out: n x 32 (may be NULL). */
+int avrf_pedersen_prove(avrf_ctx *ctx, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy,
+                        const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out,
+                        uint8_t *blindings_out);
 
 /* pedersen::Verifier::verify (src/pedersen.rs:188-249) for a batch of independent items. */
 int avrf_pedersen_verify(avrf_ctx *ctx, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,

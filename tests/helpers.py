@@ -33,3 +33,42 @@ def xy(suite, comp):
     st, out = orc.point_decompress(suite, comp)
     assert st == 0
     return out
+
+
+def nat_batch(b, with_sks=False, with_proofs=True):
+    """oracle.gen_batch dict -> ark_vrf_amd Batch."""
+    from ark_vrf_amd._native import Batch
+    return Batch(b["n"], b["ios_xy"], b["io_counts"], b["ads"], b["ad_lens"], pks_xy=b["pks_xy"] or None,
+                 proofs=b["proofs"] if with_proofs else None, sks=b["sks"] if with_sks else None)
+
+
+def compressed_items(suite, b, kind):
+    """oracle.gen_batch dict -> (pks, ios, ads, proofs) in the oracle's compressed encodings."""
+    n = b["n"]
+    psz = 96 if kind == 0 else 256
+    pks = [orc.point_compress(suite, b["pks_xy"][64 * j: 64 * j + 64]) for j in range(n)] if b["pks_xy"] else []
+    ios, ads, proofs, off = [], [], [], 0
+    for j in range(n):
+        i = orc.point_compress(suite, b["ios_xy"][128 * j: 128 * j + 64])
+        o = orc.point_compress(suite, b["ios_xy"][128 * j + 64: 128 * j + 128])
+        ios.append([(i, o)])
+        ads.append(b["ads"][off: off + b["ad_lens"][j]]); off += b["ad_lens"][j]
+        pr = b["proofs"][psz * j: psz * (j + 1)]
+        if kind == 0:
+            proofs.append(orc.point_compress(suite, pr[:64]) + pr[64:])
+        else:
+            proofs.append(b"".join(orc.point_compress(suite, pr[64 * k: 64 * k + 64]) for k in range(3)) + pr[192:])
+    return pks, ios, ads, proofs
+
+
+def proof_xy(suite, comp, kind):
+    """compressed proof (64 / 160 bytes) -> ABI proof (96 / 256 bytes)."""
+    if kind == 0:
+        return xy(suite, comp[:32]) + comp[32:]
+    return b"".join(xy(suite, comp[32 * k: 32 * k + 32]) for k in range(3)) + comp[96:]
+
+
+def proof_comp(suite, p, kind):
+    if kind == 0:
+        return orc.point_compress(suite, p[:64]) + p[64:]
+    return b"".join(orc.point_compress(suite, p[64 * k: 64 * k + 64]) for k in range(3)) + p[192:]

@@ -9,7 +9,7 @@ import os
 import pytest
 
 import oracle as orc
-from helpers import IDENTITY_XY, xy
+from helpers import IDENTITY_XY, compressed_items, nat_batch, xy
 
 pytestmark = pytest.mark.gpu
 
@@ -93,14 +93,15 @@ def test_multi_io_items(ctxs, suite):
 def test_synthetic_batch_terms_and_verdict(ctxs, suite, n):
     b = orc.gen_batch(suite, 0, n)
     c = ctxs[suite]
-    assert c.thin_batch_stage_raw(n, b["pks_xy"], b["ios_xy"], b["io_counts"], b["ads"], b["ad_lens"], b["proofs"]) == 0
+    assert c.thin_batch_stage(nat_batch(b)) == 0
     assert c.thin_batch_run() == 0
-    pks, ios, ads, proofs = orc.thin_batch_verify_raw(suite, b)
+    pks, ios, ads, proofs = compressed_items(suite, b, 0)
     st, bases, sc = orc.thin_batch_terms(suite, pks, ios, ads, proofs)
     gb, gs = c.last_terms()
     assert st == 0 and gs == sc and gb == bases
     # one tampered response scalar anywhere in the batch flips the verdict
     j = n // 2
     pr = bytearray(b["proofs"]); pr[96 * j + 64] ^= 1
-    assert c.thin_batch_stage_raw(n, b["pks_xy"], b["ios_xy"], b["io_counts"], b["ads"], b["ad_lens"], bytes(pr)) == 0
+    b2 = dict(b); b2["proofs"] = bytes(pr)
+    assert c.thin_batch_stage(nat_batch(b2)) == 0
     assert c.thin_batch_run() == 1

@@ -1,0 +1,113 @@
+"""GPU parity for Thin VRF prove / single verify and the key / codec helpers (SURVEY.md §8a rows
+a3, a4, a14): proofs byte-exact with the reference's vectors and with the oracle
+(src/thin.rs:111-165, src/lib.rs:331-334,391-393; ark-serialize point codec)."""
+import json
+import os
+import random
+
+import pytest
+
+import oracle as orc
+from helpers import IDENTITY_XY, R_ORDER, nat_batch, proof_comp, rand_scalar, xy
+
+pytestmark = pytest.mark.gpu
+NAMES = {0: "bandersnatch_sha-512_ell2", 1: "baby-jubjub_sha-512_tai"}
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    from ark_vrf_amd import _native as nat
+    return {s: nat.Context(s) for s in (0, 1)}
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_reference_vectors(ctxs, golden_dir, suite):
+    from ark_vrf_amd._native import Batch
+    with open(os.path.join(golden_dir, NAMES[suite] + "_thin.json")) as f:
+        vs = json.load(f)
+    c = ctxs[suite]
+    sks = [bytes.fromhex(v["sk"]) for v in vs]
+    # pk = sk*G, gamma = sk*h  (src/testing.rs:266-275)
+    pks = c.scalar_mul_base(b"".join(sks))
+    hs = [xy(suite, bytes.fromhex(v["h"])) for v in vs]
+    gam = c.scalar_mul(b"".join(sks), b"".join(hs))
+    assert c.points_compress(pks).hex() == "".join(v["pk"] for v in vs)
+    assert c.points_compress(gam).hex() == "".join(v["gamma"] for v in vs)
+    ios = [[(hs[j], gam[64 * j: 64 * j + 64])] for j in range(len(vs))]
+    ads = [bytes.fromhex(v["ad"]) for v in vs]
+    proofs = c.thin_prove(Batch.from_items(ios, ads, sks=sks))            # pk derived on the device
+    pl = [proofs[96 * j: 96 * j + 96] for j in range(len(vs))]
+    for j, v in enumerate(vs):
+        assert proof_comp(suite, pl[j], 0).hex() == v["proof_r"] + v["proof_s"]     # src/thin.rs:635-648
+    pkl = [pks[64 * j: 64 * j + 64] for j in range(len(vs))]
+    assert c.thin_prove(Batch.from_items(ios, ads, sks=sks, pks_xy=pkl)) == proofs
+    assert c.thin_verify(Batch.from_items(ios, ads, pks_xy=pkl, proofs=pl)) == [0] * len(vs)
+    bad = [bytearray(p) for p in pl]
+    bad[0][70] ^= 1; bad[2][:64] = pl[3][:64]
+    st = c.thin_verify(Batch.from_items(ios, ads[:4] + [b"q"] + ads[5:], pks_xy=[IDENTITY_XY] + pkl[1:-1] + [pkl[0]],
+                                        proofs=[bytes(x) for x in bad]))
+    assert st == [2, 0, 1, 0, 1, 0, 1]     # identity pk -> InvalidData (src/thin.rs:140-142); wrong R / ad / pk -> failure
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_multi_io(ctxs, suite):
+    """prove_verify_multi / _multi_empty / _multi_single (src/thin.rs:390-470)."""
+    from ark_vrf_amd._native import Batch
+    c = ctxs[suite]
+    sks, pks, ios_c, ads = [], [], [], []
+    for j, m in enumerate([0, 1, 2, 3, 5]):
+        sk, pk = orc.from_seed(suite, bytes([j + 40]) + bytes(31))
+        io = []
+        for i in range(m):
+            h = orc.hash_to_curve(suite, b"t-%d-%d" % (j, i))
+            io.append((h, orc.vrf_output(suite, sk, h)))
+        sks.append(sk); pks.append(pk); ios_c.append(io); ads.append(b"ad" * j)
+    want = [orc.thin_prove(suite, sk, io, ad) for sk, io, ad in zip(sks, ios_c, ads)]
+    ios = [[(xy(suite, i), xy(suite, o)) for i, o in io] for io in ios_c]
+    proofs = c.thin_prove(Batch.from_items(ios, ads, sks=sks))
+    pl = [proofs[96 * j: 96 * j + 96] for j in range(len(sks))]
+    assert [proof_comp(suite, p, 0) for p in pl] == want
+    pkl = [xy(suite, p) for p in pks]
+    assert c.thin_verify(Batch.from_items(ios, ads, pks_xy=pkl, proofs=pl)) == [0] * len(sks)
+    # tamper an output of the 3-pair item, and an input of the 5-pair item
+    ios[3][1] = (ios[3][1][0], ios[3][0][1]); ios[4][4] = (ios[4][3][0], ios[4][4][1])
+    assert c.thin_verify(Batch.from_items(ios, ads, pks_xy=pkl, proofs=pl)) == [0, 0, 0, 1, 1]
+
+
+@pytest.mark.parametrize("suite,n", [(0, 600), (1, 200)])
+def test_synthetic(ctxs, suite, n):
+    b = orc.gen_batch(suite, 0, n)
+    c = ctxs[suite]
+    assert c.thin_prove(nat_batch(b, with_sks=True, with_proofs=False)) == b["proofs"]
+    assert c.scalar_mul_base(b["sks"]) == b["pks_xy"]
+    assert c.thin_verify(nat_batch(b)) == [0] * n
+    p2 = bytearray(b["proofs"]); p2[96 * 7 + 65] ^= 1
+    b2 = dict(b); b2["proofs"] = bytes(p2)
+    st = c.thin_verify(nat_batch(b2))
+    assert st[7] == 1 and sum(st) == 1
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_point_codec(ctxs, suite):
+    c = ctxs[suite]
+    rng = random.Random(5 + suite)
+    g = orc.suite_point(suite, 0)
+    comps = [orc.smul(suite, rand_scalar(rng, suite), g) for _ in range(50)] + [bytes([1]) + bytes(31)]
+    xys, st = c.points_decompress(b"".join(comps))
+    assert st == [0] * len(comps)
+    for j, cp in enumerate(comps):
+        assert xys[64 * j: 64 * j + 64] == orc.point_decompress(suite, cp)[1]
+    assert c.points_compress(xys) == b"".join(comps)
+    # validate: identity rejected, subgroup points accepted
+    _, st = c.points_decompress(b"".join(comps), validate=True)
+    assert st == [0] * 50 + [2]
+    # garbage: agree with the oracle's decoder on accept / reject, and on the subgroup check
+    junk = [bytes(rng.getrandbits(8) for _ in range(32)) for _ in range(64)]
+    xs, st = c.points_decompress(b"".join(junk))
+    xs2, st2 = c.points_decompress(b"".join(junk), validate=True)
+    for j, cp in enumerate(junk):
+        o_st, o_xy = orc.point_decompress(suite, cp)
+        assert st[j] == o_st
+        if o_st == 0:
+            assert xs[64 * j: 64 * j + 64] == o_xy
+        assert st2[j] == orc.point_decompress(suite, cp, validate=True)[0]
