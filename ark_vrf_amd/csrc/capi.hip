@@ -287,6 +287,15 @@ void avrf_last_timing(avrf_ctx *c, double out[8]) {
   for (int i = 0; i < 8; i++) out[i] = c->timing[i];
 }
 
+int avrf_kernel_stats(avrf_ctx *c, int reset, double *accum_ms_total, uint64_t *accum_launches, int32_t plan[4]) {
+  if (!c) return AVRF_ERR_BAD_ARG;
+  if (accum_ms_total) *accum_ms_total = c->ws.accum_ms_total;
+  if (accum_launches) *accum_launches = c->ws.accum_launches;
+  if (plan) { plan[0] = c->ws.last_plan.c; plan[1] = c->ws.last_plan.nwin; plan[2] = c->ws.last_plan.nb; plan[3] = c->ws.last_plan.lpb; }
+  if (reset) { c->ws.accum_ms_total = 0; c->ws.accum_launches = 0; }
+  return AVRF_OK;
+}
+
 // ---------------------------------------------------------------- independent per-item calls
 
 static int read_flags(avrf_ctx *c) {

@@ -16,7 +16,7 @@ struct MsmPlan {
   int c;         // window bits
   int nwin;      // number of windows: nwin * c >= scalar bits + 1
   int nb;        // buckets per window = 2^(c-1) (signed digits)
-  int lpb;       // lanes cooperating on one bucket
+  int lpb;       // SEG: entries of one bucket handled by one lane
 };
 MsmPlan msm_plan(size_t n, int scalar_bits);
 
@@ -24,12 +24,18 @@ MsmPlan msm_plan(size_t n, int scalar_bits);
 struct MsmWorkspace {
   uint32_t *keys = nullptr;      // nwin * n
   uint32_t *counts = nullptr;    // nwin * nb   (histogram, then reused as cursors)
-  uint32_t *offsets = nullptr;   // nwin * nb + 1
+  uint32_t *offsets = nullptr;   // nwin * nb + 1  (entry offsets)
+  uint32_t *lane_off = nullptr;  // nwin * nb + 1  (lane offsets: ceil(count / seg) lanes per bucket)
   uint32_t *sorted = nullptr;    // nwin * n
   te_ext_raw *buckets = nullptr; // nwin * nb
+  te_ext_raw *part = nullptr;    // 2 per wave of k_accumulate: partial sums of runs that cross a wave boundary
   te_ext_raw *bits = nullptr;    // nwin * c
   te_ext_raw *bits_host = nullptr; // pinned
-  size_t cap_n = 0, cap_buckets = 0, cap_bits = 0;
+  size_t cap_n = 0, cap_buckets = 0, cap_bits = 0, cap_part = 0;
+  // HIP events bracketing the dominant kernel (k_accumulate) on the launch stream
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double accum_ms_total = 0; uint64_t accum_launches = 0; float accum_ms_last = 0;
+  MsmPlan last_plan = {0, 0, 0, 0};
   void ensure(size_t n, const MsmPlan &p);
   void release();
 };

@@ -88,6 +88,11 @@ size_t avrf_batch_last_terms(avrf_ctx *ctx, uint8_t *bases_xy, uint8_t *scalars)
  * [0] total, [1] device prepare (hash), [2] host weight transcript, [3] scalars, [4] msm, [5] finish */
 void avrf_last_timing(avrf_ctx *ctx, double out[8]);
 
+/* Device-side timing of the dominant kernel (MSM bucket accumulation), measured with HIP events
+ * recorded on the context's stream around every launch since the last reset: total milliseconds,
+ * number of launches, and the plan of the last MSM {window bits c, windows, buckets/window, lanes/bucket}. */
+int avrf_kernel_stats(avrf_ctx *ctx, int reset, double *accum_ms_total, uint64_t *accum_launches, int32_t plan[4]);
+
 /* thin::Prover::prove for a batch of independent (sk, ios, ad)  (src/thin.rs:111-129).
  * sks: n x 32; pks_xy: the cached `Secret::public` (n x 64) or NULL to derive sk*G on the device;
  * ios as above; proofs_out: n x 96 (R_xy || s). */

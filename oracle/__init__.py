@@ -236,3 +236,14 @@ def thin_batch_verify_raw(suite, b):
         pr = b["proofs"][96 * j: 96 * j + 96]
         proofs.append(point_compress(suite, pr[:64]) + pr[64:])
     return pks, ios, ads, proofs
+
+
+def thin_batch_verify_xy(suite, b):
+    """thin::BatchVerifier on a gen_batch-style dict in the C-ABI (xy) layout; returns the status."""
+    return lib().orc_thin_batch_verify_xy(suite, C.c_size_t(b["n"]), _u8(b["pks_xy"]), _u8(b["ios_xy"]), _u32(b["io_counts"]),
+                                          _u8(b["ads"]), _u32(b["ad_lens"]), _u8(b["proofs"]))
+
+
+def pedersen_batch_verify_xy(suite, b):
+    return lib().orc_pedersen_batch_verify_xy(suite, C.c_size_t(b["n"]), _u8(b["ios_xy"]), _u32(b["io_counts"]),
+                                              _u8(b["ads"]), _u32(b["ad_lens"]), _u8(b["proofs"]))

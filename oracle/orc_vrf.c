@@ -92,9 +92,16 @@ static void transcript_merged(transcript_t *t, vrf_io *merged, uint8_t scheme, c
     merged->in = norm[0]; merged->out = norm[1];
 }
 
+/* Point wire format of the batch entry points: compressed 32-byte (default) or, for the *_xy
+ * wrappers at the end of this file, the C-ABI's 64-byte LE32(x)||LE32(y) -- what a caller of the
+ * reference holds AFTER deserialisation (the reference's BatchVerifier takes typed points, so
+ * decompression is outside `prepare`/`verify`; benches/thin.rs:46-90). */
+static __thread int g_xy = 0;
+#define PSZ ((size_t)(g_xy ? 64 : 32))
+static int pt_dec(te_aff *o, const uint8_t *b, const suite_t *s) { return g_xy ? te_decode_xy(o, b, s) : te_decode(o, b, s); }
 static int decode_ios(vrf_io *o, const uint8_t *b, size_t n, const suite_t *s) {
     for (size_t i = 0; i < n; i++) {
-        if (te_decode(&o[i].in, b + 64 * i, s) || te_decode(&o[i].out, b + 64 * i + 32, s)) return ORC_INVALID_DATA;
+        if (pt_dec(&o[i].in, b + 2 * PSZ * i, s) || pt_dec(&o[i].out, b + 2 * PSZ * i + PSZ, s)) return ORC_INVALID_DATA;
     }
     return ORC_OK;
 }
@@ -315,8 +322,8 @@ int orc_thin_batch_terms(int suite, size_t n, const uint8_t *pks, const uint8_t 
     int st = ORC_OK;
     /* decode everything first (the reference's typed API has done so before push) */
     for (size_t j = 0; j < n && !st; j++)
-        if (te_decode(&pk[j], pks + 32 * j, s) || te_decode(&R[j], proofs + 64 * j, s) ||
-            decode_scalar(&sv[j], proofs + 64 * j + 32, s)) st = ORC_INVALID_DATA;
+        if (pt_dec(&pk[j], pks + PSZ * j, s) || pt_dec(&R[j], proofs + (PSZ + 32) * j, s) ||
+            decode_scalar(&sv[j], proofs + (PSZ + 32) * j + PSZ, s)) st = ORC_INVALID_DATA;
     if (!st && decode_ios(ios, ios_b, tot_io, s)) st = ORC_INVALID_DATA;
     if (!st) {
         /* prepare: thin.rs:209-226 */
@@ -409,9 +416,9 @@ int orc_pedersen_prove(int suite, const uint8_t sk_b[32], const uint8_t *ios_b, 
 }
 
 typedef struct { te_aff yb, r, ok; u256 s, sb; } ped_proof;
-static int decode_ped(ped_proof *p, const uint8_t b[160], const suite_t *s) {
-    if (te_decode(&p->yb, b, s) || te_decode(&p->r, b + 32, s) || te_decode(&p->ok, b + 64, s) ||
-        decode_scalar(&p->s, b + 96, s) || decode_scalar(&p->sb, b + 128, s)) return ORC_INVALID_DATA;
+static int decode_ped(ped_proof *p, const uint8_t *b, const suite_t *s) {
+    if (pt_dec(&p->yb, b, s) || pt_dec(&p->r, b + PSZ, s) || pt_dec(&p->ok, b + 2 * PSZ, s) ||
+        decode_scalar(&p->s, b + 3 * PSZ, s) || decode_scalar(&p->sb, b + 3 * PSZ + 32, s)) return ORC_INVALID_DATA;
     return ORC_OK;
 }
 
@@ -450,7 +457,7 @@ int orc_pedersen_batch_terms(int suite, size_t n, const uint8_t *ios_b, const ui
     vrf_io *ios = (vrf_io *)malloc((tot_io + 1) * sizeof(vrf_io)), *merged = (vrf_io *)malloc(n * sizeof(vrf_io));
     u256 *c = (u256 *)malloc(n * sizeof(u256));
     int st = ORC_OK, any_io_identity = 0;
-    for (size_t j = 0; j < n && !st; j++) if (decode_ped(&pp[j], proofs + 160 * j, s)) st = ORC_INVALID_DATA;
+    for (size_t j = 0; j < n && !st; j++) if (decode_ped(&pp[j], proofs + (3 * PSZ + 64) * j, s)) st = ORC_INVALID_DATA;
     if (!st && decode_ios(ios, ios_b, tot_io, s)) st = ORC_INVALID_DATA;
     if (!st) {
         size_t io_off = 0, ad_off = 0;
@@ -507,6 +514,17 @@ int orc_pedersen_batch_verify(int suite, size_t n, const uint8_t *ios_b, const u
         st = te_is_identity_aff(&r, s) ? ORC_OK : ORC_VERIFICATION_FAILURE;
     }
     free(bases); free(sc); return st;
+}
+
+/* Same verifiers on the C-ABI layouts of include/avrf.h (points as 64-byte xy): used as the
+ * CPU baseline in bench.py, where -- as in benches/thin.rs:46-90 -- deserialisation is not timed. */
+int orc_thin_batch_verify_xy(int suite, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
+                             const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
+    g_xy = 1; int st = orc_thin_batch_verify(suite, n, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs); g_xy = 0; return st;
+}
+int orc_pedersen_batch_verify_xy(int suite, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,
+                                 const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
+    g_xy = 1; int st = orc_pedersen_batch_verify(suite, n, ios_xy, io_counts, ads, ad_lens, proofs); g_xy = 0; return st;
 }
 
 /* ------------------------------------------------------------------ raw MSM / codec helpers */
