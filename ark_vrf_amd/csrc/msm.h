@@ -22,16 +22,19 @@ MsmPlan msm_plan(size_t n, int scalar_bits);
 
 // Device workspace owned by a context; grows on demand, never shrinks.
 struct MsmWorkspace {
-  uint32_t *keys = nullptr;      // nwin * n
-  uint32_t *counts = nullptr;    // nwin * nb   (histogram, then reused as cursors)
-  uint32_t *offsets = nullptr;   // nwin * nb + 1  (entry offsets)
-  uint32_t *lane_off = nullptr;  // nwin * nb + 1  (lane offsets: ceil(count / seg) lanes per bucket)
-  uint32_t *sorted = nullptr;    // nwin * n
+  uint16_t *keys = nullptr;      // nwin * n      bucket | sign << 15
+  uint32_t *sorted = nullptr;    // nwin * n      term index | sign << 31, grouped by (window, bucket)
+  uint32_t *hist = nullptr;      // nwin * ntiles * nb   per-tile histograms -> per-tile prefixes
+  uint32_t *cnts = nullptr;      // nwin * nb     entries per bucket
+  uint32_t *offsets = nullptr;   // nwin * nb     first entry of the bucket in sorted[]
+  uint32_t *lane_off = nullptr;  // nwin * nb     first lane of the bucket (local to its window)
+  uint32_t *lane_tot = nullptr;  // nwin          lanes used per window
   te_ext_raw *buckets = nullptr; // nwin * nb
+  te_ext_raw *rc = nullptr;      // nwin * (rows + cols) partial sums of the bucket reduction
   te_ext_raw *part = nullptr;    // 2 per wave of k_accumulate: partial sums of runs that cross a wave boundary
   te_ext_raw *bits = nullptr;    // nwin * c
   te_ext_raw *bits_host = nullptr; // pinned
-  size_t cap_n = 0, cap_buckets = 0, cap_bits = 0, cap_part = 0;
+  size_t cap_n = 0, cap_buckets = 0, cap_bits = 0, cap_part = 0, cap_hist = 0;
   // HIP events bracketing the dominant kernel (k_accumulate) on the launch stream
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double accum_ms_total = 0; uint64_t accum_launches = 0; float accum_ms_last = 0;

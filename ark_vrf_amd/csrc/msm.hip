@@ -5,19 +5,22 @@
 // Any correct MSM yields the same group element; parity is on the normalised result
 // (SURVEY.md A.9), so the decomposition below is designed for the GPU, not copied:
 //
-//   k_digits     one lane per scalar: signed c-bit digits for every window, key = bucket|sign,
-//                global histogram per (window, bucket)
-//   k_scan       one workgroup: exclusive prefix of the histogram (entry offsets) and of the
-//                per-bucket LANE counts  lanes_b = ceil(count_b / SEG)
-//   k_scatter    counting-sort scatter of term indices into bucket order
+//   k_digits     one lane per scalar: signed c-bit digits of every window -> 16-bit keys
+//                (bucket | sign<<15), window-major, coalesced
+//   k_hist       workgroup (tile, window): LDS histogram of its tile of keys -> H[w][tile][b]
+//   k_scan_win   workgroup per window: per-bucket prefix over tiles (in place), exclusive scan of
+//                the bucket totals (entry offsets) and of lanes_b = ceil(count_b / SEG)
+//   k_scatter    workgroup (tile, window): LDS cursors seeded from the scanned histogram; every
+//                key gets its slot with an LDS atomic -- no global atomics anywhere in the sort
 //   k_accumulate load-balanced: every lane owns <= SEG consecutive entries of ONE bucket (big
 //                buckets simply get more lanes), does its mixed additions (8M each) on gathered
 //                96-byte precomputed points, then a wave-level SEGMENTED shuffle reduction
 //                folds the lanes of a bucket; runs that cross a wave boundary leave a partial
 //   k_fixup      per bucket: identity for empty buckets, sum of wave partials for split ones
-//   k_bits       bucket reduction without a serial running sum:  sum_b b*B_b =
-//                sum_k 2^k * (sum of buckets whose index has bit k set); one workgroup per
-//                (window, bit) tree-reduces its half of the buckets through LDS
+//   k_rowcol     bucket index b = hi * 2^h + lo: one wave per row sum R_hi and per column sum C_lo
+//   k_bits       one wave per (window, bit k):  T_k = sum of the buckets whose index has bit k set
+//                = sum of C_lo (lo has bit k) or of R_hi (hi has bit k-h);  sum_b b*B_b = sum_k 2^k T_k
+//                (no serial running sum; 2 adds per bucket instead of c/2)
 //   host         Horner over the nwin*c bit sums (<= 2*260 point ops)
 //
 // Layout in HBM: points AoS te_pre (x|y|k, 96 B, gathered whole by one lane with 6 dwordx4
@@ -56,11 +59,11 @@ void launch_pre_from_affine(int suite, const uint8_t *d_xy, size_t n, te_pre_raw
   else hipLaunchKernelGGL(k_pre_from_affine<SuiteBabyJubJub>, g, b, 0, stream, d_xy, (uint32_t)n, (te_pre *)d_pre, d_flag, check_curve);
 }
 
-// ---------------------------------------------------------------- digits + histogram
+// ---------------------------------------------------------------- digits
 
-// signed digit of window w with carry chain; digits in [-(2^(c-1)-1), 2^(c-1)]
-__global__ void k_digits(const uint32_t *__restrict__ scalars, uint32_t n, int c, int nwin,
-                         uint32_t *__restrict__ keys, uint32_t *__restrict__ counts) {
+// signed digit of window w with carry chain; digits in [-(2^(c-1)-1), 2^(c-1)];
+// key = bucket (1..2^(c-1), 0 = skip) | sign << 15
+__global__ void k_digits(const uint32_t *__restrict__ scalars, uint32_t n, int c, int nwin, uint16_t *__restrict__ keys) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t s[9];
@@ -78,51 +81,83 @@ __global__ void k_digits(const uint32_t *__restrict__ scalars, uint32_t n, int c
       v = (uint32_t)(two >> sh) & mask;
     }
     v += carry;
-    uint32_t key = 0;
-    if (v > nb) { key = ((1u << c) - v) | 0x80000000u; carry = 1; }   // negative digit: bucket 2^c - v
+    uint32_t key;
+    if (v > nb) { key = ((1u << c) - v) | 0x8000u; carry = 1; }   // negative digit: bucket 2^c - v
     else { key = v; carry = 0; }
-    keys[(size_t)w * n + i] = key;
-    uint32_t bucket = key & 0x7fffffffu;
-    if (bucket) atomicAdd(&counts[(size_t)w * nb + bucket - 1], 1u);
+    keys[(size_t)w * n + i] = (uint16_t)key;
   }
 }
 
-// One workgroup of 1024 lanes: exclusive scans of counts[] (entry offsets) and of the per-bucket lane
-// counts ceil(count / seg) (lane offsets); both arrays get total + 1 entries.
-__global__ void k_scan(const uint32_t *__restrict__ counts, uint32_t total, uint32_t seg,
-                       uint32_t *__restrict__ offsets, uint32_t *__restrict__ lane_off) {
+// ---------------------------------------------------------------- counting sort (LDS only)
+
+// H[(w * ntiles + tile) * nb + (bucket-1)] = number of keys of `tile` in that bucket
+__global__ void __launch_bounds__(256)
+k_hist(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int c, uint32_t *__restrict__ H) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t nb = 1u << (c - 1), tile = blockIdx.x, w = blockIdx.y, ntiles = gridDim.x;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lds[b] = 0;
+  __syncthreads();
+  uint32_t lo = tile * tile_len, hi = lo + tile_len; if (hi > n) hi = n;
+  const uint16_t *kw = keys + (size_t)w * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    uint32_t b = kw[i] & 0x7fffu;
+    if (b) atomicAdd(&lds[b - 1], 1u);
+  }
+  __syncthreads();
+  uint32_t *out = H + ((size_t)w * ntiles + tile) * nb;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) out[b] = lds[b];
+}
+
+// One workgroup (1024 lanes) per window.  In place: H[w][tile][b] becomes the exclusive prefix over
+// tiles; offs/cnts/lane_off per slot (= w*nb + b-1): entry offset (global, w*n based), entry count,
+// lane offset (local to the window); lane_tot[w] = lanes used by the window.
+__global__ void __launch_bounds__(1024)
+k_scan_win(uint32_t *__restrict__ H, uint32_t n, uint32_t ntiles, int c, uint32_t seg,
+           uint32_t *__restrict__ offs, uint32_t *__restrict__ cnts, uint32_t *__restrict__ lane_off,
+           uint32_t *__restrict__ lane_tot) {
   __shared__ uint32_t part[1024], partl[1024];
-  uint32_t t = threadIdx.x;
-  uint32_t per = (total + 1023) / 1024;
-  uint32_t lo = t * per, hi = lo + per; if (hi > total) hi = total; if (lo > total) lo = total;
+  const uint32_t nb = 1u << (c - 1), w = blockIdx.x, t = threadIdx.x;
+  uint32_t *Hw = H + (size_t)w * ntiles * nb;
+  const uint32_t per = (nb + 1023) / 1024;
+  uint32_t b0 = t * per, b1 = b0 + per; if (b1 > nb) b1 = nb; if (b0 > nb) b0 = nb;
   uint32_t sum = 0, suml = 0;
-  for (uint32_t i = lo; i < hi; i++) { uint32_t c = counts[i]; sum += c; suml += (c + seg - 1) / seg; }
+  for (uint32_t b = b0; b < b1; b++) {
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < ntiles; k++) { uint32_t v = Hw[(size_t)k * nb + b]; Hw[(size_t)k * nb + b] = run; run += v; }
+    cnts[(size_t)w * nb + b] = run;
+    sum += run; suml += (run + seg - 1) / seg;
+  }
   part[t] = sum; partl[t] = suml;
   __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
     uint32_t v = (t >= off) ? part[t - off] : 0, vl = (t >= off) ? partl[t - off] : 0;
     __syncthreads();
     part[t] += v; partl[t] += vl;
     __syncthreads();
   }
-  uint32_t run = part[t] - sum, runl = partl[t] - suml;
-  for (uint32_t i = lo; i < hi; i++) { uint32_t c = counts[i]; offsets[i] = run; lane_off[i] = runl; run += c; runl += (c + seg - 1) / seg; }
-  if (t == 1023) { offsets[total] = part[1023]; lane_off[total] = partl[1023]; }
+  uint32_t run = part[t] - sum + w * n, runl = partl[t] - suml;
+  for (uint32_t b = b0; b < b1; b++) {
+    uint32_t cnt = cnts[(size_t)w * nb + b];
+    offs[(size_t)w * nb + b] = run; lane_off[(size_t)w * nb + b] = runl;
+    run += cnt; runl += (cnt + seg - 1) / seg;
+  }
+  if (t == 1023) lane_tot[w] = partl[1023];
 }
 
-__global__ void k_scatter(const uint32_t *__restrict__ keys, uint32_t n, int c, int nwin,
-                          const uint32_t *__restrict__ offsets, uint32_t *__restrict__ cursors,
-                          uint32_t *__restrict__ sorted) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  int w = blockIdx.y;
-  if (i >= n) return;
-  const uint32_t nb = 1u << (c - 1);
-  uint32_t key = keys[(size_t)w * n + i];
-  uint32_t bucket = key & 0x7fffffffu;
-  if (!bucket) return;
-  size_t slot = (size_t)w * nb + bucket - 1;
-  uint32_t pos = offsets[slot] + atomicAdd(&cursors[slot], 1u);
-  sorted[pos] = i | (key & 0x80000000u);
+__global__ void __launch_bounds__(256)
+k_scatter(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int c, const uint32_t *__restrict__ H,
+          const uint32_t *__restrict__ offs, uint32_t *__restrict__ sorted) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t nb = 1u << (c - 1), tile = blockIdx.x, w = blockIdx.y, ntiles = gridDim.x;
+  const uint32_t *Hin = H + ((size_t)w * ntiles + tile) * nb;
+  for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lds[b] = offs[(size_t)w * nb + b] + Hin[b];
+  __syncthreads();
+  uint32_t lo = tile * tile_len, hi = lo + tile_len; if (hi > n) hi = n;
+  const uint16_t *kw = keys + (size_t)w * n;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    uint32_t key = kw[i], b = key & 0x7fffu;
+    if (b) { uint32_t pos = atomicAdd(&lds[b - 1], 1u); sorted[pos] = i | ((key & 0x8000u) << 16); }
+  }
 }
 
 // ---------------------------------------------------------------- bucket accumulation
@@ -137,27 +172,31 @@ AVRF_DI te_ext shfl_down_ext(const te_ext &p, int delta) {
   return r;
 }
 
-// Lane t owns a segment of bucket `slot` (the slot with lane_off[slot] <= t < lane_off[slot+1]).
-// part[2*wave + k]: partial of the run of wave `wave` that includes lane 0 (k = 0) or that starts
-// later and runs past lane 63 (k = 1); complete runs are written straight to buckets[].
+// Lane t = w * lcap + lt owns a segment of the bucket `slot` of window w with
+// lane_off[slot] <= lt < lane_off[slot] + lanes(slot).  part[2*wave + k]: partial of the run of wave
+// `wave` that includes lane 0 (k = 0) or that starts later and runs past lane 63 (k = 1); complete
+// runs are written straight to buckets[].  lcap is a multiple of 64 (a wave never spans two windows).
 template <class S>
 __global__ void __launch_bounds__(256)
 k_accumulate(const te_pre *__restrict__ pre, const uint32_t *__restrict__ sorted,
-             const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ lane_off,
-             uint32_t nslots, te_ext *__restrict__ buckets, te_ext *__restrict__ part) {
+             const uint32_t *__restrict__ offs, const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off,
+             const uint32_t *__restrict__ lane_tot, uint32_t nwin, uint32_t nb, uint32_t lcap, uint32_t seg,
+             te_ext *__restrict__ buckets, te_ext *__restrict__ part) {
   using Fq = typename S::Fq;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63, wave = t >> 6;
-  const uint32_t total_lanes = lane_off[nslots];
-  const bool live = t < total_lanes;
+  const uint32_t w = t / lcap, lt = t - w * lcap;
+  const bool live = w < nwin && lt < lane_tot[w];
   uint32_t slot = 0xffffffffu, l0 = 0, nl = 0;
   te_ext acc = te_identity<S>();
   if (live) {
-    uint32_t lo = 0, hi = nslots;                       // last slot with lane_off[slot] <= t
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (lane_off[mid] <= t) lo = mid; else hi = mid; }
-    slot = lo; l0 = lane_off[slot]; nl = lane_off[slot + 1] - l0;
-    const uint32_t e0 = offsets[slot], cnt = offsets[slot + 1] - e0;
-    const uint32_t per = (cnt + nl - 1) / nl, r = t - l0;
+    const uint32_t *lo_w = lane_off + (size_t)w * nb;
+    uint32_t lo = 0, hi = nb;                           // last bucket with lane_off <= lt
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (lo_w[mid] <= lt) lo = mid; else hi = mid; }
+    slot = w * nb + lo;
+    const uint32_t e0 = offs[slot], cnt = cnts[slot];
+    l0 = lo_w[lo]; nl = (cnt + seg - 1) / seg;
+    const uint32_t per = (cnt + nl - 1) / nl, r = lt - l0;
     uint32_t b = e0 + r * per, e = b + per; if (e > e0 + cnt) e = e0 + cnt;
     for (uint32_t i = b; i < e; i++) {
       uint32_t idx = sorted[i];
@@ -177,7 +216,8 @@ k_accumulate(const te_pre *__restrict__ pre, const uint32_t *__restrict__ sorted
   uint32_t pslot = __shfl_up(slot, 1);
   bool head = live && (lane == 0 || pslot != slot);
   if (head) {
-    bool complete = (l0 >= (wave << 6)) && (l0 + nl <= (wave << 6) + 64);
+    uint32_t g0 = w * lcap + l0, wbase = wave << 6;
+    bool complete = (g0 >= wbase) && (g0 + nl <= wbase + 64);
     if (complete) store_ext(buckets + slot, acc);
     else store_ext(part + 2 * (size_t)wave + (lane == 0 ? 0 : 1), acc);
   }
@@ -185,46 +225,65 @@ k_accumulate(const te_pre *__restrict__ pre, const uint32_t *__restrict__ sorted
 
 template <class S>
 __global__ void __launch_bounds__(256)
-k_fixup(const uint32_t *__restrict__ lane_off, uint32_t nslots, const te_ext *__restrict__ part, te_ext *__restrict__ buckets) {
+k_fixup(const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off, uint32_t nslots, uint32_t nb,
+        uint32_t lcap, uint32_t seg, const te_ext *__restrict__ part, te_ext *__restrict__ buckets) {
   uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= nslots) return;
-  uint32_t l0 = lane_off[slot], nl = lane_off[slot + 1] - l0;
+  uint32_t cnt = cnts[slot], nl = (cnt + seg - 1) / seg;
   if (nl == 0) { store_ext(buckets + slot, te_identity<S>()); return; }
-  uint32_t wa = l0 >> 6, wb = (l0 + nl - 1) >> 6;
+  uint32_t g0 = (slot / nb) * lcap + lane_off[slot];
+  uint32_t wa = g0 >> 6, wb = (g0 + nl - 1) >> 6;
   if (wa == wb) return;                                  // complete inside one wave: already written
-  te_ext acc = load_ext(part + 2 * (size_t)wa + ((l0 & 63) == 0 ? 0 : 1));
-  for (uint32_t w = wa + 1; w <= wb; w++) acc = te_add<S>(acc, load_ext(part + 2 * (size_t)w));
+  te_ext acc = load_ext(part + 2 * (size_t)wa + ((g0 & 63) == 0 ? 0 : 1));
+  for (uint32_t wv = wa + 1; wv <= wb; wv++) acc = te_add<S>(acc, load_ext(part + 2 * (size_t)wv));
   store_ext(buckets + slot, acc);
 }
 
 // ---------------------------------------------------------------- bucket reduction by index bits
 
-// grid = nwin * c workgroups; workgroup (w, k) sums the buckets of window w whose index b (1..nb)
-// has bit k set.  sum_b b*B_b = sum_k 2^k * T_k.
+template <class S> AVRF_DI te_ext wave_sum(te_ext acc) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc = te_add<S>(acc, shfl_down_ext(acc, off));
+  return acc;                                             // valid in lane 0
+}
+
+// Bucket index b in [1, nb-1] (nb = 2^(c-1)) split as b = hi * 2^h + lo; B_0 = identity.
+// One wave per task: tasks [0, NR) are row sums R_hi (2^h contiguous buckets), tasks [NR, NR+NC)
+// are column sums C_lo (stride 2^h).  rc[w * (NR+NC) + task].
 template <class S>
 __global__ void __launch_bounds__(256)
-k_bits(const te_ext *__restrict__ buckets, int c, te_ext *__restrict__ out) {
-  __shared__ te_ext sh[256];
-  int w = blockIdx.x / c, k = blockIdx.x % c;
-  const uint32_t nb = 1u << (c - 1);
-  const te_ext *B = buckets + (size_t)w * nb;
+k_rowcol(const te_ext *__restrict__ buckets, int c, int h, uint32_t total_waves, te_ext *__restrict__ rc) {
+  const uint32_t nb = 1u << (c - 1), NC = 1u << h, NR = nb >> h;
+  const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (gw >= total_waves) return;
+  const uint32_t tasks = NR + NC, w = gw / tasks, task = gw - w * tasks;
+  const te_ext *B = buckets + (size_t)w * nb;              // B[b-1]
   te_ext acc = te_identity<S>();
-  if (k == c - 1) {
-    if (threadIdx.x == 0) acc = load_ext(B + (nb - 1));       // only b = nb = 2^(c-1)
+  if (task < NR) {
+    for (uint32_t lo = lane; lo < NC; lo += 64) { uint32_t b = task * NC + lo; if (b >= 1) acc = te_add<S>(acc, load_ext(B + (b - 1))); }
   } else {
-    uint32_t cnt = nb >> 1;                                    // b in [1, nb-1] with bit k set
-    for (uint32_t m = threadIdx.x; m < cnt; m += blockDim.x) {
-      uint32_t b = ((m >> k) << (k + 1)) | (1u << k) | (m & ((1u << k) - 1));
-      acc = te_add<S>(acc, load_ext(B + (b - 1)));
-    }
+    uint32_t lo = task - NR;
+    for (uint32_t hi = lane; hi < NR; hi += 64) { uint32_t b = hi * NC + lo; if (b >= 1) acc = te_add<S>(acc, load_ext(B + (b - 1))); }
   }
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s >= 1; s >>= 1) {
-    if ((int)threadIdx.x < s) { acc = te_add<S>(acc, sh[threadIdx.x + s]); sh[threadIdx.x] = acc; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) store_ext(out + blockIdx.x, acc);
+  acc = wave_sum<S>(acc);
+  if (lane == 0) store_ext(rc + gw, acc);
+}
+
+// One wave per (window, bit k), k in [0, c): out[w*c + k] = T_k.
+template <class S>
+__global__ void __launch_bounds__(256)
+k_bits(const te_ext *__restrict__ buckets, const te_ext *__restrict__ rc, int c, int h, uint32_t total_waves, te_ext *__restrict__ out) {
+  const uint32_t nb = 1u << (c - 1), NC = 1u << h, NR = nb >> h;
+  const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (gw >= total_waves) return;
+  const uint32_t w = gw / c, k = gw - w * c;
+  const te_ext *RC = rc + (size_t)w * (NR + NC);
+  te_ext acc = te_identity<S>();
+  if ((int)k == c - 1) { if (lane == 0) acc = load_ext(buckets + (size_t)w * nb + (nb - 1)); }   // only b = nb
+  else if ((int)k < h) { for (uint32_t lo = lane; lo < NC; lo += 64) if ((lo >> k) & 1) acc = te_add<S>(acc, load_ext(RC + NR + lo)); }
+  else { uint32_t kk = k - h; for (uint32_t hi = lane; hi < NR; hi += 64) if ((hi >> kk) & 1) acc = te_add<S>(acc, load_ext(RC + hi)); }
+  acc = wave_sum<S>(acc);
+  if (lane == 0) store_ext(out + gw, acc);
 }
 
 // ---------------------------------------------------------------- host engine
@@ -232,36 +291,47 @@ k_bits(const te_ext *__restrict__ buckets, int c, te_ext *__restrict__ out) {
 MsmPlan msm_plan(size_t n, int scalar_bits) {
   MsmPlan p;
   int lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
-  int c = lg - 4; if (c < 4) c = 4; if (c > 14) c = 14;
+  int c = lg - 5; if (c < 4) c = 4; if (c > 15) c = 15;
   p.c = c; p.lpb = 16;                                   // lpb = SEG: entries per lane
-  if (const char *e = getenv("AVRF_MSM_C")) { int v = atoi(e); if (v >= 2 && v <= 20) p.c = v; }
+  if (const char *e = getenv("AVRF_MSM_C")) { int v = atoi(e); if (v >= 3 && v <= 15) p.c = v; }
   if (const char *e = getenv("AVRF_MSM_SEG")) { int v = atoi(e); if (v >= 1 && v <= 1024) p.lpb = v; }
   p.nb = 1 << (p.c - 1);
   p.nwin = (scalar_bits + 1 + p.c - 1) / p.c;
   return p;
 }
 
+static uint32_t tile_len_for(size_t n) { return 8192; }
+static uint32_t lcap_for(size_t n, const MsmPlan &p) { return (uint32_t)(((n / (size_t)p.lpb + p.nb + 1) + 63) / 64 * 64); }
+
 void MsmWorkspace::ensure(size_t n, const MsmPlan &p) {
   size_t nbk = (size_t)p.nwin * p.nb, nbits = (size_t)p.nwin * p.c;
   size_t need_n = (size_t)p.nwin * n;
+  size_t ntiles = (n + tile_len_for(n) - 1) / tile_len_for(n);
   if (need_n > cap_n) {
     if (keys) HIP_CHECK(hipFree(keys));
     if (sorted) HIP_CHECK(hipFree(sorted));
-    HIP_CHECK(hipMalloc(&keys, need_n * 4)); HIP_CHECK(hipMalloc(&sorted, need_n * 4));
+    HIP_CHECK(hipMalloc(&keys, need_n * 2 + 16)); HIP_CHECK(hipMalloc(&sorted, need_n * 4));
     cap_n = need_n;
   }
+  if (nbk * ntiles > cap_hist) {
+    if (hist) HIP_CHECK(hipFree(hist));
+    HIP_CHECK(hipMalloc(&hist, nbk * ntiles * 4));
+    cap_hist = nbk * ntiles;
+  }
   if (nbk > cap_buckets) {
-    if (counts) HIP_CHECK(hipFree(counts));
+    if (cnts) HIP_CHECK(hipFree(cnts));
     if (offsets) HIP_CHECK(hipFree(offsets));
     if (lane_off) HIP_CHECK(hipFree(lane_off));
+    if (lane_tot) HIP_CHECK(hipFree(lane_tot));
     if (buckets) HIP_CHECK(hipFree(buckets));
-    HIP_CHECK(hipMalloc(&counts, nbk * 4)); HIP_CHECK(hipMalloc(&offsets, (nbk + 1) * 4)); HIP_CHECK(hipMalloc(&lane_off, (nbk + 1) * 4));
+    if (rc) HIP_CHECK(hipFree(rc));
+    HIP_CHECK(hipMalloc(&cnts, nbk * 4)); HIP_CHECK(hipMalloc(&offsets, nbk * 4)); HIP_CHECK(hipMalloc(&lane_off, nbk * 4));
+    HIP_CHECK(hipMalloc(&lane_tot, 64 * 4 * 8));
     HIP_CHECK(hipMalloc(&buckets, nbk * sizeof(te_ext_raw)));
+    HIP_CHECK(hipMalloc(&rc, nbk * sizeof(te_ext_raw)));       // >= nwin * (NR + NC)
     cap_buckets = nbk;
   }
-  // lanes <= entries/seg + buckets  =>  waves <= that / 64 + 1; two partial slots per wave
-  size_t max_lanes = need_n / (size_t)(p.lpb > 0 ? p.lpb : 1) + nbk + 64;
-  size_t need_part = 2 * (max_lanes / 64 + 2);
+  size_t need_part = 2 * ((size_t)p.nwin * lcap_for(n, p) / 64 + 2);
   if (need_part > cap_part) {
     if (part) HIP_CHECK(hipFree(part));
     HIP_CHECK(hipMalloc(&part, need_part * sizeof(te_ext_raw)));
@@ -276,13 +346,13 @@ void MsmWorkspace::ensure(size_t n, const MsmPlan &p) {
   }
 }
 void MsmWorkspace::release() {
-  if (keys) (void)hipFree(keys); if (sorted) (void)hipFree(sorted); if (counts) (void)hipFree(counts);
-  if (offsets) (void)hipFree(offsets); if (lane_off) (void)hipFree(lane_off); if (buckets) (void)hipFree(buckets);
-  if (part) (void)hipFree(part); if (bits) (void)hipFree(bits);
+  void *dev[] = {keys, sorted, hist, cnts, offsets, lane_off, lane_tot, buckets, rc, part, bits};
+  for (void *q : dev) if (q) (void)hipFree(q);
   if (bits_host) (void)hipHostFree(bits_host);
   if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr;
-  keys = sorted = counts = offsets = lane_off = nullptr; buckets = part = bits = bits_host = nullptr;
-  cap_n = cap_buckets = cap_bits = cap_part = 0;
+  keys = nullptr; sorted = hist = cnts = offsets = lane_off = lane_tot = nullptr;
+  buckets = rc = part = bits = bits_host = nullptr;
+  cap_n = cap_buckets = cap_bits = cap_part = cap_hist = 0;
 }
 
 template <class S>
@@ -293,25 +363,31 @@ static int msm_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n
   if (n == 0) return 0;
   MsmPlan p = msm_plan(n, S::Fr::BITS);
   ws.ensure(n, p);
-  const uint32_t nbk = (uint32_t)p.nwin * p.nb;
-  HIP_CHECK(hipMemsetAsync(ws.counts, 0, (size_t)nbk * 4, stream));
+  const uint32_t nbk = (uint32_t)p.nwin * p.nb, seg = (uint32_t)p.lpb;
+  const uint32_t tile_len = tile_len_for(n), ntiles = (uint32_t)((n + tile_len - 1) / tile_len);
+  const uint32_t lcap = lcap_for(n, p);
+  const size_t lds_bytes = (size_t)p.nb * 4;
   dim3 b256(256), gn((unsigned)((n + 255) / 256));
-  hipLaunchKernelGGL(k_digits, gn, b256, 0, stream, d_scalars, (uint32_t)n, p.c, p.nwin, ws.keys, ws.counts);
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, stream, ws.counts, nbk, (uint32_t)p.lpb, ws.offsets, ws.lane_off);
-  HIP_CHECK(hipMemsetAsync(ws.counts, 0, (size_t)nbk * 4, stream));
-  hipLaunchKernelGGL(k_scatter, dim3(gn.x, p.nwin), b256, 0, stream, ws.keys, (uint32_t)n, p.c, p.nwin, ws.offsets, ws.counts, ws.sorted);
+  hipLaunchKernelGGL(k_digits, gn, b256, 0, stream, d_scalars, (uint32_t)n, p.c, p.nwin, ws.keys);
+  hipLaunchKernelGGL(k_hist, dim3(ntiles, p.nwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist);
+  hipLaunchKernelGGL(k_scan_win, dim3(p.nwin), dim3(1024), 0, stream, ws.hist, (uint32_t)n, ntiles, p.c, seg,
+                     ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot);
+  hipLaunchKernelGGL(k_scatter, dim3(ntiles, p.nwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist, ws.offsets, ws.sorted);
   const te_pre *pre = (const te_pre *)d_pre;
   te_ext *bk = (te_ext *)ws.buckets;
-  // upper bound on the lane count (the exact number lives in lane_off[nbk] on the device)
-  size_t max_lanes = ((size_t)p.nwin * n) / (size_t)p.lpb + nbk;
-  dim3 ga((unsigned)((max_lanes + 255) / 256));
+  dim3 ga((unsigned)(((size_t)p.nwin * lcap + 255) / 256));
   if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
   HIP_CHECK(hipEventRecord(ws.ev0, stream));
-  hipLaunchKernelGGL(k_accumulate<S>, ga, b256, 0, stream, pre, ws.sorted, ws.offsets, ws.lane_off, nbk, bk, (te_ext *)ws.part);
+  hipLaunchKernelGGL(k_accumulate<S>, ga, b256, 0, stream, pre, ws.sorted, ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot,
+                     (uint32_t)p.nwin, (uint32_t)p.nb, lcap, seg, bk, (te_ext *)ws.part);
   HIP_CHECK(hipEventRecord(ws.ev1, stream));
-  hipLaunchKernelGGL(k_fixup<S>, dim3((nbk + 255) / 256), b256, 0, stream, ws.lane_off, nbk, (const te_ext *)ws.part, bk);
+  hipLaunchKernelGGL(k_fixup<S>, dim3((nbk + 255) / 256), b256, 0, stream, ws.cnts, ws.lane_off, nbk, (uint32_t)p.nb, lcap, seg,
+                     (const te_ext *)ws.part, bk);
+  const int h = (p.c - 1) / 2;
+  const uint32_t tasks = (1u << h) + ((uint32_t)p.nb >> h);
+  hipLaunchKernelGGL(k_rowcol<S>, dim3(((size_t)p.nwin * tasks * 64 + 255) / 256), b256, 0, stream, bk, p.c, h, (uint32_t)p.nwin * tasks, (te_ext *)ws.rc);
   const int nbits = p.nwin * p.c;
-  hipLaunchKernelGGL(k_bits<S>, dim3(nbits), b256, 0, stream, bk, p.c, (te_ext *)ws.bits);
+  hipLaunchKernelGGL(k_bits<S>, dim3(((size_t)nbits * 64 + 255) / 256), b256, 0, stream, bk, (const te_ext *)ws.rc, p.c, h, (uint32_t)nbits, (te_ext *)ws.bits);
   HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.bits, (size_t)nbits * sizeof(te_ext_raw), hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
   HIP_CHECK(hipGetLastError());
