@@ -236,7 +236,7 @@ static int batch_run(avrf_ctx *c, int kind) {
   Seed64 seed;
   for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, dg + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
   double t2 = now_us();
-  if (kind == 1) launch_thin_terms(c->suite, b, seed, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_scalars.as<uint32_t>(),
+  if (kind == 1) launch_thin_terms(c->suite, b, seed, 0, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_scalars.as<uint32_t>(),
                                    c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
   else launch_ped_terms(c->suite, b, seed, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_scalars.as<uint32_t>(),
                         c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
@@ -262,6 +262,68 @@ int avrf_pedersen_batch_verify(avrf_ctx *c, size_t n, const uint8_t *ios_xy, con
                                const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
   int st = avrf_pedersen_batch_stage(c, n, ios_xy, io_counts, ads, ad_lens, proofs);
   return st ? st : avrf_pedersen_batch_run(c);
+}
+
+// ---------------------------------------------------------------- one batch split over several GPUs
+
+// weight transcript of src/thin.rs:274-279 / src/pedersen.rs:361-367 over ALL items of a batch (host only)
+int avrf_batch_weight_seed(int suite, int pedersen, size_t n, const uint8_t *c16, const uint8_t *resp, uint8_t seed_out[64]) {
+  if (suite < 0 || suite > 1 || !seed_out || (n && (!c16 || !resp))) return AVRF_ERR_BAD_ARG;
+  HostSha512 h;
+  if (suite == 0) h.update(SuiteBandersnatch::SUITE_ID, SuiteBandersnatch::SUITE_ID_LEN);
+  else h.update(SuiteBabyJubJub::SUITE_ID, SuiteBabyJubJub::SUITE_ID_LEN);
+  const uint8_t tag = DS_BATCH_VERIFY; h.update(&tag, 1);
+  const size_t rsz = pedersen ? 64 : 32;
+  uint8_t rec[96]; memset(rec, 0, sizeof rec);
+  for (size_t j = 0; j < n; j++) { memcpy(rec, c16 + 16 * j, 16); memcpy(rec + 32, resp + rsz * j, rsz); h.update(rec, 32 + rsz); }
+  h.final(seed_out);
+  return AVRF_OK;
+}
+
+// prepare (src/thin.rs:209-226) on the staged shard: per-item challenges, 16 bytes each
+int avrf_thin_batch_challenges(avrf_ctx *c, uint8_t *c_out) {
+  if (!c || c->staged_kind != 1 || (c->n && !c_out)) return AVRF_ERR_BAD_ARG;
+  if (c->n == 0) return AVRF_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  BatchDev b = batch_of(c);
+  HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  launch_thin_prepare(c->suite, b, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_flags.as<uint32_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(c_out, c->d_c.p, c->n * 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return *c->h_flags.as<uint32_t>() ? AVRF_INVALID_DATA : AVRF_OK;
+}
+
+// MSM of the staged shard's terms under the GLOBAL weight stream `seed`; the shard's first item has
+// global index first_index.  Includes the shard's share (G, -sum w s z0) of the shared-generator term,
+// so the partial points of all shards add up to the batch MSM of src/thin.rs:319.
+int avrf_thin_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t first_index, uint8_t out_xy[64]) {
+  if (!c || c->staged_kind != 1 || !seed64 || !out_xy) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  HostExt r;
+  if (c->n == 0) { r = c->suite == 0 ? HostTe<SuiteBandersnatch>::identity() : HostTe<SuiteBabyJubJub>::identity(); return finish_point(c, r, out_xy); }
+  Seed64 seed;
+  for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, seed64 + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
+  BatchDev b = batch_of(c);
+  launch_thin_terms(c->suite, b, seed, first_index, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_scalars.as<uint32_t>(),
+                    c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
+  if (msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r)) return AVRF_ERR_BAD_ARG;
+  return finish_point(c, r, out_xy);
+}
+
+// sum of k affine points on the host (combining per-GPU partial MSM results)
+int avrf_points_sum(int suite, size_t k, const uint8_t *points_xy, uint8_t out_xy[64]) {
+  if (suite < 0 || suite > 1 || !out_xy || (k && !points_xy)) return AVRF_ERR_BAD_ARG;
+  if (suite == 0) {
+    using T = HostTe<SuiteBandersnatch>; HostExt acc = T::identity(), p;
+    for (size_t i = 0; i < k; i++) { if (!T::from_affine_bytes(points_xy + 64 * i, &p)) return AVRF_INVALID_DATA; acc = T::add(acc, p); }
+    T::to_affine_bytes(acc, out_xy);
+  } else {
+    using T = HostTe<SuiteBabyJubJub>; HostExt acc = T::identity(), p;
+    for (size_t i = 0; i < k; i++) { if (!T::from_affine_bytes(points_xy + 64 * i, &p)) return AVRF_INVALID_DATA; acc = T::add(acc, p); }
+    T::to_affine_bytes(acc, out_xy);
+  }
+  return AVRF_OK;
 }
 
 size_t avrf_batch_last_terms(avrf_ctx *c, uint8_t *bases_xy, uint8_t *scalars) {

@@ -16,7 +16,7 @@ void launch_thin_prepare(int suite, const BatchDev &b, uint32_t *d_c, uint32_t *
 
 // Builds the MSM of src/thin.rs:282-317: scalars (n_terms x 8 u32, plain) and precomputed bases,
 // given the weight-transcript seed.  n_terms = 2 n + 2 tot_io + 1.
-void launch_thin_terms(int suite, const BatchDev &b, const Seed64 &seed, const uint32_t *d_c, const uint32_t *d_z,
+void launch_thin_terms(int suite, const BatchDev &b, const Seed64 &seed, uint64_t j0, const uint32_t *d_c, const uint32_t *d_z,
                        uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st);
 
 // pedersen::BatchItem::new (src/pedersen.rs:276-293) and the (5N+2)-term MSM of :369-418.

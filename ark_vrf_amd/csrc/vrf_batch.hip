@@ -81,7 +81,7 @@ template <class S> AVRF_DI void emit_term(uint32_t *scalars, te_pre *pre, uint32
 
 template <class S>
 __global__ void __launch_bounds__(128)
-k_thin_terms(BatchDev b, Seed64 seed, const uint32_t *__restrict__ c_in, const uint32_t *__restrict__ z_in,
+k_thin_terms(BatchDev b, Seed64 seed, uint64_t j0, const uint32_t *__restrict__ c_in, const uint32_t *__restrict__ z_in,
              uint32_t *__restrict__ scalars, te_pre *__restrict__ pre, uint32_t *__restrict__ gpart) {
   using Fr = typename S::Fr;
   __shared__ fp red[128];
@@ -90,8 +90,10 @@ k_thin_terms(BatchDev b, Seed64 seed, const uint32_t *__restrict__ c_in, const u
   if (j < b.n) {
     uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0;
     // w_j = challenge_scalar(&mut t): 16 bytes of the weight stream (thin.rs:289, common.rs:72-76)
-    uint64_t blk[8]; sha512_xof_block(seed.w, j >> 2, blk);
-    uint32_t ww[4]; digest_le128(blk, j & 3, ww);
+    // (j0 = global index of this shard's first item when one batch is split over several GPUs)
+    uint64_t gj = j0 + j;
+    uint64_t blk[8]; sha512_xof_block(seed.w, gj >> 2, blk);
+    uint32_t ww[4]; digest_le128(blk, (int)(gj & 3), ww);
     fp w_plain = fp_zero(); w_plain.v[0] = ww[0]; w_plain.v[1] = ww[1]; w_plain.v[2] = ww[2]; w_plain.v[3] = ww[3];
     fp w = fp_to_mont<Fr>(w_plain);
     fp c = fp_to_mont<Fr>(fp_from_u128(c_in + 4 * (size_t)j));
@@ -259,15 +261,15 @@ void launch_thin_prepare(int suite, const BatchDev &b, uint32_t *d_c, uint32_t *
   else hipLaunchKernelGGL(k_thin_prepare<SuiteBabyJubJub>, g, blk, 0, st, b, d_c, d_z, d_flags);
 }
 
-void launch_thin_terms(int suite, const BatchDev &b, const Seed64 &seed, const uint32_t *d_c, const uint32_t *d_z,
+void launch_thin_terms(int suite, const BatchDev &b, const Seed64 &seed, uint64_t j0, const uint32_t *d_c, const uint32_t *d_z,
                        uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st) {
   if (!b.n) return;
   dim3 g((b.n + 127) / 128), blk(128);
   if (suite == 0) {
-    hipLaunchKernelGGL(k_thin_terms<SuiteBandersnatch>, g, blk, 0, st, b, seed, d_c, d_z, d_scalars, (te_pre *)d_pre, d_gpart);
+    hipLaunchKernelGGL(k_thin_terms<SuiteBandersnatch>, g, blk, 0, st, b, seed, j0, d_c, d_z, d_scalars, (te_pre *)d_pre, d_gpart);
     hipLaunchKernelGGL(k_g_final<SuiteBandersnatch>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 0);
   } else {
-    hipLaunchKernelGGL(k_thin_terms<SuiteBabyJubJub>, g, blk, 0, st, b, seed, d_c, d_z, d_scalars, (te_pre *)d_pre, d_gpart);
+    hipLaunchKernelGGL(k_thin_terms<SuiteBabyJubJub>, g, blk, 0, st, b, seed, j0, d_c, d_z, d_scalars, (te_pre *)d_pre, d_gpart);
     hipLaunchKernelGGL(k_g_final<SuiteBabyJubJub>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 0);
   }
 }

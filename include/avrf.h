@@ -79,6 +79,18 @@ int avrf_thin_batch_stage(avrf_ctx *ctx, size_t n, const uint8_t *pks_xy, const 
                           const uint8_t *proofs);
 int avrf_thin_batch_run(avrf_ctx *ctx);
 
+/* One BatchVerifier split over several GPUs; see ark_vrf_amd/dist.py.
+ * The weights of src/thin.rs:274-289 depend on ALL items, so: every rank stages its shard and calls
+ * avrf_thin_batch_challenges (per-item c_j, 16 bytes each); the c_j and response scalars are
+ * all-gathered; avrf_batch_weight_seed hashes them (host, sequential) into the 64-byte stream seed;
+ * avrf_thin_batch_partial returns the MSM of the shard's terms (incl. its share of the G term) under
+ * that seed; the partial points are all-gathered and added with avrf_points_sum; the batch verifies
+ * iff the sum is the identity (0, 1). */
+int avrf_thin_batch_challenges(avrf_ctx *ctx, uint8_t *c_out);
+int avrf_batch_weight_seed(int suite, int pedersen, size_t n, const uint8_t *c16, const uint8_t *resp, uint8_t seed_out[64]);
+int avrf_thin_batch_partial(avrf_ctx *ctx, const uint8_t seed[64], uint64_t first_index, uint8_t out_xy[64]);
+int avrf_points_sum(int suite, size_t k, const uint8_t *points_xy, uint8_t out_xy[64]);
+
 /* Exposes the MSM the last avrf_thin_batch_run / avrf_pedersen_batch_run built
  * (bases_xy: n_terms x 64, scalars: n_terms x 32) so tests can compare weights and terms with
  * the oracle bit for bit.  Either output pointer may be NULL; returns the number of terms. */

@@ -1,0 +1,60 @@
+"""GPU: one thin BatchVerifier split into shards through the C ABI pieces used by
+ark_vrf_amd/dist.py -- P logical shards on the one visible device (the box has a single GPU; RCCL
+refuses two ranks on one device), combined on the host -- and the same through dist.sharded_thin_batch_verify
+with a 1-rank process group."""
+import os
+import socket
+
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shards", [1, 3, 4])
+def test_logical_shards_sum_to_identity(shards):
+    from ark_vrf_amd import _native as nat
+    from ark_vrf_amd.dist import GpuEngine, IDENTITY_XY, shard_range, shard_thin_batch
+    n = 501
+    good = orc.gen_batch(0, 0, n)
+    for tamper in (False, True):
+        b = dict(good)
+        if tamper:
+            p = bytearray(b["proofs"]); p[96 * 77 + 64] ^= 1; b["proofs"] = bytes(p)
+        engs = [GpuEngine(nat.Context(0)) for _ in range(shards)]
+        cs, ss = [], []
+        for r, e in enumerate(engs):
+            lo, hi = shard_range(n, r, shards)
+            sh = shard_thin_batch(b, lo, hi)
+            st, c = e.challenges(sh)
+            assert st == 0
+            cs.append(c); ss.append(b"".join(sh["proofs"][96 * j + 64: 96 * j + 96] for j in range(sh["n"])))
+        seed = engs[0].weight_seed(0, b"".join(cs), b"".join(ss))
+        parts = [e.partial(seed, shard_range(n, r, shards)[0]) for r, e in enumerate(engs)]
+        total = engs[0].points_sum(0, b"".join(parts))
+        assert (total == IDENTITY_XY) == (not tamper)
+        # the unsharded verifier agrees
+        c0 = engs[0].ctx
+        assert c0.thin_batch_stage(nat.Batch(n, b["ios_xy"], b["io_counts"], b["ads"], b["ad_lens"], pks_xy=b["pks_xy"], proofs=b["proofs"])) == 0
+        assert c0.thin_batch_run() == (1 if tamper else 0)
+
+
+def test_sharded_verify_one_rank_group():
+    import torch.distributed as dist
+    from ark_vrf_amd import _native as nat
+    from ark_vrf_amd.dist import GpuEngine, sharded_thin_batch_verify
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        b = orc.gen_batch(0, 0, 200)
+        eng = GpuEngine(nat.Context(0))
+        assert sharded_thin_batch_verify(eng, 0, b, dist) == 0
+        p = bytearray(b["proofs"]); p[96 * 5 + 64] ^= 1
+        b2 = dict(b); b2["proofs"] = bytes(p)
+        assert sharded_thin_batch_verify(eng, 0, b2, dist) == 1
+        b3 = dict(b); b3["pks_xy"] = bytes(32) + (1).to_bytes(32, "little") + b["pks_xy"][64:]
+        assert sharded_thin_batch_verify(eng, 0, b3, dist) == 2
+    finally:
+        dist.destroy_process_group()

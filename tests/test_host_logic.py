@@ -1,0 +1,68 @@
+"""Host-side product logic that needs no GPU: the sequential weight transcript (host_sha512.h via
+avrf_batch_weight_seed), the host point arithmetic that finishes an MSM / combines per-GPU partials
+(host_te.h via avrf_points_sum), batch packing and sharding helpers."""
+import ctypes as C
+import hashlib
+import random
+
+import pytest
+
+import oracle as orc
+from helpers import IDENTITY_XY, rand_points_xy, rand_scalar
+
+SUITE_ID = {0: b"Bandersnatch-SHA512-ELL2-v1", 1: b"BabyJubJub-SHA512-TAI-v1"}
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+@pytest.mark.parametrize("pedersen", [0, 1])
+def test_weight_seed_matches_transcript(suite, pedersen):
+    """src/thin.rs:274-279 / src/pedersen.rs:361-367: new(SUITE_ID); absorb [0x50]; per item
+    LE32(c) || LE32(s) [|| LE32(sb)]; seed = SHA-512 of all of it (src/utils/transcript.rs:227-240)."""
+    from ark_vrf_amd import _native as nat
+    rng = random.Random(3)
+    for n in [0, 1, 2, 7, 300]:
+        cs = [rng.getrandbits(128).to_bytes(16, "little") for _ in range(n)]
+        rs = [b"".join(rand_scalar(rng, suite) for _ in range(2 if pedersen else 1)) for _ in range(n)]
+        h = hashlib.sha512(SUITE_ID[suite] + b"\x50")
+        for c, r in zip(cs, rs):
+            h.update(c + bytes(16) + r)
+        seed = (C.c_uint8 * 64)()
+        st = nat.lib().avrf_batch_weight_seed(suite, pedersen, C.c_size_t(n), nat._u8(b"".join(cs)), nat._u8(b"".join(rs)), seed)
+        assert st == 0 and bytes(seed) == h.digest()
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_points_sum_matches_oracle(suite):
+    from ark_vrf_amd import _native as nat
+    rng = random.Random(11 + suite)
+    pts = rand_points_xy(rng, suite, 9) + [IDENTITY_XY]
+    out = (C.c_uint8 * 64)()
+    assert nat.lib().avrf_points_sum(suite, C.c_size_t(len(pts)), nat._u8(b"".join(pts)), out) == 0
+    ones = b"".join((1).to_bytes(32, "little") for _ in pts)
+    assert bytes(out) == orc.msm(suite, b"".join(pts), ones, algo=0)
+    assert nat.lib().avrf_points_sum(suite, C.c_size_t(0), None, out) == 0 and bytes(out) == IDENTITY_XY
+    bad = b"\xff" * 64
+    assert nat.lib().avrf_points_sum(suite, C.c_size_t(1), nat._u8(bad), out) == nat.INVALID_DATA
+
+
+def test_shard_helpers():
+    from ark_vrf_amd.dist import shard_range, shard_thin_batch
+    for n in [0, 1, 5, 8, 65536, 65537]:
+        for world in [1, 2, 3, 8]:
+            rs = [shard_range(n, r, world) for r in range(world)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            assert max(h - l for l, h in rs) - min(h - l for l, h in rs) <= 1
+    b = dict(n=3, pks_xy=bytes(range(192)), ios_xy=bytes(128 * 4), io_counts=[2, 0, 2], ads=b"abcdef", ad_lens=[1, 2, 3],
+             proofs=bytes(96 * 3))
+    s = shard_thin_batch(b, 1, 3)
+    assert s["n"] == 2 and s["ads"] == b"bcdef" and s["io_counts"] == [0, 2] and len(s["ios_xy"]) == 256
+    assert s["pks_xy"] == bytes(range(64, 192))
+
+
+def test_batch_packing():
+    from ark_vrf_amd._native import Batch
+    b = Batch.from_items([[(b"i" * 64, b"o" * 64)], [], [(b"a" * 64, b"b" * 64), (b"c" * 64, b"d" * 64)]], [b"x", b"", b"yz"],
+                         pks_xy=[b"p" * 64] * 3, proofs=[b"q" * 96] * 3)
+    assert b.n == 3 and list(b.io_counts)[:3] == [1, 0, 2] and list(b.ad_lens)[:3] == [1, 0, 2]
+    assert bytes(b.ads)[:3] == b"xyz" and bytes(b.ios_xy)[:128] == b"i" * 64 + b"o" * 64
