@@ -1,0 +1,170 @@
+// avrf.hpp -- header-only C++17 mirror of the reference's scheme-layer interface for the
+// accelerated path, on top of the C ABI (avrf.h).  The reference is Rust; with no Rust toolchain
+// in this image the host side above the boundary is C++ with the reference's names, argument
+// meaning and error behaviour, so call sites read like the reference's own tests:
+//
+//   ark_vrf::Suite                         -> avrf::Suite            (src/lib.rs:177-250)
+//   ark_vrf::{Secret, Public, VrfIo}       -> avrf::Secret / Public / VrfIo   (src/lib.rs:258-635)
+//   ark_vrf::Error                         -> avrf::Error            (src/lib.rs:135-147)
+//   thin::{Proof, Prover, Verifier, BatchVerifier}     -> avrf::thin::...     (src/thin.rs:43-326)
+//   pedersen::{Proof, Prover, Verifier, BatchVerifier} -> avrf::pedersen::... (src/pedersen.rs:69-426)
+//
+// Differences forced by the device: provers/verifiers take *batches* of independent items (one GPU
+// lane each); single-item calls are batches of one.  Points are 64-byte affine x||y (see avrf.h).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "avrf.h"
+
+namespace avrf {
+
+enum class Error : int { VerificationFailure = 1, InvalidData = 2, RingCapacityExceeded = 3, SrsLookupFailed = 4 };
+// Result<(), Error>: 0 = Ok(())
+using Status = int;
+
+using Point = std::array<uint8_t, 64>;   // affine x || y, LE32 each
+using Scalar = std::array<uint8_t, 32>;  // LE32 canonical
+
+struct VrfIo { Point input, output; };   // src/lib.rs:615-619
+
+// trait Suite: a context binds the suite parameterisation to one GPU stream.
+class Suite {
+ public:
+  enum Id { BandersnatchSha512Ell2 = AVRF_SUITE_BANDERSNATCH_SHA512_ELL2, BabyJubJubSha512Tai = AVRF_SUITE_BABYJUBJUB_SHA512_TAI };
+  explicit Suite(Id id, int device = 0) {
+    if (avrf_ctx_create(id, device, &ctx_) != AVRF_OK) throw std::runtime_error("avrf: no MI355X device (there is no CPU fallback)");
+  }
+  ~Suite() { avrf_ctx_destroy(ctx_); }
+  Suite(const Suite &) = delete;
+  Suite &operator=(const Suite &) = delete;
+  avrf_ctx *ctx() const { return ctx_; }
+
+ private:
+  avrf_ctx *ctx_ = nullptr;
+};
+
+struct Public { Point point; };          // src/lib.rs:408
+struct Secret {                          // src/lib.rs:258
+  Scalar scalar; Public public_key;
+  // Secret::from_scalar (src/lib.rs:331-334): pk = sk * G on the device
+  static Secret from_scalar(const Suite &s, const Scalar &sk) {
+    Secret r; r.scalar = sk;
+    if (avrf_scalar_mul_base(s.ctx(), 1, sk.data(), r.public_key.point.data()) != AVRF_OK) throw std::invalid_argument("avrf: bad scalar");
+    return r;
+  }
+  // Secret::output / vrf_io (src/lib.rs:391-401)
+  VrfIo vrf_io(const Suite &s, const Point &input) const {
+    VrfIo io; io.input = input;
+    if (avrf_scalar_mul(s.ctx(), 1, scalar.data(), input.data(), io.output.data()) != AVRF_OK) throw std::invalid_argument("avrf: bad input");
+    return io;
+  }
+};
+
+namespace detail {
+// flattens {ios per item, ad per item} into the C-ABI layout
+struct Packed {
+  std::vector<uint8_t> ios, ads; std::vector<uint32_t> io_counts, ad_lens;
+  void push(const std::vector<VrfIo> &item_ios, const std::string &ad) {
+    for (const VrfIo &io : item_ios) { ios.insert(ios.end(), io.input.begin(), io.input.end()); ios.insert(ios.end(), io.output.begin(), io.output.end()); }
+    io_counts.push_back((uint32_t)item_ios.size());
+    ads.insert(ads.end(), ad.begin(), ad.end()); ad_lens.push_back((uint32_t)ad.size());
+  }
+};
+}  // namespace detail
+
+namespace thin {
+
+struct Proof { Point r; Scalar s; };     // src/thin.rs:43-48  (wire: R_xy || s)
+
+// thin::Prover::prove for Secret (src/thin.rs:111-129)
+inline Proof prove(const Suite &su, const Secret &sk, const std::vector<VrfIo> &ios, const std::string &ad) {
+  detail::Packed p; p.push(ios, ad);
+  uint8_t out[96];
+  if (avrf_thin_prove(su.ctx(), 1, sk.scalar.data(), sk.public_key.point.data(), p.ios.data(), p.io_counts.data(),
+                      p.ads.data(), p.ad_lens.data(), out) != AVRF_OK) throw std::invalid_argument("avrf: thin prove");
+  Proof pr; std::copy(out, out + 64, pr.r.begin()); std::copy(out + 64, out + 96, pr.s.begin()); return pr;
+}
+// thin::Verifier::verify for Public (src/thin.rs:131-165): 0 = Ok, else Error
+inline Status verify(const Suite &su, const Public &pk, const std::vector<VrfIo> &ios, const std::string &ad, const Proof &proof) {
+  detail::Packed p; p.push(ios, ad);
+  uint8_t pr[96]; std::copy(proof.r.begin(), proof.r.end(), pr); std::copy(proof.s.begin(), proof.s.end(), pr + 64);
+  int32_t st = 0;
+  if (avrf_thin_verify(su.ctx(), 1, pk.point.data(), p.ios.data(), p.io_counts.data(), p.ads.data(), p.ad_lens.data(), pr, &st) != AVRF_OK)
+    throw std::runtime_error("avrf: thin verify");
+  return st;
+}
+
+// thin::BatchVerifier (src/thin.rs:188-326): new / push / verify
+class BatchVerifier {
+ public:
+  explicit BatchVerifier(const Suite &su) : su_(su) {}
+  void push(const Public &pk, const std::vector<VrfIo> &ios, const std::string &ad, const Proof &proof) {   // :234-243
+    pks_.insert(pks_.end(), pk.point.begin(), pk.point.end());
+    packed_.push(ios, ad);
+    proofs_.insert(proofs_.end(), proof.r.begin(), proof.r.end()); proofs_.insert(proofs_.end(), proof.s.begin(), proof.s.end());
+    n_++;
+  }
+  Status verify() const {                                                                                     // :257-325
+    return avrf_thin_batch_verify(su_.ctx(), n_, pks_.data(), packed_.ios.data(), packed_.io_counts.data(), packed_.ads.data(),
+                                  packed_.ad_lens.data(), proofs_.data());
+  }
+  size_t len() const { return n_; }
+
+ private:
+  const Suite &su_; size_t n_ = 0;
+  std::vector<uint8_t> pks_, proofs_; detail::Packed packed_;
+};
+
+}  // namespace thin
+
+namespace pedersen {
+
+struct Proof { Point pk_com, r, ok; Scalar s, sb; };   // src/pedersen.rs:69-75 (wire: Yb_xy || R_xy || Ok_xy || s || sb)
+
+inline void to_wire(const Proof &p, uint8_t out[256]) {
+  std::copy(p.pk_com.begin(), p.pk_com.end(), out); std::copy(p.r.begin(), p.r.end(), out + 64); std::copy(p.ok.begin(), p.ok.end(), out + 128);
+  std::copy(p.s.begin(), p.s.end(), out + 192); std::copy(p.sb.begin(), p.sb.end(), out + 224);
+}
+// pedersen::Prover::prove (src/pedersen.rs:136-186): returns (proof, blinding)
+inline std::pair<Proof, Scalar> prove(const Suite &su, const Secret &sk, const std::vector<VrfIo> &ios, const std::string &ad) {
+  detail::Packed p; p.push(ios, ad);
+  uint8_t out[256]; Scalar bl;
+  if (avrf_pedersen_prove(su.ctx(), 1, sk.scalar.data(), sk.public_key.point.data(), p.ios.data(), p.io_counts.data(), p.ads.data(),
+                          p.ad_lens.data(), out, bl.data()) != AVRF_OK) throw std::invalid_argument("avrf: pedersen prove");
+  Proof pr;
+  std::copy(out, out + 64, pr.pk_com.begin()); std::copy(out + 64, out + 128, pr.r.begin()); std::copy(out + 128, out + 192, pr.ok.begin());
+  std::copy(out + 192, out + 224, pr.s.begin()); std::copy(out + 224, out + 256, pr.sb.begin());
+  return {pr, bl};
+}
+// pedersen::Verifier::verify (src/pedersen.rs:188-249)
+inline Status verify(const Suite &su, const std::vector<VrfIo> &ios, const std::string &ad, const Proof &proof) {
+  detail::Packed p; p.push(ios, ad);
+  uint8_t pr[256]; to_wire(proof, pr);
+  int32_t st = 0;
+  if (avrf_pedersen_verify(su.ctx(), 1, p.ios.data(), p.io_counts.data(), p.ads.data(), p.ad_lens.data(), pr, &st) != AVRF_OK)
+    throw std::runtime_error("avrf: pedersen verify");
+  return st;
+}
+// pedersen::BatchVerifier (src/pedersen.rs:303-426)
+class BatchVerifier {
+ public:
+  explicit BatchVerifier(const Suite &su) : su_(su) {}
+  void push(const std::vector<VrfIo> &ios, const std::string &ad, const Proof &proof) {                        // :324-326
+    packed_.push(ios, ad);
+    uint8_t pr[256]; to_wire(proof, pr); proofs_.insert(proofs_.end(), pr, pr + 256); n_++;
+  }
+  Status verify() const {                                                                                     // :341-426
+    return avrf_pedersen_batch_verify(su_.ctx(), n_, packed_.ios.data(), packed_.io_counts.data(), packed_.ads.data(),
+                                      packed_.ad_lens.data(), proofs_.data());
+  }
+
+ private:
+  const Suite &su_; size_t n_ = 0;
+  std::vector<uint8_t> proofs_; detail::Packed packed_;
+};
+
+}  // namespace pedersen
+}  // namespace avrf

@@ -1,0 +1,40 @@
+"""The C++ mirror of the reference interface (include/avrf.hpp) against the reference's golden
+vectors: compiled with g++ against libavrf.so and run on the GPU box."""
+import json
+import os
+import subprocess
+
+import pytest
+
+import oracle as orc
+from conftest import ROOT
+from helpers import xy
+
+pytestmark = pytest.mark.gpu
+NAMES = {0: "bandersnatch_sha-512_ell2", 1: "baby-jubjub_sha-512_tai"}
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("cpp") / "mirror_check")
+    lib = os.path.join(ROOT, "ark_vrf_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "mirror_check.cpp"),
+                           "-o", out, "-L", lib, "-lavrf", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_mirror_reproduces_vectors(exe, golden_dir, suite):
+    vt = json.load(open(os.path.join(golden_dir, NAMES[suite] + "_thin.json")))
+    vp = json.load(open(os.path.join(golden_dir, NAMES[suite] + "_pedersen.json")))
+    for t, p in list(zip(vt, vp))[:3]:
+        res = subprocess.run([exe, str(suite), t["sk"], xy(suite, bytes.fromhex(t["h"])).hex(), t["ad"] or ""],
+                             capture_output=True, text=True, check=True).stdout
+        kv = dict(line.split("=", 1) for line in res.strip().splitlines())
+        comp = lambda k: orc.point_compress(suite, bytes.fromhex(kv[k])).hex()
+        assert comp("pk") == t["pk"] and comp("output") == t["gamma"]
+        assert comp("thin_r") == t["proof_r"] and kv["thin_s"] == t["proof_s"]
+        assert comp("ped_pk_com") == p["proof_pk_com"] and comp("ped_r") == p["proof_r"] and comp("ped_ok") == p["proof_ok"]
+        assert kv["ped_s"] == p["proof_s"] and kv["ped_sb"] == p["proof_sb"] and kv["ped_blinding"] == p["blinding"]
+        assert [kv[k] for k in ("thin_verify", "thin_verify_bad_ad", "thin_batch_empty", "thin_batch", "thin_batch_bad")] == ["0", "1", "0", "0", "1"]
+        assert [kv[k] for k in ("ped_verify", "ped_batch", "ped_batch_bad")] == ["0", "0", "1"]
