@@ -198,11 +198,16 @@ k_accumulate(const te_pre *__restrict__ pre, const uint32_t *__restrict__ sorted
     l0 = lo_w[lo]; nl = (cnt + seg - 1) / seg;
     const uint32_t per = (cnt + nl - 1) / nl, r = lt - l0;
     uint32_t b = e0 + r * per, e = b + per; if (e > e0 + cnt) e = e0 + cnt;
-    for (uint32_t i = b; i < e; i++) {
-      uint32_t idx = sorted[i];
+    // software-pipelined gather: the next base is in flight while the current addition runs
+    if (b < e) {
+      uint32_t idx = sorted[b];
       te_pre q = load_pre(pre + (idx & 0x7fffffffu));
-      if (idx & 0x80000000u) { q.x = fp_neg<Fq>(q.x); q.k = fp_neg<Fq>(q.k); }
-      acc = te_madd<S>(acc, q);
+      for (uint32_t i = b; i < e; i++) {
+        const uint32_t cidx = idx; te_pre cur = q;
+        if (i + 1 < e) { idx = sorted[i + 1]; q = load_pre(pre + (idx & 0x7fffffffu)); }
+        if (cidx & 0x80000000u) { cur.x = fp_neg<Fq>(cur.x); cur.k = fp_neg<Fq>(cur.k); }
+        acc = te_madd<S>(acc, cur);
+      }
     }
   }
   // segmented reduction by doubling: after step `off` a run head holds the sum of min(run, 2*off) lanes
