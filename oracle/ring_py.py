@@ -1,0 +1,541 @@
+"""oracle/ring_py.py -- pure-Python restatement of the Ring-VRF SNARK path (TEST ORACLE, small cases).
+
+Restates what ark-vrf delegates to the un-vendored crate `w3f-ring-proof 0.0.10` (+ w3f-plonk-common,
+w3f-pcs, ark-transcript) at src/ring.rs:220 (`ring_prover.prove`), :242 (`verifier.verify`),
+:404,416 (`ring_proof::index`), following the byte-exact specification in SURVEY.md Appendix A.5,
+A.7, A.8, and is PINNED to the reference's ring vectors (tests/golden/*_ring.json + the two SRS
+files): ring commitment and the complete 592-byte / 480-byte ring proof of all 7 vectors of both
+suites (tests/test_oracle_ring.py).  Big-int Python: fine for the vectors' domain N = 512; the C
+port (orc_ring.c) handles benchmark sizes.
+
+Only tests/ import this module.
+"""
+import hashlib
+
+# ---------------------------------------------------------------------------------------------
+# curves
+
+
+class Suite:
+    pass
+
+
+def _bander():
+    s = Suite()
+    s.name = "bandersnatch"
+    s.suite_id = b"Bandersnatch-SHA512-ELL2-v1"
+    s.r = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001   # Fr(BLS12-381) = Fq(Bandersnatch)
+    s.te_a = s.r - 5
+    s.te_d = 45022363124591815672509500913686876175488063829319466900776701791074614335719
+    s.te_order_bits = 253
+    s.blinding_base = (23335687741101763108036518445642207119627658113885888016488710494487028845889,
+                       5552214580375038693022409684979828600325210968745774080859660443337357929963)
+    s.accumulator_base = (14056632001415368875257708737821299882600475929746323097150942355715730684350,
+                          10322661992765989500407719465917595459409463902187386706652408883505670839210)
+    s.padding = (26913883415342152801331916189968962157924271221160514298872262294143390094043,
+                 30874728313203001508631936119690348239461579770372782660098261717479009115354)
+    s.p = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    s.g1_b = 4
+    s.fp_bytes = 48
+    s.zcash = True
+    s.two_adicity = 32
+    s.root_of_unity = 10238227357739495823651030575849232062558860180284477541189508159991286009131
+    return s
+
+
+def _bjj():
+    s = Suite()
+    s.name = "babyjubjub"
+    s.suite_id = b"BabyJubJub-SHA512-TAI-v1"
+    s.r = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001      # Fr(BN254)
+    s.te_a = 1
+    s.te_d = 9706598848417545097372247223557719406784115219466060233080913168975159366771
+    s.te_order_bits = 251
+    s.blinding_base = (15549380791300914366206471199568039679131690710803662429646809536753521087193,
+                       15218614024055502695611547593111691164731001864276292210438920202280814188379)
+    s.accumulator_base = (6402374321243162085389111671722843560682527921646684137786768606010797479351,
+                          9735581299071570006712034490635195155689931359428941496570758703259384062170)
+    s.padding = (11167490195257431015694161063225325511805242064780376648595733691987293447528,
+                 18403369502642103292159933062507105566469227524991433735553439433605496057425)
+    s.p = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    s.g1_b = 3
+    s.fp_bytes = 32
+    s.zcash = False
+    s.two_adicity = 28
+    s.root_of_unity = 19103219067921713944291392827692070036145651957329286315305642004821462161904
+    return s
+
+
+SUITES = {0: _bander(), 1: _bjj()}
+
+# ---- twisted Edwards (affine, big-int)
+
+
+def te_add(s, P, Q):
+    (x1, y1), (x2, y2) = P, Q
+    r = s.r
+    dxy = s.te_d * x1 * x2 % r * y1 % r * y2 % r
+    x3 = (x1 * y2 + y1 * x2) * pow(1 + dxy, -1, r) % r
+    y3 = (y1 * y2 - s.te_a * x1 * x2) * pow(1 - dxy, -1, r) % r
+    return (x3, y3)
+
+
+def te_dbl_pow2(s, P, n):
+    out = []
+    for _ in range(n):
+        out.append(P)
+        P = te_add(s, P, P)
+    return out
+
+
+def te_decode(s, b):
+    r = s.r
+    y = int.from_bytes(b, "little")
+    neg = y >> 255
+    y &= (1 << 255) - 1
+    x2 = (1 - y * y) * pow(s.te_a - s.te_d * y * y, -1, r) % r
+    x = sqrt_mod(x2, r)
+    assert x is not None
+    if (x > (r - 1) // 2) != bool(neg):
+        x = r - x
+    return (x, y)
+
+
+def sqrt_mod(a, p):
+    a %= p
+    if a == 0:
+        return 0
+    if pow(a, (p - 1) // 2, p) != 1:
+        return None
+    if p % 4 == 3:
+        return pow(a, (p + 1) // 4, p)
+    q, s_ = p - 1, 0
+    while q % 2 == 0:
+        q //= 2
+        s_ += 1
+    z = 2
+    while pow(z, (p - 1) // 2, p) != p - 1:
+        z += 1
+    m, c, t, rr = s_, pow(z, q, p), pow(a, q, p), pow(a, (q + 1) // 2, p)
+    while t != 1:
+        i, t2 = 0, t
+        while t2 != 1:
+            t2 = t2 * t2 % p
+            i += 1
+        b = pow(c, 1 << (m - i - 1), p)
+        m, c = i, b * b % p
+        t, rr = t * c % p, rr * b % p
+    return rr
+
+# ---- G1 (short Weierstrass y^2 = x^3 + b over Fp), Jacobian; None = infinity
+
+
+def g1_dbl(p, P):
+    if P is None:
+        return None
+    X, Y, Z = P
+    if Y == 0:
+        return None
+    A = X * X % p; B = Y * Y % p; C = B * B % p
+    D = 2 * ((X + B) * (X + B) - A - C) % p
+    E = 3 * A % p; F = E * E % p
+    X3 = (F - 2 * D) % p
+    Y3 = (E * (D - X3) - 8 * C) % p
+    Z3 = 2 * Y * Z % p
+    return (X3, Y3, Z3)
+
+
+def g1_add(p, P, Q):
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    X1, Y1, Z1 = P; X2, Y2, Z2 = Q
+    Z1Z1 = Z1 * Z1 % p; Z2Z2 = Z2 * Z2 % p
+    U1 = X1 * Z2Z2 % p; U2 = X2 * Z1Z1 % p
+    S1 = Y1 * Z2 % p * Z2Z2 % p; S2 = Y2 * Z1 % p * Z1Z1 % p
+    if U1 == U2:
+        return g1_dbl(p, P) if S1 == S2 else None
+    H = (U2 - U1) % p; I = 4 * H * H % p; J = H * I % p
+    rr = 2 * (S2 - S1) % p; V = U1 * I % p
+    X3 = (rr * rr - J - 2 * V) % p
+    Y3 = (rr * (V - X3) - 2 * S1 * J) % p
+    Z3 = ((Z1 + Z2) * (Z1 + Z2) - Z1Z1 - Z2Z2) % p * H % p
+    return (X3, Y3, Z3)
+
+
+def g1_neg(p, P):
+    return None if P is None else (P[0], (-P[1]) % p, P[2])
+
+
+def g1_affine(p, P):
+    if P is None:
+        return None
+    zi = pow(P[2], -1, p)
+    return (P[0] * zi * zi % p, P[1] * zi * zi % p * zi % p)
+
+
+def g1_mul(p, P, k):
+    acc = None
+    for bit in bin(k)[2:]:
+        acc = g1_dbl(p, acc)
+        if bit == "1":
+            acc = g1_add(p, acc, P)
+    return acc
+
+
+def g1_msm(p, pts, scalars, c=8):
+    """sum scalars[i] * pts[i]; pts affine (x, y) or None.  Plain Pippenger."""
+    pairs = [(P, k) for P, k in zip(pts, scalars) if P is not None and k]
+    if not pairs:
+        return None
+    nbits = max(k.bit_length() for _, k in pairs)
+    total = None
+    for w in reversed(range((nbits + c - 1) // c)):
+        for _ in range(c):
+            total = g1_dbl(p, total)
+        buckets = [None] * (1 << c)
+        for P, k in pairs:
+            d = (k >> (w * c)) & ((1 << c) - 1)
+            if d:
+                buckets[d] = g1_add(p, buckets[d], (P[0], P[1], 1))
+        run = acc = None
+        for d in range((1 << c) - 1, 0, -1):
+            run = g1_add(p, run, buckets[d])
+            acc = g1_add(p, acc, run)
+        total = g1_add(p, total, acc)
+    return total
+
+# ---- G1 codecs
+
+
+def g1_encode(s, P, compressed):
+    n = s.fp_bytes
+    if s.zcash:                                        # BLS12-381: big-endian, flags in the first byte
+        if P is None:
+            out = bytearray(n if compressed else 2 * n); out[0] |= 0x40
+            if compressed:
+                out[0] |= 0x80
+            return bytes(out)
+        x, y = P
+        if compressed:
+            out = bytearray(x.to_bytes(n, "big")); out[0] |= 0x80
+            if y > (s.p - 1) // 2:
+                out[0] |= 0x20
+            return bytes(out)
+        return x.to_bytes(n, "big") + y.to_bytes(n, "big")
+    # BN254: arkworks default SW format, little-endian, flags in the last byte
+    if P is None:
+        out = bytearray(n if compressed else 2 * n); out[-1] |= 0x40
+        return bytes(out)
+    x, y = P
+    neg = 0x80 if y > (s.p - 1) // 2 else 0
+    if compressed:
+        out = bytearray(x.to_bytes(n, "little")); out[-1] |= neg
+        return bytes(out)
+    out = bytearray(x.to_bytes(n, "little") + y.to_bytes(n, "little")); out[-1] |= neg
+    return bytes(out)
+
+
+def g1_decode_uncompressed(s, b):
+    n = s.fp_bytes
+    if s.zcash:
+        if b[0] & 0x40:
+            return None
+        return (int.from_bytes(b[:n], "big"), int.from_bytes(b[n:2 * n], "big"))
+    if b[2 * n - 1] & 0x40:
+        return None
+    yb = bytearray(b[n:2 * n]); yb[-1] &= 0x3f
+    return (int.from_bytes(b[:n], "little"), int.from_bytes(yb, "little"))
+
+
+def g1_decode_compressed(s, b):
+    n = s.fp_bytes
+    p = s.p
+    if s.zcash:
+        if b[0] & 0x40:
+            return None
+        big = b[0] & 0x20
+        xb = bytearray(b); xb[0] &= 0x1f
+        x = int.from_bytes(xb, "big")
+    else:
+        if b[-1] & 0x40:
+            return None
+        big = b[-1] & 0x80
+        xb = bytearray(b); xb[-1] &= 0x3f
+        x = int.from_bytes(xb, "little")
+    y = sqrt_mod((x * x * x + s.g1_b) % p, p)
+    assert y is not None
+    if (y > (p - 1) // 2) != bool(big):
+        y = p - y
+    return (x, y)
+
+
+class Srs:
+    """URS { powers_in_g1: Vec<G1>, powers_in_g2: Vec<G2> }, serialize_uncompressed."""
+
+    def __init__(self, s, data):
+        n = s.fp_bytes
+        cnt = int.from_bytes(data[:8], "little")
+        off = 8
+        self.g1 = [g1_decode_uncompressed(s, data[off + 2 * n * i: off + 2 * n * (i + 1)]) for i in range(cnt)]
+        off += 2 * n * cnt
+        cnt2 = int.from_bytes(data[off: off + 8], "little")
+        off += 8
+        self.g2_raw = [data[off + 4 * n * i: off + 4 * n * (i + 1)] for i in range(cnt2)]
+        assert off + 4 * n * cnt2 == len(data)
+
+# ---------------------------------------------------------------------------------------------
+# polynomials over Fr
+
+
+def domain_root(s, n):
+    lg = n.bit_length() - 1
+    assert 1 << lg == n
+    return pow(s.root_of_unity, 1 << (s.two_adicity - lg), s.r)
+
+
+def fft(s, a, w):
+    """evaluations of the polynomial with coefficients a on {w^i}; len(a) a power of two."""
+    r = s.r
+    n = len(a)
+    a = list(a)
+    j = 0
+    for i in range(1, n):
+        bit = n >> 1
+        while j & bit:
+            j ^= bit
+            bit >>= 1
+        j |= bit
+        if i < j:
+            a[i], a[j] = a[j], a[i]
+    length = 2
+    while length <= n:
+        wl = pow(w, n // length, r)
+        for i in range(0, n, length):
+            x = 1
+            for k in range(length // 2):
+                u, v = a[i + k], a[i + k + length // 2] * x % r
+                a[i + k], a[i + k + length // 2] = (u + v) % r, (u - v) % r
+                x = x * wl % r
+        length <<= 1
+    return a
+
+
+def ifft(s, ev, w):
+    r = s.r
+    n = len(ev)
+    out = fft(s, ev, pow(w, -1, r))
+    ninv = pow(n, -1, r)
+    return [x * ninv % r for x in out]
+
+
+def poly_eval(s, c, x):
+    acc = 0
+    for v in reversed(c):
+        acc = (acc * x + v) % s.r
+    return acc
+
+
+def poly_div_linear(s, c, z):
+    """(c(X) - c(z)) / (X - z) by synthetic division."""
+    r = s.r
+    out = [0] * (len(c) - 1)
+    acc = 0
+    for i in range(len(c) - 1, 0, -1):
+        acc = (c[i] + acc * z) % r
+        out[i - 1] = acc
+    return out
+
+# ---------------------------------------------------------------------------------------------
+# ark-transcript over SHAKE128
+
+
+class ArkTranscript:
+    def __init__(self, label):
+        self.h = hashlib.shake_128()
+        self.len = None
+        self.label(label)
+
+    def write(self, b):
+        self.h.update(b)
+        self.len = (self.len or 0) + len(b)
+
+    def separate(self):
+        if self.len is not None:
+            self.h.update(self.len.to_bytes(4, "big"))
+            self.len = None
+
+    def label(self, l):
+        self.separate(); self.write(l); self.separate()
+
+    def append(self, data):
+        self.separate(); self.write(data); self.separate()
+
+    def challenge_bytes(self, l, n):
+        self.label(l)
+        self.write(b"challenge")
+        out = self.h.copy().digest(n)
+        self.separate()
+        return out
+
+    def challenge_fr(self, s, l):
+        return int.from_bytes(self.challenge_bytes(l, 48), "big") % s.r
+
+# ---------------------------------------------------------------------------------------------
+# PIOP parameters, index, prover, verifier
+
+
+class Params:
+    def __init__(self, s, ring_size=None, domain_size=None):
+        L = s.te_order_bits
+        if domain_size is None:
+            need = ring_size + 4 + L                      # src/ring.rs:810-821
+            domain_size = 1 << (need - 1).bit_length()
+        self.s = s
+        self.N = domain_size
+        self.L = L
+        self.capacity = self.N - 3                        # ZK_ROWS = 3
+        self.keyset_part_size = self.capacity - L - 1
+        self.w = domain_root(s, self.N)
+        self.w4 = domain_root(s, 4 * self.N)
+        self.h_pows = te_dbl_pow2(s, s.blinding_base, L)  # 2^i * H
+
+
+def index(prm, srs, keys):
+    """ring_proof::index (src/ring.rs:404,416): fixed columns + their KZG commitments."""
+    s = prm.s
+    assert len(keys) <= prm.keyset_part_size
+    points = list(keys) + [s.padding] * (prm.keyset_part_size - len(keys)) + prm.h_pows
+    assert len(points) == prm.capacity - 1
+    xs = [P[0] for P in points] + [0] * (prm.N - len(points))
+    ys = [P[1] for P in points] + [0] * (prm.N - len(points))
+    sel = [1] * prm.keyset_part_size + [0] * (prm.N - prm.keyset_part_size)
+    cols = {"points": points, "x": xs, "y": ys, "sel": sel}
+    cols["x_poly"] = ifft(s, xs, prm.w); cols["y_poly"] = ifft(s, ys, prm.w); cols["sel_poly"] = ifft(s, sel, prm.w)
+    commit = lambda c: g1_affine(s.p, g1_msm(s.p, srs.g1[: len(c)], c))
+    cols["C"] = [commit(cols["x_poly"]), commit(cols["y_poly"]), commit(cols["sel_poly"])]
+    return cols
+
+
+def commitment_bytes(s, cols):
+    return b"".join(g1_encode(s, C, True) for C in cols["C"])
+
+
+def _transcript_prelude(prm, srs, cols):
+    s = prm.s
+    t = ArkTranscript(s.suite_id)
+    t.label(b"vk")
+    vk = g1_encode(s, srs.g1[0], False) + srs.g2_raw[0] + srs.g2_raw[1] + b"".join(g1_encode(s, C, False) for C in cols["C"])
+    t.append(vk)
+    return t
+
+
+def _le32(x):
+    return x.to_bytes(32, "little")
+
+
+def prove(prm, srs, cols, key_index, blinding_scalar):
+    """RingProver::prove with blinding disabled (src/ring.rs:220, 273-275).  Returns proof bytes."""
+    s = prm.s
+    r, N, cap, w = s.r, prm.N, prm.capacity, prm.w
+    points, sel = cols["points"], cols["sel"]
+    # -- witness (A.7 step 1)
+    bits = [0] * (cap - 1)
+    bits[key_index] = 1
+    for i in range(prm.L):
+        bits[prm.keyset_part_size + i] = (blinding_scalar >> i) & 1
+    ip = [0] * cap
+    for i in range(cap - 1):
+        ip[i + 1] = (ip[i] + sel[i] * bits[i]) % r
+    acc = [s.accumulator_base]
+    for i in range(cap - 1):
+        acc.append(te_add(s, acc[i], points[i]) if bits[i] else acc[i])
+    result = acc[cap - 1]
+    neg_seed = ((-s.accumulator_base[0]) % r, s.accumulator_base[1])
+    instance = te_add(s, result, neg_seed)                          # Yb = pk_k + b*H
+    pad = lambda v: list(v) + [0] * (N - len(v))                    # private column, blinding disabled
+    ev = {"bits": pad(bits), "ip": pad(ip), "ax": pad([P[0] for P in acc]), "ay": pad([P[1] for P in acc])}
+    poly = {k: ifft(s, v, w) for k, v in ev.items()}
+    poly["px"], poly["py"], poly["sel"] = cols["x_poly"], cols["y_poly"], cols["sel_poly"]
+    commit = lambda c: g1_affine(s.p, g1_msm(s.p, srs.g1[: len(c)], c))
+    C = [commit(poly[k]) for k in ("bits", "ip", "ax", "ay")]
+    # -- transcript
+    t = _transcript_prelude(prm, srs, cols)
+    t.label(b"instance"); t.append(_le32(instance[0]) + _le32(instance[1]))
+    t.label(b"committed_cols"); t.append(b"".join(g1_encode(s, c, False) for c in C))
+    alphas = [t.challenge_fr(s, b"constraints_aggregation") for _ in range(7)]
+    # -- constraints on the 4N domain (A.7 step 4)
+    M = 4 * N
+    w4 = prm.w4
+    e4 = {k: fft(s, poly[k] + [0] * (M - N), w4) for k in poly}
+    sh = lambda v, i: v[(i + 4) % M]                                # c(wX) on the 4N domain
+    xs4 = [1] * M
+    for i in range(1, M):
+        xs4[i] = xs4[i - 1] * w4 % r
+    w_last = pow(w, cap - 1, r)
+    # Lagrange basis polynomials of rows 0 and cap-1 over the size-N domain
+    lf = ifft(s, [1] + [0] * (N - 1), w)
+    ll_ev = [0] * N; ll_ev[cap - 1] = 1
+    ll = ifft(s, ll_ev, w)
+    lf4 = fft(s, lf + [0] * (M - N), w4); ll4 = fft(s, ll + [0] * (M - N), w4)
+    a = s.te_a
+    seed = s.accumulator_base
+    agg = [0] * M
+    for i in range(M):
+        b = e4["bits"][i]; x1 = e4["ax"][i]; y1 = e4["ay"][i]; x2 = e4["px"][i]; y2 = e4["py"][i]
+        x3 = sh(e4["ax"], i); y3 = sh(e4["ay"], i)
+        nl = (xs4[i] - w_last) % r
+        c0 = (sh(e4["ip"], i) - e4["ip"][i] - e4["sel"][i] * b) % r * nl % r
+        c1 = (b * (x3 * ((y1 * y2 + a * x1 % r * x2) % r) - x1 * y1 - x2 * y2) + (1 - b) * (x3 - x1)) % r * nl % r
+        c2 = (b * (y3 * ((x1 * y2 - x2 * y1) % r) - x1 * y1 + x2 * y2) + (1 - b) * (y3 - y1)) % r * nl % r
+        c3 = b * (1 - b) % r
+        c4 = (lf4[i] * (x1 - seed[0]) + ll4[i] * (x1 - result[0])) % r
+        c5 = (lf4[i] * (y1 - seed[1]) + ll4[i] * (y1 - result[1])) % r
+        c6 = (lf4[i] * e4["ip"][i] + ll4[i] * (e4["ip"][i] - 1)) % r
+        agg[i] = (alphas[0] * c0 + alphas[1] * c1 + alphas[2] * c2 + alphas[3] * c3 + alphas[4] * c4 + alphas[5] * c5 + alphas[6] * c6) % r
+    aggc = ifft(s, agg, w4)
+    # * prod_{i=N-3}^{N-1} (X - w^i), / (X^N - 1)
+    num = aggc + [0, 0, 0, 0]
+    for i in (N - 3, N - 2, N - 1):
+        z = pow(w, i, r)
+        nxt = [0] * len(num)
+        for k in range(len(num) - 1):
+            nxt[k + 1] = (nxt[k + 1] + num[k]) % r
+            nxt[k] = (nxt[k] - z * num[k]) % r
+        num = nxt
+    while num and num[-1] == 0:
+        num.pop()
+    q = [0] * (len(num) - N)
+    rem = list(num)
+    for k in range(len(num) - 1, N - 1, -1):                         # divide by X^N - 1
+        q[k - N] = rem[k]
+        rem[k - N] = (rem[k - N] + rem[k]) % r
+        rem[k] = 0
+    assert not any(rem), "quotient not exact"
+    Cq = commit(q)
+    t.label(b"quotient"); t.append(g1_encode(s, Cq, False))
+    zeta = t.challenge_fr(s, b"evaluation_point")
+    order = ("px", "py", "sel", "bits", "ip", "ax", "ay")
+    evals = [poly_eval(s, poly[k], zeta) for k in order]
+    t.label(b"register_evaluations"); t.append(b"".join(_le32(v) for v in evals))
+    x2, y2, _, b, _, x1, y1 = evals
+    nl_z = (zeta - w_last) % r
+    k1 = (b * ((y1 * y2 + a * x1 % r * x2) % r) + 1 - b) % r
+    k2 = (b * ((x1 * y2 - x2 * y1) % r) + 1 - b) % r
+    lin = [nl_z * ((alphas[0] * poly["ip"][i] + alphas[1] * k1 % r * poly["ax"][i] + alphas[2] * k2 % r * poly["ay"][i]) % r) % r for i in range(N)]
+    zw = zeta * w % r
+    lin_zw = poly_eval(s, lin, zw)
+    t.label(b"shifted_linearization_evaluation"); t.append(_le32(lin_zw))
+    nus = [t.challenge_fr(s, b"kzg_aggregation") for _ in range(8)]
+    aggz = [0] * len(q)
+    for nu, k in zip(nus, order):
+        for i, v in enumerate(poly[k]):
+            aggz[i] = (aggz[i] + nu * v) % r
+    for i, v in enumerate(q):
+        aggz[i] = (aggz[i] + nus[7] * v) % r
+    pi1 = commit(poly_div_linear(s, aggz, zeta))
+    pi2 = commit(poly_div_linear(s, lin, zw))
+    proof = b"".join(g1_encode(s, c, True) for c in C) + b"".join(_le32(v) for v in evals) + g1_encode(s, Cq, True) + \
+        _le32(lin_zw) + g1_encode(s, pi1, True) + g1_encode(s, pi2, True)
+    return proof, instance

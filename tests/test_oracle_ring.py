@@ -1,0 +1,52 @@
+"""Pins the ring-SNARK oracle (oracle/ring_py.py) to the reference's ring vectors:
+ring commitment (`ring_pks_com`, 3 x G1) and the complete deterministic ring proof (`ring_proof`,
+592 B BLS12-381 / 480 B BN254) of tests/golden/*_ring.json, with the SRS files the reference's
+tests load (src/ring.rs:1412-1421, 1529-1571)."""
+import json
+import os
+
+import pytest
+
+from oracle import ring_py as R
+
+FILES = {0: ("bandersnatch_sha-512_ell2_ring.json", "bls12-381-srs-2-11-uncompressed-zcash.bin"),
+         1: ("baby-jubjub_sha-512_tai_ring.json", "bn254-testing-2-9-uncompressed.bin")}
+
+
+@pytest.fixture(scope="module")
+def setups(golden_dir):
+    out = {}
+    for i, (vec, srsf) in FILES.items():
+        s = R.SUITES[i]
+        srs = R.Srs(s, open(os.path.join(golden_dir, srsf), "rb").read())
+        out[i] = (s, srs, json.load(open(os.path.join(golden_dir, vec))), R.Params(s, ring_size=8))
+    return out
+
+
+def test_domain_sizes(setups):
+    # src/ring.rs:810-843: piop = next_pow2(ring + 4 + L); pcs = 3*piop + 1
+    for i, L in ((0, 253), (1, 251)):
+        s = R.SUITES[i]
+        assert R.Params(s, ring_size=8).N == 512
+        assert R.Params(s, ring_size=1024).N == 2048
+        assert R.Params(s, ring_size=4096).N == 8192
+        p = R.Params(s, ring_size=8)
+        assert p.keyset_part_size == 512 - 4 - L and p.capacity == 509
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+@pytest.mark.parametrize("vec", [0, 1, 2, 3, 4, 5, 6])
+def test_ring_commitment_and_proof(setups, suite, vec):
+    s, srs, vs, prm = setups[suite]
+    v = vs[vec]
+    pks = bytes.fromhex(v["ring_pks"])
+    keys = [R.te_decode(s, pks[32 * i: 32 * i + 32]) for i in range(len(pks) // 32)]
+    cols = R.index(prm, srs, keys)
+    assert R.commitment_bytes(s, cols).hex() == v["ring_pks_com"]
+    idx = keys.index(R.te_decode(s, bytes.fromhex(v["pk"])))
+    assert idx == 3                                                   # src/ring.rs:1477
+    b = int.from_bytes(bytes.fromhex(v["blinding"]), "little")
+    proof, instance = R.prove(prm, srs, cols, idx, b)
+    assert proof.hex() == v["ring_proof"]
+    # the instance is the Pedersen key commitment Yb of the same vector (src/ring.rs:237-242)
+    assert instance == R.te_decode(s, bytes.fromhex(v["proof_pk_com"]))
