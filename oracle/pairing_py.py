@@ -1,0 +1,180 @@
+"""oracle/pairing_py.py -- slow, generic pairing for the ring verifier oracle (TEST ORACLE).
+
+Restates from the published definitions what the reference gets from arkworks `Pairing`
+(ark-ec / ark-bls12-381, third-party; reached via `verifier.verify`, src/ring.rs:242, and
+`ring_batch.verify`, src/ring.rs:731): the ate pairing on BLS12-381 with Fp12 represented directly
+as Fp[w]/(w^12 - 2 w^6 + 2) (w^6 = 1 + u, u^2 = -1), the M-twist untwisting (x, y) -> (x/w^2, y/w^3),
+a Miller loop over |x| = 0xd201000000010000 with affine line functions on E(Fp12), and the plain
+final exponentiation f^((p^12 - 1)/r).  Only product-equals-one tests are needed, so the sign of x
+is ignored.  Pinned by: e(tau*g1, g2) == e(g1, tau*g2) on the reference's SRS file
+and by the reference's ring proofs verifying (tests/test_oracle_ring.py).
+"""
+
+P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+ATE_LOOP = 0xd201000000010000
+MOD_COEFFS = [2, 0, 0, 0, 0, 0, -2, 0, 0, 0, 0, 0]     # w^12 = 2 w^6 - 2
+
+
+class F12:
+    __slots__ = ("c",)
+
+    def __init__(self, c):
+        self.c = [x % P for x in c]
+
+    @staticmethod
+    def one():
+        return F12([1] + [0] * 11)
+
+    @staticmethod
+    def zero():
+        return F12([0] * 12)
+
+    def __add__(self, o):
+        return F12([a + b for a, b in zip(self.c, o.c)])
+
+    def __sub__(self, o):
+        return F12([a - b for a, b in zip(self.c, o.c)])
+
+    def __neg__(self):
+        return F12([-a for a in self.c])
+
+    def __eq__(self, o):
+        return self.c == o.c
+
+    def scale(self, k):
+        return F12([a * k for a in self.c])
+
+    def __mul__(self, o):
+        if isinstance(o, int):
+            return self.scale(o)
+        b = [0] * 23
+        for i, x in enumerate(self.c):
+            if x:
+                for j, y in enumerate(o.c):
+                    b[i + j] += x * y
+        for k in range(22, 11, -1):                     # reduce with w^12 = 2 w^6 - 2
+            t = b[k]
+            if t:
+                b[k - 6] += 2 * t
+                b[k - 12] -= 2 * t
+        return F12(b[:12])
+
+    def inv(self):
+        # extended Euclid over Fp[w]
+        lm, hm = [1] + [0] * 12, [0] * 13
+        low, high = self.c + [0], [x % P for x in MOD_COEFFS] + [1]
+        deg = lambda p: max([i for i, x in enumerate(p) if x] or [0])
+        while deg(low):
+            # r = high / low
+            dl, dh = deg(low), deg(high)
+            r = [0] * 13
+            temp = list(high)
+            inv_lead = pow(low[dl], -1, P)
+            for i in range(dh - dl, -1, -1):
+                r[i] = temp[dl + i] * inv_lead % P
+                for c in range(dl + 1):
+                    temp[c + i] = (temp[c + i] - low[c] * r[i]) % P
+            nm, new = list(hm), list(high)
+            for i in range(13):
+                for j in range(13 - i):
+                    nm[i + j] = (nm[i + j] - lm[i] * r[j]) % P
+                    new[i + j] = (new[i + j] - low[i] * r[j]) % P
+            lm, low, hm, high = nm, new, lm, low
+        k = pow(low[0], -1, P)
+        return F12([x * k for x in lm[:12]])
+
+    def __truediv__(self, o):
+        return self * o.inv()
+
+    def __pow__(self, e):
+        out, base = F12.one(), self
+        while e:
+            if e & 1:
+                out = out * base
+            base = base * base
+            e >>= 1
+        return out
+
+
+W = F12([0, 1] + [0] * 10)
+
+
+def embed_fp(x):
+    return F12([x] + [0] * 11)
+
+
+def embed_fp2(a, b):
+    """a + b u  ->  (a - b) + b w^6   (u = w^6 - 1)"""
+    return F12([a - b] + [0] * 5 + [b] + [0] * 5)
+
+
+def untwist(q):
+    """G2 point ((x0, x1), (y0, y1)) on y^2 = x^3 + 4(1 + u)  ->  point of E(Fp12): y^2 = x^3 + 4."""
+    (x0, x1), (y0, y1) = q
+    w2 = W * W
+    return (embed_fp2(x0, x1) / w2, embed_fp2(y0, y1) / (w2 * W))
+
+
+def _double(pt):
+    x, y = pt
+    m = (x * x).scale(3) / y.scale(2)
+    nx = m * m - x.scale(2)
+    return (nx, m * (x - nx) - y)
+
+
+def _add(p1, p2):
+    x1, y1 = p1; x2, y2 = p2
+    if x1 == x2:
+        return _double(p1) if y1 == y2 else None
+    m = (y2 - y1) / (x2 - x1)
+    nx = m * m - x1 - x2
+    return (nx, m * (x1 - nx) - y1)
+
+
+def _line(p1, p2, t):
+    x1, y1 = p1; x2, y2 = p2; xt, yt = t
+    if not (x1 == x2):
+        m = (y2 - y1) / (x2 - x1)
+        return m * (xt - x1) - (yt - y1)
+    if y1 == y2:
+        m = (x1 * x1).scale(3) / y1.scale(2)
+        return m * (xt - x1) - (yt - y1)
+    return xt - x1
+
+
+def miller_loop(q_g2, p_g1):
+    """q_g2: ((x0,x1),(y0,y1)) affine on the twist; p_g1: (x, y) affine.  No final exponentiation."""
+    if q_g2 is None or p_g1 is None:
+        return F12.one()
+    Q = untwist(q_g2)
+    Pt = (embed_fp(p_g1[0]), embed_fp(p_g1[1]))
+    Rr, f = Q, F12.one()
+    for i in range(ATE_LOOP.bit_length() - 2, -1, -1):
+        f = f * f * _line(Rr, Rr, Pt)
+        Rr = _double(Rr)
+        if (ATE_LOOP >> i) & 1:
+            f = f * _line(Rr, Q, Pt)
+            Rr = _add(Rr, Q)
+    return f
+
+
+def final_exp(f):
+    return f ** ((P ** 12 - 1) // R_ORDER)
+
+
+def pairing_product_is_one(pairs):
+    """prod e(P_i, Q_i) == 1 for pairs [(g1_affine, g2_affine)]"""
+    f = F12.one()
+    for p1, q2 in pairs:
+        f = f * miller_loop(q2, p1)
+    return final_exp(f) == F12.one()
+
+
+def g2_decode_zcash_uncompressed(b):
+    """192 bytes: x.c1 || x.c0 || y.c1 || y.c0, 48-byte big-endian each."""
+    v = [int.from_bytes(b[48 * i: 48 * i + 48], "big") for i in range(4)]
+    if b[0] & 0x40:
+        return None
+    v[0] &= (1 << 381) - 1
+    return ((v[1], v[0]), (v[3], v[2]))

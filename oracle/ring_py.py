@@ -539,3 +539,90 @@ def prove(prm, srs, cols, key_index, blinding_scalar):
     proof = b"".join(g1_encode(s, c, True) for c in C) + b"".join(_le32(v) for v in evals) + g1_encode(s, Cq, True) + \
         _le32(lin_zw) + g1_encode(s, pi1, True) + g1_encode(s, pi2, True)
     return proof, instance
+
+
+# ---------------------------------------------------------------------------------------------
+# verifier: RingVerifier::verify, src/ring.rs:242
+
+def _g1_lincomb(s, terms):
+    """sum k_i * P_i for [(k, affine P)]"""
+    acc = None
+    for k, Pt in terms:
+        if Pt is None or k % s.r == 0:
+            continue
+        acc = g1_add(s.p, acc, g1_mul(s.p, (Pt[0], Pt[1], 1), k % s.r))
+    return acc
+
+
+def verify(prm, srs, fixed_commitments, proof, instance, pairing=None):
+    """Returns True iff the ring proof verifies for `instance` (the Pedersen key commitment Yb as a TE
+    point) under the verifier key (srs.g1[0], srs.g2[0..2], fixed_commitments).  BLS12-381 only
+    (the pairing of pairing_py)."""
+    from . import pairing_py as PP
+    s = prm.s
+    r, N, cap, w = s.r, prm.N, prm.capacity, prm.w
+    n = s.fp_bytes
+    off = 0
+    C = []
+    for _ in range(4):
+        C.append(g1_decode_compressed(s, proof[off: off + n])); off += n
+    evals = [int.from_bytes(proof[off + 32 * i: off + 32 * i + 32], "little") for i in range(7)]; off += 32 * 7
+    Cq = g1_decode_compressed(s, proof[off: off + n]); off += n
+    lin_zw = int.from_bytes(proof[off: off + 32], "little"); off += 32
+    pi1 = g1_decode_compressed(s, proof[off: off + n]); off += n
+    pi2 = g1_decode_compressed(s, proof[off: off + n]); off += n
+    assert off == len(proof)
+    if any(v >= r for v in evals) or lin_zw >= r:
+        return False
+    cols = {"C": fixed_commitments}
+    t = _transcript_prelude(prm, srs, cols)
+    t.label(b"instance"); t.append(_le32(instance[0]) + _le32(instance[1]))
+    t.label(b"committed_cols"); t.append(b"".join(g1_encode(s, c, False) for c in C))
+    alphas = [t.challenge_fr(s, b"constraints_aggregation") for _ in range(7)]
+    t.label(b"quotient"); t.append(g1_encode(s, Cq, False))
+    zeta = t.challenge_fr(s, b"evaluation_point")
+    t.label(b"register_evaluations"); t.append(b"".join(_le32(v) for v in evals))
+    t.label(b"shifted_linearization_evaluation"); t.append(_le32(lin_zw))
+    nus = [t.challenge_fr(s, b"kzg_aggregation") for _ in range(8)]
+    x2, y2, sel, b, ip, x1, y1 = evals
+    a = s.te_a
+    w_last = pow(w, cap - 1, r)
+    nl = (zeta - w_last) % r
+    zn1 = (pow(zeta, N, r) - 1) % r
+    ninv = pow(N, -1, r)
+    lag = lambda i: pow(w, i, r) * zn1 % r * ninv % r * pow((zeta - pow(w, i, r)) % r, -1, r) % r
+    lf, ll = lag(0), lag(cap - 1)
+    seed = s.accumulator_base
+    res = te_add(s, seed, instance)
+    rest = [
+        (-ip - sel * b) % r * nl % r,
+        (b * (-x1 * y1 - x2 * y2) - (1 - b) * x1) % r * nl % r,
+        (b * (-x1 * y1 + x2 * y2) - (1 - b) * y1) % r * nl % r,
+        b * (1 - b) % r,
+        (lf * (x1 - seed[0]) + ll * (x1 - res[0])) % r,
+        (lf * (y1 - seed[1]) + ll * (y1 - res[1])) % r,
+        (lf * ip + ll * (ip - 1)) % r,
+    ]
+    agg_z = (sum(al * c for al, c in zip(alphas, rest)) + lin_zw) % r
+    zk = 1
+    for i in (N - 3, N - 2, N - 1):
+        zk = zk * (zeta - pow(w, i, r)) % r
+    q_z = agg_z * zk % r * pow(zn1, -1, r) % r
+    col_commits = list(fixed_commitments) + C                      # px, py, sel, bits, ip, ax, ay
+    C_agg = _g1_lincomb(s, [(nu, c) for nu, c in zip(nus, col_commits)] + [(nus[7], Cq)])
+    v_agg = (sum(nu * e for nu, e in zip(nus, evals)) + nus[7] * q_z) % r
+    k1 = (b * ((y1 * y2 + a * x1 % r * x2) % r) + 1 - b) % r
+    k2 = (b * ((x1 * y2 - x2 * y1) % r) + 1 - b) % r
+    C_lin = _g1_lincomb(s, [(nl * alphas[0] % r, C[1]), (nl * alphas[1] % r * k1 % r, C[2]), (nl * alphas[2] % r * k2 % r, C[3])])
+    g1 = srs.g1[0]
+    g2 = PP.g2_decode_zcash_uncompressed(srs.g2_raw[0]); tg2 = PP.g2_decode_zcash_uncompressed(srs.g2_raw[1])
+    zw = zeta * w % r
+    ok = True
+    for Cm, z, v, pi in ((C_agg, zeta, v_agg, pi1), (C_lin, zw, lin_zw, pi2)):
+        # e(C - v g1 + z pi, g2) * e(-pi, tau g2) == 1
+        lhs = g1_add(s.p, Cm, g1_neg(s.p, g1_mul(s.p, (g1[0], g1[1], 1), v)))
+        lhs = g1_add(s.p, lhs, g1_mul(s.p, (pi[0], pi[1], 1), z))
+        lhs_a = g1_affine(s.p, lhs)
+        npi = (pi[0], (-pi[1]) % s.p)
+        ok &= PP.pairing_product_is_one([(lhs_a, g2), (npi, tg2)])
+    return ok

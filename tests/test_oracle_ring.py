@@ -50,3 +50,37 @@ def test_ring_commitment_and_proof(setups, suite, vec):
     assert proof.hex() == v["ring_proof"]
     # the instance is the Pedersen key commitment Yb of the same vector (src/ring.rs:237-242)
     assert instance == R.te_decode(s, bytes.fromhex(v["proof_pk_com"]))
+
+
+def test_srs_pairing_consistency(setups):
+    """e(tau*g1, g2) == e(g1, tau*g2) on the reference's BLS12-381 SRS file (pins the pairing and the
+    zcash G2 byte order)."""
+    from oracle import pairing_py as PP
+    s, srs, _, _ = setups[0]
+    g2, tg2 = PP.g2_decode_zcash_uncompressed(srs.g2_raw[0]), PP.g2_decode_zcash_uncompressed(srs.g2_raw[1])
+    g1, tg1 = srs.g1[0], srs.g1[1]
+    neg = lambda P: (P[0], (-P[1]) % s.p)
+    assert PP.pairing_product_is_one([(tg1, g2), (neg(g1), tg2)])
+    assert not PP.pairing_product_is_one([(tg1, g2), (neg(tg1), tg2)])
+    # powers of tau are consistent further up the SRS too
+    assert PP.pairing_product_is_one([(srs.g1[5], g2), (neg(srs.g1[4]), tg2)])
+
+
+@pytest.mark.parametrize("vec", [0, 3, 6])
+def test_reference_ring_proofs_verify(setups, vec):
+    """RingVerifier::verify (src/ring.rs:242) restated per SURVEY.md A.8 accepts the reference's own
+    proofs and rejects perturbed ones."""
+    s, srs, vs, prm = setups[0]
+    v = vs[vec]
+    com = bytes.fromhex(v["ring_pks_com"])
+    fixed = [R.g1_decode_compressed(s, com[48 * i: 48 * i + 48]) for i in range(3)]
+    inst = R.te_decode(s, bytes.fromhex(v["proof_pk_com"]))
+    proof = bytes.fromhex(v["ring_proof"])
+    assert R.verify(prm, srs, fixed, proof, inst)
+    bad = bytearray(proof); bad[4 * 48 + 3 * 32 + 1] ^= 1               # evaluation of `bits`
+    assert not R.verify(prm, srs, fixed, bytes(bad), inst)
+    assert not R.verify(prm, srs, fixed, proof, R.te_add(s, inst, s.blinding_base))   # other key commitment
+    other = bytes.fromhex(vs[(vec + 1) % 7]["ring_pks_com"])
+    if other != com:                                                   # other ring
+        fixed2 = [R.g1_decode_compressed(s, other[48 * i: 48 * i + 48]) for i in range(3)]
+        assert not R.verify(prm, srs, fixed2, proof, inst)
