@@ -107,6 +107,17 @@ class Context:
             raise AvrfError(f"avrf_msm_te -> {st}")
         return bytes(out)
 
+    def g1_msm(self, bases_xy, scalars):
+        """KZG-side MSM on the suite's pairing curve; points as LE x||y (48+48 / 32+32 bytes)."""
+        n = len(scalars) // 32
+        fq = 48 if self.suite == 0 else 32
+        assert len(bases_xy) == 2 * fq * n
+        out = (C.c_uint8 * (2 * fq))()
+        st = lib().avrf_g1_msm(self._h, C.c_size_t(n), _u8(bases_xy), _u8(scalars), out)
+        if st != OK:
+            raise AvrfError(f"avrf_g1_msm -> {st}")
+        return bytes(out)
+
     # -- batch verifiers
     def thin_batch_verify(self, pks_xy, items_ios_xy, ads, proofs):
         b = Batch.from_items(items_ios_xy, ads, pks_xy=pks_xy, proofs=proofs)

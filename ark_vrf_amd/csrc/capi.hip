@@ -147,6 +147,31 @@ int avrf_msm_te(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *s
   return finish_point(c, r, out_xy);
 }
 
+// G1 MSM of the suite's pairing curve (KZG commit / open): bases as canonical little-endian x || y
+// (48+48 bytes BLS12-381, 32+32 bytes BN254; all-zero = infinity), scalars LE32 < r.
+int avrf_g1_msm(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *scalars, uint8_t *out_xy) {
+  if (!c || !out_xy || (n && (!bases_xy || !scalars))) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t fqb = c->suite == 0 ? 48 : 32;
+  for (size_t i = 0; i < n; i++) {
+    H256 v; memcpy(v.l, scalars + 32 * i, 32);
+    bool ok = c->suite == 0 ? !HostField<FqBandersnatch>::geq_p(v) : !HostField<FqBabyJubJub>::geq_p(v);   // Fr of the pairing curve
+    if (!ok) return AVRF_INVALID_DATA;
+  }
+  c->staged_kind = 0;
+  if (n) {
+    HIP_TRY(c->d_misc.ensure(n * 2 * fqb)); HIP_TRY(c->d_scalars.ensure(n * 32)); HIP_TRY(c->d_pre.ensure(n * 2 * fqb));
+    HIP_TRY(hipMemcpyAsync(c->d_misc.p, bases_xy, n * 2 * fqb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+    launch_g1_bases(c->suite, c->d_misc.as<uint8_t>(), n, c->d_pre.as<uint32_t>(), c->d_flags.as<uint32_t>(), c->stream);
+    HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  if (msm_g1_device(c->suite, c->d_pre.as<uint32_t>(), c->d_scalars.as<uint32_t>(), n, c->ws, c->stream, out_xy)) return AVRF_ERR_BAD_ARG;
+  if (n && *c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;
+  return AVRF_OK;
+}
+
 // ---------------------------------------------------------------- staging
 
 // kind: 1 thin (pks + 96-byte proofs), 2 pedersen (256-byte proofs); proofs/pks/sks may be NULL for provers

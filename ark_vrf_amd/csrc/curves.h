@@ -1,0 +1,120 @@
+// curves.h -- curve policies for the generic Pippenger kernels (msm_kernels.h):
+//   TeCurve<Suite>   twisted Edwards, extended coordinates (te.h)           -> Thin / Pedersen batch MSMs
+//   G1Curve<G1>      short Weierstrass y^2 = x^3 + b (a = 0), XYZZ coordinates -> KZG commit / open MSMs
+//                    of the ring SNARK (ark-bls12-381 / ark-bn254 G1; w3f-pcs KZG; src/ring.rs:220,404,416,731)
+// A policy provides: base_t (precomputed affine base as stored in HBM), acc_t (accumulator),
+// identity / madd(acc, base, negate) / add(acc, acc), raw load/store, and a lane shuffle.
+#pragma once
+#include "fpn.h"
+#include "te.h"
+
+namespace avrf {
+
+template <class S> struct TeCurve {
+  using base_t = te_pre; using acc_t = te_ext;
+  static constexpr int BASE_WORDS = 24, ACC_WORDS = 32;
+  static AVRF_DI acc_t identity() { return te_identity<S>(); }
+  static AVRF_DI acc_t madd(const acc_t &a, base_t q, bool neg) {
+    using Fq = typename S::Fq;
+    if (neg) { q.x = fp_neg<Fq>(q.x); q.k = fp_neg<Fq>(q.k); }
+    return te_madd<S>(a, q);
+  }
+  static AVRF_DI acc_t add(const acc_t &a, const acc_t &b) { return te_add<S>(a, b); }
+  static AVRF_DI base_t load_base(const uint32_t *p) { return load_pre(reinterpret_cast<const te_pre *>(p)); }
+  static AVRF_DI acc_t load_acc(const uint32_t *p) { return load_ext(reinterpret_cast<const te_ext *>(p)); }
+  static AVRF_DI void store_acc(uint32_t *p, const acc_t &a) { store_ext(reinterpret_cast<te_ext *>(p), a); }
+  static AVRF_DI acc_t shfl_down(const acc_t &p, int delta) {
+    acc_t r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      r.x.v[i] = __shfl_down(p.x.v[i], delta); r.y.v[i] = __shfl_down(p.y.v[i], delta);
+      r.t.v[i] = __shfl_down(p.t.v[i], delta); r.z.v[i] = __shfl_down(p.z.v[i], delta);
+    }
+    return r;
+  }
+};
+
+// XYZZ: x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; identity <=> ZZ = 0.  Affine bases: (0, 0) = infinity.
+template <class C> struct G1Curve {
+  using Fq = typename C::Fq;
+  static constexpr int N = Fq::N;
+  using el = fpn<N>;
+  struct base_t { el x, y; };
+  struct acc_t { el x, y, zz, zzz; };
+  static constexpr int BASE_WORDS = 2 * N, ACC_WORDS = 4 * N;
+
+  static AVRF_DI acc_t identity() { acc_t r; r.x = fn_one<Fq>(); r.y = fn_one<Fq>(); r.zz = fn_zero<N>(); r.zzz = fn_zero<N>(); return r; }
+  static AVRF_DI bool is_identity(const acc_t &a) { return fn_is_zero(a.zz); }
+  static AVRF_DI acc_t from_affine(const base_t &q) {
+    acc_t r; r.x = q.x; r.y = q.y; r.zz = fn_one<Fq>(); r.zzz = fn_one<Fq>();
+    if (fn_is_zero(q.x) && fn_is_zero(q.y)) { r.zz = fn_zero<N>(); r.zzz = fn_zero<N>(); }
+    return r;
+  }
+  // 2 * (affine q)  (mdbl-2008-s-1, a = 0)
+  static AVRF_DI acc_t dbl_affine(const base_t &q) {
+    el U = fn_dbl<Fq>(q.y), V = fn_sqr<Fq>(U), W = fn_mul<Fq>(U, V), S = fn_mul<Fq>(q.x, V);
+    el X2 = fn_sqr<Fq>(q.x), M = fn_add<Fq>(fn_dbl<Fq>(X2), X2);
+    acc_t r;
+    r.x = fn_sub<Fq>(fn_sqr<Fq>(M), fn_dbl<Fq>(S));
+    r.y = fn_sub<Fq>(fn_mul<Fq>(M, fn_sub<Fq>(S, r.x)), fn_mul<Fq>(W, q.y));
+    r.zz = V; r.zzz = W;
+    if (fn_is_zero(q.y)) return identity();
+    return r;
+  }
+  // 2 * a  (dbl-2008-s-1, a = 0)
+  static AVRF_DI acc_t dbl(const acc_t &a) {
+    el U = fn_dbl<Fq>(a.y), V = fn_sqr<Fq>(U), W = fn_mul<Fq>(U, V), S = fn_mul<Fq>(a.x, V);
+    el X2 = fn_sqr<Fq>(a.x), M = fn_add<Fq>(fn_dbl<Fq>(X2), X2);
+    acc_t r;
+    r.x = fn_sub<Fq>(fn_sqr<Fq>(M), fn_dbl<Fq>(S));
+    r.y = fn_sub<Fq>(fn_mul<Fq>(M, fn_sub<Fq>(S, r.x)), fn_mul<Fq>(W, a.y));
+    r.zz = fn_mul<Fq>(V, a.zz); r.zzz = fn_mul<Fq>(W, a.zzz);
+    return r;                                     // a identity (zz = 0) or y = 0 -> zz = 0: identity
+  }
+  // a + (neg ? -q : q), q affine  (madd-2008-s: 8M + 2S), with the exceptional cases handled
+  static AVRF_DI acc_t madd(const acc_t &a, base_t q, bool neg) {
+    if (neg) q.y = fn_neg<Fq>(q.y);
+    const bool q_inf = fn_is_zero(q.x) && fn_is_zero(q.y);
+    const bool a_inf = is_identity(a);
+    el U2 = fn_mul<Fq>(q.x, a.zz), S2 = fn_mul<Fq>(q.y, a.zzz);
+    el P = fn_sub<Fq>(U2, a.x), R = fn_sub<Fq>(S2, a.y);
+    el PP = fn_sqr<Fq>(P), PPP = fn_mul<Fq>(P, PP), Q = fn_mul<Fq>(a.x, PP);
+    acc_t r;
+    r.x = fn_sub<Fq>(fn_sub<Fq>(fn_sqr<Fq>(R), PPP), fn_dbl<Fq>(Q));
+    r.y = fn_sub<Fq>(fn_mul<Fq>(R, fn_sub<Fq>(Q, r.x)), fn_mul<Fq>(a.y, PPP));
+    r.zz = fn_mul<Fq>(a.zz, PP); r.zzz = fn_mul<Fq>(a.zzz, PPP);
+    if (q_inf) return a;
+    if (a_inf) return from_affine(q);
+    if (fn_is_zero(P)) return fn_is_zero(R) ? dbl_affine(q) : identity();
+    return r;
+  }
+  // a + b  (add-2008-s: 12M + 2S)
+  static AVRF_DI acc_t add(const acc_t &a, const acc_t &b) {
+    const bool a_inf = is_identity(a), b_inf = is_identity(b);
+    el U1 = fn_mul<Fq>(a.x, b.zz), U2 = fn_mul<Fq>(b.x, a.zz);
+    el S1 = fn_mul<Fq>(a.y, b.zzz), S2 = fn_mul<Fq>(b.y, a.zzz);
+    el P = fn_sub<Fq>(U2, U1), R = fn_sub<Fq>(S2, S1);
+    el PP = fn_sqr<Fq>(P), PPP = fn_mul<Fq>(P, PP), Q = fn_mul<Fq>(U1, PP);
+    acc_t r;
+    r.x = fn_sub<Fq>(fn_sub<Fq>(fn_sqr<Fq>(R), PPP), fn_dbl<Fq>(Q));
+    r.y = fn_sub<Fq>(fn_mul<Fq>(R, fn_sub<Fq>(Q, r.x)), fn_mul<Fq>(S1, PPP));
+    r.zz = fn_mul<Fq>(fn_mul<Fq>(a.zz, b.zz), PP); r.zzz = fn_mul<Fq>(fn_mul<Fq>(a.zzz, b.zzz), PPP);
+    if (a_inf) return b;
+    if (b_inf) return a;
+    if (fn_is_zero(P)) return fn_is_zero(R) ? dbl(a) : identity();
+    return r;
+  }
+  static AVRF_DI base_t load_base(const uint32_t *p) { base_t r; r.x = fn_load<N>(p); r.y = fn_load<N>(p + N); return r; }
+  static AVRF_DI acc_t load_acc(const uint32_t *p) {
+    acc_t r; r.x = fn_load<N>(p); r.y = fn_load<N>(p + N); r.zz = fn_load<N>(p + 2 * N); r.zzz = fn_load<N>(p + 3 * N); return r;
+  }
+  static AVRF_DI void store_acc(uint32_t *p, const acc_t &a) {
+    fn_store<N>(p, a.x); fn_store<N>(p + N, a.y); fn_store<N>(p + 2 * N, a.zz); fn_store<N>(p + 3 * N, a.zzz);
+  }
+  static AVRF_DI acc_t shfl_down(const acc_t &a, int delta) {
+    acc_t r; r.x = fn_shfl_down<N>(a.x, delta); r.y = fn_shfl_down<N>(a.y, delta);
+    r.zz = fn_shfl_down<N>(a.zz, delta); r.zzz = fn_shfl_down<N>(a.zzz, delta); return r;
+  }
+};
+
+}  // namespace avrf

@@ -1,0 +1,123 @@
+// fpn.h -- N x u32-limb prime-field arithmetic for gfx950 VALU (Montgomery, R = 2^(32 N)); N = 12 for the
+// BLS12-381 base field (381 bits), N = 8 for BN254's.  Device counterpart of arkworks
+// `Fp<MontBackend<_, 6>>` / `<_, 4>` behind the KZG commit/open MSMs of the ring SNARK
+// (w3f-ring-proof, reached from src/ring.rs:220,404,416,731).  Same carry-free CIOS as fp256.h
+// (every modulus on the path leaves its top limb's high bit clear).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "consts_gen.h"
+
+namespace avrf {
+
+#ifndef AVRF_DI
+#define AVRF_DI __device__ __forceinline__
+#endif
+
+template <int N> struct fpn { uint32_t v[N]; };
+template <class F> using fe = fpn<F::N>;
+
+template <int N> AVRF_DI fpn<N> fn_zero() { fpn<N> r;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = 0;
+  return r; }
+template <class F> AVRF_DI fe<F> fn_const(const uint32_t (&c)[F::N]) { fe<F> r;
+#pragma unroll
+  for (int i = 0; i < F::N; i++) r.v[i] = c[i];
+  return r; }
+template <class F> AVRF_DI fe<F> fn_one() { return fn_const<F>(F::ONE); }
+template <int N> AVRF_DI bool fn_is_zero(const fpn<N> &a) { uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) o |= a.v[i];
+  return o == 0; }
+template <int N> AVRF_DI bool fn_eq(const fpn<N> &a, const fpn<N> &b) { uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) o |= a.v[i] ^ b.v[i];
+  return o == 0; }
+
+template <class F> AVRF_DI uint32_t fn_sub_p(fe<F> &r, const fe<F> &a) {
+  int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < F::N; i++) { c += (int64_t)a.v[i] - (int64_t)F::P[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+  return (uint32_t)(c & 1);
+}
+template <class F> AVRF_DI bool fn_ge_p(const fe<F> &a) { fe<F> t; return fn_sub_p<F>(t, a) == 0; }
+template <class F> AVRF_DI fe<F> fn_add(const fe<F> &a, const fe<F> &b) {
+  fe<F> t, u; uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < F::N; i++) { c += (uint64_t)a.v[i] + b.v[i]; t.v[i] = (uint32_t)c; c >>= 32; }
+  uint32_t br = fn_sub_p<F>(u, t);
+#pragma unroll
+  for (int i = 0; i < F::N; i++) t.v[i] = br ? t.v[i] : u.v[i];
+  return t;
+}
+template <class F> AVRF_DI fe<F> fn_sub(const fe<F> &a, const fe<F> &b) {
+  fe<F> t; int64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < F::N; i++) { c += (int64_t)a.v[i] - (int64_t)b.v[i]; t.v[i] = (uint32_t)c; c >>= 32; }
+  uint32_t br = (uint32_t)(c & 1);
+  uint64_t d = 0;
+#pragma unroll
+  for (int i = 0; i < F::N; i++) { d += (uint64_t)t.v[i] + (br ? F::P[i] : 0u); t.v[i] = (uint32_t)d; d >>= 32; }
+  return t;
+}
+template <class F> AVRF_DI fe<F> fn_neg(const fe<F> &a) {
+  fe<F> t; int64_t c = 0; bool z = fn_is_zero(a);
+#pragma unroll
+  for (int i = 0; i < F::N; i++) { c += (int64_t)F::P[i] - (int64_t)a.v[i]; t.v[i] = z ? 0u : (uint32_t)c; c >>= 32; }
+  return t;
+}
+template <class F> AVRF_DI fe<F> fn_dbl(const fe<F> &a) { return fn_add<F>(a, a); }
+
+template <class F> AVRF_DI fe<F> fn_mul(const fe<F> &a, const fe<F> &b) {
+  constexpr int N = F::N;
+  uint32_t t[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    uint64_t A = (uint64_t)a.v[0] * b.v[i] + t[0];
+    uint32_t m = (uint32_t)A * F::NINV;
+    uint64_t C = (uint64_t)m * F::P[0] + (uint32_t)A;
+    A >>= 32; C >>= 32;
+#pragma unroll
+    for (int j = 1; j < N; j++) {
+      A += (uint64_t)a.v[j] * b.v[i] + t[j];
+      C += (uint64_t)m * F::P[j] + (uint32_t)A;
+      t[j - 1] = (uint32_t)C;
+      A >>= 32; C >>= 32;
+    }
+    t[N - 1] = (uint32_t)(A + C);
+  }
+  fe<F> r, u;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = t[i];
+  uint32_t br = fn_sub_p<F>(u, r);
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = br ? r.v[i] : u.v[i];
+  return r;
+}
+template <class F> AVRF_DI fe<F> fn_sqr(const fe<F> &a) { return fn_mul<F>(a, a); }
+template <class F> AVRF_DI fe<F> fn_to_mont(const fe<F> &a) { return fn_mul<F>(a, fn_const<F>(F::R2)); }
+template <class F> AVRF_DI fe<F> fn_from_mont(const fe<F> &a) { fe<F> one = fn_zero<F::N>(); one.v[0] = 1; return fn_mul<F>(a, one); }
+
+// 16-byte vectorised global loads / stores (N is a multiple of 4)
+template <int N> AVRF_DI fpn<N> fn_load(const uint32_t *s) {
+  fpn<N> r; const uint4 *s4 = reinterpret_cast<const uint4 *>(s);
+#pragma unroll
+  for (int i = 0; i < N / 4; i++) { uint4 q = s4[i]; r.v[4 * i] = q.x; r.v[4 * i + 1] = q.y; r.v[4 * i + 2] = q.z; r.v[4 * i + 3] = q.w; }
+  return r;
+}
+template <int N> AVRF_DI void fn_store(uint32_t *d, const fpn<N> &a) {
+  uint4 *d4 = reinterpret_cast<uint4 *>(d);
+#pragma unroll
+  for (int i = 0; i < N / 4; i++) d4[i] = make_uint4(a.v[4 * i], a.v[4 * i + 1], a.v[4 * i + 2], a.v[4 * i + 3]);
+}
+template <int N> AVRF_DI fpn<N> fn_shfl_down(const fpn<N> &a, int delta) {
+  fpn<N> r;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = __shfl_down(a.v[i], delta);
+  return r;
+}
+
+}  // namespace avrf

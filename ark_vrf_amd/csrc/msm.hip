@@ -26,7 +26,8 @@
 // Layout in HBM: points AoS te_pre (x|y|k, 96 B, gathered whole by one lane with 6 dwordx4
 // loads); keys/sorted SoA per window (coalesced); buckets AoS te_ext (128 B).
 #include "msm.h"
-#include "te.h"
+#include "curves.h"
+#include "host_g1.h"
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -160,35 +161,25 @@ k_scatter(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int 
   }
 }
 
-// ---------------------------------------------------------------- bucket accumulation
-
-AVRF_DI te_ext shfl_down_ext(const te_ext &p, int delta) {
-  te_ext r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    r.x.v[i] = __shfl_down(p.x.v[i], delta); r.y.v[i] = __shfl_down(p.y.v[i], delta);
-    r.t.v[i] = __shfl_down(p.t.v[i], delta); r.z.v[i] = __shfl_down(p.z.v[i], delta);
-  }
-  return r;
-}
+// ---------------------------------------------------------------- bucket accumulation (curve-generic)
 
 // Lane t = w * lcap + lt owns a segment of the bucket `slot` of window w with
 // lane_off[slot] <= lt < lane_off[slot] + lanes(slot).  part[2*wave + k]: partial of the run of wave
 // `wave` that includes lane 0 (k = 0) or that starts later and runs past lane 63 (k = 1); complete
 // runs are written straight to buckets[].  lcap is a multiple of 64 (a wave never spans two windows).
-template <class S>
+template <class CV>
 __global__ void __launch_bounds__(256)
-k_accumulate(const te_pre *__restrict__ pre, const uint32_t *__restrict__ sorted,
+k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
              const uint32_t *__restrict__ offs, const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off,
              const uint32_t *__restrict__ lane_tot, uint32_t nwin, uint32_t nb, uint32_t lcap, uint32_t seg,
-             te_ext *__restrict__ buckets, te_ext *__restrict__ part) {
-  using Fq = typename S::Fq;
+             uint32_t *__restrict__ buckets, uint32_t *__restrict__ part) {
+  using acc_t = typename CV::acc_t; using base_t = typename CV::base_t;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63, wave = t >> 6;
   const uint32_t w = t / lcap, lt = t - w * lcap;
   const bool live = w < nwin && lt < lane_tot[w];
   uint32_t slot = 0xffffffffu, l0 = 0, nl = 0;
-  te_ext acc = te_identity<S>();
+  acc_t acc = CV::identity();
   if (live) {
     const uint32_t *lo_w = lane_off + (size_t)w * nb;
     uint32_t lo = 0, hi = nb;                           // last bucket with lane_off <= lt
@@ -201,12 +192,11 @@ k_accumulate(const te_pre *__restrict__ pre, const uint32_t *__restrict__ sorted
     // software-pipelined gather: the next base is in flight while the current addition runs
     if (b < e) {
       uint32_t idx = sorted[b];
-      te_pre q = load_pre(pre + (idx & 0x7fffffffu));
+      base_t q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS);
       for (uint32_t i = b; i < e; i++) {
-        const uint32_t cidx = idx; te_pre cur = q;
-        if (i + 1 < e) { idx = sorted[i + 1]; q = load_pre(pre + (idx & 0x7fffffffu)); }
-        if (cidx & 0x80000000u) { cur.x = fp_neg<Fq>(cur.x); cur.k = fp_neg<Fq>(cur.k); }
-        acc = te_madd<S>(acc, cur);
+        const uint32_t cidx = idx; const base_t cur = q;
+        if (i + 1 < e) { idx = sorted[i + 1]; q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS); }
+        acc = CV::madd(acc, cur, (cidx & 0x80000000u) != 0);
       }
     }
   }
@@ -215,80 +205,80 @@ k_accumulate(const te_pre *__restrict__ pre, const uint32_t *__restrict__ sorted
     uint32_t oslot = __shfl_down(slot, off);
     bool take = live && (lane + off < 64) && (oslot == slot);
     if (!__any(take)) break;                            // no run in this wave is longer than `off`
-    te_ext o = shfl_down_ext(acc, off);
-    if (take) acc = te_add<S>(acc, o);
+    acc_t o = CV::shfl_down(acc, off);
+    if (take) acc = CV::add(acc, o);
   }
   uint32_t pslot = __shfl_up(slot, 1);
   bool head = live && (lane == 0 || pslot != slot);
   if (head) {
     uint32_t g0 = w * lcap + l0, wbase = wave << 6;
     bool complete = (g0 >= wbase) && (g0 + nl <= wbase + 64);
-    if (complete) store_ext(buckets + slot, acc);
-    else store_ext(part + 2 * (size_t)wave + (lane == 0 ? 0 : 1), acc);
+    if (complete) CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, acc);
+    else CV::store_acc(part + (2 * (size_t)wave + (lane == 0 ? 0 : 1)) * CV::ACC_WORDS, acc);
   }
 }
 
-template <class S>
+template <class CV>
 __global__ void __launch_bounds__(256)
 k_fixup(const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off, uint32_t nslots, uint32_t nb,
-        uint32_t lcap, uint32_t seg, const te_ext *__restrict__ part, te_ext *__restrict__ buckets) {
+        uint32_t lcap, uint32_t seg, const uint32_t *__restrict__ part, uint32_t *__restrict__ buckets) {
   uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= nslots) return;
   uint32_t cnt = cnts[slot], nl = (cnt + seg - 1) / seg;
-  if (nl == 0) { store_ext(buckets + slot, te_identity<S>()); return; }
+  if (nl == 0) { CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, CV::identity()); return; }
   uint32_t g0 = (slot / nb) * lcap + lane_off[slot];
   uint32_t wa = g0 >> 6, wb = (g0 + nl - 1) >> 6;
   if (wa == wb) return;                                  // complete inside one wave: already written
-  te_ext acc = load_ext(part + 2 * (size_t)wa + ((g0 & 63) == 0 ? 0 : 1));
-  for (uint32_t wv = wa + 1; wv <= wb; wv++) acc = te_add<S>(acc, load_ext(part + 2 * (size_t)wv));
-  store_ext(buckets + slot, acc);
+  typename CV::acc_t acc = CV::load_acc(part + (2 * (size_t)wa + ((g0 & 63) == 0 ? 0 : 1)) * CV::ACC_WORDS);
+  for (uint32_t wv = wa + 1; wv <= wb; wv++) acc = CV::add(acc, CV::load_acc(part + 2 * (size_t)wv * CV::ACC_WORDS));
+  CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, acc);
 }
 
 // ---------------------------------------------------------------- bucket reduction by index bits
 
-template <class S> AVRF_DI te_ext wave_sum(te_ext acc) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) acc = te_add<S>(acc, shfl_down_ext(acc, off));
+template <class CV> AVRF_DI typename CV::acc_t wave_sum(typename CV::acc_t acc) {
+#pragma unroll 1
+  for (int off = 32; off >= 1; off >>= 1) acc = CV::add(acc, CV::shfl_down(acc, off));
   return acc;                                             // valid in lane 0
 }
 
 // Bucket index b in [1, nb-1] (nb = 2^(c-1)) split as b = hi * 2^h + lo; B_0 = identity.
 // One wave per task: tasks [0, NR) are row sums R_hi (2^h contiguous buckets), tasks [NR, NR+NC)
 // are column sums C_lo (stride 2^h).  rc[w * (NR+NC) + task].
-template <class S>
+template <class CV>
 __global__ void __launch_bounds__(256)
-k_rowcol(const te_ext *__restrict__ buckets, int c, int h, uint32_t total_waves, te_ext *__restrict__ rc) {
+k_rowcol(const uint32_t *__restrict__ buckets, int c, int h, uint32_t total_waves, uint32_t *__restrict__ rc) {
   const uint32_t nb = 1u << (c - 1), NC = 1u << h, NR = nb >> h;
   const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (gw >= total_waves) return;
   const uint32_t tasks = NR + NC, w = gw / tasks, task = gw - w * tasks;
-  const te_ext *B = buckets + (size_t)w * nb;              // B[b-1]
-  te_ext acc = te_identity<S>();
+  const uint32_t *B = buckets + (size_t)w * nb * CV::ACC_WORDS;              // B[b-1]
+  typename CV::acc_t acc = CV::identity();
   if (task < NR) {
-    for (uint32_t lo = lane; lo < NC; lo += 64) { uint32_t b = task * NC + lo; if (b >= 1) acc = te_add<S>(acc, load_ext(B + (b - 1))); }
+    for (uint32_t lo = lane; lo < NC; lo += 64) { uint32_t b = task * NC + lo; if (b >= 1) acc = CV::add(acc, CV::load_acc(B + (size_t)(b - 1) * CV::ACC_WORDS)); }
   } else {
     uint32_t lo = task - NR;
-    for (uint32_t hi = lane; hi < NR; hi += 64) { uint32_t b = hi * NC + lo; if (b >= 1) acc = te_add<S>(acc, load_ext(B + (b - 1))); }
+    for (uint32_t hi = lane; hi < NR; hi += 64) { uint32_t b = hi * NC + lo; if (b >= 1) acc = CV::add(acc, CV::load_acc(B + (size_t)(b - 1) * CV::ACC_WORDS)); }
   }
-  acc = wave_sum<S>(acc);
-  if (lane == 0) store_ext(rc + gw, acc);
+  acc = wave_sum<CV>(acc);
+  if (lane == 0) CV::store_acc(rc + (size_t)gw * CV::ACC_WORDS, acc);
 }
 
 // One wave per (window, bit k), k in [0, c): out[w*c + k] = T_k.
-template <class S>
+template <class CV>
 __global__ void __launch_bounds__(256)
-k_bits(const te_ext *__restrict__ buckets, const te_ext *__restrict__ rc, int c, int h, uint32_t total_waves, te_ext *__restrict__ out) {
+k_bits(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ rc, int c, int h, uint32_t total_waves, uint32_t *__restrict__ out) {
   const uint32_t nb = 1u << (c - 1), NC = 1u << h, NR = nb >> h;
   const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (gw >= total_waves) return;
   const uint32_t w = gw / c, k = gw - w * c;
-  const te_ext *RC = rc + (size_t)w * (NR + NC);
-  te_ext acc = te_identity<S>();
-  if ((int)k == c - 1) { if (lane == 0) acc = load_ext(buckets + (size_t)w * nb + (nb - 1)); }   // only b = nb
-  else if ((int)k < h) { for (uint32_t lo = lane; lo < NC; lo += 64) if ((lo >> k) & 1) acc = te_add<S>(acc, load_ext(RC + NR + lo)); }
-  else { uint32_t kk = k - h; for (uint32_t hi = lane; hi < NR; hi += 64) if ((hi >> kk) & 1) acc = te_add<S>(acc, load_ext(RC + hi)); }
-  acc = wave_sum<S>(acc);
-  if (lane == 0) store_ext(out + gw, acc);
+  const uint32_t *RC = rc + (size_t)w * (NR + NC) * CV::ACC_WORDS;
+  typename CV::acc_t acc = CV::identity();
+  if ((int)k == c - 1) { if (lane == 0) acc = CV::load_acc(buckets + ((size_t)w * nb + (nb - 1)) * CV::ACC_WORDS); }   // only b = nb
+  else if ((int)k < h) { for (uint32_t lo = lane; lo < NC; lo += 64) if ((lo >> k) & 1) acc = CV::add(acc, CV::load_acc(RC + (size_t)(NR + lo) * CV::ACC_WORDS)); }
+  else { uint32_t kk = k - h; for (uint32_t hi = lane; hi < NR; hi += 64) if ((hi >> kk) & 1) acc = CV::add(acc, CV::load_acc(RC + (size_t)hi * CV::ACC_WORDS)); }
+  acc = wave_sum<CV>(acc);
+  if (lane == 0) CV::store_acc(out + (size_t)gw * CV::ACC_WORDS, acc);
 }
 
 // ---------------------------------------------------------------- host engine
@@ -308,7 +298,7 @@ MsmPlan msm_plan(size_t n, int scalar_bits) {
 static uint32_t tile_len_for(size_t n) { return 8192; }
 static uint32_t lcap_for(size_t n, const MsmPlan &p) { return (uint32_t)(((n / (size_t)p.lpb + p.nb + 1) + 63) / 64 * 64); }
 
-void MsmWorkspace::ensure(size_t n, const MsmPlan &p) {
+void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes) {
   size_t nbk = (size_t)p.nwin * p.nb, nbits = (size_t)p.nwin * p.c;
   size_t need_n = (size_t)p.nwin * n;
   size_t ntiles = (n + tile_len_for(n) - 1) / tile_len_for(n);
@@ -323,31 +313,34 @@ void MsmWorkspace::ensure(size_t n, const MsmPlan &p) {
     HIP_CHECK(hipMalloc(&hist, nbk * ntiles * 4));
     cap_hist = nbk * ntiles;
   }
-  if (nbk > cap_buckets) {
+  if (nbk > cap_slots) {
     if (cnts) HIP_CHECK(hipFree(cnts));
     if (offsets) HIP_CHECK(hipFree(offsets));
     if (lane_off) HIP_CHECK(hipFree(lane_off));
     if (lane_tot) HIP_CHECK(hipFree(lane_tot));
-    if (buckets) HIP_CHECK(hipFree(buckets));
-    if (rc) HIP_CHECK(hipFree(rc));
     HIP_CHECK(hipMalloc(&cnts, nbk * 4)); HIP_CHECK(hipMalloc(&offsets, nbk * 4)); HIP_CHECK(hipMalloc(&lane_off, nbk * 4));
     HIP_CHECK(hipMalloc(&lane_tot, 64 * 4 * 8));
-    HIP_CHECK(hipMalloc(&buckets, nbk * sizeof(te_ext_raw)));
-    HIP_CHECK(hipMalloc(&rc, nbk * sizeof(te_ext_raw)));       // >= nwin * (NR + NC)
-    cap_buckets = nbk;
+    cap_slots = nbk;
   }
-  size_t need_part = 2 * ((size_t)p.nwin * lcap_for(n, p) / 64 + 2);
+  if (nbk * acc_bytes > cap_buckets) {
+    if (buckets) HIP_CHECK(hipFree(buckets));
+    if (rc) HIP_CHECK(hipFree(rc));
+    HIP_CHECK(hipMalloc(&buckets, nbk * acc_bytes));
+    HIP_CHECK(hipMalloc(&rc, nbk * acc_bytes));               // >= nwin * (NR + NC)
+    cap_buckets = nbk * acc_bytes;
+  }
+  size_t need_part = 2 * ((size_t)p.nwin * lcap_for(n, p) / 64 + 2) * acc_bytes;
   if (need_part > cap_part) {
     if (part) HIP_CHECK(hipFree(part));
-    HIP_CHECK(hipMalloc(&part, need_part * sizeof(te_ext_raw)));
+    HIP_CHECK(hipMalloc(&part, need_part));
     cap_part = need_part;
   }
-  if (nbits > cap_bits) {
+  if (nbits * acc_bytes > cap_bits) {
     if (bits) HIP_CHECK(hipFree(bits));
     if (bits_host) HIP_CHECK(hipHostFree(bits_host));
-    HIP_CHECK(hipMalloc(&bits, nbits * sizeof(te_ext_raw)));
-    HIP_CHECK(hipHostMalloc(&bits_host, nbits * sizeof(te_ext_raw)));
-    cap_bits = nbits;
+    HIP_CHECK(hipMalloc(&bits, nbits * acc_bytes));
+    HIP_CHECK(hipHostMalloc(&bits_host, nbits * acc_bytes));
+    cap_bits = nbits * acc_bytes;
   }
 }
 void MsmWorkspace::release() {
@@ -357,17 +350,16 @@ void MsmWorkspace::release() {
   if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr;
   keys = nullptr; sorted = hist = cnts = offsets = lane_off = lane_tot = nullptr;
   buckets = rc = part = bits = bits_host = nullptr;
-  cap_n = cap_buckets = cap_bits = cap_part = cap_hist = 0;
+  cap_n = cap_slots = cap_buckets = cap_bits = cap_part = cap_hist = 0;
 }
 
-template <class S>
-static int msm_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws,
-                    hipStream_t stream, HostExt *out) {
-  using HT = HostTe<S>;
-  *out = HT::identity();
-  if (n == 0) return 0;
-  MsmPlan p = msm_plan(n, S::Fr::BITS);
-  ws.ensure(n, p);
+// Runs the whole device pipeline for one MSM and leaves the nwin*c bit sums T_p in ws.bits_host
+// (accumulator layout of CV); returns the number of bit sums.
+template <class CV>
+static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, int scalar_bits, MsmWorkspace &ws, hipStream_t stream) {
+  MsmPlan p = msm_plan(n, scalar_bits);
+  const size_t acc_bytes = (size_t)CV::ACC_WORDS * 4;
+  ws.ensure(n, p, acc_bytes);
   const uint32_t nbk = (uint32_t)p.nwin * p.nb, seg = (uint32_t)p.lpb;
   const uint32_t tile_len = tile_len_for(n), ntiles = (uint32_t)((n + tile_len - 1) / tile_len);
   const uint32_t lcap = lcap_for(n, p);
@@ -378,30 +370,40 @@ static int msm_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n
   hipLaunchKernelGGL(k_scan_win, dim3(p.nwin), dim3(1024), 0, stream, ws.hist, (uint32_t)n, ntiles, p.c, seg,
                      ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot);
   hipLaunchKernelGGL(k_scatter, dim3(ntiles, p.nwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist, ws.offsets, ws.sorted);
-  const te_pre *pre = (const te_pre *)d_pre;
-  te_ext *bk = (te_ext *)ws.buckets;
   dim3 ga((unsigned)(((size_t)p.nwin * lcap + 255) / 256));
   if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
   HIP_CHECK(hipEventRecord(ws.ev0, stream));
-  hipLaunchKernelGGL(k_accumulate<S>, ga, b256, 0, stream, pre, ws.sorted, ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot,
-                     (uint32_t)p.nwin, (uint32_t)p.nb, lcap, seg, bk, (te_ext *)ws.part);
+  hipLaunchKernelGGL(k_accumulate<CV>, ga, b256, 0, stream, d_bases, ws.sorted, ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot,
+                     (uint32_t)p.nwin, (uint32_t)p.nb, lcap, seg, ws.buckets, ws.part);
   HIP_CHECK(hipEventRecord(ws.ev1, stream));
-  hipLaunchKernelGGL(k_fixup<S>, dim3((nbk + 255) / 256), b256, 0, stream, ws.cnts, ws.lane_off, nbk, (uint32_t)p.nb, lcap, seg,
-                     (const te_ext *)ws.part, bk);
+  hipLaunchKernelGGL(k_fixup<CV>, dim3((nbk + 255) / 256), b256, 0, stream, ws.cnts, ws.lane_off, nbk, (uint32_t)p.nb, lcap, seg,
+                     (const uint32_t *)ws.part, ws.buckets);
   const int h = (p.c - 1) / 2;
   const uint32_t tasks = (1u << h) + ((uint32_t)p.nb >> h);
-  hipLaunchKernelGGL(k_rowcol<S>, dim3(((size_t)p.nwin * tasks * 64 + 255) / 256), b256, 0, stream, bk, p.c, h, (uint32_t)p.nwin * tasks, (te_ext *)ws.rc);
+  hipLaunchKernelGGL(k_rowcol<CV>, dim3(((size_t)p.nwin * tasks * 64 + 255) / 256), b256, 0, stream, (const uint32_t *)ws.buckets, p.c, h,
+                     (uint32_t)p.nwin * tasks, ws.rc);
   const int nbits = p.nwin * p.c;
-  hipLaunchKernelGGL(k_bits<S>, dim3(((size_t)nbits * 64 + 255) / 256), b256, 0, stream, bk, (const te_ext *)ws.rc, p.c, h, (uint32_t)nbits, (te_ext *)ws.bits);
-  HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.bits, (size_t)nbits * sizeof(te_ext_raw), hipMemcpyDeviceToHost, stream));
+  hipLaunchKernelGGL(k_bits<CV>, dim3(((size_t)nbits * 64 + 255) / 256), b256, 0, stream, (const uint32_t *)ws.buckets, (const uint32_t *)ws.rc,
+                     p.c, h, (uint32_t)nbits, ws.bits);
+  HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.bits, (size_t)nbits * acc_bytes, hipMemcpyDeviceToHost, stream));
   HIP_CHECK(hipStreamSynchronize(stream));
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventElapsedTime(&ws.accum_ms_last, ws.ev0, ws.ev1));
   ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = p;
+  return nbits;
+}
+
+template <class S>
+static int msm_te_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, HostExt *out) {
+  using HT = HostTe<S>;
+  *out = HT::identity();
+  if (n == 0) return 0;
+  int nbits = msm_device<TeCurve<S>>((const uint32_t *)d_pre, d_scalars, n, S::Fr::BITS, ws, stream);
   HostExt acc = HT::identity();
-  for (int i = nbits - 1; i >= 0; i--) {
+  const uint32_t *bh = ws.bits_host;
+  for (int i = nbits - 1; i >= 0; i--) {                  // sum_p 2^p T_p
     acc = HT::dbl(acc);
-    acc = HT::add(acc, HT::from_raw32(ws.bits_host[i].w));
+    acc = HT::add(acc, HT::from_raw32(bh + (size_t)i * 32));
   }
   *out = acc;
   return 0;
@@ -409,8 +411,51 @@ static int msm_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n
 
 int msm_te_device(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n,
                   MsmWorkspace &ws, hipStream_t stream, HostExt *out) {
-  if (suite == 0) return msm_impl<SuiteBandersnatch>(d_pre, d_scalars, n, ws, stream, out);
-  if (suite == 1) return msm_impl<SuiteBabyJubJub>(d_pre, d_scalars, n, ws, stream, out);
+  if (suite == 0) return msm_te_impl<SuiteBandersnatch>(d_pre, d_scalars, n, ws, stream, out);
+  if (suite == 1) return msm_te_impl<SuiteBabyJubJub>(d_pre, d_scalars, n, ws, stream, out);
+  return -1;
+}
+
+// ---------------------------------------------------------------- G1 (KZG) MSM
+
+// canonical affine coordinates (x || y, FQ_BYTES little-endian each; (0,0) = infinity) -> Montgomery bases
+template <class C>
+__global__ void k_g1_bases(const uint8_t *__restrict__ xy, uint32_t n, uint32_t *__restrict__ out, uint32_t *__restrict__ flag) {
+  using Fq = typename C::Fq; constexpr int N = Fq::N;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(xy + (size_t)i * N * 8);
+  fpn<N> x = fn_load<N>(src), y = fn_load<N>(src + N);
+  if (fn_ge_p<Fq>(x) || fn_ge_p<Fq>(y)) atomicOr(flag, 1u);
+  fn_store<N>(out + (size_t)i * 2 * N, fn_to_mont<Fq>(x)); fn_store<N>(out + (size_t)i * 2 * N + N, fn_to_mont<Fq>(y));
+}
+
+template <class C>
+static int msm_g1_impl(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy) {
+  using HG = HostG1<C>;
+  typename HG::Pt acc = HG::identity();
+  if (n) {
+    int nbits = msm_device<G1Curve<C>>(d_bases, d_scalars, n, C::Fr::BITS, ws, stream);
+    const uint32_t *bh = ws.bits_host;
+    for (int i = nbits - 1; i >= 0; i--) {
+      acc = HG::dbl(acc);
+      acc = HG::add(acc, HG::from_raw32(bh + (size_t)i * 4 * C::Fq::N));
+    }
+  }
+  HG::to_affine_bytes(acc, out_xy);
+  return 0;
+}
+
+void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, uint32_t *d_flag, hipStream_t stream) {
+  if (!n) return;
+  dim3 g((unsigned)((n + 255) / 256)), b(256);
+  if (curve == 0) hipLaunchKernelGGL(k_g1_bases<G1Bls12381>, g, b, 0, stream, d_xy, (uint32_t)n, d_out, d_flag);
+  else hipLaunchKernelGGL(k_g1_bases<G1Bn254>, g, b, 0, stream, d_xy, (uint32_t)n, d_out, d_flag);
+}
+
+int msm_g1_device(int curve, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy) {
+  if (curve == 0) return msm_g1_impl<G1Bls12381>(d_bases, d_scalars, n, ws, stream, out_xy);
+  if (curve == 1) return msm_g1_impl<G1Bn254>(d_bases, d_scalars, n, ws, stream, out_xy);
   return -1;
 }
 

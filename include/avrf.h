@@ -61,6 +61,12 @@ void avrf_ctx_destroy(avrf_ctx *ctx);
  * "unchecked": no subgroup check; off-range coordinates / scalars give AVRF_INVALID_DATA. */
 int avrf_msm_te(avrf_ctx *ctx, size_t n, const uint8_t *bases_xy, const uint8_t *scalars, uint8_t out_xy[64]);
 
+/* <E::G1 as VariableBaseMSM>::msm on the suite's pairing curve (BLS12-381 for Bandersnatch, BN254 for
+ * Baby-JubJub) -- the KZG commit/open MSMs inside w3f-ring-proof reached from src/ring.rs:220,404,416,731.
+ * bases_xy: n x (2*FQ) bytes, canonical little-endian x || y (FQ = 48 / 32), all-zero = point at infinity;
+ * scalars: n x 32 (< r of the pairing curve); out_xy: same point format. */
+int avrf_g1_msm(avrf_ctx *ctx, size_t n, const uint8_t *bases_xy, const uint8_t *scalars, uint8_t *out_xy);
+
 /* thin::BatchVerifier::{new, push*, verify}  (src/thin.rs:188-326).
  * n items; item j has io_counts[j] VRF I/O pairs; ios_xy holds sum(io_counts) pairs as
  * input_xy(64) || output_xy(64); ads holds the concatenated additional-data strings with
