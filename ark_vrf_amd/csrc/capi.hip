@@ -80,6 +80,11 @@ static BatchDev batch_of(avrf_ctx *c) {
 
 extern "C" {
 
+// accessors for the other translation units of the library (ring.hip)
+hipStream_t avrf_ctx_stream_(avrf_ctx *c) { return c->stream; }
+int avrf_ctx_suite_(avrf_ctx *c) { return c->suite; }
+int avrf_ctx_device_(avrf_ctx *c) { return c->device; }
+
 const char *avrf_version(void) { return "avrf 0.2 (gfx950; te-msm, thin/pedersen prove+verify+batch)"; }
 
 int avrf_device_count(void) {

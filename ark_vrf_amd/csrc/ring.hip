@@ -1,0 +1,514 @@
+// ring.hip -- Ring-VRF membership SNARK: setup (SRS), ring indexing (`ring_proof::index`,
+// src/ring.rs:404,416) and the ring prover (`RingProver::prove`, src/ring.rs:220), following the
+// byte-exact specification in SURVEY.md Appendix A.5 / A.7 (w3f-ring-proof 0.0.10, un-vendored).
+//
+// Round-1 split of the work: every G1 multi-scalar multiplication (3 per index, 7 per
+// proof -- the part that is >90 % of the reference's 419 ms/proof) and every NTT run on the GPU
+// (msm.hip kernels over the device-resident SRS; k_ntt_* below); the remaining O(N) polynomial
+// bookkeeping (constraint evaluation, division, Horner, Fiat-Shamir over SHAKE128) still runs on the
+// host in this file and moves to device kernels next.
+#include "../../include/avrf.h"
+#include "te.h"
+#include "host_g1.h"
+#include "host_te.h"
+#include "msm.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace avrf {
+
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "avrf: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); abort(); } } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device NTT over Fr of the pairing curve (radix-2, in place, global memory; batch of equal sizes)
+
+template <class F>
+__global__ void k_ntt_bitrev(uint32_t *__restrict__ data, uint32_t n, int logn, uint32_t batch) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t b = t / n, i = t - b * n;
+  if (b >= batch) return;
+  uint32_t j = __brev(i) >> (32 - logn);
+  if (i < j) {
+    uint32_t *p = data + ((size_t)b * n + i) * 8, *q = data + ((size_t)b * n + j) * 8;
+    fp x = load_fp(p), y = load_fp(q);
+    store_fp(p, y); store_fp(q, x);
+  }
+}
+// one butterfly per lane; tw[k] = w^k (Montgomery), k < n/2
+template <class F>
+__global__ void k_ntt_stage(uint32_t *__restrict__ data, uint32_t n, uint32_t half, const uint32_t *__restrict__ tw, uint32_t batch) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t hn = n >> 1, b = t / hn, j = t - b * hn;
+  if (b >= batch) return;
+  uint32_t grp = j / half, pos = j - grp * half;
+  uint32_t i0 = grp * 2 * half + pos, i1 = i0 + half;
+  uint32_t *p = data + ((size_t)b * n + i0) * 8, *q = data + ((size_t)b * n + i1) * 8;
+  fp u = load_fp(p), v = fp_mul<F>(load_fp(q), load_fp(tw + (size_t)pos * (hn / half) * 8));
+  store_fp(p, fp_add<F>(u, v)); store_fp(q, fp_sub<F>(u, v));
+}
+template <class F>
+__global__ void k_ntt_scale(uint32_t *__restrict__ data, uint32_t total, fp k) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  uint32_t *p = data + (size_t)t * 8;
+  store_fp(p, fp_mul<F>(load_fp(p), k));
+}
+
+template <class F>
+static void ntt_launch(uint32_t *d_data, uint32_t n, const uint32_t *d_tw, uint32_t batch, const fp *scale, hipStream_t st) {
+  int logn = 0; while ((1u << logn) < n) logn++;
+  hipLaunchKernelGGL(k_ntt_bitrev<F>, dim3(((size_t)n * batch + 255) / 256), dim3(256), 0, st, d_data, n, logn, batch);
+  for (uint32_t half = 1; half < n; half <<= 1)
+    hipLaunchKernelGGL(k_ntt_stage<F>, dim3(((size_t)(n / 2) * batch + 255) / 256), dim3(256), 0, st, d_data, n, half, d_tw, batch);
+  if (scale) hipLaunchKernelGGL(k_ntt_scale<F>, dim3(((size_t)n * batch + 255) / 256), dim3(256), 0, st, d_data, n * batch, *scale);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SHAKE128 + ark-transcript
+
+struct Shake128 {
+  uint64_t s[25]; uint8_t buf[168]; size_t fill = 0;
+  Shake128() { memset(s, 0, sizeof s); }
+  static void keccakf(uint64_t st[25]) {
+    static const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+      0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL,
+      0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL,
+      0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL,
+      0x8000000080008008ULL};
+    static const int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+    static const int PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    for (int r = 0; r < 24; r++) {
+      uint64_t bc[5];
+      for (int i = 0; i < 5; i++) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
+      for (int i = 0; i < 5; i++) { uint64_t t = bc[(i + 4) % 5] ^ ((bc[(i + 1) % 5] << 1) | (bc[(i + 1) % 5] >> 63)); for (int j = 0; j < 25; j += 5) st[j + i] ^= t; }
+      uint64_t t = st[1];
+      for (int i = 0; i < 24; i++) { int j = PIL[i]; uint64_t b = st[j]; st[j] = (t << ROT[i]) | (t >> (64 - ROT[i])); t = b; }
+      for (int j = 0; j < 25; j += 5) { for (int i = 0; i < 5; i++) bc[i] = st[j + i]; for (int i = 0; i < 5; i++) st[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5]; }
+      st[0] ^= RC[r];
+    }
+  }
+  void absorb_block() { for (int i = 0; i < 21; i++) { uint64_t v; memcpy(&v, buf + 8 * i, 8); s[i] ^= v; } keccakf(s); fill = 0; }
+  void update(const void *d, size_t n) { const uint8_t *p = (const uint8_t *)d; while (n) { size_t k = 168 - fill; if (k > n) k = n; memcpy(buf + fill, p, k); fill += k; p += k; n -= k; if (fill == 168) absorb_block(); } }
+  // squeeze the first `n` bytes of the XOF output of a COPY of the state (the transcript continues)
+  void squeeze_copy(uint8_t *out, size_t n) const {
+    Shake128 c = *this;
+    memset(c.buf + c.fill, 0, 168 - c.fill); c.buf[c.fill] ^= 0x1f; c.buf[167] ^= 0x80; c.absorb_block();
+    while (n) { size_t k = n < 168 ? n : 168; memcpy(out, c.s, k); out += k; n -= k; if (n) keccakf(c.s); }
+  }
+};
+
+struct ArkTranscript {
+  Shake128 h; bool has_len = false; uint32_t len = 0;
+  void write(const void *d, size_t n) { h.update(d, n); len = (has_len ? len : 0) + (uint32_t)n; has_len = true; }
+  void separate() { if (has_len) { uint8_t b[4] = {(uint8_t)(len >> 24), (uint8_t)(len >> 16), (uint8_t)(len >> 8), (uint8_t)len}; h.update(b, 4); has_len = false; } }
+  void label(const char *l) { separate(); write(l, strlen(l)); separate(); }
+  void label(const uint8_t *l, size_t n) { separate(); write(l, n); separate(); }
+  void append(const std::vector<uint8_t> &d) { separate(); write(d.data(), d.size()); separate(); }
+  void challenge48(const char *l, uint8_t out[48]) { label(l); write("challenge", 9); h.squeeze_copy(out, 48); separate(); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// suite-generic host helpers
+
+template <class S, class G> struct RingTypes {
+  using Fr = HostField<typename S::Fq>;              // Fr(pairing curve) = Fq(TE curve)
+  using Te = HostTe<S>;
+  using HG = HostG1<G>;
+  using FqN = HostFieldN<typename G::Fq>;
+  static constexpr int FQB = G::Fq::N * 4;            // bytes of a G1 coordinate
+};
+
+// int_BE(48 bytes) mod r, Montgomery form
+template <class F> static H256 fr_from_be48(const uint8_t b[48]) {
+  using Fr = HostField<F>;
+  H256 acc = {{0, 0, 0, 0}}, c256 = Fr::to_mont(H256{{256, 0, 0, 0}});
+  for (int i = 0; i < 48; i++) { acc = Fr::mul(acc, c256); acc = Fr::add(acc, Fr::to_mont(H256{{b[i], 0, 0, 0}})); }
+  return acc;
+}
+template <class F> static H256 fr_pow(H256 a, uint64_t e) {
+  using Fr = HostField<F>; H256 r = Fr::one();
+  while (e) { if (e & 1) r = Fr::mul(r, a); a = Fr::sqr(a); e >>= 1; }
+  return r;
+}
+template <class F> static H256 fr_small(uint64_t v) { return HostField<F>::to_mont(H256{{v, 0, 0, 0}}); }
+
+struct G1Aff { uint8_t xy[96]; bool inf; };           // canonical LE x || y (FQB bytes each)
+
+// ark-serialize G1 encodings: BLS12-381 zcash big-endian; BN254 arkworks little-endian
+template <class G> static void g1_encode(const G1Aff &p, bool compressed, std::vector<uint8_t> &out) {
+  constexpr int B = G::Fq::N * 4;
+  using FqN = HostFieldN<typename G::Fq>;
+  typename FqN::El y, half = FqN::from32(G::Fq::HALF), t;
+  memcpy(y.l, p.xy + B, B);
+  bool big = !p.inf && FqN::subb(t, half, y) != 0;    // y > (p-1)/2
+  size_t o = out.size();
+  if (B == 48) {                                      // zcash
+    out.resize(o + (compressed ? B : 2 * B), 0);
+    if (p.inf) { out[o] = compressed ? 0xC0 : 0x40; return; }
+    for (int i = 0; i < B; i++) out[o + i] = p.xy[B - 1 - i];
+    if (compressed) { out[o] |= 0x80; if (big) out[o] |= 0x20; }
+    else for (int i = 0; i < B; i++) out[o + B + i] = p.xy[2 * B - 1 - i];
+  } else {
+    out.resize(o + (compressed ? B : 2 * B), 0);
+    if (p.inf) { out[out.size() - 1] |= 0x40; return; }
+    memcpy(&out[o], p.xy, compressed ? B : 2 * B);
+    if (big) out[out.size() - 1] |= 0x80;
+  }
+}
+
+}  // namespace avrf
+
+using namespace avrf;
+
+// ------------------------------------------------------------------------------------------------
+// handles
+
+struct avrf_ring_setup {
+  avrf_ctx *ctx; int suite; hipStream_t stream; int device;
+  size_t N, cap, keyset, L, n_srs;
+  uint32_t *d_srs = nullptr;                          // n_srs Montgomery affine points
+  G1Aff g1_0;                                         // powers_in_g1[0]
+  std::vector<uint8_t> g2_raw;                        // powers_in_g2[0..2] exactly as in the SRS file
+  H256 w, w4;                                         // domain generators (Montgomery)
+  uint32_t *d_tw_n = nullptr, *d_tw_n_inv = nullptr, *d_tw_4n = nullptr, *d_tw_4n_inv = nullptr;
+  H256 ninv, n4inv;
+  std::vector<std::pair<H256, H256>> h_pows;          // 2^i * BLINDING_BASE, affine Montgomery
+  uint32_t *d_buf = nullptr; size_t buf_cap = 0;      // scratch for NTT batches / MSM scalars
+  MsmWorkspace ws;
+};
+struct avrf_ring_key {
+  avrf_ring_setup *setup;
+  size_t n_keys;
+  std::vector<std::pair<H256, H256>> points;          // cap-1 points, affine Montgomery
+  std::vector<H256> px, py, sel;                      // evaluations (N each, Montgomery)
+  std::vector<H256> px_poly, py_poly, sel_poly;       // coefficients
+  std::vector<H256> px4, py4, sel4;                   // evaluations on the 4N domain
+  G1Aff C[3];
+};
+
+extern "C" hipStream_t avrf_ctx_stream_(avrf_ctx *c);
+extern "C" int avrf_ctx_suite_(avrf_ctx *c);
+extern "C" int avrf_ctx_device_(avrf_ctx *c);
+
+namespace {
+
+template <class S, class G> struct Ring {
+  using T = RingTypes<S, G>;
+  using Fr = typename T::Fr; using Te = typename T::Te;
+  using F = typename S::Fq;
+  static constexpr int FQB = T::FQB;
+
+  static void ensure_buf(avrf_ring_setup *su, size_t bytes) {
+    if (bytes <= su->buf_cap) return;
+    if (su->d_buf) HIP_CHECK(hipFree(su->d_buf));
+    HIP_CHECK(hipMalloc(&su->d_buf, bytes)); su->buf_cap = bytes;
+  }
+  static uint32_t *make_twiddles(H256 w, size_t n) {
+    std::vector<H256> tw(n / 2);
+    H256 x = Fr::one();
+    for (size_t i = 0; i < n / 2; i++) { tw[i] = x; x = Fr::mul(x, w); }
+    uint32_t *d; HIP_CHECK(hipMalloc(&d, (n / 2) * 32)); HIP_CHECK(hipMemcpy(d, tw.data(), (n / 2) * 32, hipMemcpyHostToDevice));
+    return d;
+  }
+  // in-place (i)NTT of `batch` vectors of size n held on the host, via the device
+  static void ntt(avrf_ring_setup *su, std::vector<H256> &v, size_t n, size_t batch, bool inverse) {
+    ensure_buf(su, n * batch * 32);
+    HIP_CHECK(hipMemcpyAsync(su->d_buf, v.data(), n * batch * 32, hipMemcpyHostToDevice, su->stream));
+    const uint32_t *tw = n == su->N ? (inverse ? su->d_tw_n_inv : su->d_tw_n) : (inverse ? su->d_tw_4n_inv : su->d_tw_4n);
+    fp sc; H256 k = n == su->N ? su->ninv : su->n4inv; memcpy(sc.v, k.l, 32);
+    ntt_launch<F>(su->d_buf, (uint32_t)n, tw, (uint32_t)batch, inverse ? &sc : nullptr, su->stream);
+    HIP_CHECK(hipMemcpyAsync(v.data(), su->d_buf, n * batch * 32, hipMemcpyDeviceToHost, su->stream));
+    HIP_CHECK(hipStreamSynchronize(su->stream));
+  }
+  // KZG commit: sum coeffs[i] * powers_in_g1[i] on the device
+  static G1Aff commit(avrf_ring_setup *su, const H256 *coeffs_mont, size_t n) {
+    std::vector<H256> plain(n);
+    for (size_t i = 0; i < n; i++) plain[i] = Fr::from_mont(coeffs_mont[i]);
+    ensure_buf(su, n * 32);
+    HIP_CHECK(hipMemcpyAsync(su->d_buf, plain.data(), n * 32, hipMemcpyHostToDevice, su->stream));
+    G1Aff r; memset(&r, 0, sizeof r);
+    msm_g1_device(su->suite, su->d_srs, su->d_buf, n, su->ws, su->stream, r.xy);
+    r.inf = true; for (int i = 0; i < 2 * FQB; i++) if (r.xy[i]) r.inf = false;
+    return r;
+  }
+  static H256 poly_eval(const std::vector<H256> &c, const H256 &x) {
+    H256 acc = {{0, 0, 0, 0}};
+    for (size_t i = c.size(); i-- > 0;) acc = Fr::add(Fr::mul(acc, x), c[i]);
+    return acc;
+  }
+  static std::vector<H256> div_linear(const std::vector<H256> &c, const H256 &z) {   // (c(X) - c(z)) / (X - z)
+    std::vector<H256> out(c.size() - 1); H256 acc = {{0, 0, 0, 0}};
+    for (size_t i = c.size() - 1; i >= 1; i--) { acc = Fr::add(c[i], Fr::mul(acc, z)); out[i - 1] = acc; }
+    return out;
+  }
+  static H256 challenge(ArkTranscript &t, const char *l) { uint8_t b[48]; t.challenge48(l, b); return fr_from_be48<F>(b); }
+  static void push_le32(std::vector<uint8_t> &o, const H256 &mont) { H256 p = Fr::from_mont(mont); size_t k = o.size(); o.resize(k + 32); memcpy(&o[k], p.l, 32); }
+
+  // ---- setup: parse `URS { powers_in_g1, powers_in_g2 }` (serialize_uncompressed), src/ring.rs:380-393,1412-1421
+  static int setup_load(avrf_ctx *ctx, const uint8_t *srs, size_t len, size_t ring_size, avrf_ring_setup **out) {
+    const size_t L = S::Fr::BITS;
+    size_t need = ring_size + 4 + L, N = 1; while (N < need) N <<= 1;      // src/ring.rs:810-821
+    const size_t pcs = 3 * N + 1;
+    if (len < 8) return AVRF_INVALID_DATA;
+    uint64_t cnt; memcpy(&cnt, srs, 8);
+    const size_t e1 = 2 * FQB, e2 = 4 * FQB;
+    if (len < 8 + cnt * e1 + 8) return AVRF_INVALID_DATA;
+    uint64_t cnt2; memcpy(&cnt2, srs + 8 + cnt * e1, 8);
+    if (len != 8 + cnt * e1 + 8 + cnt2 * e2) return AVRF_INVALID_DATA;
+    if (cnt < pcs || cnt2 < 2) return AVRF_RING_CAPACITY_EXCEEDED;      // src/ring.rs:382-384
+    avrf_ring_setup *su = new avrf_ring_setup();
+    su->ctx = ctx; su->suite = S::ID; su->stream = avrf_ctx_stream_(ctx); su->device = avrf_ctx_device_(ctx);
+    su->N = N; su->cap = N - 3; su->L = L; su->keyset = su->cap - L - 1; su->n_srs = pcs;
+    std::vector<uint8_t> le(pcs * e1);
+    for (size_t i = 0; i < pcs; i++) {
+      const uint8_t *p = srs + 8 + i * e1; uint8_t *q = &le[i * e1];
+      if (FQB == 48) { bool inf = p[0] & 0x40; for (int k = 0; k < FQB; k++) { q[k] = inf ? 0 : p[FQB - 1 - k]; q[FQB + k] = inf ? 0 : p[2 * FQB - 1 - k]; } }
+      else { bool inf = p[2 * FQB - 1] & 0x40; memcpy(q, p, e1); q[e1 - 1] &= 0x3f; if (inf) memset(q, 0, e1); }
+    }
+    memcpy(su->g1_0.xy, le.data(), e1); su->g1_0.inf = false;
+    su->g2_raw.assign(srs + 8 + cnt * e1 + 8, srs + 8 + cnt * e1 + 8 + 2 * e2);
+    HIP_CHECK(hipSetDevice(su->device));
+    uint8_t *d_le; uint32_t *d_flag; uint32_t flag = 0;
+    HIP_CHECK(hipMalloc(&d_le, le.size())); HIP_CHECK(hipMalloc(&d_flag, 4)); HIP_CHECK(hipMalloc(&su->d_srs, pcs * e1));
+    HIP_CHECK(hipMemcpy(d_le, le.data(), le.size(), hipMemcpyHostToDevice)); HIP_CHECK(hipMemset(d_flag, 0, 4));
+    launch_g1_bases(su->suite, d_le, pcs, su->d_srs, d_flag, su->stream);
+    HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, su->stream)); HIP_CHECK(hipStreamSynchronize(su->stream));
+    HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag));
+    if (flag) { HIP_CHECK(hipFree(su->d_srs)); delete su; return AVRF_INVALID_DATA; }
+    // domain
+    H256 root = Fr::from32(G::ROOT_OF_UNITY);
+    int lg = 0; while (((size_t)1 << lg) < N) lg++;
+    H256 w4 = root; for (int i = 0; i < G::TWO_ADICITY - (lg + 2); i++) w4 = Fr::sqr(w4);
+    su->w4 = w4; su->w = Fr::sqr(Fr::sqr(w4));
+    su->d_tw_n = make_twiddles(su->w, N); su->d_tw_n_inv = make_twiddles(Fr::inv(su->w), N);
+    su->d_tw_4n = make_twiddles(su->w4, 4 * N); su->d_tw_4n_inv = make_twiddles(Fr::inv(su->w4), 4 * N);
+    su->ninv = Fr::inv(fr_small<F>(N)); su->n4inv = Fr::inv(fr_small<F>(4 * N));
+    // 2^i * H  (A.5)
+    HostExt h; h.x = Fr::from32(S::B_X); h.y = Fr::from32(S::B_Y); h.t = Fr::mul(h.x, h.y); h.z = Fr::one();
+    for (size_t i = 0; i < L; i++) {
+      H256 zi = Fr::inv(h.z); su->h_pows.push_back({Fr::mul(h.x, zi), Fr::mul(h.y, zi)});
+      h = Te::dbl(h);
+    }
+    *out = su;
+    return AVRF_OK;
+  }
+
+  // ---- ring_proof::index (A.5): fixed columns and their commitments
+  static int index(avrf_ring_setup *su, const uint8_t *pks_xy, size_t n_keys, avrf_ring_key **out) {
+    if (n_keys > su->keyset) return AVRF_RING_CAPACITY_EXCEEDED;       // src/ring.rs:400-402
+    const size_t N = su->N;
+    avrf_ring_key *k = new avrf_ring_key(); k->setup = su; k->n_keys = n_keys;
+    H256 padx = Fr::from32(S::PAD_X), pady = Fr::from32(S::PAD_Y);
+    for (size_t i = 0; i < n_keys; i++) {
+      H256 x = Fr::load_le(pks_xy + 64 * i), y = Fr::load_le(pks_xy + 64 * i + 32);
+      if (Fr::geq_p(x) || Fr::geq_p(y)) { delete k; return AVRF_INVALID_DATA; }
+      k->points.push_back({Fr::to_mont(x), Fr::to_mont(y)});
+    }
+    for (size_t i = n_keys; i < su->keyset; i++) k->points.push_back({padx, pady});
+    for (auto &p : su->h_pows) k->points.push_back(p);
+    H256 zero = {{0, 0, 0, 0}};
+    std::vector<H256> cols(3 * N, zero);
+    for (size_t i = 0; i < k->points.size(); i++) { cols[i] = k->points[i].first; cols[N + i] = k->points[i].second; }
+    for (size_t i = 0; i < su->keyset; i++) cols[2 * N + i] = Fr::one();
+    k->px.assign(cols.begin(), cols.begin() + N); k->py.assign(cols.begin() + N, cols.begin() + 2 * N); k->sel.assign(cols.begin() + 2 * N, cols.end());
+    ntt(su, cols, N, 3, true);
+    k->px_poly.assign(cols.begin(), cols.begin() + N); k->py_poly.assign(cols.begin() + N, cols.begin() + 2 * N); k->sel_poly.assign(cols.begin() + 2 * N, cols.end());
+    k->C[0] = commit(su, k->px_poly.data(), N); k->C[1] = commit(su, k->py_poly.data(), N); k->C[2] = commit(su, k->sel_poly.data(), N);
+    // evaluations of the fixed columns on the 4N domain (shared by every proof over this ring)
+    std::vector<H256> e4(3 * 4 * N, zero);
+    for (size_t i = 0; i < N; i++) { e4[i] = k->px_poly[i]; e4[4 * N + i] = k->py_poly[i]; e4[8 * N + i] = k->sel_poly[i]; }
+    ntt(su, e4, 4 * N, 3, false);
+    k->px4.assign(e4.begin(), e4.begin() + 4 * N); k->py4.assign(e4.begin() + 4 * N, e4.begin() + 8 * N); k->sel4.assign(e4.begin() + 8 * N, e4.end());
+    *out = k;
+    return AVRF_OK;
+  }
+
+  static void transcript_prelude(avrf_ring_key *k, ArkTranscript &t) {
+    avrf_ring_setup *su = k->setup;
+    t.label(S::SUITE_ID, S::SUITE_ID_LEN);
+    t.label("vk");
+    std::vector<uint8_t> vk; g1_encode<G>(su->g1_0, false, vk);
+    vk.insert(vk.end(), su->g2_raw.begin(), su->g2_raw.end());
+    for (int i = 0; i < 3; i++) g1_encode<G>(k->C[i], false, vk);
+    t.append(vk);
+  }
+
+  // ---- RingProver::prove with blinding disabled (A.7); out: 4*G1 || 7*Fr || G1 || Fr || G1 || G1
+  static int prove_one(avrf_ring_key *k, size_t key_index, const uint8_t blinding_le[32], uint8_t *out) {
+    avrf_ring_setup *su = k->setup;
+    const size_t N = su->N, cap = su->cap, M = 4 * N;
+    if (key_index >= k->n_keys) return AVRF_ERR_BAD_ARG;
+    const H256 zero = {{0, 0, 0, 0}}, one = Fr::one();
+    // witness
+    std::vector<uint8_t> bits(cap - 1, 0);
+    bits[key_index] = 1;
+    for (size_t i = 0; i < su->L; i++) bits[su->keyset + i] = (blinding_le[i >> 3] >> (i & 7)) & 1;
+    std::vector<H256> cols(4 * N, zero);                               // bits | ip | ax | ay evaluations
+    H256 ipv = zero;
+    for (size_t i = 0; i < cap - 1; i++) {
+      if (bits[i]) cols[i] = one;
+      if (bits[i] && i < su->keyset) ipv = Fr::add(ipv, one);
+      cols[N + i + 1] = ipv;
+    }
+    HostExt acc; acc.x = Fr::from32(S::ACC_X); acc.y = Fr::from32(S::ACC_Y); acc.t = Fr::mul(acc.x, acc.y); acc.z = one;
+    const H256 seedx = acc.x, seedy = acc.y;
+    std::vector<HostExt> accs(cap);
+    accs[0] = acc;
+    for (size_t i = 0; i < cap - 1; i++) {
+      if (bits[i]) { HostExt p; p.x = k->points[i].first; p.y = k->points[i].second; p.t = Fr::mul(p.x, p.y); p.z = one; acc = Te::add(acc, p); }
+      accs[i + 1] = acc;
+    }
+    {  // batch normalisation (one inversion)
+      std::vector<H256> pre(cap); H256 run = one;
+      for (size_t i = 0; i < cap; i++) { pre[i] = run; run = Fr::mul(run, accs[i].z); }
+      H256 inv = Fr::inv(run);
+      for (size_t i = cap; i-- > 0;) { H256 zi = Fr::mul(inv, pre[i]); inv = Fr::mul(inv, accs[i].z); cols[2 * N + i] = Fr::mul(accs[i].x, zi); cols[3 * N + i] = Fr::mul(accs[i].y, zi); }
+    }
+    const H256 resx = cols[2 * N + cap - 1], resy = cols[3 * N + cap - 1];
+    // instance = result - seed
+    HostExt r; r.x = resx; r.y = resy; r.t = Fr::mul(resx, resy); r.z = one;
+    HostExt ns; ns.x = Fr::neg(seedx); ns.y = seedy; ns.t = Fr::mul(ns.x, ns.y); ns.z = one;
+    HostExt inst = Te::add(r, ns); H256 izi = Fr::inv(inst.z);
+    H256 instx = Fr::mul(inst.x, izi), insty = Fr::mul(inst.y, izi);
+    ntt(su, cols, N, 4, true);                                         // -> coefficients
+    const H256 *pb = &cols[0], *pip = &cols[N], *pax = &cols[2 * N], *pay = &cols[3 * N];
+    G1Aff C[4]; for (int i = 0; i < 4; i++) C[i] = commit(su, &cols[i * N], N);
+    ArkTranscript t; transcript_prelude(k, t);
+    { std::vector<uint8_t> b; push_le32(b, instx); push_le32(b, insty); t.label("instance"); t.append(b); }
+    { std::vector<uint8_t> b; for (int i = 0; i < 4; i++) g1_encode<G>(C[i], false, b); t.label("committed_cols"); t.append(b); }
+    H256 al[7]; for (int i = 0; i < 7; i++) al[i] = challenge(t, "constraints_aggregation");
+    // evaluations on the 4N domain
+    std::vector<H256> e4(4 * M, zero);
+    for (int c = 0; c < 4; c++) for (size_t i = 0; i < N; i++) e4[c * M + i] = cols[c * N + i];
+    ntt(su, e4, M, 4, false);
+    const H256 *eb = &e4[0], *eip = &e4[M], *eax = &e4[2 * M], *eay = &e4[3 * M];
+    std::vector<H256> lfl(2 * N, zero); lfl[0] = one; lfl[N + cap - 1] = one;     // L_first, L_last
+    ntt(su, lfl, N, 2, true);
+    std::vector<H256> l4(2 * M, zero);
+    for (size_t i = 0; i < N; i++) { l4[i] = lfl[i]; l4[M + i] = lfl[N + i]; }
+    ntt(su, l4, M, 2, false);
+    const H256 w_last = fr_pow<F>(su->w, cap - 1);
+    H256 a_coef = S::A_KIND == 1 ? Fr::neg(fr_small<F>(5)) : one;
+    std::vector<H256> agg(M + 4, zero);
+    H256 xi = one;
+    for (size_t i = 0; i < M; i++) {
+      const H256 b = eb[i], x1 = eax[i], y1 = eay[i], x2 = k->px4[i], y2 = k->py4[i];
+      const H256 x3 = eax[(i + 4) % M], y3 = eay[(i + 4) % M], ip = eip[i], ips = eip[(i + 4) % M];
+      const H256 nl = Fr::sub(xi, w_last), omb = Fr::sub(one, b);
+      const H256 x1y1 = Fr::mul(x1, y1), x2y2 = Fr::mul(x2, y2);
+      H256 c0 = Fr::mul(Fr::sub(Fr::sub(ips, ip), Fr::mul(k->sel4[i], b)), nl);
+      H256 t1 = Fr::add(Fr::mul(y1, y2), Fr::mul(a_coef, Fr::mul(x1, x2)));
+      H256 c1 = Fr::mul(Fr::add(Fr::mul(b, Fr::sub(Fr::sub(Fr::mul(x3, t1), x1y1), x2y2)), Fr::mul(omb, Fr::sub(x3, x1))), nl);
+      H256 t2 = Fr::sub(Fr::mul(x1, y2), Fr::mul(x2, y1));
+      H256 c2 = Fr::mul(Fr::add(Fr::mul(b, Fr::add(Fr::sub(Fr::mul(y3, t2), x1y1), x2y2)), Fr::mul(omb, Fr::sub(y3, y1))), nl);
+      H256 c3 = Fr::mul(b, omb);
+      H256 lf = l4[i], ll = l4[M + i];
+      H256 c4 = Fr::add(Fr::mul(lf, Fr::sub(x1, seedx)), Fr::mul(ll, Fr::sub(x1, resx)));
+      H256 c5 = Fr::add(Fr::mul(lf, Fr::sub(y1, seedy)), Fr::mul(ll, Fr::sub(y1, resy)));
+      H256 c6 = Fr::add(Fr::mul(lf, ip), Fr::mul(ll, Fr::sub(ip, one)));
+      H256 s = Fr::mul(al[0], c0);
+      s = Fr::add(s, Fr::mul(al[1], c1)); s = Fr::add(s, Fr::mul(al[2], c2)); s = Fr::add(s, Fr::mul(al[3], c3));
+      s = Fr::add(s, Fr::mul(al[4], c4)); s = Fr::add(s, Fr::mul(al[5], c5)); s = Fr::add(s, Fr::mul(al[6], c6));
+      agg[i] = s;
+      xi = Fr::mul(xi, su->w4);
+    }
+    {
+      std::vector<H256> tmp(agg.begin(), agg.begin() + M);
+      ntt(su, tmp, M, 1, true);
+      for (size_t i = 0; i < M; i++) agg[i] = tmp[i];
+    }
+    for (size_t j = N - 3; j < N; j++) {                               // * (X - w^j)
+      H256 z = fr_pow<F>(su->w, j);
+      for (size_t kx = M + 3; kx >= 1; kx--) agg[kx] = Fr::sub(agg[kx - 1], Fr::mul(z, agg[kx]));
+      agg[0] = Fr::neg(Fr::mul(z, agg[0]));
+    }
+    size_t deg = M + 3; while (deg > 0 && Fr::is_zero(agg[deg])) deg--;
+    if (deg < N) return AVRF_ERR_BAD_ARG;
+    std::vector<H256> q(deg + 1 - N);
+    for (size_t kx = deg; kx >= N; kx--) { q[kx - N] = agg[kx]; agg[kx - N] = Fr::add(agg[kx - N], agg[kx]); }   // / (X^N - 1)
+    G1Aff Cq = commit(su, q.data(), q.size());
+    { std::vector<uint8_t> b; g1_encode<G>(Cq, false, b); t.label("quotient"); t.append(b); }
+    H256 zeta = challenge(t, "evaluation_point");
+    auto vec = [](const H256 *p, size_t n) { return std::vector<H256>(p, p + n); };
+    std::vector<H256> polys[7] = {k->px_poly, k->py_poly, k->sel_poly, vec(pb, N), vec(pip, N), vec(pax, N), vec(pay, N)};
+    H256 ev[7]; for (int i = 0; i < 7; i++) ev[i] = poly_eval(polys[i], zeta);
+    { std::vector<uint8_t> b; for (int i = 0; i < 7; i++) push_le32(b, ev[i]); t.label("register_evaluations"); t.append(b); }
+    const H256 x2 = ev[0], y2 = ev[1], b = ev[3], x1 = ev[5], y1 = ev[6];
+    const H256 nlz = Fr::sub(zeta, w_last), omb = Fr::sub(one, b);
+    H256 k1 = Fr::add(Fr::mul(b, Fr::add(Fr::mul(y1, y2), Fr::mul(a_coef, Fr::mul(x1, x2)))), omb);
+    H256 k2 = Fr::add(Fr::mul(b, Fr::sub(Fr::mul(x1, y2), Fr::mul(x2, y1))), omb);
+    std::vector<H256> lin(N);
+    { H256 f0 = Fr::mul(nlz, al[0]), f1 = Fr::mul(nlz, Fr::mul(al[1], k1)), f2 = Fr::mul(nlz, Fr::mul(al[2], k2));
+      for (size_t i = 0; i < N; i++) lin[i] = Fr::add(Fr::add(Fr::mul(f0, pip[i]), Fr::mul(f1, pax[i])), Fr::mul(f2, pay[i])); }
+    H256 zw = Fr::mul(zeta, su->w), lin_zw = poly_eval(lin, zw);
+    { std::vector<uint8_t> bb; push_le32(bb, lin_zw); t.label("shifted_linearization_evaluation"); t.append(bb); }
+    H256 nu[8]; for (int i = 0; i < 8; i++) nu[i] = challenge(t, "kzg_aggregation");
+    std::vector<H256> aggz(q.size(), zero);
+    for (int c = 0; c < 7; c++) for (size_t i = 0; i < N; i++) aggz[i] = Fr::add(aggz[i], Fr::mul(nu[c], polys[c][i]));
+    for (size_t i = 0; i < q.size(); i++) aggz[i] = Fr::add(aggz[i], Fr::mul(nu[7], q[i]));
+    std::vector<H256> q1 = div_linear(aggz, zeta), q2 = div_linear(lin, zw);
+    G1Aff pi1 = commit(su, q1.data(), q1.size()), pi2 = commit(su, q2.data(), q2.size());
+    std::vector<uint8_t> pr;
+    for (int i = 0; i < 4; i++) g1_encode<G>(C[i], true, pr);
+    for (int i = 0; i < 7; i++) push_le32(pr, ev[i]);
+    g1_encode<G>(Cq, true, pr); push_le32(pr, lin_zw); g1_encode<G>(pi1, true, pr); g1_encode<G>(pi2, true, pr);
+    memcpy(out, pr.data(), pr.size());
+    return AVRF_OK;
+  }
+};
+
+using RingB = Ring<SuiteBandersnatch, G1Bls12381>;
+using RingJ = Ring<SuiteBabyJubJub, G1Bn254>;
+
+}  // namespace
+
+extern "C" {
+
+int avrf_ring_setup_load(avrf_ctx *ctx, const uint8_t *srs, size_t srs_len, size_t ring_size, avrf_ring_setup **out) {
+  if (!ctx || !srs || !out || ring_size == 0) return AVRF_ERR_BAD_ARG;
+  *out = nullptr;
+  return avrf_ctx_suite_(ctx) == 0 ? RingB::setup_load(ctx, srs, srs_len, ring_size, out) : RingJ::setup_load(ctx, srs, srs_len, ring_size, out);
+}
+void avrf_ring_setup_free(avrf_ring_setup *su) {
+  if (!su) return;
+  (void)hipSetDevice(su->device);
+  void *d[] = {su->d_srs, su->d_tw_n, su->d_tw_n_inv, su->d_tw_4n, su->d_tw_4n_inv, su->d_buf};
+  for (void *p : d) if (p) (void)hipFree(p);
+  su->ws.release();
+  delete su;
+}
+size_t avrf_ring_max_ring_size(const avrf_ring_setup *su) { return su ? su->keyset : 0; }
+size_t avrf_ring_domain_size(const avrf_ring_setup *su) { return su ? su->N : 0; }
+size_t avrf_ring_proof_len(const avrf_ring_setup *su) { return su ? (su->suite == 0 ? 592 : 480) : 0; }
+size_t avrf_ring_commitment_len(const avrf_ring_setup *su) { return su ? (su->suite == 0 ? 144 : 96) : 0; }
+
+int avrf_ring_index(avrf_ring_setup *su, const uint8_t *pks_xy, size_t n_keys, avrf_ring_key **out, uint8_t *commitment_out) {
+  if (!su || !out || (n_keys && !pks_xy)) return AVRF_ERR_BAD_ARG;
+  *out = nullptr;
+  if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
+  int st = su->suite == 0 ? RingB::index(su, pks_xy, n_keys, out) : RingJ::index(su, pks_xy, n_keys, out);
+  if (st == AVRF_OK && commitment_out) {
+    std::vector<uint8_t> b;
+    for (int i = 0; i < 3; i++) { if (su->suite == 0) g1_encode<G1Bls12381>((*out)->C[i], true, b); else g1_encode<G1Bn254>((*out)->C[i], true, b); }
+    memcpy(commitment_out, b.data(), b.size());
+  }
+  return st;
+}
+void avrf_ring_key_free(avrf_ring_key *k) { delete k; }
+
+int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const uint8_t *blindings, int blinding_mode, uint8_t *proofs_out) {
+  if (!k || (n && (!key_index || !blindings || !proofs_out))) return AVRF_ERR_BAD_ARG;
+  if (blinding_mode != 0) return AVRF_ERR_BAD_ARG;                     // zero-knowledge blinding rows: not yet
+  if (hipSetDevice(k->setup->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
+  const size_t plen = k->setup->suite == 0 ? 592 : 480;
+  for (size_t i = 0; i < n; i++) {
+    int st = k->setup->suite == 0 ? RingB::prove_one(k, key_index[i], blindings + 32 * i, proofs_out + plen * i)
+                                  : RingJ::prove_one(k, key_index[i], blindings + 32 * i, proofs_out + plen * i);
+    if (st) return st;
+  }
+  return AVRF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+"""ctypes harness for the Ring-VRF entry points of libavrf.so (include/avrf.h, "Ring VRF" section).
+
+Mirrors `RingSetup` / `RingProverKey` of the reference (src/ring.rs:340-464):
+    setup = RingSetup(ctx, srs_bytes, ring_size)      # RingSetup::from_pcs_params
+    key, commitment = setup.index(pks_xy)             # prover_key / verifier_key -> ring_proof::index
+    proofs = key.prove(key_indices, blindings)        # RingProver::prove (blinding disabled)
+"""
+import ctypes as C
+
+from . import _native as nat
+
+
+class RingKey:
+    def __init__(self, setup, handle, commitment):
+        self.setup, self._h, self.commitment = setup, handle, commitment
+
+    def prove(self, key_indices, blindings, blinding_mode=0):
+        n = len(key_indices)
+        plen = self.setup.proof_len
+        out = (C.c_uint8 * max(1, n * plen))()
+        st = nat.lib().avrf_ring_prove(self._h, C.c_size_t(n), nat._u32(key_indices), nat._u8(b"".join(blindings)), int(blinding_mode), out)
+        if st != nat.OK:
+            raise nat.AvrfError(f"avrf_ring_prove -> {st}")
+        b = bytes(out)
+        return [b[i * plen: (i + 1) * plen] for i in range(n)]
+
+    def close(self):
+        if self._h:
+            nat.lib().avrf_ring_key_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RingSetup:
+    def __init__(self, ctx, srs_bytes, ring_size):
+        L = nat.lib()
+        for f in ("avrf_ring_max_ring_size", "avrf_ring_domain_size", "avrf_ring_proof_len", "avrf_ring_commitment_len"):
+            getattr(L, f).restype = C.c_size_t
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        st = L.avrf_ring_setup_load(ctx._h, nat._u8(srs_bytes), C.c_size_t(len(srs_bytes)), C.c_size_t(ring_size), C.byref(self._h))
+        self.status = st
+        if st != nat.OK:
+            self._h = None
+            raise nat.AvrfError(f"avrf_ring_setup_load -> {st}")
+        self.max_ring_size = L.avrf_ring_max_ring_size(self._h)
+        self.domain_size = L.avrf_ring_domain_size(self._h)
+        self.proof_len = L.avrf_ring_proof_len(self._h)
+        self.commitment_len = L.avrf_ring_commitment_len(self._h)
+
+    def index(self, pks_xy):
+        """pks_xy: list of 64-byte keys.  Returns a RingKey (its .commitment = compressed RingCommitment)."""
+        h = C.c_void_p()
+        com = (C.c_uint8 * self.commitment_len)()
+        st = nat.lib().avrf_ring_index(self._h, nat._u8(b"".join(pks_xy)), C.c_size_t(len(pks_xy)), C.byref(h), com)
+        if st != nat.OK:
+            raise nat.AvrfError(f"avrf_ring_index -> {st}")
+        return RingKey(self, h, bytes(com))
+
+    def close(self):
+        if self._h:
+            nat.lib().avrf_ring_setup_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

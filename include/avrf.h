@@ -140,6 +140,36 @@ int avrf_pedersen_prove(avrf_ctx *ctx, size_t n, const uint8_t *sks, const uint8
 int avrf_pedersen_verify(avrf_ctx *ctx, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,
                          const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, int32_t *status_out);
 
+/* ---- Ring VRF (src/ring.rs).  Handles own device-resident state; free them with *_free. ----
+ *
+ * RingSetup::from_pcs_params (src/ring.rs:380-393) on an arkworks `URS` file (`serialize_uncompressed`,
+ * e.g. data/srs/bls12-381-srs-2-11-uncompressed-zcash.bin): parses and uploads the first 3N+1 G1 powers,
+ * keeps the two G2 powers, builds the PIOP domain for `ring_size` (src/ring.rs:810-843).
+ * Returns AVRF_RING_CAPACITY_EXCEEDED when the SRS is too short for the ring size. */
+typedef struct avrf_ring_setup avrf_ring_setup;
+typedef struct avrf_ring_key avrf_ring_key;
+int avrf_ring_setup_load(avrf_ctx *ctx, const uint8_t *srs, size_t srs_len, size_t ring_size, avrf_ring_setup **out);
+void avrf_ring_setup_free(avrf_ring_setup *setup);
+size_t avrf_ring_max_ring_size(const avrf_ring_setup *setup);   /* RingContext::max_ring_size, src/ring.rs:298-300 */
+size_t avrf_ring_domain_size(const avrf_ring_setup *setup);     /* piop_domain_size, src/ring.rs:819-821 */
+size_t avrf_ring_proof_len(const avrf_ring_setup *setup);       /* 592 (BLS12-381) / 480 (BN254) */
+size_t avrf_ring_commitment_len(const avrf_ring_setup *setup);  /* 144 / 96 */
+
+/* RingSetup::prover_key / verifier_key -> ring_proof::index (src/ring.rs:399-417): fixed columns of the
+ * ring `pks_xy` (n_keys x 64) and their three KZG commitments.  commitment_out (may be NULL) receives the
+ * RingCommitment in its compressed serialisation (3 x G1), i.e. the `ring_pks_com` of the reference vectors.
+ * AVRF_RING_CAPACITY_EXCEEDED if n_keys > max ring size. */
+int avrf_ring_index(avrf_ring_setup *setup, const uint8_t *pks_xy, size_t n_keys, avrf_ring_key **out, uint8_t *commitment_out);
+void avrf_ring_key_free(avrf_ring_key *key);
+
+/* RingProver::prove (the `ring_prover.prove(blinding)` half of ring::Prover::prove, src/ring.rs:219-221) for n
+ * proofs over one ring: key_index[i] is the prover's position in the ring, blindings[i] the secret blinding
+ * returned by avrf_pedersen_prove.  blinding_mode 0 = RingContext::new_without_blinding (deterministic,
+ * reproduces the reference vectors).  proofs_out: n x avrf_ring_proof_len bytes (the RingBareProof in its
+ * compressed serialisation); the full ring-VRF proof is the Pedersen proof followed by it (src/ring.rs:160-166). */
+int avrf_ring_prove(avrf_ring_key *key, size_t n, const uint32_t *key_index, const uint8_t *blindings, int blinding_mode,
+                    uint8_t *proofs_out);
+
 /* CanonicalSerialize / CanonicalDeserialize of curve points, batched on the device
  * (ark-serialize compressed form; checked constructors src/lib.rs:410-494).
  * decompress: in n x 32 -> out n x 64; status_out[j] = AVRF_OK / AVRF_INVALID_DATA.

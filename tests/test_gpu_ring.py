@@ -1,0 +1,89 @@
+"""GPU parity for the Ring-VRF rows a10 / a13 / a9 of SURVEY.md §8 through the C ABI:
+SRS load, `ring_proof::index` (ring commitment) and `RingProver::prove` (blinding disabled) must
+reproduce the reference's ring vectors byte for byte (src/ring.rs:1529-1571): `ring_pks_com`
+(144 B / 96 B) and `ring_proof` (592 B / 480 B), for both suites; the proofs also verify under the
+oracle's verifier (BLS12-381)."""
+import json
+import os
+
+import pytest
+
+from helpers import xy
+from oracle import ring_py as R
+
+pytestmark = pytest.mark.gpu
+FILES = {0: ("bandersnatch_sha-512_ell2_ring.json", "bls12-381-srs-2-11-uncompressed-zcash.bin"),
+         1: ("baby-jubjub_sha-512_tai_ring.json", "bn254-testing-2-9-uncompressed.bin")}
+
+
+@pytest.fixture(scope="module")
+def env(golden_dir):
+    from ark_vrf_amd import _native as nat
+    from ark_vrf_amd.ring import RingSetup
+    out = {}
+    for i, (vec, srsf) in FILES.items():
+        srs = open(os.path.join(golden_dir, srsf), "rb").read()
+        ctx = nat.Context(i)
+        out[i] = (ctx, RingSetup(ctx, srs, 8), json.load(open(os.path.join(golden_dir, vec))), srs)
+    return out
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_setup_parameters(env, suite):
+    ctx, setup, vs, srs = env[suite]
+    assert setup.domain_size == 512                                        # src/ring.rs:810-821, TEST_RING_SIZE = 8
+    assert setup.max_ring_size == 512 - 4 - (253 if suite == 0 else 251)   # src/ring.rs:298-300
+    assert (setup.proof_len, setup.commitment_len) == ((592, 144) if suite == 0 else (480, 96))
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_ring_capacity_exceeded(env, suite):
+    """ring_size_exceeded (src/ring.rs:1145-1170): SRS too short / too many keys."""
+    from ark_vrf_amd import _native as nat
+    from ark_vrf_amd.ring import RingSetup
+    ctx, setup, vs, srs = env[suite]
+    with pytest.raises(nat.AvrfError, match="-> 3"):
+        RingSetup(ctx, srs, 100000)
+    pk = xy(suite, bytes.fromhex(vs[0]["pk"]))
+    with pytest.raises(nat.AvrfError, match="-> 3"):
+        setup.index([pk] * (setup.max_ring_size + 1))
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_reference_ring_vectors(env, suite):
+    ctx, setup, vs, srs = env[suite]
+    s = R.SUITES[suite]
+    for v in vs:
+        raw = bytes.fromhex(v["ring_pks"])
+        pks = [xy(suite, raw[32 * i: 32 * i + 32]) for i in range(len(raw) // 32)]
+        key = setup.index(pks)
+        assert key.commitment.hex() == v["ring_pks_com"]                   # RingCommitment, 3 KZG commits
+        idx = pks.index(xy(suite, bytes.fromhex(v["pk"])))
+        proof = key.prove([idx], [bytes.fromhex(v["blinding"])])[0]
+        assert proof.hex() == v["ring_proof"]                              # full deterministic ring proof
+        key.close()
+
+
+def test_gpu_proof_verifies_under_oracle(env):
+    """A proof made on the GPU for a ring/prover not in the vectors is accepted by the oracle's
+    RingVerifier restatement (pairing check), and rejected for another key commitment."""
+    import oracle as orc
+    ctx, setup, vs, srs_bytes = env[0]
+    s = R.SUITES[0]
+    sks = [orc.from_seed(0, bytes([40 + i]) + bytes(31)) for i in range(5)]
+    pks = [xy(0, pk) for _, pk in sks]
+    key = setup.index(pks)
+    h = orc.hash_to_curve(0, b"ring-gpu-test")
+    sk, pk = sks[2]
+    ped, blinding = orc.pedersen_prove(0, sk, [(h, orc.vrf_output(0, sk, h))], b"ad")
+    proof = key.prove([2], [blinding])[0]
+    prm = R.Params(s, ring_size=8)
+    srs = R.Srs(s, srs_bytes)
+    fixed = [R.g1_decode_compressed(s, key.commitment[48 * i: 48 * i + 48]) for i in range(3)]
+    inst = R.te_decode(s, ped[:32])                                        # Yb = pk + b*B
+    assert R.verify(prm, srs, fixed, proof, inst)
+    assert not R.verify(prm, srs, fixed, proof, R.te_add(s, inst, s.blinding_base))
+    # and the oracle's own prover gives the same bytes
+    cols = R.index(prm, srs, [R.te_decode(s, p) for _, p in sks])
+    want, _ = R.prove(prm, srs, cols, 2, int.from_bytes(blinding, "little"))
+    assert proof == want
