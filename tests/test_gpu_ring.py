@@ -87,3 +87,28 @@ def test_gpu_proof_verifies_under_oracle(env):
     cols = R.index(prm, srs, [R.te_decode(s, p) for _, p in sks])
     want, _ = R.prove(prm, srs, cols, 2, int.from_bytes(blinding, "little"))
     assert proof == want
+
+
+def test_ring_1024_matches_oracle(env, golden_dir):
+    """BASELINE configs[3] shape: ring of 1024 keys -> PIOP domain N = 2048, SRS 6145 G1 powers.  No reference
+    vector exists at this size (SURVEY.md §8c iii): commitment and proof are pinned to the oracle, which is
+    itself pinned at N = 512."""
+    import hashlib
+    from ark_vrf_amd.ring import RingSetup
+    ctx, _, _, srs_bytes = env[0]
+    s = R.SUITES[0]
+    setup = RingSetup(ctx, srs_bytes, 1024)
+    assert setup.domain_size == 2048 and setup.max_ring_size == 2048 - 257
+    ks = b"".join((int.from_bytes(hashlib.sha512(b"k%d" % i).digest(), "little") % (s.r >> 3) + 1).to_bytes(32, "little") for i in range(1024))
+    pks_xy = ctx.scalar_mul_base(ks)
+    pkl = [pks_xy[64 * i: 64 * i + 64] for i in range(1024)]
+    key = setup.index(pkl)
+    prm = R.Params(s, ring_size=1024)
+    srs = R.Srs(s, srs_bytes)
+    keys = [(int.from_bytes(p[:32], "little"), int.from_bytes(p[32:], "little")) for p in pkl]
+    cols = R.index(prm, srs, keys)
+    assert key.commitment == R.commitment_bytes(s, cols)
+    b = int.from_bytes(hashlib.sha512(b"blinding").digest(), "little") % (s.r >> 3)
+    proof = key.prove([777], [b.to_bytes(32, "little")])[0]
+    want, _ = R.prove(prm, srs, cols, 777, b)
+    assert proof == want

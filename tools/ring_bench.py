@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Times the Ring-VRF path (BASELINE configs[3] shape: Bandersnatch / BLS12-381, ring 1024 -> N = 2048)."""
+import hashlib
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from ark_vrf_amd import _native as nat  # noqa: E402
+from ark_vrf_amd.ring import RingSetup  # noqa: E402
+
+ring = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+nproofs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+ctx = nat.Context(0)
+srs = open(os.path.join(ROOT, "tests", "golden", "bls12-381-srs-2-11-uncompressed-zcash.bin"), "rb").read()
+t = time.perf_counter(); setup = RingSetup(ctx, srs, ring); t_setup = time.perf_counter() - t
+sks = bench.derive_scalars(b"ring-bench-sk", 0, ring, bench.R_BANDERSNATCH)
+pks = ctx.scalar_mul_base(sks)
+pkl = [pks[64 * i: 64 * i + 64] for i in range(ring)]
+t = time.perf_counter(); key = setup.index(pkl); t_index = time.perf_counter() - t
+t = time.perf_counter(); key2 = setup.index(pkl); t_index2 = time.perf_counter() - t
+bl = [bench.derive_scalars(b"ring-bench-bl", i, 1, bench.R_BANDERSNATCH) for i in range(nproofs)]
+key.prove([3], bl[:1])
+t = time.perf_counter(); proofs = key.prove([3] * nproofs, bl); t_prove = (time.perf_counter() - t) / nproofs
+print(f"ring {ring} (N={setup.domain_size}): setup {t_setup*1e3:.1f} ms, index {t_index*1e3:.1f} / {t_index2*1e3:.1f} ms, prove {t_prove*1e3:.1f} ms/proof "
+      f"({1/t_prove:.1f} proofs/s, one context, one host thread)")
