@@ -10,10 +10,33 @@ is ignored.  Pinned by: e(tau*g1, g2) == e(g1, tau*g2) on the re
 and by the reference's ring proofs verifying (tests/test_oracle_ring.py).
 """
 
-P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
-R_ORDER = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
-ATE_LOOP = 0xd201000000010000
-MOD_COEFFS = [2, 0, 0, 0, 0, 0, -2, 0, 0, 0, 0, 0]     # w^12 = 2 w^6 - 2
+# The module is parameterised by one global curve description; `use_curve("bls12_381" | "bn254")` switches.
+# BLS12-381: u^2 = -1, xi = 1 + u, w^6 = xi  =>  w^12 - 2 w^6 + 2 = 0; M-twist, untwist (x/w^2, y/w^3);
+#            Miller loop over |x| = 0xd201000000010000 (= t - 1).
+# BN254:     u^2 = -1, xi = 9 + u, w^6 = xi  =>  w^12 - 18 w^6 + 82 = 0; D-twist, untwist (x w^2, y w^3);
+#            plain ate pairing: Miller loop over t - 1 = 6 x^2, x = 4965661367192848881 (no Frobenius end
+#            steps needed; any non-degenerate bilinear pairing decides product-equals-one checks).
+CURVES = {
+    "bls12_381": dict(P=0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab,
+                      R=0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+                      LOOP=0xd201000000010000, XI0=1, MTWIST=True),
+    "bn254": dict(P=21888242871839275222246405745257275088696311157297823662689037894645226208583,
+                  R=21888242871839275222246405745257275088548364400416034343698204186575808495617,
+                  LOOP=6 * 4965661367192848881 ** 2, XI0=9, MTWIST=False),
+}
+P = R_ORDER = ATE_LOOP = XI0 = MTWIST = None
+MOD_COEFFS = None
+
+
+def use_curve(name):
+    global P, R_ORDER, ATE_LOOP, XI0, MTWIST, MOD_COEFFS
+    c = CURVES[name]
+    P, R_ORDER, ATE_LOOP, XI0, MTWIST = c["P"], c["R"], c["LOOP"], c["XI0"], c["MTWIST"]
+    # (w^6 - XI0)^2 = -1  =>  w^12 = 2 XI0 w^6 - (XI0^2 + 1)
+    MOD_COEFFS = [XI0 * XI0 + 1, 0, 0, 0, 0, 0, -2 * XI0, 0, 0, 0, 0, 0]
+
+
+use_curve("bls12_381")
 
 
 class F12:
@@ -53,11 +76,12 @@ class F12:
             if x:
                 for j, y in enumerate(o.c):
                     b[i + j] += x * y
-        for k in range(22, 11, -1):                     # reduce with w^12 = 2 w^6 - 2
+        m6, m0 = -MOD_COEFFS[6], -MOD_COEFFS[0]           # w^12 = m6 w^6 + m0
+        for k in range(22, 11, -1):
             t = b[k]
             if t:
-                b[k - 6] += 2 * t
-                b[k - 12] -= 2 * t
+                b[k - 6] += m6 * t
+                b[k - 12] += m0 * t
         return F12(b[:12])
 
     def inv(self):
@@ -105,15 +129,17 @@ def embed_fp(x):
 
 
 def embed_fp2(a, b):
-    """a + b u  ->  (a - b) + b w^6   (u = w^6 - 1)"""
-    return F12([a - b] + [0] * 5 + [b] + [0] * 5)
+    """a + b u  ->  (a - XI0 b) + b w^6   (u = w^6 - XI0)"""
+    return F12([a - XI0 * b] + [0] * 5 + [b] + [0] * 5)
 
 
 def untwist(q):
-    """G2 point ((x0, x1), (y0, y1)) on y^2 = x^3 + 4(1 + u)  ->  point of E(Fp12): y^2 = x^3 + 4."""
+    """G2 point ((x0, x1), (y0, y1)) on the sextic twist -> point of E(Fp12)."""
     (x0, x1), (y0, y1) = q
     w2 = W * W
-    return (embed_fp2(x0, x1) / w2, embed_fp2(y0, y1) / (w2 * W))
+    if MTWIST:
+        return (embed_fp2(x0, x1) / w2, embed_fp2(y0, y1) / (w2 * W))
+    return (embed_fp2(x0, x1) * w2, embed_fp2(y0, y1) * (w2 * W))
 
 
 def _double(pt):
@@ -169,6 +195,16 @@ def pairing_product_is_one(pairs):
     for p1, q2 in pairs:
         f = f * miller_loop(q2, p1)
     return final_exp(f) == F12.one()
+
+
+def g2_decode_arkworks_uncompressed(b):
+    """BN254, arkworks default SW format: x.c0 || x.c1 || y.c0 || y.c1, 32-byte little-endian each, flags in
+    the two top bits of the last byte."""
+    if b[-1] & 0x40:
+        return None
+    v = [int.from_bytes(b[32 * i: 32 * i + 32], "little") for i in range(4)]
+    v[3] &= (1 << 254) - 1
+    return ((v[0], v[1]), (v[2], v[3]))
 
 
 def g2_decode_zcash_uncompressed(b):

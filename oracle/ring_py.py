@@ -556,10 +556,11 @@ def _g1_lincomb(s, terms):
 
 def verify(prm, srs, fixed_commitments, proof, instance, pairing=None):
     """Returns True iff the ring proof verifies for `instance` (the Pedersen key commitment Yb as a TE
-    point) under the verifier key (srs.g1[0], srs.g2[0..2], fixed_commitments).  BLS12-381 only
-    (the pairing of pairing_py)."""
+    point) under the verifier key (srs.g1[0], srs.g2[0..2], fixed_commitments)."""
     from . import pairing_py as PP
     s = prm.s
+    PP.use_curve("bls12_381" if s.zcash else "bn254")
+    g2_decode = PP.g2_decode_zcash_uncompressed if s.zcash else PP.g2_decode_arkworks_uncompressed
     r, N, cap, w = s.r, prm.N, prm.capacity, prm.w
     n = s.fp_bytes
     off = 0
@@ -615,7 +616,7 @@ def verify(prm, srs, fixed_commitments, proof, instance, pairing=None):
     k2 = (b * ((x1 * y2 - x2 * y1) % r) + 1 - b) % r
     C_lin = _g1_lincomb(s, [(nl * alphas[0] % r, C[1]), (nl * alphas[1] % r * k1 % r, C[2]), (nl * alphas[2] % r * k2 % r, C[3])])
     g1 = srs.g1[0]
-    g2 = PP.g2_decode_zcash_uncompressed(srs.g2_raw[0]); tg2 = PP.g2_decode_zcash_uncompressed(srs.g2_raw[1])
+    g2 = g2_decode(srs.g2_raw[0]); tg2 = g2_decode(srs.g2_raw[1])
     zw = zeta * w % r
     ok = True
     for Cm, z, v, pi in ((C_agg, zeta, v_agg, pi1), (C_lin, zw, lin_zw, pi2)):

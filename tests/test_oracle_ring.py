@@ -57,6 +57,7 @@ def test_srs_pairing_consistency(setups):
     zcash G2 byte order)."""
     from oracle import pairing_py as PP
     s, srs, _, _ = setups[0]
+    PP.use_curve("bls12_381")
     g2, tg2 = PP.g2_decode_zcash_uncompressed(srs.g2_raw[0]), PP.g2_decode_zcash_uncompressed(srs.g2_raw[1])
     g1, tg1 = srs.g1[0], srs.g1[1]
     neg = lambda P: (P[0], (-P[1]) % s.p)
@@ -66,21 +67,36 @@ def test_srs_pairing_consistency(setups):
     assert PP.pairing_product_is_one([(srs.g1[5], g2), (neg(srs.g1[4]), tg2)])
 
 
-@pytest.mark.parametrize("vec", [0, 3, 6])
-def test_reference_ring_proofs_verify(setups, vec):
+def test_bn254_srs_pairing_consistency(setups):
+    """Same for BN254 (arkworks little-endian G2: x.c0 || x.c1 || y.c0 || y.c1) -- the survey left the BN254
+    pairing unprobed; the reference's SRS file pins it here."""
+    from oracle import pairing_py as PP
+    s, srs, _, _ = setups[1]
+    PP.use_curve("bn254")
+    g2, tg2 = PP.g2_decode_arkworks_uncompressed(srs.g2_raw[0]), PP.g2_decode_arkworks_uncompressed(srs.g2_raw[1])
+    neg = lambda P: (P[0], (-P[1]) % s.p)
+    assert PP.pairing_product_is_one([(srs.g1[1], g2), (neg(srs.g1[0]), tg2)])
+    assert PP.pairing_product_is_one([(srs.g1[9], g2), (neg(srs.g1[8]), tg2)])
+    assert not PP.pairing_product_is_one([(srs.g1[1], g2), (neg(srs.g1[1]), tg2)])
+    PP.use_curve("bls12_381")
+
+
+@pytest.mark.parametrize("suite,vec", [(0, 0), (0, 3), (0, 6), (1, 0), (1, 5)])
+def test_reference_ring_proofs_verify(setups, suite, vec):
     """RingVerifier::verify (src/ring.rs:242) restated per SURVEY.md A.8 accepts the reference's own
-    proofs and rejects perturbed ones."""
-    s, srs, vs, prm = setups[0]
+    proofs and rejects perturbed ones (both pairing curves)."""
+    s, srs, vs, prm = setups[suite]
     v = vs[vec]
     com = bytes.fromhex(v["ring_pks_com"])
-    fixed = [R.g1_decode_compressed(s, com[48 * i: 48 * i + 48]) for i in range(3)]
+    n48 = s.fp_bytes
+    fixed = [R.g1_decode_compressed(s, com[n48 * i: n48 * i + n48]) for i in range(3)]
     inst = R.te_decode(s, bytes.fromhex(v["proof_pk_com"]))
     proof = bytes.fromhex(v["ring_proof"])
     assert R.verify(prm, srs, fixed, proof, inst)
-    bad = bytearray(proof); bad[4 * 48 + 3 * 32 + 1] ^= 1               # evaluation of `bits`
+    bad = bytearray(proof); bad[4 * n48 + 3 * 32 + 1] ^= 1              # evaluation of `bits`
     assert not R.verify(prm, srs, fixed, bytes(bad), inst)
     assert not R.verify(prm, srs, fixed, proof, R.te_add(s, inst, s.blinding_base))   # other key commitment
     other = bytes.fromhex(vs[(vec + 1) % 7]["ring_pks_com"])
     if other != com:                                                   # other ring
-        fixed2 = [R.g1_decode_compressed(s, other[48 * i: 48 * i + 48]) for i in range(3)]
+        fixed2 = [R.g1_decode_compressed(s, other[n48 * i: n48 * i + n48]) for i in range(3)]
         assert not R.verify(prm, srs, fixed2, proof, inst)
