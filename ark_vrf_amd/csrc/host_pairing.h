@@ -1,0 +1,138 @@
+// host_pairing.h -- host-side pairing check for the ring verifier: e(A, g2) * e(B, tau*g2) == 1.
+//
+// Counterpart of arkworks `Pairing::multi_pairing` + final exponentiation reached from
+// `RingVerifier::verify` (src/ring.rs:242) and the multi-ring batch verifier (src/ring.rs:731).
+// A ring *batch* verification needs exactly two Miller loops and one final exponentiation however
+// many proofs it covers (the per-proof work is the G1 MSM, which runs on the GPU), so the pairing is
+// kept on the host (SURVEY.md §7 "Pairing on GPU ... 2 pairings per batch -- run on CPU").
+//
+// Tower: Fp2 = Fp[u]/(u^2+1), xi = XI0 + u, Fp6 = Fp2[v]/(v^3 - xi), Fp12 = Fp6[w]/(w^2 - v).
+// Plain ate pairing: Miller loop over t - 1 with affine points on the sextic twist, lines evaluated
+// at P in G1 in sparse form, then f^((p^12-1)/r).  Product code (not the oracle).
+#pragma once
+#include "host_g1.h"
+
+namespace avrf {
+
+template <class C> struct HostPairing {
+  using Fp = HostFieldN<typename C::Fq>;
+  using El = typename Fp::El;
+  struct F2 { El a, b; };                    // a + b u
+  struct F6 { F2 c0, c1, c2; };              // c0 + c1 v + c2 v^2
+  struct F12 { F6 c0, c1; };                 // c0 + c1 w
+  struct G2 { F2 x, y; bool inf; };
+
+  static F2 f2(const El &a, const El &b) { F2 r; r.a = a; r.b = b; return r; }
+  static F2 f2_zero() { return f2(Fp::zero(), Fp::zero()); }
+  static F2 f2_one() { return f2(Fp::one(), Fp::zero()); }
+  static bool f2_is_zero(const F2 &x) { return Fp::is_zero(x.a) && Fp::is_zero(x.b); }
+  static bool f2_eq(const F2 &x, const F2 &y) { return Fp::eq(x.a, y.a) && Fp::eq(x.b, y.b); }
+  static F2 f2_add(const F2 &x, const F2 &y) { return f2(Fp::add(x.a, y.a), Fp::add(x.b, y.b)); }
+  static F2 f2_sub(const F2 &x, const F2 &y) { return f2(Fp::sub(x.a, y.a), Fp::sub(x.b, y.b)); }
+  static F2 f2_neg(const F2 &x) { return f2(Fp::neg(x.a), Fp::neg(x.b)); }
+  static F2 f2_mul(const F2 &x, const F2 &y) {
+    El t0 = Fp::mul(x.a, y.a), t1 = Fp::mul(x.b, y.b);
+    El t2 = Fp::mul(Fp::add(x.a, x.b), Fp::add(y.a, y.b));
+    return f2(Fp::sub(t0, t1), Fp::sub(Fp::sub(t2, t0), t1));
+  }
+  static F2 f2_sqr(const F2 &x) { return f2_mul(x, x); }
+  static F2 f2_scale(const F2 &x, const El &k) { return f2(Fp::mul(x.a, k), Fp::mul(x.b, k)); }
+  static F2 f2_inv(const F2 &x) {
+    El n = Fp::inv(Fp::add(Fp::sqr(x.a), Fp::sqr(x.b)));
+    return f2(Fp::mul(x.a, n), Fp::neg(Fp::mul(x.b, n)));
+  }
+  static El small(int k) { El r = Fp::zero(), one = Fp::one(); for (int i = 0; i < k; i++) r = Fp::add(r, one); return r; }
+  static F2 f2_mul_xi(const F2 &x) {          // (a + b u)(XI0 + u) = (XI0 a - b) + (a + XI0 b) u
+    static const El k = small(C::XI0);
+    return f2(Fp::sub(Fp::mul(x.a, k), x.b), Fp::add(x.a, Fp::mul(x.b, k)));
+  }
+  static F6 f6(const F2 &a, const F2 &b, const F2 &c) { F6 r; r.c0 = a; r.c1 = b; r.c2 = c; return r; }
+  static F6 f6_zero() { return f6(f2_zero(), f2_zero(), f2_zero()); }
+  static F6 f6_add(const F6 &x, const F6 &y) { return f6(f2_add(x.c0, y.c0), f2_add(x.c1, y.c1), f2_add(x.c2, y.c2)); }
+  static F6 f6_sub(const F6 &x, const F6 &y) { return f6(f2_sub(x.c0, y.c0), f2_sub(x.c1, y.c1), f2_sub(x.c2, y.c2)); }
+  static F6 f6_mul(const F6 &x, const F6 &y) {
+    F2 v0 = f2_mul(x.c0, y.c0), v1 = f2_mul(x.c1, y.c1), v2 = f2_mul(x.c2, y.c2);
+    F2 t0 = f2_sub(f2_sub(f2_mul(f2_add(x.c1, x.c2), f2_add(y.c1, y.c2)), v1), v2);
+    F2 t1 = f2_sub(f2_sub(f2_mul(f2_add(x.c0, x.c1), f2_add(y.c0, y.c1)), v0), v1);
+    F2 t2 = f2_sub(f2_sub(f2_mul(f2_add(x.c0, x.c2), f2_add(y.c0, y.c2)), v0), v2);
+    return f6(f2_add(v0, f2_mul_xi(t0)), f2_add(t1, f2_mul_xi(v2)), f2_add(t2, v1));
+  }
+  static F6 f6_mul_v(const F6 &x) { return f6(f2_mul_xi(x.c2), x.c0, x.c1); }
+  static F12 f12_one() { F12 r; r.c0 = f6(f2_one(), f2_zero(), f2_zero()); r.c1 = f6_zero(); return r; }
+  static F12 f12_mul(const F12 &x, const F12 &y) {
+    F6 v0 = f6_mul(x.c0, y.c0), v1 = f6_mul(x.c1, y.c1);
+    F12 r;
+    r.c1 = f6_sub(f6_sub(f6_mul(f6_add(x.c0, x.c1), f6_add(y.c0, y.c1)), v0), v1);
+    r.c0 = f6_add(v0, f6_mul_v(v1));
+    return r;
+  }
+  static bool f12_is_one(const F12 &x) {
+    return Fp::eq(x.c0.c0.a, Fp::one()) && Fp::is_zero(x.c0.c0.b) && f2_is_zero(x.c0.c1) && f2_is_zero(x.c0.c2) &&
+           f2_is_zero(x.c1.c0) && f2_is_zero(x.c1.c1) && f2_is_zero(x.c1.c2);
+  }
+
+  // line through twist points with slope lam, passing (tx, ty), evaluated at P = (px, py) in G1
+  static F12 line(const F2 &lam, const F2 &tx, const F2 &ty, const El &px, const El &py) {
+    F2 c = f2_sub(f2_mul(lam, tx), ty);            // lam x' - y'
+    F2 m = f2_neg(f2_scale(lam, px));              // -lam xP
+    F2 yp = f2(py, Fp::zero());
+    F12 r;
+    if (C::MTWIST) { r.c0 = f6(c, m, f2_zero()); r.c1 = f6(f2_zero(), yp, f2_zero()); }      // (l * w^3): c + m v + yP v w
+    else { r.c0 = f6(yp, f2_zero(), f2_zero()); r.c1 = f6(m, c, f2_zero()); }                // yP + m w + c v w
+    return r;
+  }
+
+  // prod_i e(P_i, Q_i) == 1 ?   P_i affine G1 (Montgomery x, y; inf flag), Q_i affine G2 on the twist
+  static bool product_is_one(const El *px, const El *py, const bool *pinf, const G2 *q, int n) {
+    std::vector<F2> rx(n), ry(n);
+    std::vector<bool> live(n);
+    for (int i = 0; i < n; i++) { live[i] = !pinf[i] && !q[i].inf; rx[i] = q[i].x; ry[i] = q[i].y; }
+    F12 f = f12_one();
+    static const El three = small(3), two = small(2);
+    for (int bit = C::ATE_LOOP_BITS - 2; bit >= 0; bit--) {
+      f = f12_mul(f, f);
+      for (int i = 0; i < n; i++) {
+        if (!live[i]) continue;
+        F2 lam = f2_mul(f2_scale(f2_sqr(rx[i]), three), f2_inv(f2_scale(ry[i], two)));   // 3 x^2 / (2 y)
+        f = f12_mul(f, line(lam, rx[i], ry[i], px[i], py[i]));
+        F2 nx = f2_sub(f2_sqr(lam), f2_add(rx[i], rx[i]));
+        ry[i] = f2_sub(f2_mul(lam, f2_sub(rx[i], nx)), ry[i]); rx[i] = nx;
+      }
+      if ((C::ATE_LOOP[bit >> 6] >> (bit & 63)) & 1) {
+        for (int i = 0; i < n; i++) {
+          if (!live[i]) continue;
+          if (f2_eq(rx[i], q[i].x)) { live[i] = false; continue; }      // cannot happen for points of order r
+          F2 lam = f2_mul(f2_sub(q[i].y, ry[i]), f2_inv(f2_sub(q[i].x, rx[i])));
+          f = f12_mul(f, line(lam, rx[i], ry[i], px[i], py[i]));
+          F2 nx = f2_sub(f2_sub(f2_sqr(lam), rx[i]), q[i].x);
+          ry[i] = f2_sub(f2_mul(lam, f2_sub(rx[i], nx)), ry[i]); rx[i] = nx;
+        }
+      }
+    }
+    // f^((p^12 - 1) / r)
+    F12 out = f12_one();
+    for (int bit = C::FINAL_EXP_BITS - 1; bit >= 0; bit--) {
+      out = f12_mul(out, out);
+      if ((C::FINAL_EXP[bit >> 6] >> (bit & 63)) & 1) out = f12_mul(out, f);
+    }
+    return f12_is_one(out);
+  }
+
+  // G2 from the `powers_in_g2` bytes of an arkworks URS file
+  static bool g2_decode(const uint8_t *b, G2 *out) {
+    constexpr int B = 8 * Fp::L;
+    El v[4];
+    if (B == 48) {                                                     // zcash: x.c1 || x.c0 || y.c1 || y.c0, big-endian
+      out->inf = (b[0] & 0x40) != 0;
+      for (int k = 0; k < 4; k++) { uint8_t le[48]; for (int i = 0; i < B; i++) le[i] = b[k * B + B - 1 - i]; if (k == 0) le[B - 1] &= 0x1f; memcpy(v[k].l, le, B); }
+      out->x = f2(Fp::to_mont(v[1]), Fp::to_mont(v[0])); out->y = f2(Fp::to_mont(v[3]), Fp::to_mont(v[2]));
+    } else {                                                           // arkworks: x.c0 || x.c1 || y.c0 || y.c1, little-endian
+      out->inf = (b[4 * B - 1] & 0x40) != 0;
+      for (int k = 0; k < 4; k++) { uint8_t le[32]; memcpy(le, b + k * B, B); if (k == 3) le[B - 1] &= 0x3f; memcpy(v[k].l, le, B); }
+      out->x = f2(Fp::to_mont(v[0]), Fp::to_mont(v[1])); out->y = f2(Fp::to_mont(v[2]), Fp::to_mont(v[3]));
+    }
+    return true;
+  }
+};
+
+}  // namespace avrf

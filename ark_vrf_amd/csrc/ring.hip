@@ -10,6 +10,7 @@
 #include "../../include/avrf.h"
 #include "te.h"
 #include "host_g1.h"
+#include "host_pairing.h"
 #include "host_te.h"
 #include "msm.h"
 #include <stdio.h>
@@ -457,6 +458,151 @@ template <class S, class G> struct Ring {
     memcpy(out, pr.data(), pr.size());
     return AVRF_OK;
   }
+
+  // ---- G1 decompression (ark-serialize compressed forms); p = 3 mod 4 for both curves
+  using FqN = typename T::FqN; using QEl = typename FqN::El;
+  static bool g1_decompress(const uint8_t *b, G1Aff *out) {
+    memset(out, 0, sizeof *out);
+    uint8_t le[48]; bool big, inf;
+    if (FQB == 48) { inf = b[0] & 0x40; big = b[0] & 0x20; if (!(b[0] & 0x80)) return false; for (int i = 0; i < FQB; i++) le[i] = b[FQB - 1 - i]; le[FQB - 1] &= 0x1f; }
+    else { inf = b[FQB - 1] & 0x40; big = b[FQB - 1] & 0x80; memcpy(le, b, FQB); le[FQB - 1] &= 0x3f; }
+    if (inf) { out->inf = true; return true; }
+    QEl x; memcpy(x.l, le, FQB);
+    QEl t; if (FqN::subb(t, x, FqN::P()) == 0) return false;           // x >= p
+    QEl xm = FqN::to_mont(x);
+    QEl rhs = FqN::add(FqN::mul(FqN::sqr(xm), xm), FqN::from32(G::B));
+    static const QEl e = [] { QEl v = FqN::P(), one = FqN::zero(); one.l[0] = 1; FqN::addc(v, v, one);   // (p + 1) / 4
+                              for (int k = 0; k < 2; k++) for (int i = 0; i < FqN::L; i++) v.l[i] = (v.l[i] >> 1) | (i + 1 < FqN::L ? v.l[i + 1] << 63 : 0);
+                              return v; }();
+    QEl y = FqN::one();
+    for (int i = 64 * FqN::L - 1; i >= 0; i--) { y = FqN::sqr(y); if ((e.l[i / 64] >> (i % 64)) & 1) y = FqN::mul(y, rhs); }
+    if (!FqN::eq(FqN::sqr(y), rhs)) return false;                       // not on the curve
+    QEl yp = FqN::from_mont(y), half = FqN::from32(G::Fq::HALF);
+    bool is_big = FqN::subb(t, half, yp) != 0;
+    if (is_big != big) { y = FqN::neg(y); yp = FqN::from_mont(y); }
+    memcpy(out->xy, x.l, FQB); memcpy(out->xy + FQB, yp.l, FQB);
+    return true;
+  }
+  static G1Aff g1_msm(avrf_ring_setup *su, const std::vector<uint8_t> &bases_xy, const std::vector<H256> &scalars_plain) {
+    const size_t n = scalars_plain.size();
+    G1Aff r; memset(&r, 0, sizeof r); r.inf = true;
+    if (!n) return r;
+    uint8_t *d_xy; uint32_t *d_b, *d_s, *d_flag;
+    HIP_CHECK(hipMalloc(&d_xy, n * 2 * FQB)); HIP_CHECK(hipMalloc(&d_b, n * 2 * FQB)); HIP_CHECK(hipMalloc(&d_s, n * 32)); HIP_CHECK(hipMalloc(&d_flag, 4));
+    HIP_CHECK(hipMemcpyAsync(d_xy, bases_xy.data(), n * 2 * FQB, hipMemcpyHostToDevice, su->stream));
+    HIP_CHECK(hipMemcpyAsync(d_s, scalars_plain.data(), n * 32, hipMemcpyHostToDevice, su->stream));
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream));
+    launch_g1_bases(su->suite, d_xy, n, d_b, d_flag, su->stream);
+    msm_g1_device(su->suite, d_b, d_s, n, su->ws, su->stream, r.xy);
+    HIP_CHECK(hipFree(d_xy)); HIP_CHECK(hipFree(d_b)); HIP_CHECK(hipFree(d_s)); HIP_CHECK(hipFree(d_flag));
+    r.inf = true; for (int i = 0; i < 2 * FQB; i++) if (r.xy[i]) r.inf = false;
+    return r;
+  }
+
+  // ---- RingVerifier::verify / multi-ring batch verifier (src/ring.rs:242,693-735).
+  // Every item's two KZG openings are folded with 128-bit randomisers into
+  //   e(sum r (C - v g1 + z pi), g2) * e(-sum r pi, tau g2) == 1 :
+  // two G1 MSMs on the GPU (10 n + 1 and 2 n terms) and one 2-pairing check on the host.
+  static int verify_batch(avrf_ring_setup *su, size_t n, const uint8_t *commitments, const uint32_t *ring_of_item, size_t n_rings,
+                          const uint8_t *instances_xy, const uint8_t *proofs) {
+    if (n == 0) return AVRF_OK;
+    const size_t N = su->N, cap = su->cap, plen = 4 * FQB + 7 * 32 + FQB + 32 + 2 * FQB, clen = 3 * FQB;
+    const H256 one = Fr::one();
+    std::vector<G1Aff> fixed(3 * n_rings);
+    for (size_t i = 0; i < 3 * n_rings; i++) if (!g1_decompress(commitments + FQB * i, &fixed[i])) return AVRF_INVALID_DATA;
+    (void)clen;
+    // randomisers: SHAKE128 over everything the batch contains
+    Shake128 rh; rh.update("avrf-ring-batch", 15); rh.update(commitments, 3 * FQB * n_rings); rh.update(instances_xy, 64 * n); rh.update(proofs, plen * n);
+    std::vector<uint8_t> rnd(32 * n); rh.squeeze_copy(rnd.data(), rnd.size());
+    std::vector<uint8_t> b1, b2; std::vector<H256> s1, s2;
+    auto push = [&](std::vector<uint8_t> &b, std::vector<H256> &sv, const G1Aff &p, const H256 &k_mont) {
+      b.insert(b.end(), p.xy, p.xy + 2 * FQB); sv.push_back(Fr::from_mont(k_mont)); };
+    H256 g1_scalar = {{0, 0, 0, 0}};
+    const H256 w_last = fr_pow<F>(su->w, cap - 1), ninv = su->ninv;
+    const H256 a_coef = S::A_KIND == 1 ? Fr::neg(fr_small<F>(5)) : one;
+    H256 wz[3]; for (int j = 0; j < 3; j++) wz[j] = fr_pow<F>(su->w, N - 3 + j);
+    H256 seedx = Fr::from32(S::ACC_X), seedy = Fr::from32(S::ACC_Y);
+    for (size_t it = 0; it < n; it++) {
+      const uint8_t *pr = proofs + plen * it;
+      const uint32_t ring = ring_of_item ? ring_of_item[it] : 0;
+      if (ring >= n_rings) return AVRF_ERR_BAD_ARG;
+      const G1Aff *fx = &fixed[3 * ring];
+      G1Aff C[4], Cq, pi1, pi2; H256 ev[7], lin_zw;
+      size_t off = 0;
+      for (int i = 0; i < 4; i++) { if (!g1_decompress(pr + off, &C[i])) return AVRF_INVALID_DATA; off += FQB; }
+      for (int i = 0; i < 7; i++) { H256 v = Fr::load_le(pr + off); if (Fr::geq_p(v)) return AVRF_INVALID_DATA; ev[i] = Fr::to_mont(v); off += 32; }
+      if (!g1_decompress(pr + off, &Cq)) return AVRF_INVALID_DATA; off += FQB;
+      { H256 v = Fr::load_le(pr + off); if (Fr::geq_p(v)) return AVRF_INVALID_DATA; lin_zw = Fr::to_mont(v); off += 32; }
+      if (!g1_decompress(pr + off, &pi1)) return AVRF_INVALID_DATA; off += FQB;
+      if (!g1_decompress(pr + off, &pi2)) return AVRF_INVALID_DATA; off += FQB;
+      H256 ix = Fr::load_le(instances_xy + 64 * it), iy = Fr::load_le(instances_xy + 64 * it + 32);
+      if (Fr::geq_p(ix) || Fr::geq_p(iy)) return AVRF_INVALID_DATA;
+      H256 ixm = Fr::to_mont(ix), iym = Fr::to_mont(iy);
+      // transcript replay
+      ArkTranscript t;
+      t.label(S::SUITE_ID, S::SUITE_ID_LEN); t.label("vk");
+      { std::vector<uint8_t> vk; g1_encode<G>(su->g1_0, false, vk); vk.insert(vk.end(), su->g2_raw.begin(), su->g2_raw.end());
+        for (int i = 0; i < 3; i++) g1_encode<G>(fx[i], false, vk); t.append(vk); }
+      { std::vector<uint8_t> b(instances_xy + 64 * it, instances_xy + 64 * it + 64); t.label("instance"); t.append(b); }
+      { std::vector<uint8_t> b; for (int i = 0; i < 4; i++) g1_encode<G>(C[i], false, b); t.label("committed_cols"); t.append(b); }
+      H256 al[7]; for (int i = 0; i < 7; i++) al[i] = challenge(t, "constraints_aggregation");
+      { std::vector<uint8_t> b; g1_encode<G>(Cq, false, b); t.label("quotient"); t.append(b); }
+      H256 zeta = challenge(t, "evaluation_point");
+      { std::vector<uint8_t> b(pr + 4 * FQB, pr + 4 * FQB + 7 * 32); t.label("register_evaluations"); t.append(b); }
+      { std::vector<uint8_t> b(pr + 5 * FQB + 7 * 32, pr + 5 * FQB + 8 * 32); t.label("shifted_linearization_evaluation"); t.append(b); }
+      H256 nu[8]; for (int i = 0; i < 8; i++) nu[i] = challenge(t, "kzg_aggregation");
+      // q(zeta) from the evaluations (A.8)
+      const H256 x2 = ev[0], y2 = ev[1], sel = ev[2], b = ev[3], ip = ev[4], x1 = ev[5], y1 = ev[6];
+      const H256 nl = Fr::sub(zeta, w_last), omb = Fr::sub(one, b);
+      H256 zn = zeta; for (size_t k = 1; k < N; k <<= 1) zn = Fr::sqr(zn);
+      const H256 zn1 = Fr::sub(zn, one);
+      if (Fr::is_zero(zn1)) return AVRF_VERIFICATION_FAILURE;
+      auto lag = [&](size_t i) { H256 wi = fr_pow<F>(su->w, i); return Fr::mul(Fr::mul(Fr::mul(wi, zn1), ninv), Fr::inv(Fr::sub(zeta, wi))); };
+      const H256 lf = lag(0), ll = lag(cap - 1);
+      HostExt sd; sd.x = seedx; sd.y = seedy; sd.t = Fr::mul(seedx, seedy); sd.z = one;
+      HostExt in; in.x = ixm; in.y = iym; in.t = Fr::mul(ixm, iym); in.z = one;
+      HostExt rs = Te::add(sd, in); H256 rzi = Fr::inv(rs.z); const H256 resx = Fr::mul(rs.x, rzi), resy = Fr::mul(rs.y, rzi);
+      const H256 x1y1 = Fr::mul(x1, y1), x2y2 = Fr::mul(x2, y2);
+      H256 rest[7];
+      rest[0] = Fr::mul(Fr::neg(Fr::add(ip, Fr::mul(sel, b))), nl);
+      rest[1] = Fr::mul(Fr::sub(Fr::mul(b, Fr::neg(Fr::add(x1y1, x2y2))), Fr::mul(omb, x1)), nl);
+      rest[2] = Fr::mul(Fr::sub(Fr::mul(b, Fr::sub(x2y2, x1y1)), Fr::mul(omb, y1)), nl);
+      rest[3] = Fr::mul(b, omb);
+      rest[4] = Fr::add(Fr::mul(lf, Fr::sub(x1, seedx)), Fr::mul(ll, Fr::sub(x1, resx)));
+      rest[5] = Fr::add(Fr::mul(lf, Fr::sub(y1, seedy)), Fr::mul(ll, Fr::sub(y1, resy)));
+      rest[6] = Fr::add(Fr::mul(lf, ip), Fr::mul(ll, Fr::sub(ip, one)));
+      H256 aggz = lin_zw; for (int i = 0; i < 7; i++) aggz = Fr::add(aggz, Fr::mul(al[i], rest[i]));
+      H256 zk = one; for (int j = 0; j < 3; j++) zk = Fr::mul(zk, Fr::sub(zeta, wz[j]));
+      const H256 qz = Fr::mul(Fr::mul(aggz, zk), Fr::inv(zn1));
+      H256 vagg = Fr::mul(nu[7], qz); for (int i = 0; i < 7; i++) vagg = Fr::add(vagg, Fr::mul(nu[i], ev[i]));
+      const H256 k1 = Fr::add(Fr::mul(b, Fr::add(Fr::mul(y1, y2), Fr::mul(a_coef, Fr::mul(x1, x2)))), omb);
+      const H256 k2 = Fr::add(Fr::mul(b, Fr::sub(Fr::mul(x1, y2), Fr::mul(x2, y1))), omb);
+      const H256 zw = Fr::mul(zeta, su->w);
+      // randomisers r1, r2 (128 bits each)
+      H256 r1 = Fr::to_mont(H256{{0, 0, 0, 0}}), r2 = r1;
+      { H256 a = {{0, 0, 0, 0}}, c = {{0, 0, 0, 0}}; memcpy(a.l, &rnd[32 * it], 16); memcpy(c.l, &rnd[32 * it + 16], 16); r1 = Fr::to_mont(a); r2 = Fr::to_mont(c); }
+      if (n == 1) r1 = one;
+      for (int j = 0; j < 3; j++) push(b1, s1, fx[j], Fr::mul(r1, nu[j]));
+      push(b1, s1, C[0], Fr::mul(r1, nu[3]));
+      push(b1, s1, C[1], Fr::add(Fr::mul(r1, nu[4]), Fr::mul(r2, Fr::mul(nl, al[0]))));
+      push(b1, s1, C[2], Fr::add(Fr::mul(r1, nu[5]), Fr::mul(r2, Fr::mul(nl, Fr::mul(al[1], k1)))));
+      push(b1, s1, C[3], Fr::add(Fr::mul(r1, nu[6]), Fr::mul(r2, Fr::mul(nl, Fr::mul(al[2], k2)))));
+      push(b1, s1, Cq, Fr::mul(r1, nu[7]));
+      push(b1, s1, pi1, Fr::mul(r1, zeta)); push(b1, s1, pi2, Fr::mul(r2, zw));
+      g1_scalar = Fr::sub(g1_scalar, Fr::add(Fr::mul(r1, vagg), Fr::mul(r2, lin_zw)));
+      push(b2, s2, pi1, Fr::neg(r1)); push(b2, s2, pi2, Fr::neg(r2));
+    }
+    push(b1, s1, su->g1_0, g1_scalar);
+    G1Aff acc1 = g1_msm(su, b1, s1), acc2 = g1_msm(su, b2, s2);
+    using HP = HostPairing<G>;
+    typename HP::G2 q[2];
+    const size_t g2len = su->g2_raw.size() / 2;
+    HP::g2_decode(su->g2_raw.data(), &q[0]); HP::g2_decode(su->g2_raw.data() + g2len, &q[1]);
+    QEl px[2], py[2]; bool pinf[2] = {acc1.inf, acc2.inf};
+    const G1Aff *accs[2] = {&acc1, &acc2};
+    for (int i = 0; i < 2; i++) { QEl x, y; memset(&x, 0, sizeof x); memset(&y, 0, sizeof y); memcpy(x.l, accs[i]->xy, FQB); memcpy(y.l, accs[i]->xy + FQB, FQB); px[i] = FqN::to_mont(x); py[i] = FqN::to_mont(y); }
+    return HP::product_is_one(px, py, pinf, q, 2) ? AVRF_OK : AVRF_VERIFICATION_FAILURE;
+  }
 };
 
 using RingB = Ring<SuiteBandersnatch, G1Bls12381>;
@@ -509,6 +655,14 @@ int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const
     if (st) return st;
   }
   return AVRF_OK;
+}
+
+int avrf_ring_batch_verify(avrf_ring_setup *su, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,
+                           const uint8_t *instances_xy, const uint8_t *ring_proofs) {
+  if (!su || (n && (!ring_commitments || !n_rings || !instances_xy || !ring_proofs))) return AVRF_ERR_BAD_ARG;
+  if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
+  return su->suite == 0 ? RingB::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs)
+                        : RingJ::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs);
 }
 
 }  // extern "C"

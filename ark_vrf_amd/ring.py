@@ -72,3 +72,13 @@ class RingSetup:
             self.close()
         except Exception:
             pass
+
+
+def ring_batch_verify(setup, ring_commitments, ring_of_item, instances_xy, ring_proofs):
+    """RingVerifier::verify / RingBatchVerifier (src/ring.rs:242,682-735) on bare ring proofs.
+    ring_commitments: list of compressed RingCommitment bytes; ring_of_item: list of indices into it (or None);
+    instances_xy: list of 64-byte key commitments Yb; ring_proofs: list of proof bytes.  Returns the status."""
+    n = len(ring_proofs)
+    roi = nat._u32(ring_of_item) if ring_of_item is not None else None
+    return nat.lib().avrf_ring_batch_verify(setup._h, C.c_size_t(n), nat._u8(b"".join(ring_commitments)), C.c_size_t(len(ring_commitments)),
+                                            roi, nat._u8(b"".join(instances_xy)), nat._u8(b"".join(ring_proofs)))

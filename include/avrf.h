@@ -170,6 +170,17 @@ void avrf_ring_key_free(avrf_ring_key *key);
 int avrf_ring_prove(avrf_ring_key *key, size_t n, const uint32_t *key_index, const uint8_t *blindings, int blinding_mode,
                     uint8_t *proofs_out);
 
+/* RingVerifier::verify (n = 1) and the multi-ring RingBatchVerifier::{push, verify} (src/ring.rs:242,682-735):
+ * verifies n bare ring proofs (compressed serialisation, avrf_ring_proof_len bytes each) for the key
+ * commitments instances_xy (n x 64: the Pedersen proof's Yb, src/ring.rs:237-241) against ring commitments
+ * (n_rings x avrf_ring_commitment_len, cf. verifier_key_from_commitment src/ring.rs:477-482); ring_of_item[i]
+ * selects the ring of item i (NULL = all items use ring 0).  One randomised check: two G1 MSMs on the GPU and
+ * a 2-pairing check.  A complete ring-VRF (batch) verification is avrf_pedersen_(batch_)verify on the Pedersen
+ * halves plus this call (src/ring.rs:236-242,729-735).  Returns AVRF_OK / AVRF_VERIFICATION_FAILURE /
+ * AVRF_INVALID_DATA (undecodable point or scalar). */
+int avrf_ring_batch_verify(avrf_ring_setup *setup, size_t n, const uint8_t *ring_commitments, size_t n_rings,
+                           const uint32_t *ring_of_item, const uint8_t *instances_xy, const uint8_t *ring_proofs);
+
 /* CanonicalSerialize / CanonicalDeserialize of curve points, batched on the device
  * (ark-serialize compressed form; checked constructors src/lib.rs:410-494).
  * decompress: in n x 32 -> out n x 64; status_out[j] = AVRF_OK / AVRF_INVALID_DATA.

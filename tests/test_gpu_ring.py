@@ -112,3 +112,57 @@ def test_ring_1024_matches_oracle(env, golden_dir):
     proof = key.prove([777], [b.to_bytes(32, "little")])[0]
     want, _ = R.prove(prm, srs, cols, 777, b)
     assert proof == want
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_ring_verify_reference_vectors(env, suite):
+    """a11 / a12: the reference's ring proofs verify one by one and as ONE multi-ring batch (every vector
+    has its own ring: its public key sits at index 3 of an otherwise common ring, src/ring.rs:1475-1478);
+    perturbations are rejected (prove_verify_batch, src/ring.rs:1017-1140)."""
+    from ark_vrf_amd.ring import ring_batch_verify
+    ctx, setup, vs, srs = env[suite]
+    coms = [bytes.fromhex(v["ring_pks_com"]) for v in vs]
+    insts = [xy(suite, bytes.fromhex(v["proof_pk_com"])) for v in vs]
+    proofs = [bytes.fromhex(v["ring_proof"]) for v in vs]
+    for i in (0, 4):
+        assert ring_batch_verify(setup, [coms[i]], None, [insts[i]], [proofs[i]]) == 0       # single verify
+    assert ring_batch_verify(setup, coms, list(range(7)), insts, proofs) == 0                # multi-ring batch
+    assert ring_batch_verify(setup, [], None, [], []) == 0
+    # wrong ring for one item
+    assert ring_batch_verify(setup, coms, [1, 1, 2, 3, 4, 5, 6], insts, proofs) == 1
+    # tampered evaluation / tampered commitment point / other key commitment
+    fq = 48 if suite == 0 else 32
+    bad = bytearray(proofs[2]); bad[4 * fq + 5] ^= 1
+    assert ring_batch_verify(setup, coms, list(range(7)), insts, proofs[:2] + [bytes(bad)] + proofs[3:]) == 1
+    swapped = proofs[:5] + [proofs[6], proofs[5]]
+    assert ring_batch_verify(setup, coms, list(range(7)), insts, swapped) == 1
+    assert ring_batch_verify(setup, coms, list(range(7)), insts[1:] + insts[:1], proofs) == 1
+    junk = bytearray(proofs[0]); junk[1:fq] = b"\x7f" * (fq - 1)
+    assert ring_batch_verify(setup, [coms[0]], None, [insts[0]], [bytes(junk)]) in (1, 2)   # undecodable or wrong
+
+
+def test_ring_vrf_end_to_end_gpu(env):
+    """ring::Prover::prove + ring::Verifier::verify composed from the ABI pieces (src/ring.rs:211-247): Pedersen
+    proof + ring proof for the returned blinding; verify = Pedersen verify + ring verify of Yb."""
+    import hashlib
+    from ark_vrf_amd._native import Batch
+    from ark_vrf_amd.ring import ring_batch_verify
+    ctx, setup, vs, srs = env[0]
+    r_te = 0x1cfb69d4ca675f520cce760202687600ff8f87007419047174fd06b52876e7e1
+    sks = [(int.from_bytes(hashlib.sha512(b"e2e%d" % i).digest(), "little") % r_te).to_bytes(32, "little") for i in range(6)]
+    pks = ctx.scalar_mul_base(b"".join(sks))
+    pkl = [pks[64 * i: 64 * i + 64] for i in range(6)]
+    key = setup.index(pkl)
+    inputs = ctx.scalar_mul_base(b"".join((i + 7).to_bytes(32, "little") for i in range(6)))
+    outs = ctx.scalar_mul(b"".join(sks), inputs)
+    ios = [[(inputs[64 * i: 64 * i + 64], outs[64 * i: 64 * i + 64])] for i in range(6)]
+    ads = [b"ad%d" % i for i in range(6)]
+    ped, blind = ctx.pedersen_prove(Batch.from_items(ios, ads, sks=sks, pks_xy=pkl))
+    pedl = [ped[256 * i: 256 * i + 256] for i in range(6)]
+    rproofs = key.prove(list(range(6)), [blind[32 * i: 32 * i + 32] for i in range(6)])
+    assert ctx.pedersen_batch_verify(ios, ads, pedl) == 0
+    ybs = [p[:64] for p in pedl]
+    assert ring_batch_verify(setup, [key.commitment], None, ybs, rproofs) == 0
+    # a proof by a key outside the ring: index with a different key set
+    key2 = setup.index(pkl[:5] + [pkl[0]])
+    assert ring_batch_verify(setup, [key2.commitment], None, ybs, rproofs) == 1
