@@ -20,6 +20,7 @@ template <class S> struct TeCurve {
     return te_madd<S>(a, q);
   }
   static AVRF_DI acc_t add(const acc_t &a, const acc_t &b) { return te_add<S>(a, b); }
+  static AVRF_DI acc_t dbl(const acc_t &a) { return te_dbl<S>(a); }
   static AVRF_DI base_t load_base(const uint32_t *p) { return load_pre(reinterpret_cast<const te_pre *>(p)); }
   static AVRF_DI acc_t load_acc(const uint32_t *p) { return load_ext(reinterpret_cast<const te_ext *>(p)); }
   static AVRF_DI void store_acc(uint32_t *p, const acc_t &a) { store_ext(reinterpret_cast<te_ext *>(p), a); }

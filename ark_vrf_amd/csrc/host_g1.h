@@ -99,6 +99,28 @@ template <class C> struct HostG1 {
     El x = Fq::from_mont(Fq::mul(a.x, zi)), y = Fq::from_mont(Fq::mul(a.y, zzzi));
     memcpy(out, x.l, B); memcpy(out + B, y.l, B);
   }
+  // same for many points with one field inversion (Montgomery's trick over all zz and zzz)
+  static void to_affine_bytes_batch(const Pt *pts, size_t n, uint8_t *out) {
+    constexpr int B = 8 * Fq::L;
+    if (n == 1) { to_affine_bytes(pts[0], out); return; }
+    El *pre = new El[2 * n + 1];
+    El run = Fq::one();
+    for (size_t i = 0; i < n; i++) {
+      const bool id = is_identity(pts[i]);
+      pre[2 * i] = run; if (!id) run = Fq::mul(run, pts[i].zz);
+      pre[2 * i + 1] = run; if (!id) run = Fq::mul(run, pts[i].zzz);
+    }
+    El inv = Fq::inv(run);
+    for (size_t i = n; i-- > 0;) {
+      uint8_t *o = out + 2 * B * i;
+      if (is_identity(pts[i])) { memset(o, 0, 2 * B); continue; }
+      El zzzi = Fq::mul(inv, pre[2 * i + 1]); inv = Fq::mul(inv, pts[i].zzz);
+      El zzi = Fq::mul(inv, pre[2 * i]); inv = Fq::mul(inv, pts[i].zz);
+      El x = Fq::from_mont(Fq::mul(pts[i].x, zzi)), y = Fq::from_mont(Fq::mul(pts[i].y, zzzi));
+      memcpy(o, x.l, B); memcpy(o + B, y.l, B);
+    }
+    delete[] pre;
+  }
 };
 
 }  // namespace avrf

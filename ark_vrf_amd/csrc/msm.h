@@ -35,12 +35,12 @@ struct MsmWorkspace {
   uint32_t *part = nullptr;      // 2 per wave of k_accumulate: partial sums of runs that cross a wave boundary
   uint32_t *bits = nullptr;      // nwin * c
   uint32_t *bits_host = nullptr; // pinned
-  size_t cap_n = 0, cap_slots = 0, cap_buckets = 0, cap_bits = 0, cap_part = 0, cap_hist = 0;   // cap_buckets.. in bytes
+  size_t cap_n = 0, cap_slots = 0, cap_buckets = 0, cap_bits = 0, cap_part = 0, cap_hist = 0, cap_vwin = 0;   // cap_buckets.. in bytes
   // HIP events bracketing the dominant kernel (k_accumulate) on the launch stream
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double accum_ms_total = 0; uint64_t accum_launches = 0; float accum_ms_last = 0;
   MsmPlan last_plan = {0, 0, 0, 0};
-  void ensure(size_t n, const MsmPlan &p, size_t acc_bytes);
+  void ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch = 1);
   void release();
 };
 
@@ -52,7 +52,9 @@ int msm_te_device(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars,
 // G1 MSM over a short-Weierstrass curve (curve: 0 BLS12-381, 1 BN254): d_bases = n Montgomery affine
 // points (2 * Fq words each, (0,0) = infinity), d_scalars = n plain 256-bit scalars (< r).
 // out_xy: canonical affine x || y little-endian (2 * FQ_BYTES), all-zero for the point at infinity.
-int msm_g1_device(int curve, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy);
+// batch > 1: `batch` scalar vectors (batch x n x 8 words) over the same bases, `batch` results in out_xy.
+int msm_g1_device(int curve, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy,
+                  size_t batch = 1);
 void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, uint32_t *d_flag, hipStream_t stream);
 
 // canonical affine bytes (x||y LE32) -> te_pre (device); flags[i] |= 1 if a coordinate >= q, |= 2 if off-curve (when check_curve)

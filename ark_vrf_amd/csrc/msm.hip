@@ -30,6 +30,7 @@
 #include "host_g1.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 namespace avrf {
 
@@ -64,11 +65,15 @@ void launch_pre_from_affine(int suite, const uint8_t *d_xy, size_t n, te_pre_raw
 
 // signed digit of window w with carry chain; digits in [-(2^(c-1)-1), 2^(c-1)];
 // key = bucket (1..2^(c-1), 0 = skip) | sign << 15
+// blockIdx.y = index of the scalar vector in a batch of MSMs over the same bases ("virtual windows"
+// v = batch * nwin + w everywhere downstream)
 __global__ void k_digits(const uint32_t *__restrict__ scalars, uint32_t n, int c, int nwin, uint16_t *__restrict__ keys) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const uint32_t bat = blockIdx.y;
+  keys += (size_t)bat * nwin * n;
   uint32_t s[9];
-  const uint4 *p = reinterpret_cast<const uint4 *>(scalars + 8 * (size_t)i);
+  const uint4 *p = reinterpret_cast<const uint4 *>(scalars + 8 * ((size_t)bat * n + i));
   uint4 a = p[0], b = p[1];
   s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; s[8] = 0;
   const uint32_t nb = 1u << (c - 1), mask = (1u << c) - 1;
@@ -281,12 +286,49 @@ k_bits(const uint32_t *__restrict__ buckets, const uint32_t *__restrict__ rc, in
   if (lane == 0) CV::store_acc(out + (size_t)gw * CV::ACC_WORDS, acc);
 }
 
+// Small bucket counts (nb <= 256, the batched KZG-sized MSMs): one LANE per (window, bit k) adds the nb/2
+// buckets whose index has bit k set -- the wave-per-task row/column kernels above would spend a whole
+// wave (and a 6-step shuffle tree) on a handful of buckets.
+template <class CV>
+__global__ void __launch_bounds__(128)
+k_bits_direct(const uint32_t *__restrict__ buckets, int c, uint32_t total, uint32_t *__restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const uint32_t nb = 1u << (c - 1), w = t / c, k = t - w * c;
+  const uint32_t *B = buckets + (size_t)w * nb * CV::ACC_WORDS;
+  typename CV::acc_t acc = CV::identity();
+  if ((int)k == c - 1) acc = CV::load_acc(B + (size_t)(nb - 1) * CV::ACC_WORDS);
+  else for (uint32_t m = 0; m < (nb >> 1); m++) {
+    uint32_t b = ((m >> k) << (k + 1)) | (1u << k) | (m & ((1u << k) - 1));
+    acc = CV::add(acc, CV::load_acc(B + (size_t)(b - 1) * CV::ACC_WORDS));
+  }
+  CV::store_acc(out + (size_t)t * CV::ACC_WORDS, acc);
+}
+
+// Window/bit Horner on the device for BATCHED MSMs: one lane per MSM walks its nbits bit sums,
+// result = sum_p 2^p T_p.  (A single MSM finishes faster on the host; with hundreds of MSMs per launch
+// chain the host Horner would dominate.)
+template <class CV>
+__global__ void __launch_bounds__(64)
+k_horner(const uint32_t *__restrict__ bits, uint32_t nbits, uint32_t batch, uint32_t *__restrict__ out) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const uint32_t *T = bits + (size_t)b * nbits * CV::ACC_WORDS;
+  typename CV::acc_t acc = CV::identity();
+  for (int i = (int)nbits - 1; i >= 0; i--) {
+    acc = CV::dbl(acc);
+    acc = CV::add(acc, CV::load_acc(T + (size_t)i * CV::ACC_WORDS));
+  }
+  CV::store_acc(out + (size_t)b * CV::ACC_WORDS, acc);
+}
+
 // ---------------------------------------------------------------- host engine
 
 MsmPlan msm_plan(size_t n, int scalar_bits) {
   MsmPlan p;
   int lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
-  int c = lg - 5; if (c < 4) c = 4; if (c > 15) c = 15;
+  int c = lg >= 16 ? lg - 5 : lg - 3;                   // small (KZG-sized, batched) MSMs: ~8 entries per bucket
+  if (c < 4) c = 4; if (c > 15) c = 15;
   p.c = c; p.lpb = 16;                                   // lpb = SEG: entries per lane
   if (const char *e = getenv("AVRF_MSM_C")) { int v = atoi(e); if (v >= 3 && v <= 15) p.c = v; }
   if (const char *e = getenv("AVRF_MSM_SEG")) { int v = atoi(e); if (v >= 1 && v <= 1024) p.lpb = v; }
@@ -298,9 +340,10 @@ MsmPlan msm_plan(size_t n, int scalar_bits) {
 static uint32_t tile_len_for(size_t n) { return 8192; }
 static uint32_t lcap_for(size_t n, const MsmPlan &p) { return (uint32_t)(((n / (size_t)p.lpb + p.nb + 1) + 63) / 64 * 64); }
 
-void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes) {
-  size_t nbk = (size_t)p.nwin * p.nb, nbits = (size_t)p.nwin * p.c;
-  size_t need_n = (size_t)p.nwin * n;
+void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch) {
+  const size_t vwin = (size_t)p.nwin * batch;           // virtual windows
+  size_t nbk = vwin * p.nb, nbits = vwin * p.c;
+  size_t need_n = vwin * n;
   size_t ntiles = (n + tile_len_for(n) - 1) / tile_len_for(n);
   if (need_n > cap_n) {
     if (keys) HIP_CHECK(hipFree(keys));
@@ -317,10 +360,13 @@ void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes) {
     if (cnts) HIP_CHECK(hipFree(cnts));
     if (offsets) HIP_CHECK(hipFree(offsets));
     if (lane_off) HIP_CHECK(hipFree(lane_off));
-    if (lane_tot) HIP_CHECK(hipFree(lane_tot));
     HIP_CHECK(hipMalloc(&cnts, nbk * 4)); HIP_CHECK(hipMalloc(&offsets, nbk * 4)); HIP_CHECK(hipMalloc(&lane_off, nbk * 4));
-    HIP_CHECK(hipMalloc(&lane_tot, 64 * 4 * 8));
     cap_slots = nbk;
+  }
+  if (vwin > cap_vwin) {
+    if (lane_tot) HIP_CHECK(hipFree(lane_tot));
+    HIP_CHECK(hipMalloc(&lane_tot, (vwin + 64) * 4));
+    cap_vwin = vwin;
   }
   if (nbk * acc_bytes > cap_buckets) {
     if (buckets) HIP_CHECK(hipFree(buckets));
@@ -329,7 +375,7 @@ void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes) {
     HIP_CHECK(hipMalloc(&rc, nbk * acc_bytes));               // >= nwin * (NR + NC)
     cap_buckets = nbk * acc_bytes;
   }
-  size_t need_part = 2 * ((size_t)p.nwin * lcap_for(n, p) / 64 + 2) * acc_bytes;
+  size_t need_part = 2 * (vwin * lcap_for(n, p) / 64 + 2) * acc_bytes;
   if (need_part > cap_part) {
     if (part) HIP_CHECK(hipFree(part));
     HIP_CHECK(hipMalloc(&part, need_part));
@@ -350,47 +396,61 @@ void MsmWorkspace::release() {
   if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr;
   keys = nullptr; sorted = hist = cnts = offsets = lane_off = lane_tot = nullptr;
   buckets = rc = part = bits = bits_host = nullptr;
-  cap_n = cap_slots = cap_buckets = cap_bits = cap_part = cap_hist = 0;
+  cap_n = cap_slots = cap_buckets = cap_bits = cap_part = cap_hist = cap_vwin = 0;
 }
 
 // Runs the whole device pipeline for one MSM and leaves the nwin*c bit sums T_p in ws.bits_host
 // (accumulator layout of CV); returns the number of bit sums.
+// `batch` scalar vectors of length n over the SAME n bases (d_scalars = batch x n x 8 words): every vector
+// gets its own nwin windows; returns the number of bit sums per vector (vector b's sums start at b * that).
 template <class CV>
-static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, int scalar_bits, MsmWorkspace &ws, hipStream_t stream) {
+static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, int scalar_bits, MsmWorkspace &ws, hipStream_t stream,
+                      size_t batch = 1) {
   MsmPlan p = msm_plan(n, scalar_bits);
   const size_t acc_bytes = (size_t)CV::ACC_WORDS * 4;
-  ws.ensure(n, p, acc_bytes);
-  const uint32_t nbk = (uint32_t)p.nwin * p.nb, seg = (uint32_t)p.lpb;
+  ws.ensure(n, p, acc_bytes, batch);
+  const uint32_t vwin = (uint32_t)(p.nwin * batch);
+  const uint32_t nbk = vwin * p.nb, seg = (uint32_t)p.lpb;
   const uint32_t tile_len = tile_len_for(n), ntiles = (uint32_t)((n + tile_len - 1) / tile_len);
   const uint32_t lcap = lcap_for(n, p);
   const size_t lds_bytes = (size_t)p.nb * 4;
   dim3 b256(256), gn((unsigned)((n + 255) / 256));
-  hipLaunchKernelGGL(k_digits, gn, b256, 0, stream, d_scalars, (uint32_t)n, p.c, p.nwin, ws.keys);
-  hipLaunchKernelGGL(k_hist, dim3(ntiles, p.nwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist);
-  hipLaunchKernelGGL(k_scan_win, dim3(p.nwin), dim3(1024), 0, stream, ws.hist, (uint32_t)n, ntiles, p.c, seg,
+  hipLaunchKernelGGL(k_digits, dim3(gn.x, (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n, p.c, p.nwin, ws.keys);
+  hipLaunchKernelGGL(k_hist, dim3(ntiles, vwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist);
+  hipLaunchKernelGGL(k_scan_win, dim3(vwin), dim3(1024), 0, stream, ws.hist, (uint32_t)n, ntiles, p.c, seg,
                      ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot);
-  hipLaunchKernelGGL(k_scatter, dim3(ntiles, p.nwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist, ws.offsets, ws.sorted);
-  dim3 ga((unsigned)(((size_t)p.nwin * lcap + 255) / 256));
+  hipLaunchKernelGGL(k_scatter, dim3(ntiles, vwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist, ws.offsets, ws.sorted);
+  dim3 ga((unsigned)(((size_t)vwin * lcap + 255) / 256));
   if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
   HIP_CHECK(hipEventRecord(ws.ev0, stream));
   hipLaunchKernelGGL(k_accumulate<CV>, ga, b256, 0, stream, d_bases, ws.sorted, ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot,
-                     (uint32_t)p.nwin, (uint32_t)p.nb, lcap, seg, ws.buckets, ws.part);
+                     vwin, (uint32_t)p.nb, lcap, seg, ws.buckets, ws.part);
   HIP_CHECK(hipEventRecord(ws.ev1, stream));
   hipLaunchKernelGGL(k_fixup<CV>, dim3((nbk + 255) / 256), b256, 0, stream, ws.cnts, ws.lane_off, nbk, (uint32_t)p.nb, lcap, seg,
                      (const uint32_t *)ws.part, ws.buckets);
   const int h = (p.c - 1) / 2;
   const uint32_t tasks = (1u << h) + ((uint32_t)p.nb >> h);
-  hipLaunchKernelGGL(k_rowcol<CV>, dim3(((size_t)p.nwin * tasks * 64 + 255) / 256), b256, 0, stream, (const uint32_t *)ws.buckets, p.c, h,
-                     (uint32_t)p.nwin * tasks, ws.rc);
-  const int nbits = p.nwin * p.c;
-  hipLaunchKernelGGL(k_bits<CV>, dim3(((size_t)nbits * 64 + 255) / 256), b256, 0, stream, (const uint32_t *)ws.buckets, (const uint32_t *)ws.rc,
-                     p.c, h, (uint32_t)nbits, ws.bits);
-  HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.bits, (size_t)nbits * acc_bytes, hipMemcpyDeviceToHost, stream));
+  const int nbits = (int)vwin * p.c;
+  if (p.nb <= 256 && batch >= 8) {
+    hipLaunchKernelGGL(k_bits_direct<CV>, dim3(((unsigned)nbits + 127) / 128), dim3(128), 0, stream, (const uint32_t *)ws.buckets, p.c, (uint32_t)nbits, ws.bits);
+  } else {
+    hipLaunchKernelGGL(k_rowcol<CV>, dim3(((size_t)vwin * tasks * 64 + 255) / 256), b256, 0, stream, (const uint32_t *)ws.buckets, p.c, h,
+                       vwin * tasks, ws.rc);
+    hipLaunchKernelGGL(k_bits<CV>, dim3(((size_t)nbits * 64 + 255) / 256), b256, 0, stream, (const uint32_t *)ws.buckets, (const uint32_t *)ws.rc,
+                       p.c, h, (uint32_t)nbits, ws.bits);
+  }
+  if (batch >= 8) {                                        // device Horner: only `batch` points come back
+    hipLaunchKernelGGL(k_horner<CV>, dim3(((unsigned)batch + 63) / 64), dim3(64), 0, stream, (const uint32_t *)ws.bits, (uint32_t)(p.nwin * p.c),
+                       (uint32_t)batch, ws.rc);
+    HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.rc, batch * acc_bytes, hipMemcpyDeviceToHost, stream));
+  } else {
+    HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.bits, (size_t)nbits * acc_bytes, hipMemcpyDeviceToHost, stream));
+  }
   HIP_CHECK(hipStreamSynchronize(stream));
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventElapsedTime(&ws.accum_ms_last, ws.ev0, ws.ev1));
   ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = p;
-  return nbits;
+  return p.nwin * p.c;
 }
 
 template <class S>
@@ -431,18 +491,26 @@ __global__ void k_g1_bases(const uint8_t *__restrict__ xy, uint32_t n, uint32_t 
 }
 
 template <class C>
-static int msm_g1_impl(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy) {
+static int msm_g1_impl(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy,
+                       size_t batch) {
   using HG = HostG1<C>;
-  typename HG::Pt acc = HG::identity();
-  if (n) {
-    int nbits = msm_device<G1Curve<C>>(d_bases, d_scalars, n, C::Fr::BITS, ws, stream);
-    const uint32_t *bh = ws.bits_host;
-    for (int i = nbits - 1; i >= 0; i--) {
-      acc = HG::dbl(acc);
-      acc = HG::add(acc, HG::from_raw32(bh + (size_t)i * 4 * C::Fq::N));
+  constexpr size_t OUT = 8 * C::Fq::N;                    // bytes of one affine result
+  int nbits = n ? msm_device<G1Curve<C>>(d_bases, d_scalars, n, C::Fr::BITS, ws, stream, batch) : 0;
+  std::vector<typename HG::Pt> res(batch);
+  for (size_t b = 0; b < batch; b++) {
+    typename HG::Pt acc = HG::identity();
+    if (batch >= 8) acc = HG::from_raw32(ws.bits_host + b * 4 * C::Fq::N);      // Horner already done on the device
+    else if (n) {
+      const uint32_t *bh = ws.bits_host + b * (size_t)nbits * 4 * C::Fq::N;
+      for (int i = nbits - 1; i >= 0; i--) {
+        acc = HG::dbl(acc);
+        acc = HG::add(acc, HG::from_raw32(bh + (size_t)i * 4 * C::Fq::N));
+      }
     }
+    res[b] = acc;
   }
-  HG::to_affine_bytes(acc, out_xy);
+  HG::to_affine_bytes_batch(res.data(), batch, out_xy);
+  (void)OUT;
   return 0;
 }
 
@@ -453,9 +521,10 @@ void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, 
   else hipLaunchKernelGGL(k_g1_bases<G1Bn254>, g, b, 0, stream, d_xy, (uint32_t)n, d_out, d_flag);
 }
 
-int msm_g1_device(int curve, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy) {
-  if (curve == 0) return msm_g1_impl<G1Bls12381>(d_bases, d_scalars, n, ws, stream, out_xy);
-  if (curve == 1) return msm_g1_impl<G1Bn254>(d_bases, d_scalars, n, ws, stream, out_xy);
+int msm_g1_device(int curve, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy,
+                  size_t batch) {
+  if (curve == 0) return msm_g1_impl<G1Bls12381>(d_bases, d_scalars, n, ws, stream, out_xy, batch);
+  if (curve == 1) return msm_g1_impl<G1Bn254>(d_bases, d_scalars, n, ws, stream, out_xy, batch);
   return -1;
 }
 

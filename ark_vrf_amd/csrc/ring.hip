@@ -16,6 +16,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 namespace avrf {
@@ -64,6 +67,49 @@ static void ntt_launch(uint32_t *d_data, uint32_t n, const uint32_t *d_tw, uint3
   for (uint32_t half = 1; half < n; half <<= 1)
     hipLaunchKernelGGL(k_ntt_stage<F>, dim3(((size_t)(n / 2) * batch + 255) / 256), dim3(256), 0, st, d_data, n, half, d_tw, batch);
   if (scale) hipLaunchKernelGGL(k_ntt_scale<F>, dim3(((size_t)n * batch + 255) / 256), dim3(256), 0, st, d_data, n * batch, *scale);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// PIOP constraint aggregation on the 4N domain: one lane per domain point.
+// e4 = evaluations of bits | ip_acc | acc_x | acc_y (4 x M), fixed4 = points.x | points.y | selector
+// (3 x M), l4 = L_first | L_last (2 x M), tw4[k] = w4^k (k < M/2; w4^(M/2) = -1).
+struct RingConsts { fp alpha[7]; fp w_last, seedx, seedy, resx, resy; };
+
+template <class S>
+__global__ void __launch_bounds__(256)
+k_ring_constraints(const uint32_t *__restrict__ e4, const uint32_t *__restrict__ fixed4, const uint32_t *__restrict__ l4,
+                   const uint32_t *__restrict__ tw4, const RingConsts *__restrict__ consts, uint32_t M, uint32_t *__restrict__ out) {
+  using F = typename S::Fq;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const uint32_t proof = blockIdx.y;                                  // one proof per grid row
+  e4 += (size_t)proof * 4 * M * 8; out += (size_t)proof * M * 8;
+  const RingConsts &c = consts[proof];
+  const uint32_t is = (i + 4) & (M - 1);                              // column(wX) on the 4N domain
+  auto at = [&](const uint32_t *base, uint32_t col, uint32_t idx) { return load_fp(base + ((size_t)col * M + idx) * 8); };
+  const fp one = fp_one<F>();
+  const fp b = at(e4, 0, i), ip = at(e4, 1, i), x1 = at(e4, 2, i), y1 = at(e4, 3, i);
+  const fp ips = at(e4, 1, is), x3 = at(e4, 2, is), y3 = at(e4, 3, is);
+  const fp x2 = at(fixed4, 0, i), y2 = at(fixed4, 1, i), sel = at(fixed4, 2, i);
+  const fp lf = at(l4, 0, i), ll = at(l4, 1, i);
+  fp xi = load_fp(tw4 + (size_t)(i & (M / 2 - 1)) * 8);
+  if (i >= M / 2) xi = fp_neg<F>(xi);
+  const fp nl = fp_sub<F>(xi, c.w_last), omb = fp_sub<F>(one, b);
+  const fp x1y1 = fp_mul<F>(x1, y1), x2y2 = fp_mul<F>(x2, y2);
+  fp c0 = fp_mul<F>(fp_sub<F>(fp_sub<F>(ips, ip), fp_mul<F>(sel, b)), nl);
+  fp t1 = fp_add<F>(fp_mul<F>(y1, y2), mul_a<S>(fp_mul<F>(x1, x2)));
+  fp c1 = fp_mul<F>(fp_add<F>(fp_mul<F>(b, fp_sub<F>(fp_sub<F>(fp_mul<F>(x3, t1), x1y1), x2y2)), fp_mul<F>(omb, fp_sub<F>(x3, x1))), nl);
+  fp t2 = fp_sub<F>(fp_mul<F>(x1, y2), fp_mul<F>(x2, y1));
+  fp c2 = fp_mul<F>(fp_add<F>(fp_mul<F>(b, fp_add<F>(fp_sub<F>(fp_mul<F>(y3, t2), x1y1), x2y2)), fp_mul<F>(omb, fp_sub<F>(y3, y1))), nl);
+  fp c3 = fp_mul<F>(b, omb);
+  fp c4 = fp_add<F>(fp_mul<F>(lf, fp_sub<F>(x1, c.seedx)), fp_mul<F>(ll, fp_sub<F>(x1, c.resx)));
+  fp c5 = fp_add<F>(fp_mul<F>(lf, fp_sub<F>(y1, c.seedy)), fp_mul<F>(ll, fp_sub<F>(y1, c.resy)));
+  fp c6 = fp_add<F>(fp_mul<F>(lf, ip), fp_mul<F>(ll, fp_sub<F>(ip, one)));
+  fp s = fp_mul<F>(c.alpha[0], c0);
+  s = fp_add<F>(s, fp_mul<F>(c.alpha[1], c1)); s = fp_add<F>(s, fp_mul<F>(c.alpha[2], c2)); s = fp_add<F>(s, fp_mul<F>(c.alpha[3], c3));
+  s = fp_add<F>(s, fp_mul<F>(c.alpha[4], c4)); s = fp_add<F>(s, fp_mul<F>(c.alpha[5], c5)); s = fp_add<F>(s, fp_mul<F>(c.alpha[6], c6));
+  store_fp(out + (size_t)i * 8, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -121,6 +167,17 @@ template <class S, class G> struct RingTypes {
   static constexpr int FQB = G::Fq::N * 4;            // bytes of a G1 coordinate
 };
 
+// host-side data parallelism over the proofs of a chunk (the per-proof O(N) bookkeeping between device rounds)
+template <class Fn> static void parallel_for(size_t n, Fn fn) {
+  size_t nt = std::thread::hardware_concurrency(); if (nt > 32) nt = 32; if (nt > n) nt = n;
+  if (const char *e = getenv("AVRF_HOST_THREADS")) { long v = atol(e); if (v >= 1 && v <= 256) nt = (size_t)v < n ? (size_t)v : n; }
+  if (nt <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; t++) th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) fn(i); });
+  for (auto &x : th) x.join();
+}
+
 // int_BE(48 bytes) mod r, Montgomery form
 template <class F> static H256 fr_from_be48(const uint8_t b[48]) {
   using Fr = HostField<F>;
@@ -177,6 +234,9 @@ struct avrf_ring_setup {
   H256 ninv, n4inv;
   std::vector<std::pair<H256, H256>> h_pows;          // 2^i * BLINDING_BASE, affine Montgomery
   uint32_t *d_buf = nullptr; size_t buf_cap = 0;      // scratch for NTT batches / MSM scalars
+  uint32_t *d_l4 = nullptr;                           // L_first | L_last evaluated on the 4N domain (2 x 4N)
+  uint32_t *d_e4 = nullptr, *d_agg = nullptr, *d_coef = nullptr;   // per chunk: witness evaluations (4 x 4N), aggregated constraints (4N), coefficients (4 x N)
+  size_t e4_cap = 0, agg_cap = 0, coef_cap = 0;
   MsmWorkspace ws;
 };
 struct avrf_ring_key {
@@ -187,6 +247,7 @@ struct avrf_ring_key {
   std::vector<H256> px_poly, py_poly, sel_poly;       // coefficients
   std::vector<H256> px4, py4, sel4;                   // evaluations on the 4N domain
   G1Aff C[3];
+  uint32_t *d_fixed4 = nullptr;                       // px4 | py4 | sel4 on the device (3 x 4N)
 };
 
 extern "C" hipStream_t avrf_ctx_stream_(avrf_ctx *c);
@@ -233,6 +294,19 @@ template <class S, class G> struct Ring {
     msm_g1_device(su->suite, su->d_srs, su->d_buf, n, su->ws, su->stream, r.xy);
     r.inf = true; for (int i = 0; i < 2 * FQB; i++) if (r.xy[i]) r.inf = false;
     return r;
+  }
+  // `batch` KZG commits in one launch chain: coeffs = batch vectors of length n (Montgomery; pad with zeros)
+  static void commit_batch(avrf_ring_setup *su, const H256 *coeffs_mont, size_t n, size_t batch, G1Aff *out) {
+    std::vector<H256> plain(n * batch);
+    for (size_t i = 0; i < n * batch; i++) plain[i] = Fr::from_mont(coeffs_mont[i]);
+    ensure_buf(su, n * batch * 32);
+    HIP_CHECK(hipMemcpyAsync(su->d_buf, plain.data(), n * batch * 32, hipMemcpyHostToDevice, su->stream));
+    std::vector<uint8_t> xy(batch * 2 * FQB);
+    msm_g1_device(su->suite, su->d_srs, su->d_buf, n, su->ws, su->stream, xy.data(), batch);
+    for (size_t b = 0; b < batch; b++) {
+      memset(&out[b], 0, sizeof(G1Aff)); memcpy(out[b].xy, &xy[b * 2 * FQB], 2 * FQB);
+      out[b].inf = true; for (int i = 0; i < 2 * FQB; i++) if (out[b].xy[i]) out[b].inf = false;
+    }
   }
   static H256 poly_eval(const std::vector<H256> &c, const H256 &x) {
     H256 acc = {{0, 0, 0, 0}};
@@ -286,6 +360,16 @@ template <class S, class G> struct Ring {
     su->d_tw_n = make_twiddles(su->w, N); su->d_tw_n_inv = make_twiddles(Fr::inv(su->w), N);
     su->d_tw_4n = make_twiddles(su->w4, 4 * N); su->d_tw_4n_inv = make_twiddles(Fr::inv(su->w4), 4 * N);
     su->ninv = Fr::inv(fr_small<F>(N)); su->n4inv = Fr::inv(fr_small<F>(4 * N));
+    {  // Lagrange basis polynomials of rows 0 and cap-1, evaluated on the 4N domain (shared by every proof)
+      const H256 zero = {{0, 0, 0, 0}};
+      std::vector<H256> lfl(2 * N, zero); lfl[0] = Fr::one(); lfl[N + su->cap - 1] = Fr::one();
+      ntt(su, lfl, N, 2, true);
+      std::vector<H256> l4(2 * 4 * N, zero);
+      for (size_t i = 0; i < N; i++) { l4[i] = lfl[i]; l4[4 * N + i] = lfl[N + i]; }
+      ntt(su, l4, 4 * N, 2, false);
+      HIP_CHECK(hipMalloc(&su->d_l4, l4.size() * 32)); HIP_CHECK(hipMemcpy(su->d_l4, l4.data(), l4.size() * 32, hipMemcpyHostToDevice));
+
+    }
     // 2^i * H  (A.5)
     HostExt h; h.x = Fr::from32(S::B_X); h.y = Fr::from32(S::B_Y); h.t = Fr::mul(h.x, h.y); h.z = Fr::one();
     for (size_t i = 0; i < L; i++) {
@@ -316,12 +400,13 @@ template <class S, class G> struct Ring {
     k->px.assign(cols.begin(), cols.begin() + N); k->py.assign(cols.begin() + N, cols.begin() + 2 * N); k->sel.assign(cols.begin() + 2 * N, cols.end());
     ntt(su, cols, N, 3, true);
     k->px_poly.assign(cols.begin(), cols.begin() + N); k->py_poly.assign(cols.begin() + N, cols.begin() + 2 * N); k->sel_poly.assign(cols.begin() + 2 * N, cols.end());
-    k->C[0] = commit(su, k->px_poly.data(), N); k->C[1] = commit(su, k->py_poly.data(), N); k->C[2] = commit(su, k->sel_poly.data(), N);
+    commit_batch(su, cols.data(), N, 3, k->C);
     // evaluations of the fixed columns on the 4N domain (shared by every proof over this ring)
     std::vector<H256> e4(3 * 4 * N, zero);
     for (size_t i = 0; i < N; i++) { e4[i] = k->px_poly[i]; e4[4 * N + i] = k->py_poly[i]; e4[8 * N + i] = k->sel_poly[i]; }
     ntt(su, e4, 4 * N, 3, false);
     k->px4.assign(e4.begin(), e4.begin() + 4 * N); k->py4.assign(e4.begin() + 4 * N, e4.begin() + 8 * N); k->sel4.assign(e4.begin() + 8 * N, e4.end());
+    HIP_CHECK(hipMalloc(&k->d_fixed4, e4.size() * 32)); HIP_CHECK(hipMemcpy(k->d_fixed4, e4.data(), e4.size() * 32, hipMemcpyHostToDevice));
     *out = k;
     return AVRF_OK;
   }
@@ -336,126 +421,196 @@ template <class S, class G> struct Ring {
     t.append(vk);
   }
 
-  // ---- RingProver::prove with blinding disabled (A.7); out: 4*G1 || 7*Fr || G1 || Fr || G1 || G1
-  static int prove_one(avrf_ring_key *k, size_t key_index, const uint8_t blinding_le[32], uint8_t *out) {
+  // ---- RingProver::prove with blinding disabled (A.7) for a batch of proofs over one ring, in lockstep:
+  // every device stage (iNTT, KZG commits, NTT(4N) + constraint aggregation + iNTT(4N), openings) runs ONCE for
+  // the whole chunk -- batched NTTs and one batched MSM launch chain over the shared SRS per round of the
+  // Fiat-Shamir transcript -- while the O(N) per-proof bookkeeping runs on the host between the rounds.
+  // out: per proof 4*G1 || 7*Fr || G1 || Fr || G1 || G1.
+  struct ProofState {
+    std::vector<H256> coef;          // 4 x N witness coefficients: bits | ip | ax | ay
+    std::vector<H256> q, lin, aggz;
+    H256 seedx, seedy, resx, resy, instx, insty, al[7], zeta, ev[7], lin_zw, nu[8];
+    G1Aff C[4], Cq, pi[2];
+    ArkTranscript t;
+  };
+  static uint32_t *dev_scratch(avrf_ring_setup *su, int which, size_t bytes) {
+    uint32_t **p = which == 0 ? &su->d_e4 : which == 1 ? &su->d_agg : &su->d_coef;
+    size_t *cap = which == 0 ? &su->e4_cap : which == 1 ? &su->agg_cap : &su->coef_cap;
+    if (bytes > *cap) { if (*p) HIP_CHECK(hipFree(*p)); HIP_CHECK(hipMalloc(p, bytes)); *cap = bytes; }
+    return *p;
+  }
+  // batched commit of `batch` coefficient vectors already on the device in Montgomery form (stride n)
+  static void commit_device(avrf_ring_setup *su, uint32_t *d_coeffs_mont, size_t n, size_t batch, std::vector<G1Aff> &out) {
+    fp one_plain = fp_zero_host(); one_plain.v[0] = 1;                 // a * 1 / R: Montgomery -> plain, in place
+    hipLaunchKernelGGL(k_ntt_scale<F>, dim3((n * batch + 255) / 256), dim3(256), 0, su->stream, d_coeffs_mont, (uint32_t)(n * batch), one_plain);
+    std::vector<uint8_t> xy(batch * 2 * FQB);
+    msm_g1_device(su->suite, su->d_srs, d_coeffs_mont, n, su->ws, su->stream, xy.data(), batch);
+    out.resize(batch);
+    for (size_t b = 0; b < batch; b++) {
+      memset(&out[b], 0, sizeof(G1Aff)); memcpy(out[b].xy, &xy[b * 2 * FQB], 2 * FQB);
+      out[b].inf = true; for (int i = 0; i < 2 * FQB; i++) if (out[b].xy[i]) out[b].inf = false;
+    }
+  }
+  static fp fp_zero_host() { fp r; memset(&r, 0, sizeof r); return r; }
+
+  static int prove_chunk(avrf_ring_key *k, size_t n, const uint32_t *key_index, const uint8_t *blindings, uint8_t *out) {
     avrf_ring_setup *su = k->setup;
-    const size_t N = su->N, cap = su->cap, M = 4 * N;
-    if (key_index >= k->n_keys) return AVRF_ERR_BAD_ARG;
+    const size_t N = su->N, cap = su->cap, M = 4 * N, plen = 4 * FQB + 7 * 32 + FQB + 32 + 2 * FQB;
     const H256 zero = {{0, 0, 0, 0}}, one = Fr::one();
-    // witness
-    std::vector<uint8_t> bits(cap - 1, 0);
-    bits[key_index] = 1;
-    for (size_t i = 0; i < su->L; i++) bits[su->keyset + i] = (blinding_le[i >> 3] >> (i & 7)) & 1;
-    std::vector<H256> cols(4 * N, zero);                               // bits | ip | ax | ay evaluations
-    H256 ipv = zero;
-    for (size_t i = 0; i < cap - 1; i++) {
-      if (bits[i]) cols[i] = one;
-      if (bits[i] && i < su->keyset) ipv = Fr::add(ipv, one);
-      cols[N + i + 1] = ipv;
-    }
-    HostExt acc; acc.x = Fr::from32(S::ACC_X); acc.y = Fr::from32(S::ACC_Y); acc.t = Fr::mul(acc.x, acc.y); acc.z = one;
-    const H256 seedx = acc.x, seedy = acc.y;
-    std::vector<HostExt> accs(cap);
-    accs[0] = acc;
-    for (size_t i = 0; i < cap - 1; i++) {
-      if (bits[i]) { HostExt p; p.x = k->points[i].first; p.y = k->points[i].second; p.t = Fr::mul(p.x, p.y); p.z = one; acc = Te::add(acc, p); }
-      accs[i + 1] = acc;
-    }
-    {  // batch normalisation (one inversion)
-      std::vector<H256> pre(cap); H256 run = one;
+    static const bool trace = getenv("AVRF_RING_TRACE") != nullptr;
+    auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    double t_prev = now();
+    auto lap = [&](const char *what) { if (trace) { double t = now(); fprintf(stderr, "  ring_prove[%zu] %-24s %8.3f ms\n", n, what, t - t_prev); t_prev = t; } };
+    for (size_t i = 0; i < n; i++) if (key_index[i] >= k->n_keys) return AVRF_ERR_BAD_ARG;
+    std::vector<ProofState> st(n);
+    const H256 w_last = fr_pow<F>(su->w, cap - 1);
+    const H256 a_coef = S::A_KIND == 1 ? Fr::neg(fr_small<F>(5)) : one;
+    // ---- round 0 (host): witness columns (A.7 step 1)
+    std::vector<H256> cols(n * 4 * N, zero);                           // per proof: bits | ip | ax | ay evaluations
+    parallel_for(n, [&](size_t p) {
+      ProofState &ps = st[p];
+      H256 *c = &cols[p * 4 * N];
+      const uint8_t *bl = blindings + 32 * p;
+      std::vector<uint8_t> bits(cap - 1, 0);
+      bits[key_index[p]] = 1;
+      for (size_t i = 0; i < su->L; i++) bits[su->keyset + i] = (bl[i >> 3] >> (i & 7)) & 1;
+      H256 ipv = zero;
+      for (size_t i = 0; i < cap - 1; i++) {
+        if (bits[i]) c[i] = one;
+        if (bits[i] && i < su->keyset) ipv = Fr::add(ipv, one);
+        c[N + i + 1] = ipv;
+      }
+      HostExt acc; acc.x = Fr::from32(S::ACC_X); acc.y = Fr::from32(S::ACC_Y); acc.t = Fr::mul(acc.x, acc.y); acc.z = one;
+      ps.seedx = acc.x; ps.seedy = acc.y;
+      std::vector<HostExt> accs(cap);
+      accs[0] = acc;
+      for (size_t i = 0; i < cap - 1; i++) {
+        if (bits[i]) { HostExt q; q.x = k->points[i].first; q.y = k->points[i].second; q.t = Fr::mul(q.x, q.y); q.z = one; acc = Te::add(acc, q); }
+        accs[i + 1] = acc;
+      }
+      std::vector<H256> pre(cap); H256 run = one;                      // batch normalisation (one inversion)
       for (size_t i = 0; i < cap; i++) { pre[i] = run; run = Fr::mul(run, accs[i].z); }
       H256 inv = Fr::inv(run);
-      for (size_t i = cap; i-- > 0;) { H256 zi = Fr::mul(inv, pre[i]); inv = Fr::mul(inv, accs[i].z); cols[2 * N + i] = Fr::mul(accs[i].x, zi); cols[3 * N + i] = Fr::mul(accs[i].y, zi); }
+      for (size_t i = cap; i-- > 0;) { H256 zi = Fr::mul(inv, pre[i]); inv = Fr::mul(inv, accs[i].z); c[2 * N + i] = Fr::mul(accs[i].x, zi); c[3 * N + i] = Fr::mul(accs[i].y, zi); }
+      ps.resx = c[2 * N + cap - 1]; ps.resy = c[3 * N + cap - 1];
+      HostExt r; r.x = ps.resx; r.y = ps.resy; r.t = Fr::mul(r.x, r.y); r.z = one;     // instance = result - seed
+      HostExt ns; ns.x = Fr::neg(ps.seedx); ns.y = ps.seedy; ns.t = Fr::mul(ns.x, ns.y); ns.z = one;
+      HostExt inst = Te::add(r, ns); H256 izi = Fr::inv(inst.z);
+      ps.instx = Fr::mul(inst.x, izi); ps.insty = Fr::mul(inst.y, izi);
+    });
+    lap("witness (host)");
+    // ---- round 1 (device): coefficients, their 4N evaluations, 4n commits in one MSM chain
+    uint32_t *d_coef = dev_scratch(su, 2, n * 4 * N * 32), *d_e4 = dev_scratch(su, 0, n * 4 * M * 32);
+    HIP_CHECK(hipMemcpyAsync(d_coef, cols.data(), n * 4 * N * 32, hipMemcpyHostToDevice, su->stream));
+    { fp sc; memcpy(sc.v, su->ninv.l, 32); ntt_launch<F>(d_coef, (uint32_t)N, su->d_tw_n_inv, (uint32_t)(4 * n), &sc, su->stream); }
+    HIP_CHECK(hipMemcpyAsync(cols.data(), d_coef, n * 4 * N * 32, hipMemcpyDeviceToHost, su->stream));   // coefficients, for the host rounds
+    HIP_CHECK(hipMemsetAsync(d_e4, 0, n * 4 * M * 32, su->stream));
+    HIP_CHECK(hipMemcpy2DAsync(d_e4, M * 32, d_coef, N * 32, N * 32, 4 * n, hipMemcpyDeviceToDevice, su->stream));
+    ntt_launch<F>(d_e4, (uint32_t)M, su->d_tw_4n, (uint32_t)(4 * n), nullptr, su->stream);
+    { std::vector<G1Aff> C; commit_device(su, d_coef, N, 4 * n, C);
+      for (size_t p = 0; p < n; p++) for (int i = 0; i < 4; i++) st[p].C[i] = C[4 * p + i]; }
+    lap("intt + ntt4n + 4n commits");
+    for (size_t p = 0; p < n; p++) {
+      ProofState &ps = st[p];
+      ps.coef.assign(cols.begin() + p * 4 * N, cols.begin() + (p + 1) * 4 * N);
+      transcript_prelude(k, ps.t);
+      { std::vector<uint8_t> b; push_le32(b, ps.instx); push_le32(b, ps.insty); ps.t.label("instance"); ps.t.append(b); }
+      { std::vector<uint8_t> b; for (int i = 0; i < 4; i++) g1_encode<G>(ps.C[i], false, b); ps.t.label("committed_cols"); ps.t.append(b); }
+      for (int i = 0; i < 7; i++) ps.al[i] = challenge(ps.t, "constraints_aggregation");
     }
-    const H256 resx = cols[2 * N + cap - 1], resy = cols[3 * N + cap - 1];
-    // instance = result - seed
-    HostExt r; r.x = resx; r.y = resy; r.t = Fr::mul(resx, resy); r.z = one;
-    HostExt ns; ns.x = Fr::neg(seedx); ns.y = seedy; ns.t = Fr::mul(ns.x, ns.y); ns.z = one;
-    HostExt inst = Te::add(r, ns); H256 izi = Fr::inv(inst.z);
-    H256 instx = Fr::mul(inst.x, izi), insty = Fr::mul(inst.y, izi);
-    ntt(su, cols, N, 4, true);                                         // -> coefficients
-    const H256 *pb = &cols[0], *pip = &cols[N], *pax = &cols[2 * N], *pay = &cols[3 * N];
-    G1Aff C[4]; for (int i = 0; i < 4; i++) C[i] = commit(su, &cols[i * N], N);
-    ArkTranscript t; transcript_prelude(k, t);
-    { std::vector<uint8_t> b; push_le32(b, instx); push_le32(b, insty); t.label("instance"); t.append(b); }
-    { std::vector<uint8_t> b; for (int i = 0; i < 4; i++) g1_encode<G>(C[i], false, b); t.label("committed_cols"); t.append(b); }
-    H256 al[7]; for (int i = 0; i < 7; i++) al[i] = challenge(t, "constraints_aggregation");
-    // evaluations on the 4N domain
-    std::vector<H256> e4(4 * M, zero);
-    for (int c = 0; c < 4; c++) for (size_t i = 0; i < N; i++) e4[c * M + i] = cols[c * N + i];
-    ntt(su, e4, M, 4, false);
-    const H256 *eb = &e4[0], *eip = &e4[M], *eax = &e4[2 * M], *eay = &e4[3 * M];
-    std::vector<H256> lfl(2 * N, zero); lfl[0] = one; lfl[N + cap - 1] = one;     // L_first, L_last
-    ntt(su, lfl, N, 2, true);
-    std::vector<H256> l4(2 * M, zero);
-    for (size_t i = 0; i < N; i++) { l4[i] = lfl[i]; l4[M + i] = lfl[N + i]; }
-    ntt(su, l4, M, 2, false);
-    const H256 w_last = fr_pow<F>(su->w, cap - 1);
-    H256 a_coef = S::A_KIND == 1 ? Fr::neg(fr_small<F>(5)) : one;
-    std::vector<H256> agg(M + 4, zero);
-    H256 xi = one;
-    for (size_t i = 0; i < M; i++) {
-      const H256 b = eb[i], x1 = eax[i], y1 = eay[i], x2 = k->px4[i], y2 = k->py4[i];
-      const H256 x3 = eax[(i + 4) % M], y3 = eay[(i + 4) % M], ip = eip[i], ips = eip[(i + 4) % M];
-      const H256 nl = Fr::sub(xi, w_last), omb = Fr::sub(one, b);
-      const H256 x1y1 = Fr::mul(x1, y1), x2y2 = Fr::mul(x2, y2);
-      H256 c0 = Fr::mul(Fr::sub(Fr::sub(ips, ip), Fr::mul(k->sel4[i], b)), nl);
-      H256 t1 = Fr::add(Fr::mul(y1, y2), Fr::mul(a_coef, Fr::mul(x1, x2)));
-      H256 c1 = Fr::mul(Fr::add(Fr::mul(b, Fr::sub(Fr::sub(Fr::mul(x3, t1), x1y1), x2y2)), Fr::mul(omb, Fr::sub(x3, x1))), nl);
-      H256 t2 = Fr::sub(Fr::mul(x1, y2), Fr::mul(x2, y1));
-      H256 c2 = Fr::mul(Fr::add(Fr::mul(b, Fr::add(Fr::sub(Fr::mul(y3, t2), x1y1), x2y2)), Fr::mul(omb, Fr::sub(y3, y1))), nl);
-      H256 c3 = Fr::mul(b, omb);
-      H256 lf = l4[i], ll = l4[M + i];
-      H256 c4 = Fr::add(Fr::mul(lf, Fr::sub(x1, seedx)), Fr::mul(ll, Fr::sub(x1, resx)));
-      H256 c5 = Fr::add(Fr::mul(lf, Fr::sub(y1, seedy)), Fr::mul(ll, Fr::sub(y1, resy)));
-      H256 c6 = Fr::add(Fr::mul(lf, ip), Fr::mul(ll, Fr::sub(ip, one)));
-      H256 s = Fr::mul(al[0], c0);
-      s = Fr::add(s, Fr::mul(al[1], c1)); s = Fr::add(s, Fr::mul(al[2], c2)); s = Fr::add(s, Fr::mul(al[3], c3));
-      s = Fr::add(s, Fr::mul(al[4], c4)); s = Fr::add(s, Fr::mul(al[5], c5)); s = Fr::add(s, Fr::mul(al[6], c6));
-      agg[i] = s;
-      xi = Fr::mul(xi, su->w4);
-    }
+    // ---- round 2 (device): constraint aggregation on the 4N domain, iNTT(4N); host: * Z_zk / (X^N - 1)
+    uint32_t *d_agg = dev_scratch(su, 1, n * M * 32);
     {
-      std::vector<H256> tmp(agg.begin(), agg.begin() + M);
-      ntt(su, tmp, M, 1, true);
-      for (size_t i = 0; i < M; i++) agg[i] = tmp[i];
+      std::vector<RingConsts> rc(n);
+      auto setfp = [](fp &d, const H256 &v) { memcpy(d.v, v.l, 32); };
+      for (size_t p = 0; p < n; p++) {
+        for (int i = 0; i < 7; i++) setfp(rc[p].alpha[i], st[p].al[i]);
+        setfp(rc[p].w_last, w_last); setfp(rc[p].seedx, st[p].seedx); setfp(rc[p].seedy, st[p].seedy); setfp(rc[p].resx, st[p].resx); setfp(rc[p].resy, st[p].resy);
+      }
+      ensure_buf(su, n * sizeof(RingConsts));
+      HIP_CHECK(hipMemcpyAsync(su->d_buf, rc.data(), n * sizeof(RingConsts), hipMemcpyHostToDevice, su->stream));
+      hipLaunchKernelGGL(k_ring_constraints<S>, dim3((M + 255) / 256, (unsigned)n), dim3(256), 0, su->stream, d_e4, k->d_fixed4, su->d_l4, su->d_tw_4n,
+                         (const RingConsts *)su->d_buf, (uint32_t)M, d_agg);
+      fp sc; memcpy(sc.v, su->n4inv.l, 32);
+      ntt_launch<F>(d_agg, (uint32_t)M, su->d_tw_4n_inv, (uint32_t)n, &sc, su->stream);
     }
-    for (size_t j = N - 3; j < N; j++) {                               // * (X - w^j)
-      H256 z = fr_pow<F>(su->w, j);
-      for (size_t kx = M + 3; kx >= 1; kx--) agg[kx] = Fr::sub(agg[kx - 1], Fr::mul(z, agg[kx]));
-      agg[0] = Fr::neg(Fr::mul(z, agg[0]));
+    std::vector<H256> aggh(n * M);
+    HIP_CHECK(hipMemcpyAsync(aggh.data(), d_agg, n * M * 32, hipMemcpyDeviceToHost, su->stream));
+    HIP_CHECK(hipStreamSynchronize(su->stream));
+    lap("constraints + intt4n");
+    const size_t qlen = 3 * N + 1;
+    std::vector<H256> qall(n * qlen, zero);
+    H256 wz[3]; for (int j = 0; j < 3; j++) wz[j] = fr_pow<F>(su->w, N - 3 + j);
+    std::atomic<int> bad{0};
+    parallel_for(n, [&](size_t p) {
+      std::vector<H256> agg(M + 4, zero);
+      memcpy(agg.data(), &aggh[p * M], M * 32);
+      for (int j = 0; j < 3; j++) {                                    // * (X - w^(N-3+j))
+        for (size_t kx = M + 3; kx >= 1; kx--) agg[kx] = Fr::sub(agg[kx - 1], Fr::mul(wz[j], agg[kx]));
+        agg[0] = Fr::neg(Fr::mul(wz[j], agg[0]));
+      }
+      size_t deg = M + 3; while (deg > 0 && Fr::is_zero(agg[deg])) deg--;
+      if (deg < N || deg - N + 1 > qlen) { bad = 1; return; }
+      st[p].q.assign(deg + 1 - N, zero);
+      for (size_t kx = deg; kx >= N; kx--) { st[p].q[kx - N] = agg[kx]; agg[kx - N] = Fr::add(agg[kx - N], agg[kx]); }   // / (X^N - 1)
+      memcpy(&qall[p * qlen], st[p].q.data(), st[p].q.size() * 32);
+    });
+    if (bad) return AVRF_ERR_BAD_ARG;
+    lap("quotient polys (host)");
+    {
+      ensure_buf(su, n * qlen * 32);
+      HIP_CHECK(hipMemcpyAsync(su->d_buf, qall.data(), n * qlen * 32, hipMemcpyHostToDevice, su->stream));
+      std::vector<G1Aff> C; commit_device(su, su->d_buf, qlen, n, C);
+      for (size_t p = 0; p < n; p++) st[p].Cq = C[p];
     }
-    size_t deg = M + 3; while (deg > 0 && Fr::is_zero(agg[deg])) deg--;
-    if (deg < N) return AVRF_ERR_BAD_ARG;
-    std::vector<H256> q(deg + 1 - N);
-    for (size_t kx = deg; kx >= N; kx--) { q[kx - N] = agg[kx]; agg[kx - N] = Fr::add(agg[kx - N], agg[kx]); }   // / (X^N - 1)
-    G1Aff Cq = commit(su, q.data(), q.size());
-    { std::vector<uint8_t> b; g1_encode<G>(Cq, false, b); t.label("quotient"); t.append(b); }
-    H256 zeta = challenge(t, "evaluation_point");
-    auto vec = [](const H256 *p, size_t n) { return std::vector<H256>(p, p + n); };
-    std::vector<H256> polys[7] = {k->px_poly, k->py_poly, k->sel_poly, vec(pb, N), vec(pip, N), vec(pax, N), vec(pay, N)};
-    H256 ev[7]; for (int i = 0; i < 7; i++) ev[i] = poly_eval(polys[i], zeta);
-    { std::vector<uint8_t> b; for (int i = 0; i < 7; i++) push_le32(b, ev[i]); t.label("register_evaluations"); t.append(b); }
-    const H256 x2 = ev[0], y2 = ev[1], b = ev[3], x1 = ev[5], y1 = ev[6];
-    const H256 nlz = Fr::sub(zeta, w_last), omb = Fr::sub(one, b);
-    H256 k1 = Fr::add(Fr::mul(b, Fr::add(Fr::mul(y1, y2), Fr::mul(a_coef, Fr::mul(x1, x2)))), omb);
-    H256 k2 = Fr::add(Fr::mul(b, Fr::sub(Fr::mul(x1, y2), Fr::mul(x2, y1))), omb);
-    std::vector<H256> lin(N);
-    { H256 f0 = Fr::mul(nlz, al[0]), f1 = Fr::mul(nlz, Fr::mul(al[1], k1)), f2 = Fr::mul(nlz, Fr::mul(al[2], k2));
-      for (size_t i = 0; i < N; i++) lin[i] = Fr::add(Fr::add(Fr::mul(f0, pip[i]), Fr::mul(f1, pax[i])), Fr::mul(f2, pay[i])); }
-    H256 zw = Fr::mul(zeta, su->w), lin_zw = poly_eval(lin, zw);
-    { std::vector<uint8_t> bb; push_le32(bb, lin_zw); t.label("shifted_linearization_evaluation"); t.append(bb); }
-    H256 nu[8]; for (int i = 0; i < 8; i++) nu[i] = challenge(t, "kzg_aggregation");
-    std::vector<H256> aggz(q.size(), zero);
-    for (int c = 0; c < 7; c++) for (size_t i = 0; i < N; i++) aggz[i] = Fr::add(aggz[i], Fr::mul(nu[c], polys[c][i]));
-    for (size_t i = 0; i < q.size(); i++) aggz[i] = Fr::add(aggz[i], Fr::mul(nu[7], q[i]));
-    std::vector<H256> q1 = div_linear(aggz, zeta), q2 = div_linear(lin, zw);
-    G1Aff pi1 = commit(su, q1.data(), q1.size()), pi2 = commit(su, q2.data(), q2.size());
-    std::vector<uint8_t> pr;
-    for (int i = 0; i < 4; i++) g1_encode<G>(C[i], true, pr);
-    for (int i = 0; i < 7; i++) push_le32(pr, ev[i]);
-    g1_encode<G>(Cq, true, pr); push_le32(pr, lin_zw); g1_encode<G>(pi1, true, pr); g1_encode<G>(pi2, true, pr);
-    memcpy(out, pr.data(), pr.size());
+    lap("n quotient commits");
+    // ---- round 3 (host): evaluation point, evaluations, linearisation, opening polynomials
+    const size_t olen = 3 * N;                                         // length of the longer opening quotient
+    std::vector<H256> oall(n * 2 * olen, zero);
+    parallel_for(n, [&](size_t p) {
+      ProofState &ps = st[p];
+      { std::vector<uint8_t> b; g1_encode<G>(ps.Cq, false, b); ps.t.label("quotient"); ps.t.append(b); }
+      ps.zeta = challenge(ps.t, "evaluation_point");
+      const H256 *pb = &ps.coef[0], *pip = &ps.coef[N], *pax = &ps.coef[2 * N], *pay = &ps.coef[3 * N];
+      const H256 *polys[7] = {k->px_poly.data(), k->py_poly.data(), k->sel_poly.data(), pb, pip, pax, pay};
+      for (int c = 0; c < 7; c++) { H256 acc = zero; for (size_t i = N; i-- > 0;) acc = Fr::add(Fr::mul(acc, ps.zeta), polys[c][i]); ps.ev[c] = acc; }
+      { std::vector<uint8_t> b; for (int i = 0; i < 7; i++) push_le32(b, ps.ev[i]); ps.t.label("register_evaluations"); ps.t.append(b); }
+      const H256 x2 = ps.ev[0], y2 = ps.ev[1], b = ps.ev[3], x1 = ps.ev[5], y1 = ps.ev[6];
+      const H256 nlz = Fr::sub(ps.zeta, w_last), omb = Fr::sub(one, b);
+      const H256 k1 = Fr::add(Fr::mul(b, Fr::add(Fr::mul(y1, y2), Fr::mul(a_coef, Fr::mul(x1, x2)))), omb);
+      const H256 k2 = Fr::add(Fr::mul(b, Fr::sub(Fr::mul(x1, y2), Fr::mul(x2, y1))), omb);
+      ps.lin.resize(N);
+      { const H256 f0 = Fr::mul(nlz, ps.al[0]), f1 = Fr::mul(nlz, Fr::mul(ps.al[1], k1)), f2 = Fr::mul(nlz, Fr::mul(ps.al[2], k2));
+        for (size_t i = 0; i < N; i++) ps.lin[i] = Fr::add(Fr::add(Fr::mul(f0, pip[i]), Fr::mul(f1, pax[i])), Fr::mul(f2, pay[i])); }
+      const H256 zw = Fr::mul(ps.zeta, su->w);
+      ps.lin_zw = poly_eval(ps.lin, zw);
+      { std::vector<uint8_t> bb; push_le32(bb, ps.lin_zw); ps.t.label("shifted_linearization_evaluation"); ps.t.append(bb); }
+      for (int i = 0; i < 8; i++) ps.nu[i] = challenge(ps.t, "kzg_aggregation");
+      ps.aggz.assign(ps.q.size(), zero);
+      for (int c = 0; c < 7; c++) for (size_t i = 0; i < N; i++) ps.aggz[i] = Fr::add(ps.aggz[i], Fr::mul(ps.nu[c], polys[c][i]));
+      for (size_t i = 0; i < ps.q.size(); i++) ps.aggz[i] = Fr::add(ps.aggz[i], Fr::mul(ps.nu[7], ps.q[i]));
+      std::vector<H256> q1 = div_linear(ps.aggz, ps.zeta), q2 = div_linear(ps.lin, zw);
+      if (q1.size() > olen || q2.size() > olen) { bad = 1; return; }
+      memcpy(&oall[(2 * p) * olen], q1.data(), q1.size() * 32); memcpy(&oall[(2 * p + 1) * olen], q2.data(), q2.size() * 32);
+    });
+    if (bad) return AVRF_ERR_BAD_ARG;
+    lap("evals + openings (host)");
+    {
+      ensure_buf(su, n * 2 * olen * 32);
+      HIP_CHECK(hipMemcpyAsync(su->d_buf, oall.data(), n * 2 * olen * 32, hipMemcpyHostToDevice, su->stream));
+      std::vector<G1Aff> C; commit_device(su, su->d_buf, olen, 2 * n, C);
+      for (size_t p = 0; p < n; p++) { st[p].pi[0] = C[2 * p]; st[p].pi[1] = C[2 * p + 1]; }
+    }
+    lap("2n opening commits");
+    for (size_t p = 0; p < n; p++) {
+      const ProofState &ps = st[p];
+      std::vector<uint8_t> pr;
+      for (int i = 0; i < 4; i++) g1_encode<G>(ps.C[i], true, pr);
+      for (int i = 0; i < 7; i++) push_le32(pr, ps.ev[i]);
+      g1_encode<G>(ps.Cq, true, pr); push_le32(pr, ps.lin_zw); g1_encode<G>(ps.pi[0], true, pr); g1_encode<G>(ps.pi[1], true, pr);
+      if (pr.size() != plen) return AVRF_ERR_BAD_ARG;
+      memcpy(out + plen * p, pr.data(), plen);
+    }
     return AVRF_OK;
   }
 
@@ -620,7 +775,7 @@ int avrf_ring_setup_load(avrf_ctx *ctx, const uint8_t *srs, size_t srs_len, size
 void avrf_ring_setup_free(avrf_ring_setup *su) {
   if (!su) return;
   (void)hipSetDevice(su->device);
-  void *d[] = {su->d_srs, su->d_tw_n, su->d_tw_n_inv, su->d_tw_4n, su->d_tw_4n_inv, su->d_buf};
+  void *d[] = {su->d_srs, su->d_tw_n, su->d_tw_n_inv, su->d_tw_4n, su->d_tw_4n_inv, su->d_buf, su->d_l4, su->d_e4, su->d_agg, su->d_coef};
   for (void *p : d) if (p) (void)hipFree(p);
   su->ws.release();
   delete su;
@@ -642,16 +797,19 @@ int avrf_ring_index(avrf_ring_setup *su, const uint8_t *pks_xy, size_t n_keys, a
   }
   return st;
 }
-void avrf_ring_key_free(avrf_ring_key *k) { delete k; }
+void avrf_ring_key_free(avrf_ring_key *k) { if (!k) return; if (k->d_fixed4) (void)hipFree(k->d_fixed4); delete k; }
 
 int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const uint8_t *blindings, int blinding_mode, uint8_t *proofs_out) {
   if (!k || (n && (!key_index || !blindings || !proofs_out))) return AVRF_ERR_BAD_ARG;
   if (blinding_mode != 0) return AVRF_ERR_BAD_ARG;                     // zero-knowledge blinding rows: not yet
   if (hipSetDevice(k->setup->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   const size_t plen = k->setup->suite == 0 ? 592 : 480;
-  for (size_t i = 0; i < n; i++) {
-    int st = k->setup->suite == 0 ? RingB::prove_one(k, key_index[i], blindings + 32 * i, proofs_out + plen * i)
-                                  : RingJ::prove_one(k, key_index[i], blindings + 32 * i, proofs_out + plen * i);
+  size_t chunk = 128;                                                  // proofs proved in lockstep per device round
+  if (const char *e = getenv("AVRF_RING_CHUNK")) { long v = atol(e); if (v >= 1 && v <= 4096) chunk = (size_t)v; }
+  for (size_t i = 0; i < n; i += chunk) {
+    const size_t m = n - i < chunk ? n - i : chunk;
+    int st = k->setup->suite == 0 ? RingB::prove_chunk(k, m, key_index + i, blindings + 32 * i, proofs_out + plen * i)
+                                  : RingJ::prove_chunk(k, m, key_index + i, blindings + 32 * i, proofs_out + plen * i);
     if (st) return st;
   }
   return AVRF_OK;
