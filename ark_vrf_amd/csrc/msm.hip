@@ -173,7 +173,7 @@ k_scatter(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int 
 // `wave` that includes lane 0 (k = 0) or that starts later and runs past lane 63 (k = 1); complete
 // runs are written straight to buckets[].  lcap is a multiple of 64 (a wave never spans two windows).
 template <class CV>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, CV::MIN_WAVES)
 k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
              const uint32_t *__restrict__ offs, const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off,
              const uint32_t *__restrict__ lane_tot, uint32_t nwin, uint32_t nb, uint32_t lcap, uint32_t seg,
@@ -194,14 +194,21 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
     l0 = lo_w[lo]; nl = (cnt + seg - 1) / seg;
     const uint32_t per = (cnt + nl - 1) / nl, r = lt - l0;
     uint32_t b = e0 + r * per, e = b + per; if (e > e0 + cnt) e = e0 + cnt;
-    // software-pipelined gather: the next base is in flight while the current addition runs
-    if (b < e) {
-      uint32_t idx = sorted[b];
-      base_t q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS);
+    if (CV::PREFETCH) {
+      // software-pipelined gather: the next base is in flight while the current addition runs
+      if (b < e) {
+        uint32_t idx = sorted[b];
+        base_t q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS);
+        for (uint32_t i = b; i < e; i++) {
+          const uint32_t cidx = idx; const base_t cur = q;
+          if (i + 1 < e) { idx = sorted[i + 1]; q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS); }
+          acc = CV::madd(acc, cur, (cidx & 0x80000000u) != 0);
+        }
+      }
+    } else {                                            // 381-bit points: registers are the scarcer resource
       for (uint32_t i = b; i < e; i++) {
-        const uint32_t cidx = idx; const base_t cur = q;
-        if (i + 1 < e) { idx = sorted[i + 1]; q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS); }
-        acc = CV::madd(acc, cur, (cidx & 0x80000000u) != 0);
+        const uint32_t idx = sorted[i];
+        acc = CV::madd(acc, CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS), (idx & 0x80000000u) != 0);
       }
     }
   }
