@@ -669,29 +669,32 @@ template <class S, class G> struct Ring {
     // randomisers: SHAKE128 over everything the batch contains
     Shake128 rh; rh.update("avrf-ring-batch", 15); rh.update(commitments, 3 * FQB * n_rings); rh.update(instances_xy, 64 * n); rh.update(proofs, plen * n);
     std::vector<uint8_t> rnd(32 * n); rh.squeeze_copy(rnd.data(), rnd.size());
-    std::vector<uint8_t> b1, b2; std::vector<H256> s1, s2;
-    auto push = [&](std::vector<uint8_t> &b, std::vector<H256> &sv, const G1Aff &p, const H256 &k_mont) {
-      b.insert(b.end(), p.xy, p.xy + 2 * FQB); sv.push_back(Fr::from_mont(k_mont)); };
-    H256 g1_scalar = {{0, 0, 0, 0}};
+    // per item: 10 terms of the first MSM (3 fixed + 4 witness + C_q + pi1 + pi2) and 2 of the second; the
+    // items are independent until the MSMs, so the host part runs on the thread pool
+    std::vector<uint8_t> b1((10 * n + 1) * 2 * FQB), b2(2 * n * 2 * FQB); std::vector<H256> s1(10 * n + 1), s2(2 * n);
+    auto put = [&](std::vector<uint8_t> &b, std::vector<H256> &sv, size_t slot, const G1Aff &p, const H256 &k_mont) {
+      memcpy(&b[slot * 2 * FQB], p.xy, 2 * FQB); sv[slot] = Fr::from_mont(k_mont); };
+    std::vector<H256> gsc(n);
+    std::atomic<int> status{AVRF_OK};
     const H256 w_last = fr_pow<F>(su->w, cap - 1), ninv = su->ninv;
     const H256 a_coef = S::A_KIND == 1 ? Fr::neg(fr_small<F>(5)) : one;
     H256 wz[3]; for (int j = 0; j < 3; j++) wz[j] = fr_pow<F>(su->w, N - 3 + j);
     H256 seedx = Fr::from32(S::ACC_X), seedy = Fr::from32(S::ACC_Y);
-    for (size_t it = 0; it < n; it++) {
+    parallel_for(n, [&](size_t it) {
       const uint8_t *pr = proofs + plen * it;
       const uint32_t ring = ring_of_item ? ring_of_item[it] : 0;
-      if (ring >= n_rings) return AVRF_ERR_BAD_ARG;
+      if (ring >= n_rings) { status = AVRF_ERR_BAD_ARG; return; }
       const G1Aff *fx = &fixed[3 * ring];
       G1Aff C[4], Cq, pi1, pi2; H256 ev[7], lin_zw;
       size_t off = 0;
-      for (int i = 0; i < 4; i++) { if (!g1_decompress(pr + off, &C[i])) return AVRF_INVALID_DATA; off += FQB; }
-      for (int i = 0; i < 7; i++) { H256 v = Fr::load_le(pr + off); if (Fr::geq_p(v)) return AVRF_INVALID_DATA; ev[i] = Fr::to_mont(v); off += 32; }
-      if (!g1_decompress(pr + off, &Cq)) return AVRF_INVALID_DATA; off += FQB;
-      { H256 v = Fr::load_le(pr + off); if (Fr::geq_p(v)) return AVRF_INVALID_DATA; lin_zw = Fr::to_mont(v); off += 32; }
-      if (!g1_decompress(pr + off, &pi1)) return AVRF_INVALID_DATA; off += FQB;
-      if (!g1_decompress(pr + off, &pi2)) return AVRF_INVALID_DATA; off += FQB;
+      for (int i = 0; i < 4; i++) { if (!g1_decompress(pr + off, &C[i])) { status = AVRF_INVALID_DATA; return; } off += FQB; }
+      for (int i = 0; i < 7; i++) { H256 v = Fr::load_le(pr + off); if (Fr::geq_p(v)) { status = AVRF_INVALID_DATA; return; } ev[i] = Fr::to_mont(v); off += 32; }
+      if (!g1_decompress(pr + off, &Cq)) { status = AVRF_INVALID_DATA; return; } off += FQB;
+      { H256 v = Fr::load_le(pr + off); if (Fr::geq_p(v)) { status = AVRF_INVALID_DATA; return; } lin_zw = Fr::to_mont(v); off += 32; }
+      if (!g1_decompress(pr + off, &pi1)) { status = AVRF_INVALID_DATA; return; } off += FQB;
+      if (!g1_decompress(pr + off, &pi2)) { status = AVRF_INVALID_DATA; return; } off += FQB;
       H256 ix = Fr::load_le(instances_xy + 64 * it), iy = Fr::load_le(instances_xy + 64 * it + 32);
-      if (Fr::geq_p(ix) || Fr::geq_p(iy)) return AVRF_INVALID_DATA;
+      if (Fr::geq_p(ix) || Fr::geq_p(iy)) { status = AVRF_INVALID_DATA; return; }
       H256 ixm = Fr::to_mont(ix), iym = Fr::to_mont(iy);
       // transcript replay
       ArkTranscript t;
@@ -711,7 +714,7 @@ template <class S, class G> struct Ring {
       const H256 nl = Fr::sub(zeta, w_last), omb = Fr::sub(one, b);
       H256 zn = zeta; for (size_t k = 1; k < N; k <<= 1) zn = Fr::sqr(zn);
       const H256 zn1 = Fr::sub(zn, one);
-      if (Fr::is_zero(zn1)) return AVRF_VERIFICATION_FAILURE;
+      if (Fr::is_zero(zn1)) { status = AVRF_VERIFICATION_FAILURE; return; }
       auto lag = [&](size_t i) { H256 wi = fr_pow<F>(su->w, i); return Fr::mul(Fr::mul(Fr::mul(wi, zn1), ninv), Fr::inv(Fr::sub(zeta, wi))); };
       const H256 lf = lag(0), ll = lag(cap - 1);
       HostExt sd; sd.x = seedx; sd.y = seedy; sd.t = Fr::mul(seedx, seedy); sd.z = one;
@@ -737,17 +740,21 @@ template <class S, class G> struct Ring {
       H256 r1 = Fr::to_mont(H256{{0, 0, 0, 0}}), r2 = r1;
       { H256 a = {{0, 0, 0, 0}}, c = {{0, 0, 0, 0}}; memcpy(a.l, &rnd[32 * it], 16); memcpy(c.l, &rnd[32 * it + 16], 16); r1 = Fr::to_mont(a); r2 = Fr::to_mont(c); }
       if (n == 1) r1 = one;
-      for (int j = 0; j < 3; j++) push(b1, s1, fx[j], Fr::mul(r1, nu[j]));
-      push(b1, s1, C[0], Fr::mul(r1, nu[3]));
-      push(b1, s1, C[1], Fr::add(Fr::mul(r1, nu[4]), Fr::mul(r2, Fr::mul(nl, al[0]))));
-      push(b1, s1, C[2], Fr::add(Fr::mul(r1, nu[5]), Fr::mul(r2, Fr::mul(nl, Fr::mul(al[1], k1)))));
-      push(b1, s1, C[3], Fr::add(Fr::mul(r1, nu[6]), Fr::mul(r2, Fr::mul(nl, Fr::mul(al[2], k2)))));
-      push(b1, s1, Cq, Fr::mul(r1, nu[7]));
-      push(b1, s1, pi1, Fr::mul(r1, zeta)); push(b1, s1, pi2, Fr::mul(r2, zw));
-      g1_scalar = Fr::sub(g1_scalar, Fr::add(Fr::mul(r1, vagg), Fr::mul(r2, lin_zw)));
-      push(b2, s2, pi1, Fr::neg(r1)); push(b2, s2, pi2, Fr::neg(r2));
-    }
-    push(b1, s1, su->g1_0, g1_scalar);
+      const size_t o = 10 * it;
+      for (int j = 0; j < 3; j++) put(b1, s1, o + j, fx[j], Fr::mul(r1, nu[j]));
+      put(b1, s1, o + 3, C[0], Fr::mul(r1, nu[3]));
+      put(b1, s1, o + 4, C[1], Fr::add(Fr::mul(r1, nu[4]), Fr::mul(r2, Fr::mul(nl, al[0]))));
+      put(b1, s1, o + 5, C[2], Fr::add(Fr::mul(r1, nu[5]), Fr::mul(r2, Fr::mul(nl, Fr::mul(al[1], k1)))));
+      put(b1, s1, o + 6, C[3], Fr::add(Fr::mul(r1, nu[6]), Fr::mul(r2, Fr::mul(nl, Fr::mul(al[2], k2)))));
+      put(b1, s1, o + 7, Cq, Fr::mul(r1, nu[7]));
+      put(b1, s1, o + 8, pi1, Fr::mul(r1, zeta)); put(b1, s1, o + 9, pi2, Fr::mul(r2, zw));
+      gsc[it] = Fr::add(Fr::mul(r1, vagg), Fr::mul(r2, lin_zw));
+      put(b2, s2, 2 * it, pi1, Fr::neg(r1)); put(b2, s2, 2 * it + 1, pi2, Fr::neg(r2));
+    });
+    if (status != AVRF_OK) return status;
+    H256 g1_scalar = {{0, 0, 0, 0}};
+    for (size_t it = 0; it < n; it++) g1_scalar = Fr::sub(g1_scalar, gsc[it]);
+    put(b1, s1, 10 * n, su->g1_0, g1_scalar);
     G1Aff acc1 = g1_msm(su, b1, s1), acc2 = g1_msm(su, b2, s2);
     using HP = HostPairing<G>;
     typename HP::G2 q[2];

@@ -1,0 +1,42 @@
+// CPU-only check of the product's host-side pairing and G1 code (host_pairing.h, host_g1.h):
+// e(tau*g1, g2) * e(-g1, tau*g2) == 1 on the reference's SRS files, and a negative control.
+// Usage: host_pairing_check <curve 0|1> <srs file>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../ark_vrf_amd/csrc/host_pairing.h"
+
+using namespace avrf;
+
+template <class G> static int run(const std::vector<uint8_t> &srs) {
+  using HP = HostPairing<G>; using Fp = typename HP::Fp; using El = typename HP::El;
+  constexpr int B = 8 * Fp::L;
+  uint64_t cnt; memcpy(&cnt, srs.data(), 8);
+  auto g1_at = [&](size_t i, El &x, El &y) {
+    const uint8_t *p = srs.data() + 8 + i * 2 * B; uint8_t le[96];
+    if (B == 48) { for (int k = 0; k < B; k++) { le[k] = p[B - 1 - k]; le[B + k] = p[2 * B - 1 - k]; } }
+    else { memcpy(le, p, 2 * B); le[2 * B - 1] &= 0x3f; }
+    El xr, yr; memcpy(xr.l, le, B); memcpy(yr.l, le + B, B); x = Fp::to_mont(xr); y = Fp::to_mont(yr);
+  };
+  const uint8_t *g2p = srs.data() + 8 + cnt * 2 * B + 8;
+  typename HP::G2 q[2]; HP::g2_decode(g2p, &q[0]); HP::g2_decode(g2p + 4 * B, &q[1]);
+  El px[2], py[2]; bool inf[2] = {false, false};
+  g1_at(1, px[0], py[0]);                       // tau * g1
+  g1_at(0, px[1], py[1]); py[1] = Fp::neg(py[1]);   // -g1
+  bool ok = HP::product_is_one(px, py, inf, q, 2);
+  g1_at(1, px[1], py[1]); py[1] = Fp::neg(py[1]);   // -tau*g1 against tau*g2: must fail
+  bool bad = HP::product_is_one(px, py, inf, q, 2);
+  g1_at(6, px[0], py[0]); g1_at(5, px[1], py[1]); py[1] = Fp::neg(py[1]);
+  bool ok2 = HP::product_is_one(px, py, inf, q, 2);
+  printf("consistent=%d negative=%d consistent_high=%d\n", ok, bad, ok2);
+  return (ok && !bad && ok2) ? 0 : 1;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 3) return 2;
+  FILE *f = fopen(argv[2], "rb"); if (!f) return 2;
+  std::vector<uint8_t> srs; uint8_t buf[65536]; size_t n;
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0) srs.insert(srs.end(), buf, buf + n);
+  fclose(f);
+  return atoi(argv[1]) == 0 ? run<G1Bls12381>(srs) : run<G1Bn254>(srs);
+}

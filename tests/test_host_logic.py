@@ -66,3 +66,17 @@ def test_batch_packing():
                          pks_xy=[b"p" * 64] * 3, proofs=[b"q" * 96] * 3)
     assert b.n == 3 and list(b.io_counts)[:3] == [1, 0, 2] and list(b.ad_lens)[:3] == [1, 0, 2]
     assert bytes(b.ads)[:3] == b"xyz" and bytes(b.ios_xy)[:128] == b"i" * 64 + b"o" * 64
+
+
+@pytest.mark.parametrize("curve,srs", [(0, "bls12-381-srs-2-11-uncompressed-zcash.bin"), (1, "bn254-testing-2-9-uncompressed.bin")])
+def test_host_pairing_on_reference_srs(tmp_path, golden_dir, curve, srs):
+    """Product host code (host_pairing.h / host_g1.h, plain C++): e(tau g1, g2) == e(g1, tau g2) on the
+    reference's SRS files for both pairing curves, and a negative control.  Compiled with g++, no GPU."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "hp")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(ROOT, "tests", "cpp", "host_pairing_check.cpp"), "-o", exe])
+    out = subprocess.run([exe, str(curve), os.path.join(golden_dir, srs)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip() == "consistent=1 negative=0 consistent_high=1"
