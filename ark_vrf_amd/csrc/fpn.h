@@ -101,6 +101,17 @@ template <class F> AVRF_DI fe<F> fn_sqr(const fe<F> &a) { return fn_mul<F>(a, a)
 template <class F> AVRF_DI fe<F> fn_to_mont(const fe<F> &a) { return fn_mul<F>(a, fn_const<F>(F::R2)); }
 template <class F> AVRF_DI fe<F> fn_from_mont(const fe<F> &a) { fe<F> one = fn_zero<F::N>(); one.v[0] = 1; return fn_mul<F>(a, one); }
 
+// a^(p-2) (field inversion), square-and-multiply over the constant exponent
+template <class F> AVRF_DI fe<F> fn_inv(const fe<F> &a) {
+  fe<F> r = fn_one<F>();
+  bool started = false;
+  for (int i = 32 * F::N - 1; i >= 0; i--) {
+    if (started) r = fn_sqr<F>(r);
+    if ((F::PM2[i >> 5] >> (i & 31)) & 1) { r = started ? fn_mul<F>(r, a) : a; started = true; }
+  }
+  return r;
+}
+
 // 16-byte vectorised global loads / stores (N is a multiple of 4)
 template <int N> AVRF_DI fpn<N> fn_load(const uint32_t *s) {
   fpn<N> r; const uint4 *s4 = reinterpret_cast<const uint4 *>(s);

@@ -67,6 +67,8 @@ void launch_pre_from_affine(int suite, const uint8_t *d_xy, size_t n, te_pre_raw
 // key = bucket (1..2^(c-1), 0 = skip) | sign << 15
 // blockIdx.y = index of the scalar vector in a batch of MSMs over the same bases ("virtual windows"
 // v = batch * nwin + w everywhere downstream)
+// (With fixed-base window tables the nwin digit rows of one vector are simply consumed as ONE window of
+// n * nwin keys: same layout, different interpretation downstream.)
 __global__ void k_digits(const uint32_t *__restrict__ scalars, uint32_t n, int c, int nwin, uint16_t *__restrict__ keys) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -150,9 +152,10 @@ k_scan_win(uint32_t *__restrict__ H, uint32_t n, uint32_t ntiles, int c, uint32_
   if (t == 1023) lane_tot[w] = partl[1023];
 }
 
+// remap_n != 0 (fixed-base tables): key position p = w * remap_n + i refers to table entry w * remap_stride + i
 __global__ void __launch_bounds__(256)
 k_scatter(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int c, const uint32_t *__restrict__ H,
-          const uint32_t *__restrict__ offs, uint32_t *__restrict__ sorted) {
+          const uint32_t *__restrict__ offs, uint32_t *__restrict__ sorted, uint32_t remap_n, uint32_t remap_stride) {
   extern __shared__ uint32_t lds[];
   const uint32_t nb = 1u << (c - 1), tile = blockIdx.x, w = blockIdx.y, ntiles = gridDim.x;
   const uint32_t *Hin = H + ((size_t)w * ntiles + tile) * nb;
@@ -162,7 +165,11 @@ k_scatter(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int 
   const uint16_t *kw = keys + (size_t)w * n;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     uint32_t key = kw[i], b = key & 0x7fffu;
-    if (b) { uint32_t pos = atomicAdd(&lds[b - 1], 1u); sorted[pos] = i | ((key & 0x8000u) << 16); }
+    if (b) {
+      uint32_t pos = atomicAdd(&lds[b - 1], 1u);
+      uint32_t idx = remap_n ? (i / remap_n) * remap_stride + (i % remap_n) : i;
+      sorted[pos] = idx | ((key & 0x8000u) << 16);
+    }
   }
 }
 
@@ -410,23 +417,37 @@ void MsmWorkspace::release() {
 // (accumulator layout of CV); returns the number of bit sums.
 // `batch` scalar vectors of length n over the SAME n bases (d_scalars = batch x n x 8 words): every vector
 // gets its own nwin windows; returns the number of bit sums per vector (vector b's sums start at b * that).
+// Fixed-base mode (table_c != 0): d_bases is a window table T[w * table_stride + i] = 2^(table_c * w) * P_i, so all
+// windows of a vector share ONE bucket set: downstream it is a 1-window MSM over n * nwin (table) bases.
 template <class CV>
-static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, int scalar_bits, MsmWorkspace &ws, hipStream_t stream,
-                      size_t batch = 1) {
-  MsmPlan p = msm_plan(n, scalar_bits);
+static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n_in, int scalar_bits, MsmWorkspace &ws, hipStream_t stream,
+                      size_t batch = 1, int table_c = 0, size_t table_stride = 0) {
+  MsmPlan p = msm_plan(n_in, scalar_bits);
+  size_t n = n_in;
+  uint32_t remap_n = 0, remap_stride = 0;
+  dim3 b256(256);
+  if (table_c) {
+    const int dig_nwin = (scalar_bits + 1 + table_c - 1) / table_c;
+    p.c = table_c; p.nb = 1 << (table_c - 1); p.nwin = dig_nwin;
+    ws.ensure(n_in, p, (size_t)CV::ACC_WORDS * 4, batch);             // keys: batch x nwin x n
+    hipLaunchKernelGGL(k_digits, dim3((unsigned)((n_in + 255) / 256), (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n_in, p.c, dig_nwin, ws.keys);
+    n = n_in * (size_t)dig_nwin; p.nwin = 1;
+    remap_n = (uint32_t)n_in; remap_stride = (uint32_t)table_stride;
+  }
   const size_t acc_bytes = (size_t)CV::ACC_WORDS * 4;
-  ws.ensure(n, p, acc_bytes, batch);
+  if (!table_c) ws.ensure(n, p, acc_bytes, batch);
   const uint32_t vwin = (uint32_t)(p.nwin * batch);
   const uint32_t nbk = vwin * p.nb, seg = (uint32_t)p.lpb;
   const uint32_t tile_len = tile_len_for(n), ntiles = (uint32_t)((n + tile_len - 1) / tile_len);
   const uint32_t lcap = lcap_for(n, p);
   const size_t lds_bytes = (size_t)p.nb * 4;
-  dim3 b256(256), gn((unsigned)((n + 255) / 256));
-  hipLaunchKernelGGL(k_digits, dim3(gn.x, (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n, p.c, p.nwin, ws.keys);
+  dim3 gn((unsigned)((n + 255) / 256));
+  if (!table_c) hipLaunchKernelGGL(k_digits, dim3(gn.x, (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n, p.c, p.nwin, ws.keys);
   hipLaunchKernelGGL(k_hist, dim3(ntiles, vwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist);
   hipLaunchKernelGGL(k_scan_win, dim3(vwin), dim3(1024), 0, stream, ws.hist, (uint32_t)n, ntiles, p.c, seg,
                      ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot);
-  hipLaunchKernelGGL(k_scatter, dim3(ntiles, vwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist, ws.offsets, ws.sorted);
+  hipLaunchKernelGGL(k_scatter, dim3(ntiles, vwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist, ws.offsets, ws.sorted,
+                     remap_n, remap_stride);
   dim3 ga((unsigned)(((size_t)vwin * lcap + 255) / 256));
   if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
   HIP_CHECK(hipEventRecord(ws.ev0, stream));
@@ -497,12 +518,39 @@ __global__ void k_g1_bases(const uint8_t *__restrict__ xy, uint32_t n, uint32_t 
   fn_store<N>(out + (size_t)i * 2 * N, fn_to_mont<Fq>(x)); fn_store<N>(out + (size_t)i * 2 * N + N, fn_to_mont<Fq>(y));
 }
 
+// Fixed-base window table over `n` affine bases: table[w * n + i] = 2^(c w) * P_i, w < nwin, affine Montgomery.
+template <class C>
+__global__ void __launch_bounds__(64)
+k_g1_table(const uint32_t *__restrict__ bases, uint32_t n, int c, int nwin, uint32_t *__restrict__ table) {
+  using CV = G1Curve<C>; using Fq = typename C::Fq; constexpr int N = Fq::N;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  typename CV::base_t b = CV::load_base(bases + (size_t)i * 2 * N);
+  typename CV::acc_t acc = CV::from_affine(b);
+  for (int w = 0; w < nwin; w++) {
+    uint32_t *o = table + ((size_t)w * n + i) * 2 * N;
+    if (CV::is_identity(acc)) { fn_store<N>(o, fn_zero<N>()); fn_store<N>(o + N, fn_zero<N>()); }
+    else {
+      fpn<N> zzi = fn_inv<Fq>(acc.zz), zzzi = fn_inv<Fq>(acc.zzz);
+      fn_store<N>(o, fn_mul<Fq>(acc.x, zzi)); fn_store<N>(o + N, fn_mul<Fq>(acc.y, zzzi));
+    }
+    if (w + 1 < nwin) for (int k = 0; k < c; k++) acc = CV::dbl(acc);
+  }
+}
+
+void build_g1_table(int curve, const uint32_t *d_bases, size_t n, int c, int nwin, uint32_t *d_table, hipStream_t stream) {
+  if (!n) return;
+  dim3 g((unsigned)((n + 63) / 64)), b(64);
+  if (curve == 0) hipLaunchKernelGGL(k_g1_table<G1Bls12381>, g, b, 0, stream, d_bases, (uint32_t)n, c, nwin, d_table);
+  else hipLaunchKernelGGL(k_g1_table<G1Bn254>, g, b, 0, stream, d_bases, (uint32_t)n, c, nwin, d_table);
+}
+
 template <class C>
 static int msm_g1_impl(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy,
-                       size_t batch) {
+                       size_t batch, int table_c = 0, size_t table_stride = 0) {
   using HG = HostG1<C>;
   constexpr size_t OUT = 8 * C::Fq::N;                    // bytes of one affine result
-  int nbits = n ? msm_device<G1Curve<C>>(d_bases, d_scalars, n, C::Fr::BITS, ws, stream, batch) : 0;
+  int nbits = n ? msm_device<G1Curve<C>>(d_bases, d_scalars, n, C::Fr::BITS, ws, stream, batch, table_c, table_stride) : 0;
   std::vector<typename HG::Pt> res(batch);
   for (size_t b = 0; b < batch; b++) {
     typename HG::Pt acc = HG::identity();
@@ -532,6 +580,12 @@ int msm_g1_device(int curve, const uint32_t *d_bases, const uint32_t *d_scalars,
                   size_t batch) {
   if (curve == 0) return msm_g1_impl<G1Bls12381>(d_bases, d_scalars, n, ws, stream, out_xy, batch);
   if (curve == 1) return msm_g1_impl<G1Bn254>(d_bases, d_scalars, n, ws, stream, out_xy, batch);
+  return -1;
+}
+int msm_g1_fixed_device(int curve, const uint32_t *d_table, int table_c, size_t table_stride, const uint32_t *d_scalars, size_t n,
+                        MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch) {
+  if (curve == 0) return msm_g1_impl<G1Bls12381>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride);
+  if (curve == 1) return msm_g1_impl<G1Bn254>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride);
   return -1;
 }
 

@@ -227,6 +227,7 @@ struct avrf_ring_setup {
   avrf_ctx *ctx; int suite; hipStream_t stream; int device;
   size_t N, cap, keyset, L, n_srs;
   uint32_t *d_srs = nullptr;                          // n_srs Montgomery affine points
+  uint32_t *d_srs_table = nullptr; int table_c = 0, table_nwin = 0;   // fixed-base window table over the SRS (batched commits)
   G1Aff g1_0;                                         // powers_in_g1[0]
   std::vector<uint8_t> g2_raw;                        // powers_in_g2[0..2] exactly as in the SRS file
   H256 w, w4;                                         // domain generators (Montgomery)
@@ -352,6 +353,16 @@ template <class S, class G> struct Ring {
     HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, su->stream)); HIP_CHECK(hipStreamSynchronize(su->stream));
     HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag));
     if (flag) { HIP_CHECK(hipFree(su->d_srs)); delete su; return AVRF_INVALID_DATA; }
+    {  // fixed-base window table: T[w][i] = 2^(c w) * tau^i G, all windows of a commit then share one bucket set
+      su->table_c = 10;
+      if (const char *e = getenv("AVRF_RING_TABLE_C")) { int v = atoi(e); if (v >= 4 && v <= 14) su->table_c = v; else if (v == 0) su->table_c = 0; }
+      if (su->table_c) {
+        su->table_nwin = (G::Fr::BITS + 1 + su->table_c - 1) / su->table_c;
+        HIP_CHECK(hipMalloc(&su->d_srs_table, (size_t)su->table_nwin * pcs * e1));
+        build_g1_table(su->suite, su->d_srs, pcs, su->table_c, su->table_nwin, su->d_srs_table, su->stream);
+        HIP_CHECK(hipStreamSynchronize(su->stream));
+      }
+    }
     // domain
     H256 root = Fr::from32(G::ROOT_OF_UNITY);
     int lg = 0; while (((size_t)1 << lg) < N) lg++;
@@ -444,7 +455,8 @@ template <class S, class G> struct Ring {
     fp one_plain = fp_zero_host(); one_plain.v[0] = 1;                 // a * 1 / R: Montgomery -> plain, in place
     hipLaunchKernelGGL(k_ntt_scale<F>, dim3((n * batch + 255) / 256), dim3(256), 0, su->stream, d_coeffs_mont, (uint32_t)(n * batch), one_plain);
     std::vector<uint8_t> xy(batch * 2 * FQB);
-    msm_g1_device(su->suite, su->d_srs, d_coeffs_mont, n, su->ws, su->stream, xy.data(), batch);
+    if (su->table_c && batch >= 8) msm_g1_fixed_device(su->suite, su->d_srs_table, su->table_c, su->n_srs, d_coeffs_mont, n, su->ws, su->stream, xy.data(), batch);
+    else msm_g1_device(su->suite, su->d_srs, d_coeffs_mont, n, su->ws, su->stream, xy.data(), batch);
     out.resize(batch);
     for (size_t b = 0; b < batch; b++) {
       memset(&out[b], 0, sizeof(G1Aff)); memcpy(out[b].xy, &xy[b * 2 * FQB], 2 * FQB);
@@ -782,7 +794,7 @@ int avrf_ring_setup_load(avrf_ctx *ctx, const uint8_t *srs, size_t srs_len, size
 void avrf_ring_setup_free(avrf_ring_setup *su) {
   if (!su) return;
   (void)hipSetDevice(su->device);
-  void *d[] = {su->d_srs, su->d_tw_n, su->d_tw_n_inv, su->d_tw_4n, su->d_tw_4n_inv, su->d_buf, su->d_l4, su->d_e4, su->d_agg, su->d_coef};
+  void *d[] = {su->d_srs, su->d_tw_n, su->d_tw_n_inv, su->d_tw_4n, su->d_tw_4n_inv, su->d_buf, su->d_l4, su->d_e4, su->d_agg, su->d_coef, su->d_srs_table};
   for (void *p : d) if (p) (void)hipFree(p);
   su->ws.release();
   delete su;
