@@ -14,6 +14,7 @@ template <class S> struct TeCurve {
   using base_t = te_pre; using acc_t = te_ext;
   static constexpr int BASE_WORDS = 24, ACC_WORDS = 32;
   static constexpr bool PREFETCH = true;
+  static constexpr bool FIXED_TABLE = false;          // no fixed-base window-table mode (bases change per batch)
   static constexpr int MIN_WAVES = 3;                 // waves per SIMD asked of the register allocator in k_accumulate
   static AVRF_DI acc_t identity() { return te_identity<S>(); }
   static AVRF_DI acc_t madd(const acc_t &a, base_t q, bool neg) {
@@ -47,6 +48,7 @@ template <class C> struct G1Curve {
   static constexpr int BASE_WORDS = 2 * N, ACC_WORDS = 4 * N;
   static constexpr bool PREFETCH = (N <= 8);
   static constexpr int MIN_WAVES = 2;
+  static constexpr bool FIXED_TABLE = true;           // KZG SRS: msm_g1_fixed_device
 
   static AVRF_DI acc_t identity() { acc_t r; r.x = fn_one<Fq>(); r.y = fn_one<Fq>(); r.zz = fn_zero<N>(); r.zzz = fn_zero<N>(); return r; }
   static AVRF_DI bool is_identity(const acc_t &a) { return fn_is_zero(a.zz); }

@@ -52,15 +52,16 @@ int msm_te_device(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars,
 // G1 MSM over a short-Weierstrass curve (curve: 0 BLS12-381, 1 BN254): d_bases = n Montgomery affine
 // points (2 * Fq words each, (0,0) = infinity), d_scalars = n plain 256-bit scalars (< r).
 // out_xy: canonical affine x || y little-endian (2 * FQ_BYTES), all-zero for the point at infinity.
-// batch > 1: `batch` scalar vectors (batch x n x 8 words) over the same bases, `batch` results in out_xy.
+// batch > 1: `batch` scalar vectors over the same bases (vector b starts at element b * scalar_stride; 0 = n),
+// `batch` results in out_xy.
 int msm_g1_device(int curve, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy,
-                  size_t batch = 1);
+                  size_t batch = 1, size_t scalar_stride = 0);
 // Fixed-base form for MSMs over one shared base set (the KZG SRS): build_g1_table fills
 // table[w * n + i] = 2^(c w) * P_i (nwin = ceil((Fr bits + 1) / c) rows); msm_g1_fixed_device then treats all
 // windows of a scalar vector as ONE bucket set (n may be smaller than the table's row length `table_stride`).
 void build_g1_table(int curve, const uint32_t *d_bases, size_t n, int c, int nwin, uint32_t *d_table, hipStream_t stream);
 int msm_g1_fixed_device(int curve, const uint32_t *d_table, int table_c, size_t table_stride, const uint32_t *d_scalars, size_t n,
-                        MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch);
+                        size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch);
 void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, uint32_t *d_flag, hipStream_t stream);
 
 // canonical affine bytes (x||y LE32) -> te_pre (device); flags[i] |= 1 if a coordinate >= q, |= 2 if off-curve (when check_curve)

@@ -69,13 +69,13 @@ void launch_pre_from_affine(int suite, const uint8_t *d_xy, size_t n, te_pre_raw
 // v = batch * nwin + w everywhere downstream)
 // (With fixed-base window tables the nwin digit rows of one vector are simply consumed as ONE window of
 // n * nwin keys: same layout, different interpretation downstream.)
-__global__ void k_digits(const uint32_t *__restrict__ scalars, uint32_t n, int c, int nwin, uint16_t *__restrict__ keys) {
+__global__ void k_digits(const uint32_t *__restrict__ scalars, uint32_t n, uint32_t stride, int c, int nwin, uint16_t *__restrict__ keys) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t bat = blockIdx.y;
   keys += (size_t)bat * nwin * n;
   uint32_t s[9];
-  const uint4 *p = reinterpret_cast<const uint4 *>(scalars + 8 * ((size_t)bat * n + i));
+  const uint4 *p = reinterpret_cast<const uint4 *>(scalars + 8 * ((size_t)bat * stride + i));
   uint4 a = p[0], b = p[1];
   s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; s[8] = 0;
   const uint32_t nb = 1u << (c - 1), mask = (1u << c) - 1;
@@ -255,6 +255,12 @@ k_fixup(const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off
 
 // ---------------------------------------------------------------- bucket reduction by index bits
 
+// out-of-line point ops for the (cold) reduction kernels: keeps their code size and compile time down
+template <class CV> __device__ __noinline__ void cv_add_nf(typename CV::acc_t *r, const typename CV::acc_t *a, const typename CV::acc_t *b) { *r = CV::add(*a, *b); }
+template <class CV> __device__ __noinline__ void cv_dbl_nf(typename CV::acc_t *r, const typename CV::acc_t *a) { *r = CV::dbl(*a); }
+template <class CV> AVRF_DI typename CV::acc_t cv_add(const typename CV::acc_t &a, const typename CV::acc_t &b) { typename CV::acc_t r; cv_add_nf<CV>(&r, &a, &b); return r; }
+template <class CV> AVRF_DI typename CV::acc_t cv_dbl(const typename CV::acc_t &a) { typename CV::acc_t r; cv_dbl_nf<CV>(&r, &a); return r; }
+
 template <class CV> AVRF_DI typename CV::acc_t wave_sum(typename CV::acc_t acc) {
 #pragma unroll 1
   for (int off = 32; off >= 1; off >>= 1) acc = CV::add(acc, CV::shfl_down(acc, off));
@@ -334,6 +340,55 @@ k_horner(const uint32_t *__restrict__ bits, uint32_t nbits, uint32_t batch, uint
     acc = CV::add(acc, CV::load_acc(T + (size_t)i * CV::ACC_WORDS));
   }
   CV::store_acc(out + (size_t)b * CV::ACC_WORDS, acc);
+}
+
+template <class CV> AVRF_DI typename CV::acc_t wave_sum_nf(typename CV::acc_t acc) {
+#pragma unroll 1
+  for (int off = 32; off >= 1; off >>= 1) acc = cv_add<CV>(acc, CV::shfl_down(acc, off));
+  return acc;
+}
+
+// Fixed-base (table) batched MSMs have ONE bucket set per MSM: a workgroup per set computes sum_b b * B_b
+// directly.  Thread t owns the m = nb / 256 consecutive buckets above t*m (running sums: 2 adds per bucket);
+// then sum_t W_t + m * sum_t t * S_t by a wave suffix scan + reduction and a 4-term tail across waves.
+template <class CV>
+__global__ void __launch_bounds__(256, CV::MIN_WAVES)
+k_wsum(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t *__restrict__ out) {
+  using acc_t = typename CV::acc_t;
+  __shared__ uint32_t lds[4 * 2 * CV::ACC_WORDS];
+  const uint32_t v = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const uint32_t m = (nb + 255) / 256;
+  const uint32_t *B = buckets + (size_t)v * nb * CV::ACC_WORDS;              // B[b-1]
+  acc_t S = CV::identity(), W = CV::identity();
+  {
+    uint32_t lo = t * m + 1, hi = lo + m - 1; if (hi > nb) hi = nb;
+    for (uint32_t b = hi; b >= lo && b >= 1 && lo <= nb; b--) {               // S = sum B_b, W = sum (b - t*m) B_b
+      S = cv_add<CV>(S, CV::load_acc(B + (size_t)(b - 1) * CV::ACC_WORDS));
+      W = cv_add<CV>(W, S);
+    }
+  }
+  // suffix sums of S over the wave: A_l = sum_{l' >= l} S_l'
+  acc_t A = S;
+#pragma unroll 1
+  for (int off = 1; off < 64; off <<= 1) {
+    acc_t o = CV::shfl_down(A, off);
+    if (lane + off < 64) A = cv_add<CV>(A, o);
+  }
+  // wave: sum_l W_l + m * sum_l l * S_l = sum_l (W_l + m * [l >= 1] A_l);   Y = A_0 = sum_l S_l
+  acc_t Z = lane ? A : CV::identity();
+  for (uint32_t k = m; k > 1; k >>= 1) Z = cv_dbl<CV>(Z);
+  acc_t V = wave_sum_nf<CV>(cv_add<CV>(W, Z));
+  if (lane == 0) { CV::store_acc(lds + (2 * wv) * CV::ACC_WORDS, V); CV::store_acc(lds + (2 * wv + 1) * CV::ACC_WORDS, A); }
+  __syncthreads();
+  if (t == 0) {
+    acc_t Y3 = CV::load_acc(lds + 7 * CV::ACC_WORDS), Y2 = CV::load_acc(lds + 5 * CV::ACC_WORDS), Y1 = CV::load_acc(lds + 3 * CV::ACC_WORDS);
+    acc_t s2 = cv_add<CV>(Y2, Y3), s1 = cv_add<CV>(Y1, s2);
+    acc_t q = cv_add<CV>(cv_add<CV>(s1, s2), Y3);                                   // Y1 + 2 Y2 + 3 Y3
+    for (uint32_t k = 64 * m; k > 1; k >>= 1) q = cv_dbl<CV>(q);
+    acc_t r = cv_add<CV>(cv_add<CV>(CV::load_acc(lds), CV::load_acc(lds + 2 * CV::ACC_WORDS)),
+                      cv_add<CV>(CV::load_acc(lds + 4 * CV::ACC_WORDS), CV::load_acc(lds + 6 * CV::ACC_WORDS)));
+    CV::store_acc(out + (size_t)v * CV::ACC_WORDS, cv_add<CV>(r, q));
+  }
 }
 
 // ---------------------------------------------------------------- host engine
@@ -421,17 +476,22 @@ void MsmWorkspace::release() {
 // windows of a vector share ONE bucket set: downstream it is a 1-window MSM over n * nwin (table) bases.
 template <class CV>
 static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n_in, int scalar_bits, MsmWorkspace &ws, hipStream_t stream,
-                      size_t batch = 1, int table_c = 0, size_t table_stride = 0) {
+                      size_t batch = 1, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0) {
   MsmPlan p = msm_plan(n_in, scalar_bits);
+  if (!scalar_stride) scalar_stride = n_in;                            // vector b's scalars start at b * scalar_stride
   size_t n = n_in;
   uint32_t remap_n = 0, remap_stride = 0;
   dim3 b256(256);
   if (table_c) {
     const int dig_nwin = (scalar_bits + 1 + table_c - 1) / table_c;
-    p.c = table_c; p.nb = 1 << (table_c - 1); p.nwin = dig_nwin;
-    ws.ensure(n_in, p, (size_t)CV::ACC_WORDS * 4, batch);             // keys: batch x nwin x n
-    hipLaunchKernelGGL(k_digits, dim3((unsigned)((n_in + 255) / 256), (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n_in, p.c, dig_nwin, ws.keys);
-    n = n_in * (size_t)dig_nwin; p.nwin = 1;
+    p.c = table_c; p.nb = 1 << (table_c - 1); p.nwin = 1;
+    if (!getenv("AVRF_MSM_SEG")) {                                      // ~entries per bucket, 16..64 per lane
+      size_t avg = n_in * (size_t)dig_nwin / p.nb;
+      p.lpb = avg >= 64 ? 64 : avg >= 32 ? 32 : 16;
+    }
+    n = n_in * (size_t)dig_nwin;                                        // one window of n_in * dig_nwin keys per vector
+    ws.ensure(n, p, (size_t)CV::ACC_WORDS * 4, batch);
+    hipLaunchKernelGGL(k_digits, dim3((unsigned)((n_in + 255) / 256), (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n_in, (uint32_t)scalar_stride, p.c, dig_nwin, ws.keys);
     remap_n = (uint32_t)n_in; remap_stride = (uint32_t)table_stride;
   }
   const size_t acc_bytes = (size_t)CV::ACC_WORDS * 4;
@@ -442,7 +502,7 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   const uint32_t lcap = lcap_for(n, p);
   const size_t lds_bytes = (size_t)p.nb * 4;
   dim3 gn((unsigned)((n + 255) / 256));
-  if (!table_c) hipLaunchKernelGGL(k_digits, dim3(gn.x, (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n, p.c, p.nwin, ws.keys);
+  if (!table_c) hipLaunchKernelGGL(k_digits, dim3(gn.x, (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n, (uint32_t)scalar_stride, p.c, p.nwin, ws.keys);
   hipLaunchKernelGGL(k_hist, dim3(ntiles, vwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist);
   hipLaunchKernelGGL(k_scan_win, dim3(vwin), dim3(1024), 0, stream, ws.hist, (uint32_t)n, ntiles, p.c, seg,
                      ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot);
@@ -459,6 +519,15 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   const int h = (p.c - 1) / 2;
   const uint32_t tasks = (1u << h) + ((uint32_t)p.nb >> h);
   const int nbits = (int)vwin * p.c;
+  if constexpr (CV::FIXED_TABLE) if (table_c && batch >= 8) {   // one bucket set per MSM: weighted sum in one kernel, no bit sums
+    hipLaunchKernelGGL(k_wsum<CV>, dim3((unsigned)batch), b256, 0, stream, (const uint32_t *)ws.buckets, (uint32_t)p.nb, ws.rc);
+    HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.rc, batch * acc_bytes, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventElapsedTime(&ws.accum_ms_last, ws.ev0, ws.ev1));
+    ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = p;
+    return p.c;
+  }
   if (p.nb <= 256 && batch >= 8) {
     hipLaunchKernelGGL(k_bits_direct<CV>, dim3(((unsigned)nbits + 127) / 128), dim3(128), 0, stream, (const uint32_t *)ws.buckets, p.c, (uint32_t)nbits, ws.bits);
   } else {
@@ -547,10 +616,10 @@ void build_g1_table(int curve, const uint32_t *d_bases, size_t n, int c, int nwi
 
 template <class C>
 static int msm_g1_impl(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy,
-                       size_t batch, int table_c = 0, size_t table_stride = 0) {
+                       size_t batch, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0) {
   using HG = HostG1<C>;
   constexpr size_t OUT = 8 * C::Fq::N;                    // bytes of one affine result
-  int nbits = n ? msm_device<G1Curve<C>>(d_bases, d_scalars, n, C::Fr::BITS, ws, stream, batch, table_c, table_stride) : 0;
+  int nbits = n ? msm_device<G1Curve<C>>(d_bases, d_scalars, n, C::Fr::BITS, ws, stream, batch, table_c, table_stride, scalar_stride) : 0;
   std::vector<typename HG::Pt> res(batch);
   for (size_t b = 0; b < batch; b++) {
     typename HG::Pt acc = HG::identity();
@@ -577,15 +646,15 @@ void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, 
 }
 
 int msm_g1_device(int curve, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy,
-                  size_t batch) {
-  if (curve == 0) return msm_g1_impl<G1Bls12381>(d_bases, d_scalars, n, ws, stream, out_xy, batch);
-  if (curve == 1) return msm_g1_impl<G1Bn254>(d_bases, d_scalars, n, ws, stream, out_xy, batch);
+                  size_t batch, size_t scalar_stride) {
+  if (curve == 0) return msm_g1_impl<G1Bls12381>(d_bases, d_scalars, n, ws, stream, out_xy, batch, 0, 0, scalar_stride);
+  if (curve == 1) return msm_g1_impl<G1Bn254>(d_bases, d_scalars, n, ws, stream, out_xy, batch, 0, 0, scalar_stride);
   return -1;
 }
 int msm_g1_fixed_device(int curve, const uint32_t *d_table, int table_c, size_t table_stride, const uint32_t *d_scalars, size_t n,
-                        MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch) {
-  if (curve == 0) return msm_g1_impl<G1Bls12381>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride);
-  if (curve == 1) return msm_g1_impl<G1Bn254>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride);
+                        size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch) {
+  if (curve == 0) return msm_g1_impl<G1Bls12381>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride, scalar_stride);
+  if (curve == 1) return msm_g1_impl<G1Bn254>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride, scalar_stride);
   return -1;
 }
 

@@ -112,6 +112,152 @@ k_ring_constraints(const uint32_t *__restrict__ e4, const uint32_t *__restrict__
   store_fp(out + (size_t)i * 8, s);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// per-proof polynomial rounds of the prover on the device; grid.y / blockIdx = proof.
+// All vectors are Montgomery Fr, 8 words per element.
+
+struct Fp3 { fp v[3]; };
+
+template <class F> AVRF_DI fp fp_pow_u32(fp a, uint32_t e) {
+  fp r = fp_one<F>();
+  while (e) { if (e & 1) r = fp_mul<F>(r, a); e >>= 1; if (e) a = fp_sqr<F>(a); }
+  return r;
+}
+// sum over the 256 lanes of a workgroup (sh: 256 x 8 words); result valid in every lane
+template <class F> AVRF_DI fp block_sum256(fp v, uint32_t *sh) {
+  const uint32_t t = threadIdx.x;
+  __syncthreads();
+  store_fp(sh + t * 8, v);
+  __syncthreads();
+  for (uint32_t s = 128; s > 0; s >>= 1) {
+    if (t < s) store_fp(sh + t * 8, fp_add<F>(load_fp(sh + t * 8), load_fp(sh + (t + s) * 8)));
+    __syncthreads();
+  }
+  return load_fp(sh);
+}
+// value at x of the length-len polynomial c: lane t takes coefficients [t*L, (t+1)*L)
+template <class F> AVRF_DI fp block_eval256(const uint32_t *c, uint32_t len, const fp &x, uint32_t *sh) {
+  const uint32_t t = threadIdx.x, L = (len + 255) / 256;
+  uint32_t lo = t * L, hi = lo + L; if (hi > len) hi = len;
+  fp h = fp_zero();
+  for (uint32_t i = hi; i > lo; i--) h = fp_add<F>(fp_mul<F>(h, x), load_fp(c + (size_t)(i - 1) * 8));
+  if (lo < hi) h = fp_mul<F>(h, fp_pow_u32<F>(x, lo));
+  return block_sum256<F>(h, sh);
+}
+
+// quotient: q = agg * Z / (X^N - 1) with Z = X^3 + z2 X^2 + z1 X + z0 (the three zk rows), agg of length M = 4N:
+// t[k] = sum_m z[m] agg[k-m];  q[i] = sum_{j >= 1} t[i + jN]   (exact division: the remainder is zero)
+template <class F>
+__global__ void __launch_bounds__(256)
+k_ring_quotient(const uint32_t *__restrict__ agg, uint32_t N, uint32_t qlen, Fp3 z, uint32_t *__restrict__ q) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, M = 4 * N;
+  if (i >= qlen) return;
+  const uint32_t *a = agg + (size_t)blockIdx.y * M * 8;
+  fp acc = fp_zero();
+  for (uint32_t k = i + N; k <= M + 2; k += N) {
+    if (k < M) acc = fp_add<F>(acc, fp_mul<F>(z.v[0], load_fp(a + (size_t)k * 8)));
+    if (k >= 1 && k - 1 < M) acc = fp_add<F>(acc, fp_mul<F>(z.v[1], load_fp(a + (size_t)(k - 1) * 8)));
+    if (k >= 2 && k - 2 < M) acc = fp_add<F>(acc, fp_mul<F>(z.v[2], load_fp(a + (size_t)(k - 2) * 8)));
+    if (k >= 3 && k - 3 < M) acc = fp_add<F>(acc, load_fp(a + (size_t)(k - 3) * 8));
+  }
+  store_fp(q + ((size_t)blockIdx.y * qlen + i) * 8, acc);
+}
+
+// ev[proof][c] = poly_c(zeta_proof), c: px | py | sel (fixed, shared) | bits | ip | ax | ay (coef: proof x 4 x N)
+template <class F>
+__global__ void __launch_bounds__(256)
+k_ring_evals(const uint32_t *__restrict__ coef, const uint32_t *__restrict__ fixed, const uint32_t *__restrict__ zeta, uint32_t N,
+             uint32_t *__restrict__ ev) {
+  __shared__ uint32_t sh[256 * 8];
+  const uint32_t c = blockIdx.x, p = blockIdx.y;
+  const uint32_t *poly = c < 3 ? fixed + (size_t)c * N * 8 : coef + ((size_t)p * 4 + (c - 3)) * N * 8;
+  fp v = block_eval256<F>(poly, N, load_fp(zeta + (size_t)p * 8), sh);
+  if (threadIdx.x == 0) store_fp(ev + ((size_t)p * 7 + c) * 8, v);
+}
+
+// linearisation polynomial lin = f0 ip + f1 ax + f2 ay (f from the evaluations, A.7 step 6) and lin(zeta w)
+template <class S>
+__global__ void __launch_bounds__(256)
+k_ring_lin(const uint32_t *__restrict__ coef, const RingConsts *__restrict__ consts, const uint32_t *__restrict__ zeta,
+           const uint32_t *__restrict__ ev, fp w, uint32_t N, uint32_t *__restrict__ lin, uint32_t *__restrict__ lin_zw) {
+  using F = typename S::Fq;
+  __shared__ uint32_t sh[256 * 8];
+  const uint32_t p = blockIdx.x, t = threadIdx.x;
+  const RingConsts &c = consts[p];
+  const uint32_t *e = ev + (size_t)p * 7 * 8;
+  const fp z = load_fp(zeta + (size_t)p * 8), one = fp_one<F>();
+  const fp x2 = load_fp(e), y2 = load_fp(e + 8), b = load_fp(e + 24), x1 = load_fp(e + 40), y1 = load_fp(e + 48);
+  const fp nlz = fp_sub<F>(z, c.w_last), omb = fp_sub<F>(one, b);
+  const fp k1 = fp_add<F>(fp_mul<F>(b, fp_add<F>(fp_mul<F>(y1, y2), mul_a<S>(fp_mul<F>(x1, x2)))), omb);
+  const fp k2 = fp_add<F>(fp_mul<F>(b, fp_sub<F>(fp_mul<F>(x1, y2), fp_mul<F>(x2, y1))), omb);
+  const fp f0 = fp_mul<F>(nlz, c.alpha[0]), f1 = fp_mul<F>(nlz, fp_mul<F>(c.alpha[1], k1)), f2 = fp_mul<F>(nlz, fp_mul<F>(c.alpha[2], k2));
+  const uint32_t *ip = coef + ((size_t)p * 4 + 1) * N * 8, *ax = ip + (size_t)N * 8, *ay = ax + (size_t)N * 8;
+  uint32_t *out = lin + (size_t)p * N * 8;
+  for (uint32_t i = t; i < N; i += 256)
+    store_fp(out + (size_t)i * 8, fp_add<F>(fp_add<F>(fp_mul<F>(f0, load_fp(ip + (size_t)i * 8)), fp_mul<F>(f1, load_fp(ax + (size_t)i * 8))),
+                                            fp_mul<F>(f2, load_fp(ay + (size_t)i * 8))));
+  __syncthreads();
+  fp v = block_eval256<F>(out, N, fp_mul<F>(z, w), sh);
+  if (t == 0) store_fp(lin_zw + (size_t)p * 8, v);
+}
+
+// aggregated opening polynomial at zeta: sum_c nu_c poly_c + nu_7 q   (length qlen; the 7 columns have length N)
+template <class F>
+__global__ void __launch_bounds__(256)
+k_ring_aggz(const uint32_t *__restrict__ coef, const uint32_t *__restrict__ fixed, const uint32_t *__restrict__ q, const uint32_t *__restrict__ nu,
+            uint32_t N, uint32_t qlen, uint32_t *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+  if (i >= qlen) return;
+  const uint32_t *nup = nu + (size_t)p * 8 * 8;
+  fp acc = fp_mul<F>(load_fp(nup + 7 * 8), load_fp(q + ((size_t)p * qlen + i) * 8));
+  if (i < N) {
+    for (int c = 0; c < 3; c++) acc = fp_add<F>(acc, fp_mul<F>(load_fp(nup + c * 8), load_fp(fixed + ((size_t)c * N + i) * 8)));
+    for (int c = 0; c < 4; c++) acc = fp_add<F>(acc, fp_mul<F>(load_fp(nup + (3 + c) * 8), load_fp(coef + (((size_t)p * 4 + c) * N + i) * 8)));
+  }
+  store_fp(out + ((size_t)p * qlen + i) * 8, acc);
+}
+
+// out = (c(X) - c(z)) / (X - z), z = zs[proof] * zmul: out[i-1] = A_i = c[i] + z A_{i+1}.  Lane t owns indices
+// [t*L, (t+1)*L); the carry into a chunk comes from a suffix scan of the chunk values with multiplier z^L.
+template <class F>
+__global__ void __launch_bounds__(256)
+k_ring_divlin(const uint32_t *__restrict__ in, uint32_t in_stride, uint32_t len, const uint32_t *__restrict__ zs, fp zmul,
+              uint32_t *__restrict__ out, uint32_t out_stride) {
+  __shared__ uint32_t sh[256 * 8];
+  const uint32_t p = blockIdx.x, t = threadIdx.x, L = (len + 255) / 256;
+  const uint32_t *c = in + (size_t)p * in_stride * 8;
+  uint32_t *o = out + (size_t)p * out_stride * 8;
+  const fp z = fp_mul<F>(load_fp(zs + (size_t)p * 8), zmul);
+  uint32_t lo = t * L, hi = lo + L; if (hi > len) hi = len; if (lo > len) lo = len;
+  fp h = fp_zero();
+  for (uint32_t i = hi; i > lo; i--) h = fp_add<F>(fp_mul<F>(h, z), load_fp(c + (size_t)(i - 1) * 8));
+  // carry[t] = sum_{t' > t} h_{t'} z^(L (t' - t - 1)):  start from h_{t+1}, then Hillis-Steele with z^(L d)
+  store_fp(sh + t * 8, h);
+  __syncthreads();
+  fp A = t + 1 < 256 ? load_fp(sh + (t + 1) * 8) : fp_zero();
+  fp mul = fp_pow_u32<F>(z, L);
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    __syncthreads();
+    store_fp(sh + t * 8, A);
+    __syncthreads();
+    if (t + d < 256) A = fp_add<F>(A, fp_mul<F>(mul, load_fp(sh + (t + d) * 8)));
+    mul = fp_sqr<F>(mul);
+  }
+  for (uint32_t i = hi; i > lo; i--) {
+    A = fp_add<F>(load_fp(c + (size_t)(i - 1) * 8), fp_mul<F>(A, z));
+    if (i >= 2) store_fp(o + (size_t)(i - 2) * 8, A);
+  }
+}
+
+// Montgomery -> plain copy (MSM scalars), out of place
+template <class F>
+__global__ void k_mont_to_plain(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t total) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  store_fp(dst + (size_t)t * 8, fp_from_mont<F>(load_fp(src + (size_t)t * 8)));
+}
+
 // ------------------------------------------------------------------------------------------------
 // SHAKE128 + ark-transcript
 
@@ -236,8 +382,10 @@ struct avrf_ring_setup {
   std::vector<std::pair<H256, H256>> h_pows;          // 2^i * BLINDING_BASE, affine Montgomery
   uint32_t *d_buf = nullptr; size_t buf_cap = 0;      // scratch for NTT batches / MSM scalars
   uint32_t *d_l4 = nullptr;                           // L_first | L_last evaluated on the 4N domain (2 x 4N)
-  uint32_t *d_e4 = nullptr, *d_agg = nullptr, *d_coef = nullptr;   // per chunk: witness evaluations (4 x 4N), aggregated constraints (4N), coefficients (4 x N)
-  size_t e4_cap = 0, agg_cap = 0, coef_cap = 0;
+  // per-chunk scratch: 0 witness evaluations (4 x 4N; later the opening quotients), 1 aggregated constraints (4N; later
+  // the aggregated opening polynomial), 2 coefficients (4 x N), 3 parameter block, 4 quotient, 5 linearisation
+  uint32_t *d_scr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t scr_cap[6] = {0, 0, 0, 0, 0, 0};
   MsmWorkspace ws;
 };
 struct avrf_ring_key {
@@ -249,6 +397,7 @@ struct avrf_ring_key {
   std::vector<H256> px4, py4, sel4;                   // evaluations on the 4N domain
   G1Aff C[3];
   uint32_t *d_fixed4 = nullptr;                       // px4 | py4 | sel4 on the device (3 x 4N)
+  uint32_t *d_fixed_coef = nullptr;                   // px | py | sel coefficients on the device (3 x N)
 };
 
 extern "C" hipStream_t avrf_ctx_stream_(avrf_ctx *c);
@@ -412,6 +561,7 @@ template <class S, class G> struct Ring {
     ntt(su, cols, N, 3, true);
     k->px_poly.assign(cols.begin(), cols.begin() + N); k->py_poly.assign(cols.begin() + N, cols.begin() + 2 * N); k->sel_poly.assign(cols.begin() + 2 * N, cols.end());
     commit_batch(su, cols.data(), N, 3, k->C);
+    HIP_CHECK(hipMalloc(&k->d_fixed_coef, 3 * N * 32)); HIP_CHECK(hipMemcpy(k->d_fixed_coef, cols.data(), 3 * N * 32, hipMemcpyHostToDevice));
     // evaluations of the fixed columns on the 4N domain (shared by every proof over this ring)
     std::vector<H256> e4(3 * 4 * N, zero);
     for (size_t i = 0; i < N; i++) { e4[i] = k->px_poly[i]; e4[4 * N + i] = k->py_poly[i]; e4[8 * N + i] = k->sel_poly[i]; }
@@ -438,25 +588,28 @@ template <class S, class G> struct Ring {
   // Fiat-Shamir transcript -- while the O(N) per-proof bookkeeping runs on the host between the rounds.
   // out: per proof 4*G1 || 7*Fr || G1 || Fr || G1 || G1.
   struct ProofState {
-    std::vector<H256> coef;          // 4 x N witness coefficients: bits | ip | ax | ay
-    std::vector<H256> q, lin, aggz;
     H256 seedx, seedy, resx, resy, instx, insty, al[7], zeta, ev[7], lin_zw, nu[8];
     G1Aff C[4], Cq, pi[2];
     ArkTranscript t;
   };
   static uint32_t *dev_scratch(avrf_ring_setup *su, int which, size_t bytes) {
-    uint32_t **p = which == 0 ? &su->d_e4 : which == 1 ? &su->d_agg : &su->d_coef;
-    size_t *cap = which == 0 ? &su->e4_cap : which == 1 ? &su->agg_cap : &su->coef_cap;
+    uint32_t **p = &su->d_scr[which]; size_t *cap = &su->scr_cap[which];
     if (bytes > *cap) { if (*p) HIP_CHECK(hipFree(*p)); HIP_CHECK(hipMalloc(p, bytes)); *cap = bytes; }
     return *p;
   }
-  // batched commit of `batch` coefficient vectors already on the device in Montgomery form (stride n)
-  static void commit_device(avrf_ring_setup *su, uint32_t *d_coeffs_mont, size_t n, size_t batch, std::vector<G1Aff> &out) {
-    fp one_plain = fp_zero_host(); one_plain.v[0] = 1;                 // a * 1 / R: Montgomery -> plain, in place
-    hipLaunchKernelGGL(k_ntt_scale<F>, dim3((n * batch + 255) / 256), dim3(256), 0, su->stream, d_coeffs_mont, (uint32_t)(n * batch), one_plain);
+  // batched commit of `batch` coefficient vectors on the device in Montgomery form: vector b starts at
+  // d_coeffs_mont + b * stride elements, its first n coefficients are committed (the source is left untouched)
+  static void commit_device(avrf_ring_setup *su, const uint32_t *d_coeffs_mont, size_t stride, size_t n, size_t batch, std::vector<G1Aff> &out) {
+    ensure_buf(su, stride * batch * 32);
+    hipLaunchKernelGGL(k_mont_to_plain<F>, dim3((unsigned)((stride * batch + 255) / 256)), dim3(256), 0, su->stream, d_coeffs_mont, su->d_buf, (uint32_t)(stride * batch));
     std::vector<uint8_t> xy(batch * 2 * FQB);
-    if (su->table_c && batch >= 8) msm_g1_fixed_device(su->suite, su->d_srs_table, su->table_c, su->n_srs, d_coeffs_mont, n, su->ws, su->stream, xy.data(), batch);
-    else msm_g1_device(su->suite, su->d_srs, d_coeffs_mont, n, su->ws, su->stream, xy.data(), batch);
+    static const bool trace = getenv("AVRF_RING_TRACE") != nullptr;
+    struct timespec t0; if (trace) { HIP_CHECK(hipStreamSynchronize(su->stream)); clock_gettime(CLOCK_MONOTONIC, &t0); }
+    if (su->table_c && batch >= 8) msm_g1_fixed_device(su->suite, su->d_srs_table, su->table_c, su->n_srs, su->d_buf, n, stride, su->ws, su->stream, xy.data(), batch);
+    else msm_g1_device(su->suite, su->d_srs, su->d_buf, n, su->ws, su->stream, xy.data(), batch, stride);
+    if (trace) { struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+      fprintf(stderr, "    commit n=%zu batch=%zu: %.3f ms wall, accumulate %.3f ms (c=%d seg=%d)\n", n, batch,
+              (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, su->ws.accum_ms_last, su->ws.last_plan.c, su->ws.last_plan.lpb); }
     out.resize(batch);
     for (size_t b = 0; b < batch; b++) {
       memset(&out[b], 0, sizeof(G1Aff)); memcpy(out[b].xy, &xy[b * 2 * FQB], 2 * FQB);
@@ -515,23 +668,28 @@ template <class S, class G> struct Ring {
     uint32_t *d_coef = dev_scratch(su, 2, n * 4 * N * 32), *d_e4 = dev_scratch(su, 0, n * 4 * M * 32);
     HIP_CHECK(hipMemcpyAsync(d_coef, cols.data(), n * 4 * N * 32, hipMemcpyHostToDevice, su->stream));
     { fp sc; memcpy(sc.v, su->ninv.l, 32); ntt_launch<F>(d_coef, (uint32_t)N, su->d_tw_n_inv, (uint32_t)(4 * n), &sc, su->stream); }
-    HIP_CHECK(hipMemcpyAsync(cols.data(), d_coef, n * 4 * N * 32, hipMemcpyDeviceToHost, su->stream));   // coefficients, for the host rounds
     HIP_CHECK(hipMemsetAsync(d_e4, 0, n * 4 * M * 32, su->stream));
     HIP_CHECK(hipMemcpy2DAsync(d_e4, M * 32, d_coef, N * 32, N * 32, 4 * n, hipMemcpyDeviceToDevice, su->stream));
     ntt_launch<F>(d_e4, (uint32_t)M, su->d_tw_4n, (uint32_t)(4 * n), nullptr, su->stream);
-    { std::vector<G1Aff> C; commit_device(su, d_coef, N, 4 * n, C);
+    { std::vector<G1Aff> C; commit_device(su, d_coef, N, N, 4 * n, C);
       for (size_t p = 0; p < n; p++) for (int i = 0; i < 4; i++) st[p].C[i] = C[4 * p + i]; }
     lap("intt + ntt4n + 4n commits");
-    for (size_t p = 0; p < n; p++) {
+    ArkTranscript t0; transcript_prelude(k, t0);                       // shared by every proof over this ring
+    parallel_for(n, [&](size_t p) {
       ProofState &ps = st[p];
-      ps.coef.assign(cols.begin() + p * 4 * N, cols.begin() + (p + 1) * 4 * N);
-      transcript_prelude(k, ps.t);
+      ps.t = t0;
       { std::vector<uint8_t> b; push_le32(b, ps.instx); push_le32(b, ps.insty); ps.t.label("instance"); ps.t.append(b); }
       { std::vector<uint8_t> b; for (int i = 0; i < 4; i++) g1_encode<G>(ps.C[i], false, b); ps.t.label("committed_cols"); ps.t.append(b); }
       for (int i = 0; i < 7; i++) ps.al[i] = challenge(ps.t, "constraints_aggregation");
-    }
-    // ---- round 2 (device): constraint aggregation on the 4N domain, iNTT(4N); host: * Z_zk / (X^N - 1)
-    uint32_t *d_agg = dev_scratch(su, 1, n * M * 32);
+    });
+    // per-chunk parameter block on the device: RingConsts[n] | zeta[n] | nu[8n] | ev[7n] | lin_zw[n]
+    const size_t qlen = 3 * N + 1, olen = 3 * N;
+    const size_t rc_bytes = (n * sizeof(RingConsts) + 31) / 32 * 32;
+    uint32_t *d_par = dev_scratch(su, 3, rc_bytes + n * (1 + 8 + 7 + 1) * 32);
+    RingConsts *d_rc = (RingConsts *)d_par;
+    uint32_t *d_zeta = d_par + rc_bytes / 4, *d_nu = d_zeta + n * 8, *d_ev = d_nu + n * 64, *d_linzw = d_ev + n * 56;
+    // ---- round 2 (device): constraint aggregation on the 4N domain, iNTT(4N), * Z_zk / (X^N - 1), n quotient commits
+    uint32_t *d_agg = dev_scratch(su, 1, n * M * 32), *d_q = dev_scratch(su, 4, n * qlen * 32);
     {
       std::vector<RingConsts> rc(n);
       auto setfp = [](fp &d, const H256 &v) { memcpy(d.v, v.l, 32); };
@@ -539,79 +697,71 @@ template <class S, class G> struct Ring {
         for (int i = 0; i < 7; i++) setfp(rc[p].alpha[i], st[p].al[i]);
         setfp(rc[p].w_last, w_last); setfp(rc[p].seedx, st[p].seedx); setfp(rc[p].seedy, st[p].seedy); setfp(rc[p].resx, st[p].resx); setfp(rc[p].resy, st[p].resy);
       }
-      ensure_buf(su, n * sizeof(RingConsts));
-      HIP_CHECK(hipMemcpyAsync(su->d_buf, rc.data(), n * sizeof(RingConsts), hipMemcpyHostToDevice, su->stream));
+      HIP_CHECK(hipMemcpyAsync(d_rc, rc.data(), n * sizeof(RingConsts), hipMemcpyHostToDevice, su->stream));
       hipLaunchKernelGGL(k_ring_constraints<S>, dim3((M + 255) / 256, (unsigned)n), dim3(256), 0, su->stream, d_e4, k->d_fixed4, su->d_l4, su->d_tw_4n,
-                         (const RingConsts *)su->d_buf, (uint32_t)M, d_agg);
+                         (const RingConsts *)d_rc, (uint32_t)M, d_agg);
       fp sc; memcpy(sc.v, su->n4inv.l, 32);
       ntt_launch<F>(d_agg, (uint32_t)M, su->d_tw_4n_inv, (uint32_t)n, &sc, su->stream);
-    }
-    std::vector<H256> aggh(n * M);
-    HIP_CHECK(hipMemcpyAsync(aggh.data(), d_agg, n * M * 32, hipMemcpyDeviceToHost, su->stream));
-    HIP_CHECK(hipStreamSynchronize(su->stream));
-    lap("constraints + intt4n");
-    const size_t qlen = 3 * N + 1;
-    std::vector<H256> qall(n * qlen, zero);
-    H256 wz[3]; for (int j = 0; j < 3; j++) wz[j] = fr_pow<F>(su->w, N - 3 + j);
-    std::atomic<int> bad{0};
-    parallel_for(n, [&](size_t p) {
-      std::vector<H256> agg(M + 4, zero);
-      memcpy(agg.data(), &aggh[p * M], M * 32);
-      for (int j = 0; j < 3; j++) {                                    // * (X - w^(N-3+j))
-        for (size_t kx = M + 3; kx >= 1; kx--) agg[kx] = Fr::sub(agg[kx - 1], Fr::mul(wz[j], agg[kx]));
-        agg[0] = Fr::neg(Fr::mul(wz[j], agg[0]));
-      }
-      size_t deg = M + 3; while (deg > 0 && Fr::is_zero(agg[deg])) deg--;
-      if (deg < N || deg - N + 1 > qlen) { bad = 1; return; }
-      st[p].q.assign(deg + 1 - N, zero);
-      for (size_t kx = deg; kx >= N; kx--) { st[p].q[kx - N] = agg[kx]; agg[kx - N] = Fr::add(agg[kx - N], agg[kx]); }   // / (X^N - 1)
-      memcpy(&qall[p * qlen], st[p].q.data(), st[p].q.size() * 32);
-    });
-    if (bad) return AVRF_ERR_BAD_ARG;
-    lap("quotient polys (host)");
-    {
-      ensure_buf(su, n * qlen * 32);
-      HIP_CHECK(hipMemcpyAsync(su->d_buf, qall.data(), n * qlen * 32, hipMemcpyHostToDevice, su->stream));
-      std::vector<G1Aff> C; commit_device(su, su->d_buf, qlen, n, C);
+      Fp3 z;                                                           // Z(X) = prod_j (X - w^(N-3+j)) = X^3 + z2 X^2 + z1 X + z0
+      { H256 r0 = fr_pow<F>(su->w, N - 3), r1 = Fr::mul(r0, su->w), r2 = Fr::mul(r1, su->w);
+        H256 z2 = Fr::neg(Fr::add(Fr::add(r0, r1), r2)), z1 = Fr::add(Fr::add(Fr::mul(r0, r1), Fr::mul(r0, r2)), Fr::mul(r1, r2)), z0 = Fr::neg(Fr::mul(Fr::mul(r0, r1), r2));
+        setfp(z.v[0], z0); setfp(z.v[1], z1); setfp(z.v[2], z2); }
+      hipLaunchKernelGGL(k_ring_quotient<F>, dim3((unsigned)((qlen + 255) / 256), (unsigned)n), dim3(256), 0, su->stream, (const uint32_t *)d_agg, (uint32_t)N,
+                         (uint32_t)qlen, z, d_q);
+      lap("constraints + quotient (launch)");
+      std::vector<G1Aff> C; commit_device(su, d_q, qlen, qlen, n, C);
       for (size_t p = 0; p < n; p++) st[p].Cq = C[p];
     }
     lap("n quotient commits");
-    // ---- round 3 (host): evaluation point, evaluations, linearisation, opening polynomials
-    const size_t olen = 3 * N;                                         // length of the longer opening quotient
-    std::vector<H256> oall(n * 2 * olen, zero);
-    parallel_for(n, [&](size_t p) {
-      ProofState &ps = st[p];
-      { std::vector<uint8_t> b; g1_encode<G>(ps.Cq, false, b); ps.t.label("quotient"); ps.t.append(b); }
-      ps.zeta = challenge(ps.t, "evaluation_point");
-      const H256 *pb = &ps.coef[0], *pip = &ps.coef[N], *pax = &ps.coef[2 * N], *pay = &ps.coef[3 * N];
-      const H256 *polys[7] = {k->px_poly.data(), k->py_poly.data(), k->sel_poly.data(), pb, pip, pax, pay};
-      for (int c = 0; c < 7; c++) { H256 acc = zero; for (size_t i = N; i-- > 0;) acc = Fr::add(Fr::mul(acc, ps.zeta), polys[c][i]); ps.ev[c] = acc; }
-      { std::vector<uint8_t> b; for (int i = 0; i < 7; i++) push_le32(b, ps.ev[i]); ps.t.label("register_evaluations"); ps.t.append(b); }
-      const H256 x2 = ps.ev[0], y2 = ps.ev[1], b = ps.ev[3], x1 = ps.ev[5], y1 = ps.ev[6];
-      const H256 nlz = Fr::sub(ps.zeta, w_last), omb = Fr::sub(one, b);
-      const H256 k1 = Fr::add(Fr::mul(b, Fr::add(Fr::mul(y1, y2), Fr::mul(a_coef, Fr::mul(x1, x2)))), omb);
-      const H256 k2 = Fr::add(Fr::mul(b, Fr::sub(Fr::mul(x1, y2), Fr::mul(x2, y1))), omb);
-      ps.lin.resize(N);
-      { const H256 f0 = Fr::mul(nlz, ps.al[0]), f1 = Fr::mul(nlz, Fr::mul(ps.al[1], k1)), f2 = Fr::mul(nlz, Fr::mul(ps.al[2], k2));
-        for (size_t i = 0; i < N; i++) ps.lin[i] = Fr::add(Fr::add(Fr::mul(f0, pip[i]), Fr::mul(f1, pax[i])), Fr::mul(f2, pay[i])); }
-      const H256 zw = Fr::mul(ps.zeta, su->w);
-      ps.lin_zw = poly_eval(ps.lin, zw);
-      { std::vector<uint8_t> bb; push_le32(bb, ps.lin_zw); ps.t.label("shifted_linearization_evaluation"); ps.t.append(bb); }
-      for (int i = 0; i < 8; i++) ps.nu[i] = challenge(ps.t, "kzg_aggregation");
-      ps.aggz.assign(ps.q.size(), zero);
-      for (int c = 0; c < 7; c++) for (size_t i = 0; i < N; i++) ps.aggz[i] = Fr::add(ps.aggz[i], Fr::mul(ps.nu[c], polys[c][i]));
-      for (size_t i = 0; i < ps.q.size(); i++) ps.aggz[i] = Fr::add(ps.aggz[i], Fr::mul(ps.nu[7], ps.q[i]));
-      std::vector<H256> q1 = div_linear(ps.aggz, ps.zeta), q2 = div_linear(ps.lin, zw);
-      if (q1.size() > olen || q2.size() > olen) { bad = 1; return; }
-      memcpy(&oall[(2 * p) * olen], q1.data(), q1.size() * 32); memcpy(&oall[(2 * p + 1) * olen], q2.data(), q2.size() * 32);
-    });
-    if (bad) return AVRF_ERR_BAD_ARG;
-    lap("evals + openings (host)");
+    // ---- round 3: evaluation point (host transcript), evaluations + linearisation (device)
+    std::vector<H256> zs(n);
     {
-      ensure_buf(su, n * 2 * olen * 32);
-      HIP_CHECK(hipMemcpyAsync(su->d_buf, oall.data(), n * 2 * olen * 32, hipMemcpyHostToDevice, su->stream));
-      std::vector<G1Aff> C; commit_device(su, su->d_buf, olen, 2 * n, C);
-      for (size_t p = 0; p < n; p++) { st[p].pi[0] = C[2 * p]; st[p].pi[1] = C[2 * p + 1]; }
+      parallel_for(n, [&](size_t p) {
+        ProofState &ps = st[p];
+        std::vector<uint8_t> b; g1_encode<G>(ps.Cq, false, b); ps.t.label("quotient"); ps.t.append(b);
+        ps.zeta = challenge(ps.t, "evaluation_point"); zs[p] = ps.zeta;
+      });
+      HIP_CHECK(hipMemcpyAsync(d_zeta, zs.data(), n * 32, hipMemcpyHostToDevice, su->stream));
+    }
+    uint32_t *d_lin = dev_scratch(su, 5, n * N * 32);
+    fp w_dev; memcpy(w_dev.v, su->w.l, 32);
+    hipLaunchKernelGGL(k_ring_evals<F>, dim3(7, (unsigned)n), dim3(256), 0, su->stream, (const uint32_t *)d_coef, (const uint32_t *)k->d_fixed_coef,
+                       (const uint32_t *)d_zeta, (uint32_t)N, d_ev);
+    hipLaunchKernelGGL(k_ring_lin<S>, dim3((unsigned)n), dim3(256), 0, su->stream, (const uint32_t *)d_coef, (const RingConsts *)d_rc, (const uint32_t *)d_zeta,
+                       (const uint32_t *)d_ev, w_dev, (uint32_t)N, d_lin, d_linzw);
+    {
+      std::vector<H256> evh(n * 8);                                    // ev[7n] | lin_zw[n] are contiguous on the device
+      HIP_CHECK(hipMemcpyAsync(evh.data(), d_ev, n * 8 * 32, hipMemcpyDeviceToHost, su->stream));
+      HIP_CHECK(hipStreamSynchronize(su->stream));
+      std::vector<H256> nus(n * 8);
+      parallel_for(n, [&](size_t p) {
+        ProofState &ps = st[p];
+        for (int i = 0; i < 7; i++) ps.ev[i] = evh[p * 7 + i];
+        ps.lin_zw = evh[n * 7 + p];
+        { std::vector<uint8_t> b; for (int i = 0; i < 7; i++) push_le32(b, ps.ev[i]); ps.t.label("register_evaluations"); ps.t.append(b); }
+        { std::vector<uint8_t> bb; push_le32(bb, ps.lin_zw); ps.t.label("shifted_linearization_evaluation"); ps.t.append(bb); }
+        for (int i = 0; i < 8; i++) { ps.nu[i] = challenge(ps.t, "kzg_aggregation"); nus[p * 8 + i] = ps.nu[i]; }
+      });
+      HIP_CHECK(hipMemcpyAsync(d_nu, nus.data(), n * 8 * 32, hipMemcpyHostToDevice, su->stream));
+      HIP_CHECK(hipStreamSynchronize(su->stream));                     // nus goes out of scope
+    }
+    lap("evals + linearisation");
+    // ---- round 4 (device): aggregated opening at zeta, opening of lin at zeta*w, 2n opening commits
+    {
+      uint32_t *d_aggz = d_agg;                                        // the 4N aggregate is dead: reuse (qlen <= 4N)
+      uint32_t *d_open = dev_scratch(su, 0, n * 4 * M * 32);           // = d_e4 (dead): q1 (n x olen) | q2 (n x N)
+      uint32_t *d_q1 = d_open, *d_q2 = d_open + n * olen * 8;
+      hipLaunchKernelGGL(k_ring_aggz<F>, dim3((unsigned)((qlen + 255) / 256), (unsigned)n), dim3(256), 0, su->stream, (const uint32_t *)d_coef,
+                         (const uint32_t *)k->d_fixed_coef, (const uint32_t *)d_q, (const uint32_t *)d_nu, (uint32_t)N, (uint32_t)qlen, d_aggz);
+      fp one_m; memcpy(one_m.v, one.l, 32);
+      hipLaunchKernelGGL(k_ring_divlin<F>, dim3((unsigned)n), dim3(256), 0, su->stream, (const uint32_t *)d_aggz, (uint32_t)qlen, (uint32_t)qlen,
+                         (const uint32_t *)d_zeta, one_m, d_q1, (uint32_t)olen);
+      hipLaunchKernelGGL(k_ring_divlin<F>, dim3((unsigned)n), dim3(256), 0, su->stream, (const uint32_t *)d_lin, (uint32_t)N, (uint32_t)N,
+                         (const uint32_t *)d_zeta, w_dev, d_q2, (uint32_t)N);
+      std::vector<G1Aff> C1, C2;
+      commit_device(su, d_q1, olen, olen, n, C1);
+      commit_device(su, d_q2, N, N - 1, n, C2);
+      for (size_t p = 0; p < n; p++) { st[p].pi[0] = C1[p]; st[p].pi[1] = C2[p]; }
     }
     lap("2n opening commits");
     for (size_t p = 0; p < n; p++) {
@@ -794,7 +944,8 @@ int avrf_ring_setup_load(avrf_ctx *ctx, const uint8_t *srs, size_t srs_len, size
 void avrf_ring_setup_free(avrf_ring_setup *su) {
   if (!su) return;
   (void)hipSetDevice(su->device);
-  void *d[] = {su->d_srs, su->d_tw_n, su->d_tw_n_inv, su->d_tw_4n, su->d_tw_4n_inv, su->d_buf, su->d_l4, su->d_e4, su->d_agg, su->d_coef, su->d_srs_table};
+  void *d[] = {su->d_srs, su->d_tw_n, su->d_tw_n_inv, su->d_tw_4n, su->d_tw_4n_inv, su->d_buf, su->d_l4, su->d_srs_table,
+               su->d_scr[0], su->d_scr[1], su->d_scr[2], su->d_scr[3], su->d_scr[4], su->d_scr[5]};
   for (void *p : d) if (p) (void)hipFree(p);
   su->ws.release();
   delete su;
@@ -816,7 +967,7 @@ int avrf_ring_index(avrf_ring_setup *su, const uint8_t *pks_xy, size_t n_keys, a
   }
   return st;
 }
-void avrf_ring_key_free(avrf_ring_key *k) { if (!k) return; if (k->d_fixed4) (void)hipFree(k->d_fixed4); delete k; }
+void avrf_ring_key_free(avrf_ring_key *k) { if (!k) return; if (k->d_fixed4) (void)hipFree(k->d_fixed4); if (k->d_fixed_coef) (void)hipFree(k->d_fixed_coef); delete k; }
 
 int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const uint8_t *blindings, int blinding_mode, uint8_t *proofs_out) {
   if (!k || (n && (!key_index || !blindings || !proofs_out))) return AVRF_ERR_BAD_ARG;
