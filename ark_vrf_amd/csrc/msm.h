@@ -59,9 +59,11 @@ int msm_g1_device(int curve, const uint32_t *d_bases, const uint32_t *d_scalars,
 // Fixed-base form for MSMs over one shared base set (the KZG SRS): build_g1_table fills
 // table[w * n + i] = 2^(c w) * P_i (nwin = ceil((Fr bits + 1) / c) rows); msm_g1_fixed_device then treats all
 // windows of a scalar vector as ONE bucket set (n may be smaller than the table's row length `table_stride`).
+// d_base_idx != nullptr: sparse form -- entry i of vector b multiplies table base d_base_idx[b * n + i] instead of base i.
 void build_g1_table(int curve, const uint32_t *d_bases, size_t n, int c, int nwin, uint32_t *d_table, hipStream_t stream);
 int msm_g1_fixed_device(int curve, const uint32_t *d_table, int table_c, size_t table_stride, const uint32_t *d_scalars, size_t n,
-                        size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch);
+                        size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch,
+                        const uint32_t *d_base_idx = nullptr);
 void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, uint32_t *d_flag, hipStream_t stream);
 
 // canonical affine bytes (x||y LE32) -> te_pre (device); flags[i] |= 1 if a coordinate >= q, |= 2 if off-curve (when check_curve)

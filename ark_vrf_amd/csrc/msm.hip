@@ -152,10 +152,12 @@ k_scan_win(uint32_t *__restrict__ H, uint32_t n, uint32_t ntiles, int c, uint32_
   if (t == 1023) lane_tot[w] = partl[1023];
 }
 
-// remap_n != 0 (fixed-base tables): key position p = w * remap_n + i refers to table entry w * remap_stride + i
+// remap_n != 0 (fixed-base tables): key position p = dw * remap_n + i refers to table entry dw * remap_stride + i
+// (or dw * remap_stride + bidx[v][i] when the vector names its own bases)
 __global__ void __launch_bounds__(256)
 k_scatter(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int c, const uint32_t *__restrict__ H,
-          const uint32_t *__restrict__ offs, uint32_t *__restrict__ sorted, uint32_t remap_n, uint32_t remap_stride) {
+          const uint32_t *__restrict__ offs, uint32_t *__restrict__ sorted, uint32_t remap_n, uint32_t remap_stride,
+          const uint32_t *__restrict__ bidx) {
   extern __shared__ uint32_t lds[];
   const uint32_t nb = 1u << (c - 1), tile = blockIdx.x, w = blockIdx.y, ntiles = gridDim.x;
   const uint32_t *Hin = H + ((size_t)w * ntiles + tile) * nb;
@@ -167,7 +169,11 @@ k_scatter(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int 
     uint32_t key = kw[i], b = key & 0x7fffu;
     if (b) {
       uint32_t pos = atomicAdd(&lds[b - 1], 1u);
-      uint32_t idx = remap_n ? (i / remap_n) * remap_stride + (i % remap_n) : i;
+      uint32_t idx = i;
+      if (remap_n) {                                      // bidx: per-vector base indices (sparse MSMs over a shared table)
+        uint32_t j = i % remap_n;
+        idx = (i / remap_n) * remap_stride + (bidx ? bidx[(size_t)w * remap_n + j] : j);
+      }
       sorted[pos] = idx | ((key & 0x8000u) << 16);
     }
   }
@@ -476,7 +482,7 @@ void MsmWorkspace::release() {
 // windows of a vector share ONE bucket set: downstream it is a 1-window MSM over n * nwin (table) bases.
 template <class CV>
 static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n_in, int scalar_bits, MsmWorkspace &ws, hipStream_t stream,
-                      size_t batch = 1, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0) {
+                      size_t batch = 1, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0, const uint32_t *d_base_idx = nullptr) {
   MsmPlan p = msm_plan(n_in, scalar_bits);
   if (!scalar_stride) scalar_stride = n_in;                            // vector b's scalars start at b * scalar_stride
   size_t n = n_in;
@@ -488,6 +494,7 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
     if (!getenv("AVRF_MSM_SEG")) {                                      // ~entries per bucket, 16..64 per lane
       size_t avg = n_in * (size_t)dig_nwin / p.nb;
       p.lpb = avg >= 64 ? 64 : avg >= 32 ? 32 : 16;
+      while (p.lpb > 16 && batch * n_in * (size_t)dig_nwin / p.lpb < 200000) p.lpb >>= 1;   // few vectors: favour lanes over segment length
     }
     n = n_in * (size_t)dig_nwin;                                        // one window of n_in * dig_nwin keys per vector
     ws.ensure(n, p, (size_t)CV::ACC_WORDS * 4, batch);
@@ -507,7 +514,7 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   hipLaunchKernelGGL(k_scan_win, dim3(vwin), dim3(1024), 0, stream, ws.hist, (uint32_t)n, ntiles, p.c, seg,
                      ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot);
   hipLaunchKernelGGL(k_scatter, dim3(ntiles, vwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist, ws.offsets, ws.sorted,
-                     remap_n, remap_stride);
+                     remap_n, remap_stride, d_base_idx);
   dim3 ga((unsigned)(((size_t)vwin * lcap + 255) / 256));
   if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
   HIP_CHECK(hipEventRecord(ws.ev0, stream));
@@ -519,7 +526,7 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   const int h = (p.c - 1) / 2;
   const uint32_t tasks = (1u << h) + ((uint32_t)p.nb >> h);
   const int nbits = (int)vwin * p.c;
-  if constexpr (CV::FIXED_TABLE) if (table_c && batch >= 8) {   // one bucket set per MSM: weighted sum in one kernel, no bit sums
+  if constexpr (CV::FIXED_TABLE) if (table_c) {   // one bucket set per MSM: weighted sum in one kernel, no bit sums
     hipLaunchKernelGGL(k_wsum<CV>, dim3((unsigned)batch), b256, 0, stream, (const uint32_t *)ws.buckets, (uint32_t)p.nb, ws.rc);
     HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.rc, batch * acc_bytes, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -616,14 +623,14 @@ void build_g1_table(int curve, const uint32_t *d_bases, size_t n, int c, int nwi
 
 template <class C>
 static int msm_g1_impl(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy,
-                       size_t batch, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0) {
+                       size_t batch, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0, const uint32_t *d_base_idx = nullptr) {
   using HG = HostG1<C>;
   constexpr size_t OUT = 8 * C::Fq::N;                    // bytes of one affine result
-  int nbits = n ? msm_device<G1Curve<C>>(d_bases, d_scalars, n, C::Fr::BITS, ws, stream, batch, table_c, table_stride, scalar_stride) : 0;
+  int nbits = n ? msm_device<G1Curve<C>>(d_bases, d_scalars, n, C::Fr::BITS, ws, stream, batch, table_c, table_stride, scalar_stride, d_base_idx) : 0;
   std::vector<typename HG::Pt> res(batch);
   for (size_t b = 0; b < batch; b++) {
     typename HG::Pt acc = HG::identity();
-    if (batch >= 8) acc = HG::from_raw32(ws.bits_host + b * 4 * C::Fq::N);      // Horner already done on the device
+    if (batch >= 8 || table_c) acc = HG::from_raw32(ws.bits_host + b * 4 * C::Fq::N);      // Horner already done on the device
     else if (n) {
       const uint32_t *bh = ws.bits_host + b * (size_t)nbits * 4 * C::Fq::N;
       for (int i = nbits - 1; i >= 0; i--) {
@@ -652,9 +659,9 @@ int msm_g1_device(int curve, const uint32_t *d_bases, const uint32_t *d_scalars,
   return -1;
 }
 int msm_g1_fixed_device(int curve, const uint32_t *d_table, int table_c, size_t table_stride, const uint32_t *d_scalars, size_t n,
-                        size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch) {
-  if (curve == 0) return msm_g1_impl<G1Bls12381>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride, scalar_stride);
-  if (curve == 1) return msm_g1_impl<G1Bn254>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride, scalar_stride);
+                        size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch, const uint32_t *d_base_idx) {
+  if (curve == 0) return msm_g1_impl<G1Bls12381>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride, scalar_stride, d_base_idx);
+  if (curve == 1) return msm_g1_impl<G1Bn254>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride, scalar_stride, d_base_idx);
   return -1;
 }
 

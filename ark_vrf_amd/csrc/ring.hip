@@ -250,6 +250,36 @@ k_ring_divlin(const uint32_t *__restrict__ in, uint32_t in_stride, uint32_t len,
   }
 }
 
+// Witness columns from their sparse description (A.7 step 1): pos = sorted rows with bit 1 (<= 256 per proof,
+// padded), vals = the cnt+1 successive accumulator points (x | y), kidx = the signer's row.
+// cols[proof] = bits | ip | ax | ay (4 x N evaluations).
+template <class F>
+__global__ void __launch_bounds__(256)
+k_ring_witness_cols(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ kidx,
+                    const uint32_t *__restrict__ vals, uint32_t N, uint32_t cap, uint32_t *__restrict__ cols) {
+  __shared__ uint32_t sp[256];
+  const uint32_t p = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  sp[threadIdx.x] = pos[(size_t)p * 256 + threadIdx.x];
+  __syncthreads();
+  if (i >= N) return;
+  const uint32_t m = cnt[p], ki = kidx[p];
+  uint32_t lo = 0, hi = m;                               // r = number of pos < i
+  while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (sp[mid] < i) lo = mid + 1; else hi = mid; }
+  const bool bit = lo < m && sp[lo] == i;
+  const fp one = fp_one<F>(), zero = fp_zero();
+  uint32_t *c = cols + (size_t)p * 4 * N * 8;
+  store_fp(c + (size_t)i * 8, bit ? one : zero);
+  store_fp(c + ((size_t)N + i) * 8, (i > ki && i < cap) ? one : zero);
+  const uint32_t *v = vals + ((size_t)p * 257 + lo) * 16;
+  store_fp(c + ((size_t)2 * N + i) * 8, i < cap ? load_fp(v) : zero);
+  store_fp(c + ((size_t)3 * N + i) * 8, i < cap ? load_fp(v + 8) : zero);
+}
+template <class F>
+__global__ void k_set_diag(uint32_t *__restrict__ mat, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) store_fp(mat + ((size_t)i * n + i) * 8, fp_one<F>());
+}
+
 // Montgomery -> plain copy (MSM scalars), out of place
 template <class F>
 __global__ void k_mont_to_plain(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t total) {
@@ -374,6 +404,7 @@ struct avrf_ring_setup {
   size_t N, cap, keyset, L, n_srs;
   uint32_t *d_srs = nullptr;                          // n_srs Montgomery affine points
   uint32_t *d_srs_table = nullptr; int table_c = 0, table_nwin = 0;   // fixed-base window table over the SRS (batched commits)
+  uint32_t *d_wit_table = nullptr;                    // same over [L_i(tau) G, i < N | prefix sums PS_k = sum_{i<k} L_i(tau) G, k <= N] (witness commits)
   G1Aff g1_0;                                         // powers_in_g1[0]
   std::vector<uint8_t> g2_raw;                        // powers_in_g2[0..2] exactly as in the SRS file
   H256 w, w4;                                         // domain generators (Montgomery)
@@ -504,8 +535,8 @@ template <class S, class G> struct Ring {
     if (flag) { HIP_CHECK(hipFree(su->d_srs)); delete su; return AVRF_INVALID_DATA; }
     {  // fixed-base window table: T[w][i] = 2^(c w) * tau^i G, all windows of a commit then share one bucket set
       su->table_c = 10;
-      if (const char *e = getenv("AVRF_RING_TABLE_C")) { int v = atoi(e); if (v >= 4 && v <= 14) su->table_c = v; else if (v == 0) su->table_c = 0; }
-      if (su->table_c) {
+      if (const char *e = getenv("AVRF_RING_TABLE_C")) { int v = atoi(e); if (v >= 4 && v <= 14) su->table_c = v; }
+      {
         su->table_nwin = (G::Fr::BITS + 1 + su->table_c - 1) / su->table_c;
         HIP_CHECK(hipMalloc(&su->d_srs_table, (size_t)su->table_nwin * pcs * e1));
         build_g1_table(su->suite, su->d_srs, pcs, su->table_c, su->table_nwin, su->d_srs_table, su->stream);
@@ -605,11 +636,51 @@ template <class S, class G> struct Ring {
     std::vector<uint8_t> xy(batch * 2 * FQB);
     static const bool trace = getenv("AVRF_RING_TRACE") != nullptr;
     struct timespec t0; if (trace) { HIP_CHECK(hipStreamSynchronize(su->stream)); clock_gettime(CLOCK_MONOTONIC, &t0); }
-    if (su->table_c && batch >= 8) msm_g1_fixed_device(su->suite, su->d_srs_table, su->table_c, su->n_srs, su->d_buf, n, stride, su->ws, su->stream, xy.data(), batch);
-    else msm_g1_device(su->suite, su->d_srs, su->d_buf, n, su->ws, su->stream, xy.data(), batch, stride);
+    msm_g1_fixed_device(su->suite, su->d_srs_table, su->table_c, su->n_srs, su->d_buf, n, stride, su->ws, su->stream, xy.data(), batch);
     if (trace) { struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
       fprintf(stderr, "    commit n=%zu batch=%zu: %.3f ms wall, accumulate %.3f ms (c=%d seg=%d)\n", n, batch,
               (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, su->ws.accum_ms_last, su->ws.last_plan.c, su->ws.last_plan.lpb); }
+    out.resize(batch);
+    for (size_t b = 0; b < batch; b++) {
+      memset(&out[b], 0, sizeof(G1Aff)); memcpy(out[b].xy, &xy[b * 2 * FQB], 2 * FQB);
+      out[b].inf = true; for (int i = 0; i < 2 * FQB; i++) if (out[b].xy[i]) out[b].inf = false;
+    }
+  }
+  // Lagrange-basis SRS for the witness columns, built on first use: L_i(tau) G = commit(iNTT(e_i)) (N commits in one
+  // batched MSM), then the prefix sums PS_k on the host and a window table over [L_0 .. L_{N-1} | PS_0 .. PS_N].
+  static void ensure_lagrange(avrf_ring_setup *su) {
+    if (su->d_wit_table) return;
+    const size_t N = su->N, nb = 2 * N + 1;
+    uint32_t *d_mat = dev_scratch(su, 0, N * N * 32);
+    HIP_CHECK(hipMemsetAsync(d_mat, 0, N * N * 32, su->stream));
+    hipLaunchKernelGGL(k_set_diag<F>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, su->stream, d_mat, (uint32_t)N);
+    { fp sc; memcpy(sc.v, su->ninv.l, 32); ntt_launch<F>(d_mat, (uint32_t)N, su->d_tw_n_inv, (uint32_t)N, &sc, su->stream); }
+    std::vector<G1Aff> lag; commit_device(su, d_mat, N, N, N, lag);
+    using HG = typename T::HG; using FqN = typename T::FqN;
+    std::vector<typename HG::Pt> ps(N + 1);
+    ps[0] = HG::identity();
+    for (size_t i = 0; i < N; i++) {
+      typename HG::Pt q = HG::identity();
+      if (!lag[i].inf) { typename FqN::El x, y; memcpy(x.l, lag[i].xy, FQB); memcpy(y.l, lag[i].xy + FQB, FQB);
+        q.x = FqN::to_mont(x); q.y = FqN::to_mont(y); q.zz = FqN::one(); q.zzz = FqN::one(); }
+      ps[i + 1] = HG::add(ps[i], q);
+    }
+    std::vector<uint8_t> le(nb * 2 * FQB);
+    for (size_t i = 0; i < N; i++) memcpy(&le[i * 2 * FQB], lag[i].xy, 2 * FQB);
+    HG::to_affine_bytes_batch(ps.data(), N + 1, &le[N * 2 * FQB]);
+    uint8_t *d_le; uint32_t *d_flag, *d_bases;
+    HIP_CHECK(hipMalloc(&d_le, le.size())); HIP_CHECK(hipMalloc(&d_flag, 4)); HIP_CHECK(hipMalloc(&d_bases, nb * 2 * FQB));
+    HIP_CHECK(hipMemcpy(d_le, le.data(), le.size(), hipMemcpyHostToDevice)); HIP_CHECK(hipMemset(d_flag, 0, 4));
+    launch_g1_bases(su->suite, d_le, nb, d_bases, d_flag, su->stream);
+    HIP_CHECK(hipMalloc(&su->d_wit_table, (size_t)su->table_nwin * nb * 2 * FQB));
+    build_g1_table(su->suite, d_bases, nb, su->table_c, su->table_nwin, su->d_wit_table, su->stream);
+    HIP_CHECK(hipStreamSynchronize(su->stream));
+    HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag)); HIP_CHECK(hipFree(d_bases));
+  }
+  // `batch` sparse commits over the witness table: vector b = m (base index, plain scalar) pairs
+  static void commit_sparse(avrf_ring_setup *su, const uint32_t *d_scalars_plain, const uint32_t *d_base_idx, size_t m, size_t batch, std::vector<G1Aff> &out) {
+    std::vector<uint8_t> xy(batch * 2 * FQB);
+    msm_g1_fixed_device(su->suite, su->d_wit_table, su->table_c, 2 * su->N + 1, d_scalars_plain, m, m, su->ws, su->stream, xy.data(), batch, d_base_idx);
     out.resize(batch);
     for (size_t b = 0; b < batch; b++) {
       memset(&out[b], 0, sizeof(G1Aff)); memcpy(out[b].xy, &xy[b * 2 * FQB], 2 * FQB);
@@ -630,49 +701,72 @@ template <class S, class G> struct Ring {
     std::vector<ProofState> st(n);
     const H256 w_last = fr_pow<F>(su->w, cap - 1);
     const H256 a_coef = S::A_KIND == 1 ? Fr::neg(fr_small<F>(5)) : one;
-    // ---- round 0 (host): witness columns (A.7 step 1)
-    std::vector<H256> cols(n * 4 * N, zero);                           // per proof: bits | ip | ax | ay evaluations
+    // ---- round 0 (host): the witness in sparse form (A.7 step 1).  Rows with bit 1: the signer's key and the set bits
+    // of the blinding; the accumulator column only changes there, so it is cnt+1 points; the four KZG commits are
+    // sparse MSMs over the Lagrange-basis SRS and its prefix sums (same group elements as the coefficient-form commits).
+    ensure_lagrange(su);
+    constexpr size_t MP = 256;                                         // padded entries per sparse vector (L + 2 <= 256)
+    std::vector<uint32_t> pos(n * MP, 0xffffffffu), cnt(n), bidx(n * 4 * MP, 0);
+    std::vector<H256> vals(n * 257 * 2, zero), spsc(n * 4 * MP, zero);
+    const H256 minus1 = Fr::from_mont(Fr::neg(one)), one_plain = {{1, 0, 0, 0}};
     parallel_for(n, [&](size_t p) {
       ProofState &ps = st[p];
-      H256 *c = &cols[p * 4 * N];
       const uint8_t *bl = blindings + 32 * p;
-      std::vector<uint8_t> bits(cap - 1, 0);
-      bits[key_index[p]] = 1;
-      for (size_t i = 0; i < su->L; i++) bits[su->keyset + i] = (bl[i >> 3] >> (i & 7)) & 1;
-      H256 ipv = zero;
-      for (size_t i = 0; i < cap - 1; i++) {
-        if (bits[i]) c[i] = one;
-        if (bits[i] && i < su->keyset) ipv = Fr::add(ipv, one);
-        c[N + i + 1] = ipv;
-      }
+      uint32_t *ppos = &pos[p * MP]; size_t m = 0;
+      ppos[m++] = key_index[p];
+      for (size_t i = 0; i < su->L; i++) if ((bl[i >> 3] >> (i & 7)) & 1) ppos[m++] = (uint32_t)(su->keyset + i);
+      cnt[p] = (uint32_t)m;
       HostExt acc; acc.x = Fr::from32(S::ACC_X); acc.y = Fr::from32(S::ACC_Y); acc.t = Fr::mul(acc.x, acc.y); acc.z = one;
       ps.seedx = acc.x; ps.seedy = acc.y;
-      std::vector<HostExt> accs(cap);
+      std::vector<HostExt> accs(m + 1);
       accs[0] = acc;
-      for (size_t i = 0; i < cap - 1; i++) {
-        if (bits[i]) { HostExt q; q.x = k->points[i].first; q.y = k->points[i].second; q.t = Fr::mul(q.x, q.y); q.z = one; acc = Te::add(acc, q); }
-        accs[i + 1] = acc;
+      for (size_t j = 0; j < m; j++) {
+        HostExt q; q.x = k->points[ppos[j]].first; q.y = k->points[ppos[j]].second; q.t = Fr::mul(q.x, q.y); q.z = one;
+        acc = Te::add(acc, q); accs[j + 1] = acc;
       }
-      std::vector<H256> pre(cap); H256 run = one;                      // batch normalisation (one inversion)
-      for (size_t i = 0; i < cap; i++) { pre[i] = run; run = Fr::mul(run, accs[i].z); }
+      std::vector<H256> pre(m + 1); H256 run = one;                    // batch normalisation (one inversion)
+      for (size_t i = 0; i <= m; i++) { pre[i] = run; run = Fr::mul(run, accs[i].z); }
       H256 inv = Fr::inv(run);
-      for (size_t i = cap; i-- > 0;) { H256 zi = Fr::mul(inv, pre[i]); inv = Fr::mul(inv, accs[i].z); c[2 * N + i] = Fr::mul(accs[i].x, zi); c[3 * N + i] = Fr::mul(accs[i].y, zi); }
-      ps.resx = c[2 * N + cap - 1]; ps.resy = c[3 * N + cap - 1];
+      H256 *v = &vals[p * 257 * 2];
+      for (size_t i = m + 1; i-- > 0;) { H256 zi = Fr::mul(inv, pre[i]); inv = Fr::mul(inv, accs[i].z); v[2 * i] = Fr::mul(accs[i].x, zi); v[2 * i + 1] = Fr::mul(accs[i].y, zi); }
+      ps.resx = v[2 * m]; ps.resy = v[2 * m + 1];
       HostExt r; r.x = ps.resx; r.y = ps.resy; r.t = Fr::mul(r.x, r.y); r.z = one;     // instance = result - seed
       HostExt ns; ns.x = Fr::neg(ps.seedx); ns.y = ps.seedy; ns.t = Fr::mul(ns.x, ns.y); ns.z = one;
       HostExt inst = Te::add(r, ns); H256 izi = Fr::inv(inst.z);
       ps.instx = Fr::mul(inst.x, izi); ps.insty = Fr::mul(inst.y, izi);
+      // sparse vectors: bits | ip | ax | ay
+      uint32_t *bi = &bidx[p * 4 * MP]; H256 *sc = &spsc[p * 4 * MP];
+      for (size_t j = 0; j < m; j++) { bi[j] = ppos[j]; sc[j] = one_plain; }
+      bi[MP] = (uint32_t)(N + cap); sc[MP] = one_plain; bi[MP + 1] = (uint32_t)(N + key_index[p] + 1); sc[MP + 1] = minus1;
+      for (size_t j = 0; j < m; j++) {
+        bi[2 * MP + j] = bi[3 * MP + j] = (uint32_t)(N + ppos[j] + 1);
+        sc[2 * MP + j] = Fr::from_mont(Fr::sub(v[2 * j], v[2 * j + 2])); sc[3 * MP + j] = Fr::from_mont(Fr::sub(v[2 * j + 1], v[2 * j + 3]));
+      }
+      bi[2 * MP + m] = bi[3 * MP + m] = (uint32_t)(N + cap);
+      sc[2 * MP + m] = Fr::from_mont(v[2 * m]); sc[3 * MP + m] = Fr::from_mont(v[2 * m + 1]);
     });
     lap("witness (host)");
-    // ---- round 1 (device): coefficients, their 4N evaluations, 4n commits in one MSM chain
+    // ---- round 1 (device): columns, coefficients, their 4N evaluations, 4n sparse commits in one MSM chain
     uint32_t *d_coef = dev_scratch(su, 2, n * 4 * N * 32), *d_e4 = dev_scratch(su, 0, n * 4 * M * 32);
-    HIP_CHECK(hipMemcpyAsync(d_coef, cols.data(), n * 4 * N * 32, hipMemcpyHostToDevice, su->stream));
-    { fp sc; memcpy(sc.v, su->ninv.l, 32); ntt_launch<F>(d_coef, (uint32_t)N, su->d_tw_n_inv, (uint32_t)(4 * n), &sc, su->stream); }
-    HIP_CHECK(hipMemsetAsync(d_e4, 0, n * 4 * M * 32, su->stream));
-    HIP_CHECK(hipMemcpy2DAsync(d_e4, M * 32, d_coef, N * 32, N * 32, 4 * n, hipMemcpyDeviceToDevice, su->stream));
-    ntt_launch<F>(d_e4, (uint32_t)M, su->d_tw_4n, (uint32_t)(4 * n), nullptr, su->stream);
-    { std::vector<G1Aff> C; commit_device(su, d_coef, N, N, 4 * n, C);
-      for (size_t p = 0; p < n; p++) for (int i = 0; i < 4; i++) st[p].C[i] = C[4 * p + i]; }
+    {
+      const size_t b_pos = n * MP * 4, b_cnt = n * 4, b_val = n * 257 * 64, b_sc = n * 4 * MP * 32, b_bi = n * 4 * MP * 4;
+      uint32_t *d_w = dev_scratch(su, 1, b_sc + b_val + b_pos + b_bi + 2 * b_cnt);
+      uint32_t *d_sc = d_w, *d_val = d_sc + b_sc / 4, *d_pos = d_val + b_val / 4, *d_bi = d_pos + b_pos / 4, *d_cnt = d_bi + b_bi / 4, *d_ki = d_cnt + n;
+      HIP_CHECK(hipMemcpyAsync(d_sc, spsc.data(), b_sc, hipMemcpyHostToDevice, su->stream));
+      HIP_CHECK(hipMemcpyAsync(d_val, vals.data(), b_val, hipMemcpyHostToDevice, su->stream));
+      HIP_CHECK(hipMemcpyAsync(d_pos, pos.data(), b_pos, hipMemcpyHostToDevice, su->stream));
+      HIP_CHECK(hipMemcpyAsync(d_bi, bidx.data(), b_bi, hipMemcpyHostToDevice, su->stream));
+      HIP_CHECK(hipMemcpyAsync(d_cnt, cnt.data(), b_cnt, hipMemcpyHostToDevice, su->stream));
+      HIP_CHECK(hipMemcpyAsync(d_ki, key_index, b_cnt, hipMemcpyHostToDevice, su->stream));
+      hipLaunchKernelGGL(k_ring_witness_cols<F>, dim3((unsigned)((N + 255) / 256), (unsigned)n), dim3(256), 0, su->stream, (const uint32_t *)d_pos,
+                         (const uint32_t *)d_cnt, (const uint32_t *)d_ki, (const uint32_t *)d_val, (uint32_t)N, (uint32_t)cap, d_coef);
+      { fp sc; memcpy(sc.v, su->ninv.l, 32); ntt_launch<F>(d_coef, (uint32_t)N, su->d_tw_n_inv, (uint32_t)(4 * n), &sc, su->stream); }
+      HIP_CHECK(hipMemsetAsync(d_e4, 0, n * 4 * M * 32, su->stream));
+      HIP_CHECK(hipMemcpy2DAsync(d_e4, M * 32, d_coef, N * 32, N * 32, 4 * n, hipMemcpyDeviceToDevice, su->stream));
+      ntt_launch<F>(d_e4, (uint32_t)M, su->d_tw_4n, (uint32_t)(4 * n), nullptr, su->stream);
+      std::vector<G1Aff> C; commit_sparse(su, d_sc, d_bi, MP, 4 * n, C);
+      for (size_t p = 0; p < n; p++) for (int i = 0; i < 4; i++) st[p].C[i] = C[4 * p + i];
+    }
     lap("intt + ntt4n + 4n commits");
     ArkTranscript t0; transcript_prelude(k, t0);                       // shared by every proof over this ring
     parallel_for(n, [&](size_t p) {
@@ -944,7 +1038,7 @@ int avrf_ring_setup_load(avrf_ctx *ctx, const uint8_t *srs, size_t srs_len, size
 void avrf_ring_setup_free(avrf_ring_setup *su) {
   if (!su) return;
   (void)hipSetDevice(su->device);
-  void *d[] = {su->d_srs, su->d_tw_n, su->d_tw_n_inv, su->d_tw_4n, su->d_tw_4n_inv, su->d_buf, su->d_l4, su->d_srs_table,
+  void *d[] = {su->d_srs, su->d_tw_n, su->d_tw_n_inv, su->d_tw_4n, su->d_tw_4n_inv, su->d_buf, su->d_l4, su->d_srs_table, su->d_wit_table,
                su->d_scr[0], su->d_scr[1], su->d_scr[2], su->d_scr[3], su->d_scr[4], su->d_scr[5]};
   for (void *p : d) if (p) (void)hipFree(p);
   su->ws.release();
