@@ -14,6 +14,7 @@ template <class S> struct TeCurve {
   using base_t = te_pre; using acc_t = te_ext;
   static constexpr int BASE_WORDS = 24, ACC_WORDS = 32;
   static constexpr bool PREFETCH = true;
+  static constexpr bool ZERO_IS_IDENTITY = false;     // (0, 1, 0, 1)
   static constexpr bool FIXED_TABLE = false;          // no fixed-base window-table mode (bases change per batch)
   static constexpr int MIN_WAVES = 3;                 // waves per SIMD asked of the register allocator in k_accumulate
   static AVRF_DI acc_t identity() { return te_identity<S>(); }
@@ -48,6 +49,7 @@ template <class C> struct G1Curve {
   static constexpr int BASE_WORDS = 2 * N, ACC_WORDS = 4 * N;
   static constexpr bool PREFETCH = (N <= 8);
   static constexpr int MIN_WAVES = 2;
+  static constexpr bool ZERO_IS_IDENTITY = true;      // zz = 0; all-zero memory reads as the identity
   static constexpr bool FIXED_TABLE = true;           // KZG SRS: msm_g1_fixed_device
 
   static AVRF_DI acc_t identity() { acc_t r; r.x = fn_one<Fq>(); r.y = fn_one<Fq>(); r.zz = fn_zero<N>(); r.zzz = fn_zero<N>(); return r; }

@@ -250,7 +250,7 @@ k_fixup(const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off
   uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= nslots) return;
   uint32_t cnt = cnts[slot], nl = (cnt + seg - 1) / seg;
-  if (nl == 0) { CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, CV::identity()); return; }
+  if (nl == 0) { if (!CV::ZERO_IS_IDENTITY) CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, CV::identity()); return; }
   uint32_t g0 = (slot / nb) * lcap + lane_off[slot];
   uint32_t wa = g0 >> 6, wb = (g0 + nl - 1) >> 6;
   if (wa == wb) return;                                  // complete inside one wave: already written
@@ -348,53 +348,42 @@ k_horner(const uint32_t *__restrict__ bits, uint32_t nbits, uint32_t batch, uint
   CV::store_acc(out + (size_t)b * CV::ACC_WORDS, acc);
 }
 
-template <class CV> AVRF_DI typename CV::acc_t wave_sum_nf(typename CV::acc_t acc) {
-#pragma unroll 1
-  for (int off = 32; off >= 1; off >>= 1) acc = cv_add<CV>(acc, CV::shfl_down(acc, off));
-  return acc;
-}
-
-// Fixed-base (table) batched MSMs have ONE bucket set per MSM: a workgroup per set computes sum_b b * B_b
-// directly.  Thread t owns the m = nb / 256 consecutive buckets above t*m (running sums: 2 adds per bucket);
-// then sum_t W_t + m * sum_t t * S_t by a wave suffix scan + reduction and a 4-term tail across waves.
+// Fixed-base (table) batched MSMs have ONE bucket set per MSM: out[set] = sum_b b * B_b.  A group of 2^lps_log lanes
+// (inside one wave) shares a set; lane g owns the m = nb >> lps_log consecutive buckets above g*m (running sums: 2 adds
+// per bucket); then sum_g W_g + m * sum_g g * S_g by a group suffix scan and a group reduction.
 template <class CV>
 __global__ void __launch_bounds__(256, CV::MIN_WAVES)
-k_wsum(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t *__restrict__ out) {
+k_wsum(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t nsets, uint32_t lps_log, uint32_t *__restrict__ out) {
   using acc_t = typename CV::acc_t;
-  __shared__ uint32_t lds[4 * 2 * CV::ACC_WORDS];
-  const uint32_t v = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const uint32_t m = (nb + 255) / 256;
-  const uint32_t *B = buckets + (size_t)v * nb * CV::ACC_WORDS;              // B[b-1]
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lps = 1u << lps_log, set = t >> lps_log, g = t & (lps - 1), m = nb >> lps_log;
+  const bool live = set < nsets;
   acc_t S = CV::identity(), W = CV::identity();
-  {
-    uint32_t lo = t * m + 1, hi = lo + m - 1; if (hi > nb) hi = nb;
-    for (uint32_t b = hi; b >= lo && b >= 1 && lo <= nb; b--) {               // S = sum B_b, W = sum (b - t*m) B_b
-      S = cv_add<CV>(S, CV::load_acc(B + (size_t)(b - 1) * CV::ACC_WORDS));
-      W = cv_add<CV>(W, S);
+  if (live) {
+    const uint32_t *B = buckets + (size_t)set * nb * CV::ACC_WORDS;          // B[b-1]
+    const uint32_t lo = g * m + 1;
+#pragma unroll 1
+    for (uint32_t b = lo + m - 1; b >= lo; b--) {                              // S = sum B_b, W = sum (b - g*m) B_b
+      S = CV::add(S, CV::load_acc(B + (size_t)(b - 1) * CV::ACC_WORDS));
+      W = CV::add(W, S);
     }
   }
-  // suffix sums of S over the wave: A_l = sum_{l' >= l} S_l'
-  acc_t A = S;
+  acc_t A = S;                                                                // suffix sums of S over the group
 #pragma unroll 1
-  for (int off = 1; off < 64; off <<= 1) {
+  for (uint32_t off = 1; off < lps; off <<= 1) {
     acc_t o = CV::shfl_down(A, off);
-    if (lane + off < 64) A = cv_add<CV>(A, o);
+    if (g + off < lps) A = cv_add<CV>(A, o);
   }
-  // wave: sum_l W_l + m * sum_l l * S_l = sum_l (W_l + m * [l >= 1] A_l);   Y = A_0 = sum_l S_l
-  acc_t Z = lane ? A : CV::identity();
+  acc_t Z = g ? A : CV::identity();                                           // sum_g g * S_g = sum_{g >= 1} A_g
+#pragma unroll 1
   for (uint32_t k = m; k > 1; k >>= 1) Z = cv_dbl<CV>(Z);
-  acc_t V = wave_sum_nf<CV>(cv_add<CV>(W, Z));
-  if (lane == 0) { CV::store_acc(lds + (2 * wv) * CV::ACC_WORDS, V); CV::store_acc(lds + (2 * wv + 1) * CV::ACC_WORDS, A); }
-  __syncthreads();
-  if (t == 0) {
-    acc_t Y3 = CV::load_acc(lds + 7 * CV::ACC_WORDS), Y2 = CV::load_acc(lds + 5 * CV::ACC_WORDS), Y1 = CV::load_acc(lds + 3 * CV::ACC_WORDS);
-    acc_t s2 = cv_add<CV>(Y2, Y3), s1 = cv_add<CV>(Y1, s2);
-    acc_t q = cv_add<CV>(cv_add<CV>(s1, s2), Y3);                                   // Y1 + 2 Y2 + 3 Y3
-    for (uint32_t k = 64 * m; k > 1; k >>= 1) q = cv_dbl<CV>(q);
-    acc_t r = cv_add<CV>(cv_add<CV>(CV::load_acc(lds), CV::load_acc(lds + 2 * CV::ACC_WORDS)),
-                      cv_add<CV>(CV::load_acc(lds + 4 * CV::ACC_WORDS), CV::load_acc(lds + 6 * CV::ACC_WORDS)));
-    CV::store_acc(out + (size_t)v * CV::ACC_WORDS, cv_add<CV>(r, q));
+  acc_t V = cv_add<CV>(W, Z);
+#pragma unroll 1
+  for (uint32_t off = lps >> 1; off >= 1; off >>= 1) {
+    acc_t o = CV::shfl_down(V, off);
+    if (g + off < lps) V = cv_add<CV>(V, o);
   }
+  if (live && g == 0) CV::store_acc(out + (size_t)set * CV::ACC_WORDS, V);
 }
 
 // ---------------------------------------------------------------- host engine
@@ -517,6 +506,7 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
                      remap_n, remap_stride, d_base_idx);
   dim3 ga((unsigned)(((size_t)vwin * lcap + 255) / 256));
   if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
+  if (CV::ZERO_IS_IDENTITY) HIP_CHECK(hipMemsetAsync(ws.buckets, 0, (size_t)nbk * acc_bytes, stream));   // empty buckets
   HIP_CHECK(hipEventRecord(ws.ev0, stream));
   hipLaunchKernelGGL(k_accumulate<CV>, ga, b256, 0, stream, d_bases, ws.sorted, ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot,
                      vwin, (uint32_t)p.nb, lcap, seg, ws.buckets, ws.part);
@@ -527,7 +517,11 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   const uint32_t tasks = (1u << h) + ((uint32_t)p.nb >> h);
   const int nbits = (int)vwin * p.c;
   if constexpr (CV::FIXED_TABLE) if (table_c) {   // one bucket set per MSM: weighted sum in one kernel, no bit sums
-    hipLaunchKernelGGL(k_wsum<CV>, dim3((unsigned)batch), b256, 0, stream, (const uint32_t *)ws.buckets, (uint32_t)p.nb, ws.rc);
+    uint32_t lps_log = 6;                                  // lanes per bucket set: enough waves to cover the chip, <= nb
+    while (lps_log > 2 && (batch << (lps_log - 1)) >= 2048 * 64) lps_log--;
+    while ((1u << lps_log) > (uint32_t)p.nb) lps_log--;
+    hipLaunchKernelGGL(k_wsum<CV>, dim3((unsigned)(((batch << lps_log) + 255) / 256)), b256, 0, stream, (const uint32_t *)ws.buckets, (uint32_t)p.nb,
+                       (uint32_t)batch, lps_log, ws.rc);
     HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.rc, batch * acc_bytes, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     HIP_CHECK(hipGetLastError());

@@ -404,6 +404,7 @@ struct avrf_ring_setup {
   size_t N, cap, keyset, L, n_srs;
   uint32_t *d_srs = nullptr;                          // n_srs Montgomery affine points
   uint32_t *d_srs_table = nullptr; int table_c = 0, table_nwin = 0;   // fixed-base window table over the SRS (batched commits)
+  int wit_c = 0, wit_nwin = 0;                        // window width of the witness table (sparse MSMs: few entries, small buckets)
   uint32_t *d_wit_table = nullptr;                    // same over [L_i(tau) G, i < N | prefix sums PS_k = sum_{i<k} L_i(tau) G, k <= N] (witness commits)
   G1Aff g1_0;                                         // powers_in_g1[0]
   std::vector<uint8_t> g2_raw;                        // powers_in_g2[0..2] exactly as in the SRS file
@@ -672,15 +673,18 @@ template <class S, class G> struct Ring {
     HIP_CHECK(hipMalloc(&d_le, le.size())); HIP_CHECK(hipMalloc(&d_flag, 4)); HIP_CHECK(hipMalloc(&d_bases, nb * 2 * FQB));
     HIP_CHECK(hipMemcpy(d_le, le.data(), le.size(), hipMemcpyHostToDevice)); HIP_CHECK(hipMemset(d_flag, 0, 4));
     launch_g1_bases(su->suite, d_le, nb, d_bases, d_flag, su->stream);
-    HIP_CHECK(hipMalloc(&su->d_wit_table, (size_t)su->table_nwin * nb * 2 * FQB));
-    build_g1_table(su->suite, d_bases, nb, su->table_c, su->table_nwin, su->d_wit_table, su->stream);
+    su->wit_c = 7;
+    if (const char *e = getenv("AVRF_RING_WIT_C")) { int v = atoi(e); if (v >= 4 && v <= 14) su->wit_c = v; }
+    su->wit_nwin = (G::Fr::BITS + 1 + su->wit_c - 1) / su->wit_c;
+    HIP_CHECK(hipMalloc(&su->d_wit_table, (size_t)su->wit_nwin * nb * 2 * FQB));
+    build_g1_table(su->suite, d_bases, nb, su->wit_c, su->wit_nwin, su->d_wit_table, su->stream);
     HIP_CHECK(hipStreamSynchronize(su->stream));
     HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag)); HIP_CHECK(hipFree(d_bases));
   }
   // `batch` sparse commits over the witness table: vector b = m (base index, plain scalar) pairs
   static void commit_sparse(avrf_ring_setup *su, const uint32_t *d_scalars_plain, const uint32_t *d_base_idx, size_t m, size_t batch, std::vector<G1Aff> &out) {
     std::vector<uint8_t> xy(batch * 2 * FQB);
-    msm_g1_fixed_device(su->suite, su->d_wit_table, su->table_c, 2 * su->N + 1, d_scalars_plain, m, m, su->ws, su->stream, xy.data(), batch, d_base_idx);
+    msm_g1_fixed_device(su->suite, su->d_wit_table, su->wit_c, 2 * su->N + 1, d_scalars_plain, m, m, su->ws, su->stream, xy.data(), batch, d_base_idx);
     out.resize(batch);
     for (size_t b = 0; b < batch; b++) {
       memset(&out[b], 0, sizeof(G1Aff)); memcpy(out[b].xy, &xy[b * 2 * FQB], 2 * FQB);
