@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "consts_gen.h"
+#include "mac96.h"
 
 namespace avrf {
 
@@ -86,29 +87,10 @@ template <class F> AVRF_DI fp fp_neg(const fp &a) {
 }
 template <class F> AVRF_DI fp fp_dbl(const fp &a) { return fp_add<F>(a, a); }
 
-// Montgomery product a*b/R mod p.  Carry-free CIOS (top bit of p clear).
+// Montgomery product a*b/R mod p (top bit of p clear), product scanning (mac96.h)
 template <class F> AVRF_DI fp fp_mul(const fp &a, const fp &b) {
-  uint32_t t[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) t[i] = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t A = (uint64_t)a.v[0] * b.v[i] + t[0];
-    uint32_t m = (uint32_t)A * F::NINV;
-    uint64_t C = (uint64_t)m * F::P[0] + (uint32_t)A;
-    A >>= 32; C >>= 32;
-#pragma unroll
-    for (int j = 1; j < 8; j++) {
-      A += (uint64_t)a.v[j] * b.v[i] + t[j];
-      C += (uint64_t)m * F::P[j] + (uint32_t)A;
-      t[j - 1] = (uint32_t)C;
-      A >>= 32; C >>= 32;
-    }
-    t[7] = (uint32_t)(A + C);
-  }
   fp r, u;
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = t[i];
+  mont_mul_ps<8, F>(r.v, a.v, b.v);
   uint32_t br = sub_p<F>(u, r);
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = br ? r.v[i] : u.v[i];

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "consts_gen.h"
+#include "mac96.h"
 
 namespace avrf {
 
@@ -69,7 +70,18 @@ template <class F> AVRF_DI fe<F> fn_neg(const fe<F> &a) {
 }
 template <class F> AVRF_DI fe<F> fn_dbl(const fe<F> &a) { return fn_add<F>(a, a); }
 
+// Montgomery product a*b/R mod p, product scanning (mac96.h)
 template <class F> AVRF_DI fe<F> fn_mul(const fe<F> &a, const fe<F> &b) {
+  constexpr int N = F::N;
+  fe<F> r, u;
+  mont_mul_ps<N, F>(r.v, a.v, b.v);
+  uint32_t br = fn_sub_p<F>(u, r);
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = br ? r.v[i] : u.v[i];
+  return r;
+}
+// the operand-scanning (carry-free CIOS) form, kept as the cross-check in tools/ubench.hip
+template <class F> AVRF_DI fe<F> fn_mul_cios(const fe<F> &a, const fe<F> &b) {
   constexpr int N = F::N;
   uint32_t t[N];
 #pragma unroll

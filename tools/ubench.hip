@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "../ark_vrf_amd/csrc/te.h"
+#include "../ark_vrf_amd/csrc/curves.h"
 
 using namespace avrf;
 
@@ -73,6 +74,31 @@ template <class S> __global__ void k_madd(uint32_t *out, int iters, uint32_t see
   out[blockIdx.x * blockDim.x + threadIdx.x] = r + seed;
 }
 
+// N-limb field (KZG G1 base fields): VARIANT 0 = fn_mul_cios (operand scanning), 1 = fn_mul (product scanning)
+template <class F, int VARIANT> __global__ void k_fnmul(uint32_t *out, int iters, uint32_t seed) {
+  constexpr int N = F::N;
+  fpn<N> a, b;
+  for (int i = 0; i < N; i++) { a.v[i] = seed * (i + 1) + threadIdx.x; b.v[i] = seed * (i + 7) + blockIdx.x; }
+  a.v[N - 1] &= 0x00ffffff; b.v[N - 1] &= 0x00ffffff;
+  for (int i = 0; i < iters; i++) {
+    if (VARIANT == 0) { a = fn_mul_cios<F>(a, b); b = fn_mul_cios<F>(b, a); }
+    else { a = fn_mul<F>(a, b); b = fn_mul<F>(b, a); }
+  }
+  uint32_t r = 0;
+  for (int i = 0; i < N; i++) r ^= a.v[i] ^ b.v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+template <class C> __global__ void __launch_bounds__(256, 2) k_g1madd(uint32_t *out, int iters, uint32_t seed) {
+  using CV = G1Curve<C>; constexpr int N = C::Fq::N;
+  typename CV::acc_t p = CV::identity();
+  typename CV::base_t q; q.x = fn_one<typename C::Fq>(); q.y = fn_one<typename C::Fq>();
+  q.x.v[0] ^= (threadIdx.x & 1); q.y.v[1] ^= seed;
+  for (int i = 0; i < iters; i++) { p = CV::madd(p, q, (i & 1) != 0); q.x.v[0] += 2; }
+  uint32_t r = 0;
+  for (int i = 0; i < N; i++) r ^= p.x.v[i] ^ p.y.v[i] ^ p.zz.v[i] ^ p.zzz.v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = r + seed;
+}
+
 template <class K> double time_kernel(K launch, int reps = 3) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   launch();  // warm-up
@@ -85,7 +111,23 @@ template <class K> double time_kernel(K launch, int reps = 3) {
   return best * 1e-3;
 }
 
+struct FqBandersnatch8 : FqBandersnatch { static constexpr int N = 8; };
+
 int main() {
+  {  // fn_mul_ps agrees with fn_mul
+    uint32_t *o0, *o1; CK(hipMalloc(&o0, 64 * 256 * 4)); CK(hipMalloc(&o1, 64 * 256 * 4));
+    hipLaunchKernelGGL((k_fnmul<FqBls12381, 0>), dim3(64), dim3(256), 0, 0, o0, 16, 99u);
+    hipLaunchKernelGGL((k_fnmul<FqBls12381, 1>), dim3(64), dim3(256), 0, 0, o1, 16, 99u);
+    static uint32_t h0[64 * 256], h1[64 * 256];
+    CK(hipMemcpy(h0, o0, sizeof h0, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1, o1, sizeof h1, hipMemcpyDeviceToHost));
+    int bad = 0; for (int i = 0; i < 64 * 256; i++) bad += h0[i] != h1[i];
+    printf("fn_mul vs fn_mul_cios (12 limbs): %d mismatches\n", bad);
+    hipLaunchKernelGGL((k_fnmul<FqBandersnatch8, 0>), dim3(64), dim3(256), 0, 0, o0, 16, 99u);
+    hipLaunchKernelGGL((k_fnmul<FqBandersnatch8, 1>), dim3(64), dim3(256), 0, 0, o1, 16, 99u);
+    CK(hipMemcpy(h0, o0, sizeof h0, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1, o1, sizeof h1, hipMemcpyDeviceToHost));
+    bad = 0; for (int i = 0; i < 64 * 256; i++) bad += h0[i] != h1[i];
+    printf("fn_mul vs fn_mul_cios (8 limbs): %d mismatches\n", bad);
+  }
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s, CUs %d, clock %d MHz\n", prop.name, prop.multiProcessorCount, prop.clockRate / 1000);
   uint32_t *out; CK(hipMalloc(&out, 256 * 32 * 256 * 4 * 4));
@@ -112,6 +154,18 @@ int main() {
     printf("  %-22s %8.2f Gmul/s\n", "fp_mul<FqBandersnatch>", (double)blocks * threads * fit * 2 / t * 1e-9);
     t = time_kernel([&] { hipLaunchKernelGGL(k_fmul<FqBabyJubJub>, dim3(blocks), dim3(threads), 0, 0, out, fit, 777u); });
     printf("  %-22s %8.2f Gmul/s\n", "fp_mul<FqBabyJubJub>", (double)blocks * threads * fit * 2 / t * 1e-9);
+    t = time_kernel([&] { hipLaunchKernelGGL((k_fnmul<FqBls12381, 0>), dim3(blocks), dim3(threads), 0, 0, out, fit, 777u); });
+    printf("  %-22s %8.2f Gmul/s\n", "fn_mul_cios<Bls12381>", (double)blocks * threads * fit * 2 / t * 1e-9);
+    t = time_kernel([&] { hipLaunchKernelGGL((k_fnmul<FqBls12381, 1>), dim3(blocks), dim3(threads), 0, 0, out, fit, 777u); });
+    printf("  %-22s %8.2f Gmul/s\n", "fn_mul<FqBls12381>", (double)blocks * threads * fit * 2 / t * 1e-9);
+    t = time_kernel([&] { hipLaunchKernelGGL((k_fnmul<FqBandersnatch8, 0>), dim3(blocks), dim3(threads), 0, 0, out, fit, 777u); });
+    printf("  %-22s %8.2f Gmul/s\n", "fn_mul_cios<8 limbs>", (double)blocks * threads * fit * 2 / t * 1e-9);
+    t = time_kernel([&] { hipLaunchKernelGGL((k_fnmul<FqBandersnatch8, 1>), dim3(blocks), dim3(threads), 0, 0, out, fit, 777u); });
+    printf("  %-22s %8.2f Gmul/s\n", "fn_mul<8 limbs>", (double)blocks * threads * fit * 2 / t * 1e-9);
+    if (wpc <= 8) {
+      t = time_kernel([&] { hipLaunchKernelGGL(k_g1madd<G1Bls12381>, dim3(blocks), dim3(threads), 0, 0, out, 64, 777u); });
+      printf("  %-22s %8.3f Gadd/s\n", "g1_madd<Bls12381>", (double)blocks * threads * 64 / t * 1e-9);
+    }
     t = time_kernel([&] { hipLaunchKernelGGL(k_fadd<FqBandersnatch>, dim3(blocks), dim3(threads), 0, 0, out, fit * 4, 777u); });
     printf("  %-22s %8.2f Gop/s\n", "fp_add/sub", (double)blocks * threads * fit * 4 * 2 / t * 1e-9);
     t = time_kernel([&] { hipLaunchKernelGGL(k_madd<SuiteBandersnatch>, dim3(blocks), dim3(threads), 0, 0, out, 128, 777u); });
