@@ -29,6 +29,8 @@ struct MsmWorkspace {
   uint32_t *offsets = nullptr;   // nwin * nb     first entry of the bucket in sorted[]
   uint32_t *lane_off = nullptr;  // nwin * nb     first lane of the bucket (local to its window)
   uint32_t *lane_tot = nullptr;  // nwin          lanes used per window
+  uint32_t *lane_slot = nullptr; // nwin * lcap   bucket of every lane (lanes ordered by descending load)
+  size_t cap_lanes = 0;
   // accumulator arrays (layout of the curve policy: te_ext 128 B, G1 XYZZ 4 * Fq)
   uint32_t *buckets = nullptr;   // nwin * nb
   uint32_t *rc = nullptr;        // nwin * (rows + cols) partial sums of the bucket reduction

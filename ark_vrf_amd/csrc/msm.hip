@@ -117,39 +117,58 @@ k_hist(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int c, 
 }
 
 // One workgroup (1024 lanes) per window.  In place: H[w][tile][b] becomes the exclusive prefix over
-// tiles; offs/cnts/lane_off per slot (= w*nb + b-1): entry offset (global, w*n based), entry count,
-// lane offset (local to the window); lane_tot[w] = lanes used by the window.
+// tiles; offs/cnts per slot (= w*nb + b-1): entry offset (global, w*n based) and entry count.
+// Lane placement: bucket b gets nl_b = ceil(cnt_b / seg) lanes of per_b = ceil(cnt_b / nl_b) entries each.  Buckets are
+// placed in order of DESCENDING per_b (counting sort over per values in LDS), so the 64 lanes of a wave carry
+// near-equal loads and the heaviest waves start first; lane_off[slot] = first lane (local to the window),
+// lane_slot[w * lcap + lane] = bucket of that lane, lane_tot[w] = lanes used by the window.
 __global__ void __launch_bounds__(1024)
-k_scan_win(uint32_t *__restrict__ H, uint32_t n, uint32_t ntiles, int c, uint32_t seg,
+k_scan_win(uint32_t *__restrict__ H, uint32_t n, uint32_t ntiles, int c, uint32_t seg, uint32_t lcap,
            uint32_t *__restrict__ offs, uint32_t *__restrict__ cnts, uint32_t *__restrict__ lane_off,
-           uint32_t *__restrict__ lane_tot) {
-  __shared__ uint32_t part[1024], partl[1024];
+           uint32_t *__restrict__ lane_tot, uint32_t *__restrict__ lane_slot) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t bin[1026];                           // lanes per `per` value (0..seg), then bin cursors
   const uint32_t nb = 1u << (c - 1), w = blockIdx.x, t = threadIdx.x;
   uint32_t *Hw = H + (size_t)w * ntiles * nb;
-  const uint32_t per = (nb + 1023) / 1024;
-  uint32_t b0 = t * per, b1 = b0 + per; if (b1 > nb) b1 = nb; if (b0 > nb) b0 = nb;
-  uint32_t sum = 0, suml = 0;
+  const uint32_t bpt = (nb + 1023) / 1024;
+  uint32_t b0 = t * bpt, b1 = b0 + bpt; if (b1 > nb) b1 = nb; if (b0 > nb) b0 = nb;
+  for (uint32_t i = t; i < 1026; i += 1024) bin[i] = 0;
+  __syncthreads();
+  uint32_t sum = 0;
   for (uint32_t b = b0; b < b1; b++) {
     uint32_t run = 0;
     for (uint32_t k = 0; k < ntiles; k++) { uint32_t v = Hw[(size_t)k * nb + b]; Hw[(size_t)k * nb + b] = run; run += v; }
     cnts[(size_t)w * nb + b] = run;
-    sum += run; suml += (run + seg - 1) / seg;
+    sum += run;
+    if (run) { uint32_t nl = (run + seg - 1) / seg, per = (run + nl - 1) / nl; atomicAdd(&bin[per], nl); }
   }
-  part[t] = sum; partl[t] = suml;
+  part[t] = sum;
   __syncthreads();
   for (uint32_t off = 1; off < 1024; off <<= 1) {
-    uint32_t v = (t >= off) ? part[t - off] : 0, vl = (t >= off) ? partl[t - off] : 0;
+    uint32_t v = (t >= off) ? part[t - off] : 0;
     __syncthreads();
-    part[t] += v; partl[t] += vl;
+    part[t] += v;
     __syncthreads();
   }
-  uint32_t run = part[t] - sum + w * n, runl = partl[t] - suml;
+  if (t == 0) {                                            // bin start = lanes of all larger `per` values
+    uint32_t run = 0;
+    for (int p = (int)seg; p >= 1; p--) { uint32_t v = bin[p]; bin[p] = run; run += v; }
+    lane_tot[w] = run;
+  }
+  __syncthreads();
+  uint32_t run = part[t] - sum + w * n;
   for (uint32_t b = b0; b < b1; b++) {
     uint32_t cnt = cnts[(size_t)w * nb + b];
-    offs[(size_t)w * nb + b] = run; lane_off[(size_t)w * nb + b] = runl;
-    run += cnt; runl += (cnt + seg - 1) / seg;
+    offs[(size_t)w * nb + b] = run;
+    run += cnt;
+    uint32_t lo = 0;
+    if (cnt) {
+      uint32_t nl = (cnt + seg - 1) / seg, per = (cnt + nl - 1) / nl;
+      lo = atomicAdd(&bin[per], nl);
+      for (uint32_t r = 0; r < nl; r++) lane_slot[(size_t)w * lcap + lo + r] = b;
+    }
+    lane_off[(size_t)w * nb + b] = lo;
   }
-  if (t == 1023) lane_tot[w] = partl[1023];
 }
 
 // remap_n != 0 (fixed-base tables): key position p = dw * remap_n + i refers to table entry dw * remap_stride + i
@@ -181,16 +200,16 @@ k_scatter(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int 
 
 // ---------------------------------------------------------------- bucket accumulation (curve-generic)
 
-// Lane t = w * lcap + lt owns a segment of the bucket `slot` of window w with
-// lane_off[slot] <= lt < lane_off[slot] + lanes(slot).  part[2*wave + k]: partial of the run of wave
+// Lane t = w * lcap + lt owns a segment of the bucket `slot` = lane_slot[t] of window w, with
+// lane_off[slot] <= lt < lane_off[slot] + lanes(slot) (the lanes of a bucket are consecutive).  part[2*wave + k]: partial of the run of wave
 // `wave` that includes lane 0 (k = 0) or that starts later and runs past lane 63 (k = 1); complete
 // runs are written straight to buckets[].  lcap is a multiple of 64 (a wave never spans two windows).
 template <class CV>
 __global__ void __launch_bounds__(256, CV::MIN_WAVES)
 k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
              const uint32_t *__restrict__ offs, const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off,
-             const uint32_t *__restrict__ lane_tot, uint32_t nwin, uint32_t nb, uint32_t lcap, uint32_t seg,
-             uint32_t *__restrict__ buckets, uint32_t *__restrict__ part) {
+             const uint32_t *__restrict__ lane_tot, const uint32_t *__restrict__ lane_slot, uint32_t nwin, uint32_t nb, uint32_t lcap,
+             uint32_t seg, uint32_t *__restrict__ buckets, uint32_t *__restrict__ part) {
   using acc_t = typename CV::acc_t; using base_t = typename CV::base_t;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63, wave = t >> 6;
@@ -199,12 +218,9 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
   uint32_t slot = 0xffffffffu, l0 = 0, nl = 0;
   acc_t acc = CV::identity();
   if (live) {
-    const uint32_t *lo_w = lane_off + (size_t)w * nb;
-    uint32_t lo = 0, hi = nb;                           // last bucket with lane_off <= lt
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (lo_w[mid] <= lt) lo = mid; else hi = mid; }
-    slot = w * nb + lo;
+    slot = w * nb + lane_slot[t];
     const uint32_t e0 = offs[slot], cnt = cnts[slot];
-    l0 = lo_w[lo]; nl = (cnt + seg - 1) / seg;
+    l0 = lane_off[slot]; nl = (cnt + seg - 1) / seg;
     const uint32_t per = (cnt + nl - 1) / nl, r = lt - l0;
     uint32_t b = e0 + r * per, e = b + per; if (e > e0 + cnt) e = e0 + cnt;
     if (CV::PREFETCH) {
@@ -439,6 +455,11 @@ void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t b
     HIP_CHECK(hipMalloc(&rc, nbk * acc_bytes));               // >= nwin * (NR + NC)
     cap_buckets = nbk * acc_bytes;
   }
+  if (vwin * lcap_for(n, p) > cap_lanes) {
+    if (lane_slot) HIP_CHECK(hipFree(lane_slot));
+    cap_lanes = vwin * lcap_for(n, p);
+    HIP_CHECK(hipMalloc(&lane_slot, cap_lanes * 4));
+  }
   size_t need_part = 2 * (vwin * lcap_for(n, p) / 64 + 2) * acc_bytes;
   if (need_part > cap_part) {
     if (part) HIP_CHECK(hipFree(part));
@@ -454,11 +475,11 @@ void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t b
   }
 }
 void MsmWorkspace::release() {
-  void *dev[] = {keys, sorted, hist, cnts, offsets, lane_off, lane_tot, buckets, rc, part, bits};
+  void *dev[] = {keys, sorted, hist, cnts, offsets, lane_off, lane_tot, lane_slot, buckets, rc, part, bits};
   for (void *q : dev) if (q) (void)hipFree(q);
   if (bits_host) (void)hipHostFree(bits_host);
   if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr;
-  keys = nullptr; sorted = hist = cnts = offsets = lane_off = lane_tot = nullptr;
+  keys = nullptr; sorted = hist = cnts = offsets = lane_off = lane_tot = lane_slot = nullptr; cap_lanes = 0;
   buckets = rc = part = bits = bits_host = nullptr;
   cap_n = cap_slots = cap_buckets = cap_bits = cap_part = cap_hist = cap_vwin = 0;
 }
@@ -474,17 +495,18 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
                       size_t batch = 1, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0, const uint32_t *d_base_idx = nullptr) {
   MsmPlan p = msm_plan(n_in, scalar_bits);
   if (!scalar_stride) scalar_stride = n_in;                            // vector b's scalars start at b * scalar_stride
+  if (!getenv("AVRF_MSM_SEG")) {
+    // entries per lane: 32 once the launch has plenty of lanes, else 16.  (Measured on MI355X: longer segments save
+    // cross-lane reductions but lose more to exposed gather latency -- 64+ entries per lane ran 10-50 % slower.)
+    const size_t digs = table_c ? (size_t)((scalar_bits + 1 + table_c - 1) / table_c) : (size_t)p.nwin;
+    p.lpb = batch * n_in * digs / 32 >= 65536 ? 32 : 16;
+  }
   size_t n = n_in;
   uint32_t remap_n = 0, remap_stride = 0;
   dim3 b256(256);
   if (table_c) {
     const int dig_nwin = (scalar_bits + 1 + table_c - 1) / table_c;
     p.c = table_c; p.nb = 1 << (table_c - 1); p.nwin = 1;
-    if (!getenv("AVRF_MSM_SEG")) {                                      // ~entries per bucket, 16..64 per lane
-      size_t avg = n_in * (size_t)dig_nwin / p.nb;
-      p.lpb = avg >= 64 ? 64 : avg >= 32 ? 32 : 16;
-      while (p.lpb > 16 && batch * n_in * (size_t)dig_nwin / p.lpb < 200000) p.lpb >>= 1;   // few vectors: favour lanes over segment length
-    }
     n = n_in * (size_t)dig_nwin;                                        // one window of n_in * dig_nwin keys per vector
     ws.ensure(n, p, (size_t)CV::ACC_WORDS * 4, batch);
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((n_in + 255) / 256), (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n_in, (uint32_t)scalar_stride, p.c, dig_nwin, ws.keys);
@@ -500,15 +522,15 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   dim3 gn((unsigned)((n + 255) / 256));
   if (!table_c) hipLaunchKernelGGL(k_digits, dim3(gn.x, (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n, (uint32_t)scalar_stride, p.c, p.nwin, ws.keys);
   hipLaunchKernelGGL(k_hist, dim3(ntiles, vwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist);
-  hipLaunchKernelGGL(k_scan_win, dim3(vwin), dim3(1024), 0, stream, ws.hist, (uint32_t)n, ntiles, p.c, seg,
-                     ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot);
+  hipLaunchKernelGGL(k_scan_win, dim3(vwin), dim3(1024), 0, stream, ws.hist, (uint32_t)n, ntiles, p.c, seg, lcap,
+                     ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot, ws.lane_slot);
   hipLaunchKernelGGL(k_scatter, dim3(ntiles, vwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist, ws.offsets, ws.sorted,
                      remap_n, remap_stride, d_base_idx);
   dim3 ga((unsigned)(((size_t)vwin * lcap + 255) / 256));
   if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
   if (CV::ZERO_IS_IDENTITY) HIP_CHECK(hipMemsetAsync(ws.buckets, 0, (size_t)nbk * acc_bytes, stream));   // empty buckets
   HIP_CHECK(hipEventRecord(ws.ev0, stream));
-  hipLaunchKernelGGL(k_accumulate<CV>, ga, b256, 0, stream, d_bases, ws.sorted, ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot,
+  hipLaunchKernelGGL(k_accumulate<CV>, ga, b256, 0, stream, d_bases, ws.sorted, ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot, ws.lane_slot,
                      vwin, (uint32_t)p.nb, lcap, seg, ws.buckets, ws.part);
   HIP_CHECK(hipEventRecord(ws.ev1, stream));
   hipLaunchKernelGGL(k_fixup<CV>, dim3((nbk + 255) / 256), b256, 0, stream, ws.cnts, ws.lane_off, nbk, (uint32_t)p.nb, lcap, seg,
