@@ -535,7 +535,7 @@ template <class S, class G> struct Ring {
     HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag));
     if (flag) { HIP_CHECK(hipFree(su->d_srs)); delete su; return AVRF_INVALID_DATA; }
     {  // fixed-base window table: T[w][i] = 2^(c w) * tau^i G, all windows of a commit then share one bucket set
-      su->table_c = 10;
+      su->table_c = 12;
       if (const char *e = getenv("AVRF_RING_TABLE_C")) { int v = atoi(e); if (v >= 4 && v <= 14) su->table_c = v; }
       {
         su->table_nwin = (G::Fr::BITS + 1 + su->table_c - 1) / su->table_c;

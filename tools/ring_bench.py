@@ -26,3 +26,21 @@ key.prove([3], bl[:1])
 t = time.perf_counter(); proofs = key.prove([3] * nproofs, bl); t_prove = (time.perf_counter() - t) / nproofs
 print(f"ring {ring} (N={setup.domain_size}): setup {t_setup*1e3:.1f} ms, index {t_index*1e3:.1f} / {t_index2*1e3:.1f} ms, prove {t_prove*1e3:.1f} ms/proof "
       f"({1/t_prove:.1f} proofs/s, one context, one host thread)")
+
+nctx = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+if nctx > 1:
+    # independent contexts (stream + SRS tables + scratch each), one host thread per context, proofs split evenly
+    from concurrent.futures import ThreadPoolExecutor
+    ctxs = [ctx] + [nat.Context(0) for _ in range(nctx - 1)]
+    setups = [setup] + [RingSetup(c, srs, ring) for c in ctxs[1:]]
+    keys = [key] + [su.index(pkl) for su in setups[1:]]
+    for k in keys:
+        k.prove([3], bl[:1])
+    per = nproofs // nctx
+    def work(i):
+        return keys[i].prove([3] * per, bl[i * per:(i + 1) * per])
+    pool = ThreadPoolExecutor(nctx)
+    list(pool.map(work, range(nctx)))                        # warm (scratch allocation)
+    t = time.perf_counter(); res = list(pool.map(work, range(nctx))); dt = time.perf_counter() - t
+    assert res[0][0] == proofs[0]
+    print(f"  {nctx} contexts x {per} proofs: {per * nctx / dt:.1f} proofs/s")
