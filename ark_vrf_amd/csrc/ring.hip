@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <sys/random.h>
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -251,12 +252,12 @@ k_ring_divlin(const uint32_t *__restrict__ in, uint32_t in_stride, uint32_t len,
 }
 
 // Witness columns from their sparse description (A.7 step 1): pos = sorted rows with bit 1 (<= 256 per proof,
-// padded), vals = the cnt+1 successive accumulator points (x | y), kidx = the signer's row.
-// cols[proof] = bits | ip | ax | ay (4 x N evaluations).
+// padded), vals = the cnt+1 successive accumulator points (x | y), kidx = the signer's row, zk = the values of the
+// last 3 rows of each column (proof x 4 x 3; nullptr: zeros).  cols[proof] = bits | ip | ax | ay (4 x N evaluations).
 template <class F>
 __global__ void __launch_bounds__(256)
 k_ring_witness_cols(const uint32_t *__restrict__ pos, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ kidx,
-                    const uint32_t *__restrict__ vals, uint32_t N, uint32_t cap, uint32_t *__restrict__ cols) {
+                    const uint32_t *__restrict__ vals, const uint32_t *__restrict__ zk, uint32_t N, uint32_t cap, uint32_t *__restrict__ cols) {
   __shared__ uint32_t sp[256];
   const uint32_t p = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
   sp[threadIdx.x] = pos[(size_t)p * 256 + threadIdx.x];
@@ -268,11 +269,16 @@ k_ring_witness_cols(const uint32_t *__restrict__ pos, const uint32_t *__restrict
   const bool bit = lo < m && sp[lo] == i;
   const fp one = fp_one<F>(), zero = fp_zero();
   uint32_t *c = cols + (size_t)p * 4 * N * 8;
+  if (i >= cap) {                                          // the 3 zero-knowledge rows: random when hiding, else zero
+    for (int col = 0; col < 4; col++)
+      store_fp(c + ((size_t)col * N + i) * 8, zk ? load_fp(zk + (((size_t)p * 4 + col) * 3 + (i - cap)) * 8) : zero);
+    return;
+  }
   store_fp(c + (size_t)i * 8, bit ? one : zero);
-  store_fp(c + ((size_t)N + i) * 8, (i > ki && i < cap) ? one : zero);
+  store_fp(c + ((size_t)N + i) * 8, i > ki ? one : zero);
   const uint32_t *v = vals + ((size_t)p * 257 + lo) * 16;
-  store_fp(c + ((size_t)2 * N + i) * 8, i < cap ? load_fp(v) : zero);
-  store_fp(c + ((size_t)3 * N + i) * 8, i < cap ? load_fp(v + 8) : zero);
+  store_fp(c + ((size_t)2 * N + i) * 8, load_fp(v));
+  store_fp(c + ((size_t)3 * N + i) * 8, load_fp(v + 8));
 }
 template <class F>
 __global__ void k_set_diag(uint32_t *__restrict__ mat, uint32_t n) {
@@ -693,7 +699,7 @@ template <class S, class G> struct Ring {
   }
   static fp fp_zero_host() { fp r; memset(&r, 0, sizeof r); return r; }
 
-  static int prove_chunk(avrf_ring_key *k, size_t n, const uint32_t *key_index, const uint8_t *blindings, uint8_t *out) {
+  static int prove_chunk(avrf_ring_key *k, size_t n, const uint32_t *key_index, const uint8_t *blindings, bool hiding, uint8_t *out) {
     avrf_ring_setup *su = k->setup;
     const size_t N = su->N, cap = su->cap, M = 4 * N, plen = 4 * FQB + 7 * 32 + FQB + 32 + 2 * FQB;
     const H256 zero = {{0, 0, 0, 0}}, one = Fr::one();
@@ -704,19 +710,27 @@ template <class S, class G> struct Ring {
     for (size_t i = 0; i < n; i++) if (key_index[i] >= k->n_keys) return AVRF_ERR_BAD_ARG;
     std::vector<ProofState> st(n);
     const H256 w_last = fr_pow<F>(su->w, cap - 1);
-    const H256 a_coef = S::A_KIND == 1 ? Fr::neg(fr_small<F>(5)) : one;
     // ---- round 0 (host): the witness in sparse form (A.7 step 1).  Rows with bit 1: the signer's key and the set bits
     // of the blinding; the accumulator column only changes there, so it is cnt+1 points; the four KZG commits are
     // sparse MSMs over the Lagrange-basis SRS and its prefix sums (same group elements as the coefficient-form commits).
     ensure_lagrange(su);
-    constexpr size_t MP = 256;                                         // padded entries per sparse vector (L + 2 <= 256)
-    std::vector<uint32_t> pos(n * MP, 0xffffffffu), cnt(n), bidx(n * 4 * MP, 0);
+    constexpr size_t MP = 264;                                         // padded entries per sparse vector (L + 2 + 3 zk rows <= 264)
+    // hiding (RingContext with blinding, src/ring.rs:277-295): the last 3 rows of every witness column are uniformly
+    // random field elements (w3f-ring-proof `private_column`); they only add 3 sparse terms to each commitment
+    std::vector<H256> zk;
+    if (hiding) {
+      std::vector<uint8_t> rnd(n * 12 * 48);
+      for (size_t o = 0; o < rnd.size();) { ssize_t g = getrandom(&rnd[o], rnd.size() - o, 0); if (g <= 0) return AVRF_ERR_BAD_ARG; o += (size_t)g; }
+      zk.resize(n * 12);
+      for (size_t i = 0; i < n * 12; i++) zk[i] = fr_from_be48<F>(&rnd[i * 48]);
+    }
+    std::vector<uint32_t> pos(n * 256, 0xffffffffu), cnt(n), bidx(n * 4 * MP, 0);
     std::vector<H256> vals(n * 257 * 2, zero), spsc(n * 4 * MP, zero);
     const H256 minus1 = Fr::from_mont(Fr::neg(one)), one_plain = {{1, 0, 0, 0}};
     parallel_for(n, [&](size_t p) {
       ProofState &ps = st[p];
       const uint8_t *bl = blindings + 32 * p;
-      uint32_t *ppos = &pos[p * MP]; size_t m = 0;
+      uint32_t *ppos = &pos[p * 256]; size_t m = 0;
       ppos[m++] = key_index[p];
       for (size_t i = 0; i < su->L; i++) if ((bl[i >> 3] >> (i & 7)) & 1) ppos[m++] = (uint32_t)(su->keyset + i);
       cnt[p] = (uint32_t)m;
@@ -748,14 +762,19 @@ template <class S, class G> struct Ring {
       }
       bi[2 * MP + m] = bi[3 * MP + m] = (uint32_t)(N + cap);
       sc[2 * MP + m] = Fr::from_mont(v[2 * m]); sc[3 * MP + m] = Fr::from_mont(v[2 * m + 1]);
+      if (hiding) for (int col = 0; col < 4; col++) for (int j = 0; j < 3; j++) {      // + zk_j * L_{cap+j}(tau) G
+        bi[col * MP + m + 1 + j] = (uint32_t)(cap + j); sc[col * MP + m + 1 + j] = Fr::from_mont(zk[(p * 4 + col) * 3 + j]);
+      }
     });
     lap("witness (host)");
     // ---- round 1 (device): columns, coefficients, their 4N evaluations, 4n sparse commits in one MSM chain
     uint32_t *d_coef = dev_scratch(su, 2, n * 4 * N * 32), *d_e4 = dev_scratch(su, 0, n * 4 * M * 32);
     {
-      const size_t b_pos = n * MP * 4, b_cnt = n * 4, b_val = n * 257 * 64, b_sc = n * 4 * MP * 32, b_bi = n * 4 * MP * 4;
-      uint32_t *d_w = dev_scratch(su, 1, b_sc + b_val + b_pos + b_bi + 2 * b_cnt);
-      uint32_t *d_sc = d_w, *d_val = d_sc + b_sc / 4, *d_pos = d_val + b_val / 4, *d_bi = d_pos + b_pos / 4, *d_cnt = d_bi + b_bi / 4, *d_ki = d_cnt + n;
+      const size_t b_pos = n * 256 * 4, b_cnt = n * 4, b_val = n * 257 * 64, b_sc = n * 4 * MP * 32, b_bi = n * 4 * MP * 4, b_zk = n * 12 * 32;
+      uint32_t *d_w = dev_scratch(su, 1, b_sc + b_val + b_zk + b_pos + b_bi + 2 * b_cnt);
+      uint32_t *d_sc = d_w, *d_val = d_sc + b_sc / 4, *d_zk = d_val + b_val / 4, *d_pos = d_zk + b_zk / 4, *d_bi = d_pos + b_pos / 4, *d_cnt = d_bi + b_bi / 4,
+               *d_ki = d_cnt + n;
+      if (hiding) HIP_CHECK(hipMemcpyAsync(d_zk, zk.data(), b_zk, hipMemcpyHostToDevice, su->stream));
       HIP_CHECK(hipMemcpyAsync(d_sc, spsc.data(), b_sc, hipMemcpyHostToDevice, su->stream));
       HIP_CHECK(hipMemcpyAsync(d_val, vals.data(), b_val, hipMemcpyHostToDevice, su->stream));
       HIP_CHECK(hipMemcpyAsync(d_pos, pos.data(), b_pos, hipMemcpyHostToDevice, su->stream));
@@ -763,7 +782,7 @@ template <class S, class G> struct Ring {
       HIP_CHECK(hipMemcpyAsync(d_cnt, cnt.data(), b_cnt, hipMemcpyHostToDevice, su->stream));
       HIP_CHECK(hipMemcpyAsync(d_ki, key_index, b_cnt, hipMemcpyHostToDevice, su->stream));
       hipLaunchKernelGGL(k_ring_witness_cols<F>, dim3((unsigned)((N + 255) / 256), (unsigned)n), dim3(256), 0, su->stream, (const uint32_t *)d_pos,
-                         (const uint32_t *)d_cnt, (const uint32_t *)d_ki, (const uint32_t *)d_val, (uint32_t)N, (uint32_t)cap, d_coef);
+                         (const uint32_t *)d_cnt, (const uint32_t *)d_ki, (const uint32_t *)d_val, hiding ? (const uint32_t *)d_zk : nullptr, (uint32_t)N, (uint32_t)cap, d_coef);
       { fp sc; memcpy(sc.v, su->ninv.l, 32); ntt_launch<F>(d_coef, (uint32_t)N, su->d_tw_n_inv, (uint32_t)(4 * n), &sc, su->stream); }
       HIP_CHECK(hipMemsetAsync(d_e4, 0, n * 4 * M * 32, su->stream));
       HIP_CHECK(hipMemcpy2DAsync(d_e4, M * 32, d_coef, N * 32, N * 32, 4 * n, hipMemcpyDeviceToDevice, su->stream));
@@ -937,7 +956,6 @@ template <class S, class G> struct Ring {
     std::vector<H256> gsc(n);
     std::atomic<int> status{AVRF_OK};
     const H256 w_last = fr_pow<F>(su->w, cap - 1), ninv = su->ninv;
-    const H256 a_coef = S::A_KIND == 1 ? Fr::neg(fr_small<F>(5)) : one;
     H256 wz[3]; for (int j = 0; j < 3; j++) wz[j] = fr_pow<F>(su->w, N - 3 + j);
     H256 seedx = Fr::from32(S::ACC_X), seedy = Fr::from32(S::ACC_Y);
     parallel_for(n, [&](size_t it) {
@@ -993,6 +1011,7 @@ template <class S, class G> struct Ring {
       H256 zk = one; for (int j = 0; j < 3; j++) zk = Fr::mul(zk, Fr::sub(zeta, wz[j]));
       const H256 qz = Fr::mul(Fr::mul(aggz, zk), Fr::inv(zn1));
       H256 vagg = Fr::mul(nu[7], qz); for (int i = 0; i < 7; i++) vagg = Fr::add(vagg, Fr::mul(nu[i], ev[i]));
+      const H256 a_coef = S::A_KIND == 1 ? Fr::neg(fr_small<F>(5)) : one;
       const H256 k1 = Fr::add(Fr::mul(b, Fr::add(Fr::mul(y1, y2), Fr::mul(a_coef, Fr::mul(x1, x2)))), omb);
       const H256 k2 = Fr::add(Fr::mul(b, Fr::sub(Fr::mul(x1, y2), Fr::mul(x2, y1))), omb);
       const H256 zw = Fr::mul(zeta, su->w);
@@ -1069,15 +1088,15 @@ void avrf_ring_key_free(avrf_ring_key *k) { if (!k) return; if (k->d_fixed4) (vo
 
 int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const uint8_t *blindings, int blinding_mode, uint8_t *proofs_out) {
   if (!k || (n && (!key_index || !blindings || !proofs_out))) return AVRF_ERR_BAD_ARG;
-  if (blinding_mode != 0) return AVRF_ERR_BAD_ARG;                     // zero-knowledge blinding rows: not yet
+  if (blinding_mode != 0 && blinding_mode != 1) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(k->setup->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   const size_t plen = k->setup->suite == 0 ? 592 : 480;
-  size_t chunk = 128;                                                  // proofs proved in lockstep per device round
+  size_t chunk = 512;                                                  // proofs proved in lockstep per device round
   if (const char *e = getenv("AVRF_RING_CHUNK")) { long v = atol(e); if (v >= 1 && v <= 4096) chunk = (size_t)v; }
   for (size_t i = 0; i < n; i += chunk) {
     const size_t m = n - i < chunk ? n - i : chunk;
-    int st = k->setup->suite == 0 ? RingB::prove_chunk(k, m, key_index + i, blindings + 32 * i, proofs_out + plen * i)
-                                  : RingJ::prove_chunk(k, m, key_index + i, blindings + 32 * i, proofs_out + plen * i);
+    int st = k->setup->suite == 0 ? RingB::prove_chunk(k, m, key_index + i, blindings + 32 * i, blinding_mode == 1, proofs_out + plen * i)
+                                  : RingJ::prove_chunk(k, m, key_index + i, blindings + 32 * i, blinding_mode == 1, proofs_out + plen * i);
     if (st) return st;
   }
   return AVRF_OK;

@@ -165,7 +165,8 @@ void avrf_ring_key_free(avrf_ring_key *key);
 /* RingProver::prove (the `ring_prover.prove(blinding)` half of ring::Prover::prove, src/ring.rs:219-221) for n
  * proofs over one ring: key_index[i] is the prover's position in the ring, blindings[i] the secret blinding
  * returned by avrf_pedersen_prove.  blinding_mode 0 = RingContext::new_without_blinding (deterministic,
- * reproduces the reference vectors).  proofs_out: n x avrf_ring_proof_len bytes (the RingBareProof in its
+ * reproduces the reference vectors); 1 = hiding (the reference's default RingContext): the last 3 rows of every
+ * witness column are fresh uniformly random field elements (getrandom(2)), so proofs are not reproducible.  proofs_out: n x avrf_ring_proof_len bytes (the RingBareProof in its
  * compressed serialisation); the full ring-VRF proof is the Pedersen proof followed by it (src/ring.rs:160-166). */
 int avrf_ring_prove(avrf_ring_key *key, size_t n, const uint32_t *key_index, const uint8_t *blindings, int blinding_mode,
                     uint8_t *proofs_out);

@@ -166,3 +166,60 @@ def test_ring_vrf_end_to_end_gpu(env):
     # a proof by a key outside the ring: index with a different key set
     key2 = setup.index(pkl[:5] + [pkl[0]])
     assert ring_batch_verify(setup, [key2.commitment], None, ybs, rproofs) == 1
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_hiding_proofs(env, suite):
+    """blinding_mode 1 (the reference's default hiding RingContext, src/ring.rs:277-295): the 3 zero-knowledge rows
+    of every witness column are random, so two proofs of one statement differ, both verify (GPU verifier for both
+    suites, oracle verifier for BLS12-381), and a proof for another instance is rejected."""
+    import oracle as orc
+    from ark_vrf_amd.ring import ring_batch_verify
+    ctx, setup, vs, srs_bytes = env[suite]
+    s = R.SUITES[suite]
+    sks = [orc.from_seed(suite, bytes([90 + i]) + bytes(31)) for i in range(6)]
+    key = setup.index([xy(suite, pk) for _, pk in sks])
+    h = orc.hash_to_curve(suite, b"hiding")
+    items = []
+    for j in (0, 5, 2):
+        sk, pk = sks[j]
+        ped, blinding = orc.pedersen_prove(suite, sk, [(h, orc.vrf_output(suite, sk, h))], b"ad%d" % j)
+        items.append((j, blinding, xy(suite, ped[:32])))
+    idx = [j for j, _, _ in items]; bl = [b for _, b, _ in items]; ybs = [y for _, _, y in items]
+    p1 = key.prove(idx, bl, blinding_mode=1)
+    p2 = key.prove(idx, bl, blinding_mode=1)
+    p0 = key.prove(idx, bl, blinding_mode=0)
+    assert all(a != b for a, b in zip(p1, p2)) and all(a != b for a, b in zip(p1, p0))
+    for proofs in (p0, p1, p2):
+        assert ring_batch_verify(setup, [key.commitment], None, ybs, proofs) == 0
+    assert ring_batch_verify(setup, [key.commitment], None, ybs[1:] + ybs[:1], p1) == 1
+    if suite == 0:
+        prm = R.Params(s, ring_size=8)
+        srs = R.Srs(s, srs_bytes)
+        fixed = [R.g1_decode_compressed(s, key.commitment[48 * i: 48 * i + 48]) for i in range(3)]
+        for (j, b, y), proof in zip(items, p1):
+            inst = (int.from_bytes(y[:32], "little"), int.from_bytes(y[32:], "little"))
+            assert R.verify(prm, srs, fixed, proof, inst)
+
+
+def test_witness_edge_cases_match_oracle(env):
+    """Sparse witness path at its corners: signer in the first / last key slot of a FULL ring, blinding with every
+    bit set (253 ones -> 254 accumulator steps) and the zero blinding; bytes equal the oracle prover's."""
+    ctx, setup, vs, srs_bytes = env[0]
+    s = R.SUITES[0]
+    import oracle as orc
+    nmax = setup.max_ring_size
+    base = [orc.from_seed(0, bytes([i % 251, i // 251]) + bytes(30)) for i in range(4)]
+    pks = [base[i % 4][1] for i in range(nmax)]
+    pkl = [xy(0, p) for p in pks]
+    key = setup.index(pkl)
+    prm = R.Params(s, ring_size=8)
+    srs = R.Srs(s, srs_bytes)
+    cols = R.index(prm, srs, [R.te_decode(s, p) for p in pks])
+    assert key.commitment == R.commitment_bytes(s, cols)
+    ones = (1 << 253) - 1
+    cases = [(0, ones), (nmax - 1, ones), (nmax - 1, 0), (0, 1 << 252), (7, 0x5555555555555555555555555555555555555555555555555555555555555555 >> 3)]
+    got = key.prove([c[0] for c in cases], [c[1].to_bytes(32, "little") for c in cases])
+    for (k, b), proof in zip(cases, got):
+        want, _ = R.prove(prm, srs, cols, k, b)
+        assert proof == want, (k, hex(b))
