@@ -118,6 +118,49 @@ template <class C> struct HostPairing {
     return f12_is_one(out);
   }
 
+  // affine G2 arithmetic on the twist (y^2 = x^3 + b'), only for tau * g2 when an SRS is generated (Kzg::setup)
+  static G2 g2_dbl(const G2 &p) {
+    if (p.inf || f2_is_zero(p.y)) { G2 r = p; r.inf = true; return r; }
+    static const El three = small(3), two = small(2);
+    F2 lam = f2_mul(f2_scale(f2_sqr(p.x), three), f2_inv(f2_scale(p.y, two)));
+    G2 r; r.inf = false;
+    r.x = f2_sub(f2_sqr(lam), f2_add(p.x, p.x));
+    r.y = f2_sub(f2_mul(lam, f2_sub(p.x, r.x)), p.y);
+    return r;
+  }
+  static G2 g2_add(const G2 &a, const G2 &b) {
+    if (a.inf) return b;
+    if (b.inf) return a;
+    if (f2_eq(a.x, b.x)) { if (f2_eq(a.y, b.y)) return g2_dbl(a); G2 r = a; r.inf = true; return r; }
+    F2 lam = f2_mul(f2_sub(b.y, a.y), f2_inv(f2_sub(b.x, a.x)));
+    G2 r; r.inf = false;
+    r.x = f2_sub(f2_sub(f2_sqr(lam), a.x), b.x);
+    r.y = f2_sub(f2_mul(lam, f2_sub(a.x, r.x)), a.y);
+    return r;
+  }
+  static G2 g2_mul(const G2 &p, const uint64_t k[4]) {               // k: plain 256-bit scalar, little-endian limbs
+    G2 r = p; r.inf = true;
+    for (int i = 255; i >= 0; i--) { r = g2_dbl(r); if ((k[i >> 6] >> (i & 63)) & 1) r = g2_add(r, p); }
+    return r;
+  }
+  // inverse of g2_decode: one `powers_in_g2` entry (serialize_uncompressed)
+  static void g2_encode(const G2 &p, uint8_t *b) {
+    constexpr int B = 8 * Fp::L;
+    memset(b, 0, 4 * B);
+    if (B == 48) {
+      if (p.inf) { b[0] = 0x40; return; }
+      El v[4] = {Fp::from_mont(p.x.b), Fp::from_mont(p.x.a), Fp::from_mont(p.y.b), Fp::from_mont(p.y.a)};
+      for (int k = 0; k < 4; k++) { uint8_t le[48]; memcpy(le, v[k].l, B); for (int i = 0; i < B; i++) b[k * B + i] = le[B - 1 - i]; }
+    } else {
+      if (p.inf) { b[4 * B - 1] = 0x40; return; }
+      El v[4] = {Fp::from_mont(p.x.a), Fp::from_mont(p.x.b), Fp::from_mont(p.y.a), Fp::from_mont(p.y.b)};
+      for (int k = 0; k < 4; k++) memcpy(b + k * B, v[k].l, B);
+      // arkworks SWFlags: y > -y, Fp2 ordered by (c1, c0)
+      El half = Fp::from32(C::Fq::HALF), t; const El &key = Fp::is_zero(v[3]) ? v[2] : v[3];
+      if (Fp::subb(t, half, key)) b[4 * B - 1] |= 0x80;
+    }
+  }
+
   // G2 from the `powers_in_g2` bytes of an arkworks URS file
   static bool g2_decode(const uint8_t *b, G2 *out) {
     constexpr int B = 8 * Fp::L;

@@ -578,6 +578,61 @@ template <class S, class G> struct Ring {
     return AVRF_OK;
   }
 
+  // ---- Kzg::setup (reached from RingSetup::from_rand / from_seed, src/ring.rs:359-374) with the trapdoor and the two
+  // generators given explicitly: writes `URS { powers_in_g1: tau^i g1 (i < n_g1), powers_in_g2: [g2, tau g2] }` in the
+  // serialize_uncompressed layout that setup_load reads.  The n_g1 fixed-base multiplications are ONE batched table MSM.
+  static int srs_generate(avrf_ctx *ctx, const uint8_t tau_le[32], const uint8_t *g1_urs, const uint8_t *g2_urs, size_t n_g1,
+                          uint8_t *out, size_t out_cap, size_t *out_len) {
+    const size_t e1 = 2 * FQB, e2 = 4 * FQB, need = 8 + n_g1 * e1 + 8 + 2 * e2;
+    if (out_len) *out_len = need;
+    if (!out || out_cap < need) return AVRF_ERR_BAD_ARG;
+    H256 tau = Fr::load_le(tau_le);
+    if (Fr::geq_p(tau) || !n_g1) return AVRF_INVALID_DATA;
+    hipStream_t stream = avrf_ctx_stream_(ctx);
+    HIP_CHECK(hipSetDevice(avrf_ctx_device_(ctx)));
+    // g1: URS entry -> canonical little-endian x || y
+    uint8_t le[2 * 48];
+    if (FQB == 48) { if (g1_urs[0] & 0xC0) return AVRF_INVALID_DATA; for (int k = 0; k < FQB; k++) { le[k] = g1_urs[FQB - 1 - k]; le[FQB + k] = g1_urs[2 * FQB - 1 - k]; } }
+    else { if (g1_urs[e1 - 1] & 0x40) return AVRF_INVALID_DATA; memcpy(le, g1_urs, e1); le[e1 - 1] &= 0x3f; }   // 0x80: arkworks' sign-of-y flag
+    std::vector<H256> pw(n_g1);                                        // tau^i, plain
+    { H256 tm = Fr::to_mont(tau), run = Fr::one(); for (size_t i = 0; i < n_g1; i++) { pw[i] = Fr::from_mont(run); run = Fr::mul(run, tm); } }
+    const int c = 4, nwin = (G::Fr::BITS + 1 + c - 1) / c;
+    uint8_t *d_le; uint32_t *d_flag, *d_base, *d_table, *d_sc; uint32_t flag = 0;
+    HIP_CHECK(hipMalloc(&d_le, e1)); HIP_CHECK(hipMalloc(&d_flag, 4)); HIP_CHECK(hipMalloc(&d_base, e1));
+    HIP_CHECK(hipMalloc(&d_table, (size_t)nwin * e1)); HIP_CHECK(hipMalloc(&d_sc, n_g1 * 32));
+    HIP_CHECK(hipMemcpy(d_le, le, e1, hipMemcpyHostToDevice)); HIP_CHECK(hipMemset(d_flag, 0, 4));
+    HIP_CHECK(hipMemcpy(d_sc, pw.data(), n_g1 * 32, hipMemcpyHostToDevice));
+    launch_g1_bases(S::ID, d_le, 1, d_base, d_flag, stream);
+    HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, stream)); HIP_CHECK(hipStreamSynchronize(stream));
+    int st = AVRF_OK;
+    std::vector<uint8_t> xy(n_g1 * e1);
+    if (flag) st = AVRF_INVALID_DATA;
+    else {
+      build_g1_table(S::ID, d_base, 1, c, nwin, d_table, stream);
+      MsmWorkspace ws;
+      msm_g1_fixed_device(S::ID, d_table, c, 1, d_sc, 1, 1, ws, stream, xy.data(), n_g1);
+      ws.release();
+    }
+    HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag)); HIP_CHECK(hipFree(d_base)); HIP_CHECK(hipFree(d_table)); HIP_CHECK(hipFree(d_sc));
+    if (st) return st;
+    uint64_t cnt = n_g1; memcpy(out, &cnt, 8);
+    {
+      std::vector<uint8_t> enc; enc.reserve(n_g1 * e1);
+      for (size_t i = 0; i < n_g1; i++) {
+        G1Aff a; memset(&a, 0, sizeof a); memcpy(a.xy, &xy[i * e1], e1);
+        a.inf = true; for (size_t k = 0; k < e1; k++) if (a.xy[k]) a.inf = false;
+        g1_encode<G>(a, false, enc);                                   // serialize_uncompressed (with arkworks' y flag on BN254)
+      }
+      memcpy(out + 8, enc.data(), n_g1 * e1);
+    }
+    using HP = HostPairing<G>;
+    typename HP::G2 g2; HP::g2_decode(g2_urs, &g2);
+    typename HP::G2 tg2 = HP::g2_mul(g2, tau.l);
+    uint8_t *o2 = out + 8 + n_g1 * e1; cnt = 2; memcpy(o2, &cnt, 8);
+    memcpy(o2 + 8, g2_urs, e2); HP::g2_encode(tg2, o2 + 8 + e2);
+    return AVRF_OK;
+  }
+
   // ---- ring_proof::index (A.5): fixed columns and their commitments
   static int index(avrf_ring_setup *su, const uint8_t *pks_xy, size_t n_keys, avrf_ring_key **out) {
     if (n_keys > su->keyset) return AVRF_RING_CAPACITY_EXCEEDED;       // src/ring.rs:400-402
@@ -1057,6 +1112,15 @@ int avrf_ring_setup_load(avrf_ctx *ctx, const uint8_t *srs, size_t srs_len, size
   if (!ctx || !srs || !out || ring_size == 0) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
   return avrf_ctx_suite_(ctx) == 0 ? RingB::setup_load(ctx, srs, srs_len, ring_size, out) : RingJ::setup_load(ctx, srs, srs_len, ring_size, out);
+}
+int avrf_ring_srs_generate(avrf_ctx *ctx, const uint8_t *tau, const uint8_t *g1, const uint8_t *g2, size_t n_g1, uint8_t *out, size_t out_cap, size_t *out_len) {
+  if (!ctx || !tau || !g1 || !g2) return AVRF_ERR_BAD_ARG;
+  return avrf_ctx_suite_(ctx) == 0 ? RingB::srs_generate(ctx, tau, g1, g2, n_g1, out, out_cap, out_len) : RingJ::srs_generate(ctx, tau, g1, g2, n_g1, out, out_cap, out_len);
+}
+size_t avrf_ring_pcs_domain_size(int suite, size_t ring_size) {       /* pcs_domain_size, src/ring.rs:810-817: 3 * piop_domain + 1 */
+  const size_t L = suite == 0 ? (size_t)SuiteBandersnatch::Fr::BITS : (size_t)SuiteBabyJubJub::Fr::BITS;
+  size_t need = ring_size + 4 + L, N = 1; while (N < need) N <<= 1;
+  return 3 * N + 1;
 }
 void avrf_ring_setup_free(avrf_ring_setup *su) {
   if (!su) return;

@@ -82,3 +82,18 @@ def ring_batch_verify(setup, ring_commitments, ring_of_item, instances_xy, ring_
     roi = nat._u32(ring_of_item) if ring_of_item is not None else None
     return nat.lib().avrf_ring_batch_verify(setup._h, C.c_size_t(n), nat._u8(b"".join(ring_commitments)), C.c_size_t(len(ring_commitments)),
                                             roi, nat._u8(b"".join(instances_xy)), nat._u8(b"".join(ring_proofs)))
+
+
+def srs_generate(ctx, suite, tau, g1, g2, ring_size):
+    """Kzg::setup with an explicit trapdoor (RingSetup::from_seed / from_rand, src/ring.rs:359-374): URS bytes for a ring
+    of `ring_size` keys.  tau: int < r; g1, g2: generator entries in URS encoding (e.g. sliced from an SRS file)."""
+    L = nat.lib()
+    L.avrf_ring_pcs_domain_size.restype = C.c_size_t
+    n_g1 = L.avrf_ring_pcs_domain_size(int(suite), C.c_size_t(ring_size))
+    need = 8 + n_g1 * len(g1) + 8 + 2 * len(g2)
+    out = (C.c_uint8 * need)()
+    ln = C.c_size_t(0)
+    st = L.avrf_ring_srs_generate(ctx._h, nat._u8(int(tau).to_bytes(32, "little")), nat._u8(g1), nat._u8(g2), C.c_size_t(n_g1), out, C.c_size_t(need), C.byref(ln))
+    if st != nat.OK:
+        raise nat.AvrfError(f"avrf_ring_srs_generate -> {st}")
+    return bytes(out)[:ln.value]

@@ -150,6 +150,15 @@ typedef struct avrf_ring_setup avrf_ring_setup;
 typedef struct avrf_ring_key avrf_ring_key;
 int avrf_ring_setup_load(avrf_ctx *ctx, const uint8_t *srs, size_t srs_len, size_t ring_size, avrf_ring_setup **out);
 void avrf_ring_setup_free(avrf_ring_setup *setup);
+/* Kzg::setup as reached from RingSetup::from_rand / from_seed (src/ring.rs:359-374), with the trapdoor tau (32 B LE,
+ * < r) and the generators given explicitly (g1: one `powers_in_g1` entry, g2: one `powers_in_g2` entry, both in the
+ * URS serialize_uncompressed encoding, e.g. the first entries of an existing SRS file).  Writes the URS bytes
+ * { tau^i g1, i < n_g1 ; g2, tau g2 } that avrf_ring_setup_load reads; *out_len = bytes needed (also when out is too
+ * small -> AVRF_ERR_BAD_ARG).  n_g1 = avrf_ring_pcs_domain_size(suite, ring_size) for a ring of that size.
+ * Insecure by construction (the caller knows tau) -- exactly like the reference's from_seed; for tests and benches. */
+int avrf_ring_srs_generate(avrf_ctx *ctx, const uint8_t *tau, const uint8_t *g1, const uint8_t *g2, size_t n_g1,
+                           uint8_t *out, size_t out_cap, size_t *out_len);
+size_t avrf_ring_pcs_domain_size(int suite, size_t ring_size);   /* pcs_domain_size, src/ring.rs:810-817 */
 size_t avrf_ring_max_ring_size(const avrf_ring_setup *setup);   /* RingContext::max_ring_size, src/ring.rs:298-300 */
 size_t avrf_ring_domain_size(const avrf_ring_setup *setup);     /* piop_domain_size, src/ring.rs:819-821 */
 size_t avrf_ring_proof_len(const avrf_ring_setup *setup);       /* 592 (BLS12-381) / 480 (BN254) */

@@ -3,6 +3,7 @@
 // Usage: host_pairing_check <curve 0|1> <srs file>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "../../ark_vrf_amd/csrc/host_pairing.h"
 
@@ -28,8 +29,15 @@ template <class G> static int run(const std::vector<uint8_t> &srs) {
   bool bad = HP::product_is_one(px, py, inf, q, 2);
   g1_at(6, px[0], py[0]); g1_at(5, px[1], py[1]); py[1] = Fp::neg(py[1]);
   bool ok2 = HP::product_is_one(px, py, inf, q, 2);
-  printf("consistent=%d negative=%d consistent_high=%d\n", ok, bad, ok2);
-  return (ok && !bad && ok2) ? 0 : 1;
+  // G2 codec round trip (g2_encode is what avrf_ring_srs_generate writes): re-encoding the file's entries gives the
+  // file's bytes, flags included; and the affine G2 group law: 2*(q0) + q0 == 3*q0 by two routes
+  uint8_t enc[2][4 * 48]; HP::g2_encode(q[0], enc[0]); HP::g2_encode(q[1], enc[1]);
+  bool codec = memcmp(enc[0], g2p, 4 * B) == 0 && memcmp(enc[1], g2p + 4 * B, 4 * B) == 0;
+  const uint64_t three[4] = {3, 0, 0, 0};
+  typename HP::G2 a = HP::g2_add(HP::g2_dbl(q[0]), q[0]), b3 = HP::g2_mul(q[0], three);
+  bool law = !a.inf && HP::f2_eq(a.x, b3.x) && HP::f2_eq(a.y, b3.y);
+  printf("consistent=%d negative=%d consistent_high=%d g2_codec=%d g2_law=%d\n", ok, bad, ok2, codec, law);
+  return (ok && !bad && ok2 && codec && law) ? 0 : 1;
 }
 
 int main(int argc, char **argv) {

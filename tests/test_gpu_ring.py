@@ -223,3 +223,48 @@ def test_witness_edge_cases_match_oracle(env):
     for (k, b), proof in zip(cases, got):
         want, _ = R.prove(prm, srs, cols, k, b)
         assert proof == want, (k, hex(b))
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_srs_generate(env, suite):
+    """a13, RingSetup::from_seed / from_rand -> Kzg::setup (src/ring.rs:359-374) with an explicit trapdoor: the generated
+    URS has powers tau^i g1 (checked against the oracle's G1 scalar multiplication and, by pairing, against tau g2),
+    loads like a file, and a ring proof made over it verifies -- on the GPU (both suites) and under the oracle (BLS)."""
+    import oracle as orc
+    from oracle import pairing_py as PP
+    from ark_vrf_amd.ring import RingSetup, ring_batch_verify, srs_generate
+    ctx, _, vs, srs_bytes = env[suite]
+    s = R.SUITES[suite]
+    fq = s.fp_bytes
+    tau = int.from_bytes(b"\x42" * 31 + b"\x05", "little") % s.r
+    g1 = srs_bytes[8: 8 + 2 * fq]
+    cnt = int.from_bytes(srs_bytes[:8], "little")
+    g2 = srs_bytes[8 + cnt * 2 * fq + 8: 8 + cnt * 2 * fq + 8 + 4 * fq]
+    gen = srs_generate(ctx, suite, tau, g1, g2, 8)
+    srs = R.Srs(s, gen)
+    assert len(srs.g1) == 3 * 512 + 1 and len(srs.g2_raw) == 2 and srs.g2_raw[0] == g2
+    p = s.p
+    G = srs.g1[0] + (1,)
+    for i in (1, 2, 7, 1536):
+        assert srs.g1[i] == R.g1_affine(p, R.g1_mul(p, G, pow(tau, i, s.r)))
+    PP.use_curve("bls12_381" if suite == 0 else "bn254")
+    dec = PP.g2_decode_zcash_uncompressed if suite == 0 else PP.g2_decode_arkworks_uncompressed
+    neg = lambda P: (P[0], (-P[1]) % p)
+    assert PP.pairing_product_is_one([(srs.g1[1], dec(srs.g2_raw[0])), (neg(srs.g1[0]), dec(srs.g2_raw[1]))])
+    PP.use_curve("bls12_381")
+    setup = RingSetup(ctx, gen, 8)
+    sks = [orc.from_seed(suite, bytes([7, i]) + bytes(30)) for i in range(5)]
+    key = setup.index([xy(suite, pk) for _, pk in sks])
+    h = orc.hash_to_curve(suite, b"generated-srs")
+    sk, pk = sks[4]
+    ped, blinding = orc.pedersen_prove(suite, sk, [(h, orc.vrf_output(suite, sk, h))], b"")
+    proof = key.prove([4], [blinding])[0]
+    yb = xy(suite, ped[:32])
+    assert ring_batch_verify(setup, [key.commitment], None, [yb], [proof]) == 0
+    assert ring_batch_verify(setup, [key.commitment], None, [xy(suite, pk)], [proof]) == 1
+    if suite == 0:
+        prm = R.Params(s, ring_size=8)
+        fixed = [R.g1_decode_compressed(s, key.commitment[48 * i: 48 * i + 48]) for i in range(3)]
+        assert R.verify(prm, srs, fixed, proof, R.te_decode(s, ped[:32]))
+    with pytest.raises(Exception):
+        srs_generate(ctx, suite, s.r, g1, g2, 8)                           # tau must be < r
