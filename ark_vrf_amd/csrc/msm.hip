@@ -402,6 +402,57 @@ k_wsum(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t nsets, uint32
   if (live && g == 0) CV::store_acc(out + (size_t)set * CV::ACC_WORDS, V);
 }
 
+// Same weighted sum with a whole workgroup (wps waves) per bucket set, for launches with few sets: lane t of the
+// group owns m = nb / (64 wps) consecutive buckets; each wave reduces to (V_w, Y_w) = (sum_l W_l + m l S_l, sum_l S_l)
+// as above, and lane 0 finishes sum_w V_w + 64 m sum_w w Y_w over the wps pairs left in LDS.
+template <class CV>
+__global__ void __launch_bounds__(256, CV::MIN_WAVES)
+k_wsum_blk(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t *__restrict__ out) {
+  using acc_t = typename CV::acc_t;
+  extern __shared__ uint32_t lds[];                                            // wps x {V, Y}
+  const uint32_t set = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6, wps = blockDim.x >> 6;
+  const uint32_t m = nb / blockDim.x;
+  const uint32_t *B = buckets + (size_t)set * nb * CV::ACC_WORDS;              // B[b-1]
+  acc_t S = CV::identity(), W = CV::identity();
+  {
+    const uint32_t lo = t * m + 1;
+#pragma unroll 1
+    for (uint32_t b = lo + m - 1; b >= lo; b--) {
+      S = CV::add(S, CV::load_acc(B + (size_t)(b - 1) * CV::ACC_WORDS));
+      W = CV::add(W, S);
+    }
+  }
+  acc_t A = S;
+#pragma unroll 1
+  for (uint32_t off = 1; off < 64; off <<= 1) {
+    acc_t o = CV::shfl_down(A, off);
+    if (lane + off < 64) A = cv_add<CV>(A, o);
+  }
+  acc_t Z = lane ? A : CV::identity();
+#pragma unroll 1
+  for (uint32_t k = m; k > 1; k >>= 1) Z = cv_dbl<CV>(Z);
+  acc_t V = cv_add<CV>(W, Z);
+#pragma unroll 1
+  for (uint32_t off = 32; off >= 1; off >>= 1) {
+    acc_t o = CV::shfl_down(V, off);
+    if (lane + off < 64) V = cv_add<CV>(V, o);
+  }
+  if (lane == 0) { CV::store_acc(lds + (2 * wv) * CV::ACC_WORDS, V); CV::store_acc(lds + (2 * wv + 1) * CV::ACC_WORDS, A); }
+  __syncthreads();
+  if (t == 0) {
+    acc_t r = V, suf = CV::identity(), q = CV::identity();                     // q = sum_{w >= 1} w Y_w = sum of suffix sums
+#pragma unroll 1
+    for (uint32_t w = wps - 1; w >= 1; w--) {
+      suf = cv_add<CV>(suf, CV::load_acc(lds + (2 * w + 1) * CV::ACC_WORDS));
+      q = cv_add<CV>(q, suf);
+      r = cv_add<CV>(r, CV::load_acc(lds + (2 * w) * CV::ACC_WORDS));
+    }
+#pragma unroll 1
+    for (uint32_t k = 64 * m; k > 1; k >>= 1) q = cv_dbl<CV>(q);
+    CV::store_acc(out + (size_t)set * CV::ACC_WORDS, cv_add<CV>(r, q));
+  }
+}
+
 // ---------------------------------------------------------------- host engine
 
 MsmPlan msm_plan(size_t n, int scalar_bits) {
@@ -539,11 +590,18 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   const uint32_t tasks = (1u << h) + ((uint32_t)p.nb >> h);
   const int nbits = (int)vwin * p.c;
   if constexpr (CV::FIXED_TABLE) if (table_c) {   // one bucket set per MSM: weighted sum in one kernel, no bit sums
-    uint32_t lps_log = 6;                                  // lanes per bucket set: enough waves to cover the chip, <= nb
-    while (lps_log > 2 && (batch << (lps_log - 1)) >= 2048 * 64) lps_log--;
-    while ((1u << lps_log) > (uint32_t)p.nb) lps_log--;
-    hipLaunchKernelGGL(k_wsum<CV>, dim3((unsigned)(((batch << lps_log) + 255) / 256)), b256, 0, stream, (const uint32_t *)ws.buckets, (uint32_t)p.nb,
-                       (uint32_t)batch, lps_log, ws.rc);
+    uint32_t wps = 1;                                      // waves per bucket set when the launch has few sets
+    while (wps < 4 && batch * wps * 2 <= 2048 && (uint32_t)p.nb >= 64 * wps * 2) wps *= 2;
+    if (wps > 1) {
+      hipLaunchKernelGGL(k_wsum_blk<CV>, dim3((unsigned)batch), dim3(64 * wps), (size_t)wps * 2 * acc_bytes, stream, (const uint32_t *)ws.buckets,
+                         (uint32_t)p.nb, ws.rc);
+    } else {
+      uint32_t lps_log = 6;                                // lanes per bucket set: enough waves to cover the chip, <= nb
+      while (lps_log > 2 && (batch << (lps_log - 1)) >= 2048 * 64) lps_log--;
+      while ((1u << lps_log) > (uint32_t)p.nb) lps_log--;
+      hipLaunchKernelGGL(k_wsum<CV>, dim3((unsigned)(((batch << lps_log) + 255) / 256)), b256, 0, stream, (const uint32_t *)ws.buckets, (uint32_t)p.nb,
+                         (uint32_t)batch, lps_log, ws.rc);
+    }
     HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.rc, batch * acc_bytes, hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     HIP_CHECK(hipGetLastError());

@@ -13,8 +13,19 @@ from ark_vrf_amd.ring import RingSetup  # noqa: E402
 
 ring = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nproofs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-ctx = nat.Context(0)
-srs = open(os.path.join(ROOT, "tests", "golden", "bls12-381-srs-2-11-uncompressed-zcash.bin"), "rb").read()
+suite = int(sys.argv[4]) if len(sys.argv) > 4 else 0                # 0 Bandersnatch/BLS12-381, 1 Baby-JubJub/BN254
+ctx = nat.Context(suite)
+srs = open(os.path.join(ROOT, "tests", "golden", ["bls12-381-srs-2-11-uncompressed-zcash.bin", "bn254-testing-2-9-uncompressed.bin"][suite]), "rb").read()
+fq = 48 if suite == 0 else 32
+have = int.from_bytes(srs[:8], "little")
+if have < 3 * (1 << (ring + 4 + (253 if suite == 0 else 251) - 1).bit_length()) + 1:
+    # no file that large: generate powers of a fixed tau from the file's generators
+    from ark_vrf_amd.ring import srs_generate
+    t = time.perf_counter()
+    srs = srs_generate(ctx, suite, 0x1234567890abcdef1234567890abcdef, srs[8: 8 + 2 * fq], srs[8 + have * 2 * fq + 8: 8 + have * 2 * fq + 8 + 4 * fq], ring)
+    print(f"generated SRS: {int.from_bytes(srs[:8], 'little')} G1 powers in {(time.perf_counter() - t)*1e3:.1f} ms")
+R_SUB = bench.R_BANDERSNATCH if suite == 0 else 0x60c89ce5c263405370a08b6d0302b0bab3eedb83920ee0a677297dc392126f1
+bench.R_BANDERSNATCH = R_SUB
 t = time.perf_counter(); setup = RingSetup(ctx, srs, ring); t_setup = time.perf_counter() - t
 sks = bench.derive_scalars(b"ring-bench-sk", 0, ring, bench.R_BANDERSNATCH)
 pks = ctx.scalar_mul_base(sks)
@@ -31,7 +42,7 @@ nctx = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 if nctx > 1:
     # independent contexts (stream + SRS tables + scratch each), one host thread per context, proofs split evenly
     from concurrent.futures import ThreadPoolExecutor
-    ctxs = [ctx] + [nat.Context(0) for _ in range(nctx - 1)]
+    ctxs = [ctx] + [nat.Context(suite) for _ in range(nctx - 1)]
     setups = [setup] + [RingSetup(c, srs, ring) for c in ctxs[1:]]
     keys = [key] + [su.index(pkl) for su in setups[1:]]
     for k in keys:
