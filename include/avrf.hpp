@@ -8,6 +8,8 @@
 //   ark_vrf::Error                         -> avrf::Error            (src/lib.rs:135-147)
 //   thin::{Proof, Prover, Verifier, BatchVerifier}     -> avrf::thin::...     (src/thin.rs:43-326)
 //   pedersen::{Proof, Prover, Verifier, BatchVerifier} -> avrf::pedersen::... (src/pedersen.rs:69-426)
+//   ring::{RingSetup, RingProverKey, RingVerifierKey, RingProver, RingVerifier, Proof, Prover, Verifier,
+//          BatchVerifier}                             -> avrf::ring::...     (src/ring.rs:160-735)
 //
 // Differences forced by the device: provers/verifiers take *batches* of independent items (one GPU
 // lane each); single-item calls are batches of one.  Points are 64-byte affine x||y (see avrf.h).
@@ -167,4 +169,121 @@ class BatchVerifier {
 };
 
 }  // namespace pedersen
+
+namespace ring {
+
+using RingCommitment = std::vector<uint8_t>;   // 3 x G1 compressed (144 B BLS12-381 / 96 B BN254), src/ring.rs:125-127
+using RingBareProof = std::vector<uint8_t>;    // RingBareProof, compressed serialisation (592 B / 480 B)
+
+// ring::Proof (src/ring.rs:160-166)
+struct Proof { pedersen::Proof pedersen_proof; RingBareProof ring_proof; };
+
+// RingSetup (src/ring.rs:340-464): PCS parameters + ring context, SRS resident on the device
+class RingSetup {
+ public:
+  // RingSetup::from_pcs_params (src/ring.rs:380-393): `srs` = URS { powers_in_g1, powers_in_g2 }, serialize_uncompressed
+  static Status from_pcs_params(const Suite &su, size_t ring_size, const std::vector<uint8_t> &srs, RingSetup *out) {
+    out->reset();
+    return avrf_ring_setup_load(su.ctx(), srs.data(), srs.size(), ring_size, &out->h_);
+  }
+  // Kzg::setup with an explicit trapdoor (what from_seed / from_rand reach, src/ring.rs:359-374); g1 / g2: generator
+  // entries in the URS encoding
+  static std::vector<uint8_t> generate_pcs_params(const Suite &su, int suite_id, size_t ring_size, const Scalar &tau, const std::vector<uint8_t> &g1,
+                                                  const std::vector<uint8_t> &g2) {
+    const size_t n_g1 = avrf_ring_pcs_domain_size(suite_id, ring_size);
+    std::vector<uint8_t> out(8 + n_g1 * g1.size() + 8 + 2 * g2.size()); size_t len = 0;
+    if (avrf_ring_srs_generate(su.ctx(), tau.data(), g1.data(), g2.data(), n_g1, out.data(), out.size(), &len) != AVRF_OK)
+      throw std::invalid_argument("avrf: srs generate");
+    out.resize(len);
+    return out;
+  }
+  RingSetup() = default;
+  ~RingSetup() { reset(); }
+  RingSetup(const RingSetup &) = delete;
+  RingSetup &operator=(const RingSetup &) = delete;
+  size_t max_ring_size() const { return avrf_ring_max_ring_size(h_); }       // src/ring.rs:298-300
+  size_t proof_len() const { return avrf_ring_proof_len(h_); }
+  avrf_ring_setup *handle() const { return h_; }
+
+ private:
+  void reset() { if (h_) avrf_ring_setup_free(h_); h_ = nullptr; }
+  avrf_ring_setup *h_ = nullptr;
+};
+
+// RingProverKey + RingVerifierKey of one ring (`ring_proof::index`, src/ring.rs:399-417)
+class RingKey {
+ public:
+  // RingSetup::prover_key / verifier_key: Err(RingCapacityExceeded) when pks.len() > max_ring_size
+  static Status index(const RingSetup &setup, const std::vector<Public> &pks, RingKey *out) {
+    out->reset();
+    std::vector<uint8_t> xy; for (const Public &p : pks) xy.insert(xy.end(), p.point.begin(), p.point.end());
+    out->commitment_.assign(avrf_ring_commitment_len(setup.handle()), 0);
+    out->setup_ = &setup;
+    return avrf_ring_index(setup.handle(), xy.data(), pks.size(), &out->h_, out->commitment_.data());
+  }
+  RingKey() = default;
+  ~RingKey() { reset(); }
+  RingKey(const RingKey &) = delete;
+  RingKey &operator=(const RingKey &) = delete;
+  const RingCommitment &commitment() const { return commitment_; }          // RingVerifierKey::commitment
+  avrf_ring_key *handle() const { return h_; }
+  const RingSetup &setup() const { return *setup_; }
+
+ private:
+  void reset() { if (h_) avrf_ring_key_free(h_); h_ = nullptr; }
+  avrf_ring_key *h_ = nullptr; const RingSetup *setup_ = nullptr; RingCommitment commitment_;
+};
+
+// RingSetup::prover(prover_key, key_index) (src/ring.rs:419-426)
+struct RingProver { const RingKey *key; uint32_t key_index; bool hiding = false; };
+// RingSetup::verifier(verifier_key) / verifier_key_from_commitment (src/ring.rs:428-440,477-521)
+struct RingVerifier { const RingSetup *setup; RingCommitment commitment; };
+
+// ring::Prover::prove for Secret (src/ring.rs:211-226): Pedersen proof, then the ring proof of its blinding
+inline Proof prove(const Suite &su, const Secret &sk, const std::vector<VrfIo> &ios, const std::string &ad, const RingProver &prover) {
+  auto pp = pedersen::prove(su, sk, ios, ad);
+  Proof pr; pr.pedersen_proof = pp.first;
+  pr.ring_proof.assign(prover.key->setup().proof_len(), 0);
+  if (avrf_ring_prove(prover.key->handle(), 1, &prover.key_index, pp.second.data(), prover.hiding ? 1 : 0, pr.ring_proof.data()) != AVRF_OK)
+    throw std::invalid_argument("avrf: ring prove");
+  return pr;
+}
+// ring::Verifier::verify for Public (src/ring.rs:228-247): Pedersen verify, then the ring proof of the key commitment
+inline Status verify(const Suite &su, const std::vector<VrfIo> &ios, const std::string &ad, const Proof &proof, const RingVerifier &verifier) {
+  Status st = pedersen::verify(su, ios, ad, proof.pedersen_proof);
+  if (st) return st;
+  return avrf_ring_batch_verify(verifier.setup->handle(), 1, verifier.commitment.data(), 1, nullptr, proof.pedersen_proof.pk_com.data(),
+                                proof.ring_proof.data());
+}
+
+// ring::BatchVerifier (src/ring.rs:682-735): proofs from one or more rings sharing the SRS
+class BatchVerifier {
+ public:
+  BatchVerifier(const Suite &su, const RingVerifier &ring_verifier) : su_(su), setup_(ring_verifier.setup), ped_(su) {}
+  // push (src/ring.rs:713-723)
+  void push(const RingVerifier &verifier, const std::vector<VrfIo> &ios, const std::string &ad, const Proof &proof) {
+    uint32_t ring = 0;
+    for (; ring < rings_.size(); ring++) if (rings_[ring] == verifier.commitment) break;
+    if (ring == rings_.size()) rings_.push_back(verifier.commitment);
+    ring_of_.push_back(ring);
+    ped_.push(ios, ad, proof.pedersen_proof);
+    inst_.insert(inst_.end(), proof.pedersen_proof.pk_com.begin(), proof.pedersen_proof.pk_com.end());
+    proofs_.insert(proofs_.end(), proof.ring_proof.begin(), proof.ring_proof.end());
+  }
+  // verify (src/ring.rs:729-735): Pedersen batch first, then the ring batch
+  Status verify() const {
+    Status st = ped_.verify();
+    if (st) return st;
+    std::vector<uint8_t> coms; for (const RingCommitment &c : rings_) coms.insert(coms.end(), c.begin(), c.end());
+    return avrf_ring_batch_verify(setup_->handle(), ring_of_.size(), coms.data(), rings_.size(), ring_of_.data(), inst_.data(), proofs_.data());
+  }
+
+ private:
+  const Suite &su_; const RingSetup *setup_;
+  pedersen::BatchVerifier ped_;
+  std::vector<RingCommitment> rings_; std::vector<uint32_t> ring_of_;
+  std::vector<uint8_t> inst_, proofs_;
+};
+
+}  // namespace ring
 }  // namespace avrf

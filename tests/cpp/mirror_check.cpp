@@ -1,6 +1,8 @@
 // Exercises the C++ mirror of the reference interface (include/avrf.hpp) the way the reference's
 // own tests do (src/thin.rs:333-384 prove_verify / batch_verify; src/pedersen.rs:434-488).
-// Usage: mirror_check <suite> <sk_hex> <input_xy_hex> <ad_hex>; prints hex lines checked by pytest.
+// Usage: mirror_check <suite> <sk_hex> <input_xy_hex> <ad_hex> [<srs file> <ring pks xy hex> <key index>];
+// prints hex lines checked by pytest.  With the ring arguments it also runs ring::{prove, verify, BatchVerifier}
+// (src/ring.rs:1017-1140 prove_verify / prove_verify_batch).
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -48,5 +50,33 @@ int main(int argc, char **argv) {
   pedersen::Proof pbad = pp.first; pbad.sb[1] ^= 2;
   pb.push({io}, ad, pbad);
   printf("ped_batch_bad=%d\n", pb.verify());
+  if (argc >= 8) {
+    std::vector<uint8_t> srs; { FILE *f = fopen(argv[5], "rb"); if (!f) return 3; uint8_t buf[65536]; size_t k; while ((k = fread(buf, 1, sizeof buf, f)) > 0) srs.insert(srs.end(), buf, buf + k); fclose(f); }
+    auto ringb = unhex(argv[6]);
+    std::vector<Public> pks(ringb.size() / 64);
+    for (size_t i = 0; i < pks.size(); i++) std::copy(ringb.begin() + 64 * i, ringb.begin() + 64 * (i + 1), pks[i].point.begin());
+    ring::RingSetup setup;
+    printf("ring_setup_too_big=%d\n", ring::RingSetup::from_pcs_params(su, 1000000, srs, &setup));
+    printf("ring_setup=%d\n", ring::RingSetup::from_pcs_params(su, pks.size(), srs, &setup));
+    ring::RingKey key;
+    printf("ring_index=%d\n", ring::RingKey::index(setup, pks, &key));
+    put("ring_commitment", key.commitment());
+    ring::RingProver prover{&key, (uint32_t)atoi(argv[7])};
+    ring::RingVerifier verifier{&setup, key.commitment()};
+    ring::Proof rp = ring::prove(su, secret, {io}, ad, prover);
+    put("ring_proof", rp.ring_proof); put("ring_ped_pk_com", rp.pedersen_proof.pk_com);
+    printf("ring_verify=%d\n", ring::verify(su, {io}, ad, rp, verifier));
+    printf("ring_verify_bad_ad=%d\n", ring::verify(su, {io}, ad + "x", rp, verifier));
+    ring::Proof other = rp; other.ring_proof[other.ring_proof.size() - 40] ^= 4;
+    printf("ring_verify_bad_proof=%d\n", ring::verify(su, {io}, ad, other, verifier) != 0);
+    prover.hiding = true;
+    ring::Proof hp = ring::prove(su, secret, {io}, ad, prover);
+    printf("ring_hiding_differs=%d\n", hp.ring_proof != rp.ring_proof);
+    ring::BatchVerifier rb(su, verifier);
+    rb.push(verifier, {io}, ad, rp); rb.push(verifier, {io}, ad, hp);
+    printf("ring_batch=%d\n", rb.verify());
+    rb.push(verifier, {io}, ad, other);
+    printf("ring_batch_bad=%d\n", rb.verify() != 0);
+  }
   return 0;
 }

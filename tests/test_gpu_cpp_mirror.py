@@ -38,3 +38,22 @@ def test_mirror_reproduces_vectors(exe, golden_dir, suite):
         assert kv["ped_s"] == p["proof_s"] and kv["ped_sb"] == p["proof_sb"] and kv["ped_blinding"] == p["blinding"]
         assert [kv[k] for k in ("thin_verify", "thin_verify_bad_ad", "thin_batch_empty", "thin_batch", "thin_batch_bad")] == ["0", "1", "0", "0", "1"]
         assert [kv[k] for k in ("ped_verify", "ped_batch", "ped_batch_bad")] == ["0", "0", "1"]
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_mirror_ring(exe, golden_dir, suite):
+    """ring::{RingSetup, prover_key, Prover::prove, Verifier::verify, BatchVerifier} through the C++ mirror reproduce the
+    reference's ring vector (commitment + deterministic ring proof) and its accept / reject behaviour."""
+    v = json.load(open(os.path.join(golden_dir, NAMES[suite] + "_ring.json")))[0]
+    srs = os.path.join(golden_dir, ["bls12-381-srs-2-11-uncompressed-zcash.bin", "bn254-testing-2-9-uncompressed.bin"][suite])
+    raw = bytes.fromhex(v["ring_pks"])
+    pks = [xy(suite, raw[32 * i: 32 * i + 32]) for i in range(len(raw) // 32)]
+    idx = pks.index(xy(suite, bytes.fromhex(v["pk"])))
+    res = subprocess.run([exe, str(suite), v["sk"], xy(suite, bytes.fromhex(v["h"])).hex(), v["ad"] or "", srs, b"".join(pks).hex(), str(idx)],
+                         capture_output=True, text=True, check=True).stdout
+    kv = dict(line.split("=", 1) for line in res.strip().splitlines())
+    assert kv["ring_setup_too_big"] == "3" and kv["ring_setup"] == "0" and kv["ring_index"] == "0"
+    assert kv["ring_commitment"] == v["ring_pks_com"]
+    assert kv["ring_proof"] == v["ring_proof"]
+    assert orc.point_compress(suite, bytes.fromhex(kv["ring_ped_pk_com"])).hex() == v["proof_pk_com"]
+    assert [kv[k] for k in ("ring_verify", "ring_verify_bad_ad", "ring_verify_bad_proof", "ring_hiding_differs", "ring_batch", "ring_batch_bad")] == ["0", "1", "1", "1", "0", "1"]

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""BASELINE configs[2] shape: Pedersen-VRF Bandersnatch, 65 536 independent items on one context:
+prove (a5), independent verify (a6), one (5N+2)-term batch verification (a7); plus Thin prove / verify (a3, a4)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from ark_vrf_amd import _native as nat  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+ctx = nat.Context(0)
+sks = bench.derive_scalars(b"ped-bench-sk", 0, n, bench.R_BANDERSNATCH)
+pks = ctx.scalar_mul_base(sks)
+inputs = ctx.scalar_mul_base(bench.derive_scalars(b"ped-bench-in", 0, n, bench.R_BANDERSNATCH))
+outs = ctx.scalar_mul(sks, inputs)
+ios = b"".join(inputs[64 * j: 64 * j + 64] + outs[64 * j: 64 * j + 64] for j in range(n))
+ads = [b"ad-%d" % j for j in range(n)]
+adb, adl = b"".join(ads), [len(a) for a in ads]
+
+
+def timed(f, reps=3):
+    f()
+    t = time.perf_counter()
+    for _ in range(reps):
+        r = f()
+    return (time.perf_counter() - t) / reps, r
+
+
+pb = nat.Batch(n, ios, [1] * n, adb, adl, pks_xy=pks, sks=sks)
+t, (ped, blind) = timed(lambda: ctx.pedersen_prove(pb))
+print(f"pedersen prove        {n / t:12.0f} /s  ({t * 1e3:.2f} ms per {n})")
+vb = nat.Batch(n, ios, [1] * n, adb, adl, proofs=ped)
+t, st = timed(lambda: ctx.pedersen_verify(vb))
+print(f"pedersen verify       {n / t:12.0f} /s  ({t * 1e3:.2f} ms), all ok: {all(s == 0 for s in st) if hasattr(st, '__iter__') else st}")
+ctx.pedersen_batch_stage(vb)
+t, st = timed(lambda: ctx.pedersen_batch_run())
+print(f"pedersen batch verify {n / t:12.0f} /s  ({t * 1e3:.2f} ms), status {st}")
+t, proofs = timed(lambda: ctx.thin_prove(pb))
+print(f"thin prove            {n / t:12.0f} /s  ({t * 1e3:.2f} ms)")
+tb = nat.Batch(n, ios, [1] * n, adb, adl, pks_xy=pks, proofs=proofs)
+t, st = timed(lambda: ctx.thin_verify(tb))
+print(f"thin verify           {n / t:12.0f} /s  ({t * 1e3:.2f} ms)")
