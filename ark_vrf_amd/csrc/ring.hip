@@ -2,11 +2,13 @@
 // src/ring.rs:404,416) and the ring prover (`RingProver::prove`, src/ring.rs:220), following the
 // byte-exact specification in SURVEY.md Appendix A.5 / A.7 (w3f-ring-proof 0.0.10, un-vendored).
 //
-// Round-1 split of the work: every G1 multi-scalar multiplication (3 per index, 7 per
-// proof -- the part that is >90 % of the reference's 419 ms/proof) and every NTT run on the GPU
-// (msm.hip kernels over the device-resident SRS; k_ntt_* below); the remaining O(N) polynomial
-// bookkeeping (constraint evaluation, division, Horner, Fiat-Shamir over SHAKE128) still runs on the
-// host in this file and moves to device kernels next.
+// Split of the work: proofs are proved in lockstep chunks.  On the device: the witness columns
+// (expanded from their sparse description), all NTTs, the constraint aggregation on the 4N domain, quotient,
+// evaluations, linearisation and opening quotients (k_ring_* / k_ntt_* below) and every KZG commitment as a batched
+// fixed-base MSM (msm.hip) over window tables of the SRS -- the four witness columns in the Lagrange basis, where
+// they are sparse.  On host threads between the device rounds: the Fiat-Shamir transcript (SHAKE128) and the
+// <= 254 twisted-Edwards additions of the witness accumulator.  Verification: transcript replay and scalars on the
+// host pool, two G1 MSMs on the device, one 2-pairing check on the host (host_pairing.h).
 #include "../../include/avrf.h"
 #include "te.h"
 #include "host_g1.h"
