@@ -29,7 +29,8 @@ namespace avrf {
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "avrf: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); abort(); } } while (0)
 
 // ------------------------------------------------------------------------------------------------
-// device NTT over Fr of the pairing curve (radix-2, in place, global memory; batch of equal sizes)
+// device NTT over Fr of the pairing curve (radix-2, stages fused through LDS; batch of equal sizes);
+// tw[k] = w^k (Montgomery), k < n/2
 
 template <class F>
 __global__ void k_ntt_bitrev(uint32_t *__restrict__ data, uint32_t n, int logn, uint32_t batch) {
@@ -43,18 +44,6 @@ __global__ void k_ntt_bitrev(uint32_t *__restrict__ data, uint32_t n, int logn, 
     store_fp(p, y); store_fp(q, x);
   }
 }
-// one butterfly per lane; tw[k] = w^k (Montgomery), k < n/2
-template <class F>
-__global__ void k_ntt_stage(uint32_t *__restrict__ data, uint32_t n, uint32_t half, const uint32_t *__restrict__ tw, uint32_t batch) {
-  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t hn = n >> 1, b = t / hn, j = t - b * hn;
-  if (b >= batch) return;
-  uint32_t grp = j / half, pos = j - grp * half;
-  uint32_t i0 = grp * 2 * half + pos, i1 = i0 + half;
-  uint32_t *p = data + ((size_t)b * n + i0) * 8, *q = data + ((size_t)b * n + i1) * 8;
-  fp u = load_fp(p), v = fp_mul<F>(load_fp(q), load_fp(tw + (size_t)pos * (hn / half) * 8));
-  store_fp(p, fp_add<F>(u, v)); store_fp(q, fp_sub<F>(u, v));
-}
 template <class F>
 __global__ void k_ntt_scale(uint32_t *__restrict__ data, uint32_t total, fp k) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,15 +52,75 @@ __global__ void k_ntt_scale(uint32_t *__restrict__ data, uint32_t total, fp k) {
   store_fp(p, fp_mul<F>(load_fp(p), k));
 }
 
+// Up to 8 consecutive butterfly stages [s0, s1) on a tile held in LDS: 2^(s1-s0) rows with row stride 2^s0 elements
+// times 2^cols_log adjacent columns (<= 256 elements, whole 128-byte lines when s0 > 0).  A size-2^13 transform is
+// 2 passes over HBM instead of 13.  brev_load: the tile is gathered from the bit-reversed positions of `src` (another
+// buffer, `src_n` <= n valid elements per vector, the rest read as zero -- zero-extension of a shorter coefficient
+// vector costs nothing); otherwise src == dst is read in place.  do_scale: multiply by `scale` on the way out.
 template <class F>
-static void ntt_launch(uint32_t *d_data, uint32_t n, const uint32_t *d_tw, uint32_t batch, const fp *scale, hipStream_t st) {
-  int logn = 0; while ((1u << logn) < n) logn++;
-  hipLaunchKernelGGL(k_ntt_bitrev<F>, dim3(((size_t)n * batch + 255) / 256), dim3(256), 0, st, d_data, n, logn, batch);
-  for (uint32_t half = 1; half < n; half <<= 1)
-    hipLaunchKernelGGL(k_ntt_stage<F>, dim3(((size_t)(n / 2) * batch + 255) / 256), dim3(256), 0, st, d_data, n, half, d_tw, batch);
-  if (scale) hipLaunchKernelGGL(k_ntt_scale<F>, dim3(((size_t)n * batch + 255) / 256), dim3(256), 0, st, d_data, n * batch, *scale);
+__global__ void __launch_bounds__(128)
+k_ntt_fused(const uint32_t *__restrict__ src, uint32_t src_n, uint32_t *__restrict__ dst, uint32_t n, int logn, int s0, int s1, uint32_t cols_log,
+            const uint32_t *__restrict__ tw, int brev_load, fp scale, int do_scale) {
+  __shared__ uint32_t sh[256 * 8];
+  const uint32_t cols = 1u << cols_log, tile = (1u << (s1 - s0)) << cols_log;
+  const uint32_t tiles_per_vec = n / tile, b = blockIdx.x / tiles_per_vec, t = blockIdx.x - b * tiles_per_vec;
+  const uint32_t low_groups = (1u << s0) >> cols_log;
+  const uint32_t hi = t / low_groups, lo = t - hi * low_groups;
+  const uint32_t base = (hi << s1) + (lo << cols_log);
+  for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+    const uint32_t i = base + ((e >> cols_log) << s0) + (e & (cols - 1));
+    fp v;
+    if (brev_load) { const uint32_t j = __brev(i) >> (32 - logn); v = j < src_n ? load_fp(src + ((size_t)b * src_n + j) * 8) : fp_zero(); }
+    else v = load_fp(src + ((size_t)b * n + i) * 8);
+    store_fp(sh + e * 8, v);
+  }
+  __syncthreads();
+  for (int s = s0; s < s1; s++) {
+    const int hl = s - s0;                                             // half = 2^hl rows
+    for (uint32_t j = threadIdx.x; j < tile / 2; j += blockDim.x) {
+      const uint32_t c = j & (cols - 1), jr = j >> cols_log;
+      const uint32_t grp = jr >> hl, pos = jr & ((1u << hl) - 1);
+      const uint32_t r0 = (grp << (hl + 1)) + pos, r1 = r0 + (1u << hl);
+      const uint32_t pg = (pos << s0) + (lo << cols_log) + c;          // position inside the stage's global group
+      const fp w = load_fp(tw + ((size_t)pg << (logn - 1 - s)) * 8);
+      uint32_t *p = sh + ((r0 << cols_log) + c) * 8, *q = sh + ((r1 << cols_log) + c) * 8;
+      const fp u = load_fp(p), v = fp_mul<F>(load_fp(q), w);
+      store_fp(p, fp_add<F>(u, v)); store_fp(q, fp_sub<F>(u, v));
+    }
+    __syncthreads();
+  }
+  for (uint32_t e = threadIdx.x; e < tile; e += blockDim.x) {
+    const uint32_t i = base + ((e >> cols_log) << s0) + (e & (cols - 1));
+    fp v = load_fp(sh + e * 8);
+    if (do_scale) v = fp_mul<F>(v, scale);
+    store_fp(dst + ((size_t)b * n + i) * 8, v);
+  }
 }
 
+// (i)NTT of `batch` vectors of size n (tw = powers of the root or of its inverse; scale = 1/n for the inverse).
+// src == dst: in place (a bit-reversal pass first).  Otherwise dst = NTT(zero-extended src), src vectors of src_n <= n.
+template <class F>
+static void ntt_launch2(const uint32_t *d_src, uint32_t src_n, uint32_t *d_dst, uint32_t n, const uint32_t *d_tw, uint32_t batch, const fp *scale, hipStream_t st) {
+  int logn = 0; while ((1u << logn) < n) logn++;
+  const bool inplace = d_src == d_dst;
+  if (inplace) hipLaunchKernelGGL(k_ntt_bitrev<F>, dim3(((size_t)n * batch + 255) / 256), dim3(256), 0, st, d_dst, n, logn, batch);
+  fp one; memset(&one, 0, sizeof one);
+  for (int s0 = 0; s0 < logn;) {
+    int s1 = s0 + 8 < logn ? s0 + 8 : logn;
+    if (s1 < logn && logn - s1 < 3) s1 = logn - 3 > s0 ? logn - 3 : s1;   // keep the last pass at >= 3 stages
+    uint32_t cols_log = 8 - (uint32_t)(s1 - s0); if ((int)cols_log > s0) cols_log = (uint32_t)s0;
+    const uint32_t tile = (1u << (s1 - s0)) << cols_log;
+    const bool last = s1 == logn;
+    hipLaunchKernelGGL(k_ntt_fused<F>, dim3((unsigned)((size_t)(n / tile) * batch)), dim3(tile / 2 < 128 ? (tile / 2 ? tile / 2 : 1) : 128), 0, st,
+                       (s0 == 0 && !inplace) ? d_src : (const uint32_t *)d_dst, src_n, d_dst, n, logn, s0, s1, cols_log, d_tw,
+                       (s0 == 0 && !inplace) ? 1 : 0, (last && scale) ? *scale : one, (last && scale) ? 1 : 0);
+    s0 = s1;
+  }
+}
+template <class F>
+static void ntt_launch(uint32_t *d_data, uint32_t n, const uint32_t *d_tw, uint32_t batch, const fp *scale, hipStream_t st) {
+  ntt_launch2<F>(d_data, n, d_data, n, d_tw, batch, scale, st);
+}
 
 // ------------------------------------------------------------------------------------------------
 // PIOP constraint aggregation on the 4N domain: one lane per domain point.
@@ -841,9 +890,7 @@ template <class S, class G> struct Ring {
       hipLaunchKernelGGL(k_ring_witness_cols<F>, dim3((unsigned)((N + 255) / 256), (unsigned)n), dim3(256), 0, su->stream, (const uint32_t *)d_pos,
                          (const uint32_t *)d_cnt, (const uint32_t *)d_ki, (const uint32_t *)d_val, hiding ? (const uint32_t *)d_zk : nullptr, (uint32_t)N, (uint32_t)cap, d_coef);
       { fp sc; memcpy(sc.v, su->ninv.l, 32); ntt_launch<F>(d_coef, (uint32_t)N, su->d_tw_n_inv, (uint32_t)(4 * n), &sc, su->stream); }
-      HIP_CHECK(hipMemsetAsync(d_e4, 0, n * 4 * M * 32, su->stream));
-      HIP_CHECK(hipMemcpy2DAsync(d_e4, M * 32, d_coef, N * 32, N * 32, 4 * n, hipMemcpyDeviceToDevice, su->stream));
-      ntt_launch<F>(d_e4, (uint32_t)M, su->d_tw_4n, (uint32_t)(4 * n), nullptr, su->stream);
+      ntt_launch2<F>(d_coef, (uint32_t)N, d_e4, (uint32_t)M, su->d_tw_4n, (uint32_t)(4 * n), nullptr, su->stream);   // zero-extended to 4N
       std::vector<G1Aff> C; commit_sparse(su, d_sc, d_bi, MP, 4 * n, C);
       for (size_t p = 0; p < n; p++) for (int i = 0; i < 4; i++) st[p].C[i] = C[4 * p + i];
     }
