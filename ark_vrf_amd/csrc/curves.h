@@ -15,6 +15,7 @@ template <class S> struct TeCurve {
   static constexpr int BASE_WORDS = 24, ACC_WORDS = 32;
   static constexpr bool PREFETCH = true;
   static constexpr bool ZERO_IS_IDENTITY = false;     // (0, 1, 0, 1)
+  static constexpr bool SPLIT_REDUCE = false;
   static constexpr bool FIXED_TABLE = false;          // no fixed-base window-table mode (bases change per batch)
   static constexpr int MIN_WAVES = 3;                 // waves per SIMD asked of the register allocator in k_accumulate
   static AVRF_DI acc_t identity() { return te_identity<S>(); }
@@ -48,8 +49,9 @@ template <class C> struct G1Curve {
   struct acc_t { el x, y, zz, zzz; };
   static constexpr int BASE_WORDS = 2 * N, ACC_WORDS = 4 * N;
   static constexpr bool PREFETCH = (N <= 8);
-  static constexpr int MIN_WAVES = 2;
+  static constexpr int MIN_WAVES = 3;
   static constexpr bool ZERO_IS_IDENTITY = true;      // zz = 0; all-zero memory reads as the identity
+  static constexpr bool SPLIT_REDUCE = (N > 8);       // 381-bit: lanes of one bucket are summed by k_fixup, not inside k_accumulate
   static constexpr bool FIXED_TABLE = true;           // KZG SRS: msm_g1_fixed_device
 
   static AVRF_DI acc_t identity() { acc_t r; r.x = fn_one<Fq>(); r.y = fn_one<Fq>(); r.zz = fn_zero<N>(); r.zzz = fn_zero<N>(); return r; }
@@ -80,21 +82,24 @@ template <class C> struct G1Curve {
     r.zz = fn_mul<Fq>(V, a.zz); r.zzz = fn_mul<Fq>(W, a.zzz);
     return r;                                     // a identity (zz = 0) or y = 0 -> zz = 0: identity
   }
-  // a + (neg ? -q : q), q affine  (madd-2008-s: 8M + 2S), with the exceptional cases handled
+  // a + (neg ? -q : q), q affine  (madd-2008-s: 8M + 2S).  The exceptional cases leave early (wave-divergent but rare:
+  // the first addition into an empty accumulator, a point at infinity in the table, P = +-Q), so that neither the old
+  // accumulator nor q stays live across the main sequence -- that is what lets the 381-bit version fit its registers.
   static AVRF_DI acc_t madd(const acc_t &a, base_t q, bool neg) {
     if (neg) q.y = fn_neg<Fq>(q.y);
-    const bool q_inf = fn_is_zero(q.x) && fn_is_zero(q.y);
-    const bool a_inf = is_identity(a);
-    el U2 = fn_mul<Fq>(q.x, a.zz), S2 = fn_mul<Fq>(q.y, a.zzz);
-    el P = fn_sub<Fq>(U2, a.x), R = fn_sub<Fq>(S2, a.y);
-    el PP = fn_sqr<Fq>(P), PPP = fn_mul<Fq>(P, PP), Q = fn_mul<Fq>(a.x, PP);
-    acc_t r;
-    r.x = fn_sub<Fq>(fn_sub<Fq>(fn_sqr<Fq>(R), PPP), fn_dbl<Fq>(Q));
-    r.y = fn_sub<Fq>(fn_mul<Fq>(R, fn_sub<Fq>(Q, r.x)), fn_mul<Fq>(a.y, PPP));
-    r.zz = fn_mul<Fq>(a.zz, PP); r.zzz = fn_mul<Fq>(a.zzz, PPP);
-    if (q_inf) return a;
-    if (a_inf) return from_affine(q);
+    if (fn_is_zero(q.x) && fn_is_zero(q.y)) return a;
+    if (is_identity(a)) return from_affine(q);
+    el P = fn_sub<Fq>(fn_mul<Fq>(q.x, a.zz), a.x), R = fn_sub<Fq>(fn_mul<Fq>(q.y, a.zzz), a.y);
     if (fn_is_zero(P)) return fn_is_zero(R) ? dbl_affine(q) : identity();
+    acc_t r;
+    el PP = fn_sqr<Fq>(P);
+    r.zz = fn_mul<Fq>(a.zz, PP);
+    el Q = fn_mul<Fq>(a.x, PP);
+    el PPP = fn_mul<Fq>(P, PP);
+    r.zzz = fn_mul<Fq>(a.zzz, PPP);
+    el T = fn_mul<Fq>(a.y, PPP);
+    r.x = fn_sub<Fq>(fn_sub<Fq>(fn_sqr<Fq>(R), PPP), fn_dbl<Fq>(Q));
+    r.y = fn_sub<Fq>(fn_mul<Fq>(R, fn_sub<Fq>(Q, r.x)), T);
     return r;
   }
   // a + b  (add-2008-s: 12M + 2S)

@@ -35,6 +35,7 @@ struct MsmWorkspace {
   uint32_t *buckets = nullptr;   // nwin * nb
   uint32_t *rc = nullptr;        // nwin * (rows + cols) partial sums of the bucket reduction
   uint32_t *part = nullptr;      // 2 per wave of k_accumulate: partial sums of runs that cross a wave boundary
+                                 // (381-bit G1: one per lane of a multi-lane bucket, summed by k_fixup)
   uint32_t *bits = nullptr;      // nwin * c
   uint32_t *bits_host = nullptr; // pinned
   size_t cap_n = 0, cap_slots = 0, cap_buckets = 0, cap_bits = 0, cap_part = 0, cap_hist = 0, cap_vwin = 0;   // cap_buckets.. in bytes
@@ -42,7 +43,7 @@ struct MsmWorkspace {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double accum_ms_total = 0; uint64_t accum_launches = 0; float accum_ms_last = 0;
   MsmPlan last_plan = {0, 0, 0, 0};
-  void ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch = 1);
+  void ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch = 1, bool lane_partials = false);
   void release();
 };
 

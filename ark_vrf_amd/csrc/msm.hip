@@ -198,6 +198,13 @@ k_scatter(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int 
   }
 }
 
+// out-of-line point ops for the (cold) reduction kernels: keeps their code size and compile time down
+template <class CV> __device__ __noinline__ void cv_add_nf(typename CV::acc_t *r, const typename CV::acc_t *a, const typename CV::acc_t *b) { *r = CV::add(*a, *b); }
+template <class CV> __device__ __noinline__ void cv_dbl_nf(typename CV::acc_t *r, const typename CV::acc_t *a) { *r = CV::dbl(*a); }
+template <class CV> AVRF_DI typename CV::acc_t cv_add(const typename CV::acc_t &a, const typename CV::acc_t &b) { typename CV::acc_t r; cv_add_nf<CV>(&r, &a, &b); return r; }
+template <class CV> AVRF_DI typename CV::acc_t cv_dbl(const typename CV::acc_t &a) { typename CV::acc_t r; cv_dbl_nf<CV>(&r, &a); return r; }
+
+
 // ---------------------------------------------------------------- bucket accumulation (curve-generic)
 
 // Lane t = w * lcap + lt owns a segment of the bucket `slot` = lane_slot[t] of window w, with
@@ -241,6 +248,12 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
       }
     }
   }
+  if (CV::SPLIT_REDUCE) {
+    // 381-bit points: the general addition would set this kernel's register budget, so multi-lane buckets leave one
+    // partial per lane and k_fixup adds them (dense: every bucket has 2-3 lanes there)
+    if (live) CV::store_acc(nl == 1 ? buckets + (size_t)slot * CV::ACC_WORDS : part + (size_t)t * CV::ACC_WORDS, acc);
+    return;
+  }
   // segmented reduction by doubling: after step `off` a run head holds the sum of min(run, 2*off) lanes
   for (int off = 1; off < 64; off <<= 1) {
     uint32_t oslot = __shfl_down(slot, off);
@@ -260,7 +273,7 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
 }
 
 template <class CV>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, CV::MIN_WAVES)
 k_fixup(const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off, uint32_t nslots, uint32_t nb,
         uint32_t lcap, uint32_t seg, const uint32_t *__restrict__ part, uint32_t *__restrict__ buckets) {
   uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -268,6 +281,13 @@ k_fixup(const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off
   uint32_t cnt = cnts[slot], nl = (cnt + seg - 1) / seg;
   if (nl == 0) { if (!CV::ZERO_IS_IDENTITY) CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, CV::identity()); return; }
   uint32_t g0 = (slot / nb) * lcap + lane_off[slot];
+  if (CV::SPLIT_REDUCE) {                                 // part[] holds one partial per lane of a multi-lane bucket
+    if (nl == 1) return;
+    typename CV::acc_t acc = CV::load_acc(part + (size_t)g0 * CV::ACC_WORDS);
+    for (uint32_t r = 1; r < nl; r++) acc = CV::add(acc, CV::load_acc(part + (size_t)(g0 + r) * CV::ACC_WORDS));
+    CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, acc);
+    return;
+  }
   uint32_t wa = g0 >> 6, wb = (g0 + nl - 1) >> 6;
   if (wa == wb) return;                                  // complete inside one wave: already written
   typename CV::acc_t acc = CV::load_acc(part + (2 * (size_t)wa + ((g0 & 63) == 0 ? 0 : 1)) * CV::ACC_WORDS);
@@ -276,12 +296,6 @@ k_fixup(const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off
 }
 
 // ---------------------------------------------------------------- bucket reduction by index bits
-
-// out-of-line point ops for the (cold) reduction kernels: keeps their code size and compile time down
-template <class CV> __device__ __noinline__ void cv_add_nf(typename CV::acc_t *r, const typename CV::acc_t *a, const typename CV::acc_t *b) { *r = CV::add(*a, *b); }
-template <class CV> __device__ __noinline__ void cv_dbl_nf(typename CV::acc_t *r, const typename CV::acc_t *a) { *r = CV::dbl(*a); }
-template <class CV> AVRF_DI typename CV::acc_t cv_add(const typename CV::acc_t &a, const typename CV::acc_t &b) { typename CV::acc_t r; cv_add_nf<CV>(&r, &a, &b); return r; }
-template <class CV> AVRF_DI typename CV::acc_t cv_dbl(const typename CV::acc_t &a) { typename CV::acc_t r; cv_dbl_nf<CV>(&r, &a); return r; }
 
 template <class CV> AVRF_DI typename CV::acc_t wave_sum(typename CV::acc_t acc) {
 #pragma unroll 1
@@ -471,7 +485,7 @@ MsmPlan msm_plan(size_t n, int scalar_bits) {
 static uint32_t tile_len_for(size_t n) { return 8192; }
 static uint32_t lcap_for(size_t n, const MsmPlan &p) { return (uint32_t)(((n / (size_t)p.lpb + p.nb + 1) + 63) / 64 * 64); }
 
-void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch) {
+void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch, bool lane_partials) {
   const size_t vwin = (size_t)p.nwin * batch;           // virtual windows
   size_t nbk = vwin * p.nb, nbits = vwin * p.c;
   size_t need_n = vwin * n;
@@ -511,7 +525,7 @@ void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t b
     cap_lanes = vwin * lcap_for(n, p);
     HIP_CHECK(hipMalloc(&lane_slot, cap_lanes * 4));
   }
-  size_t need_part = 2 * (vwin * lcap_for(n, p) / 64 + 2) * acc_bytes;
+  size_t need_part = lane_partials ? vwin * lcap_for(n, p) * acc_bytes : 2 * (vwin * lcap_for(n, p) / 64 + 2) * acc_bytes;
   if (need_part > cap_part) {
     if (part) HIP_CHECK(hipFree(part));
     HIP_CHECK(hipMalloc(&part, need_part));
@@ -559,12 +573,12 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
     const int dig_nwin = (scalar_bits + 1 + table_c - 1) / table_c;
     p.c = table_c; p.nb = 1 << (table_c - 1); p.nwin = 1;
     n = n_in * (size_t)dig_nwin;                                        // one window of n_in * dig_nwin keys per vector
-    ws.ensure(n, p, (size_t)CV::ACC_WORDS * 4, batch);
+    ws.ensure(n, p, (size_t)CV::ACC_WORDS * 4, batch, CV::SPLIT_REDUCE);
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((n_in + 255) / 256), (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n_in, (uint32_t)scalar_stride, p.c, dig_nwin, ws.keys);
     remap_n = (uint32_t)n_in; remap_stride = (uint32_t)table_stride;
   }
   const size_t acc_bytes = (size_t)CV::ACC_WORDS * 4;
-  if (!table_c) ws.ensure(n, p, acc_bytes, batch);
+  if (!table_c) ws.ensure(n, p, acc_bytes, batch, CV::SPLIT_REDUCE);
   const uint32_t vwin = (uint32_t)(p.nwin * batch);
   const uint32_t nbk = vwin * p.nb, seg = (uint32_t)p.lpb;
   const uint32_t tile_len = tile_len_for(n), ntiles = (uint32_t)((n + tile_len - 1) / tile_len);
