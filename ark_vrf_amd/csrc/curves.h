@@ -18,6 +18,8 @@ template <class S> struct TeCurve {
   static constexpr bool SPLIT_REDUCE = false;
   static constexpr bool FIXED_TABLE = false;          // no fixed-base window-table mode (bases change per batch)
   static constexpr int MIN_WAVES = 3;                 // waves per SIMD asked of the register allocator in k_accumulate
+  static constexpr int RED_WAVES = 3;                 // ... and in the reduction kernels (general additions)
+  static constexpr bool INLINE_REDUCE_OPS = false;
   static AVRF_DI acc_t identity() { return te_identity<S>(); }
   static AVRF_DI acc_t madd(const acc_t &a, base_t q, bool neg) {
     using Fq = typename S::Fq;
@@ -49,7 +51,9 @@ template <class C> struct G1Curve {
   struct acc_t { el x, y, zz, zzz; };
   static constexpr int BASE_WORDS = 2 * N, ACC_WORDS = 4 * N;
   static constexpr bool PREFETCH = (N <= 8);
-  static constexpr int MIN_WAVES = 3;
+  static constexpr int MIN_WAVES = 3;                 // k_accumulate holds one accumulator + one base: 184 VGPRs at N = 12
+  static constexpr int RED_WAVES = 2;                 // the general addition (two accumulators live) needs the 256-register budget
+  static constexpr bool INLINE_REDUCE_OPS = true;     // k_wsum*: additions inlined (the asm multiplier keeps the code small)
   static constexpr bool ZERO_IS_IDENTITY = true;      // zz = 0; all-zero memory reads as the identity
   static constexpr bool SPLIT_REDUCE = (N > 8);       // 381-bit: lanes of one bucket are summed by k_fixup, not inside k_accumulate
   static constexpr bool FIXED_TABLE = true;           // KZG SRS: msm_g1_fixed_device
@@ -102,20 +106,22 @@ template <class C> struct G1Curve {
     r.y = fn_sub<Fq>(fn_mul<Fq>(R, fn_sub<Fq>(Q, r.x)), T);
     return r;
   }
-  // a + b  (add-2008-s: 12M + 2S)
+  // a + b  (add-2008-s: 12M + 2S); exceptional cases leave early so that a and b die as the sequence consumes them
   static AVRF_DI acc_t add(const acc_t &a, const acc_t &b) {
-    const bool a_inf = is_identity(a), b_inf = is_identity(b);
-    el U1 = fn_mul<Fq>(a.x, b.zz), U2 = fn_mul<Fq>(b.x, a.zz);
-    el S1 = fn_mul<Fq>(a.y, b.zzz), S2 = fn_mul<Fq>(b.y, a.zzz);
-    el P = fn_sub<Fq>(U2, U1), R = fn_sub<Fq>(S2, S1);
-    el PP = fn_sqr<Fq>(P), PPP = fn_mul<Fq>(P, PP), Q = fn_mul<Fq>(U1, PP);
-    acc_t r;
-    r.x = fn_sub<Fq>(fn_sub<Fq>(fn_sqr<Fq>(R), PPP), fn_dbl<Fq>(Q));
-    r.y = fn_sub<Fq>(fn_mul<Fq>(R, fn_sub<Fq>(Q, r.x)), fn_mul<Fq>(S1, PPP));
-    r.zz = fn_mul<Fq>(fn_mul<Fq>(a.zz, b.zz), PP); r.zzz = fn_mul<Fq>(fn_mul<Fq>(a.zzz, b.zzz), PPP);
-    if (a_inf) return b;
-    if (b_inf) return a;
+    if (is_identity(a)) return b;
+    if (is_identity(b)) return a;
+    el U1 = fn_mul<Fq>(a.x, b.zz), P = fn_sub<Fq>(fn_mul<Fq>(b.x, a.zz), U1);
+    el S1 = fn_mul<Fq>(a.y, b.zzz), R = fn_sub<Fq>(fn_mul<Fq>(b.y, a.zzz), S1);
     if (fn_is_zero(P)) return fn_is_zero(R) ? dbl(a) : identity();
+    acc_t r;
+    el PP = fn_sqr<Fq>(P);
+    r.zz = fn_mul<Fq>(fn_mul<Fq>(a.zz, b.zz), PP);
+    el Q = fn_mul<Fq>(U1, PP);
+    el PPP = fn_mul<Fq>(P, PP);
+    r.zzz = fn_mul<Fq>(fn_mul<Fq>(a.zzz, b.zzz), PPP);
+    el T = fn_mul<Fq>(S1, PPP);
+    r.x = fn_sub<Fq>(fn_sub<Fq>(fn_sqr<Fq>(R), PPP), fn_dbl<Fq>(Q));
+    r.y = fn_sub<Fq>(fn_mul<Fq>(R, fn_sub<Fq>(Q, r.x)), T);
     return r;
   }
   static AVRF_DI base_t load_base(const uint32_t *p) { base_t r; r.x = fn_load<N>(p); r.y = fn_load<N>(p + N); return r; }

@@ -201,8 +201,14 @@ k_scatter(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int 
 // out-of-line point ops for the (cold) reduction kernels: keeps their code size and compile time down
 template <class CV> __device__ __noinline__ void cv_add_nf(typename CV::acc_t *r, const typename CV::acc_t *a, const typename CV::acc_t *b) { *r = CV::add(*a, *b); }
 template <class CV> __device__ __noinline__ void cv_dbl_nf(typename CV::acc_t *r, const typename CV::acc_t *a) { *r = CV::dbl(*a); }
-template <class CV> AVRF_DI typename CV::acc_t cv_add(const typename CV::acc_t &a, const typename CV::acc_t &b) { typename CV::acc_t r; cv_add_nf<CV>(&r, &a, &b); return r; }
-template <class CV> AVRF_DI typename CV::acc_t cv_dbl(const typename CV::acc_t &a) { typename CV::acc_t r; cv_dbl_nf<CV>(&r, &a); return r; }
+template <class CV> AVRF_DI typename CV::acc_t cv_add(const typename CV::acc_t &a, const typename CV::acc_t &b) {
+  if (CV::INLINE_REDUCE_OPS) return CV::add(a, b);
+  typename CV::acc_t r; cv_add_nf<CV>(&r, &a, &b); return r;
+}
+template <class CV> AVRF_DI typename CV::acc_t cv_dbl(const typename CV::acc_t &a) {
+  if (CV::INLINE_REDUCE_OPS) return CV::dbl(a);
+  typename CV::acc_t r; cv_dbl_nf<CV>(&r, &a); return r;
+}
 
 
 // ---------------------------------------------------------------- bucket accumulation (curve-generic)
@@ -273,7 +279,7 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
 }
 
 template <class CV>
-__global__ void __launch_bounds__(256, CV::MIN_WAVES)
+__global__ void __launch_bounds__(256, CV::RED_WAVES)
 k_fixup(const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off, uint32_t nslots, uint32_t nb,
         uint32_t lcap, uint32_t seg, const uint32_t *__restrict__ part, uint32_t *__restrict__ buckets) {
   uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -382,7 +388,7 @@ k_horner(const uint32_t *__restrict__ bits, uint32_t nbits, uint32_t batch, uint
 // (inside one wave) shares a set; lane g owns the m = nb >> lps_log consecutive buckets above g*m (running sums: 2 adds
 // per bucket); then sum_g W_g + m * sum_g g * S_g by a group suffix scan and a group reduction.
 template <class CV>
-__global__ void __launch_bounds__(256, CV::MIN_WAVES)
+__global__ void __launch_bounds__(256, CV::RED_WAVES)
 k_wsum(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t nsets, uint32_t lps_log, uint32_t *__restrict__ out) {
   using acc_t = typename CV::acc_t;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -420,7 +426,7 @@ k_wsum(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t nsets, uint32
 // group owns m = nb / (64 wps) consecutive buckets; each wave reduces to (V_w, Y_w) = (sum_l W_l + m l S_l, sum_l S_l)
 // as above, and lane 0 finishes sum_w V_w + 64 m sum_w w Y_w over the wps pairs left in LDS.
 template <class CV>
-__global__ void __launch_bounds__(256, CV::MIN_WAVES)
+__global__ void __launch_bounds__(256, CV::RED_WAVES)
 k_wsum_blk(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t *__restrict__ out) {
   using acc_t = typename CV::acc_t;
   extern __shared__ uint32_t lds[];                                            // wps x {V, Y}
