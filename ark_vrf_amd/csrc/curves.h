@@ -55,7 +55,7 @@ template <class C> struct G1Curve {
   static constexpr int RED_WAVES = 2;                 // the general addition (two accumulators live) needs the 256-register budget
   static constexpr bool INLINE_REDUCE_OPS = true;     // k_wsum*: additions inlined (the asm multiplier keeps the code small)
   static constexpr bool ZERO_IS_IDENTITY = true;      // zz = 0; all-zero memory reads as the identity
-  static constexpr bool SPLIT_REDUCE = (N > 8);       // 381-bit: lanes of one bucket are summed by k_fixup, not inside k_accumulate
+  static constexpr bool SPLIT_REDUCE = false;         // 381-bit: lanes of one bucket are summed by k_fixup, not inside k_accumulate
   static constexpr bool FIXED_TABLE = true;           // KZG SRS: msm_g1_fixed_device
 
   static AVRF_DI acc_t identity() { acc_t r; r.x = fn_one<Fq>(); r.y = fn_one<Fq>(); r.zz = fn_zero<N>(); r.zzz = fn_zero<N>(); return r; }
