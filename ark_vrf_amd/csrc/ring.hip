@@ -489,6 +489,13 @@ struct avrf_ring_key {
   uint32_t *d_fixed_coef = nullptr;                   // px | py | sel coefficients on the device (3 x N)
 };
 
+// VerifierKeyBuilder (src/ring.rs:539-637): the ring commitment under construction
+struct avrf_ring_vk_builder {
+  avrf_ring_setup *setup;
+  size_t curr = 0;                                    // keys appended so far
+  G1Aff C[3];                                         // commitments to the x, y and selector columns of the partial ring
+};
+
 extern "C" hipStream_t avrf_ctx_stream_(avrf_ctx *c);
 extern "C" int avrf_ctx_suite_(avrf_ctx *c);
 extern "C" int avrf_ctx_device_(avrf_ctx *c);
@@ -724,6 +731,51 @@ template <class S, class G> struct Ring {
     vk.insert(vk.end(), su->g2_raw.begin(), su->g2_raw.end());
     for (int i = 0; i < 3; i++) g1_encode<G>(k->C[i], false, vk);
     t.append(vk);
+  }
+
+  // ---- VerifierKeyBuilder (src/ring.rs:539-637): start from the all-padding ring, then every appended key replaces a
+  // padding point: C_x += (x - x_pad) L_i(tau) G, C_y likewise -- two sparse MSMs over the Lagrange-basis table per append
+  static G1Aff g1_add_aff(const G1Aff &a, const G1Aff &b) {
+    using HG = typename T::HG; using FqN = typename T::FqN;
+    auto lift = [](const G1Aff &p) { typename HG::Pt q = HG::identity();
+      if (!p.inf) { typename FqN::El x, y; memcpy(x.l, p.xy, FQB); memcpy(y.l, p.xy + FQB, FQB); q.x = FqN::to_mont(x); q.y = FqN::to_mont(y); q.zz = FqN::one(); q.zzz = FqN::one(); }
+      return q; };
+    typename HG::Pt r = HG::add(lift(a), lift(b));
+    G1Aff o; memset(&o, 0, sizeof o); HG::to_affine_bytes(r, o.xy);
+    o.inf = true; for (int i = 0; i < 2 * FQB; i++) if (o.xy[i]) o.inf = false;
+    return o;
+  }
+  static int builder_new(avrf_ring_setup *su, avrf_ring_vk_builder **out) {
+    avrf_ring_key *k = nullptr;
+    int st = index(su, nullptr, 0, &k);                                // the ring of padding points only
+    if (st) return st;
+    avrf_ring_vk_builder *b = new avrf_ring_vk_builder(); b->setup = su;
+    for (int i = 0; i < 3; i++) b->C[i] = k->C[i];
+    if (k->d_fixed4) (void)hipFree(k->d_fixed4); if (k->d_fixed_coef) (void)hipFree(k->d_fixed_coef); delete k;
+    ensure_lagrange(su);
+    *out = b;
+    return AVRF_OK;
+  }
+  static int builder_append(avrf_ring_vk_builder *b, const uint8_t *pks_xy, size_t n) {
+    avrf_ring_setup *su = b->setup;
+    if (n > su->keyset - b->curr) return AVRF_RING_CAPACITY_EXCEEDED;   // src/ring.rs:606-608; nothing appended
+    if (!n) return AVRF_OK;
+    const H256 padx = Fr::from32(S::PAD_X), pady = Fr::from32(S::PAD_Y);
+    std::vector<H256> sc(2 * n); std::vector<uint32_t> bi(2 * n);
+    for (size_t i = 0; i < n; i++) {
+      H256 x = Fr::load_le(pks_xy + 64 * i), y = Fr::load_le(pks_xy + 64 * i + 32);
+      if (Fr::geq_p(x) || Fr::geq_p(y)) return AVRF_INVALID_DATA;
+      sc[i] = Fr::from_mont(Fr::sub(Fr::to_mont(x), padx)); sc[n + i] = Fr::from_mont(Fr::sub(Fr::to_mont(y), pady));
+      bi[i] = bi[n + i] = (uint32_t)(b->curr + i);
+    }
+    uint32_t *d = dev_scratch(su, 1, 2 * n * 36);
+    uint32_t *d_sc = d, *d_bi = d + 2 * n * 8;
+    HIP_CHECK(hipMemcpyAsync(d_sc, sc.data(), 2 * n * 32, hipMemcpyHostToDevice, su->stream));
+    HIP_CHECK(hipMemcpyAsync(d_bi, bi.data(), 2 * n * 4, hipMemcpyHostToDevice, su->stream));
+    std::vector<G1Aff> D; commit_sparse(su, d_sc, d_bi, n, 2, D);
+    b->C[0] = g1_add_aff(b->C[0], D[0]); b->C[1] = g1_add_aff(b->C[1], D[1]);
+    b->curr += n;
+    return AVRF_OK;
   }
 
   // ---- RingProver::prove with blinding disabled (A.7) for a batch of proofs over one ring, in lockstep:
@@ -1198,6 +1250,27 @@ int avrf_ring_index(avrf_ring_setup *su, const uint8_t *pks_xy, size_t n_keys, a
   return st;
 }
 void avrf_ring_key_free(avrf_ring_key *k) { if (!k) return; if (k->d_fixed4) (void)hipFree(k->d_fixed4); if (k->d_fixed_coef) (void)hipFree(k->d_fixed_coef); delete k; }
+
+int avrf_ring_vk_builder_new(avrf_ring_setup *su, avrf_ring_vk_builder **out) {
+  if (!su || !out) return AVRF_ERR_BAD_ARG;
+  *out = nullptr;
+  if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
+  return su->suite == 0 ? RingB::builder_new(su, out) : RingJ::builder_new(su, out);
+}
+void avrf_ring_vk_builder_free(avrf_ring_vk_builder *b) { delete b; }
+size_t avrf_ring_vk_builder_free_slots(const avrf_ring_vk_builder *b) { return b ? b->setup->keyset - b->curr : 0; }
+int avrf_ring_vk_builder_append(avrf_ring_vk_builder *b, const uint8_t *pks_xy, size_t n) {
+  if (!b || (n && !pks_xy)) return AVRF_ERR_BAD_ARG;
+  if (hipSetDevice(b->setup->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
+  return b->setup->suite == 0 ? RingB::builder_append(b, pks_xy, n) : RingJ::builder_append(b, pks_xy, n);
+}
+int avrf_ring_vk_builder_finalize(const avrf_ring_vk_builder *b, uint8_t *commitment_out) {
+  if (!b || !commitment_out) return AVRF_ERR_BAD_ARG;
+  std::vector<uint8_t> o;
+  for (int i = 0; i < 3; i++) { if (b->setup->suite == 0) g1_encode<G1Bls12381>(b->C[i], true, o); else g1_encode<G1Bn254>(b->C[i], true, o); }
+  memcpy(commitment_out, o.data(), o.size());
+  return AVRF_OK;
+}
 
 int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const uint8_t *blindings, int blinding_mode, uint8_t *proofs_out) {
   if (!k || (n && (!key_index || !blindings || !proofs_out))) return AVRF_ERR_BAD_ARG;

@@ -74,6 +74,45 @@ class RingSetup:
             pass
 
 
+class VerifierKeyBuilder:
+    """VerifierKeyBuilder (src/ring.rs:539-637): ring commitment built by appending keys in batches."""
+
+    def __init__(self, setup):
+        L = nat.lib()
+        L.avrf_ring_vk_builder_free_slots.restype = C.c_size_t
+        self.setup = setup
+        self._h = C.c_void_p()
+        st = L.avrf_ring_vk_builder_new(setup._h, C.byref(self._h))
+        if st != nat.OK:
+            self._h = None
+            raise nat.AvrfError(f"avrf_ring_vk_builder_new -> {st}")
+
+    def free_slots(self):
+        return nat.lib().avrf_ring_vk_builder_free_slots(self._h)
+
+    def append(self, pks_xy):
+        """Returns the status (0 ok, 3 RingCapacityExceeded: nothing appended, 2 InvalidData)."""
+        return nat.lib().avrf_ring_vk_builder_append(self._h, nat._u8(b"".join(pks_xy)), C.c_size_t(len(pks_xy)))
+
+    def finalize(self):
+        out = (C.c_uint8 * self.setup.commitment_len)()
+        st = nat.lib().avrf_ring_vk_builder_finalize(self._h, out)
+        if st != nat.OK:
+            raise nat.AvrfError(f"avrf_ring_vk_builder_finalize -> {st}")
+        return bytes(out)
+
+    def close(self):
+        if self._h:
+            nat.lib().avrf_ring_vk_builder_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def ring_batch_verify(setup, ring_commitments, ring_of_item, instances_xy, ring_proofs):
     """RingVerifier::verify / RingBatchVerifier (src/ring.rs:242,682-735) on bare ring proofs.
     ring_commitments: list of compressed RingCommitment bytes; ring_of_item: list of indices into it (or None);

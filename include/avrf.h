@@ -171,6 +171,18 @@ size_t avrf_ring_commitment_len(const avrf_ring_setup *setup);  /* 144 / 96 */
 int avrf_ring_index(avrf_ring_setup *setup, const uint8_t *pks_xy, size_t n_keys, avrf_ring_key **out, uint8_t *commitment_out);
 void avrf_ring_key_free(avrf_ring_key *key);
 
+/* VerifierKeyBuilder (src/ring.rs:539-637): incremental construction of a ring commitment.  `new` = the ring of padding
+ * points (VerifierKeyBuilder::new; the Lagrange-basis SRS the reference passes as RingBuilderPcsParams / SrsLookup is
+ * derived from the setup's SRS on the device), `append` adds keys in order (AVRF_RING_CAPACITY_EXCEEDED and nothing
+ * appended when they do not fit, AVRF_INVALID_DATA for a non-canonical coordinate), `finalize` writes the compressed
+ * RingCommitment -- equal to avrf_ring_index's for the same key list. */
+typedef struct avrf_ring_vk_builder avrf_ring_vk_builder;
+int avrf_ring_vk_builder_new(avrf_ring_setup *setup, avrf_ring_vk_builder **out);
+void avrf_ring_vk_builder_free(avrf_ring_vk_builder *builder);
+size_t avrf_ring_vk_builder_free_slots(const avrf_ring_vk_builder *builder);          /* src/ring.rs:584-586 */
+int avrf_ring_vk_builder_append(avrf_ring_vk_builder *builder, const uint8_t *pks_xy, size_t n);   /* :598-622 */
+int avrf_ring_vk_builder_finalize(const avrf_ring_vk_builder *builder, uint8_t *commitment_out);   /* :625-627 */
+
 /* RingProver::prove (the `ring_prover.prove(blinding)` half of ring::Prover::prove, src/ring.rs:219-221) for n
  * proofs over one ring: key_index[i] is the prover's position in the ring, blindings[i] the secret blinding
  * returned by avrf_pedersen_prove.  blinding_mode 0 = RingContext::new_without_blinding (deterministic,

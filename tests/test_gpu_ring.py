@@ -268,3 +268,32 @@ def test_srs_generate(env, suite):
         assert R.verify(prm, srs, fixed, proof, R.te_decode(s, ped[:32]))
     with pytest.raises(Exception):
         srs_generate(ctx, suite, s.r, g1, g2, 8)                           # tau must be < r
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_verifier_key_builder(env, suite):
+    """VerifierKeyBuilder (src/ring.rs:539-637; reference test `verifier_key_builder`, src/ring.rs:1224-1290): keys appended
+    in batches give the commitment of `verifier_key(keys)` -- here the reference vector's `ring_pks_com` and
+    avrf_ring_index's -- at every stage; capacity is enforced and a failed append changes nothing."""
+    from ark_vrf_amd.ring import VerifierKeyBuilder
+    ctx, setup, vs, srs = env[suite]
+    v = vs[0]
+    raw = bytes.fromhex(v["ring_pks"])
+    pks = [xy(suite, raw[32 * i: 32 * i + 32]) for i in range(len(raw) // 32)]
+    b = VerifierKeyBuilder(setup)
+    assert b.free_slots() == setup.max_ring_size
+    assert b.finalize() == setup.index([]).commitment                     # empty ring = all padding
+    assert b.append(pks[:3]) == 0 and b.free_slots() == setup.max_ring_size - 3
+    assert b.finalize() == setup.index(pks[:3]).commitment
+    assert b.append([]) == 0
+    assert b.append(pks[3:]) == 0
+    assert b.finalize().hex() == v["ring_pks_com"]
+    assert b.append(pks * 64) == 3                                         # does not fit: nothing appended
+    assert b.finalize().hex() == v["ring_pks_com"]
+    fill = [pks[i % len(pks)] for i in range(b.free_slots())]
+    assert b.append(fill) == 0 and b.free_slots() == 0
+    assert b.finalize() == setup.index(pks + fill).commitment
+    assert b.append(pks[:1]) == 3
+    bad = bytes([0xff] * 32) + pks[0][32:]
+    b2 = VerifierKeyBuilder(setup)
+    assert b2.append([bad]) == 2 and b2.free_slots() == setup.max_ring_size
