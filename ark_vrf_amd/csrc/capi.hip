@@ -66,15 +66,26 @@ struct avrf_ctx {
   DevBuf d_pks, d_ios, d_io_off, d_ads, d_ad_off, d_proofs, d_sks;
   std::vector<uint8_t> h_resp;    // host copy of the response scalars (s [, sb]) for the weight transcript
   DevBuf d_c, d_z, d_flags, d_scalars, d_pre, d_gpart, d_misc, d_out, d_status;
+  DevBuf d_fixed; bool fixed_ready = false;   // fixed-base tables of G and BLINDING_BASE (provers, scalar_mul_base), built on first use
   PinBuf h_c, h_flags, h_io;
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+
+// fixed-base tables for the provers: built once per context, on the context's stream
+static int ensure_fixed(avrf_ctx *c) {
+  if (c->fixed_ready) return AVRF_OK;
+  if (c->d_fixed.ensure((size_t)2 * 32 * 256 * sizeof(te_pre_raw)) != hipSuccess) return AVRF_ERR_NO_DEVICE;
+  launch_fixed_table(c->suite, c->d_fixed.as<te_pre_raw>(), c->stream);
+  c->fixed_ready = true;
+  return AVRF_OK;
+}
 
 static BatchDev batch_of(avrf_ctx *c) {
   BatchDev b;
   b.pks_xy = c->d_pks.as<uint8_t>(); b.ios_xy = c->d_ios.as<uint8_t>(); b.io_off = c->d_io_off.as<uint32_t>();
   b.ads = c->d_ads.as<uint8_t>(); b.ad_off = c->d_ad_off.as<uint32_t>(); b.proofs = c->d_proofs.as<uint8_t>();
   b.sks = c->d_sks.as<uint8_t>(); b.n = (uint32_t)c->n;
+  b.fixed = (const te_pre *)c->d_fixed.p;
   return b;
 }
 
@@ -113,7 +124,7 @@ void avrf_ctx_destroy(avrf_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   c->ws.release();
   DevBuf *bufs[] = {&c->d_pks, &c->d_ios, &c->d_io_off, &c->d_ads, &c->d_ad_off, &c->d_proofs, &c->d_sks, &c->d_c, &c->d_z,
-                    &c->d_flags, &c->d_scalars, &c->d_pre, &c->d_gpart, &c->d_misc, &c->d_out, &c->d_status};
+                    &c->d_flags, &c->d_scalars, &c->d_pre, &c->d_gpart, &c->d_misc, &c->d_out, &c->d_status, &c->d_fixed};
   for (DevBuf *b : bufs) b->release();
   c->h_c.release(); c->h_flags.release(); c->h_io.release();
   (void)hipStreamDestroy(c->stream);
@@ -434,6 +445,7 @@ int avrf_pedersen_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t
   int st = stage(c, 2, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, nullptr);
   if (st || !n) return st;
   c->staged_kind = 0;
+  if (int fs = ensure_fixed(c)) return fs;
   BatchDev b = batch_of(c); if (!pks_xy) b.pks_xy = nullptr;
   HIP_TRY(c->d_out.ensure(n * 256)); HIP_TRY(c->d_misc.ensure(n * 32));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
@@ -471,8 +483,9 @@ static int smul_common(avrf_ctx *c, size_t n, const uint8_t *scalars, const uint
   HIP_TRY(hipMemcpyAsync(c->d_sks.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
   if (points_xy) { HIP_TRY(c->d_misc.ensure(n * 64)); HIP_TRY(hipMemcpyAsync(c->d_misc.p, points_xy, n * 64, hipMemcpyHostToDevice, c->stream)); }
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  if (!points_xy) { if (int fs = ensure_fixed(c)) return fs; }
   launch_smul(c->suite, c->d_sks.as<uint8_t>(), points_xy ? c->d_misc.as<uint8_t>() : nullptr, (uint32_t)n, c->d_out.as<uint8_t>(),
-              c->d_flags.as<uint32_t>(), c->stream);
+              c->d_flags.as<uint32_t>(), c->d_fixed.as<te_pre_raw>(), c->stream);
   HIP_TRY(hipMemcpyAsync(out_xy, c->d_out.p, n * 64, hipMemcpyDeviceToHost, c->stream));
   int f = read_flags(c);
   if (f < 0) return AVRF_ERR_NO_DEVICE;

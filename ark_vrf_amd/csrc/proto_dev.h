@@ -22,9 +22,6 @@
 #define fp_from_mont fp_from_mont_nf
 #define fp_is_negative_mont fp_is_negative_mont_nf
 #define fp_from_wide_mont fp_from_wide_mont_nf
-#define te_madd te_madd_nf
-#define te_add te_add_nf
-#define te_dbl te_dbl_nf
 #define te_to_aff te_to_aff_nf
 #define te_make_pre te_make_pre_nf
 
@@ -46,6 +43,7 @@ struct BatchDev {
   const uint8_t *proofs;    // thin: n x 96 (R_xy || s); pedersen: n x 256
   const uint8_t *sks;       // n x 32 (provers only)
   uint32_t n;
+  const te_pre *fixed;      // fixed-base tables of the suite's G and BLINDING_BASE: [2][32][256] (provers only)
 };
 struct Seed64 { uint64_t w[8]; };  // a SHA-512 digest as big-endian words
 
@@ -153,6 +151,18 @@ template <class S> AVRF_DN te_ext te_smul(te_pre p, fp k, int nbits) {
   for (int i = nbits - 1; i >= 0; i--) {
     acc = te_dbl<S>(acc);
     if ((k.v[i >> 5] >> (i & 31)) & 1) acc = te_madd<S>(acc, p);
+  }
+  return acc;
+}
+// Fixed-base table (one per context, built by k_fixed_table): tab[(base * 32 + w) * 256 + d] = d * 2^(8w) * P,
+// base 0 = the suite generator G, 1 = BLINDING_BASE; d = 0 unused.  k * P is then at most 32 mixed additions.
+enum { FIXED_G = 0, FIXED_B = 1, FIXED_TABLE_POINTS = 2 * 32 * 256 };
+template <class S> AVRF_DN te_ext te_smul_fixed(const te_pre *tab, int base, fp k) {
+  te_ext acc = te_identity<S>();
+  const te_pre *t = tab + (size_t)base * 32 * 256;
+  for (int w = 0; w < 32; w++) {
+    uint32_t d = (k.v[w >> 2] >> (8 * (w & 3))) & 255u;
+    if (d) acc = te_madd<S>(acc, load_pre(t + w * 256 + d));
   }
   return acc;
 }

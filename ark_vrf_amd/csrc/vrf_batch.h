@@ -25,7 +25,10 @@ void launch_ped_terms(int suite, const BatchDev &b, const Seed64 &seed, const ui
                       uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st);
 
 // independent per-item kernels (vrf_single.hip)
-void launch_smul(int suite, const uint8_t *d_scalars, const uint8_t *d_points_xy, uint32_t n, uint8_t *d_out, uint32_t *d_flags, hipStream_t st);
+// fixed-base tables of G and BLINDING_BASE (2 x 32 x 256 te_pre = 1.5 MB), see proto_dev.h te_smul_fixed
+void launch_fixed_table(int suite, te_pre_raw *d_tab, hipStream_t st);
+void launch_smul(int suite, const uint8_t *d_scalars, const uint8_t *d_points_xy, uint32_t n, uint8_t *d_out, uint32_t *d_flags,
+                 const te_pre_raw *d_fixed, hipStream_t st);
 void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st);
 void launch_thin_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
 void launch_ped_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st);

@@ -11,6 +11,8 @@
 // 389-419); any summation order gives the same group element.
 #include "proto_dev.h"
 
+namespace avrf { struct te_pre_raw; }   // msm.h: the 96-byte storage form of te_pre
+
 namespace avrf {
 
 // (I_m, O_m) = sum_i z_i * (I_i, O_i) over `m` caller pairs; z stream from `dseed`.
@@ -44,11 +46,24 @@ template <class S> AVRF_DI void to_aff2(const te_ext &p, const te_ext &q, te_aff
 
 // ---------------------------------------------------------------- scalar multiplication
 
-// out = k * P (P = G when points_xy == nullptr)
+// tab[(base * 32 + w) * 256 + d] = d * 2^(8w) * P for P = G (base 0) and BLINDING_BASE (base 1); one lane per entry
+template <class S>
+__global__ void __launch_bounds__(128)
+k_fixed_table(te_pre *__restrict__ tab) {
+  uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= FIXED_TABLE_POINTS) return;
+  const uint32_t d = id & 255u, w = (id >> 8) & 31u, base = id >> 13;
+  if (!d) return;
+  fp k = fp_zero(); k.v[w >> 2] = d << (8 * (w & 3));
+  te_aff r = te_to_aff<S>(te_smul<S>(base ? b_pre<S>() : g_pre<S>(), k, 8 * (int)w + 8));
+  store_pre(tab + id, te_make_pre<S>(r.x, r.y));
+}
+
+// out = k * P (P = G when points_xy == nullptr: fixed-base table)
 template <class S>
 __global__ void __launch_bounds__(128)
 k_smul(const uint8_t *__restrict__ scalars, const uint8_t *__restrict__ points_xy, uint32_t n, uint8_t *__restrict__ out_xy,
-       uint32_t *__restrict__ flags) {
+       uint32_t *__restrict__ flags, const te_pre *__restrict__ fixed) {
   using Fr = typename S::Fr;
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
@@ -59,8 +74,8 @@ k_smul(const uint8_t *__restrict__ scalars, const uint8_t *__restrict__ points_x
     fp x = fp_load_le(points_xy + 64 * (size_t)j), y = fp_load_le(points_xy + 64 * (size_t)j + 32);
     f |= point_flags<S>(x, y) & FLAG_RANGE;
     p = pre_from_xy<S>(points_xy + 64 * (size_t)j);
-  } else p = g_pre<S>();
-  te_aff r = te_to_aff<S>(te_smul<S>(p, k, Fr::BITS));
+  }
+  te_aff r = te_to_aff<S>(points_xy ? te_smul<S>(p, k, Fr::BITS) : te_smul_fixed<S>(fixed, FIXED_G, k));
   store_xy<S>(out_xy + 64 * (size_t)j, r);
   if (f) atomicOr(flags, f);
 }
@@ -169,12 +184,12 @@ k_ped_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ 
   fp bl_plain = fp_from_mont<Fr>(bl);
   te_pre pkp;
   if (b.pks_xy) pkp = pre_from_xy<S>(b.pks_xy + 64 * (size_t)j);
-  else pkp = pre_from_aff<S>(te_to_aff<S>(te_smul<S>(g_pre<S>(), sk, Fr::BITS)));
-  te_aff yb = te_to_aff<S>(te_madd<S>(te_smul<S>(b_pre<S>(), bl_plain, Fr::BITS), pkp));   // :148-149
+  else pkp = pre_from_aff<S>(te_to_aff<S>(te_smul_fixed<S>(b.fixed, FIXED_G, sk)));
+  te_aff yb = te_to_aff<S>(te_madd<S>(te_smul_fixed<S>(b.fixed, FIXED_B, bl_plain), pkp));   // :148-149
   absorb_point_mont<S>(t, yb);                                                  // :152
   fp k = nonce<S>(sk, t), kb = nonce<S>(bl_plain, t);                           // :155-156
   fp k_plain = fp_from_mont<Fr>(k);
-  te_ext R = te_smul2<S>(g_pre<S>(), k_plain, b_pre<S>(), fp_from_mont<Fr>(kb), Fr::BITS);   // :159-161
+  te_ext R = te_add<S>(te_smul_fixed<S>(b.fixed, FIXED_G, k_plain), te_smul_fixed<S>(b.fixed, FIXED_B, fp_from_mont<Fr>(kb)));   // :159-161
   te_ext OK = have_input ? te_smul<S>(ip, k_plain, Fr::BITS) : te_identity<S>();             // :164
   te_aff ra, oka; to_aff2<S>(R, OK, ra, oka);                                   // :166-167
   Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, ra); absorb_point_mont<S>(tc, oka);
@@ -288,9 +303,13 @@ k_compress(const uint8_t *__restrict__ in_xy, uint32_t n, uint8_t *__restrict__ 
     else hipLaunchKernelGGL(KERNEL<SuiteBabyJubJub>, grid, block, 0, st, __VA_ARGS__);                \
   } while (0)
 
-void launch_smul(int suite, const uint8_t *d_scalars, const uint8_t *d_points_xy, uint32_t n, uint8_t *d_out, uint32_t *d_flags, hipStream_t st) {
+void launch_fixed_table(int suite, struct te_pre_raw *d_tab, hipStream_t st) {
+  AVRF_DISPATCH(suite, k_fixed_table, dim3((FIXED_TABLE_POINTS + 127) / 128), dim3(128), st, (te_pre *)d_tab);
+}
+void launch_smul(int suite, const uint8_t *d_scalars, const uint8_t *d_points_xy, uint32_t n, uint8_t *d_out, uint32_t *d_flags,
+                 const struct te_pre_raw *d_fixed, hipStream_t st) {
   if (!n) return;
-  AVRF_DISPATCH(suite, k_smul, dim3((n + 127) / 128), dim3(128), st, d_scalars, d_points_xy, n, d_out, d_flags);
+  AVRF_DISPATCH(suite, k_smul, dim3((n + 127) / 128), dim3(128), st, d_scalars, d_points_xy, n, d_out, d_flags, (const te_pre *)d_fixed);
 }
 void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st) {
   if (!b.n) return;
