@@ -145,12 +145,18 @@ template <class S> AVRF_DI te_pre pre_from_xy(const uint8_t *xy) {
   using Fq = typename S::Fq;
   return te_make_pre<S>(fp_to_mont<Fq>(fp_load_le(xy)), fp_to_mont<Fq>(fp_load_le(xy + 32)));
 }
-// k * P, k a plain integer of `nbits` bits, binary double-and-add (MSB first)
+// k * P, k a plain integer of `nbits` bits: fixed 4-bit windows over a 16-entry per-lane table (private memory).
+// (Binary double-and-add diverges on every bit, so a wave pays doubling + addition for all 253 of them; the window
+// form pays 4 doublings + 1 addition per nibble.)
 template <class S> AVRF_DN te_ext te_smul(te_pre p, fp k, int nbits) {
+  te_ext tab[16];
+  tab[0] = te_identity<S>(); tab[1] = te_from_pre<S>(p);
+  for (int i = 2; i < 16; i++) tab[i] = te_madd<S>(tab[i - 1], p);
   te_ext acc = te_identity<S>();
-  for (int i = nbits - 1; i >= 0; i--) {
-    acc = te_dbl<S>(acc);
-    if ((k.v[i >> 5] >> (i & 31)) & 1) acc = te_madd<S>(acc, p);
+  for (int w = (nbits + 3) / 4 - 1; w >= 0; w--) {
+    acc = te_dbl<S>(te_dbl<S>(te_dbl<S>(te_dbl<S>(acc))));
+    uint32_t d = (k.v[w >> 3] >> (4 * (w & 7))) & 15u;
+    if (d) acc = te_add<S>(acc, tab[d]);
   }
   return acc;
 }
@@ -166,28 +172,18 @@ template <class S> AVRF_DN te_ext te_smul_fixed(const te_pre *tab, int base, fp 
   }
   return acc;
 }
-// a*P + b*Q (Shamir's trick), a/b plain integers of nbits bits
+// a*P + b*Q (Shamir's trick), a/b plain integers of nbits bits: joint 2-bit windows, table i*P + j*Q (i, j < 4)
 template <class S> AVRF_DN te_ext te_smul2(te_pre p, fp a, te_pre q, fp b, int nbits) {
-  using Fq = typename S::Fq;
-  te_ext pq = te_madd<S>(te_from_pre<S>(p), q);
-  te_aff pqa = te_to_aff<S>(pq);
-  te_pre pqp = te_make_pre<S>(pqa.x, pqa.y);
+  te_ext tab[16];
+  tab[0] = te_identity<S>();
+  for (int i = 1; i < 4; i++) tab[i] = te_madd<S>(tab[i - 1], p);              // i*P
+  for (int j = 1; j < 4; j++) for (int i = 0; i < 4; i++) tab[4 * j + i] = te_madd<S>(tab[4 * (j - 1) + i], q);
   te_ext acc = te_identity<S>();
-  for (int i = nbits - 1; i >= 0; i--) {
-    acc = te_dbl<S>(acc);
-    uint32_t ba = (a.v[i >> 5] >> (i & 31)) & 1, bb = (b.v[i >> 5] >> (i & 31)) & 1;
-    if (ba | bb) {
-      te_pre sel;
-#pragma unroll
-      for (int w = 0; w < 8; w++) {
-        sel.x.v[w] = (ba & bb) ? pqp.x.v[w] : (ba ? p.x.v[w] : q.x.v[w]);
-        sel.y.v[w] = (ba & bb) ? pqp.y.v[w] : (ba ? p.y.v[w] : q.y.v[w]);
-        sel.k.v[w] = (ba & bb) ? pqp.k.v[w] : (ba ? p.k.v[w] : q.k.v[w]);
-      }
-      acc = te_madd<S>(acc, sel);
-    }
+  for (int w = (nbits + 1) / 2 - 1; w >= 0; w--) {
+    acc = te_dbl<S>(te_dbl<S>(acc));
+    uint32_t da = (a.v[w >> 4] >> (2 * (w & 15))) & 3u, db = (b.v[w >> 4] >> (2 * (w & 15))) & 3u;
+    if (da | db) acc = te_add<S>(acc, tab[4 * db + da]);
   }
-  (void)sizeof(Fq);
   return acc;
 }
 template <class S> AVRF_DI void store_xy(uint8_t *out, const te_aff &a) {
