@@ -196,6 +196,16 @@ class Context:
             raise AvrfError(f"avrf_scalar_mul -> {st}")
         return bytes(out)[: 64 * n]
 
+    def hash_to_curve(self, messages):
+        """Input::new for a list of byte strings -> (xy bytes n x 64, statuses)."""
+        n = len(messages)
+        out = (C.c_uint8 * max(1, n * 64))()
+        st = (C.c_int32 * max(1, n))()
+        rc = lib().avrf_hash_to_curve(self._h, C.c_size_t(n), _u8(b"".join(messages)), _u32([len(m) for m in messages]), out, st)
+        if rc != OK:
+            raise AvrfError(f"avrf_hash_to_curve -> {rc}")
+        return bytes(out)[: n * 64], list(st)[:n]
+
     def points_decompress(self, comp, validate=False):
         n = len(comp) // 32
         out, st_out = (C.c_uint8 * max(1, 64 * n))(), (C.c_int32 * max(1, n))()

@@ -511,6 +511,25 @@ int avrf_points_decompress(avrf_ctx *c, size_t n, const uint8_t *in, uint8_t *ou
   HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
   return AVRF_OK;
 }
+int avrf_hash_to_curve(avrf_ctx *c, size_t n, const uint8_t *data, const uint32_t *data_lens, uint8_t *out_xy, int32_t *status_out) {
+  if (!c || (n && (!data_lens || !out_xy || !status_out))) return AVRF_ERR_BAD_ARG;
+  if (!n) return AVRF_OK;
+  if (n > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
+  std::vector<uint32_t> off(n + 1); uint64_t tot = 0;
+  for (size_t i = 0; i < n; i++) { off[i] = (uint32_t)tot; tot += data_lens[i]; if (tot > 0xffffffffULL) return AVRF_ERR_BAD_ARG; }
+  off[n] = (uint32_t)tot;
+  if (tot && !data) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  c->staged_kind = 0;
+  HIP_TRY(c->d_ads.ensure(tot + 16)); HIP_TRY(c->d_ad_off.ensure((n + 1) * 4)); HIP_TRY(c->d_out.ensure(n * 64)); HIP_TRY(c->d_status.ensure(n * 4));
+  if (tot) HIP_TRY(hipMemcpyAsync(c->d_ads.p, data, tot, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_ad_off.p, off.data(), (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  launch_hash_to_curve(c->suite, c->d_ads.as<uint8_t>(), c->d_ad_off.as<uint32_t>(), (uint32_t)n, c->d_out.as<uint8_t>(), c->d_status.as<int32_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(out_xy, c->d_out.p, n * 64, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
+  return AVRF_OK;
+}
 int avrf_points_compress(avrf_ctx *c, size_t n, const uint8_t *in_xy, uint8_t *out) {
   if (!c || (n && (!in_xy || !out))) return AVRF_ERR_BAD_ARG;
   if (!n) return AVRF_OK;

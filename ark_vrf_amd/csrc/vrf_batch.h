@@ -34,6 +34,7 @@ void launch_thin_verify(int suite, const BatchDev &b, int32_t *d_status, hipStre
 void launch_ped_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st);
 void launch_ped_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
 
+void launch_hash_to_curve(int suite, const uint8_t *d_data, const uint32_t *d_off, uint32_t n, uint8_t *d_out, int32_t *d_status, hipStream_t st);
 void launch_decompress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st);
 void launch_compress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st);
 

@@ -249,6 +249,106 @@ k_ped_verify(BatchDev b, int32_t *__restrict__ status) {
 // CanonicalDeserialize for TE affine points, compressed form: y = LE32 with the
 // top bit cleared, x recovered from x^2 = (1 - y^2) / (a - d y^2), sign chosen by the flag.
 // validate: additionally require the prime-order subgroup and non-identity (src/lib.rs:410-433).
+// ---------------------------------------------------------------- hash to curve (Input::new, src/lib.rs -> Suite::data_to_point)
+
+// absorb a digest (eight big-endian words) byte for byte
+AVRF_DI void sha512_digest(Sha512 &s, const uint64_t (&d)[8]) {
+  for (int i = 0; i < 8; i++) for (int k = 7; k >= 0; k--) sha512_byte(s, (uint8_t)(d[i] >> (8 * k)));
+}
+// big-endian integer of six consecutive digest words -> (low 256 bits, high 128 bits) as plain little-endian limbs
+AVRF_DI void be384_split(const uint64_t (&w)[6], fp &lo, fp &hi) {
+  hi = fp_zero();
+  for (int i = 0; i < 4; i++) { lo.v[2 * i] = (uint32_t)w[5 - i]; lo.v[2 * i + 1] = (uint32_t)(w[5 - i] >> 32); }
+  hi.v[0] = (uint32_t)w[1]; hi.v[1] = (uint32_t)(w[1] >> 32); hi.v[2] = (uint32_t)w[0]; hi.v[3] = (uint32_t)(w[0] >> 32);
+}
+// ark-ec Elligator2Map::map_to_curve for the Montgomery model (J, K) of the curve, Z = 5; TE point out
+// (src/utils/hash_to_curve.rs:66-100)
+template <class S> AVRF_DN te_aff ell2_map(fp u) {
+  using Fq = typename S::Fq;
+  const fp one = fp_one<Fq>(), jk = fp_const<Fq>(S::ELL2_JK), k2i = fp_const<Fq>(S::ELL2_KINV2), K = fp_const<Fq>(S::ELL2_K);
+  fp u2 = fp_sqr<Fq>(u), t0 = fp_add<Fq>(fp_dbl<Fq>(fp_dbl<Fq>(u2)), u2);   // Z u^2, Z = 5
+  fp den = fp_add<Fq>(one, t0);
+  if (fp_is_zero(den)) den = one;
+  fp x1 = fp_neg<Fq>(fp_mul<Fq>(jk, fp_inv<Fq>(den)));
+  auto g = [&](const fp &x) { fp x2 = fp_sqr<Fq>(x); return fp_add<Fq>(fp_add<Fq>(fp_mul<Fq>(x2, x), fp_mul<Fq>(x2, jk)), fp_mul<Fq>(x, k2i)); };
+  fp xs = x1, ys; bool want_odd = true;
+  if (!fp_sqrt_nf<Fq>(g(x1), &ys)) {
+    xs = fp_sub<Fq>(fp_neg<Fq>(x1), jk); want_odd = false;
+    (void)fp_sqrt_nf<Fq>(g(xs), &ys);
+  }
+  if (((fp_from_mont<Fq>(ys).v[0] & 1u) != 0) != want_odd) ys = fp_neg<Fq>(ys);
+  fp sx = fp_mul<Fq>(xs, K), ty = fp_mul<Fq>(ys, K), sp1 = fp_add<Fq>(sx, one);
+  fp d2 = fp_mul<Fq>(ty, sp1);
+  te_aff o;
+  if (fp_is_zero(d2)) { o.x = fp_zero(); o.y = one; return o; }
+  fp di = fp_inv<Fq>(d2);                                                   // 1 / (t (s + 1))
+  o.x = fp_mul<Fq>(sx, fp_mul<Fq>(di, sp1));                                // s / t
+  o.y = fp_mul<Fq>(fp_sub<Fq>(sx, one), fp_mul<Fq>(di, ty));                // (s - 1) / (s + 1)
+  return o;
+}
+
+// one lane per message: out_xy[j] = hash_to_curve(data[off[j] .. off[j+1])), status 2 if try-and-increment finds nothing
+template <class S>
+__global__ void __launch_bounds__(128)
+k_hash_to_curve(const uint8_t *__restrict__ data, const uint32_t *__restrict__ off, uint32_t n, uint8_t *__restrict__ out_xy, int32_t *__restrict__ status) {
+  using Fq = typename S::Fq;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint8_t *msg = data + off[j]; const uint32_t len = off[j + 1] - off[j];
+  constexpr uint8_t DS_H2C = 0x60;
+  te_ext acc; bool ok = false;
+  if (S::H2C_ELL2) {
+    // RFC 9380 expand_message_xmd(SHA-512) as instantiated by ark-ff's DefaultFieldHasher: Z_pad = 48 zero bytes,
+    // DST = suite id || 0x60, 96 uniform bytes -> two field elements of 48 big-endian bytes each
+    Sha512 h; uint64_t b0[8], b1[8], b2[8];
+    auto dst = [&](Sha512 &s) { for (int i = 0; i < S::SUITE_ID_LEN; i++) sha512_byte(s, S::SUITE_ID[i]); sha512_byte(s, DS_H2C); sha512_byte(s, (uint8_t)(S::SUITE_ID_LEN + 1)); };
+    sha512_init(h);
+    for (int i = 0; i < 48; i++) sha512_byte(h, 0);
+    sha512_bytes(h, msg, len);
+    sha512_byte(h, 0); sha512_byte(h, 96); sha512_byte(h, 0); dst(h);
+    sha512_final(h, b0);
+    sha512_init(h); sha512_digest(h, b0); sha512_byte(h, 1); dst(h); sha512_final(h, b1);
+    uint64_t x[8]; for (int i = 0; i < 8; i++) x[i] = b0[i] ^ b1[i];
+    sha512_init(h); sha512_digest(h, x); sha512_byte(h, 2); dst(h); sha512_final(h, b2);
+    uint64_t w0[6] = {b1[0], b1[1], b1[2], b1[3], b1[4], b1[5]}, w1[6] = {b1[6], b1[7], b2[0], b2[1], b2[2], b2[3]};
+    fp lo, hi;
+    be384_split(w0, lo, hi); fp u0 = fp_from_wide_mont<Fq>(lo, hi);
+    be384_split(w1, lo, hi); fp u1 = fp_from_wide_mont<Fq>(lo, hi);
+    te_aff q0 = ell2_map<S>(u0), q1 = ell2_map<S>(u1);
+    acc = te_madd<S>(te_from_pre<S>(te_make_pre<S>(q0.x, q0.y)), te_make_pre<S>(q1.x, q1.y));
+    for (int c = S::COFACTOR; c > 1; c >>= 1) acc = te_dbl<S>(acc);
+    ok = true;
+  } else {
+    // try-and-increment (src/utils/hash_to_curve.rs:34-57): transcript(suite id, 0x60, LE64(len), data, ctr) -> 32 bytes
+    // -> Affine::from_random_bytes (top bit = sign of x, bits above the modulus size cleared)
+    Sha512 pre; sha512_init(pre);
+    for (int i = 0; i < S::SUITE_ID_LEN; i++) sha512_byte(pre, S::SUITE_ID[i]);
+    sha512_byte(pre, DS_H2C); sha512_u64le(pre, (uint64_t)len); sha512_bytes(pre, msg, len);
+    for (int ctr = 0; ctr <= 255 && !ok; ctr++) {
+      Sha512 t = pre; sha512_byte(t, (uint8_t)ctr);
+      uint64_t seed[8], blk[8]; sha512_final(t, seed); sha512_xof_block(seed, 0, blk);
+      fp y; uint32_t w4[4];
+      digest_le128(blk, 0, w4); for (int i = 0; i < 4; i++) y.v[i] = w4[i];
+      digest_le128(blk, 1, w4); for (int i = 0; i < 4; i++) y.v[4 + i] = w4[i];
+      const bool neg = (y.v[7] >> 31) != 0;
+      y.v[7] &= 0xffffffffu >> (256 - Fq::BITS);
+      if (ge_p<Fq>(y)) continue;
+      fp ym = fp_to_mont<Fq>(y), y2 = fp_sqr<Fq>(ym), one = fp_one<Fq>();
+      fp a_const = S::A_KIND == 1 ? fp_neg<Fq>(fp_add<Fq>(fp_dbl<Fq>(fp_dbl<Fq>(one)), one)) : one;
+      fp den = fp_sub<Fq>(a_const, fp_mul<Fq>(fp_const<Fq>(S::D), y2)), xm;
+      if (fp_is_zero(den) || !fp_sqrt_nf<Fq>(fp_mul<Fq>(fp_sub<Fq>(one, y2), fp_inv<Fq>(den)), &xm)) continue;
+      if (fp_is_negative_mont<Fq>(xm) != neg) xm = fp_neg<Fq>(xm);
+      if (fp_is_zero(xm) && neg) continue;
+      acc = te_from_pre<S>(te_make_pre<S>(xm, ym));
+      for (int c = S::COFACTOR; c > 1; c >>= 1) acc = te_dbl<S>(acc);
+      if (te_is_identity<S>(acc)) continue;
+      ok = true;
+    }
+  }
+  if (ok) { store_xy<S>(out_xy + 64 * (size_t)j, te_to_aff<S>(acc)); status[j] = 0; }
+  else { for (int i = 0; i < 64; i++) out_xy[64 * (size_t)j + i] = 0; status[j] = 2; }
+}
+
 template <class S>
 __global__ void __launch_bounds__(128)
 k_decompress(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ out_xy, int validate, int32_t *__restrict__ status) {
@@ -328,6 +428,10 @@ void launch_ped_verify(int suite, const BatchDev &b, int32_t *d_status, hipStrea
   AVRF_DISPATCH(suite, k_ped_verify, dim3((b.n + 127) / 128), dim3(128), st, b, d_status);
 }
 
+void launch_hash_to_curve(int suite, const uint8_t *d_data, const uint32_t *d_off, uint32_t n, uint8_t *d_out, int32_t *d_status, hipStream_t st) {
+  if (!n) return;
+  AVRF_DISPATCH(suite, k_hash_to_curve, dim3((n + 127) / 128), dim3(128), st, d_data, d_off, n, d_out, d_status);
+}
 void launch_decompress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st) {
   if (!n) return;
   AVRF_DISPATCH(suite, k_decompress, dim3((n + 127) / 128), dim3(128), st, d_in, n, d_out, validate, d_status);

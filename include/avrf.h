@@ -203,6 +203,12 @@ int avrf_ring_prove(avrf_ring_key *key, size_t n, const uint32_t *key_index, con
 int avrf_ring_batch_verify(avrf_ring_setup *setup, size_t n, const uint8_t *ring_commitments, size_t n_rings,
                            const uint32_t *ring_of_item, const uint8_t *instances_xy, const uint8_t *ring_proofs);
 
+/* Input::new(data) = Suite::data_to_point (src/lib.rs:440-444 via src/utils/hash_to_curve.rs:34-100) for n messages:
+ * Elligator2 with expand_message_xmd(SHA-512) for Bandersnatch, try-and-increment for Baby-JubJub.  data = the
+ * messages concatenated, data_lens[i] their lengths.  out_xy: n x 64; status_out[i] = 0, or 2 (InvalidData) where
+ * try-and-increment found no point (the reference returns None). */
+int avrf_hash_to_curve(avrf_ctx *ctx, size_t n, const uint8_t *data, const uint32_t *data_lens, uint8_t *out_xy, int32_t *status_out);
+
 /* CanonicalSerialize / CanonicalDeserialize of curve points, batched on the device
  * (ark-serialize compressed form; checked constructors src/lib.rs:410-494).
  * decompress: in n x 32 -> out n x 64; status_out[j] = AVRF_OK / AVRF_INVALID_DATA.

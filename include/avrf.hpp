@@ -48,6 +48,13 @@ class Suite {
   avrf_ctx *ctx_ = nullptr;
 };
 
+// Input::new(data) (src/lib.rs:440-444): hash-to-curve on the device; throws where the reference returns None
+inline Point input_new(const Suite &s, const std::string &data) {
+  Point p; uint32_t len = (uint32_t)data.size(); int32_t st = 0;
+  if (avrf_hash_to_curve(s.ctx(), 1, (const uint8_t *)data.data(), &len, p.data(), &st) != AVRF_OK || st != 0) throw std::invalid_argument("avrf: hash to curve");
+  return p;
+}
+
 struct Public { Point point; };          // src/lib.rs:408
 struct Secret {                          // src/lib.rs:258
   Scalar scalar; Public public_key;
