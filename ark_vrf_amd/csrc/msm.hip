@@ -611,7 +611,10 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   const int nbits = (int)vwin * p.c;
   if constexpr (CV::FIXED_TABLE) if (table_c) {   // one bucket set per MSM: weighted sum in one kernel, no bit sums
     uint32_t wps = 1;                                      // waves per bucket set when the launch has few sets
-    while (wps < 4 && batch * wps * 2 <= 2048 && (uint32_t)p.nb >= 64 * wps * 2) wps *= 2;
+    // (a wave per set does the least work per bucket -- 2.5 adds against 4.4 with four waves -- and measured faster as
+    // soon as a few hundred sets are in flight; the workgroup form is for the handful of sets of a single proof)
+    const uint32_t wps_max = batch <= 64 ? 4 : 1;
+    while (wps < wps_max && (uint32_t)p.nb >= 64 * wps * 2) wps *= 2;
     if (wps > 1) {
       hipLaunchKernelGGL(k_wsum_blk<CV>, dim3((unsigned)batch), dim3(64 * wps), (size_t)wps * 2 * acc_bytes, stream, (const uint32_t *)ws.buckets,
                          (uint32_t)p.nb, ws.rc);
