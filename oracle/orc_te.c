@@ -10,12 +10,13 @@
  * Any correct group law yields the same group element; parity is defined on the
  * normalised affine result / its encoding.
  */
+#include <pthread.h>
 #include "orc.h"
 #include <stdlib.h>
 #include <string.h>
 
 static suite_t g_suites[2];
-static int g_init = 0;
+static pthread_once_t g_once = PTHREAD_ONCE_INIT;      /* gen_batch() calls in from several threads at once */
 
 static void fq_dec(u256 *o, const char *dec, const mont_t *m) {
     u256 t; u256_from_dec(&t, dec); mont_to(o, &t, m);
@@ -72,11 +73,10 @@ static void init_suites(void) {
     fq_dec(&s->ACC.y, "9735581299071570006712034490635195155689931359428941496570758703259384062170", &s->fq);
     fq_dec(&s->PAD.x, "11167490195257431015694161063225325511805242064780376648595733691987293447528", &s->fq);
     fq_dec(&s->PAD.y, "18403369502642103292159933062507105566469227524991433735553439433605496057425", &s->fq);
-    g_init = 1;
 }
 
 const suite_t *orc_suite(int id) {
-    if (!g_init) init_suites();
+    pthread_once(&g_once, init_suites);
     if (id < 0 || id > 1) return NULL;
     return &g_suites[id];
 }
