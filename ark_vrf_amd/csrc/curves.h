@@ -19,7 +19,8 @@ template <class S> struct TeCurve {
   static constexpr bool FIXED_TABLE = false;          // no fixed-base window-table mode (bases change per batch)
   static constexpr int MIN_WAVES = 3;                 // waves per SIMD asked of the register allocator in k_accumulate
   static constexpr int RED_WAVES = 3;                 // ... and in the reduction kernels (general additions)
-  static constexpr bool INLINE_REDUCE_OPS = false;
+  static constexpr bool INLINE_REDUCE_OPS = true;
+  static constexpr bool WINDOW_SUMS = true;           // single MSMs: one weighted bucket sum per window (k_wsum_blk) instead of row/column + bit sums
   static AVRF_DI acc_t identity() { return te_identity<S>(); }
   static AVRF_DI acc_t madd(const acc_t &a, base_t q, bool neg) {
     using Fq = typename S::Fq;
@@ -54,6 +55,7 @@ template <class C> struct G1Curve {
   static constexpr int MIN_WAVES = 3;                 // k_accumulate holds one accumulator + one base: 184 VGPRs at N = 12
   static constexpr int RED_WAVES = 2;                 // the general addition (two accumulators live) needs the 256-register budget
   static constexpr bool INLINE_REDUCE_OPS = true;     // k_wsum*: additions inlined (the asm multiplier keeps the code small)
+  static constexpr bool WINDOW_SUMS = false;
   static constexpr bool ZERO_IS_IDENTITY = true;      // zz = 0; all-zero memory reads as the identity
   static constexpr bool SPLIT_REDUCE = false;         // 381-bit: lanes of one bucket are summed by k_fixup, not inside k_accumulate
   static constexpr bool FIXED_TABLE = true;           // KZG SRS: msm_g1_fixed_device

@@ -606,6 +606,25 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   HIP_CHECK(hipEventRecord(ws.ev1, stream));
   hipLaunchKernelGGL(k_fixup<CV>, dim3((nbk + 255) / 256), b256, 0, stream, ws.cnts, ws.lane_off, nbk, (uint32_t)p.nb, lcap, seg,
                      (const uint32_t *)ws.part, ws.buckets);
+  static const bool window_sums_on = !(getenv("AVRF_TE_WINDOW_SUMS") && atoi(getenv("AVRF_TE_WINDOW_SUMS")) == 0);
+  if constexpr (CV::WINDOW_SUMS) if (batch == 1 && window_sums_on) {          // one weighted sum per window; the host does nwin Horner steps of c doublings
+    uint32_t wps = 1;
+    while (wps < 4 && (uint32_t)p.nb >= 64 * wps * 2) wps *= 2;
+    if (const char *e = getenv("AVRF_TE_WSUM_WPS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) { wps = (uint32_t)v; while (wps > 1 && (uint32_t)p.nb < 64 * wps) wps >>= 1; } }
+    if ((uint32_t)p.nb >= 64) {
+      hipLaunchKernelGGL(k_wsum_blk<CV>, dim3(vwin), dim3(64 * wps), (size_t)wps * 2 * acc_bytes, stream, (const uint32_t *)ws.buckets, (uint32_t)p.nb, ws.rc);
+    } else {
+      uint32_t lps_log = 0; while ((2u << lps_log) <= (uint32_t)p.nb) lps_log++;
+      hipLaunchKernelGGL(k_wsum<CV>, dim3((unsigned)((((size_t)vwin << lps_log) + 255) / 256)), b256, 0, stream, (const uint32_t *)ws.buckets, (uint32_t)p.nb,
+                         vwin, lps_log, ws.rc);
+    }
+    HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.rc, (size_t)vwin * acc_bytes, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventElapsedTime(&ws.accum_ms_last, ws.ev0, ws.ev1));
+    ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = p;
+    return -(int)vwin;                                       // negative: bits_host holds window sums, not bit sums
+  }
   const int h = (p.c - 1) / 2;
   const uint32_t tasks = (1u << h) + ((uint32_t)p.nb >> h);
   const int nbits = (int)vwin * p.c;
@@ -662,7 +681,13 @@ static int msm_te_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_
   int nbits = msm_device<TeCurve<S>>((const uint32_t *)d_pre, d_scalars, n, S::Fr::BITS, ws, stream);
   HostExt acc = HT::identity();
   const uint32_t *bh = ws.bits_host;
-  for (int i = nbits - 1; i >= 0; i--) {                  // sum_p 2^p T_p
+  if (nbits < 0) {                                        // window sums W_w: sum_w 2^(c w) W_w
+    const int c = ws.last_plan.c;
+    for (int w = -nbits - 1; w >= 0; w--) {
+      for (int k = 0; k < c; k++) acc = HT::dbl(acc);
+      acc = HT::add(acc, HT::from_raw32(bh + (size_t)w * 32));
+    }
+  } else for (int i = nbits - 1; i >= 0; i--) {           // bit sums T_p: sum_p 2^p T_p
     acc = HT::dbl(acc);
     acc = HT::add(acc, HT::from_raw32(bh + (size_t)i * 32));
   }
