@@ -1,30 +1,35 @@
-// msm.hip -- Pippenger bucket MSM for twisted-Edwards curves on gfx950 (CDNA4).
+// msm.hip -- Pippenger bucket MSM on gfx950 (CDNA4), curve-generic (curves.h): twisted Edwards (Thin / Pedersen batch
+// verification) and short-Weierstrass G1 (KZG commitments of the ring SNARK).
 //
 // Replaces arkworks `VariableBaseMSM::msm_unchecked` (third-party ark-ec 0.6) at the
-// reference call sites src/thin.rs:319, src/pedersen.rs:420, src/utils/common.rs:410-411.
+// reference call sites src/thin.rs:319, src/pedersen.rs:420, src/utils/common.rs:410-411 and inside w3f-pcs KZG.
 // Any correct MSM yields the same group element; parity is on the normalised result
 // (SURVEY.md A.9), so the decomposition below is designed for the GPU, not copied:
 //
 //   k_digits     one lane per scalar: signed c-bit digits of every window -> 16-bit keys
 //                (bucket | sign<<15), window-major, coalesced
 //   k_hist       workgroup (tile, window): LDS histogram of its tile of keys -> H[w][tile][b]
-//   k_scan_win   workgroup per window: per-bucket prefix over tiles (in place), exclusive scan of
-//                the bucket totals (entry offsets) and of lanes_b = ceil(count_b / SEG)
+//   k_scan_win   workgroup per window: per-bucket prefix over tiles (in place), entry offsets, and the LANE
+//                PLACEMENT: bucket b gets ceil(count_b / SEG) lanes, buckets ordered by descending entries-per-lane
+//                (counting sort in LDS) so that the 64 lanes of a wave carry equal loads
 //   k_scatter    workgroup (tile, window): LDS cursors seeded from the scanned histogram; every
 //                key gets its slot with an LDS atomic -- no global atomics anywhere in the sort
-//   k_accumulate load-balanced: every lane owns <= SEG consecutive entries of ONE bucket (big
-//                buckets simply get more lanes), does its mixed additions (8M each) on gathered
-//                96-byte precomputed points, then a wave-level SEGMENTED shuffle reduction
-//                folds the lanes of a bucket; runs that cross a wave boundary leave a partial
+//   k_accumulate every lane owns <= SEG consecutive entries of ONE bucket (big buckets simply get more
+//                lanes), does its mixed additions on gathered precomputed points, then a wave-level
+//                SEGMENTED shuffle reduction folds the lanes of a bucket; runs that cross a wave boundary
+//                leave a partial
 //   k_fixup      per bucket: identity for empty buckets, sum of wave partials for split ones
-//   k_rowcol     bucket index b = hi * 2^h + lo: one wave per row sum R_hi and per column sum C_lo
-//   k_bits       one wave per (window, bit k):  T_k = sum of the buckets whose index has bit k set
-//                = sum of C_lo (lo has bit k) or of R_hi (hi has bit k-h);  sum_b b*B_b = sum_k 2^k T_k
-//                (no serial running sum; 2 adds per bucket instead of c/2)
-//   host         Horner over the nwin*c bit sums (<= 2*260 point ops)
+//   k_wsum_blk / k_wsum   weighted bucket sum sum_b b*B_b of one window (or of one fixed-base bucket set) by
+//                a workgroup / a group of lanes: 2 additions per bucket + a suffix scan
+//   k_rowcol, k_bits, k_bits_direct, k_horner   the bit-decomposition reduction sum_b b*B_b = sum_k 2^k T_k, kept for
+//                G1 MSMs without a window table (ring_proof::index, the verifier's MSMs)
+//   host         Horner over the window sums (nwin * (c doublings + 1 addition))
 //
-// Layout in HBM: points AoS te_pre (x|y|k, 96 B, gathered whole by one lane with 6 dwordx4
-// loads); keys/sorted SoA per window (coalesced); buckets AoS te_ext (128 B).
+// Fixed-base mode (G1 only): the bases are a window table T[w][i] = 2^(c w) P_i, so ALL windows of a scalar vector
+// share one bucket set; `batch` vectors over the same table run as `batch` bucket sets in one launch chain.
+//
+// Layout in HBM: points AoS (te_pre x|y|k 96 B; G1 affine x|y 64 / 96 B), gathered whole by one lane with dwordx4
+// loads; keys/sorted SoA per window (coalesced); buckets AoS (te_ext 128 B; XYZZ 128 / 192 B).
 #include "msm.h"
 #include "curves.h"
 #include "host_g1.h"
