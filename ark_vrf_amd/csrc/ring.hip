@@ -476,6 +476,9 @@ struct avrf_ring_setup {
   uint32_t *d_scr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t scr_cap[6] = {0, 0, 0, 0, 0, 0};
   MsmWorkspace ws;
+  // second lane for avrf_ring_prove: a shallow copy (same SRS tables, twiddles, constants) with its own stream, scratch
+  // and MSM workspace, so two chunks of proofs are in flight and one hides the other's host rounds
+  avrf_ring_setup *lane1 = nullptr;
 };
 struct avrf_ring_key {
   avrf_ring_setup *setup;
@@ -857,8 +860,17 @@ template <class S, class G> struct Ring {
   }
   static fp fp_zero_host() { fp r; memset(&r, 0, sizeof r); return r; }
 
-  static int prove_chunk(avrf_ring_key *k, size_t n, const uint32_t *key_index, const uint8_t *blindings, bool hiding, uint8_t *out) {
-    avrf_ring_setup *su = k->setup;
+  static avrf_ring_setup *second_lane(avrf_ring_setup *su) {
+    if (su->lane1) return su->lane1;
+    ensure_lagrange(su);                                               // so that the copy sees the witness table
+    avrf_ring_setup *l = new avrf_ring_setup(*su);
+    l->lane1 = nullptr; l->d_buf = nullptr; l->buf_cap = 0; l->ws = MsmWorkspace();
+    for (int i = 0; i < 6; i++) { l->d_scr[i] = nullptr; l->scr_cap[i] = 0; }
+    HIP_CHECK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
+    su->lane1 = l;
+    return l;
+  }
+  static int prove_chunk(avrf_ring_key *k, avrf_ring_setup *su, size_t n, const uint32_t *key_index, const uint8_t *blindings, bool hiding, uint8_t *out) {
     const size_t N = su->N, cap = su->cap, M = 4 * N, plen = 4 * FQB + 7 * 32 + FQB + 32 + 2 * FQB;
     const H256 zero = {{0, 0, 0, 0}}, one = Fr::one();
     static const bool trace = getenv("AVRF_RING_TRACE") != nullptr;
@@ -1230,6 +1242,13 @@ void avrf_ring_setup_free(avrf_ring_setup *su) {
                su->d_scr[0], su->d_scr[1], su->d_scr[2], su->d_scr[3], su->d_scr[4], su->d_scr[5]};
   for (void *p : d) if (p) (void)hipFree(p);
   su->ws.release();
+  if (avrf_ring_setup *l = su->lane1) {                                // only what the lane owns
+    void *o[] = {l->d_buf, l->d_scr[0], l->d_scr[1], l->d_scr[2], l->d_scr[3], l->d_scr[4], l->d_scr[5]};
+    for (void *p : o) if (p) (void)hipFree(p);
+    l->ws.release();
+    (void)hipStreamDestroy(l->stream);
+    delete l;
+  }
   delete su;
 }
 size_t avrf_ring_max_ring_size(const avrf_ring_setup *su) { return su ? su->keyset : 0; }
@@ -1279,13 +1298,27 @@ int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const
   const size_t plen = k->setup->suite == 0 ? 592 : 480;
   size_t chunk = 512;                                                  // proofs proved in lockstep per device round
   if (const char *e = getenv("AVRF_RING_CHUNK")) { long v = atol(e); if (v >= 1 && v <= 4096) chunk = (size_t)v; }
-  for (size_t i = 0; i < n; i += chunk) {
+  avrf_ring_setup *su = k->setup;
+  auto run = [&](avrf_ring_setup *lane, size_t i) {
     const size_t m = n - i < chunk ? n - i : chunk;
-    int st = k->setup->suite == 0 ? RingB::prove_chunk(k, m, key_index + i, blindings + 32 * i, blinding_mode == 1, proofs_out + plen * i)
-                                  : RingJ::prove_chunk(k, m, key_index + i, blindings + 32 * i, blinding_mode == 1, proofs_out + plen * i);
-    if (st) return st;
+    return su->suite == 0 ? RingB::prove_chunk(k, lane, m, key_index + i, blindings + 32 * i, blinding_mode == 1, proofs_out + plen * i)
+                          : RingJ::prove_chunk(k, lane, m, key_index + i, blindings + 32 * i, blinding_mode == 1, proofs_out + plen * i);
+  };
+  const char *le = getenv("AVRF_RING_LANES"); const bool one_lane = le && atoi(le) == 1;
+  if (n <= chunk || one_lane) {
+    for (size_t i = 0; i < n; i += chunk) if (int st = run(su, i)) return st;
+    return AVRF_OK;
   }
-  return AVRF_OK;
+  // two chunks in flight: chunks alternate between the setup's own stream/scratch and its second lane
+  avrf_ring_setup *lanes[2] = {su, su->suite == 0 ? RingB::second_lane(su) : RingJ::second_lane(su)};
+  std::atomic<int> status{AVRF_OK};
+  std::thread th[2];
+  for (int t = 0; t < 2; t++) th[t] = std::thread([&, t] {
+    if (hipSetDevice(su->device) != hipSuccess) { status = AVRF_ERR_NO_DEVICE; return; }
+    for (size_t i = (size_t)t * chunk; i < n && status == AVRF_OK; i += 2 * chunk) if (int st = run(lanes[t], i)) status = st;
+  });
+  for (auto &x : th) x.join();
+  return status;
 }
 
 int avrf_ring_batch_verify(avrf_ring_setup *su, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,

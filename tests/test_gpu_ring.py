@@ -297,3 +297,24 @@ def test_verifier_key_builder(env, suite):
     bad = bytes([0xff] * 32) + pks[0][32:]
     b2 = VerifierKeyBuilder(setup)
     assert b2.append([bad]) == 2 and b2.free_slots() == setup.max_ring_size
+
+
+def test_chunked_two_lane_proving(env, monkeypatch):
+    """avrf_ring_prove splits a call into lockstep chunks and keeps two of them in flight (second lane: own stream,
+    scratch and MSM workspace over the shared SRS tables): the proofs do not depend on the chunking."""
+    import oracle as orc
+    ctx, setup, vs, srs_bytes = env[0]
+    sks = [orc.from_seed(0, bytes([3, i]) + bytes(30)) for i in range(6)]
+    key = setup.index([xy(0, pk) for _, pk in sks])
+    n = 11
+    idx = [(5 * j + 1) % 6 for j in range(n)]
+    bl = [(int.from_bytes(bytes([j + 1]) * 32, "little") >> 4).to_bytes(32, "little") for j in range(n)]
+    whole = key.prove(idx, bl)
+    monkeypatch.setenv("AVRF_RING_CHUNK", "2")
+    assert key.prove(idx, bl) == whole                                     # 6 chunks over two lanes
+    monkeypatch.setenv("AVRF_RING_LANES", "1")
+    assert key.prove(idx, bl) == whole
+    monkeypatch.setenv("AVRF_RING_CHUNK", "3")
+    monkeypatch.delenv("AVRF_RING_LANES")
+    assert key.prove(idx, bl) == whole
+    assert [key.prove([i], [b])[0] for i, b in zip(idx[:3], bl[:3])] == whole[:3]
