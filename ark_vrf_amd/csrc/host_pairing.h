@@ -66,6 +66,65 @@ template <class C> struct HostPairing {
     r.c0 = f6_add(v0, f6_mul_v(v1));
     return r;
   }
+  static F6 f6_neg(const F6 &x) { return f6(f2_neg(x.c0), f2_neg(x.c1), f2_neg(x.c2)); }
+  static F6 f6_scale2(const F6 &x, const F2 &k) { return f6(f2_mul(x.c0, k), f2_mul(x.c1, k), f2_mul(x.c2, k)); }
+  static F6 f6_inv(const F6 &x) {                                   // (A + B v + C v^2) / (c0 A + xi (c2 B + c1 C))
+    F2 A = f2_sub(f2_sqr(x.c0), f2_mul_xi(f2_mul(x.c1, x.c2)));
+    F2 B = f2_sub(f2_mul_xi(f2_sqr(x.c2)), f2_mul(x.c0, x.c1));
+    F2 Cc = f2_sub(f2_sqr(x.c1), f2_mul(x.c0, x.c2));
+    F2 Fd = f2_add(f2_mul(x.c0, A), f2_mul_xi(f2_add(f2_mul(x.c2, B), f2_mul(x.c1, Cc))));
+    return f6_scale2(f6(A, B, Cc), f2_inv(Fd));
+  }
+  static F12 f12_conj(const F12 &x) { F12 r; r.c0 = x.c0; r.c1 = f6_neg(x.c1); return r; }     // x^(p^6)
+  static F12 f12_inv(const F12 &x) {                                // (a - b w) / (a^2 - b^2 v)
+    F6 d = f6_inv(f6_sub(f6_mul(x.c0, x.c0), f6_mul_v(f6_mul(x.c1, x.c1))));
+    F12 r; r.c0 = f6_mul(x.c0, d); r.c1 = f6_neg(f6_mul(x.c1, d)); return r;
+  }
+  // x^(p^2): the coefficient of w^k (w^6 = xi; order c0.c0, c1.c0, c0.c1, c1.c1, c0.c2, c1.c2) times gamma^k,
+  // gamma = xi^((p^2-1)/6) in Fp
+  static F12 f12_frob2(const F12 &x) {
+    static const El g1 = Fp::from32(C::FROB2_GAMMA), g2 = Fp::mul(g1, g1), g3 = Fp::mul(g2, g1), g4 = Fp::mul(g3, g1), g5 = Fp::mul(g4, g1);
+    F12 r;
+    r.c0 = f6(x.c0.c0, f2_scale(x.c0.c1, g2), f2_scale(x.c0.c2, g4));
+    r.c1 = f6(f2_scale(x.c1.c0, g1), f2_scale(x.c1.c1, g3), f2_scale(x.c1.c2, g5));
+    return r;
+  }
+  // x^p: the coefficient of w^k is conjugated in Fp2 and multiplied by gamma1^k, gamma1 = xi^((p-1)/6)
+  static F12 f12_frob1(const F12 &x) {
+    auto g = [](int k) { return f2(Fp::from32(C::FROB1_GAMMA[k - 1][0]), Fp::from32(C::FROB1_GAMMA[k - 1][1])); };
+    auto cj = [](const F2 &a) { return f2(a.a, Fp::neg(a.b)); };
+    static const F2 g1 = g(1), g2 = g(2), g3 = g(3), g4 = g(4), g5 = g(5);
+    F12 r;
+    r.c0 = f6(cj(x.c0.c0), f2_mul(cj(x.c0.c1), g2), f2_mul(cj(x.c0.c2), g4));
+    r.c1 = f6(f2_mul(cj(x.c1.c0), g1), f2_mul(cj(x.c1.c1), g3), f2_mul(cj(x.c1.c2), g5));
+    return r;
+  }
+  // a^x for a in the cyclotomic subgroup (inverse = conjugate), x the curve parameter (negative for BLS12-381)
+  static F12 f12_pow_x(const F12 &a) {
+    F12 r = f12_one();
+    for (int bit = 63; bit >= 0; bit--) { r = f12_mul(r, r); if ((C::X_ABS >> bit) & 1) r = f12_mul(r, a); }
+    return C::X_NEG ? f12_conj(r) : r;
+  }
+  // f^((p^12-1)/r) up to a power coprime to r: easy part (p^6-1)(p^2+1) by conjugation, inversion and a p^2-Frobenius;
+  // hard part (p^4-p^2+1)/r by plain square-and-multiply, or for BLS12 three times it as
+  // (x-1)^2 (x+p) (x^2+p^2-1) + 3 (Hayashida-Hayasaka-Teruya): five 64-bit exponentiations.  Only "== 1" is used.
+  static F12 final_exp(const F12 &f) {
+    F12 t = f12_mul(f12_conj(f), f12_inv(f));
+    t = f12_mul(f12_frob2(t), t);
+    if (C::X_CHAIN) {
+      F12 a = f12_mul(f12_pow_x(t), f12_conj(t));                     // t^(x-1)
+      F12 b = f12_mul(f12_pow_x(a), f12_conj(a));                     // t^((x-1)^2)
+      F12 c = f12_mul(f12_pow_x(b), f12_frob1(b));                    // ^(x+p)
+      F12 d = f12_mul(f12_mul(f12_pow_x(f12_pow_x(c)), f12_frob2(c)), f12_conj(c));   // ^(x^2+p^2-1)
+      return f12_mul(d, f12_mul(t, f12_mul(t, t)));                   // * t^3
+    }
+    F12 out = f12_one();
+    for (int bit = C::HARD_EXP_BITS - 1; bit >= 0; bit--) {
+      out = f12_mul(out, out);
+      if ((C::HARD_EXP[bit >> 6] >> (bit & 63)) & 1) out = f12_mul(out, t);
+    }
+    return out;
+  }
   static bool f12_is_one(const F12 &x) {
     return Fp::eq(x.c0.c0.a, Fp::one()) && Fp::is_zero(x.c0.c0.b) && f2_is_zero(x.c0.c1) && f2_is_zero(x.c0.c2) &&
            f2_is_zero(x.c1.c0) && f2_is_zero(x.c1.c1) && f2_is_zero(x.c1.c2);
@@ -109,12 +168,7 @@ template <class C> struct HostPairing {
         }
       }
     }
-    // f^((p^12 - 1) / r)
-    F12 out = f12_one();
-    for (int bit = C::FINAL_EXP_BITS - 1; bit >= 0; bit--) {
-      out = f12_mul(out, out);
-      if ((C::FINAL_EXP[bit >> 6] >> (bit & 63)) & 1) out = f12_mul(out, f);
-    }
+    F12 out = final_exp(f);                                          // f^((p^12 - 1) / r)
     return f12_is_one(out);
   }
 
