@@ -279,7 +279,7 @@ static int batch_run(avrf_ctx *c, int kind) {
   double t2 = now_us();
   if (kind == 1) launch_thin_terms(c->suite, b, seed, 0, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_scalars.as<uint32_t>(),
                                    c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
-  else launch_ped_terms(c->suite, b, seed, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_scalars.as<uint32_t>(),
+  else launch_ped_terms(c->suite, b, seed, 0, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_scalars.as<uint32_t>(),
                         c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
   double t3 = now_us();
   HostExt r;
@@ -348,6 +348,34 @@ int avrf_thin_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t firs
   BatchDev b = batch_of(c);
   launch_thin_terms(c->suite, b, seed, first_index, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_scalars.as<uint32_t>(),
                     c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
+  if (msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r)) return AVRF_ERR_BAD_ARG;
+  return finish_point(c, r, out_xy);
+}
+
+// The same two steps for pedersen::BatchVerifier (src/pedersen.rs:341-426): challenges of the staged shard, then the MSM
+// of its 5 n_shard + 2 terms under the global weight stream (the shard's shares of the G and BLINDING_BASE terms included).
+int avrf_pedersen_batch_challenges(avrf_ctx *c, uint8_t *c_out) {
+  if (!c || c->staged_kind != 2 || (c->n && !c_out)) return AVRF_ERR_BAD_ARG;
+  if (c->n == 0) return AVRF_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  BatchDev b = batch_of(c);
+  HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  launch_ped_prepare(c->suite, b, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(c_out, c->d_c.p, c->n * 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return *c->h_flags.as<uint32_t>() ? AVRF_INVALID_DATA : AVRF_OK;
+}
+int avrf_pedersen_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t first_index, uint8_t out_xy[64]) {
+  if (!c || c->staged_kind != 2 || !seed64 || !out_xy) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  HostExt r;
+  if (c->n == 0) { r = c->suite == 0 ? HostTe<SuiteBandersnatch>::identity() : HostTe<SuiteBabyJubJub>::identity(); return finish_point(c, r, out_xy); }
+  Seed64 seed;
+  for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, seed64 + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
+  BatchDev b = batch_of(c);
+  launch_ped_terms(c->suite, b, seed, first_index, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_scalars.as<uint32_t>(),
+                   c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
   if (msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r)) return AVRF_ERR_BAD_ARG;
   return finish_point(c, r, out_xy);
 }

@@ -21,7 +21,7 @@ void launch_thin_terms(int suite, const BatchDev &b, const Seed64 &seed, uint64_
 
 // pedersen::BatchItem::new (src/pedersen.rs:276-293) and the (5N+2)-term MSM of :369-418.
 void launch_ped_prepare(int suite, const BatchDev &b, uint32_t *d_c, uint8_t *d_merged, uint32_t *d_flags, hipStream_t st);
-void launch_ped_terms(int suite, const BatchDev &b, const Seed64 &seed, const uint32_t *d_c, const uint8_t *d_merged,
+void launch_ped_terms(int suite, const BatchDev &b, const Seed64 &seed, uint64_t j0, const uint32_t *d_c, const uint8_t *d_merged,
                       uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st);
 
 // independent per-item kernels (vrf_single.hip)

@@ -194,7 +194,7 @@ k_ped_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint8_t *__restrict__ me
 // per-item part of pedersen::BatchVerifier::verify, src/pedersen.rs:369-410
 template <class S>
 __global__ void __launch_bounds__(128)
-k_ped_terms(BatchDev b, Seed64 seed, const uint32_t *__restrict__ c_in, const uint8_t *__restrict__ merged_xy,
+k_ped_terms(BatchDev b, Seed64 seed, uint64_t j0, const uint32_t *__restrict__ c_in, const uint8_t *__restrict__ merged_xy,
             uint32_t *__restrict__ scalars, te_pre *__restrict__ pre, uint32_t *__restrict__ gpart, uint32_t *__restrict__ bpart) {
   using Fr = typename S::Fr;
   __shared__ fp red[128];
@@ -202,7 +202,8 @@ k_ped_terms(BatchDev b, Seed64 seed, const uint32_t *__restrict__ c_in, const ui
   fp us = fp_zero(), usb = fp_zero();
   if (j < b.n) {
     // 32 squeezed bytes per item: t = bytes[0..16], u = bytes[16..32]   (:373-381)
-    fp t_plain = xof128(seed.w, 2 * j), u_plain = xof128(seed.w, 2 * j + 1);
+    // (j0: global index of the shard's first item when one batch is split over several GPUs)
+    fp t_plain = xof128(seed.w, 2 * (j0 + j)), u_plain = xof128(seed.w, 2 * (j0 + j) + 1);
     fp tt = fp_to_mont<Fr>(t_plain), uu = fp_to_mont<Fr>(u_plain);
     fp c = fp_to_mont<Fr>(fp_from_u128(c_in + 4 * (size_t)j));
     const uint8_t *pr = b.proofs + 256 * (size_t)j, *mo = merged_xy + 128 * (size_t)j;
@@ -238,17 +239,17 @@ void launch_ped_prepare(int suite, const BatchDev &b, uint32_t *d_c, uint8_t *d_
   if (suite == 0) hipLaunchKernelGGL(k_ped_prepare<SuiteBandersnatch>, g, blk, 0, st, b, d_c, d_merged, d_flags);
   else hipLaunchKernelGGL(k_ped_prepare<SuiteBabyJubJub>, g, blk, 0, st, b, d_c, d_merged, d_flags);
 }
-void launch_ped_terms(int suite, const BatchDev &b, const Seed64 &seed, const uint32_t *d_c, const uint8_t *d_merged,
+void launch_ped_terms(int suite, const BatchDev &b, const Seed64 &seed, uint64_t j0, const uint32_t *d_c, const uint8_t *d_merged,
                       uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st) {
   if (!b.n) return;
   dim3 g((b.n + 127) / 128), blk(128);
   uint32_t *bp = d_gpart + 8 * (size_t)g.x;
   if (suite == 0) {
-    hipLaunchKernelGGL(k_ped_terms<SuiteBandersnatch>, g, blk, 0, st, b, seed, d_c, d_merged, d_scalars, (te_pre *)d_pre, d_gpart, bp);
+    hipLaunchKernelGGL(k_ped_terms<SuiteBandersnatch>, g, blk, 0, st, b, seed, j0, d_c, d_merged, d_scalars, (te_pre *)d_pre, d_gpart, bp);
     hipLaunchKernelGGL(k_g_final<SuiteBandersnatch>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 2, 0);
     hipLaunchKernelGGL(k_g_final<SuiteBandersnatch>, dim3(1), dim3(256), 0, st, bp, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 1);
   } else {
-    hipLaunchKernelGGL(k_ped_terms<SuiteBabyJubJub>, g, blk, 0, st, b, seed, d_c, d_merged, d_scalars, (te_pre *)d_pre, d_gpart, bp);
+    hipLaunchKernelGGL(k_ped_terms<SuiteBabyJubJub>, g, blk, 0, st, b, seed, j0, d_c, d_merged, d_scalars, (te_pre *)d_pre, d_gpart, bp);
     hipLaunchKernelGGL(k_g_final<SuiteBabyJubJub>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 2, 0);
     hipLaunchKernelGGL(k_g_final<SuiteBabyJubJub>, dim3(1), dim3(256), 0, st, bp, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 1);
   }

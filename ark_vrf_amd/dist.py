@@ -38,12 +38,46 @@ def shard_thin_batch(b, lo, hi):
                 proofs=b["proofs"][96 * lo: 96 * hi])
 
 
+def shard_pedersen_batch(b, lo, hi):
+    """Same for a packed Pedersen batch (proofs 256 bytes per item, no public keys)."""
+    io_pre, ad_pre = [0], [0]
+    for c in b["io_counts"]:
+        io_pre.append(io_pre[-1] + c)
+    for a in b["ad_lens"]:
+        ad_pre.append(ad_pre[-1] + a)
+    return dict(n=hi - lo, ios_xy=b["ios_xy"][128 * io_pre[lo]: 128 * io_pre[hi]], io_counts=b["io_counts"][lo:hi],
+                ads=b["ads"][ad_pre[lo]: ad_pre[hi]], ad_lens=b["ad_lens"][lo:hi], proofs=b["proofs"][256 * lo: 256 * hi])
+
+
 class GpuEngine:
     """libavrf.so-backed engine for one rank (one context = one GPU stream)."""
 
     def __init__(self, ctx):
         from . import _native as nat
         self.ctx, self.nat = ctx, nat
+
+    # ---- pedersen::BatchVerifier pieces (src/pedersen.rs:276-293,341-426)
+    def ped_challenges(self, shard):
+        nat = self.nat
+        b = nat.Batch(shard["n"], shard["ios_xy"], shard["io_counts"], shard["ads"], shard["ad_lens"], proofs=shard["proofs"])
+        st = self.ctx.pedersen_batch_stage(b)
+        if st != 0:
+            return st, b""
+        out = (C.c_uint8 * max(1, 16 * shard["n"]))()
+        st = nat.lib().avrf_pedersen_batch_challenges(self.ctx._h, out)
+        return st, bytes(out)[: 16 * shard["n"]]
+
+    def ped_weight_seed(self, suite, c_all, resp_all):
+        seed = (C.c_uint8 * 64)()
+        st = self.nat.lib().avrf_batch_weight_seed(int(suite), 1, C.c_size_t(len(resp_all) // 64), self.nat._u8(c_all), self.nat._u8(resp_all), seed)
+        assert st == 0
+        return bytes(seed)
+
+    def ped_partial(self, seed, first_index):
+        out = (C.c_uint8 * 64)()
+        st = self.nat.lib().avrf_pedersen_batch_partial(self.ctx._h, self.nat._u8(seed), C.c_uint64(first_index), out)
+        assert st == 0, st
+        return bytes(out)
 
     def challenges(self, shard):
         nat = self.nat
@@ -116,5 +150,31 @@ def sharded_thin_batch_verify(engine, suite, batch, dist, group=None, device="cp
     seed = engine.weight_seed(suite, c_all, s_all)                    # sequential hash, every rank the same
     mine = engine.partial(seed, lo)
     pts = _all_gather_bytes(dist, group, mine, device)               # exchange step 2: P partial points
+    total = engine.points_sum(suite, b"".join(pts))
+    return 0 if total == IDENTITY_XY else 1
+
+
+def sharded_pedersen_batch_verify(engine, suite, batch, dist, group=None, device="cpu"):
+    """pedersen::BatchVerifier::verify (src/pedersen.rs:341-426) of ONE batch split by items over the ranks: same two
+    exchange steps as the Thin form (challenges + responses s || sb, then the partial points)."""
+    import torch
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = batch["n"]
+    if n == 0:
+        return 0                                                   # src/pedersen.rs:343-345
+    lo, hi = shard_range(n, rank, world)
+    shard = shard_pedersen_batch(batch, lo, hi)
+    st, c_mine = engine.ped_challenges(shard)
+    flag = torch.tensor([1 if st != 0 else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag.item()):
+        return 2                                                   # src/pedersen.rs:348-353
+    r_mine = b"".join(shard["proofs"][256 * j + 192: 256 * j + 256] for j in range(shard["n"]))
+    parts = _all_gather_bytes(dist, group, c_mine + r_mine, device)   # 16 bytes c + 64 bytes (s || sb) per item
+    c_all = b"".join(p[: len(p) // 5] for p in parts)
+    r_all = b"".join(p[len(p) // 5:] for p in parts)
+    seed = engine.ped_weight_seed(suite, c_all, r_all)
+    mine = engine.ped_partial(seed, lo)
+    pts = _all_gather_bytes(dist, group, mine, device)
     total = engine.points_sum(suite, b"".join(pts))
     return 0 if total == IDENTITY_XY else 1

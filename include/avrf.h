@@ -85,6 +85,12 @@ int avrf_thin_batch_stage(avrf_ctx *ctx, size_t n, const uint8_t *pks_xy, const 
                           const uint8_t *proofs);
 int avrf_thin_batch_run(avrf_ctx *ctx);
 
+/* pedersen::BatchVerifier split the same way (src/pedersen.rs:341-426): stage the shard with avrf_pedersen_batch_stage,
+ * avrf_pedersen_batch_challenges -> n_shard x 16 bytes, avrf_batch_weight_seed(pedersen = 1) over all items
+ * (resp = s || sb, 64 bytes per item), avrf_pedersen_batch_partial(seed, first_index) -> the shard's partial point. */
+int avrf_pedersen_batch_challenges(avrf_ctx *ctx, uint8_t *c_out);
+int avrf_pedersen_batch_partial(avrf_ctx *ctx, const uint8_t seed64[64], uint64_t first_index, uint8_t out_xy[64]);
+
 /* One BatchVerifier split over several GPUs; see ark_vrf_amd/dist.py.
  * The weights of src/thin.rs:274-289 depend on ALL items, so: every rank stages its shard and calls
  * avrf_thin_batch_challenges (per-item c_j, 16 bytes each); the c_j and response scalars are

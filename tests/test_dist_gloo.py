@@ -26,7 +26,7 @@ class OracleEngine:
         from helpers import compressed_items
         self.orc, self.suite, self.rank = orc, suite, rank
         self.full = full_batch
-        self.comp = compressed_items(suite, full_batch, 0)
+        self.comp = compressed_items(suite, full_batch, 0) if full_batch.get("pks_xy") else None
 
     def challenges(self, shard):
         # restates src/thin.rs:209-226 with hashlib: c = first 16 bytes of block 0 of the challenge transcript
@@ -74,6 +74,49 @@ class OracleEngine:
             sl_b += bases[-64:]; sl_s += sc[-32:]
         return orc.msm(self.suite, sl_b, sl_s) if sl_s else bytes(32) + (1).to_bytes(32, "little")
 
+    # ---- pedersen::BatchVerifier stand-ins: the oracle restates the whole batch (src/pedersen.rs:361-418); the per-item
+    # challenge is recovered from its terms, c_j = (t_j c_j) / t_j mod r (terms 5j and 5j+1)
+    R_BANDERSNATCH = 0x1cfb69d4ca675f520cce760202687600ff8f87007419047174fd06b52876e7e1
+
+    def _ped_terms(self):
+        from helpers import compressed_items
+        _, ios, ads, proofs = compressed_items(self.suite, self.full, 1)
+        return self.orc.pedersen_batch_terms(self.suite, ios, ads, proofs)
+
+    def ped_challenges(self, shard):
+        from ark_vrf_amd.dist import shard_range
+        st, bases, sc = self._ped_terms()
+        if st != 0:
+            return st, b""
+        n, r = self.full["n"], self.R_BANDERSNATCH
+        lo, hi = shard_range(n, self.rank, int(os.environ["WORLD_SIZE"]))
+        out = []
+        for j in range(lo, hi):
+            tc = int.from_bytes(sc[32 * 5 * j: 32 * 5 * j + 32], "little"); t = int.from_bytes(sc[32 * (5 * j + 1): 32 * (5 * j + 1) + 32], "little")
+            out.append((tc * pow(t, -1, r) % r).to_bytes(16, "little"))
+        return 0, b"".join(out)
+
+    def ped_weight_seed(self, suite, c_all, resp_all):
+        from ark_vrf_amd import _native as nat   # real product host code
+        seed = (C.c_uint8 * 64)()
+        assert nat.lib().avrf_batch_weight_seed(suite, 1, C.c_size_t(len(resp_all) // 64), nat._u8(c_all), nat._u8(resp_all), seed) == 0
+        self.seed = bytes(seed)
+        return self.seed
+
+    def ped_partial(self, seed, first_index):
+        from ark_vrf_amd.dist import shard_range
+        st, bases, sc = self._ped_terms()
+        assert st == 0
+        # the seed derived through the all-gather reproduces the oracle's weights: t_0 = first 16 bytes of XOF block 0
+        assert hashlib.sha512(seed + (0).to_bytes(8, "little")).digest()[:16] == sc[32: 48] and sc[48:64] == bytes(16)
+        n = self.full["n"]
+        lo, hi = shard_range(n, self.rank, int(os.environ["WORLD_SIZE"]))
+        assert lo == first_index
+        sl_b, sl_s = bases[64 * 5 * lo: 64 * 5 * hi], sc[32 * 5 * lo: 32 * 5 * hi]
+        if self.rank == 0:
+            sl_b += bases[-128:]; sl_s += sc[-64:]                  # the shared G and BLINDING_BASE terms
+        return self.orc.msm(self.suite, sl_b, sl_s) if sl_s else bytes(32) + (1).to_bytes(32, "little")
+
     def points_sum(self, suite, pts):
         from ark_vrf_amd import _native as nat   # real product host code
         out = (C.c_uint8 * 64)()
@@ -106,6 +149,16 @@ def _worker(rank, world, port, n, q):
     _, _, sc = orc.thin_batch_terms(0, pks, ios, ads, proofs)
     w0 = hashlib.sha512(eng.seed + (0).to_bytes(8, "little")).digest()[:16]
     res.append(sc[:16] == w0 and sc[16:32] == bytes(16))
+    # pedersen::BatchVerifier split the same way (src/pedersen.rs:341-426)
+    from ark_vrf_amd.dist import sharded_pedersen_batch_verify
+    pgood = orc.gen_batch(0, 1, n, threads=1)
+    for case in ["good", "tampered", "identity_yb"]:
+        b = dict(pgood)
+        if case == "tampered":
+            p = bytearray(b["proofs"]); p[256 * (n - 2) + 225] ^= 1; b["proofs"] = bytes(p)
+        if case == "identity_yb":
+            b["proofs"] = bytes(32) + (1).to_bytes(32, "little") + b["proofs"][64:]
+        res.append(sharded_pedersen_batch_verify(OracleEngine(0, b, rank), 0, b, dist))
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -122,4 +175,4 @@ def test_sharded_batch_verify_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert out[0] == out[1] == [0, 1, 2, True]
+    assert out[0] == out[1] == [0, 1, 2, True, 0, 1, 2]

@@ -58,3 +58,51 @@ def test_sharded_verify_one_rank_group():
         assert sharded_thin_batch_verify(eng, 0, b3, dist) == 2
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("suite,shards", [(0, 1), (0, 3), (1, 4)])
+def test_pedersen_logical_shards(suite, shards):
+    """pedersen::BatchVerifier (src/pedersen.rs:341-426) split into shards: the partial points add up to the identity for
+    a valid batch, not for a tampered one, and the unsharded verifier agrees."""
+    from ark_vrf_amd import _native as nat
+    from ark_vrf_amd.dist import GpuEngine, IDENTITY_XY, shard_pedersen_batch, shard_range
+    n = 333
+    good = orc.gen_batch(suite, 1, n)
+    for tamper in (False, True):
+        b = dict(good)
+        if tamper:
+            p = bytearray(b["proofs"]); p[256 * 200 + 230] ^= 1; b["proofs"] = bytes(p)
+        engs = [GpuEngine(nat.Context(suite)) for _ in range(shards)]
+        cs, rs = [], []
+        for r, e in enumerate(engs):
+            lo, hi = shard_range(n, r, shards)
+            sh = shard_pedersen_batch(b, lo, hi)
+            st, c = e.ped_challenges(sh)
+            assert st == 0
+            cs.append(c); rs.append(b"".join(sh["proofs"][256 * j + 192: 256 * j + 256] for j in range(sh["n"])))
+        seed = engs[0].ped_weight_seed(suite, b"".join(cs), b"".join(rs))
+        parts = [e.ped_partial(seed, shard_range(n, r, shards)[0]) for r, e in enumerate(engs)]
+        assert (engs[0].points_sum(suite, b"".join(parts)) == IDENTITY_XY) == (not tamper)
+        c0 = engs[0].ctx
+        assert c0.pedersen_batch_stage(nat.Batch(n, b["ios_xy"], b["io_counts"], b["ads"], b["ad_lens"], proofs=b["proofs"])) == 0
+        assert c0.pedersen_batch_run() == (1 if tamper else 0)
+
+
+def test_sharded_pedersen_verify_one_rank_group():
+    import torch.distributed as dist
+    from ark_vrf_amd import _native as nat
+    from ark_vrf_amd.dist import GpuEngine, sharded_pedersen_batch_verify
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        b = orc.gen_batch(0, 1, 150)
+        eng = GpuEngine(nat.Context(0))
+        assert sharded_pedersen_batch_verify(eng, 0, b, dist) == 0
+        p = bytearray(b["proofs"]); p[256 * 9 + 200] ^= 1
+        b2 = dict(b); b2["proofs"] = bytes(p)
+        assert sharded_pedersen_batch_verify(eng, 0, b2, dist) == 1
+        b3 = dict(b); b3["proofs"] = bytes(32) + (1).to_bytes(32, "little") + b["proofs"][64:]     # Yb = identity
+        assert sharded_pedersen_batch_verify(eng, 0, b3, dist) == 2
+    finally:
+        dist.destroy_process_group()
