@@ -65,23 +65,26 @@ class HostSha512 {
     uint64_t w[16];
     for (int i = 0; i < 16; i++) w[i] = be64(blk + 8 * i);
     uint64_t a = h_[0], b = h_[1], c = h_[2], d = h_[3], e = h_[4], f = h_[5], g = h_[6], hh = h_[7];
-#define AVRF_RND(i)                                                                          \
-  {                                                                                          \
-    uint64_t t1 = hh + (ror(e, 14) ^ ror(e, 18) ^ ror(e, 41)) + ((e & f) ^ (~e & g)) + K[r + i] + w[i]; \
-    uint64_t t2 = (ror(a, 28) ^ ror(a, 34) ^ ror(a, 39)) + ((a & b) ^ (a & c) ^ (b & c));    \
-    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;                       \
+    // one round with the eight working variables passed in rotated order (no register shuffling between rounds)
+#define AVRF_RND(A, B, C, D, E, F, G, H, kw)                                             \
+  {                                                                                      \
+    uint64_t t1 = H + (ror(E, 14) ^ ror(E, 18) ^ ror(E, 41)) + (G ^ (E & (F ^ G))) + (kw); \
+    uint64_t t2 = (ror(A, 28) ^ ror(A, 34) ^ ror(A, 39)) + ((A & B) | (C & (A | B)));    \
+    D += t1; H = t1 + t2;                                                                \
   }
-    for (int r = 0; r < 80; r += 16) {
-      if (r) {
-        for (int i = 0; i < 16; i++) {
-          uint64_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
-          w[i] += (ror(w15, 1) ^ ror(w15, 8) ^ (w15 >> 7)) + w[(i + 9) & 15] + (ror(w2, 19) ^ ror(w2, 61) ^ (w2 >> 6));
-          AVRF_RND(i)
-        }
-      } else {
-        for (int i = 0; i < 16; i++) AVRF_RND(i)
-      }
-    }
+#define AVRF_W(i) (w[(i) & 15] += (ror(w[((i) + 1) & 15], 1) ^ ror(w[((i) + 1) & 15], 8) ^ (w[((i) + 1) & 15] >> 7)) + w[((i) + 9) & 15] + \
+                                  (ror(w[((i) + 14) & 15], 19) ^ ror(w[((i) + 14) & 15], 61) ^ (w[((i) + 14) & 15] >> 6)))
+#define AVRF_8(r, W)                                                                      \
+    AVRF_RND(a, b, c, d, e, f, g, hh, K[r + 0] + W(r + 0)) AVRF_RND(hh, a, b, c, d, e, f, g, K[r + 1] + W(r + 1)) \
+    AVRF_RND(g, hh, a, b, c, d, e, f, K[r + 2] + W(r + 2)) AVRF_RND(f, g, hh, a, b, c, d, e, K[r + 3] + W(r + 3)) \
+    AVRF_RND(e, f, g, hh, a, b, c, d, K[r + 4] + W(r + 4)) AVRF_RND(d, e, f, g, hh, a, b, c, K[r + 5] + W(r + 5)) \
+    AVRF_RND(c, d, e, f, g, hh, a, b, K[r + 6] + W(r + 6)) AVRF_RND(b, c, d, e, f, g, hh, a, K[r + 7] + W(r + 7))
+#define AVRF_W0(i) w[(i) & 15]
+    AVRF_8(0, AVRF_W0) AVRF_8(8, AVRF_W0)
+    for (int r = 16; r < 80; r += 16) { AVRF_8(r, AVRF_W) AVRF_8(r + 8, AVRF_W) }
+#undef AVRF_W0
+#undef AVRF_8
+#undef AVRF_W
 #undef AVRF_RND
     h_[0] += a; h_[1] += b; h_[2] += c; h_[3] += d; h_[4] += e; h_[5] += f; h_[6] += g; h_[7] += hh;
   }
