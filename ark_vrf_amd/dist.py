@@ -178,3 +178,36 @@ def sharded_pedersen_batch_verify(engine, suite, batch, dist, group=None, device
     pts = _all_gather_bytes(dist, group, mine, device)
     total = engine.points_sum(suite, b"".join(pts))
     return 0 if total == IDENTITY_XY else 1
+
+
+# ---- Ring VRF: proofs are independent units -- static partition by proof index, per-ring state
+# (SRS tables, prover key) replicated on every rank, one gather of the proof bytes / one reduction of the verdicts.
+
+def sharded_ring_prove(prove_fn, key_indices, blindings, dist, group=None, device="cpu"):
+    """ring::Prover::prove's ring half for a list of (key index, blinding) split over the ranks of `group`.
+    prove_fn(indices, blindings) -> list of proof bytes for this rank's slice (RingKey.prove on a GPU rank).
+    Every rank returns the complete list, in input order."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = len(key_indices)
+    lo, hi = shard_range(n, rank, world)
+    mine = prove_fn(list(key_indices[lo:hi]), list(blindings[lo:hi])) if hi > lo else []
+    parts = _all_gather_bytes(dist, group, b"".join(mine), device)   # the only exchange: the proof bytes
+    out = []
+    for r, p in enumerate(parts):
+        rlo, rhi = shard_range(n, r, world)
+        if rhi > rlo:
+            plen = len(p) // (rhi - rlo)
+            out += [p[i * plen: (i + 1) * plen] for i in range(rhi - rlo)]
+    return out
+
+
+def sharded_ring_batch_verify(verify_fn, n_items, dist, group=None, device="cpu"):
+    """ring::BatchVerifier over items split by index: verify_fn(lo, hi) -> status of this rank's slice (0 Ok,
+    1 VerificationFailure, 2 InvalidData); the batch's status is the worst one (every slice is its own pairing check)."""
+    import torch
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = shard_range(n_items, rank, world)
+    st = verify_fn(lo, hi) if hi > lo else 0
+    t = torch.tensor([st], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())

@@ -176,3 +176,49 @@ def test_sharded_batch_verify_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert out[0] == out[1] == [0, 1, 2, True, 0, 1, 2]
+
+
+def _ring_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as orc
+    from oracle import ring_py as R
+    from ark_vrf_amd.dist import sharded_ring_batch_verify, sharded_ring_prove
+    s = R.SUITES[0]
+    srs = R.Srs(s, open(os.path.join(ROOT, "tests", "golden", "bls12-381-srs-2-11-uncompressed-zcash.bin"), "rb").read())
+    prm = R.Params(s, ring_size=8)
+    sks = [orc.from_seed(0, bytes([21, i]) + bytes(30)) for i in range(4)]
+    cols = R.index(prm, srs, [R.te_decode(s, pk) for _, pk in sks])
+    idx, bl = [3, 0, 2], [5, 1 << 200, (1 << 252) + 12345]
+    calls = []
+
+    def prove_fn(ii, bb):                                  # the device step of a rank, played by the oracle prover
+        calls.append(list(ii))
+        return [R.prove(prm, srs, cols, i, b)[0] for i, b in zip(ii, bb)]
+
+    proofs = sharded_ring_prove(prove_fn, idx, bl, dist)
+    ok = len(proofs) == 3 and all(len(p) == 592 for p in proofs) and calls == [[3, 0]] if rank == 0 else calls == [[2]]
+    mine = proofs[0] == R.prove(prm, srs, cols, 3, 5)[0] if rank == 0 else proofs[2] == R.prove(prm, srs, cols, 2, bl[2])[0]
+    worst = sharded_ring_batch_verify(lambda lo, hi: 1 if (lo <= 2 < hi) else 0, 3, dist)      # rank 1's slice fails
+    q.put((rank, [ok, mine, proofs, worst]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_ring_prove_world2():
+    """Ring proofs split by index over two ranks: each rank proves its slice only, everybody ends up
+    with all proofs in input order; verification status = worst slice."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ring_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0][0] and out[1][0] and out[0][1] and out[1][1]
+    assert out[0][2] == out[1][2] and out[0][3] == out[1][3] == 1

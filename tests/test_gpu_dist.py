@@ -106,3 +106,36 @@ def test_sharded_pedersen_verify_one_rank_group():
         assert sharded_pedersen_batch_verify(eng, 0, b3, dist) == 2
     finally:
         dist.destroy_process_group()
+
+
+def test_sharded_ring_prove_and_verify_one_rank_group(golden_dir):
+    """Ring proofs / verifications split by index over the process group (1 rank here; world 2 on gloo in
+    tests/test_dist_gloo.py): same bytes as one call, verdict = worst slice."""
+    import json
+    import torch.distributed as dist
+    from ark_vrf_amd import _native as nat
+    from ark_vrf_amd.dist import sharded_ring_batch_verify, sharded_ring_prove
+    from ark_vrf_amd.ring import RingSetup, ring_batch_verify
+    from helpers import xy
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        ctx = nat.Context(0)
+        setup = RingSetup(ctx, open(os.path.join(golden_dir, "bls12-381-srs-2-11-uncompressed-zcash.bin"), "rb").read(), 8)
+        sks = [orc.from_seed(0, bytes([11, i]) + bytes(30)) for i in range(5)]
+        key = setup.index([xy(0, pk) for _, pk in sks])
+        h = orc.hash_to_curve(0, b"dist-ring")
+        idx, bl, ybs = [], [], []
+        for j in (4, 0, 2):
+            ped, b = orc.pedersen_prove(0, sks[j][0], [(h, orc.vrf_output(0, sks[j][0], h))], b"x")
+            idx.append(j); bl.append(b); ybs.append(xy(0, ped[:32]))
+        proofs = sharded_ring_prove(key.prove, idx, bl, dist)
+        assert proofs == key.prove(idx, bl)
+        vf = lambda lo, hi: ring_batch_verify(setup, [key.commitment], None, ybs[lo:hi], proofs[lo:hi])
+        assert sharded_ring_batch_verify(vf, 3, dist) == 0
+        bad = list(proofs); bad[1] = bad[1][:200] + bytes([bad[1][200] ^ 1]) + bad[1][201:]
+        vb = lambda lo, hi: ring_batch_verify(setup, [key.commitment], None, ybs[lo:hi], bad[lo:hi])
+        assert sharded_ring_batch_verify(vb, 3, dist) != 0
+    finally:
+        dist.destroy_process_group()
