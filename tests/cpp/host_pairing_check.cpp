@@ -36,8 +36,14 @@ template <class G> static int run(const std::vector<uint8_t> &srs) {
   const uint64_t three[4] = {3, 0, 0, 0};
   typename HP::G2 a = HP::g2_add(HP::g2_dbl(q[0]), q[0]), b3 = HP::g2_mul(q[0], three);
   bool law = !a.inf && HP::f2_eq(a.x, b3.x) && HP::f2_eq(a.y, b3.y);
-  printf("consistent=%d negative=%d consistent_high=%d g2_codec=%d g2_law=%d\n", ok, bad, ok2, codec, law);
-  return (ok && !bad && ok2 && codec && law) ? 0 : 1;
+  // cyclotomic squaring agrees with the general product on an element of the cyclotomic subgroup (f^((p^6-1)(p^2+1)))
+  typename HP::F12 f = HP::f12_one(); f.c0.c1 = HP::f2(px[0], py[0]); f.c1.c2 = HP::f2(py[1], px[1]); f.c1.c0 = HP::f2(px[1], py[0]);
+  typename HP::F12 t = HP::f12_mul(HP::f12_conj(f), HP::f12_inv(f)); t = HP::f12_mul(HP::f12_frob2(t), t);
+  typename HP::F12 s1 = HP::f12_cyclo_sqr(t), s2 = HP::f12_mul(t, t);
+  bool cyc = HP::f12_is_one(HP::f12_mul(s1, HP::f12_conj(s2)));       // s1 / s2 == 1 (inverse = conjugate there)
+  bool inv = HP::f12_is_one(HP::f12_mul(f, HP::f12_inv(f)));
+  printf("consistent=%d negative=%d consistent_high=%d g2_codec=%d g2_law=%d cyclo_sqr=%d f12_inv=%d\n", ok, bad, ok2, codec, law, cyc, inv);
+  return (ok && !bad && ok2 && codec && law && cyc && inv) ? 0 : 1;
 }
 
 int main(int argc, char **argv) {
