@@ -32,22 +32,28 @@ template <class F> struct HostFieldN {
   static El sub(const El &a, const El &b) { El t; if (subb(t, a, b)) addc(t, t, P()); return t; }
   static El neg(const El &a) { if (is_zero(a)) return a; El t; subb(t, P(), a); return t; }
   static El dbl(const El &a) { return add(a, a); }
+  static constexpr uint64_t p_limb(int i) { return (uint64_t)F::P[2 * i] | ((uint64_t)F::P[2 * i + 1] << 32); }
+  static constexpr uint64_t ninv_c() { uint64_t p0 = p_limb(0), inv = 1; for (int i = 0; i < 7; i++) inv *= 2 - p0 * inv; return (uint64_t)0 - inv; }
+  // Montgomery product, operand scanning with the reduction interleaved (CIOS); constants folded at compile time
   static El mul(const El &a, const El &b) {
-    static const uint64_t ninv = ninv64();
-    static const El p = P();
+    constexpr uint64_t ninv = ninv_c();
     uint64_t t[L + 2];
+#pragma GCC unroll 16
     for (int i = 0; i < L + 2; i++) t[i] = 0;
+#pragma GCC unroll 16
     for (int i = 0; i < L; i++) {
       unsigned __int128 c = 0;
+#pragma GCC unroll 16
       for (int j = 0; j < L; j++) { c += (unsigned __int128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
       c += t[L]; t[L] = (uint64_t)c; t[L + 1] = (uint64_t)(c >> 64);
-      uint64_t q = t[0] * ninv;
-      c = (unsigned __int128)q * p.l[0] + t[0]; c >>= 64;
-      for (int j = 1; j < L; j++) { c += (unsigned __int128)q * p.l[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+      const uint64_t q = t[0] * ninv;
+      c = (unsigned __int128)q * p_limb(0) + t[0]; c >>= 64;
+#pragma GCC unroll 16
+      for (int j = 1; j < L; j++) { c += (unsigned __int128)q * p_limb(j) + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
       c += t[L]; t[L - 1] = (uint64_t)c; t[L] = t[L + 1] + (uint64_t)(c >> 64);
     }
     El r, u; for (int i = 0; i < L; i++) r.l[i] = t[i];
-    uint64_t br = subb(u, r, p);
+    uint64_t br = subb(u, r, P());
     return (t[L] || !br) ? u : r;
   }
   static El sqr(const El &a) { return mul(a, a); }
