@@ -1089,14 +1089,15 @@ template <class S, class G> struct Ring {
     const size_t n = scalars_plain.size();
     G1Aff r; memset(&r, 0, sizeof r); r.inf = true;
     if (!n) return r;
-    uint8_t *d_xy; uint32_t *d_b, *d_s, *d_flag;
-    HIP_CHECK(hipMalloc(&d_xy, n * 2 * FQB)); HIP_CHECK(hipMalloc(&d_b, n * 2 * FQB)); HIP_CHECK(hipMalloc(&d_s, n * 32)); HIP_CHECK(hipMalloc(&d_flag, 4));
+    // staging in the setup's grow-only scratch (no allocation on the verification path)
+    const size_t pb = (n * 2 * FQB + 255) / 256 * 256, sb = (n * 32 + 255) / 256 * 256;
+    uint8_t *base = (uint8_t *)dev_scratch(su, 1, 2 * pb + sb + 256);
+    uint8_t *d_xy = base; uint32_t *d_b = (uint32_t *)(base + pb), *d_s = (uint32_t *)(base + 2 * pb), *d_flag = (uint32_t *)(base + 2 * pb + sb);
     HIP_CHECK(hipMemcpyAsync(d_xy, bases_xy.data(), n * 2 * FQB, hipMemcpyHostToDevice, su->stream));
     HIP_CHECK(hipMemcpyAsync(d_s, scalars_plain.data(), n * 32, hipMemcpyHostToDevice, su->stream));
     HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream));
     launch_g1_bases(su->suite, d_xy, n, d_b, d_flag, su->stream);
     msm_g1_device(su->suite, d_b, d_s, n, su->ws, su->stream, r.xy);
-    HIP_CHECK(hipFree(d_xy)); HIP_CHECK(hipFree(d_b)); HIP_CHECK(hipFree(d_s)); HIP_CHECK(hipFree(d_flag));
     r.inf = true; for (int i = 0; i < 2 * FQB; i++) if (r.xy[i]) r.inf = false;
     return r;
   }
@@ -1108,6 +1109,10 @@ template <class S, class G> struct Ring {
   static int verify_batch(avrf_ring_setup *su, size_t n, const uint8_t *commitments, const uint32_t *ring_of_item, size_t n_rings,
                           const uint8_t *instances_xy, const uint8_t *proofs) {
     if (n == 0) return AVRF_OK;
+    static const bool trace = getenv("AVRF_RING_TRACE") != nullptr;
+    auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    double t_prev = now();
+    auto lap = [&](const char *what) { if (trace) { double t = now(); fprintf(stderr, "  ring_verify[%zu] %-28s %8.3f ms\n", n, what, t - t_prev); t_prev = t; } };
     const size_t N = su->N, cap = su->cap, plen = 4 * FQB + 7 * 32 + FQB + 32 + 2 * FQB, clen = 3 * FQB;
     const H256 one = Fr::one();
     std::vector<G1Aff> fixed(3 * n_rings);
@@ -1199,10 +1204,12 @@ template <class S, class G> struct Ring {
       put(b2, s2, 2 * it, pi1, Fr::neg(r1)); put(b2, s2, 2 * it + 1, pi2, Fr::neg(r2));
     });
     if (status != AVRF_OK) return status;
+    lap("decode + transcripts (host)");
     H256 g1_scalar = {{0, 0, 0, 0}};
     for (size_t it = 0; it < n; it++) g1_scalar = Fr::sub(g1_scalar, gsc[it]);
     put(b1, s1, 10 * n, su->g1_0, g1_scalar);
     G1Aff acc1 = g1_msm(su, b1, s1), acc2 = g1_msm(su, b2, s2);
+    lap("two G1 MSMs (device)");
     using HP = HostPairing<G>;
     typename HP::G2 q[2];
     const size_t g2len = su->g2_raw.size() / 2;
@@ -1210,7 +1217,9 @@ template <class S, class G> struct Ring {
     QEl px[2], py[2]; bool pinf[2] = {acc1.inf, acc2.inf};
     const G1Aff *accs[2] = {&acc1, &acc2};
     for (int i = 0; i < 2; i++) { QEl x, y; memset(&x, 0, sizeof x); memset(&y, 0, sizeof y); memcpy(x.l, accs[i]->xy, FQB); memcpy(y.l, accs[i]->xy + FQB, FQB); px[i] = FqN::to_mont(x); py[i] = FqN::to_mont(y); }
-    return HP::product_is_one(px, py, pinf, q, 2) ? AVRF_OK : AVRF_VERIFICATION_FAILURE;
+    const bool ok = HP::product_is_one(px, py, pinf, q, 2);
+    lap("2-pairing check (host)");
+    return ok ? AVRF_OK : AVRF_VERIFICATION_FAILURE;
   }
 };
 
