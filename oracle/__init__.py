@@ -247,3 +247,20 @@ def thin_batch_verify_xy(suite, b):
 def pedersen_batch_verify_xy(suite, b):
     return lib().orc_pedersen_batch_verify_xy(suite, C.c_size_t(b["n"]), _u8(b["ios_xy"]), _u32(b["io_counts"]),
                                               _u8(b["ads"]), _u32(b["ad_lens"]), _u8(b["proofs"]))
+
+
+def thin_batch_terms_xy(suite, b):
+    """(status, bases_xy, scalars) of the batch MSM (src/thin.rs:282-317) for a gen_batch-style dict (xy layout)."""
+    n = b["n"]; cap = 2 * n + 2 * sum(b["io_counts"]) + 1
+    bases, sc, k = _buf(cap * 64), _buf(cap * 32), C.c_size_t(0)
+    st = lib().orc_thin_batch_terms_xy(suite, C.c_size_t(n), _u8(b["pks_xy"]), _u8(b["ios_xy"]), _u32(b["io_counts"]), _u8(b["ads"]),
+                                       _u32(b["ad_lens"]), _u8(b["proofs"]), bases, sc, C.byref(k))
+    return st, _b(bases)[: 64 * k.value], _b(sc)[: 32 * k.value]
+
+
+def pedersen_batch_terms_xy(suite, b):
+    n = b["n"]; cap = 5 * n + 2
+    bases, sc, k = _buf(cap * 64), _buf(cap * 32), C.c_size_t(0)
+    st = lib().orc_pedersen_batch_terms_xy(suite, C.c_size_t(n), _u8(b["ios_xy"]), _u32(b["io_counts"]), _u8(b["ads"]),
+                                           _u32(b["ad_lens"]), _u8(b["proofs"]), bases, sc, C.byref(k))
+    return st, _b(bases)[: 64 * k.value], _b(sc)[: 32 * k.value]

@@ -82,11 +82,22 @@ static void transcript_merged(transcript_t *t, vrf_io *merged, uint8_t scheme, c
     if (n == 0) { memset(merged, 0, sizeof *merged); merged->in.y = s->fq.r1; merged->out.y = s->fq.r1; return; }
     if (n == 1) { *merged = ios[0]; return; }
     te_ext acc[2]; te_identity(&acc[0], s); te_identity(&acc[1], s);
-    for (size_t i = 0; i < n; i++) {
-        u256 z, zp; if (i == 0) z = s->fr.r1; else challenge_scalar(&z, &delin, s);
-        mont_from(&zp, &z, FR);
-        te_ext a, b; te_smul(&a, &ios[i].in, &zp, s); te_smul(&b, &ios[i].out, &zp, s);
-        te_add(&acc[0], &acc[0], &a, s); te_add(&acc[1], &acc[1], &b, s);
+    if (n < 16) {                                                  /* MSM_THRESHOLD, common.rs:397; fold :400-404 */
+        for (size_t i = 0; i < n; i++) {
+            u256 z, zp; if (i == 0) z = s->fr.r1; else challenge_scalar(&z, &delin, s);
+            mont_from(&zp, &z, FR);
+            te_ext a, b; te_smul(&a, &ios[i].in, &zp, s); te_smul(&b, &ios[i].out, &zp, s);
+            te_add(&acc[0], &acc[0], &a, s); te_add(&acc[1], &acc[1], &b, s);
+        }
+    } else {                                                       /* two n-point msm_unchecked, common.rs:405-412 */
+        te_aff *pi = (te_aff *)malloc(n * sizeof(te_aff)), *po = (te_aff *)malloc(n * sizeof(te_aff));
+        u256 *zs = (u256 *)malloc(n * sizeof(u256));
+        for (size_t i = 0; i < n; i++) {
+            u256 z; if (i == 0) z = s->fr.r1; else challenge_scalar(&z, &delin, s);
+            mont_from(&zs[i], &z, FR); pi[i] = ios[i].in; po[i] = ios[i].out;
+        }
+        orc_msm_pippenger(&acc[0], pi, zs, n, s); orc_msm_pippenger(&acc[1], po, zs, n, s);
+        free(pi); free(po); free(zs);
     }
     te_aff norm[2]; te_batch_to_aff(norm, acc, 2, s);
     merged->in = norm[0]; merged->out = norm[1];
@@ -525,6 +536,17 @@ int orc_thin_batch_verify_xy(int suite, size_t n, const uint8_t *pks_xy, const u
 int orc_pedersen_batch_verify_xy(int suite, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,
                                  const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
     g_xy = 1; int st = orc_pedersen_batch_verify(suite, n, ios_xy, io_counts, ads, ad_lens, proofs); g_xy = 0; return st;
+}
+/* the MSM terms of the two batch verifiers on the same xy layouts (full-size GPU parity tests) */
+int orc_thin_batch_terms_xy(int suite, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
+                            const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs,
+                            uint8_t *bases_xy, uint8_t *scalars, size_t *n_terms_out) {
+    g_xy = 1; int st = orc_thin_batch_terms(suite, n, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs, bases_xy, scalars, n_terms_out); g_xy = 0; return st;
+}
+int orc_pedersen_batch_terms_xy(int suite, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,
+                                const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs,
+                                uint8_t *bases_xy, uint8_t *scalars, size_t *n_terms_out) {
+    g_xy = 1; int st = orc_pedersen_batch_terms(suite, n, ios_xy, io_counts, ads, ad_lens, proofs, bases_xy, scalars, n_terms_out); g_xy = 0; return st;
 }
 
 /* ------------------------------------------------------------------ raw MSM / codec helpers */

@@ -214,3 +214,73 @@ def g2_decode_zcash_uncompressed(b):
         return None
     v[0] &= (1 << 381) - 1
     return ((v[1], v[0]), (v[3], v[2]))
+
+
+# ---- G2 on the twist E'(Fp2): y^2 = x^3 + b', affine, Fp2 elements as (c0, c1) with u^2 = -1.
+# Used for `tau * g2` of Kzg::setup (src/ring.rs:359-374 -> w3f-pcs `URS::generate`) and by the GPU pairing parity tests.
+
+def f2_mul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def f2_sub(a, b):
+    return ((a[0] - b[0]) % P, (a[1] - b[1]) % P)
+
+
+def f2_add(a, b):
+    return ((a[0] + b[0]) % P, (a[1] + b[1]) % P)
+
+
+def f2_inv(a):
+    d = pow((a[0] * a[0] + a[1] * a[1]) % P, -1, P)
+    return (a[0] * d % P, (-a[1]) * d % P)
+
+
+def g2_add(q1, q2):
+    """affine addition on the twist (None = infinity); the curve coefficient is not needed (a = 0)."""
+    if q1 is None:
+        return q2
+    if q2 is None:
+        return q1
+    (x1, y1), (x2, y2) = q1, q2
+    if x1 == x2:
+        if f2_add(y1, y2) == (0, 0):
+            return None
+        m = f2_mul(f2_mul((3, 0), f2_mul(x1, x1)), f2_inv(f2_mul((2, 0), y1)))
+    else:
+        m = f2_mul(f2_sub(y2, y1), f2_inv(f2_sub(x2, x1)))
+    x3 = f2_sub(f2_sub(f2_mul(m, m), x1), x2)
+    return (x3, f2_sub(f2_mul(m, f2_sub(x1, x3)), y1))
+
+
+def g2_mul(q, k):
+    acc = None
+    for bit in bin(k)[2:]:
+        acc = g2_add(acc, acc)
+        if bit == "1":
+            acc = g2_add(acc, q)
+    return acc
+
+
+def g2_encode_arkworks_uncompressed(q):
+    """inverse of g2_decode_arkworks_uncompressed (BN254): flag bit 7 of the last byte = y is the 'larger' root
+    (Fp2 ordering of ark-ff: compare c1 first, then c0), bit 6 = infinity."""
+    if q is None:
+        out = bytearray(128); out[-1] |= 0x40
+        return bytes(out)
+    (x0, x1), (y0, y1) = q
+    neg = ((-y0) % P, (-y1) % P)
+    larger = (y1, y0) > (neg[1], neg[0])
+    out = bytearray(b"".join(v.to_bytes(32, "little") for v in (x0, x1, y0, y1)))
+    if larger:
+        out[-1] |= 0x80
+    return bytes(out)
+
+
+def g2_encode_zcash_uncompressed(q):
+    """inverse of g2_decode_zcash_uncompressed (BLS12-381): x.c1 || x.c0 || y.c1 || y.c0 big-endian."""
+    if q is None:
+        out = bytearray(192); out[0] |= 0x40
+        return bytes(out)
+    (x0, x1), (y0, y1) = q
+    return b"".join(v.to_bytes(48, "big") for v in (x1, x0, y1, y0))

@@ -69,7 +69,7 @@ def test_multi_io(ctxs, suite):
     from ark_vrf_amd._native import Batch
     c = ctxs[suite]
     sks, ios_c, ads = [], [], []
-    for j, m in enumerate([0, 1, 2, 3, 1, 4]):
+    for j, m in enumerate([0, 1, 2, 3, 1, 4, 16, 17]):       # 16, 17: the MSM branch of merge_ios (src/utils/common.rs:405-412)
         sk, _ = orc.from_seed(suite, bytes([j + 9]) + bytes(31))
         io = []
         for i in range(m):

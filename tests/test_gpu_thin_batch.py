@@ -68,9 +68,10 @@ def test_empty_and_identity(ctxs, golden_dir, suite):
 
 @pytest.mark.parametrize("suite", [0, 1])
 def test_multi_io_items(ctxs, suite):
-    """Items with 0, 1, 2, 3 and 5 I/O pairs (prove_verify_multi / _multi_empty, src/thin.rs:390-470)."""
+    """Items with 0, 1, 2, 3, 5 and -- around MSM_THRESHOLD of merge_ios (src/utils/common.rs:397-412) -- 16 and 17 I/O
+    pairs (prove_verify_multi / _multi_empty, src/thin.rs:390-470)."""
     pks, ios, ads, proofs = [], [], [], []
-    for j, m in enumerate([0, 1, 2, 3, 5, 1, 0, 2]):
+    for j, m in enumerate([0, 1, 2, 3, 5, 1, 0, 2, 16, 17]):
         sk, pk = orc.from_seed(suite, bytes([j + 1]) + bytes(31))
         io = []
         for i in range(m):

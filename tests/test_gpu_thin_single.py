@@ -55,7 +55,9 @@ def test_multi_io(ctxs, suite):
     from ark_vrf_amd._native import Batch
     c = ctxs[suite]
     sks, pks, ios_c, ads = [], [], [], []
-    for j, m in enumerate([0, 1, 2, 3, 5]):
+    # 15 / 16 / 17 / 33 pairs: both sides of MSM_THRESHOLD = 16 of merge_ios (src/utils/common.rs:397-412); the oracle takes the
+    # two-MSM branch there, the device folds -- same merged point, hence byte-identical proofs
+    for j, m in enumerate([0, 1, 2, 3, 5, 15, 16, 17, 33]):
         sk, pk = orc.from_seed(suite, bytes([j + 40]) + bytes(31))
         io = []
         for i in range(m):
@@ -71,7 +73,10 @@ def test_multi_io(ctxs, suite):
     assert c.thin_verify(Batch.from_items(ios, ads, pks_xy=pkl, proofs=pl)) == [0] * len(sks)
     # tamper an output of the 3-pair item, and an input of the 5-pair item
     ios[3][1] = (ios[3][1][0], ios[3][0][1]); ios[4][4] = (ios[4][3][0], ios[4][4][1])
-    assert c.thin_verify(Batch.from_items(ios, ads, pks_xy=pkl, proofs=pl)) == [0, 0, 0, 1, 1]
+    bad = c.thin_verify(Batch.from_items(ios, ads, pks_xy=pkl, proofs=pl))
+    assert bad == [0, 0, 0, 1, 1, 0, 0, 0, 0]
+    ios[6][15] = (ios[6][15][0], ios[6][14][1]); ios[7][16] = (ios[7][0][0], ios[7][16][1])   # last pair of the 16- and 17-pair items
+    assert c.thin_verify(Batch.from_items(ios, ads, pks_xy=pkl, proofs=pl)) == [0, 0, 0, 1, 1, 0, 1, 1, 0]
 
 
 @pytest.mark.parametrize("suite,n", [(0, 600), (1, 200)])
