@@ -11,6 +11,7 @@
 #include "proto_dev.h"
 #include "vrf_batch.h"
 #include <chrono>
+#include <new>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -49,6 +50,12 @@ struct PinBuf {
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
   template <class T> T *as() const { return (T *)p; }
 };
+
+template <class F> int guarded(F f) {
+  try { return f(); }
+  catch (const avrf::HipFailure &e) { fprintf(stderr, "avrf: HIP error %s at %s:%d\n", hipGetErrorString(e.err), e.file, e.line); return AVRF_ERR_NO_DEVICE; }
+  catch (const std::bad_alloc &) { return AVRF_ERR_NO_DEVICE; }
+}
 
 double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -158,7 +165,7 @@ int avrf_msm_te(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *s
     HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
   }
   c->staged_kind = 0;
-  if (msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), n, c->ws, c->stream, &r)) return AVRF_ERR_BAD_ARG;
+  if (int e = guarded([&] { return msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), n, c->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
   if (n && *c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;
   return finish_point(c, r, out_xy);
 }
@@ -183,7 +190,7 @@ int avrf_g1_msm(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *s
     launch_g1_bases(c->suite, c->d_misc.as<uint8_t>(), n, c->d_pre.as<uint32_t>(), c->d_flags.as<uint32_t>(), c->stream);
     HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
   }
-  if (msm_g1_device(c->suite, c->d_pre.as<uint32_t>(), c->d_scalars.as<uint32_t>(), n, c->ws, c->stream, out_xy)) return AVRF_ERR_BAD_ARG;
+  if (int e = guarded([&] { return msm_g1_device(c->suite, c->d_pre.as<uint32_t>(), c->d_scalars.as<uint32_t>(), n, c->ws, c->stream, out_xy) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
   if (n && *c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;
   return AVRF_OK;
 }
@@ -283,7 +290,7 @@ static int batch_run(avrf_ctx *c, int kind) {
                         c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
   double t3 = now_us();
   HostExt r;
-  if (msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r)) return AVRF_ERR_BAD_ARG;
+  if (int e = guarded([&] { return msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
   double t4 = now_us();
   int st = point_is_identity(c, r) ? AVRF_OK : AVRF_VERIFICATION_FAILURE;   // src/thin.rs:319-322, src/pedersen.rs:420-423
   double t5 = now_us();
@@ -348,7 +355,7 @@ int avrf_thin_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t firs
   BatchDev b = batch_of(c);
   launch_thin_terms(c->suite, b, seed, first_index, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_scalars.as<uint32_t>(),
                     c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
-  if (msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r)) return AVRF_ERR_BAD_ARG;
+  if (int e = guarded([&] { return msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
   return finish_point(c, r, out_xy);
 }
 
@@ -376,7 +383,7 @@ int avrf_pedersen_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t 
   BatchDev b = batch_of(c);
   launch_ped_terms(c->suite, b, seed, first_index, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_scalars.as<uint32_t>(),
                    c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
-  if (msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r)) return AVRF_ERR_BAD_ARG;
+  if (int e = guarded([&] { return msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
   return finish_point(c, r, out_xy);
 }
 

@@ -15,10 +15,9 @@ template <class S> struct TeCurve {
   static constexpr int BASE_WORDS = 24, ACC_WORDS = 32;
   static constexpr bool PREFETCH = true;
   static constexpr bool ZERO_IS_IDENTITY = false;     // (0, 1, 0, 1)
-  static constexpr bool SPLIT_REDUCE = false;
   static constexpr bool FIXED_TABLE = false;          // no fixed-base window-table mode (bases change per batch)
   static constexpr int MIN_WAVES = 3;                 // waves per SIMD asked of the register allocator in k_accumulate
-  static constexpr int RED_WAVES = 3;                 // ... and in the reduction kernels (general additions)
+  static constexpr int RED_WAVES = 1;                 // reduction kernels (general additions, several points live): latency-bound, full register file
   static constexpr bool INLINE_REDUCE_OPS = true;
   static constexpr bool WINDOW_SUMS = true;           // single MSMs: one weighted bucket sum per window (k_wsum_blk) instead of row/column + bit sums
   static AVRF_DI acc_t identity() { return te_identity<S>(); }
@@ -41,6 +40,15 @@ template <class S> struct TeCurve {
     }
     return r;
   }
+  static AVRF_DI acc_t shfl_from(const acc_t &p, int lane) {
+    acc_t r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      r.x.v[i] = __shfl(p.x.v[i], lane); r.y.v[i] = __shfl(p.y.v[i], lane);
+      r.t.v[i] = __shfl(p.t.v[i], lane); r.z.v[i] = __shfl(p.z.v[i], lane);
+    }
+    return r;
+  }
 };
 
 // XYZZ: x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; identity <=> ZZ = 0.  Affine bases: (0, 0) = infinity.
@@ -57,7 +65,6 @@ template <class C> struct G1Curve {
   static constexpr bool INLINE_REDUCE_OPS = true;     // k_wsum*: additions inlined (the asm multiplier keeps the code small)
   static constexpr bool WINDOW_SUMS = false;
   static constexpr bool ZERO_IS_IDENTITY = true;      // zz = 0; all-zero memory reads as the identity
-  static constexpr bool SPLIT_REDUCE = false;         // 381-bit: lanes of one bucket are summed by k_fixup, not inside k_accumulate
   static constexpr bool FIXED_TABLE = true;           // KZG SRS: msm_g1_fixed_device
 
   static AVRF_DI acc_t identity() { acc_t r; r.x = fn_one<Fq>(); r.y = fn_one<Fq>(); r.zz = fn_zero<N>(); r.zzz = fn_zero<N>(); return r; }
@@ -136,6 +143,15 @@ template <class C> struct G1Curve {
   static AVRF_DI acc_t shfl_down(const acc_t &a, int delta) {
     acc_t r; r.x = fn_shfl_down<N>(a.x, delta); r.y = fn_shfl_down<N>(a.y, delta);
     r.zz = fn_shfl_down<N>(a.zz, delta); r.zzz = fn_shfl_down<N>(a.zzz, delta); return r;
+  }
+  static AVRF_DI acc_t shfl_from(const acc_t &a, int lane) {
+    acc_t r;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      r.x.v[i] = __shfl(a.x.v[i], lane); r.y.v[i] = __shfl(a.y.v[i], lane);
+      r.zz.v[i] = __shfl(a.zz.v[i], lane); r.zzz.v[i] = __shfl(a.zzz.v[i], lane);
+    }
+    return r;
   }
 };
 

@@ -12,11 +12,14 @@ namespace avrf {
 struct te_pre_raw { uint32_t w[24]; };   // x | y | k, Montgomery, 8 x u32 each
 struct te_ext_raw { uint32_t w[32]; };   // x | y | t | z
 
+// thrown by the device engines on a failed HIP call; every extern "C" entry point catches it and returns AVRF_ERR_NO_DEVICE
+struct HipFailure { hipError_t err; const char *file; int line; };
+
 struct MsmPlan {
   int c;         // window bits
   int nwin;      // number of windows: nwin * c >= scalar bits + 1
   int nb;        // buckets per window = 2^(c-1) (signed digits)
-  int lpb;       // SEG: entries of one bucket handled by one lane
+  int lpb;       // entries per lane of the last k_accumulate launch (read back from the device plan)
 };
 MsmPlan msm_plan(size_t n, int scalar_bits);
 
@@ -27,15 +30,15 @@ struct MsmWorkspace {
   uint32_t *hist = nullptr;      // nwin * ntiles * nb   per-tile histograms -> per-tile prefixes
   uint32_t *cnts = nullptr;      // nwin * nb     entries per bucket
   uint32_t *offsets = nullptr;   // nwin * nb     first entry of the bucket in sorted[]
-  uint32_t *lane_off = nullptr;  // nwin * nb     first lane of the bucket (local to its window)
-  uint32_t *lane_tot = nullptr;  // nwin          lanes used per window
-  uint32_t *lane_slot = nullptr; // nwin * lcap   bucket of every lane (lanes ordered by descending load)
-  size_t cap_lanes = 0;
+  uint32_t *win_tot = nullptr;   // nwin          entries per window
+  uint32_t *lane_base = nullptr; // nwin + 1      first k_accumulate lane of every window
+  uint32_t *heavy = nullptr;     // nwin * nb     buckets fed by many lanes (summed by k_heavy_sum)
+  uint32_t *plan_dev = nullptr;  // {entries per lane, lanes used, heavy buckets}
+  uint32_t *plan_host = nullptr; // pinned copy of plan_dev
   // accumulator arrays (layout of the curve policy: te_ext 128 B, G1 XYZZ 4 * Fq)
   uint32_t *buckets = nullptr;   // nwin * nb
   uint32_t *rc = nullptr;        // nwin * (rows + cols) partial sums of the bucket reduction
-  uint32_t *part = nullptr;      // 2 per wave of k_accumulate: partial sums of runs that cross a wave boundary
-                                 // (381-bit G1: one per lane of a multi-lane bucket, summed by k_fixup)
+  uint32_t *part = nullptr;      // lanes + buckets slots: partial sum of lane t for bucket g at slot t + g
   uint32_t *bits = nullptr;      // nwin * c
   uint32_t *bits_host = nullptr; // pinned
   size_t cap_n = 0, cap_slots = 0, cap_buckets = 0, cap_bits = 0, cap_part = 0, cap_hist = 0, cap_vwin = 0;   // cap_buckets.. in bytes
@@ -43,7 +46,7 @@ struct MsmWorkspace {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double accum_ms_total = 0; uint64_t accum_launches = 0; float accum_ms_last = 0;
   MsmPlan last_plan = {0, 0, 0, 0};
-  void ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch = 1, bool lane_partials = false);
+  void ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch, size_t lanes_max);
   void release();
 };
 

@@ -9,16 +9,18 @@
 //   k_digits     one lane per scalar: signed c-bit digits of every window -> 16-bit keys
 //                (bucket | sign<<15), window-major, coalesced
 //   k_hist       workgroup (tile, window): LDS histogram of its tile of keys -> H[w][tile][b]
-//   k_scan_win   workgroup per window: per-bucket prefix over tiles (in place), entry offsets, and the LANE
-//                PLACEMENT: bucket b gets ceil(count_b / SEG) lanes, buckets ordered by descending entries-per-lane
-//                (counting sort in LDS) so that the 64 lanes of a wave carry equal loads
+//   k_scan_win   workgroup per window: per-bucket prefix over tiles (in place), entry offsets and counts, window total
+//   k_plan       one workgroup: entries per lane `per` = ceil(all entries / lanes the chip holds at once) and the first
+//                lane of every window
 //   k_scatter    workgroup (tile, window): LDS cursors seeded from the scanned histogram; every
 //                key gets its slot with an LDS atomic -- no global atomics anywhere in the sort
-//   k_accumulate every lane owns <= SEG consecutive entries of ONE bucket (big buckets simply get more
-//                lanes), does its mixed additions on gathered precomputed points, then a wave-level
-//                SEGMENTED shuffle reduction folds the lanes of a bucket; runs that cross a wave boundary
-//                leave a partial
-//   k_fixup      per bucket: identity for empty buckets, sum of wave partials for split ones
+//   k_accumulate EQUAL SHARES: every lane owns `per` consecutive entries of the sorted array, whatever buckets they fall
+//                in, so all lanes of the launch do the same number of mixed additions and the launch is exactly one
+//                residency round of the chip (no tail, no load sorting, no cross-lane reduction in the hot kernel).
+//                At a bucket boundary the lane writes its partial sum to slot (lane + bucket) -- strictly increasing
+//                along the sorted order, so the partials of one bucket are contiguous -- and starts over.
+//   k_bucket_sum per bucket: identity for empty buckets, else the sum of its partials (a wave cooperates on buckets
+//                that many lanes fed: skewed scalars)
 //   k_wsum_blk / k_wsum   weighted bucket sum sum_b b*B_b of one window (or of one fixed-base bucket set) by
 //                a workgroup / a group of lanes: 2 additions per bucket + a suffix scan
 //   k_rowcol, k_bits, k_bits_direct, k_horner   the bit-decomposition reduction sum_b b*B_b = sum_k 2^k T_k, kept for
@@ -39,7 +41,8 @@
 
 namespace avrf {
 
-#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "avrf: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); abort(); } } while (0)
+// a failed HIP call (out of memory, lost device) unwinds to the C-ABI entry point, which returns AVRF_ERR_NO_DEVICE
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw HipFailure{e_, __FILE__, __LINE__}; } while (0)
 
 // ---------------------------------------------------------------- conversions
 
@@ -122,30 +125,21 @@ k_hist(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int c, 
 }
 
 // One workgroup (1024 lanes) per window.  In place: H[w][tile][b] becomes the exclusive prefix over
-// tiles; offs/cnts per slot (= w*nb + b-1): entry offset (global, w*n based) and entry count.
-// Lane placement: bucket b gets nl_b = ceil(cnt_b / seg) lanes of per_b = ceil(cnt_b / nl_b) entries each.  Buckets are
-// placed in order of DESCENDING per_b (counting sort over per values in LDS), so the 64 lanes of a wave carry
-// near-equal loads and the heaviest waves start first; lane_off[slot] = first lane (local to the window),
-// lane_slot[w * lcap + lane] = bucket of that lane, lane_tot[w] = lanes used by the window.
+// tiles; offs/cnts per slot (= w*nb + b-1): entry offset (global, w*n based) and entry count; win_tot[w] = entries of the window.
 __global__ void __launch_bounds__(1024)
-k_scan_win(uint32_t *__restrict__ H, uint32_t n, uint32_t ntiles, int c, uint32_t seg, uint32_t lcap,
-           uint32_t *__restrict__ offs, uint32_t *__restrict__ cnts, uint32_t *__restrict__ lane_off,
-           uint32_t *__restrict__ lane_tot, uint32_t *__restrict__ lane_slot) {
+k_scan_win(uint32_t *__restrict__ H, uint32_t n, uint32_t ntiles, int c,
+           uint32_t *__restrict__ offs, uint32_t *__restrict__ cnts, uint32_t *__restrict__ win_tot) {
   __shared__ uint32_t part[1024];
-  __shared__ uint32_t bin[1026];                           // lanes per `per` value (0..seg), then bin cursors
   const uint32_t nb = 1u << (c - 1), w = blockIdx.x, t = threadIdx.x;
   uint32_t *Hw = H + (size_t)w * ntiles * nb;
   const uint32_t bpt = (nb + 1023) / 1024;
   uint32_t b0 = t * bpt, b1 = b0 + bpt; if (b1 > nb) b1 = nb; if (b0 > nb) b0 = nb;
-  for (uint32_t i = t; i < 1026; i += 1024) bin[i] = 0;
-  __syncthreads();
   uint32_t sum = 0;
   for (uint32_t b = b0; b < b1; b++) {
     uint32_t run = 0;
     for (uint32_t k = 0; k < ntiles; k++) { uint32_t v = Hw[(size_t)k * nb + b]; Hw[(size_t)k * nb + b] = run; run += v; }
     cnts[(size_t)w * nb + b] = run;
     sum += run;
-    if (run) { uint32_t nl = (run + seg - 1) / seg, per = (run + nl - 1) / nl; atomicAdd(&bin[per], nl); }
   }
   part[t] = sum;
   __syncthreads();
@@ -155,25 +149,49 @@ k_scan_win(uint32_t *__restrict__ H, uint32_t n, uint32_t ntiles, int c, uint32_
     part[t] += v;
     __syncthreads();
   }
-  if (t == 0) {                                            // bin start = lanes of all larger `per` values
-    uint32_t run = 0;
-    for (int p = (int)seg; p >= 1; p--) { uint32_t v = bin[p]; bin[p] = run; run += v; }
-    lane_tot[w] = run;
-  }
-  __syncthreads();
+  if (t == 1023) win_tot[w] = part[1023];
   uint32_t run = part[t] - sum + w * n;
-  for (uint32_t b = b0; b < b1; b++) {
-    uint32_t cnt = cnts[(size_t)w * nb + b];
-    offs[(size_t)w * nb + b] = run;
-    run += cnt;
-    uint32_t lo = 0;
-    if (cnt) {
-      uint32_t nl = (cnt + seg - 1) / seg, per = (cnt + nl - 1) / nl;
-      lo = atomicAdd(&bin[per], nl);
-      for (uint32_t r = 0; r < nl; r++) lane_slot[(size_t)w * lcap + lo + r] = b;
+  for (uint32_t b = b0; b < b1; b++) { offs[(size_t)w * nb + b] = run; run += cnts[(size_t)w * nb + b]; }
+}
+
+// plan[0] = per (entries per lane), plan[1] = lanes used, plan[2] = 0 (heavy-bucket counter of k_bucket_sum); lane_base[v] = first lane of window v (lane_base[vwin] = plan[1]).
+// per = max(per_min, ceil(sum of win_tot / lanes_target)): with lanes_target = what the chip holds in one residency round
+// of k_accumulate, the launch is one round of equally loaded lanes.
+__global__ void __launch_bounds__(1024)
+k_plan(const uint32_t *__restrict__ win_tot, uint32_t vwin, uint32_t lanes_target, uint32_t per_min, uint32_t *__restrict__ lane_base,
+       uint32_t *__restrict__ plan) {
+  __shared__ uint64_t red[1024];
+  __shared__ uint32_t sc[1024];
+  __shared__ uint32_t carry_s;
+  const uint32_t t = threadIdx.x;
+  uint64_t s = 0;
+  for (uint32_t v = t; v < vwin; v += 1024) s += win_tot[v];
+  red[t] = s;
+  __syncthreads();
+  for (uint32_t off = 512; off >= 1; off >>= 1) { if (t < off) red[t] += red[t + off]; __syncthreads(); }
+  const uint64_t total = red[0];
+  uint64_t per64 = (total + lanes_target - 1) / lanes_target;
+  if (per64 < per_min) per64 = per_min;
+  const uint32_t per = (uint32_t)per64;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < vwin; base += 1024) {
+    const uint32_t v = base + t;
+    const uint32_t mine = v < vwin ? (win_tot[v] + per - 1) / per : 0;
+    sc[t] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+      uint32_t x = (t >= off) ? sc[t - off] : 0;
+      __syncthreads();
+      sc[t] += x;
+      __syncthreads();
     }
-    lane_off[(size_t)w * nb + b] = lo;
+    if (v < vwin) lane_base[v] = carry_s + sc[t] - mine;
+    __syncthreads();
+    if (t == 1023) carry_s += sc[1023];
+    __syncthreads();
   }
+  if (t == 0) { lane_base[vwin] = carry_s; plan[0] = per; plan[1] = carry_s; plan[2] = 0; }
 }
 
 // remap_n != 0 (fixed-base tables): key position p = dw * remap_n + i refers to table entry dw * remap_stride + i
@@ -218,99 +236,118 @@ template <class CV> AVRF_DI typename CV::acc_t cv_dbl(const typename CV::acc_t &
 
 // ---------------------------------------------------------------- bucket accumulation (curve-generic)
 
-// Lane t = w * lcap + lt owns a segment of the bucket `slot` = lane_slot[t] of window w, with
-// lane_off[slot] <= lt < lane_off[slot] + lanes(slot) (the lanes of a bucket are consecutive).  part[2*wave + k]: partial of the run of wave
-// `wave` that includes lane 0 (k = 0) or that starts later and runs past lane 63 (k = 1); complete
-// runs are written straight to buckets[].  lcap is a multiple of 64 (a wave never spans two windows).
+// Lane t owns the entries [e0, e0 + per) of window v (lane_base[v] <= t < lane_base[v + 1]; r = t - lane_base[v];
+// e0 = v * n + r * per).  Partial sums go to part[(t + v * nb + b) * ACC_WORDS] for every bucket b the range touches.
 template <class CV>
 __global__ void __launch_bounds__(256, CV::MIN_WAVES)
 k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
-             const uint32_t *__restrict__ offs, const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off,
-             const uint32_t *__restrict__ lane_tot, const uint32_t *__restrict__ lane_slot, uint32_t nwin, uint32_t nb, uint32_t lcap,
-             uint32_t seg, uint32_t *__restrict__ buckets, uint32_t *__restrict__ part) {
+             const uint32_t *__restrict__ offs, const uint32_t *__restrict__ win_tot, const uint32_t *__restrict__ lane_base,
+             const uint32_t *__restrict__ plan, uint32_t vwin, uint32_t nb, uint32_t n, uint32_t *__restrict__ part) {
   using acc_t = typename CV::acc_t; using base_t = typename CV::base_t;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t lane = threadIdx.x & 63, wave = t >> 6;
-  const uint32_t w = t / lcap, lt = t - w * lcap;
-  const bool live = w < nwin && lt < lane_tot[w];
-  uint32_t slot = 0xffffffffu, l0 = 0, nl = 0;
+  const uint32_t per = plan[0];
+  if (t >= plan[1]) return;
+  uint32_t lo = 0, hi = vwin;                                  // largest v with lane_base[v] <= t
+  while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (lane_base[mid] <= t) lo = mid; else hi = mid; }
+  const uint32_t v = lo;
+  const uint32_t wbeg = v * n, wend = wbeg + win_tot[v];
+  const uint32_t e0 = wbeg + (t - lane_base[v]) * per;
+  uint32_t e1 = e0 + per; if (e1 > wend) e1 = wend;
+  const uint32_t *ow = offs + (size_t)v * nb;
+  lo = 0; hi = nb;                                             // largest b with offs[b] <= e0: the bucket of entry e0
+  while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (ow[mid] <= e0) lo = mid; else hi = mid; }
+  uint32_t b = lo;
+  uint32_t nxt = (b + 1 < nb) ? ow[b + 1] : 0xffffffffu;      // first entry of the next bucket
+  const size_t slot0 = (size_t)t + (size_t)v * nb;
   acc_t acc = CV::identity();
-  if (live) {
-    slot = w * nb + lane_slot[t];
-    const uint32_t e0 = offs[slot], cnt = cnts[slot];
-    l0 = lane_off[slot]; nl = (cnt + seg - 1) / seg;
-    const uint32_t per = (cnt + nl - 1) / nl, r = lt - l0;
-    uint32_t b = e0 + r * per, e = b + per; if (e > e0 + cnt) e = e0 + cnt;
-    if (CV::PREFETCH) {
-      // software-pipelined gather: the next base is in flight while the current addition runs
-      if (b < e) {
-        uint32_t idx = sorted[b];
-        base_t q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS);
-        for (uint32_t i = b; i < e; i++) {
-          const uint32_t cidx = idx; const base_t cur = q;
-          if (i + 1 < e) { idx = sorted[i + 1]; q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS); }
-          acc = CV::madd(acc, cur, (cidx & 0x80000000u) != 0);
-        }
+  if (CV::PREFETCH) {
+    // software-pipelined gather: the next base is in flight while the current addition runs
+    uint32_t idx = sorted[e0];
+    base_t q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS);
+    for (uint32_t i = e0; i < e1; i++) {
+      const uint32_t cidx = idx; const base_t cur = q;
+      if (i + 1 < e1) { idx = sorted[i + 1]; q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS); }
+      if (i >= nxt) {                                          // bucket boundary inside the lane's range
+        CV::store_acc(part + (slot0 + b) * CV::ACC_WORDS, acc);
+        acc = CV::identity();
+        do { b++; nxt = (b + 1 < nb) ? ow[b + 1] : 0xffffffffu; } while (i >= nxt);
       }
-    } else {                                            // 381-bit points: registers are the scarcer resource
-      for (uint32_t i = b; i < e; i++) {
-        const uint32_t idx = sorted[i];
-        acc = CV::madd(acc, CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS), (idx & 0x80000000u) != 0);
+      acc = CV::madd(acc, cur, (cidx & 0x80000000u) != 0);
+    }
+  } else {                                                     // 381-bit points: registers are the scarcer resource
+    for (uint32_t i = e0; i < e1; i++) {
+      if (i >= nxt) {
+        CV::store_acc(part + (slot0 + b) * CV::ACC_WORDS, acc);
+        acc = CV::identity();
+        do { b++; nxt = (b + 1 < nb) ? ow[b + 1] : 0xffffffffu; } while (i >= nxt);
       }
+      const uint32_t idx = sorted[i];
+      acc = CV::madd(acc, CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS), (idx & 0x80000000u) != 0);
     }
   }
-  if (CV::SPLIT_REDUCE) {
-    // 381-bit points: the general addition would set this kernel's register budget, so multi-lane buckets leave one
-    // partial per lane and k_fixup adds them (dense: every bucket has 2-3 lanes there)
-    if (live) CV::store_acc(nl == 1 ? buckets + (size_t)slot * CV::ACC_WORDS : part + (size_t)t * CV::ACC_WORDS, acc);
-    return;
-  }
-  // segmented reduction by doubling: after step `off` a run head holds the sum of min(run, 2*off) lanes
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t oslot = __shfl_down(slot, off);
-    bool take = live && (lane + off < 64) && (oslot == slot);
-    if (!__any(take)) break;                            // no run in this wave is longer than `off`
-    acc_t o = CV::shfl_down(acc, off);
-    if (take) acc = CV::add(acc, o);
-  }
-  uint32_t pslot = __shfl_up(slot, 1);
-  bool head = live && (lane == 0 || pslot != slot);
-  if (head) {
-    uint32_t g0 = w * lcap + l0, wbase = wave << 6;
-    bool complete = (g0 >= wbase) && (g0 + nl <= wbase + 64);
-    if (complete) CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, acc);
-    else CV::store_acc(part + (2 * (size_t)wave + (lane == 0 ? 0 : 1)) * CV::ACC_WORDS, acc);
-  }
+  CV::store_acc(part + (slot0 + b) * CV::ACC_WORDS, acc);
+}
+
+template <class CV> AVRF_DI typename CV::acc_t wave_sum(typename CV::acc_t acc);
+
+// Bucket `slot` = v * nb + b holds entries [offs, offs + cnt): they were accumulated by lanes lf..ll of window v, whose partials
+// sit in part[lf + slot .. ll + slot].  Buckets fed by more than HEAVY lanes (the short top window of a 253-bit scalar; skewed
+// scalars) are only listed here (plan[2] = count, heavy[] = slots) and summed by k_heavy_sum, one workgroup each.
+constexpr uint32_t HEAVY_PARTIALS = 12;
+template <class CV>
+__global__ void __launch_bounds__(256, CV::RED_WAVES)
+k_bucket_sum(const uint32_t *__restrict__ offs, const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_base,
+             uint32_t *__restrict__ plan, uint32_t nslots, uint32_t nb, uint32_t n, const uint32_t *__restrict__ part,
+             uint32_t *__restrict__ buckets, uint32_t *__restrict__ heavy) {
+  using acc_t = typename CV::acc_t;
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= nslots) return;
+  const uint32_t per = plan[0];
+  const uint32_t cnt = cnts[slot];
+  if (!cnt) { if (!CV::ZERO_IS_IDENTITY) CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, CV::identity()); return; }
+  const uint32_t v = slot / nb, rel = offs[slot] - v * n;
+  const uint32_t lf = rel / per, ll = (rel + cnt - 1) / per, np = ll - lf + 1;
+  if (np > HEAVY_PARTIALS) { heavy[atomicAdd(&plan[2], 1u)] = slot; return; }
+  const size_t p0 = (size_t)lane_base[v] + lf + slot;
+  acc_t acc = CV::load_acc(part + p0 * CV::ACC_WORDS);
+#pragma unroll 1
+  for (uint32_t k = 1; k < np; k++) acc = cv_add<CV>(acc, CV::load_acc(part + (p0 + k) * CV::ACC_WORDS));
+  CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, acc);
 }
 
 template <class CV>
 __global__ void __launch_bounds__(256, CV::RED_WAVES)
-k_fixup(const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_off, uint32_t nslots, uint32_t nb,
-        uint32_t lcap, uint32_t seg, const uint32_t *__restrict__ part, uint32_t *__restrict__ buckets) {
-  uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= nslots) return;
-  uint32_t cnt = cnts[slot], nl = (cnt + seg - 1) / seg;
-  if (nl == 0) { if (!CV::ZERO_IS_IDENTITY) CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, CV::identity()); return; }
-  uint32_t g0 = (slot / nb) * lcap + lane_off[slot];
-  if (CV::SPLIT_REDUCE) {                                 // part[] holds one partial per lane of a multi-lane bucket
-    if (nl == 1) return;
-    typename CV::acc_t acc = CV::load_acc(part + (size_t)g0 * CV::ACC_WORDS);
-    for (uint32_t r = 1; r < nl; r++) acc = CV::add(acc, CV::load_acc(part + (size_t)(g0 + r) * CV::ACC_WORDS));
-    CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, acc);
-    return;
+k_heavy_sum(const uint32_t *__restrict__ offs, const uint32_t *__restrict__ cnts, const uint32_t *__restrict__ lane_base,
+            const uint32_t *__restrict__ plan, uint32_t nb, uint32_t n, const uint32_t *__restrict__ part,
+            uint32_t *__restrict__ buckets, const uint32_t *__restrict__ heavy) {
+  using acc_t = typename CV::acc_t;
+  extern __shared__ uint32_t lds[];                                            // 4 accumulators
+  const uint32_t per = plan[0], nheavy = plan[2], t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+    const uint32_t slot = heavy[h], cnt = cnts[slot];
+    const uint32_t v = slot / nb, rel = offs[slot] - v * n;
+    const uint32_t lf = rel / per, ll = (rel + cnt - 1) / per, np = ll - lf + 1;
+    const size_t p0 = (size_t)lane_base[v] + lf + slot;
+    acc_t a = CV::identity();
+#pragma unroll 1
+    for (uint32_t k = t; k < np; k += 256) a = cv_add<CV>(a, CV::load_acc(part + (p0 + k) * CV::ACC_WORDS));
+    a = wave_sum<CV>(a);                                                        // valid in lane 0
+    if (lane == 0) CV::store_acc(lds + wv * CV::ACC_WORDS, a);
+    __syncthreads();
+    if (t == 0) {
+#pragma unroll 1
+      for (uint32_t w = 1; w < 4; w++) a = cv_add<CV>(a, CV::load_acc(lds + w * CV::ACC_WORDS));
+      CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, a);
+    }
+    __syncthreads();
   }
-  uint32_t wa = g0 >> 6, wb = (g0 + nl - 1) >> 6;
-  if (wa == wb) return;                                  // complete inside one wave: already written
-  typename CV::acc_t acc = CV::load_acc(part + (2 * (size_t)wa + ((g0 & 63) == 0 ? 0 : 1)) * CV::ACC_WORDS);
-  for (uint32_t wv = wa + 1; wv <= wb; wv++) acc = CV::add(acc, CV::load_acc(part + 2 * (size_t)wv * CV::ACC_WORDS));
-  CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, acc);
 }
 
 // ---------------------------------------------------------------- bucket reduction by index bits
 
 template <class CV> AVRF_DI typename CV::acc_t wave_sum(typename CV::acc_t acc) {
 #pragma unroll 1
-  for (int off = 32; off >= 1; off >>= 1) acc = CV::add(acc, CV::shfl_down(acc, off));
+  for (int off = 32; off >= 1; off >>= 1) acc = cv_add<CV>(acc, CV::shfl_down(acc, off));
   return acc;                                             // valid in lane 0
 }
 
@@ -480,82 +517,108 @@ k_wsum_blk(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t *__restri
 
 // ---------------------------------------------------------------- host engine
 
+// tuning knobs from the environment, read once per process
+struct MsmEnv {
+  int c = 0, per_min = 8, wsum_wps = 0; bool window_sums = true;
+  MsmEnv() {
+    if (const char *e = getenv("AVRF_MSM_C")) { int v = atoi(e); if (v >= 3 && v <= 15) c = v; }
+    if (const char *e = getenv("AVRF_MSM_PER_MIN")) { int v = atoi(e); if (v >= 1 && v <= 4096) per_min = v; }
+    if (const char *e = getenv("AVRF_TE_WSUM_WPS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) wsum_wps = v; }
+    if (const char *e = getenv("AVRF_TE_WINDOW_SUMS")) window_sums = atoi(e) != 0;
+  }
+};
+static const MsmEnv &msm_env() { static const MsmEnv e; return e; }
+
 MsmPlan msm_plan(size_t n, int scalar_bits) {
   MsmPlan p;
   int lg = 0; while (((size_t)1 << (lg + 1)) <= n) lg++;
   int c = lg >= 16 ? lg - 5 : lg - 3;                   // small (KZG-sized, batched) MSMs: ~8 entries per bucket
   if (c < 4) c = 4; if (c > 15) c = 15;
-  p.c = c; p.lpb = 16;                                   // lpb = SEG: entries per lane
-  if (const char *e = getenv("AVRF_MSM_C")) { int v = atoi(e); if (v >= 3 && v <= 15) p.c = v; }
-  if (const char *e = getenv("AVRF_MSM_SEG")) { int v = atoi(e); if (v >= 1 && v <= 1024) p.lpb = v; }
+  p.c = msm_env().c ? msm_env().c : c; p.lpb = 0;
   p.nb = 1 << (p.c - 1);
   p.nwin = (scalar_bits + 1 + p.c - 1) / p.c;
   return p;
 }
 
 static uint32_t tile_len_for(size_t n) { return 8192; }
-static uint32_t lcap_for(size_t n, const MsmPlan &p) { return (uint32_t)(((n / (size_t)p.lpb + p.nb + 1) + 63) / 64 * 64); }
 
-void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch, bool lane_partials) {
+// lanes one residency round of k_accumulate<CV> holds on the current device (CUs x resident workgroups x 256)
+template <class CV> static size_t accumulate_lanes() {
+  static size_t cache[64] = {0};
+  int dev = 0; HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (!cache[dev]) {
+    int cus = 0, blocks = 0;
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_accumulate<CV>, 256, 0));
+    if (blocks < 1) blocks = 1;
+    cache[dev] = (size_t)cus * blocks * 256;
+  }
+  return cache[dev];
+}
+
+template <class T> static void grow(T *&p, size_t &cap, size_t need, size_t elem) {
+  if (need <= cap) return;
+  if (p) HIP_CHECK(hipFree(p));
+  p = nullptr; cap = 0;
+  HIP_CHECK(hipMalloc(&p, need * elem + 64));
+  cap = need;
+}
+
+void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch, size_t lanes_max) {
   const size_t vwin = (size_t)p.nwin * batch;           // virtual windows
-  size_t nbk = vwin * p.nb, nbits = vwin * p.c;
-  size_t need_n = vwin * n;
-  size_t ntiles = (n + tile_len_for(n) - 1) / tile_len_for(n);
+  const size_t nbk = vwin * p.nb, nbits = vwin * p.c;
+  const size_t need_n = vwin * n;
+  const size_t ntiles = (n + tile_len_for(n) - 1) / tile_len_for(n);
   if (need_n > cap_n) {
     if (keys) HIP_CHECK(hipFree(keys));
     if (sorted) HIP_CHECK(hipFree(sorted));
-    HIP_CHECK(hipMalloc(&keys, need_n * 2 + 16)); HIP_CHECK(hipMalloc(&sorted, need_n * 4));
+    keys = nullptr; sorted = nullptr; cap_n = 0;
+    HIP_CHECK(hipMalloc(&keys, need_n * 2 + 16)); HIP_CHECK(hipMalloc(&sorted, need_n * 4 + 16));
     cap_n = need_n;
   }
-  if (nbk * ntiles > cap_hist) {
-    if (hist) HIP_CHECK(hipFree(hist));
-    HIP_CHECK(hipMalloc(&hist, nbk * ntiles * 4));
-    cap_hist = nbk * ntiles;
-  }
+  grow(hist, cap_hist, nbk * ntiles, 4);
   if (nbk > cap_slots) {
     if (cnts) HIP_CHECK(hipFree(cnts));
     if (offsets) HIP_CHECK(hipFree(offsets));
-    if (lane_off) HIP_CHECK(hipFree(lane_off));
-    HIP_CHECK(hipMalloc(&cnts, nbk * 4)); HIP_CHECK(hipMalloc(&offsets, nbk * 4)); HIP_CHECK(hipMalloc(&lane_off, nbk * 4));
+    if (heavy) HIP_CHECK(hipFree(heavy));
+    cnts = offsets = heavy = nullptr; cap_slots = 0;
+    HIP_CHECK(hipMalloc(&cnts, nbk * 4)); HIP_CHECK(hipMalloc(&offsets, nbk * 4)); HIP_CHECK(hipMalloc(&heavy, nbk * 4));
     cap_slots = nbk;
   }
   if (vwin > cap_vwin) {
-    if (lane_tot) HIP_CHECK(hipFree(lane_tot));
-    HIP_CHECK(hipMalloc(&lane_tot, (vwin + 64) * 4));
+    if (win_tot) HIP_CHECK(hipFree(win_tot));
+    if (lane_base) HIP_CHECK(hipFree(lane_base));
+    win_tot = lane_base = nullptr; cap_vwin = 0;
+    HIP_CHECK(hipMalloc(&win_tot, (vwin + 64) * 4)); HIP_CHECK(hipMalloc(&lane_base, (vwin + 64) * 4));
     cap_vwin = vwin;
   }
+  if (!plan_dev) { HIP_CHECK(hipMalloc(&plan_dev, 64)); HIP_CHECK(hipHostMalloc(&plan_host, 64)); plan_host[0] = plan_host[1] = 0; }
   if (nbk * acc_bytes > cap_buckets) {
     if (buckets) HIP_CHECK(hipFree(buckets));
     if (rc) HIP_CHECK(hipFree(rc));
+    buckets = rc = nullptr; cap_buckets = 0;
     HIP_CHECK(hipMalloc(&buckets, nbk * acc_bytes));
     HIP_CHECK(hipMalloc(&rc, nbk * acc_bytes));               // >= nwin * (NR + NC)
     cap_buckets = nbk * acc_bytes;
   }
-  if (vwin * lcap_for(n, p) > cap_lanes) {
-    if (lane_slot) HIP_CHECK(hipFree(lane_slot));
-    cap_lanes = vwin * lcap_for(n, p);
-    HIP_CHECK(hipMalloc(&lane_slot, cap_lanes * 4));
-  }
-  size_t need_part = lane_partials ? vwin * lcap_for(n, p) * acc_bytes : 2 * (vwin * lcap_for(n, p) / 64 + 2) * acc_bytes;
-  if (need_part > cap_part) {
-    if (part) HIP_CHECK(hipFree(part));
-    HIP_CHECK(hipMalloc(&part, need_part));
-    cap_part = need_part;
-  }
+  grow(part, cap_part, (lanes_max + nbk + 64) * acc_bytes, 1);
   if (nbits * acc_bytes > cap_bits) {
     if (bits) HIP_CHECK(hipFree(bits));
     if (bits_host) HIP_CHECK(hipHostFree(bits_host));
+    bits = bits_host = nullptr; cap_bits = 0;
     HIP_CHECK(hipMalloc(&bits, nbits * acc_bytes));
     HIP_CHECK(hipHostMalloc(&bits_host, nbits * acc_bytes));
     cap_bits = nbits * acc_bytes;
   }
 }
 void MsmWorkspace::release() {
-  void *dev[] = {keys, sorted, hist, cnts, offsets, lane_off, lane_tot, lane_slot, buckets, rc, part, bits};
+  void *dev[] = {keys, sorted, hist, cnts, offsets, heavy, win_tot, lane_base, plan_dev, buckets, rc, part, bits};
   for (void *q : dev) if (q) (void)hipFree(q);
   if (bits_host) (void)hipHostFree(bits_host);
+  if (plan_host) (void)hipHostFree(plan_host);
   if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1); ev0 = ev1 = nullptr;
-  keys = nullptr; sorted = hist = cnts = offsets = lane_off = lane_tot = lane_slot = nullptr; cap_lanes = 0;
+  keys = nullptr; sorted = hist = cnts = offsets = heavy = win_tot = lane_base = plan_dev = plan_host = nullptr;
   buckets = rc = part = bits = bits_host = nullptr;
   cap_n = cap_slots = cap_buckets = cap_bits = cap_part = cap_hist = cap_vwin = 0;
 }
@@ -566,56 +629,63 @@ void MsmWorkspace::release() {
 // gets its own nwin windows; returns the number of bit sums per vector (vector b's sums start at b * that).
 // Fixed-base mode (table_c != 0): d_bases is a window table T[w * table_stride + i] = 2^(table_c * w) * P_i, so all
 // windows of a vector share ONE bucket set: downstream it is a 1-window MSM over n * nwin (table) bases.
+// Throws HipFailure when a HIP call fails.
 template <class CV>
 static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n_in, int scalar_bits, MsmWorkspace &ws, hipStream_t stream,
                       size_t batch = 1, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0, const uint32_t *d_base_idx = nullptr) {
   MsmPlan p = msm_plan(n_in, scalar_bits);
   if (!scalar_stride) scalar_stride = n_in;                            // vector b's scalars start at b * scalar_stride
-  if (!getenv("AVRF_MSM_SEG")) {
-    // entries per lane: 32 once the launch has plenty of lanes, else 16.  (Measured on MI355X: longer segments save
-    // cross-lane reductions but lose more to exposed gather latency -- 64+ entries per lane ran 10-50 % slower.)
-    const size_t digs = table_c ? (size_t)((scalar_bits + 1 + table_c - 1) / table_c) : (size_t)p.nwin;
-    p.lpb = batch * n_in * digs / 32 >= 65536 ? 32 : 16;
-  }
+  const size_t lanes_target = accumulate_lanes<CV>();
   size_t n = n_in;
   uint32_t remap_n = 0, remap_stride = 0;
   dim3 b256(256);
+  int dig_nwin = p.nwin;
   if (table_c) {
-    const int dig_nwin = (scalar_bits + 1 + table_c - 1) / table_c;
+    dig_nwin = (scalar_bits + 1 + table_c - 1) / table_c;
     p.c = table_c; p.nb = 1 << (table_c - 1); p.nwin = 1;
     n = n_in * (size_t)dig_nwin;                                        // one window of n_in * dig_nwin keys per vector
-    ws.ensure(n, p, (size_t)CV::ACC_WORDS * 4, batch, CV::SPLIT_REDUCE);
-    hipLaunchKernelGGL(k_digits, dim3((unsigned)((n_in + 255) / 256), (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n_in, (uint32_t)scalar_stride, p.c, dig_nwin, ws.keys);
     remap_n = (uint32_t)n_in; remap_stride = (uint32_t)table_stride;
   }
   const size_t acc_bytes = (size_t)CV::ACC_WORDS * 4;
-  if (!table_c) ws.ensure(n, p, acc_bytes, batch, CV::SPLIT_REDUCE);
   const uint32_t vwin = (uint32_t)(p.nwin * batch);
-  const uint32_t nbk = vwin * p.nb, seg = (uint32_t)p.lpb;
+  const size_t lanes_max = lanes_target + vwin + 256;                   // sum_v ceil(tot_v / per) <= total / per + vwin
+  if ((size_t)vwin * n >= 0xffff0000ull) throw HipFailure{hipErrorInvalidValue, __FILE__, __LINE__};   // 32-bit entry offsets
+  ws.ensure(n, p, acc_bytes, batch, lanes_max);
+  const uint32_t nbk = vwin * p.nb;
   const uint32_t tile_len = tile_len_for(n), ntiles = (uint32_t)((n + tile_len - 1) / tile_len);
-  const uint32_t lcap = lcap_for(n, p);
   const size_t lds_bytes = (size_t)p.nb * 4;
-  dim3 gn((unsigned)((n + 255) / 256));
-  if (!table_c) hipLaunchKernelGGL(k_digits, dim3(gn.x, (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n, (uint32_t)scalar_stride, p.c, p.nwin, ws.keys);
+  hipLaunchKernelGGL(k_digits, dim3((unsigned)((n_in + 255) / 256), (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n_in, (uint32_t)scalar_stride,
+                     p.c, dig_nwin, ws.keys);
   hipLaunchKernelGGL(k_hist, dim3(ntiles, vwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist);
-  hipLaunchKernelGGL(k_scan_win, dim3(vwin), dim3(1024), 0, stream, ws.hist, (uint32_t)n, ntiles, p.c, seg, lcap,
-                     ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot, ws.lane_slot);
+  hipLaunchKernelGGL(k_scan_win, dim3(vwin), dim3(1024), 0, stream, ws.hist, (uint32_t)n, ntiles, p.c, ws.offsets, ws.cnts, ws.win_tot);
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint32_t *)ws.win_tot, vwin, (uint32_t)lanes_target, (uint32_t)msm_env().per_min,
+                     ws.lane_base, ws.plan_dev);
   hipLaunchKernelGGL(k_scatter, dim3(ntiles, vwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist, ws.offsets, ws.sorted,
                      remap_n, remap_stride, d_base_idx);
-  dim3 ga((unsigned)(((size_t)vwin * lcap + 255) / 256));
   if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
   if (CV::ZERO_IS_IDENTITY) HIP_CHECK(hipMemsetAsync(ws.buckets, 0, (size_t)nbk * acc_bytes, stream));   // empty buckets
   HIP_CHECK(hipEventRecord(ws.ev0, stream));
-  hipLaunchKernelGGL(k_accumulate<CV>, ga, b256, 0, stream, d_bases, ws.sorted, ws.offsets, ws.cnts, ws.lane_off, ws.lane_tot, ws.lane_slot,
-                     vwin, (uint32_t)p.nb, lcap, seg, ws.buckets, ws.part);
+  hipLaunchKernelGGL(k_accumulate<CV>, dim3((unsigned)((lanes_max + 255) / 256)), b256, 0, stream, d_bases, (const uint32_t *)ws.sorted,
+                     (const uint32_t *)ws.offsets, (const uint32_t *)ws.win_tot, (const uint32_t *)ws.lane_base, (const uint32_t *)ws.plan_dev, vwin,
+                     (uint32_t)p.nb, (uint32_t)n, ws.part);
   HIP_CHECK(hipEventRecord(ws.ev1, stream));
-  hipLaunchKernelGGL(k_fixup<CV>, dim3((nbk + 255) / 256), b256, 0, stream, ws.cnts, ws.lane_off, nbk, (uint32_t)p.nb, lcap, seg,
-                     (const uint32_t *)ws.part, ws.buckets);
-  static const bool window_sums_on = !(getenv("AVRF_TE_WINDOW_SUMS") && atoi(getenv("AVRF_TE_WINDOW_SUMS")) == 0);
-  if constexpr (CV::WINDOW_SUMS) if (batch == 1 && window_sums_on) {          // one weighted sum per window; the host does nwin Horner steps of c doublings
+  hipLaunchKernelGGL(k_bucket_sum<CV>, dim3((nbk + 255) / 256), b256, 0, stream, (const uint32_t *)ws.offsets, (const uint32_t *)ws.cnts,
+                     (const uint32_t *)ws.lane_base, ws.plan_dev, nbk, (uint32_t)p.nb, (uint32_t)n, (const uint32_t *)ws.part, ws.buckets, ws.heavy);
+  hipLaunchKernelGGL(k_heavy_sum<CV>, dim3(nbk < 1024 ? nbk : 1024), b256, 4 * acc_bytes, stream, (const uint32_t *)ws.offsets, (const uint32_t *)ws.cnts,
+                     (const uint32_t *)ws.lane_base, (const uint32_t *)ws.plan_dev, (uint32_t)p.nb, (uint32_t)n, (const uint32_t *)ws.part, ws.buckets,
+                     (const uint32_t *)ws.heavy);
+  HIP_CHECK(hipMemcpyAsync(ws.plan_host, ws.plan_dev, 8, hipMemcpyDeviceToHost, stream));
+  auto finish = [&]() {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventElapsedTime(&ws.accum_ms_last, ws.ev0, ws.ev1));
+    p.lpb = (int)ws.plan_host[0];
+    ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = p;
+  };
+  if constexpr (CV::WINDOW_SUMS) if (batch == 1 && msm_env().window_sums) {  // one weighted sum per window; the host does nwin Horner steps of c doublings
     uint32_t wps = 1;
     while (wps < 4 && (uint32_t)p.nb >= 64 * wps * 2) wps *= 2;
-    if (const char *e = getenv("AVRF_TE_WSUM_WPS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) { wps = (uint32_t)v; while (wps > 1 && (uint32_t)p.nb < 64 * wps) wps >>= 1; } }
+    if (msm_env().wsum_wps) { wps = (uint32_t)msm_env().wsum_wps; while (wps > 1 && (uint32_t)p.nb < 64 * wps) wps >>= 1; }
     if ((uint32_t)p.nb >= 64) {
       hipLaunchKernelGGL(k_wsum_blk<CV>, dim3(vwin), dim3(64 * wps), (size_t)wps * 2 * acc_bytes, stream, (const uint32_t *)ws.buckets, (uint32_t)p.nb, ws.rc);
     } else {
@@ -624,10 +694,7 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
                          vwin, lps_log, ws.rc);
     }
     HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.rc, (size_t)vwin * acc_bytes, hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipEventElapsedTime(&ws.accum_ms_last, ws.ev0, ws.ev1));
-    ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = p;
+    finish();
     return -(int)vwin;                                       // negative: bits_host holds window sums, not bit sums
   }
   const int h = (p.c - 1) / 2;
@@ -650,10 +717,7 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
                          (uint32_t)batch, lps_log, ws.rc);
     }
     HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.rc, batch * acc_bytes, hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipEventElapsedTime(&ws.accum_ms_last, ws.ev0, ws.ev1));
-    ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = p;
+    finish();
     return p.c;
   }
   if (p.nb <= 256 && batch >= 8) {
@@ -671,10 +735,7 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   } else {
     HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.bits, (size_t)nbits * acc_bytes, hipMemcpyDeviceToHost, stream));
   }
-  HIP_CHECK(hipStreamSynchronize(stream));
-  HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipEventElapsedTime(&ws.accum_ms_last, ws.ev0, ws.ev1));
-  ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = p;
+  finish();
   return p.nwin * p.c;
 }
 

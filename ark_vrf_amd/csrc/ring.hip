@@ -26,7 +26,8 @@
 
 namespace avrf {
 
-#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "avrf: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); abort(); } } while (0)
+// a failed HIP call unwinds to the extern "C" entry point (guarded() below), which returns AVRF_ERR_NO_DEVICE
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw avrf::HipFailure{e_, __FILE__, __LINE__}; } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // device NTT over Fr of the pairing curve (radix-2, stages fused through LDS; batch of equal sizes);
@@ -1228,16 +1229,22 @@ using RingJ = Ring<SuiteBabyJubJub, G1Bn254>;
 
 }  // namespace
 
+template <class F> static int guarded(F f) {
+  try { return f(); }
+  catch (const avrf::HipFailure &e) { fprintf(stderr, "avrf: HIP error %s at %s:%d\n", hipGetErrorString(e.err), e.file, e.line); return AVRF_ERR_NO_DEVICE; }
+  catch (const std::bad_alloc &) { return AVRF_ERR_NO_DEVICE; }
+}
+
 extern "C" {
 
 int avrf_ring_setup_load(avrf_ctx *ctx, const uint8_t *srs, size_t srs_len, size_t ring_size, avrf_ring_setup **out) {
   if (!ctx || !srs || !out || ring_size == 0) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
-  return avrf_ctx_suite_(ctx) == 0 ? RingB::setup_load(ctx, srs, srs_len, ring_size, out) : RingJ::setup_load(ctx, srs, srs_len, ring_size, out);
+  return guarded([&] { return avrf_ctx_suite_(ctx) == 0 ? RingB::setup_load(ctx, srs, srs_len, ring_size, out) : RingJ::setup_load(ctx, srs, srs_len, ring_size, out); });
 }
 int avrf_ring_srs_generate(avrf_ctx *ctx, const uint8_t *tau, const uint8_t *g1, const uint8_t *g2, size_t n_g1, uint8_t *out, size_t out_cap, size_t *out_len) {
   if (!ctx || !tau || !g1 || !g2) return AVRF_ERR_BAD_ARG;
-  return avrf_ctx_suite_(ctx) == 0 ? RingB::srs_generate(ctx, tau, g1, g2, n_g1, out, out_cap, out_len) : RingJ::srs_generate(ctx, tau, g1, g2, n_g1, out, out_cap, out_len);
+  return guarded([&] { return avrf_ctx_suite_(ctx) == 0 ? RingB::srs_generate(ctx, tau, g1, g2, n_g1, out, out_cap, out_len) : RingJ::srs_generate(ctx, tau, g1, g2, n_g1, out, out_cap, out_len); });
 }
 size_t avrf_ring_pcs_domain_size(int suite, size_t ring_size) {       /* pcs_domain_size, src/ring.rs:810-817: 3 * piop_domain + 1 */
   const size_t L = suite == 0 ? (size_t)SuiteBandersnatch::Fr::BITS : (size_t)SuiteBabyJubJub::Fr::BITS;
@@ -1269,7 +1276,7 @@ int avrf_ring_index(avrf_ring_setup *su, const uint8_t *pks_xy, size_t n_keys, a
   if (!su || !out || (n_keys && !pks_xy)) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
-  int st = su->suite == 0 ? RingB::index(su, pks_xy, n_keys, out) : RingJ::index(su, pks_xy, n_keys, out);
+  int st = guarded([&] { return su->suite == 0 ? RingB::index(su, pks_xy, n_keys, out) : RingJ::index(su, pks_xy, n_keys, out); });
   if (st == AVRF_OK && commitment_out) {
     std::vector<uint8_t> b;
     for (int i = 0; i < 3; i++) { if (su->suite == 0) g1_encode<G1Bls12381>((*out)->C[i], true, b); else g1_encode<G1Bn254>((*out)->C[i], true, b); }
@@ -1283,14 +1290,14 @@ int avrf_ring_vk_builder_new(avrf_ring_setup *su, avrf_ring_vk_builder **out) {
   if (!su || !out) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
-  return su->suite == 0 ? RingB::builder_new(su, out) : RingJ::builder_new(su, out);
+  return guarded([&] { return su->suite == 0 ? RingB::builder_new(su, out) : RingJ::builder_new(su, out); });
 }
 void avrf_ring_vk_builder_free(avrf_ring_vk_builder *b) { delete b; }
 size_t avrf_ring_vk_builder_free_slots(const avrf_ring_vk_builder *b) { return b ? b->setup->keyset - b->curr : 0; }
 int avrf_ring_vk_builder_append(avrf_ring_vk_builder *b, const uint8_t *pks_xy, size_t n) {
   if (!b || (n && !pks_xy)) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(b->setup->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
-  return b->setup->suite == 0 ? RingB::builder_append(b, pks_xy, n) : RingJ::builder_append(b, pks_xy, n);
+  return guarded([&] { return b->setup->suite == 0 ? RingB::builder_append(b, pks_xy, n) : RingJ::builder_append(b, pks_xy, n); });
 }
 int avrf_ring_vk_builder_finalize(const avrf_ring_vk_builder *b, uint8_t *commitment_out) {
   if (!b || !commitment_out) return AVRF_ERR_BAD_ARG;
@@ -1306,12 +1313,13 @@ int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const
   if (hipSetDevice(k->setup->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   const size_t plen = k->setup->suite == 0 ? 592 : 480;
   size_t chunk = 512;                                                  // proofs proved in lockstep per device round
-  if (const char *e = getenv("AVRF_RING_CHUNK")) { long v = atol(e); if (v >= 1 && v <= 4096) chunk = (size_t)v; }
+  if (const char *e = getenv("AVRF_RING_CHUNK")) { long v = atol(e); if (v >= 1 && v <= 4096) chunk = (size_t)v; }   // (test hook: re-read per call)
   avrf_ring_setup *su = k->setup;
   auto run = [&](avrf_ring_setup *lane, size_t i) {
     const size_t m = n - i < chunk ? n - i : chunk;
-    return su->suite == 0 ? RingB::prove_chunk(k, lane, m, key_index + i, blindings + 32 * i, blinding_mode == 1, proofs_out + plen * i)
-                          : RingJ::prove_chunk(k, lane, m, key_index + i, blindings + 32 * i, blinding_mode == 1, proofs_out + plen * i);
+    return guarded([&] {
+      return su->suite == 0 ? RingB::prove_chunk(k, lane, m, key_index + i, blindings + 32 * i, blinding_mode == 1, proofs_out + plen * i)
+                            : RingJ::prove_chunk(k, lane, m, key_index + i, blindings + 32 * i, blinding_mode == 1, proofs_out + plen * i); });
   };
   const char *le = getenv("AVRF_RING_LANES"); const bool one_lane = le && atoi(le) == 1;
   if (n <= chunk || one_lane) {
@@ -1319,7 +1327,8 @@ int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const
     return AVRF_OK;
   }
   // two chunks in flight: chunks alternate between the setup's own stream/scratch and its second lane
-  avrf_ring_setup *lanes[2] = {su, su->suite == 0 ? RingB::second_lane(su) : RingJ::second_lane(su)};
+  avrf_ring_setup *lanes[2] = {su, nullptr};
+  if (int st = guarded([&] { lanes[1] = su->suite == 0 ? RingB::second_lane(su) : RingJ::second_lane(su); return (int)AVRF_OK; })) return st;
   std::atomic<int> status{AVRF_OK};
   std::thread th[2];
   for (int t = 0; t < 2; t++) th[t] = std::thread([&, t] {
@@ -1334,8 +1343,9 @@ int avrf_ring_batch_verify(avrf_ring_setup *su, size_t n, const uint8_t *ring_co
                            const uint8_t *instances_xy, const uint8_t *ring_proofs) {
   if (!su || (n && (!ring_commitments || !n_rings || !instances_xy || !ring_proofs))) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
-  return su->suite == 0 ? RingB::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs)
-                        : RingJ::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs);
+  return guarded([&] {
+    return su->suite == 0 ? RingB::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs)
+                          : RingJ::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs); });
 }
 
 }  // extern "C"
