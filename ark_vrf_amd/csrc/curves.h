@@ -11,8 +11,9 @@
 namespace avrf {
 
 template <class S> struct TeCurve {
-  using base_t = te_pre; using acc_t = te_ext;
+  using base_t = te_pre; using acc_t = te_ext; using suite = S;
   static constexpr int BASE_WORDS = 24, ACC_WORDS = 32;
+  static constexpr bool QUAD = true;                  // reduction tails use the four-lanes-per-point addition (te_quad.h)
   static constexpr bool PREFETCH = true;
   static constexpr bool ZERO_IS_IDENTITY = false;     // (0, 1, 0, 1)
   static constexpr bool FIXED_TABLE = false;          // no fixed-base window-table mode (bases change per batch)
@@ -59,6 +60,7 @@ template <class C> struct G1Curve {
   struct base_t { el x, y; };
   struct acc_t { el x, y, zz, zzz; };
   static constexpr int BASE_WORDS = 2 * N, ACC_WORDS = 4 * N;
+  static constexpr bool QUAD = false;
   static constexpr bool PREFETCH = (N <= 8);
   static constexpr int MIN_WAVES = 3;                 // k_accumulate holds one accumulator + one base: 184 VGPRs at N = 12
   static constexpr int RED_WAVES = 2;                 // the general addition (two accumulators live) needs the 256-register budget

@@ -46,6 +46,7 @@ struct MsmWorkspace {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double accum_ms_total = 0; uint64_t accum_launches = 0; float accum_ms_last = 0;
   MsmPlan last_plan = {0, 0, 0, 0};
+  int wsum_lg = 4;               // scale 2^lg of the third point of a window triple (TE window sums)
   void ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch, size_t lanes_max);
   void release();
 };

@@ -34,6 +34,7 @@
 // loads; keys/sorted SoA per window (coalesced); buckets AoS (te_ext 128 B; XYZZ 128 / 192 B).
 #include "msm.h"
 #include "curves.h"
+#include "te_quad.h"
 #include "host_g1.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -328,6 +329,7 @@ k_heavy_sum(const uint32_t *__restrict__ offs, const uint32_t *__restrict__ cnts
     const uint32_t v = slot / nb, rel = offs[slot] - v * n;
     const uint32_t lf = rel / per, ll = (rel + cnt - 1) / per, np = ll - lf + 1;
     const size_t p0 = (size_t)lane_base[v] + lf + slot;
+    if constexpr (CV::QUAD) { q_heavy_sum<typename CV::suite>(part, p0, np, buckets + (size_t)slot * CV::ACC_WORDS, lds); continue; }
     acc_t a = CV::identity();
 #pragma unroll 1
     for (uint32_t k = t; k < np; k += 256) a = cv_add<CV>(a, CV::load_acc(part + (p0 + k) * CV::ACC_WORDS));
@@ -682,20 +684,19 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
     p.lpb = (int)ws.plan_host[0];
     ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = p;
   };
-  if constexpr (CV::WINDOW_SUMS) if (batch == 1 && msm_env().window_sums) {  // one weighted sum per window; the host does nwin Horner steps of c doublings
-    uint32_t wps = 1;
-    while (wps < 4 && (uint32_t)p.nb >= 64 * wps * 2) wps *= 2;
-    if (msm_env().wsum_wps) { wps = (uint32_t)msm_env().wsum_wps; while (wps > 1 && (uint32_t)p.nb < 64 * wps) wps >>= 1; }
-    if ((uint32_t)p.nb >= 64) {
-      hipLaunchKernelGGL(k_wsum_blk<CV>, dim3(vwin), dim3(64 * wps), (size_t)wps * 2 * acc_bytes, stream, (const uint32_t *)ws.buckets, (uint32_t)p.nb, ws.rc);
-    } else {
-      uint32_t lps_log = 0; while ((2u << lps_log) <= (uint32_t)p.nb) lps_log++;
-      hipLaunchKernelGGL(k_wsum<CV>, dim3((unsigned)((((size_t)vwin << lps_log) + 255) / 256)), b256, 0, stream, (const uint32_t *)ws.buckets, (uint32_t)p.nb,
-                         vwin, lps_log, ws.rc);
-    }
-    HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.rc, (size_t)vwin * acc_bytes, hipMemcpyDeviceToHost, stream));
+  if constexpr (CV::WINDOW_SUMS) if (batch == 1 && msm_env().window_sums) {
+    // weighted bucket sum of every window with the four-lanes-per-point kernels (te_quad.h): three points per window come
+    // back; the host folds them into its window Horner (scales 1, 2^4, 16 m), so the device does no doublings at all
+    const uint32_t nb = (uint32_t)p.nb;
+    const uint32_t wpw = nb >= 256 ? 16u : 1u, m = nb >= 256 ? nb / 256 : (nb >= 16 ? nb / 16 : 1u);
+    const uint32_t nwaves = vwin * wpw;
+    hipLaunchKernelGGL(k_wsum_q1<typename CV::suite>, dim3((nwaves + 3) / 4), b256, 0, stream, (const uint32_t *)ws.buckets, nb, m, wpw, nwaves, ws.rc);
+    hipLaunchKernelGGL(k_wsum_q2<typename CV::suite>, dim3(vwin), dim3(64), 0, stream, (const uint32_t *)ws.rc, wpw, ws.bits);
+    HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.bits, (size_t)vwin * 3 * acc_bytes, hipMemcpyDeviceToHost, stream));
     finish();
-    return -(int)vwin;                                       // negative: bits_host holds window sums, not bit sums
+    int lg = 4; while ((1u << lg) < 16 * m) lg++;
+    ws.wsum_lg = lg;
+    return -(int)vwin;                                       // negative: bits_host holds window triples, not bit sums
   }
   const int h = (p.c - 1) / 2;
   const uint32_t tasks = (1u << h) + ((uint32_t)p.nb >> h);
@@ -747,11 +748,15 @@ static int msm_te_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_
   int nbits = msm_device<TeCurve<S>>((const uint32_t *)d_pre, d_scalars, n, S::Fr::BITS, ws, stream);
   HostExt acc = HT::identity();
   const uint32_t *bh = ws.bits_host;
-  if (nbits < 0) {                                        // window sums W_w: sum_w 2^(c w) W_w
-    const int c = ws.last_plan.c;
+  if (nbits < 0) {                                        // window triples: W_w = P1 + 2^4 P2 + 2^lg P3; sum_w 2^(c w) W_w
+    const int c = ws.last_plan.c, lg = ws.wsum_lg;
     for (int w = -nbits - 1; w >= 0; w--) {
-      for (int k = 0; k < c; k++) acc = HT::dbl(acc);
-      acc = HT::add(acc, HT::from_raw32(bh + (size_t)w * 32));
+      for (int k = 0; k < c - lg; k++) acc = HT::dbl(acc);
+      acc = HT::add(acc, HT::from_raw32(bh + ((size_t)w * 3 + 2) * 32));
+      for (int k = 0; k < lg - 4; k++) acc = HT::dbl(acc);
+      acc = HT::add(acc, HT::from_raw32(bh + ((size_t)w * 3 + 1) * 32));
+      for (int k = 0; k < 4; k++) acc = HT::dbl(acc);
+      acc = HT::add(acc, HT::from_raw32(bh + (size_t)w * 3 * 32));
     }
   } else for (int i = nbits - 1; i >= 0; i--) {           // bit sums T_p: sum_p 2^p T_p
     acc = HT::dbl(acc);

@@ -1,0 +1,161 @@
+// te_quad.h -- twisted-Edwards addition spread over FOUR lanes (one coordinate per lane) for the latency-bound tails of
+// the MSM (bucket reduction, src/thin.rs:319 / src/pedersen.rs:420 via msm.hip).
+//
+// One SIMD retires about one lane-per-point te_add every 9 us however few of its lanes carry live work, so a reduction tree
+// is paced by the number of SEQUENTIAL point additions.  With lane j of a quad holding coordinate j of an extended point
+// (0 X, 1 Y, 2 T, 3 Z) the ten field multiplications of add-2008-hwcd collapse into three rounds that all four lanes
+// execute together:
+//   round 1   lane j: c1_j * c2_j                      -> A = X1 X2, B = Y1 Y2, TT = T1 T2, D = Z1 Z2
+//   round 2   lanes 0,1: (X1+Y1)(X2+Y2); lane 2: d TT   -> E', C
+//   linear    lane 0: E = E' - (A+B); lane 1: H = B - aA; lane 2: G = D + C; lane 3: F = D - C
+//   round 3   lane 0: E F; lane 1: G H; lane 2: E H; lane 3: F G      -> X3, Y3, T3, Z3
+// Operands move between the lanes of a quad with DPP quad_perm moves (no LDS).  A wave then carries 16 points and a
+// point addition costs ~1/3 of the instructions of the one-lane form.
+#pragma once
+#include "te.h"
+
+namespace avrf {
+
+template <int P0, int P1, int P2, int P3> AVRF_DI fp qperm(const fp &a) {
+  fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xf, 0xf, true);
+  return r;
+}
+AVRF_DI fp fp_sel(bool c, const fp &a, const fp &b) {
+  fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+// coordinate j of the identity (0, 1, 0, 1)
+template <class S> AVRF_DI fp q_identity(uint32_t j) { return (j & 1) ? fp_one<typename S::Fq>() : fp_zero(); }
+
+// coordinate j of P1 + P2 given coordinate j of each (all four lanes of the quad must be active)
+template <class S> __device__ __noinline__ static fp q_add(fp a, fp b, uint32_t j) {
+  using Fq = typename S::Fq;
+  const fp m1 = fp_mul<Fq>(a, b);
+  const fp sa = fp_add<Fq>(a, qperm<1, 0, 3, 2>(a)), sb = fp_add<Fq>(b, qperm<1, 0, 3, 2>(b));
+  const bool l2 = j == 2;
+  const fp m2 = fp_mul<Fq>(fp_sel(l2, m1, sa), fp_sel(l2, fp_const<Fq>(S::D), sb));
+  const fp A = qperm<0, 0, 0, 0>(m1), B = qperm<1, 1, 1, 1>(m1), D = qperm<3, 3, 3, 3>(m1);
+  const fp C = qperm<2, 2, 2, 2>(m2), Ep = qperm<0, 0, 0, 0>(m2);
+  const fp AB = fp_add<Fq>(A, B), aA = mul_a<S>(A), nC = fp_neg<Fq>(C);
+  const fp X = fp_sel(j == 0, Ep, fp_sel(j == 1, B, D));
+  const fp Y = fp_sel(j == 0, AB, fp_sel(j == 1, aA, fp_sel(l2, nC, C)));
+  const fp U = fp_sub<Fq>(X, Y);                                   // lane 0 E, 1 H, 2 G, 3 F
+  return fp_mul<Fq>(qperm<0, 1, 0, 3>(U), qperm<3, 2, 1, 2>(U));
+}
+
+AVRF_DI fp fp_shfl_down(const fp &a, int delta) {
+  fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __shfl_down(a.v[i], delta);
+  return r;
+}
+AVRF_DI fp fp_shfl_xor(const fp &a, int mask) {
+  fp r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __shfl_xor(a.v[i], mask);
+  return r;
+}
+
+// sum over the 16 quads of a wave, valid in quad 0
+template <class S> AVRF_DI fp q_wave_sum(fp v, uint32_t q, uint32_t j) {
+#pragma unroll 1
+  for (int off = 8; off >= 1; off >>= 1) {
+    const fp o = fp_shfl_down(v, 4 * off);
+    if ((int)q < off) v = q_add<S>(v, o, j);
+  }
+  return v;
+}
+// two sums at once: returns sum_q a_q in quad 0 and sum_q b_q in quad 8 (first step folds a into the low quads and b into
+// the high quads, then both halves reduce together)
+template <class S> AVRF_DI fp q_wave_sum2(const fp &a, const fp &b, uint32_t q, uint32_t j) {
+  const bool lowq = q < 8;
+  const fp send = fp_sel(lowq, b, a);                              // what the partner quad (q ^ 8) accumulates
+  const fp got = fp_shfl_xor(send, 32);
+  fp v = q_add<S>(fp_sel(lowq, a, b), got, j);
+#pragma unroll 1
+  for (int off = 4; off >= 1; off >>= 1) {
+    const fp o = fp_shfl_down(v, 4 * off);
+    if ((int)(q & 7) < off) v = q_add<S>(v, o, j);
+  }
+  return v;
+}
+// suffix sums over the quads of a wave: result_q = sum_{q' >= q} v_q'
+template <class S> AVRF_DI fp q_wave_suffix(fp v, uint32_t q, uint32_t j) {
+#pragma unroll 1
+  for (int off = 1; off < 16; off <<= 1) {
+    const fp o = fp_shfl_down(v, 4 * off);
+    if ((int)q + off < 16) v = q_add<S>(v, o, j);
+  }
+  return v;
+}
+
+// Level 1 of sum_b b * B_b for one window of nb = wpw * 16 * m buckets (b = 1 .. nb, B[b-1] as te_ext in `buckets`):
+// wave wi of the window, quad q owns buckets b0 = wi * 16 m + q + 16 k (k < m), weight b0 + 1 = wi * 16 m + (q + 1) + 16 k:
+//   S_q = sum_k B, J_q = sum_k k B  (2m - 1 quad additions)
+//   out[3 gw + 0] = V1 = sum_q (q + 1) S_q,  out[3 gw + 1] = V2 = sum_q J_q,  out[3 gw + 2] = Y = sum_q S_q
+// so that the window's sum is  sum_wi V1 + 16 sum_wi V2 + 16 m sum_wi wi Y  -- no doublings on the device.
+template <class S>
+__global__ void __launch_bounds__(256)
+k_wsum_q1(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t m, uint32_t wpw, uint32_t nwaves, uint32_t *__restrict__ out) {
+  const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
+  if (gw >= nwaves) return;
+  const uint32_t v = gw / wpw, wi = gw - v * wpw;
+  const uint32_t *B = buckets + (size_t)v * nb * 32;
+  fp Sx = q_identity<S>(j), J = q_identity<S>(j);
+#pragma unroll 1
+  for (int k = (int)m - 1; k >= 0; k--) {
+    const uint32_t b0 = wi * 16 * m + q + 16 * (uint32_t)k;
+    if (b0 < nb) Sx = q_add<S>(Sx, load_fp(B + (size_t)b0 * 32 + j * 8), j);
+    if (k > 0) J = q_add<S>(J, Sx, j);
+  }
+  const fp A = q_wave_suffix<S>(Sx, q, j);                         // A_0 = Y; sum_q (q + 1) S_q = sum_q A_q
+  const fp V = q_wave_sum2<S>(A, J, q, j);                         // quad 0: V1, quad 8: V2
+  uint32_t *o = out + (size_t)gw * 3 * 32 + j * 8;
+  if (q == 0) { store_fp(o, V); store_fp(o + 64, A); }
+  if (q == 8) store_fp(o + 32, V);
+}
+
+// Level 2: one wave per window over the wpw <= 16 triples of level 1:
+//   out[3 v + 0] = P1 = sum V1, out[3 v + 1] = P2 = sum V2, out[3 v + 2] = P3 = sum_wi wi Y_wi
+// and the host finishes  W_v = P1 + 2^4 P2 + 16 m P3  inside its window Horner.
+template <class S>
+__global__ void __launch_bounds__(64)
+k_wsum_q2(const uint32_t *__restrict__ trip, uint32_t wpw, uint32_t *__restrict__ out) {
+  const uint32_t v = blockIdx.x, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
+  fp v1 = q_identity<S>(j), v2 = v1, y = v1;
+  if (q < wpw) {
+    const uint32_t *t = trip + ((size_t)v * wpw + q) * 3 * 32 + j * 8;
+    v1 = load_fp(t); v2 = load_fp(t + 32); y = load_fp(t + 64);
+  }
+  const fp P12 = q_wave_sum2<S>(v1, v2, q, j);
+  fp A = q_wave_suffix<S>(y, q, j);                                // sum_q q Y_q = sum_{q >= 1} A_q
+  if (q == 0) A = q_identity<S>(j);
+  const fp P3 = q_wave_sum<S>(A, q, j);
+  uint32_t *o = out + (size_t)v * 3 * 32 + j * 8;
+  if (q == 0) { store_fp(o, P12); store_fp(o + 64, P3); }
+  if (q == 8) store_fp(o + 32, P12);
+}
+
+// Sum of a heavy bucket's np partials by one workgroup of 64 quads (see k_bucket_sum): quads stride over the partials,
+// each wave folds its 16 quads, the four wave results meet in LDS.
+template <class S> AVRF_DI void q_heavy_sum(const uint32_t *__restrict__ part, size_t p0, uint32_t np, uint32_t *__restrict__ dst, uint32_t *lds) {
+  const uint32_t t = threadIdx.x, lane = t & 63, q = lane >> 2, j = lane & 3, gq = t >> 2, wv = t >> 6;
+  fp a = q_identity<S>(j);
+#pragma unroll 1
+  for (uint32_t k = gq; k < np; k += 64) a = q_add<S>(a, load_fp(part + (p0 + k) * 32 + j * 8), j);
+  a = q_wave_sum<S>(a, q, j);
+  if (q == 0) store_fp(lds + wv * 32 + j * 8, a);
+  __syncthreads();
+  if (t < 4) {
+#pragma unroll 1
+    for (uint32_t w = 1; w < 4; w++) a = q_add<S>(a, load_fp(lds + w * 32 + j * 8), j);
+    store_fp(dst + j * 8, a);
+  }
+  __syncthreads();
+}
+
+}  // namespace avrf
