@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "libavrf.so")
+LIB_PATH = os.environ.get("AVRF_LIB_PATH") or os.path.join(_DIR, "libavrf.so")   # override: A/B builds of the same library
 
 OK, VERIFICATION_FAILURE, INVALID_DATA, RING_CAPACITY_EXCEEDED, SRS_LOOKUP_FAILED = 0, 1, 2, 3, 4
 ERR_NO_DEVICE, ERR_BAD_ARG = -1, -2

@@ -8,6 +8,10 @@
 #include "fpn.h"
 #include "te.h"
 
+#ifndef AVRF_TE_ACC_WAVES
+#define AVRF_TE_ACC_WAVES 2
+#endif
+
 namespace avrf {
 
 template <class S> struct TeCurve {
@@ -17,7 +21,7 @@ template <class S> struct TeCurve {
   static constexpr bool PREFETCH = true;
   static constexpr bool ZERO_IS_IDENTITY = false;     // (0, 1, 0, 1)
   static constexpr bool FIXED_TABLE = false;          // no fixed-base window-table mode (bases change per batch)
-  static constexpr int MIN_WAVES = 3;                 // waves per SIMD asked of the register allocator in k_accumulate
+  static constexpr int MIN_WAVES = AVRF_TE_ACC_WAVES; // waves per SIMD asked of the register allocator in k_accumulate
   static constexpr int RED_WAVES = 1;                 // reduction kernels (general additions, several points live): latency-bound, full register file
   static constexpr bool INLINE_REDUCE_OPS = true;
   static constexpr bool WINDOW_SUMS = true;           // single MSMs: one weighted bucket sum per window (k_wsum_blk) instead of row/column + bit sums
@@ -26,6 +30,11 @@ template <class S> struct TeCurve {
     using Fq = typename S::Fq;
     if (neg) { q.x = fp_neg<Fq>(q.x); q.k = fp_neg<Fq>(q.k); }
     return te_madd<S>(a, q);
+  }
+  static AVRF_DI acc_t from_base(base_t q, bool neg) {
+    using Fq = typename S::Fq;
+    if (neg) q.x = fp_neg<Fq>(q.x);
+    return te_from_pre<S>(q);
   }
   static AVRF_DI acc_t add(const acc_t &a, const acc_t &b) { return te_add<S>(a, b); }
   static AVRF_DI acc_t dbl(const acc_t &a) { return te_dbl<S>(a); }
@@ -76,6 +85,7 @@ template <class C> struct G1Curve {
     if (fn_is_zero(q.x) && fn_is_zero(q.y)) { r.zz = fn_zero<N>(); r.zzz = fn_zero<N>(); }
     return r;
   }
+  static AVRF_DI acc_t from_base(base_t q, bool neg) { if (neg) q.y = fn_neg<Fq>(q.y); return from_affine(q); }
   // 2 * (affine q)  (mdbl-2008-s-1, a = 0)
   static AVRF_DI acc_t dbl_affine(const base_t &q) {
     el U = fn_dbl<Fq>(q.y), V = fn_sqr<Fq>(U), W = fn_mul<Fq>(U, V), S = fn_mul<Fq>(q.x, V);

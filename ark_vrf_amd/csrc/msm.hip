@@ -260,12 +260,17 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
   uint32_t b = lo;
   uint32_t nxt = (b + 1 < nb) ? ow[b + 1] : 0xffffffffu;      // first entry of the next bucket
   const size_t slot0 = (size_t)t + (size_t)v * nb;
-  acc_t acc = CV::identity();
+  acc_t acc;
   if (CV::PREFETCH) {
     // software-pipelined gather: the next base is in flight while the current addition runs
     uint32_t idx = sorted[e0];
     base_t q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS);
-    for (uint32_t i = e0; i < e1; i++) {
+    {                                                          // first entry of every lane: no addition, just the base
+      const uint32_t cidx = idx; const base_t cur = q;
+      if (e0 + 1 < e1) { idx = sorted[e0 + 1]; q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS); }
+      acc = CV::from_base(cur, (cidx & 0x80000000u) != 0);
+    }
+    for (uint32_t i = e0 + 1; i < e1; i++) {
       const uint32_t cidx = idx; const base_t cur = q;
       if (i + 1 < e1) { idx = sorted[i + 1]; q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS); }
       if (i >= nxt) {                                          // bucket boundary inside the lane's range
@@ -276,6 +281,7 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
       acc = CV::madd(acc, cur, (cidx & 0x80000000u) != 0);
     }
   } else {                                                     // 381-bit points: registers are the scarcer resource
+    acc = CV::identity();
     for (uint32_t i = e0; i < e1; i++) {
       if (i >= nxt) {
         CV::store_acc(part + (slot0 + b) * CV::ACC_WORDS, acc);
