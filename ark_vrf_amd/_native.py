@@ -86,6 +86,12 @@ class Context:
             raise AvrfError(f"avrf_ctx_create failed with {st} (no MI355X visible? there is no CPU fallback)")
         self.suite = suite
 
+    def set_validation(self, level):
+        """0: caller guarantees on-curve subgroup points (reference's typed-point contract); 1: on-curve check; 2: + subgroup."""
+        st = lib().avrf_ctx_set_validation(self._h, int(level))
+        if st != OK:
+            raise AvrfError(f"avrf_ctx_set_validation -> {st}")
+
     def close(self):
         if self._h:
             lib().avrf_ctx_destroy(self._h)

@@ -68,6 +68,8 @@ struct avrf_ctx {
   hipStream_t stream = nullptr;
   MsmWorkspace ws;
   // staged batch
+  int validate = 0;               // avrf_ctx_set_validation: 0 unchecked (typed-point callers), 1 on-curve, 2 + subgroup
+  uint64_t stage_gen = 0, chal_gen = 0;   // challenges of *_batch_challenges belong to staging generation chal_gen
   int staged_kind = 0;            // 0 none, 1 thin, 2 pedersen
   size_t n = 0, tot_io = 0, n_terms = 0;
   DevBuf d_pks, d_ios, d_io_off, d_ads, d_ad_off, d_proofs, d_sks;
@@ -96,7 +98,37 @@ static BatchDev batch_of(avrf_ctx *c) {
   return b;
 }
 
+// Validate::Yes over every point of the staged batch (pk, I/O pairs, proof points) when the context asks for it;
+// rec_status (device, n x int32) receives 2 for items with a bad point (per-item verifiers), else NULL.
+static void validate_staged(avrf_ctx *c, int kind, int32_t *d_rec_status) {
+  if (c->validate <= 0 || !c->n) return;
+  uint32_t *fl = c->d_flags.as<uint32_t>();
+  const uint32_t n = (uint32_t)c->n;
+  if (kind == 1 && c->d_pks.p) launch_validate_xy(c->suite, c->d_pks.as<uint8_t>(), 64, 1, n, c->validate, fl, d_rec_status, c->stream);
+  if (kind == 1) launch_validate_xy(c->suite, c->d_proofs.as<uint8_t>(), 96, 1, n, c->validate, fl, d_rec_status, c->stream);
+  else launch_validate_xy(c->suite, c->d_proofs.as<uint8_t>(), 256, 3, n, c->validate, fl, d_rec_status, c->stream);
+  if (c->tot_io) {
+    if (!d_rec_status) launch_validate_xy(c->suite, c->d_ios.as<uint8_t>(), 128, 2, (uint32_t)c->tot_io, c->validate, fl, nullptr, c->stream);
+    else {   // per-item status: the I/O pairs of item j are records io_off[j] .. io_off[j+1]; uniform M = 1 is the common case
+      const uint32_t *io_off = c->h_io.as<uint32_t>();
+      bool uniform = c->tot_io == c->n;
+      for (size_t j = 0; uniform && j < c->n; j++) uniform = io_off[j] == j;
+      if (uniform) launch_validate_xy(c->suite, c->d_ios.as<uint8_t>(), 128, 2, n, c->validate, fl, d_rec_status, c->stream);
+      else for (size_t j = 0; j < c->n; j++) {
+        const uint32_t m = io_off[j + 1] - io_off[j];
+        if (m) launch_validate_xy(c->suite, c->d_ios.as<uint8_t>() + 128 * (size_t)io_off[j], 0, 2 * m, 1, c->validate, fl, d_rec_status + j, c->stream);
+      }
+    }
+  }
+}
+
 extern "C" {
+
+int avrf_ctx_set_validation(avrf_ctx *c, int level) {
+  if (!c || level < 0 || level > 2) return AVRF_ERR_BAD_ARG;
+  c->validate = level;
+  return AVRF_OK;
+}
 
 // accessors for the other translation units of the library (ring.hip)
 hipStream_t avrf_ctx_stream_(avrf_ctx *c) { return c->stream; }
@@ -204,7 +236,7 @@ static int stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint
   if (n && (!io_counts || !ad_lens)) return AVRF_ERR_BAD_ARG;
   if (n > 0x0fffffffULL) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
-  c->staged_kind = 0; c->n = n; c->tot_io = 0; c->n_terms = 0;
+  c->staged_kind = 0; c->n = n; c->tot_io = 0; c->n_terms = 0; c->stage_gen++;
   if (n == 0) { c->staged_kind = kind; return AVRF_OK; }
   HIP_TRY(c->h_io.ensure((n + 1) * 8));
   uint32_t *io_off = c->h_io.as<uint32_t>(), *ad_off = io_off + (n + 1);
@@ -260,6 +292,7 @@ static int batch_run(avrf_ctx *c, int kind) {
   const size_t n = c->n;
   BatchDev b = batch_of(c);
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  validate_staged(c, kind, nullptr);
   if (kind == 1) launch_thin_prepare(c->suite, b, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_flags.as<uint32_t>(), c->stream);
   else launch_ped_prepare(c->suite, b, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream);
   HIP_TRY(hipMemcpyAsync(c->h_c.p, c->d_c.p, n * 16, hipMemcpyDeviceToHost, c->stream));
@@ -335,11 +368,14 @@ int avrf_thin_batch_challenges(avrf_ctx *c, uint8_t *c_out) {
   HIP_TRY(hipSetDevice(c->device));
   BatchDev b = batch_of(c);
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  validate_staged(c, 1, nullptr);
   launch_thin_prepare(c->suite, b, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_flags.as<uint32_t>(), c->stream);
   HIP_TRY(hipMemcpyAsync(c_out, c->d_c.p, c->n * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return *c->h_flags.as<uint32_t>() ? AVRF_INVALID_DATA : AVRF_OK;
+  if (*c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;
+  c->chal_gen = c->stage_gen;                                         // the challenges in d_c / d_z belong to THIS staging
+  return AVRF_OK;
 }
 
 // MSM of the staged shard's terms under the GLOBAL weight stream `seed`; the shard's first item has
@@ -347,6 +383,7 @@ int avrf_thin_batch_challenges(avrf_ctx *c, uint8_t *c_out) {
 // so the partial points of all shards add up to the batch MSM of src/thin.rs:319.
 int avrf_thin_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t first_index, uint8_t out_xy[64]) {
   if (!c || c->staged_kind != 1 || !seed64 || !out_xy) return AVRF_ERR_BAD_ARG;
+  if (c->n && c->chal_gen != c->stage_gen) return AVRF_ERR_BAD_ARG;     // avrf_thin_batch_challenges has not run on this staging (or it failed)
   HIP_TRY(hipSetDevice(c->device));
   HostExt r;
   if (c->n == 0) { r = c->suite == 0 ? HostTe<SuiteBandersnatch>::identity() : HostTe<SuiteBabyJubJub>::identity(); return finish_point(c, r, out_xy); }
@@ -367,14 +404,18 @@ int avrf_pedersen_batch_challenges(avrf_ctx *c, uint8_t *c_out) {
   HIP_TRY(hipSetDevice(c->device));
   BatchDev b = batch_of(c);
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  validate_staged(c, 2, nullptr);
   launch_ped_prepare(c->suite, b, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream);
   HIP_TRY(hipMemcpyAsync(c_out, c->d_c.p, c->n * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return *c->h_flags.as<uint32_t>() ? AVRF_INVALID_DATA : AVRF_OK;
+  if (*c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;
+  c->chal_gen = c->stage_gen;                                         // the challenges in d_c / d_z belong to THIS staging
+  return AVRF_OK;
 }
 int avrf_pedersen_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t first_index, uint8_t out_xy[64]) {
   if (!c || c->staged_kind != 2 || !seed64 || !out_xy) return AVRF_ERR_BAD_ARG;
+  if (c->n && c->chal_gen != c->stage_gen) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
   HostExt r;
   if (c->n == 0) { r = c->suite == 0 ? HostTe<SuiteBandersnatch>::identity() : HostTe<SuiteBabyJubJub>::identity(); return finish_point(c, r, out_xy); }
@@ -468,6 +509,7 @@ int avrf_thin_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t
   HIP_TRY(c->d_status.ensure(n * 4));
   double t0 = now_us();
   launch_thin_verify(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream);
+  validate_staged(c, 1, c->d_status.as<int32_t>());                   // Validate::Yes failures overwrite the item's status with InvalidData
   HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
   c->timing[0] = now_us() - t0;
@@ -502,6 +544,7 @@ int avrf_pedersen_verify(avrf_ctx *c, size_t n, const uint8_t *ios_xy, const uin
   HIP_TRY(c->d_status.ensure(n * 4));
   double t0 = now_us();
   launch_ped_verify(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream);
+  validate_staged(c, 2, c->d_status.as<int32_t>());
   HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
   c->timing[0] = now_us() - t0;

@@ -72,6 +72,9 @@ int msm_g1_fixed_device(int curve, const uint32_t *d_table, int table_c, size_t 
                         size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch,
                         const uint32_t *d_base_idx = nullptr);
 void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, uint32_t *d_flag, hipStream_t stream);
+// sets bit 1 of *d_flag when one of the n Montgomery affine bases (as launch_g1_bases writes them) is outside the prime-order
+// subgroup (BLS12-381: endomorphism test; BN254: cofactor 1, no-op)
+void launch_g1_subgroup_check(int curve, const uint32_t *d_bases, size_t n, uint32_t *d_flag, hipStream_t stream);
 
 // canonical affine bytes (x||y LE32) -> te_pre (device); flags[i] |= 1 if a coordinate >= q, |= 2 if off-curve (when check_curve)
 void launch_pre_from_affine(int suite, const uint8_t *d_xy, size_t n, te_pre_raw *d_pre, uint32_t *d_flag,

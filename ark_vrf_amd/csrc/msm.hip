@@ -844,6 +844,39 @@ static int msm_g1_impl(const uint32_t *d_bases, const uint32_t *d_scalars, size_
   return 0;
 }
 
+// Prime-order-subgroup test of BLS12-381 G1 points (cofactor ~2^126, so curve membership is not enough; the reference gets
+// it from ark-serialize's Validate::Yes when it deserialises a RingProof / RingCommitment, src/ring.rs:97-150):
+//   P in G1  <=>  phi(P) = [-z^2] P,  phi(x, y) = (beta x, y),  z = 0xd201000000010000  (Scott 2021, "A note on group
+// membership tests for G1, G2 and GT on BLS pairing-friendly curves"): two 64-bit double-and-add ladders instead of a
+// 255-bit one.  One lane per point; (0, 0) = infinity passes.  BN254 G1 has cofactor 1: nothing to test.
+__device__ static const uint32_t BLS12_381_BETA_MONT[12] = {0x798a64e8, 0x30f1361b, 0x7ece5a2a, 0xf3b8ddab, 0xc61577f7, 0x16a8ca3a,
+                                                            0x74fd029b, 0xc26a2ff8, 0x60701c6e, 0x3636b766, 0x241b6160, 0x051ba4ab};
+__global__ void __launch_bounds__(64)
+k_g1_subgroup_bls(const uint32_t *__restrict__ bases, uint32_t n, uint32_t *__restrict__ flag) {
+  using CV = G1Curve<G1Bls12381>; using Fq = G1Bls12381::Fq; constexpr int N = Fq::N;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const CV::base_t P = CV::load_base(bases + (size_t)i * 2 * N);
+  if (fn_is_zero(P.x) && fn_is_zero(P.y)) return;
+  const uint64_t z = 0xd201000000010000ull;
+  CV::acc_t a = CV::from_affine(P);
+#pragma unroll 1
+  for (int b = 62; b >= 0; b--) { a = CV::dbl(a); if ((z >> b) & 1) a = CV::madd(a, P, false); }
+  const CV::acc_t q1 = a;                                                   // [z] P
+#pragma unroll 1
+  for (int b = 62; b >= 0; b--) { a = CV::dbl(a); if ((z >> b) & 1) a = CV::add(a, q1); }      // [z^2] P
+  fpn<N> beta; for (int k = 0; k < N; k++) beta.v[k] = BLS12_381_BETA_MONT[k];
+  // [z^2] P == (beta x, -y)  in XYZZ:  X = beta x ZZ,  Y = -y ZZZ,  ZZ != 0
+  bool ok = !fn_is_zero(a.zz);
+  ok = ok && fn_eq(a.x, fn_mul<Fq>(fn_mul<Fq>(beta, P.x), a.zz));
+  ok = ok && fn_eq(a.y, fn_neg<Fq>(fn_mul<Fq>(P.y, a.zzz)));
+  if (!ok) atomicOr(flag, 2u);
+}
+void launch_g1_subgroup_check(int curve, const uint32_t *d_bases, size_t n, uint32_t *d_flag, hipStream_t stream) {
+  if (!n || curve != 0) return;
+  hipLaunchKernelGGL(k_g1_subgroup_bls, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_bases, (uint32_t)n, d_flag);
+}
+
 void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, uint32_t *d_flag, hipStream_t stream) {
   if (!n) return;
   dim3 g((unsigned)((n + 255) / 256)), b(256);

@@ -333,9 +333,9 @@ k_ring_witness_cols(const uint32_t *__restrict__ pos, const uint32_t *__restrict
   store_fp(c + ((size_t)3 * N + i) * 8, load_fp(v + 8));
 }
 template <class F>
-__global__ void k_set_diag(uint32_t *__restrict__ mat, uint32_t n) {
+__global__ void k_set_diag(uint32_t *__restrict__ mat, uint32_t n, uint32_t rows, uint32_t col0) {   // row i of the tile = unit vector e_(col0 + i)
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) store_fp(mat + ((size_t)i * n + i) * 8, fp_one<F>());
+  if (i < rows) store_fp(mat + ((size_t)i * n + col0 + i) * 8, fp_one<F>());
 }
 
 // Montgomery -> plain copy (MSM scalars), out of place
@@ -820,11 +820,18 @@ template <class S, class G> struct Ring {
   static void ensure_lagrange(avrf_ring_setup *su) {
     if (su->d_wit_table) return;
     const size_t N = su->N, nb = 2 * N + 1;
-    uint32_t *d_mat = dev_scratch(su, 0, N * N * 32);
-    HIP_CHECK(hipMemsetAsync(d_mat, 0, N * N * 32, su->stream));
-    hipLaunchKernelGGL(k_set_diag<F>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, su->stream, d_mat, (uint32_t)N);
-    { fp sc; memcpy(sc.v, su->ninv.l, 32); ntt_launch<F>(d_mat, (uint32_t)N, su->d_tw_n_inv, (uint32_t)N, &sc, su->stream); }
-    std::vector<G1Aff> lag; commit_device(su, d_mat, N, N, N, lag);
+    // in tiles of 256 unit vectors: scratch is O(256 N) instead of the N x N matrix (2 GiB at N = 8192, 137 GB at 2^16)
+    const size_t TILE = N < 256 ? N : 256;
+    uint32_t *d_mat = dev_scratch(su, 0, TILE * N * 32);
+    std::vector<G1Aff> lag; lag.reserve(N);
+    for (size_t i0 = 0; i0 < N; i0 += TILE) {
+      const size_t rows = N - i0 < TILE ? N - i0 : TILE;
+      HIP_CHECK(hipMemsetAsync(d_mat, 0, rows * N * 32, su->stream));
+      hipLaunchKernelGGL(k_set_diag<F>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, su->stream, d_mat, (uint32_t)N, (uint32_t)rows, (uint32_t)i0);
+      { fp sc; memcpy(sc.v, su->ninv.l, 32); ntt_launch<F>(d_mat, (uint32_t)N, su->d_tw_n_inv, (uint32_t)rows, &sc, su->stream); }
+      std::vector<G1Aff> part; commit_device(su, d_mat, N, N, rows, part);
+      lag.insert(lag.end(), part.begin(), part.end());
+    }
     using HG = typename T::HG; using FqN = typename T::FqN;
     std::vector<typename HG::Pt> ps(N + 1);
     ps[0] = HG::identity();
@@ -1069,7 +1076,11 @@ template <class S, class G> struct Ring {
     uint8_t le[48]; bool big, inf;
     if (FQB == 48) { inf = b[0] & 0x40; big = b[0] & 0x20; if (!(b[0] & 0x80)) return false; for (int i = 0; i < FQB; i++) le[i] = b[FQB - 1 - i]; le[FQB - 1] &= 0x1f; }
     else { inf = b[FQB - 1] & 0x40; big = b[FQB - 1] & 0x80; memcpy(le, b, FQB); le[FQB - 1] &= 0x3f; }
-    if (inf) { out->inf = true; return true; }
+    if (inf) {                                                          // canonical encoding only: no sort flag, every other bit zero
+      if (big) return false;
+      for (int i = 0; i < FQB; i++) if (le[i]) return false;
+      out->inf = true; return true;
+    }
     QEl x; memcpy(x.l, le, FQB);
     QEl t; if (FqN::subb(t, x, FqN::P()) == 0) return false;           // x >= p
     QEl xm = FqN::to_mont(x);
@@ -1086,7 +1097,8 @@ template <class S, class G> struct Ring {
     memcpy(out->xy, x.l, FQB); memcpy(out->xy + FQB, yp.l, FQB);
     return true;
   }
-  static G1Aff g1_msm(avrf_ring_setup *su, const std::vector<uint8_t> &bases_xy, const std::vector<H256> &scalars_plain) {
+  static G1Aff g1_msm(avrf_ring_setup *su, const std::vector<uint8_t> &bases_xy, const std::vector<H256> &scalars_plain,
+                      bool check_subgroup = false, bool *bad_points = nullptr) {
     const size_t n = scalars_plain.size();
     G1Aff r; memset(&r, 0, sizeof r); r.inf = true;
     if (!n) return r;
@@ -1098,7 +1110,9 @@ template <class S, class G> struct Ring {
     HIP_CHECK(hipMemcpyAsync(d_s, scalars_plain.data(), n * 32, hipMemcpyHostToDevice, su->stream));
     HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream));
     launch_g1_bases(su->suite, d_xy, n, d_b, d_flag, su->stream);
-    msm_g1_device(su->suite, d_b, d_s, n, su->ws, su->stream, r.xy);
+    if (check_subgroup) launch_g1_subgroup_check(su->suite, d_b, n, d_flag, su->stream);   // Validate::Yes of the deserialised points
+    msm_g1_device(su->suite, d_b, d_s, n, su->ws, su->stream, r.xy);       // (synchronises the stream)
+    if (bad_points) { uint32_t f = 0; HIP_CHECK(hipMemcpy(&f, d_flag, 4, hipMemcpyDeviceToHost)); *bad_points = f != 0; }
     r.inf = true; for (int i = 0; i < 2 * FQB; i++) if (r.xy[i]) r.inf = false;
     return r;
   }
@@ -1120,7 +1134,12 @@ template <class S, class G> struct Ring {
     for (size_t i = 0; i < 3 * n_rings; i++) if (!g1_decompress(commitments + FQB * i, &fixed[i])) return AVRF_INVALID_DATA;
     (void)clen;
     // randomisers: SHAKE128 over everything the batch contains
-    Shake128 rh; rh.update("avrf-ring-batch", 15); rh.update(commitments, 3 * FQB * n_rings); rh.update(instances_xy, 64 * n); rh.update(proofs, plen * n);
+    // (the statement is bound in full: sizes, the verifier key, which ring every proof is checked against)
+    Shake128 rh; rh.update("avrf-ring-batch", 15);
+    { uint64_t hdr[3] = {(uint64_t)n, (uint64_t)n_rings, (uint64_t)N}; rh.update(hdr, sizeof hdr); }
+    rh.update(su->g1_0.xy, 2 * FQB); rh.update(su->g2_raw.data(), su->g2_raw.size());
+    for (size_t i = 0; i < n; i++) { uint32_t ri = ring_of_item ? ring_of_item[i] : 0; rh.update(&ri, 4); }
+    rh.update(commitments, 3 * FQB * n_rings); rh.update(instances_xy, 64 * n); rh.update(proofs, plen * n);
     std::vector<uint8_t> rnd(32 * n); rh.squeeze_copy(rnd.data(), rnd.size());
     // per item: 10 terms of the first MSM (3 fixed + 4 witness + C_q + pi1 + pi2) and 2 of the second; the
     // items are independent until the MSMs, so the host part runs on the thread pool
@@ -1209,7 +1228,12 @@ template <class S, class G> struct Ring {
     H256 g1_scalar = {{0, 0, 0, 0}};
     for (size_t it = 0; it < n; it++) g1_scalar = Fr::sub(g1_scalar, gsc[it]);
     put(b1, s1, 10 * n, su->g1_0, g1_scalar);
-    G1Aff acc1 = g1_msm(su, b1, s1), acc2 = g1_msm(su, b2, s2);
+    // b1 holds every deserialised G1 point of the batch (ring commitments, proof commitments, opening proofs): its bases are
+    // subgroup-checked on the device before they are used (ark-serialize Validate::Yes; BLS12-381 G1 has a large cofactor)
+    bool bad = false;
+    G1Aff acc1 = g1_msm(su, b1, s1, true, &bad);
+    if (bad) return AVRF_INVALID_DATA;
+    G1Aff acc2 = g1_msm(su, b2, s2);
     lap("two G1 MSMs (device)");
     using HP = HostPairing<G>;
     typename HP::G2 q[2];

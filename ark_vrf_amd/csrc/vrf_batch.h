@@ -37,5 +37,8 @@ void launch_ped_verify(int suite, const BatchDev &b, int32_t *d_status, hipStrea
 void launch_hash_to_curve(int suite, const uint8_t *d_data, const uint32_t *d_off, uint32_t n, uint8_t *d_out, int32_t *d_status, hipStream_t st);
 void launch_decompress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st);
 void launch_compress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st);
+// Validate::Yes on xy points laid out as records (see k_validate_xy): level 1 on-curve, 2 + prime-order subgroup
+void launch_validate_xy(int suite, const uint8_t *d_base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *d_flags,
+                        int32_t *d_rec_status, hipStream_t st);
 
 }  // namespace avrf

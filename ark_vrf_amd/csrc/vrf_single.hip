@@ -384,6 +384,32 @@ k_decompress(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ o
   fp_store_le(out_xy + 64 * (size_t)j, x); fp_store_le(out_xy + 64 * (size_t)j + 32, y);
   status[j] = st;
 }
+// Validate::Yes for points that cross the ABI as canonical x || y (the reference's typed points have passed
+// CanonicalDeserialize / the checked constructors, src/lib.rs:410-433,471-494): point p of record j sits at
+// base + j * stride + 64 p.  level 1: coordinates < q and on the curve; level 2: also in the prime-order subgroup (r P = 0).
+// A failing point sets FLAG_CURVE in *flags and, when rec_status is given, rec_status[j] = 2 (InvalidData).
+template <class S>
+__global__ void __launch_bounds__(128)
+k_validate_xy(const uint8_t *__restrict__ base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *__restrict__ flags,
+              int32_t *__restrict__ rec_status) {
+  using Fq = typename S::Fq; using Fr = typename S::Fr;
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nrec * ppr) return;
+  const uint32_t j = t / ppr, p = t - j * ppr;
+  const uint8_t *src = base + (size_t)j * stride + 64 * (size_t)p;
+  fp x = fp_load_le(src), y = fp_load_le(src + 32);
+  bool bad = ge_p<Fq>(x) || ge_p<Fq>(y);
+  if (!bad) {
+    fp xm = fp_to_mont<Fq>(x), ym = fp_to_mont<Fq>(y);
+    bad = !te_on_curve<S>(xm, ym);
+    if (!bad && level >= 2) {
+      te_ext rp = te_smul<S>(te_make_pre<S>(xm, ym), fp_const<Fr>(Fr::P), Fr::BITS);
+      bad = !te_is_identity<S>(rp);
+    }
+  }
+  if (bad) { atomicOr(flags, (uint32_t)FLAG_CURVE); if (rec_status) rec_status[j] = 2; }
+}
+
 template <class S>
 __global__ void __launch_bounds__(256)
 k_compress(const uint8_t *__restrict__ in_xy, uint32_t n, uint8_t *__restrict__ out) {
@@ -435,6 +461,12 @@ void launch_hash_to_curve(int suite, const uint8_t *d_data, const uint32_t *d_of
 void launch_decompress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st) {
   if (!n) return;
   AVRF_DISPATCH(suite, k_decompress, dim3((n + 127) / 128), dim3(128), st, d_in, n, d_out, validate, d_status);
+}
+void launch_validate_xy(int suite, const uint8_t *d_base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *d_flags,
+                        int32_t *d_rec_status, hipStream_t st) {
+  if (!nrec || !ppr || level <= 0) return;
+  const uint32_t tot = nrec * ppr;
+  AVRF_DISPATCH(suite, k_validate_xy, dim3((tot + 127) / 128), dim3(128), st, d_base, stride, ppr, nrec, level, d_flags, d_rec_status);
 }
 void launch_compress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st) {
   if (!n) return;

@@ -55,6 +55,18 @@ int avrf_device_count(void);
 int avrf_ctx_create(int suite, int device, avrf_ctx **out);
 void avrf_ctx_destroy(avrf_ctx *ctx);
 
+/* Input validation of the verifier entry points (SURVEY.md 8b "Input validation").  The reference's verifiers ASSUME points
+ * on the curve and in the prime-order subgroup (src/thin.rs:78-94, src/pedersen.rs:103-120): its typed points have passed
+ * CanonicalDeserialize with Validate::Yes / the checked constructors (src/lib.rs:410-433,440-444,471-494).  This ABI takes raw
+ * coordinates, so the caller says who validates:
+ *   level 0 (default)  "_unchecked": the caller guarantees on-curve subgroup points (e.g. they came from
+ *                      avrf_points_decompress(validate = 1) or from an arkworks value); off-curve input gives undefined verdicts;
+ *   level 1            every pk / I/O / proof point of avrf_{thin,pedersen}_{verify,batch_verify,batch_run,batch_challenges} must
+ *                      be on the curve, else AVRF_INVALID_DATA (per item for the *_verify calls) before any equation is evaluated;
+ *   level 2            additionally r * P = O for every point (one 253-bit scalar multiplication per point: opt-in).
+ * The identity checks of the verifiers (src/thin.rs:140-149,266-271, src/pedersen.rs:204-213,348-353) are unconditional. */
+int avrf_ctx_set_validation(avrf_ctx *ctx, int level);
+
 /* <S::Affine as AffineRepr>::Group::msm_unchecked(&bases, &scalars)
  * (call sites src/thin.rs:319, src/pedersen.rs:420, src/utils/common.rs:410-411).
  * bases_xy: n x 64, scalars: n x 32, out_xy: normalised result (64 bytes).
@@ -100,6 +112,8 @@ int avrf_pedersen_batch_partial(avrf_ctx *ctx, const uint8_t seed64[64], uint64_
  * iff the sum is the identity (0, 1). */
 int avrf_thin_batch_challenges(avrf_ctx *ctx, uint8_t *c_out);
 int avrf_batch_weight_seed(int suite, int pedersen, size_t n, const uint8_t *c16, const uint8_t *resp, uint8_t seed_out[64]);
+/* (AVRF_ERR_BAD_ARG unless avrf_thin_batch_challenges succeeded on the CURRENT staging: re-staging or any other call that
+ * stages -- avrf_thin_verify, a prover -- invalidates the challenges) */
 int avrf_thin_batch_partial(avrf_ctx *ctx, const uint8_t seed[64], uint64_t first_index, uint8_t out_xy[64]);
 int avrf_points_sum(int suite, size_t k, const uint8_t *points_xy, uint8_t out_xy[64]);
 

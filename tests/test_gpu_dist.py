@@ -139,3 +139,66 @@ def test_sharded_ring_prove_and_verify_one_rank_group(golden_dir):
         assert sharded_ring_batch_verify(vb, 3, dist) != 0
     finally:
         dist.destroy_process_group()
+
+
+def test_partial_requires_fresh_challenges():
+    """*_batch_partial must not run on challenges of an earlier staging."""
+    import ctypes as C
+    from ark_vrf_amd import _native as nat
+    from ark_vrf_amd.dist import GpuEngine, shard_thin_batch
+    b = orc.gen_batch(0, 0, 64)
+    eng = GpuEngine(nat.Context(0))
+    sh = shard_thin_batch(b, 0, 64)
+    st, c = eng.challenges(sh)
+    assert st == 0
+    seed = eng.weight_seed(0, c, b"".join(b["proofs"][96 * j + 64: 96 * j + 96] for j in range(64)))
+    eng.partial(seed, 0)                                                       # fine
+    out = (C.c_uint8 * 64)()
+    nb = nat.Batch(64, b["ios_xy"], b["io_counts"], b["ads"], b["ad_lens"], pks_xy=b["pks_xy"], proofs=b["proofs"])
+    assert eng.ctx.thin_batch_stage(nb) == 0                                   # re-staged: challenges are stale
+    assert nat.lib().avrf_thin_batch_partial(eng.ctx._h, nat._u8(seed), C.c_uint64(0), out) == nat.ERR_BAD_ARG
+    st, c = eng.challenges(sh)
+    assert st == 0 and eng.ctx.thin_verify(nb) == [0] * 64                     # thin_verify stages too
+    assert nat.lib().avrf_thin_batch_partial(eng.ctx._h, nat._u8(seed), C.c_uint64(0), out) == nat.ERR_BAD_ARG
+    # identity pk: challenges fail -> no partial either
+    bad = dict(sh); bad["pks_xy"] = bytes(32) + (1).to_bytes(32, "little") + sh["pks_xy"][64:]
+    st, _ = eng.challenges(bad)
+    assert st == 2
+    assert nat.lib().avrf_thin_batch_partial(eng.ctx._h, nat._u8(seed), C.c_uint64(0), out) == nat.ERR_BAD_ARG
+
+
+_RCCL_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import torch, torch.distributed as dist
+import oracle as orc
+from ark_vrf_amd import _native as nat
+from ark_vrf_amd.dist import GpuEngine, sharded_thin_batch_verify, sharded_pedersen_batch_verify, sharded_ring_prove
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+b = orc.gen_batch(0, 0, 300)
+eng = GpuEngine(nat.Context(0))
+assert sharded_thin_batch_verify(eng, 0, b, dist, device="cuda") == 0
+p = bytearray(b["proofs"]); p[96 * 5 + 64] ^= 1
+b2 = dict(b); b2["proofs"] = bytes(p)
+assert sharded_thin_batch_verify(eng, 0, b2, dist, device="cuda") == 1
+bp = orc.gen_batch(0, 1, 120)
+assert sharded_pedersen_batch_verify(eng, 0, bp, dist, device="cuda") == 0
+outs = sharded_ring_prove(lambda idx, bl: [bytes([i]) * 8 for i in idx], [3, 1, 2], [bytes(32)] * 3, dist, device="cuda")
+assert outs == [bytes([3]) * 8, bytes([1]) * 8, bytes([2]) * 8]
+t = torch.ones(4, device="cuda"); dist.all_reduce(t); assert float(t.sum()) == 4.0
+dist.barrier(); torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_rccl_path_world_size_one():
+    """The collectives of ark_vrf_amd/dist.py on backend "nccl" (= RCCL) with device tensors -- the path an 8-GPU run takes --
+    executed for real at world size 1.  Own process: RCCL initialisation stays out of the pytest process."""
+    import subprocess, sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

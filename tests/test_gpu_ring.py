@@ -141,6 +141,36 @@ def test_ring_verify_reference_vectors(env, suite):
     assert ring_batch_verify(setup, [coms[0]], None, [insts[0]], [bytes(junk)]) in (1, 2)   # undecodable or wrong
 
 
+def test_ring_verify_validates_g1_points(env):
+    """Validate::Yes of the deserialised RingProof / RingCommitment points (ADVICE r1): a BLS12-381 G1 point ON the curve but
+    OUTSIDE the prime-order subgroup (cofactor ~2^126) and a non-canonical encoding of infinity are InvalidData, not merely
+    a failed equation; the canonical infinity decodes (and then fails the equation)."""
+    from ark_vrf_amd.ring import ring_batch_verify
+    ctx, setup, vs, srs = env[0]
+    s = R.SUITES[0]
+    v = vs[0]
+    com, inst, proof = bytes.fromhex(v["ring_pks_com"]), xy(0, bytes.fromhex(v["proof_pk_com"])), bytes.fromhex(v["ring_proof"])
+    assert ring_batch_verify(setup, [com], None, [inst], [proof]) == 0
+    x = 0x13c60d23238642ea126a1e48cc11d357c30d8b7628dbd25e63b229f1c4069545de11cc9dea959c212e9c82b1478c281d
+    y = 0x173eb497b4648ea412daae1e11fa194e01a1d4bf7376e7bad3ef138322e23c3c5114b8a96c915d51db072395e4ad9649
+    assert (y * y - x * x * x - 4) % s.p == 0 and R.g1_mul(s.p, (x, y, 1), s.r) is not None      # on E(Fp), not in G1
+    off = R.g1_encode(s, (x, y), True)
+    assert ring_batch_verify(setup, [com], None, [inst], [off + proof[48:]]) == 2                # proof commitment
+    assert ring_batch_verify(setup, [com], None, [inst], [proof[:-48] + off]) == 2               # opening proof
+    assert ring_batch_verify(setup, [off + com[48:]], None, [inst], [proof]) == 2                # ring commitment
+    inf = bytes([0xC0]) + bytes(47)
+    assert ring_batch_verify(setup, [com], None, [inst], [inf + proof[48:]]) == 1                # canonical infinity: decodes, fails
+    assert ring_batch_verify(setup, [com], None, [inst], [bytes([0xC0]) + bytes(46) + b"\x01" + proof[48:]]) == 2
+    assert ring_batch_verify(setup, [com], None, [inst], [bytes([0xE0]) + bytes(47) + proof[48:]]) == 2   # infinity with the sort flag
+    # BN254 (cofactor 1): infinity flag with a non-zero x is rejected as well
+    ctx1, setup1, vs1, _ = env[1]
+    v1 = vs1[0]
+    com1, inst1, proof1 = bytes.fromhex(v1["ring_pks_com"]), xy(1, bytes.fromhex(v1["proof_pk_com"])), bytes.fromhex(v1["ring_proof"])
+    assert ring_batch_verify(setup1, [com1], None, [inst1], [proof1]) == 0
+    assert ring_batch_verify(setup1, [com1], None, [inst1], [b"\x01" + bytes(30) + bytes([0x40]) + proof1[32:]]) == 2
+    assert ring_batch_verify(setup1, [com1], None, [inst1], [bytes(31) + bytes([0x40]) + proof1[32:]]) == 1
+
+
 def test_ring_vrf_end_to_end_gpu(env):
     """ring::Prover::prove + ring::Verifier::verify composed from the ABI pieces (src/ring.rs:211-247): Pedersen
     proof + ring proof for the returned blinding; verify = Pedersen verify + ring verify of Yb."""

@@ -8,7 +8,7 @@ import random
 import pytest
 
 import oracle as orc
-from helpers import IDENTITY_XY, R_ORDER, nat_batch, proof_comp, rand_scalar, xy
+from helpers import IDENTITY_XY, R_ORDER, nat_batch, proof_comp, rand_scalar, xy, proof_xy
 
 pytestmark = pytest.mark.gpu
 NAMES = {0: "bandersnatch_sha-512_ell2", 1: "baby-jubjub_sha-512_tai"}
@@ -116,3 +116,42 @@ def test_point_codec(ctxs, suite):
         if o_st == 0:
             assert xs[64 * j: 64 * j + 64] == o_xy
         assert st2[j] == orc.point_decompress(suite, cp, validate=True)[0]
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_validation_levels(ctxs, golden_dir, suite):
+    """avrf_ctx_set_validation (SURVEY.md 8b "Input validation"; the reference validates in CanonicalDeserialize / the checked
+    constructors, src/lib.rs:410-433,471-494): level 1 rejects off-curve coordinates, level 2 also points of small order;
+    per item for the *_verify calls, for the whole batch in BatchVerifier."""
+    import json, os
+    from ark_vrf_amd._native import Batch
+    c = ctxs[suite]
+    name = {0: "bandersnatch_sha-512_ell2", 1: "baby-jubjub_sha-512_tai"}[suite]
+    vs = json.load(open(os.path.join(golden_dir, name + "_thin.json")))
+    pks = [xy(suite, bytes.fromhex(v["pk"])) for v in vs]
+    ios = [[(xy(suite, bytes.fromhex(v["h"])), xy(suite, bytes.fromhex(v["gamma"])))] for v in vs]
+    ads = [bytes.fromhex(v["ad"]) for v in vs]
+    proofs = [proof_xy(suite, bytes.fromhex(v["proof_r"] + v["proof_s"]), 0) for v in vs]
+    q = {0: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+         1: 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001}[suite]
+    off_curve = (5).to_bytes(32, "little") + (7).to_bytes(32, "little")
+    order2 = bytes(32) + (q - 1).to_bytes(32, "little")                     # (0, -1): on the curve, order 2
+    try:
+        for level, bad_pt, want in ((1, off_curve, 2), (2, off_curve, 2), (2, order2, 2), (1, order2, None)):
+            c.set_validation(level)
+            assert c.thin_verify(Batch.from_items(ios, ads, pks_xy=pks, proofs=proofs)) == [0] * 7
+            assert c.thin_batch_verify(pks, ios, ads, proofs) == 0
+            ios_bad = [list(x) for x in ios]; ios_bad[3] = [(ios[3][0][0], bad_pt)]
+            st = c.thin_verify(Batch.from_items(ios_bad, ads, pks_xy=pks, proofs=proofs))
+            if want is not None:
+                assert st[3] == want and st[:3] + st[4:] == [0] * 6
+                assert c.thin_batch_verify(pks, ios_bad, ads, proofs) == want
+                pks_bad = pks[:5] + [bad_pt] + pks[6:]
+                st = c.thin_verify(Batch.from_items(ios, ads, pks_xy=pks_bad, proofs=proofs))
+                assert st[5] == want and sum(st) == want
+                pr_bad = proofs[:1] + [bad_pt + proofs[1][64:]] + proofs[2:]
+                assert c.thin_batch_verify(pks, ios, ads, pr_bad) == want
+            else:
+                assert st[3] in (1, 2)                                       # level 1 does not look at the subgroup: some failure
+    finally:
+        c.set_validation(0)
