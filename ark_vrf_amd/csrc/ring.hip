@@ -15,6 +15,7 @@
 #include "host_pairing.h"
 #include "host_te.h"
 #include "msm.h"
+#include "pairing.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -477,6 +478,7 @@ struct avrf_ring_setup {
   uint32_t *d_scr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t scr_cap[6] = {0, 0, 0, 0, 0, 0};
   MsmWorkspace ws;
+  PairingTables ptab; bool ptab_ready = false;        // line tables of (g2, tau g2) for the device pairing checks (built on first use)
   // second lane for avrf_ring_prove: a shallow copy (same SRS tables, twiddles, constants) with its own stream, scratch
   // and MSM workspace, so two chunks of proofs are in flight and one hides the other's host rounds
   avrf_ring_setup *lane1 = nullptr;
@@ -1117,6 +1119,32 @@ template <class S, class G> struct Ring {
     return r;
   }
 
+  // ---- n independent KZG pairing checks on the device: ok[i] = [ e(A_i, g2) * e(B_i, tau g2) == 1 ]   (pairing.hip)
+  static void ensure_pairing(avrf_ring_setup *su) {
+    if (su->ptab_ready) return;
+    su->ptab.build(su->suite, su->g2_raw.data(), 2, su->stream);
+    su->ptab_ready = true;
+  }
+  static int pairing_check(avrf_ring_setup *su, size_t n, const uint8_t *a_xy, const uint8_t *b_xy, int32_t *ok_out) {
+    if (!n) return AVRF_OK;
+    ensure_pairing(su);
+    const size_t e1 = 2 * FQB;
+    std::vector<uint8_t> le(2 * n * e1);
+    for (size_t i = 0; i < n; i++) { memcpy(&le[(2 * i) * e1], a_xy + i * e1, e1); memcpy(&le[(2 * i + 1) * e1], b_xy + i * e1, e1); }
+    const size_t pb = (2 * n * e1 + 255) / 256 * 256, ob = (n * 4 + 255) / 256 * 256;
+    uint8_t *base = (uint8_t *)dev_scratch(su, 1, 2 * pb + ob + 256);
+    uint8_t *d_le = base; uint32_t *d_pts = (uint32_t *)(base + pb); int32_t *d_ok = (int32_t *)(base + 2 * pb); uint32_t *d_flag = (uint32_t *)(base + 2 * pb + ob);
+    HIP_CHECK(hipMemcpyAsync(d_le, le.data(), 2 * n * e1, hipMemcpyHostToDevice, su->stream));
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream));
+    launch_g1_bases(su->suite, d_le, 2 * n, d_pts, d_flag, su->stream);
+    launch_pairing_check(su->ptab, d_pts, n, d_ok, su->stream);
+    uint32_t flag = 0;
+    HIP_CHECK(hipMemcpyAsync(ok_out, d_ok, n * 4, hipMemcpyDeviceToHost, su->stream));
+    HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, su->stream));
+    HIP_CHECK(hipStreamSynchronize(su->stream)); HIP_CHECK(hipGetLastError());
+    return flag ? AVRF_INVALID_DATA : AVRF_OK;
+  }
+
   // ---- RingVerifier::verify / multi-ring batch verifier (src/ring.rs:242,693-735).
   // Every item's two KZG openings are folded with 128-bit randomisers into
   //   e(sum r (C - v g1 + z pi), g2) * e(-sum r pi, tau g2) == 1 :
@@ -1282,6 +1310,7 @@ void avrf_ring_setup_free(avrf_ring_setup *su) {
                su->d_scr[0], su->d_scr[1], su->d_scr[2], su->d_scr[3], su->d_scr[4], su->d_scr[5]};
   for (void *p : d) if (p) (void)hipFree(p);
   su->ws.release();
+  su->ptab.release();
   if (avrf_ring_setup *l = su->lane1) {                                // only what the lane owns
     void *o[] = {l->d_buf, l->d_scr[0], l->d_scr[1], l->d_scr[2], l->d_scr[3], l->d_scr[4], l->d_scr[5]};
     for (void *p : o) if (p) (void)hipFree(p);
@@ -1361,6 +1390,12 @@ int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const
   });
   for (auto &x : th) x.join();
   return status;
+}
+
+int avrf_ring_pairing_check(avrf_ring_setup *su, size_t n, const uint8_t *a_xy, const uint8_t *b_xy, int32_t *ok_out) {
+  if (!su || (n && (!a_xy || !b_xy || !ok_out))) return AVRF_ERR_BAD_ARG;
+  if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
+  return guarded([&] { return su->suite == 0 ? RingB::pairing_check(su, n, a_xy, b_xy, ok_out) : RingJ::pairing_check(su, n, a_xy, b_xy, ok_out); });
 }
 
 int avrf_ring_batch_verify(avrf_ring_setup *su, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,

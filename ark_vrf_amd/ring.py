@@ -136,3 +136,13 @@ def srs_generate(ctx, suite, tau, g1, g2, ring_size):
     if st != nat.OK:
         raise nat.AvrfError(f"avrf_ring_srs_generate -> {st}")
     return bytes(out)[:ln.value]
+
+
+def pairing_check(setup, a_xy, b_xy):
+    """ok[i] = e(A_i, g2) * e(B_i, tau g2) == 1 on the device (avrf_ring_pairing_check); a_xy, b_xy: lists of canonical LE x||y."""
+    n = len(a_xy)
+    out = (C.c_int32 * max(1, n))()
+    st = nat.lib().avrf_ring_pairing_check(setup._h, C.c_size_t(n), nat._u8(b"".join(a_xy)), nat._u8(b"".join(b_xy)), out)
+    if st != nat.OK:
+        raise nat.AvrfError(f"avrf_ring_pairing_check -> {st}")
+    return list(out)[:n]

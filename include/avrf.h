@@ -223,6 +223,14 @@ int avrf_ring_prove(avrf_ring_key *key, size_t n, const uint32_t *key_index, con
 int avrf_ring_batch_verify(avrf_ring_setup *setup, size_t n, const uint8_t *ring_commitments, size_t n_rings,
                            const uint32_t *ring_of_item, const uint8_t *instances_xy, const uint8_t *ring_proofs);
 
+/* The pairing half of the KZG verifier on the device (arkworks `Pairing::multi_pairing` + final exponentiation as reached
+ * from RingVerifier::verify, src/ring.rs:242): for i < n,  ok_out[i] = 1 iff  e(A_i, g2) * e(B_i, tau g2) == 1  with (g2, tau g2)
+ * the two `powers_in_g2` of the setup's SRS.  a_xy / b_xy: n G1 points each, canonical little-endian x || y (48+48 bytes
+ * BLS12-381, 32+32 BN254; all-zero = infinity), assumed on the curve (they are outputs of the verifier's own MSMs).  Miller
+ * loops and final exponentiations run as one kernel, an Fp12 element spread over 16 lanes (pairing.hip); the line tables of
+ * the two G2 arguments are built on the device at first use.  AVRF_INVALID_DATA for a coordinate >= p. */
+int avrf_ring_pairing_check(avrf_ring_setup *setup, size_t n, const uint8_t *a_xy, const uint8_t *b_xy, int32_t *ok_out);
+
 /* Input::new(data) = Suite::data_to_point (src/lib.rs:440-444 via src/utils/hash_to_curve.rs:34-100) for n messages:
  * Elligator2 with expand_message_xmd(SHA-512) for Bandersnatch, try-and-increment for Baby-JubJub.  data = the
  * messages concatenated, data_lens[i] their lengths.  out_xy: n x 64; status_out[i] = 0, or 2 (InvalidData) where
