@@ -74,7 +74,13 @@ int msm_g1_fixed_device(int curve, const uint32_t *d_table, int table_c, size_t 
 void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, uint32_t *d_flag, hipStream_t stream);
 // sets bit 1 of *d_flag when one of the n Montgomery affine bases (as launch_g1_bases writes them) is outside the prime-order
 // subgroup (BLS12-381: endomorphism test; BN254: cofactor 1, no-op)
-void launch_g1_subgroup_check(int curve, const uint32_t *d_bases, size_t n, uint32_t *d_flag, hipStream_t stream);
+// (d_rec_status != nullptr: record i / ppr of a failing point gets status 2)
+void launch_g1_subgroup_check(int curve, const uint32_t *d_bases, size_t n, uint32_t *d_flag, hipStream_t stream, int32_t *d_rec_status = nullptr,
+                              uint32_t ppr = 1);
+// per item (16-lane group): point 0 = sum_{t < split} s_t P_t, point 1 = sum_{split <= t < tpi} s_t P_t over the item's tpi <= 16
+// (base, scalar) pairs; out: n_items x 2 Montgomery affine points
+void launch_g1_lincomb(int curve, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n_items, uint32_t tpi, uint32_t split, uint32_t *d_out,
+                       hipStream_t stream);
 
 // canonical affine bytes (x||y LE32) -> te_pre (device); flags[i] |= 1 if a coordinate >= q, |= 2 if off-curve (when check_curve)
 void launch_pre_from_affine(int suite, const uint8_t *d_xy, size_t n, te_pre_raw *d_pre, uint32_t *d_flag,

@@ -852,7 +852,7 @@ static int msm_g1_impl(const uint32_t *d_bases, const uint32_t *d_scalars, size_
 __device__ static const uint32_t BLS12_381_BETA_MONT[12] = {0x798a64e8, 0x30f1361b, 0x7ece5a2a, 0xf3b8ddab, 0xc61577f7, 0x16a8ca3a,
                                                             0x74fd029b, 0xc26a2ff8, 0x60701c6e, 0x3636b766, 0x241b6160, 0x051ba4ab};
 __global__ void __launch_bounds__(64)
-k_g1_subgroup_bls(const uint32_t *__restrict__ bases, uint32_t n, uint32_t *__restrict__ flag) {
+k_g1_subgroup_bls(const uint32_t *__restrict__ bases, uint32_t n, uint32_t *__restrict__ flag, int32_t *__restrict__ rec_status, uint32_t ppr) {
   using CV = G1Curve<G1Bls12381>; using Fq = G1Bls12381::Fq; constexpr int N = Fq::N;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -870,11 +870,69 @@ k_g1_subgroup_bls(const uint32_t *__restrict__ bases, uint32_t n, uint32_t *__re
   bool ok = !fn_is_zero(a.zz);
   ok = ok && fn_eq(a.x, fn_mul<Fq>(fn_mul<Fq>(beta, P.x), a.zz));
   ok = ok && fn_eq(a.y, fn_neg<Fq>(fn_mul<Fq>(P.y, a.zzz)));
-  if (!ok) atomicOr(flag, 2u);
+  if (!ok) { atomicOr(flag, 2u); if (rec_status) rec_status[i / ppr] = 2; }
 }
-void launch_g1_subgroup_check(int curve, const uint32_t *d_bases, size_t n, uint32_t *d_flag, hipStream_t stream) {
+void launch_g1_subgroup_check(int curve, const uint32_t *d_bases, size_t n, uint32_t *d_flag, hipStream_t stream, int32_t *d_rec_status, uint32_t ppr) {
   if (!n || curve != 0) return;
-  hipLaunchKernelGGL(k_g1_subgroup_bls, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_bases, (uint32_t)n, d_flag);
+  hipLaunchKernelGGL(k_g1_subgroup_bls, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_bases, (uint32_t)n, d_flag, d_rec_status, ppr ? ppr : 1u);
+}
+
+// Small linear combinations, one 16-lane group per item: lane t < tpi computes scalar_t * P_t (255-bit double-and-add), lanes
+// [0, split) are summed into point 0, lanes [split, tpi) into point 1; both leave as Montgomery affine x | y ((0, 0) =
+// infinity) at out[(2 item + q) * 2N] -- the two G1 arguments of an independent KZG pairing check (RingVerifier::verify,
+// src/ring.rs:242), whose bases differ per item so that no bucket method applies.
+template <class C>
+__global__ void __launch_bounds__(64)
+k_g1_lincomb(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ scalars, uint32_t n_items, uint32_t tpi, uint32_t split,
+             uint32_t *__restrict__ out) {
+  using CV = G1Curve<C>; using Fq = typename C::Fq; constexpr int N = Fq::N;
+  const uint32_t lane = threadIdx.x & 63, k = lane & 15;
+  uint32_t item = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const bool live = item < n_items;
+  if (!live) item = n_items - 1;
+  typename CV::acc_t acc = CV::identity();
+  if (k < tpi) {
+    const size_t t = (size_t)item * tpi + k;
+    const typename CV::base_t P = CV::load_base(bases + t * 2 * N);
+    uint32_t sc[8];
+    { const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + t * 8); uint4 a = sp[0], b = sp[1];
+      sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w; }
+#pragma unroll 1
+    for (int bit = 255; bit >= 0; bit--) {
+      acc = CV::dbl(acc);
+      if ((sc[bit >> 5] >> (bit & 31)) & 1) acc = CV::madd(acc, P, false);
+    }
+  }
+  // lanes 0 and `split` gather their segment (the other lanes add along and are ignored)
+#pragma unroll 1
+  for (uint32_t t = 1; t < 16; t++) {
+    uint32_t src = k < split ? t : split + t;
+    const bool inside = k < split ? src < split : src < tpi;
+    if (src > 15) src = 15;
+    typename CV::acc_t o;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      o.x.v[i] = __shfl(acc.x.v[i], src, 16); o.y.v[i] = __shfl(acc.y.v[i], src, 16);
+      o.zz.v[i] = __shfl(acc.zz.v[i], src, 16); o.zzz.v[i] = __shfl(acc.zzz.v[i], src, 16);
+    }
+    if ((k == 0 || k == split) && inside) acc = CV::add(acc, o);
+  }
+  if (live && (k == 0 || k == split)) {
+    uint32_t *o = out + ((size_t)item * 2 + (k == 0 ? 0 : 1)) * 2 * N;
+    if (CV::is_identity(acc)) { fn_store<N>(o, fn_zero<N>()); fn_store<N>(o + N, fn_zero<N>()); }
+    else {
+      const fpn<N> inv = fn_inv<Fq>(fn_mul<Fq>(acc.zz, acc.zzz));
+      fn_store<N>(o, fn_mul<Fq>(acc.x, fn_mul<Fq>(inv, acc.zzz)));       // X / ZZ
+      fn_store<N>(o + N, fn_mul<Fq>(acc.y, fn_mul<Fq>(inv, acc.zz)));    // Y / ZZZ
+    }
+  }
+}
+void launch_g1_lincomb(int curve, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n_items, uint32_t tpi, uint32_t split, uint32_t *d_out,
+                       hipStream_t stream) {
+  if (!n_items) return;
+  const dim3 grid((unsigned)((n_items * 16 + 63) / 64)), block(64);
+  if (curve == 0) hipLaunchKernelGGL(k_g1_lincomb<G1Bls12381>, grid, block, 0, stream, d_bases, d_scalars, (uint32_t)n_items, tpi, split, d_out);
+  else hipLaunchKernelGGL(k_g1_lincomb<G1Bn254>, grid, block, 0, stream, d_bases, d_scalars, (uint32_t)n_items, tpi, split, d_out);
 }
 
 void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, uint32_t *d_flag, hipStream_t stream) {

@@ -1149,8 +1149,10 @@ template <class S, class G> struct Ring {
   // Every item's two KZG openings are folded with 128-bit randomisers into
   //   e(sum r (C - v g1 + z pi), g2) * e(-sum r pi, tau g2) == 1 :
   // two G1 MSMs on the GPU (10 n + 1 and 2 n terms) and one 2-pairing check on the host.
+  // each_status != nullptr: the n items are verified INDEPENDENTLY (n x RingVerifier::verify): per-item status, one 2-pairing
+  // check per item on the device (k_g1_lincomb + pairing.hip) instead of one randomised check for the whole batch.
   static int verify_batch(avrf_ring_setup *su, size_t n, const uint8_t *commitments, const uint32_t *ring_of_item, size_t n_rings,
-                          const uint8_t *instances_xy, const uint8_t *proofs) {
+                          const uint8_t *instances_xy, const uint8_t *proofs, int32_t *each_status = nullptr) {
     if (n == 0) return AVRF_OK;
     static const bool trace = getenv("AVRF_RING_TRACE") != nullptr;
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
@@ -1179,6 +1181,8 @@ template <class S, class G> struct Ring {
     const H256 w_last = fr_pow<F>(su->w, cap - 1), ninv = su->ninv;
     H256 wz[3]; for (int j = 0; j < 3; j++) wz[j] = fr_pow<F>(su->w, N - 3 + j);
     H256 seedx = Fr::from32(S::ACC_X), seedy = Fr::from32(S::ACC_Y);
+    std::vector<int32_t> item_st(each_status ? n : 0, 0);
+    auto fail = [&](size_t it, int st) { if (each_status) item_st[it] = st; else status = st; };
     parallel_for(n, [&](size_t it) {
       const uint8_t *pr = proofs + plen * it;
       const uint32_t ring = ring_of_item ? ring_of_item[it] : 0;
@@ -1186,14 +1190,14 @@ template <class S, class G> struct Ring {
       const G1Aff *fx = &fixed[3 * ring];
       G1Aff C[4], Cq, pi1, pi2; H256 ev[7], lin_zw;
       size_t off = 0;
-      for (int i = 0; i < 4; i++) { if (!g1_decompress(pr + off, &C[i])) { status = AVRF_INVALID_DATA; return; } off += FQB; }
-      for (int i = 0; i < 7; i++) { H256 v = Fr::load_le(pr + off); if (Fr::geq_p(v)) { status = AVRF_INVALID_DATA; return; } ev[i] = Fr::to_mont(v); off += 32; }
-      if (!g1_decompress(pr + off, &Cq)) { status = AVRF_INVALID_DATA; return; } off += FQB;
-      { H256 v = Fr::load_le(pr + off); if (Fr::geq_p(v)) { status = AVRF_INVALID_DATA; return; } lin_zw = Fr::to_mont(v); off += 32; }
-      if (!g1_decompress(pr + off, &pi1)) { status = AVRF_INVALID_DATA; return; } off += FQB;
-      if (!g1_decompress(pr + off, &pi2)) { status = AVRF_INVALID_DATA; return; } off += FQB;
+      for (int i = 0; i < 4; i++) { if (!g1_decompress(pr + off, &C[i])) { fail(it, AVRF_INVALID_DATA); return; } off += FQB; }
+      for (int i = 0; i < 7; i++) { H256 v = Fr::load_le(pr + off); if (Fr::geq_p(v)) { fail(it, AVRF_INVALID_DATA); return; } ev[i] = Fr::to_mont(v); off += 32; }
+      if (!g1_decompress(pr + off, &Cq)) { fail(it, AVRF_INVALID_DATA); return; } off += FQB;
+      { H256 v = Fr::load_le(pr + off); if (Fr::geq_p(v)) { fail(it, AVRF_INVALID_DATA); return; } lin_zw = Fr::to_mont(v); off += 32; }
+      if (!g1_decompress(pr + off, &pi1)) { fail(it, AVRF_INVALID_DATA); return; } off += FQB;
+      if (!g1_decompress(pr + off, &pi2)) { fail(it, AVRF_INVALID_DATA); return; } off += FQB;
       H256 ix = Fr::load_le(instances_xy + 64 * it), iy = Fr::load_le(instances_xy + 64 * it + 32);
-      if (Fr::geq_p(ix) || Fr::geq_p(iy)) { status = AVRF_INVALID_DATA; return; }
+      if (Fr::geq_p(ix) || Fr::geq_p(iy)) { fail(it, AVRF_INVALID_DATA); return; }
       H256 ixm = Fr::to_mont(ix), iym = Fr::to_mont(iy);
       // transcript replay
       ArkTranscript t;
@@ -1213,7 +1217,7 @@ template <class S, class G> struct Ring {
       const H256 nl = Fr::sub(zeta, w_last), omb = Fr::sub(one, b);
       H256 zn = zeta; for (size_t k = 1; k < N; k <<= 1) zn = Fr::sqr(zn);
       const H256 zn1 = Fr::sub(zn, one);
-      if (Fr::is_zero(zn1)) { status = AVRF_VERIFICATION_FAILURE; return; }
+      if (Fr::is_zero(zn1)) { fail(it, AVRF_VERIFICATION_FAILURE); return; }
       auto lag = [&](size_t i) { H256 wi = fr_pow<F>(su->w, i); return Fr::mul(Fr::mul(Fr::mul(wi, zn1), ninv), Fr::inv(Fr::sub(zeta, wi))); };
       const H256 lf = lag(0), ll = lag(cap - 1);
       HostExt sd; sd.x = seedx; sd.y = seedy; sd.t = Fr::mul(seedx, seedy); sd.z = one;
@@ -1253,6 +1257,40 @@ template <class S, class G> struct Ring {
     });
     if (status != AVRF_OK) return status;
     lap("decode + transcripts (host)");
+    if (each_status) {
+      // 13 (base, scalar) pairs per item: its 10 terms of the first argument, the g1 term, its 2 terms of the second
+      const size_t e1 = 2 * FQB, TPI = 13;
+      std::vector<uint8_t> bb(n * TPI * e1); std::vector<H256> ss(n * TPI);
+      for (size_t it = 0; it < n; it++) {
+        memcpy(&bb[(it * TPI) * e1], &b1[(10 * it) * e1], 10 * e1);
+        for (int j = 0; j < 10; j++) ss[it * TPI + j] = s1[10 * it + j];
+        memcpy(&bb[(it * TPI + 10) * e1], su->g1_0.xy, e1); ss[it * TPI + 10] = Fr::from_mont(Fr::neg(gsc[it]));
+        memcpy(&bb[(it * TPI + 11) * e1], &b2[(2 * it) * e1], 2 * e1);
+        ss[it * TPI + 11] = s2[2 * it]; ss[it * TPI + 12] = s2[2 * it + 1];
+      }
+      ensure_pairing(su);
+      const size_t nb = n * TPI;
+      const size_t pb = (nb * e1 + 255) / 256 * 256, sb = (nb * 32 + 255) / 256 * 256, ob = (n * 2 * e1 + 255) / 256 * 256, kb = (n * 4 + 255) / 256 * 256;
+      uint8_t *base = (uint8_t *)dev_scratch(su, 1, 2 * pb + sb + ob + 2 * kb + 256);
+      uint8_t *d_xy = base; uint32_t *d_b = (uint32_t *)(base + pb), *d_s = (uint32_t *)(base + 2 * pb), *d_pts = (uint32_t *)(base + 2 * pb + sb);
+      int32_t *d_ok = (int32_t *)(base + 2 * pb + sb + ob), *d_rec = (int32_t *)(base + 2 * pb + sb + ob + kb);
+      uint32_t *d_flag = (uint32_t *)(base + 2 * pb + sb + ob + 2 * kb);
+      HIP_CHECK(hipMemcpyAsync(d_xy, bb.data(), nb * e1, hipMemcpyHostToDevice, su->stream));
+      HIP_CHECK(hipMemcpyAsync(d_s, ss.data(), nb * 32, hipMemcpyHostToDevice, su->stream));
+      HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream)); HIP_CHECK(hipMemsetAsync(d_rec, 0, n * 4, su->stream));
+      launch_g1_bases(su->suite, d_xy, nb, d_b, d_flag, su->stream);
+      launch_g1_subgroup_check(su->suite, d_b, nb, d_flag, su->stream, d_rec, (uint32_t)TPI);
+      launch_g1_lincomb(su->suite, d_b, d_s, n, (uint32_t)TPI, 11, d_pts, su->stream);
+      launch_pairing_check(su->ptab, d_pts, n, d_ok, su->stream);
+      std::vector<int32_t> okv(n), rec(n);
+      HIP_CHECK(hipMemcpyAsync(okv.data(), d_ok, n * 4, hipMemcpyDeviceToHost, su->stream));
+      HIP_CHECK(hipMemcpyAsync(rec.data(), d_rec, n * 4, hipMemcpyDeviceToHost, su->stream));
+      HIP_CHECK(hipStreamSynchronize(su->stream)); HIP_CHECK(hipGetLastError());
+      lap("per-item G1 sums + pairing checks (device)");
+      for (size_t it = 0; it < n; it++)
+        each_status[it] = item_st[it] ? item_st[it] : rec[it] ? AVRF_INVALID_DATA : okv[it] ? AVRF_OK : AVRF_VERIFICATION_FAILURE;
+      return AVRF_OK;
+    }
     H256 g1_scalar = {{0, 0, 0, 0}};
     for (size_t it = 0; it < n; it++) g1_scalar = Fr::sub(g1_scalar, gsc[it]);
     put(b1, s1, 10 * n, su->g1_0, g1_scalar);
@@ -1390,6 +1428,15 @@ int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const
   });
   for (auto &x : th) x.join();
   return status;
+}
+
+int avrf_ring_verify_each(avrf_ring_setup *su, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,
+                          const uint8_t *instances_xy, const uint8_t *ring_proofs, int32_t *status_out) {
+  if (!su || (n && (!ring_commitments || !n_rings || !instances_xy || !ring_proofs || !status_out))) return AVRF_ERR_BAD_ARG;
+  if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
+  return guarded([&] {
+    return su->suite == 0 ? RingB::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs, status_out)
+                          : RingJ::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs, status_out); });
 }
 
 int avrf_ring_pairing_check(avrf_ring_setup *su, size_t n, const uint8_t *a_xy, const uint8_t *b_xy, int32_t *ok_out) {

@@ -146,3 +146,15 @@ def pairing_check(setup, a_xy, b_xy):
     if st != nat.OK:
         raise nat.AvrfError(f"avrf_ring_pairing_check -> {st}")
     return list(out)[:n]
+
+
+def ring_verify_each(setup, ring_commitments, ring_of_item, instances_xy, ring_proofs):
+    """n x RingVerifier::verify with per-proof statuses (avrf_ring_verify_each): pairings on the device."""
+    n = len(ring_proofs)
+    roi = nat._u32(ring_of_item) if ring_of_item is not None else None
+    out = (C.c_int32 * max(1, n))()
+    st = nat.lib().avrf_ring_verify_each(setup._h, C.c_size_t(n), nat._u8(b"".join(ring_commitments)), C.c_size_t(len(ring_commitments)),
+                                         roi, nat._u8(b"".join(instances_xy)), nat._u8(b"".join(ring_proofs)), out)
+    if st != nat.OK:
+        raise nat.AvrfError(f"avrf_ring_verify_each -> {st}")
+    return list(out)[:n]

@@ -223,6 +223,14 @@ int avrf_ring_prove(avrf_ring_key *key, size_t n, const uint32_t *key_index, con
 int avrf_ring_batch_verify(avrf_ring_setup *setup, size_t n, const uint8_t *ring_commitments, size_t n_rings,
                            const uint32_t *ring_of_item, const uint8_t *instances_xy, const uint8_t *ring_proofs);
 
+/* n x ring::Verifier::verify (src/ring.rs:228-247, the ring half): the same inputs as avrf_ring_batch_verify, but every proof is
+ * checked on its own and gets its own status (status_out[i] = AVRF_OK / AVRF_VERIFICATION_FAILURE / AVRF_INVALID_DATA), so a
+ * bad proof is identified instead of failing the batch: per proof two small G1 linear combinations and one 2-pairing check,
+ * all on the device (Miller loops + final exponentiations of all proofs in one kernel, pairing.hip).  A ring commitment that
+ * does not decode fails the call (AVRF_INVALID_DATA). */
+int avrf_ring_verify_each(avrf_ring_setup *setup, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,
+                          const uint8_t *instances_xy, const uint8_t *ring_proofs, int32_t *status_out);
+
 /* The pairing half of the KZG verifier on the device (arkworks `Pairing::multi_pairing` + final exponentiation as reached
  * from RingVerifier::verify, src/ring.rs:242): for i < n,  ok_out[i] = 1 iff  e(A_i, g2) * e(B_i, tau g2) == 1  with (g2, tau g2)
  * the two `powers_in_g2` of the setup's SRS.  a_xy / b_xy: n G1 points each, canonical little-endian x || y (48+48 bytes

@@ -141,6 +141,35 @@ def test_ring_verify_reference_vectors(env, suite):
     assert ring_batch_verify(setup, [coms[0]], None, [insts[0]], [bytes(junk)]) in (1, 2)   # undecodable or wrong
 
 
+@pytest.mark.parametrize("suite", [0, 1])
+def test_ring_verify_each(env, suite):
+    """n x ring::Verifier::verify (src/ring.rs:228-247) with per-proof statuses: G1 sums and the 2-pairing checks of all proofs
+    on the device (avrf_ring_verify_each).  The reference's vectors verify; exactly the perturbed proofs are reported."""
+    from ark_vrf_amd.ring import ring_batch_verify, ring_verify_each
+    ctx, setup, vs, srs = env[suite]
+    coms = [bytes.fromhex(v["ring_pks_com"]) for v in vs]
+    insts = [xy(suite, bytes.fromhex(v["proof_pk_com"])) for v in vs]
+    proofs = [bytes.fromhex(v["ring_proof"]) for v in vs]
+    assert ring_verify_each(setup, coms, list(range(7)), insts, proofs) == [0] * 7
+    assert ring_verify_each(setup, [coms[3]], None, [insts[3]], [proofs[3]]) == [0]
+    assert ring_verify_each(setup, [], None, [], []) == []
+    fq = 48 if suite == 0 else 32
+    bad = list(proofs)
+    b2 = bytearray(bad[2]); b2[4 * fq + 5] ^= 1; bad[2] = bytes(b2)                       # an evaluation
+    b5 = bytearray(bad[5]); b5[4 * fq + 7 * 32 + fq + 31] = 0xff; bad[5] = bytes(b5)      # a scalar >= r: InvalidData
+    assert ring_verify_each(setup, coms, list(range(7)), insts, bad) == [0, 0, 1, 0, 0, 2, 0]
+    assert ring_batch_verify(setup, coms, list(range(7)), insts, bad) == 2                # the batch verifier only sees "something is wrong"
+    assert ring_verify_each(setup, coms, [0, 1, 2, 4, 3, 5, 6], insts, proofs) == [0, 0, 0, 1, 1, 0, 0]      # two proofs against the wrong ring
+    assert ring_verify_each(setup, coms, list(range(7)), insts[1:] + insts[:1], proofs) == [1] * 7
+    if suite == 0:                                                                        # off-subgroup commitment in one proof
+        s = R.SUITES[0]
+        x = 0x13c60d23238642ea126a1e48cc11d357c30d8b7628dbd25e63b229f1c4069545de11cc9dea959c212e9c82b1478c281d
+        y = 0x173eb497b4648ea412daae1e11fa194e01a1d4bf7376e7bad3ef138322e23c3c5114b8a96c915d51db072395e4ad9649
+        off = R.g1_encode(s, (x, y), True)
+        bad = list(proofs); bad[4] = off + bad[4][48:]
+        assert ring_verify_each(setup, coms, list(range(7)), insts, bad) == [0, 0, 0, 0, 2, 0, 0]
+
+
 def test_ring_verify_validates_g1_points(env):
     """Validate::Yes of the deserialised RingProof / RingCommitment points (ADVICE r1): a BLS12-381 G1 point ON the curve but
     OUTSIDE the prime-order subgroup (cofactor ~2^126) and a non-canonical encoding of infinity are InvalidData, not merely
