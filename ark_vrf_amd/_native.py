@@ -172,6 +172,20 @@ class Context:
             raise AvrfError(f"avrf_thin_verify -> {st}")
         return list(out)[: b.n]
 
+    def tiny_prove(self, b):
+        out = (C.c_uint8 * max(1, 48 * b.n))()
+        st = lib().avrf_tiny_prove(self._h, C.c_size_t(b.n), b.sks, b.pks_xy, b.ios_xy, b.io_counts, b.ads, b.ad_lens, out)
+        if st != OK:
+            raise AvrfError(f"avrf_tiny_prove -> {st}")
+        return bytes(out)[: 48 * b.n]
+
+    def tiny_verify(self, b):
+        out = (C.c_int32 * max(1, b.n))()
+        st = lib().avrf_tiny_verify(self._h, C.c_size_t(b.n), b.pks_xy, b.ios_xy, b.io_counts, b.ads, b.ad_lens, b.proofs, out)
+        if st != OK:
+            raise AvrfError(f"avrf_tiny_verify -> {st}")
+        return list(out)[: b.n]
+
     def pedersen_prove(self, b):
         out, bl = (C.c_uint8 * max(1, 256 * b.n))(), (C.c_uint8 * max(1, 32 * b.n))()
         st = lib().avrf_pedersen_prove(self._h, C.c_size_t(b.n), b.sks, b.pks_xy, b.ios_xy, b.io_counts, b.ads, b.ad_lens, out, bl)

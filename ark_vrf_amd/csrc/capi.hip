@@ -104,9 +104,9 @@ static void validate_staged(avrf_ctx *c, int kind, int32_t *d_rec_status) {
   if (c->validate <= 0 || !c->n) return;
   uint32_t *fl = c->d_flags.as<uint32_t>();
   const uint32_t n = (uint32_t)c->n;
-  if (kind == 1 && c->d_pks.p) launch_validate_xy(c->suite, c->d_pks.as<uint8_t>(), 64, 1, n, c->validate, fl, d_rec_status, c->stream);
+  if (kind != 2 && c->d_pks.p) launch_validate_xy(c->suite, c->d_pks.as<uint8_t>(), 64, 1, n, c->validate, fl, d_rec_status, c->stream);
   if (kind == 1) launch_validate_xy(c->suite, c->d_proofs.as<uint8_t>(), 96, 1, n, c->validate, fl, d_rec_status, c->stream);
-  else launch_validate_xy(c->suite, c->d_proofs.as<uint8_t>(), 256, 3, n, c->validate, fl, d_rec_status, c->stream);
+  else if (kind == 2) launch_validate_xy(c->suite, c->d_proofs.as<uint8_t>(), 256, 3, n, c->validate, fl, d_rec_status, c->stream);
   if (c->tot_io) {
     if (!d_rec_status) launch_validate_xy(c->suite, c->d_ios.as<uint8_t>(), 128, 2, (uint32_t)c->tot_io, c->validate, fl, nullptr, c->stream);
     else {   // per-item status: the I/O pairs of item j are records io_off[j] .. io_off[j+1]; uniform M = 1 is the common case
@@ -252,11 +252,12 @@ static int stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint
   HIP_TRY(hipMemcpyAsync(c->d_ad_off.p, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
   if (a) HIP_TRY(hipMemcpyAsync(c->d_ios.p, ios_xy, a * 128, hipMemcpyHostToDevice, c->stream));
   if (b) HIP_TRY(hipMemcpyAsync(c->d_ads.p, ads, b, hipMemcpyHostToDevice, c->stream));
-  const size_t psz = kind == 1 ? 96 : 256;
+  const size_t psz = kind == 1 ? 96 : kind == 3 ? 48 : 256;
   if (pks_xy) { HIP_TRY(c->d_pks.ensure(n * 64)); HIP_TRY(hipMemcpyAsync(c->d_pks.p, pks_xy, n * 64, hipMemcpyHostToDevice, c->stream)); }
   if (sks) { HIP_TRY(c->d_sks.ensure(n * 32)); HIP_TRY(hipMemcpyAsync(c->d_sks.p, sks, n * 32, hipMemcpyHostToDevice, c->stream)); }
   if (proofs) {
     HIP_TRY(c->d_proofs.ensure(n * psz)); HIP_TRY(hipMemcpyAsync(c->d_proofs.p, proofs, n * psz, hipMemcpyHostToDevice, c->stream));
+    if (kind == 3) { HIP_TRY(hipStreamSynchronize(c->stream)); c->staged_kind = kind; return AVRF_OK; }   // Tiny: no batch verifier
     const size_t rsz = kind == 1 ? 32 : 64, roff = kind == 1 ? 64 : 192;
     c->h_resp.resize(n * rsz);
     for (size_t j = 0; j < n; j++) memcpy(&c->h_resp[rsz * j], proofs + psz * j + roff, rsz);
@@ -513,6 +514,37 @@ int avrf_thin_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t
   HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
   c->timing[0] = now_us() - t0;
+  return AVRF_OK;
+}
+
+// tiny::Prover::prove / tiny::Verifier::verify (src/tiny.rs:163-214) for batches of independent items
+int avrf_tiny_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
+                    const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out) {
+  if (n && (!sks || !proofs_out)) return AVRF_ERR_BAD_ARG;
+  int st = stage(c, 3, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, nullptr);
+  if (st || !n) return st;
+  c->staged_kind = 0;
+  BatchDev b = batch_of(c); if (!pks_xy) b.pks_xy = nullptr;
+  HIP_TRY(c->d_out.ensure(n * 48));
+  HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  launch_thin_prove(c->suite, b, c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream, true);
+  HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, n * 48, hipMemcpyDeviceToHost, c->stream));
+  int f = read_flags(c);
+  if (f < 0) return AVRF_ERR_NO_DEVICE;
+  return f ? AVRF_INVALID_DATA : AVRF_OK;
+}
+int avrf_tiny_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
+                     const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, int32_t *status_out) {
+  if (n && (!pks_xy || !proofs || !status_out)) return AVRF_ERR_BAD_ARG;
+  int st = stage(c, 3, n, nullptr, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs);
+  if (st || !n) return st;
+  HIP_TRY(c->d_status.ensure(n * 4));
+  HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  launch_tiny_verify(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream);
+  validate_staged(c, 3, c->d_status.as<int32_t>());
+  HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
+  c->staged_kind = 0;
   return AVRF_OK;
 }
 

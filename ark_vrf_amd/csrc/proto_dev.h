@@ -28,7 +28,7 @@
 namespace avrf {
 
 enum : uint8_t {
-  DS_THIN = 0x01, DS_PEDERSEN = 0x02, DS_NONCE_EXPAND = 0x10, DS_NONCE = 0x11, DS_PEDERSEN_BLINDING = 0x12,
+  DS_TINY = 0x00, DS_THIN = 0x01, DS_PEDERSEN = 0x02, DS_NONCE_EXPAND = 0x10, DS_NONCE = 0x11, DS_PEDERSEN_BLINDING = 0x12,
   DS_POINT_TO_HASH = 0x20, DS_DELINEARIZE = 0x30, DS_CHALLENGE = 0x40, DS_BATCH_VERIFY = 0x50
 };
 enum { FLAG_RANGE = 1, FLAG_IDENTITY = 2, FLAG_SCALAR = 4, FLAG_CURVE = 8 };

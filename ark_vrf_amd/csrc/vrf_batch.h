@@ -29,7 +29,8 @@ void launch_ped_terms(int suite, const BatchDev &b, const Seed64 &seed, uint64_t
 void launch_fixed_table(int suite, te_pre_raw *d_tab, hipStream_t st);
 void launch_smul(int suite, const uint8_t *d_scalars, const uint8_t *d_points_xy, uint32_t n, uint8_t *d_out, uint32_t *d_flags,
                  const te_pre_raw *d_fixed, hipStream_t st);
-void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st);
+void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny = false);
+void launch_tiny_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);   // proofs: n x 48 (c16 || s32)
 void launch_thin_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
 void launch_ped_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st);
 void launch_ped_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);

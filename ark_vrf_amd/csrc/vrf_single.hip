@@ -82,7 +82,9 @@ k_smul(const uint8_t *__restrict__ scalars, const uint8_t *__restrict__ points_x
 
 // ---------------------------------------------------------------- Thin VRF
 
-template <class S>
+// TINY: tiny::Prover::prove (src/tiny.rs:163-176) -- the same steps under scheme tag 0x00; the proof keeps the challenge
+// instead of the nonce commitment: LE16(c) || LE32(s), 48 bytes (src/tiny.rs:60-78)
+template <class S, bool TINY>
 __global__ void __launch_bounds__(128)
 k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict__ flags) {
   using Fr = typename S::Fr;
@@ -97,7 +99,7 @@ k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict_
   if (b.pks_xy) { for (int i = 0; i < 64; i++) pk_xy[i] = b.pks_xy[64 * (size_t)j + i]; }
   else { te_aff pk = te_to_aff<S>(te_smul<S>(g_pre<S>(), sk, Fr::BITS)); store_xy<S>(pk_xy, pk); }
   Sha512 t; uint32_t pf = 0;
-  tr_base<S>(t, DS_THIN, true, pk_xy, ios, m, b.ads + ad0, adl, &pf);          // thin.rs:112
+  tr_base<S>(t, TINY ? DS_TINY : DS_THIN, true, pk_xy, ios, m, b.ads + ad0, adl, &pf);   // thin.rs:112, tiny.rs:164
   f |= pf & FLAG_RANGE;
   // merged input I_m = G + sum z_i I_i  (only the input is needed by the prover)
   te_pre im_pre = g_pre<S>();
@@ -116,9 +118,46 @@ k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict_
   Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);    // thin.rs:122
   fp c = fp_to_mont<Fr>(challenge_finish(tc));
   fp s = fp_add<Fr>(k, fp_mul<Fr>(c, fp_to_mont<Fr>(sk)));                      // thin.rs:125
-  store_xy<S>(proofs_out + 96 * (size_t)j, r);
-  fp_store_le(proofs_out + 96 * (size_t)j + 64, fp_from_mont<Fr>(s));
+  if (TINY) {
+    const fp cp = fp_from_mont<Fr>(c);
+    uint8_t *o = proofs_out + 48 * (size_t)j;
+    for (int i = 0; i < 4; i++) for (int bb = 0; bb < 4; bb++) o[4 * i + bb] = (uint8_t)(cp.v[i] >> (8 * bb));
+    fp_store_le(o + 16, fp_from_mont<Fr>(s));
+  } else {
+    store_xy<S>(proofs_out + 96 * (size_t)j, r);
+    fp_store_le(proofs_out + 96 * (size_t)j + 64, fp_from_mont<Fr>(s));
+  }
   if (f) atomicOr(flags, f);
+}
+
+// tiny::Verifier::verify (src/tiny.rs:178-214): R = s I_m - c O_m, recompute the challenge, compare with c
+template <class S>
+__global__ void __launch_bounds__(128)
+k_tiny_verify(BatchDev b, int32_t *__restrict__ status) {
+  using Fr = typename S::Fr;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b.n) return;
+  uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pk_xy = b.pks_xy + 64 * (size_t)j, *pr = b.proofs + 48 * (size_t)j;
+  Sha512 t; uint32_t f = 0;
+  tr_base<S>(t, DS_TINY, true, pk_xy, ios, m, b.ads + ad0, adl, &f);
+  fp c = fp_zero();
+  for (int i = 0; i < 4; i++) c.v[i] = (uint32_t)pr[4 * i] | ((uint32_t)pr[4 * i + 1] << 8) | ((uint32_t)pr[4 * i + 2] << 16) | ((uint32_t)pr[4 * i + 3] << 24);
+  fp s = fp_load_le(pr + 16);
+  if (ge_p<Fr>(s)) f |= FLAG_SCALAR;
+  if (f) { status[j] = 2; return; }                                             // InvalidData, tiny.rs:186-198
+  te_pre ip = g_pre<S>(), op = pre_from_xy<S>(pk_xy);
+  if (m) {
+    uint64_t dseed[8]; delin_seed(t, dseed);
+    te_ext im = te_from_pre<S>(ip), om = te_from_pre<S>(op);
+    merge_pairs<S>(ios, m, dseed, false, im, om);
+    te_aff ia, oa; to_aff2<S>(im, om, ia, oa);
+    ip = pre_from_aff<S>(ia); op = pre_from_aff<S>(oa);
+  }
+  te_aff r = te_to_aff<S>(te_smul2<S>(ip, s, te_pre_neg<S>(op), c, Fr::BITS));  // tiny.rs:207
+  Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);
+  const fp c_exp = challenge_finish(tc);                                        // plain, 128 bits
+  status[j] = fp_eq(c_exp, c) ? 0 : 1;
 }
 
 template <class S>
@@ -437,9 +476,17 @@ void launch_smul(int suite, const uint8_t *d_scalars, const uint8_t *d_points_xy
   if (!n) return;
   AVRF_DISPATCH(suite, k_smul, dim3((n + 127) / 128), dim3(128), st, d_scalars, d_points_xy, n, d_out, d_flags, (const te_pre *)d_fixed);
 }
-void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st) {
+void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny) {
   if (!b.n) return;
-  AVRF_DISPATCH(suite, k_thin_prove, dim3((b.n + 127) / 128), dim3(128), st, b, d_proofs_out, d_flags);
+  const dim3 g((b.n + 127) / 128), bl(128);
+  if (suite == 0) { if (tiny) hipLaunchKernelGGL((k_thin_prove<SuiteBandersnatch, true>), g, bl, 0, st, b, d_proofs_out, d_flags);
+                    else hipLaunchKernelGGL((k_thin_prove<SuiteBandersnatch, false>), g, bl, 0, st, b, d_proofs_out, d_flags); }
+  else { if (tiny) hipLaunchKernelGGL((k_thin_prove<SuiteBabyJubJub, true>), g, bl, 0, st, b, d_proofs_out, d_flags);
+         else hipLaunchKernelGGL((k_thin_prove<SuiteBabyJubJub, false>), g, bl, 0, st, b, d_proofs_out, d_flags); }
+}
+void launch_tiny_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st) {
+  if (!b.n) return;
+  AVRF_DISPATCH(suite, k_tiny_verify, dim3((b.n + 127) / 128), dim3(128), st, b, d_status);
 }
 void launch_thin_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st) {
   if (!b.n) return;

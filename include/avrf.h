@@ -142,6 +142,15 @@ int avrf_thin_prove(avrf_ctx *ctx, size_t n, const uint8_t *sks, const uint8_t *
 int avrf_thin_verify(avrf_ctx *ctx, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
                      const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, int32_t *status_out);
 
+/* tiny::Prover::prove / tiny::Verifier::verify (src/tiny.rs:163-214) for batches of independent items: the Thin construction
+ * under scheme tag 0x00 with the challenge kept in the proof, proof = LE16(c) || LE32(s) = 48 bytes (Proof's compressed
+ * serialisation, src/tiny.rs:60-78).  No batch verifier exists for this scheme (src/tiny.rs:1-6).  Arguments as for
+ * avrf_thin_prove / avrf_thin_verify; proofs(_out): n x 48. */
+int avrf_tiny_prove(avrf_ctx *ctx, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy,
+                    const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out);
+int avrf_tiny_verify(avrf_ctx *ctx, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
+                     const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, int32_t *status_out);
+
 /* pedersen::BatchVerifier::{new, push*, verify} (src/pedersen.rs:303-426).
  * proofs: Yb_xy(64) || R_xy(64) || Ok_xy(64) || s(32) || sb(32) = 256 bytes per item. */
 int avrf_pedersen_batch_verify(avrf_ctx *ctx, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,

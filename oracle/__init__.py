@@ -99,6 +99,20 @@ def thin_verify(suite, pk, ios, ad, proof):
     return lib().orc_thin_verify(suite, _u8(pk), _u8(iob), C.c_size_t(len(ios)), _u8(ad), C.c_size_t(len(ad)), _u8(proof))
 
 
+def tiny_prove(suite, sk, ios, ad):
+    """tiny::Prover::prove (src/tiny.rs:163-176): 48-byte proof LE16(c) || LE32(s)."""
+    iob = b"".join(i + o for i, o in ios)
+    proof = _buf(48)
+    st = lib().orc_tiny_prove(suite, _u8(sk), _u8(iob), C.c_size_t(len(ios)), _u8(ad), C.c_size_t(len(ad)), proof)
+    assert st == 0, st
+    return _b(proof)
+
+
+def tiny_verify(suite, pk, ios, ad, proof):
+    iob = b"".join(i + o for i, o in ios)
+    return lib().orc_tiny_verify(suite, _u8(pk), _u8(iob), C.c_size_t(len(ios)), _u8(ad), C.c_size_t(len(ad)), _u8(proof))
+
+
 def _batch_args(items_ios, ads):
     iob = b"".join(i + o for ios in items_ios for i, o in ios)
     counts = [len(ios) for ios in items_ios]

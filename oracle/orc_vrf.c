@@ -314,6 +314,48 @@ int orc_thin_verify(int suite, const uint8_t pk_b[32], const uint8_t *ios_b, siz
     free(ch); free(ios); return ok ? ORC_OK : ORC_VERIFICATION_FAILURE;
 }
 
+/* ------------------------------------------------------------------ Tiny VRF (src/tiny.rs)
+ * proof = LE16(c) || LE32(s)  (CHALLENGE_LEN = 16, Proof::serialize_with_mode src/tiny.rs:60-78) */
+
+/* src/tiny.rs:163-176 */
+int orc_tiny_prove(int suite, const uint8_t sk_b[32], const uint8_t *ios_b, size_t n_ios,
+                   const uint8_t *ad, size_t ad_len, uint8_t proof[48]) {
+    const suite_t *s = orc_suite(suite); if (!s) return -1;
+    u256 sk; if (decode_scalar(&sk, sk_b, s)) return ORC_INVALID_DATA;
+    vrf_io *ios = (vrf_io *)malloc((n_ios + 1) * sizeof(vrf_io));
+    if (decode_ios(ios, ios_b, n_ios, s)) { free(ios); return ORC_INVALID_DATA; }
+    te_ext P; smul_mont(&P, &s->G, &sk, s); te_aff pk; te_to_aff(&pk, &P, s);
+    vrf_io *ch = chain_schnorr(&pk, ios, n_ios, s);
+    transcript_t t; vrf_io m; transcript_merged(&t, &m, DS_TINY, ch, n_ios + 1, ad, ad_len, s);
+    u256 k, c, sres; nonce(&k, &sk, t, s);
+    te_ext R; smul_mont(&R, &m.in, &k, s); te_aff r; te_to_aff(&r, &R, s);
+    const te_aff *pts[1] = {&r}; challenge(&c, pts, 1, t, s);
+    mont_mul(&sres, &c, &sk, FR); mont_add(&sres, &sres, &k, FR);
+    uint8_t cb[32]; encode_scalar(cb, &c, s); memcpy(proof, cb, 16);       /* c < 2^128: its first 16 bytes */
+    encode_scalar(proof + 16, &sres, s);
+    free(ch); free(ios); return ORC_OK;
+}
+
+/* src/tiny.rs:178-214 */
+int orc_tiny_verify(int suite, const uint8_t pk_b[32], const uint8_t *ios_b, size_t n_ios,
+                    const uint8_t *ad, size_t ad_len, const uint8_t proof[48]) {
+    const suite_t *s = orc_suite(suite); if (!s) return -1;
+    te_aff pk; u256 sres, c, c_exp, negc;
+    vrf_io *ios = (vrf_io *)malloc((n_ios + 1) * sizeof(vrf_io));
+    uint8_t cb[32]; memset(cb, 0, 32); memcpy(cb, proof, 16);              /* from_le_bytes_mod_order of 16 bytes */
+    if (te_decode(&pk, pk_b, s) || decode_ios(ios, ios_b, n_ios, s) || decode_scalar(&c, cb, s) ||
+        decode_scalar(&sres, proof + 16, s)) { free(ios); return ORC_INVALID_DATA; }
+    if (te_is_identity_aff(&pk, s) || io_has_identity(ios, n_ios, s)) { free(ios); return ORC_INVALID_DATA; }
+    vrf_io *ch = chain_schnorr(&pk, ios, n_ios, s);
+    transcript_t t; vrf_io m; transcript_merged(&t, &m, DS_TINY, ch, n_ios + 1, ad, ad_len, s);
+    mont_neg(&negc, &c, FR);                                               /* R = s I_m - c O_m  (short_msm, :207) */
+    te_aff P2[2] = {m.in, m.out}; u256 S2[2]; mont_from(&S2[0], &sres, FR); mont_from(&S2[1], &negc, FR);
+    te_ext R; orc_straus(&R, P2, S2, 2, 2, s); te_aff r; te_to_aff(&r, &R, s);
+    const te_aff *pts[1] = {&r}; challenge(&c_exp, pts, 1, t, s);
+    int ok = u256_cmp(&c_exp, &c) == 0;
+    free(ch); free(ios); return ok ? ORC_OK : ORC_VERIFICATION_FAILURE;
+}
+
 /* src/thin.rs:209-226 + :257-318: builds the (sum(2+2M_j)+1)-term MSM of the batch.
  * bases_xy: n_terms x 64 (LE32 x || LE32 y), scalars: n_terms x 32.  Returns status;
  * when status == ORC_OK the terms are valid.  n_terms_out may be NULL. */

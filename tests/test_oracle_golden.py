@@ -107,3 +107,22 @@ def test_suite_constants(golden_dir, name):
     assert orc.hash_to_curve(s, b"pedersen-blinding") == orc.suite_point(s, 1)
     assert orc.hash_to_curve(s, b"ring-accumulator") == orc.suite_point(s, 2)
     assert orc.hash_to_curve(s, b"ring-padding") == orc.suite_point(s, 3)
+
+
+@pytest.mark.parametrize("name", ["bandersnatch_sha-512_ell2", "baby-jubjub_sha-512_tai"])
+def test_tiny_vectors(golden_dir, name):
+    """Tiny VRF (src/tiny.rs:163-214): proof_c / proof_s of the reference's `*_tiny.json`, prove and verify."""
+    import json, os
+    s = SUITES[name] if "SUITES" in globals() else (0 if name.startswith("bander") else 1)
+    vs = json.load(open(os.path.join(golden_dir, name + "_tiny.json")))
+    assert len(vs) == 7
+    for v in vs:
+        sk, pk = bytes.fromhex(v["sk"]), bytes.fromhex(v["pk"])
+        io = [(bytes.fromhex(v["h"]), bytes.fromhex(v["gamma"]))]
+        ad = bytes.fromhex(v["ad"])
+        proof = orc.tiny_prove(s, sk, io, ad)
+        assert proof.hex() == v["proof_c"] + v["proof_s"]
+        assert orc.tiny_verify(s, pk, io, ad, proof) == orc.OK
+        bad = bytearray(proof); bad[17] ^= 1
+        assert orc.tiny_verify(s, pk, io, ad, bytes(bad)) == orc.VERIFICATION_FAILURE
+        assert orc.tiny_verify(s, pk, io, ad + b"x", proof) == orc.VERIFICATION_FAILURE
