@@ -246,6 +246,74 @@ template <class C> struct HostPairing {
     }
   }
 
+  // ---- compressed G2 encodings (ark-serialize `serialize_compressed` of a URS / RingSetup, src/ring.rs:484-521)
+  static F2 f2_pow(const F2 &x, const El &e) {                       // e: plain integer
+    F2 r = f2_one();
+    for (int i = 64 * Fp::L - 1; i >= 0; i--) { r = f2_sqr(r); if ((e.l[i / 64] >> (i % 64)) & 1) r = f2_mul(r, x); }
+    return r;
+  }
+  // square root in Fp2 for p = 3 mod 4 (Adj, Rodriguez-Henriquez, "Square root computation over even extension fields", Alg. 9)
+  static bool f2_sqrt(const F2 &a, F2 *out) {
+    if (f2_is_zero(a)) { *out = a; return true; }
+    El pm3_4 = Fp::P(), pm1_2 = Fp::P(), three = Fp::zero(), onei = Fp::zero(); three.l[0] = 3; onei.l[0] = 1;
+    Fp::subb(pm3_4, pm3_4, three); Fp::subb(pm1_2, pm1_2, onei);
+    for (int k = 0; k < 2; k++) for (int i = 0; i < Fp::L; i++) pm3_4.l[i] = (pm3_4.l[i] >> 1) | (i + 1 < Fp::L ? pm3_4.l[i + 1] << 63 : 0);
+    for (int i = 0; i < Fp::L; i++) pm1_2.l[i] = (pm1_2.l[i] >> 1) | (i + 1 < Fp::L ? pm1_2.l[i + 1] << 63 : 0);
+    const F2 a1 = f2_pow(a, pm3_4), x0 = f2_mul(a1, a), alpha = f2_mul(a1, x0);
+    F2 x;
+    if (f2_eq(alpha, f2_neg(f2_one()))) x = f2(Fp::neg(x0.b), x0.a);                            // u * x0
+    else x = f2_mul(f2_pow(f2_add(f2_one(), alpha), pm1_2), x0);
+    if (!f2_eq(f2_sqr(x), a)) return false;
+    *out = x; return true;
+  }
+  static F2 twist_b() {                                              // y^2 = x^3 + b': b' = b xi (M-twist) or b / xi (D-twist)
+    const F2 xi = f2(small(C::XI0), Fp::one()), b = f2(Fp::from32(C::B), Fp::zero());
+    return C::MTWIST ? f2_mul(b, xi) : f2_mul(b, f2_inv(xi));
+  }
+  // "y is the lexicographically largest of {y, -y}" with Fp2 ordered by (c1, c0) (ark-ff QuadExtField Ord; zcash encoding)
+  static bool f2_is_largest(const F2 &y) {
+    El half = Fp::from32(C::Fq::HALF), t;
+    El b = Fp::from_mont(y.b), a = Fp::from_mont(y.a);
+    return Fp::subb(t, half, Fp::is_zero(b) ? a : b) != 0;
+  }
+  static void g2_encode_compressed(const G2 &p, uint8_t *b) {
+    constexpr int B = 8 * Fp::L;
+    memset(b, 0, 2 * B);
+    if (B == 48) {
+      if (p.inf) { b[0] = 0xC0; return; }
+      El v[2] = {Fp::from_mont(p.x.b), Fp::from_mont(p.x.a)};
+      for (int k = 0; k < 2; k++) { uint8_t le[48]; memcpy(le, v[k].l, B); for (int i = 0; i < B; i++) b[k * B + i] = le[B - 1 - i]; }
+      b[0] |= 0x80; if (f2_is_largest(p.y)) b[0] |= 0x20;
+    } else {
+      if (p.inf) { b[2 * B - 1] = 0x40; return; }
+      El v[2] = {Fp::from_mont(p.x.a), Fp::from_mont(p.x.b)};
+      for (int k = 0; k < 2; k++) memcpy(b + k * B, v[k].l, B);
+      if (f2_is_largest(p.y)) b[2 * B - 1] |= 0x80;
+    }
+  }
+  static bool g2_decode_compressed(const uint8_t *b, G2 *out) {
+    constexpr int B = 8 * Fp::L;
+    El v[2]; bool big, inf;
+    if (B == 48) {
+      if (!(b[0] & 0x80)) return false;
+      inf = b[0] & 0x40; big = b[0] & 0x20;
+      for (int k = 0; k < 2; k++) { uint8_t le[48]; for (int i = 0; i < B; i++) le[i] = b[k * B + B - 1 - i]; if (k == 0) le[B - 1] &= 0x1f; memcpy(v[k].l, le, B); }
+      { El t = v[0]; v[0] = v[1]; v[1] = t; }                        // -> (c0, c1)
+    } else {
+      inf = b[2 * B - 1] & 0x40; big = b[2 * B - 1] & 0x80;
+      for (int k = 0; k < 2; k++) { uint8_t le[32]; memcpy(le, b + k * B, B); if (k == 1) le[B - 1] &= 0x3f; memcpy(v[k].l, le, B); }
+    }
+    out->inf = inf;
+    if (inf) { out->x = f2_zero(); out->y = f2_zero(); return !big && Fp::is_zero(v[0]) && Fp::is_zero(v[1]); }
+    { El t; if (Fp::subb(t, v[0], Fp::P()) == 0 || Fp::subb(t, v[1], Fp::P()) == 0) return false; }   // coordinate >= p
+    out->x = f2(Fp::to_mont(v[0]), Fp::to_mont(v[1]));
+    F2 y;
+    if (!f2_sqrt(f2_add(f2_mul(f2_sqr(out->x), out->x), twist_b()), &y)) return false;
+    if (f2_is_largest(y) != big) y = f2_neg(y);
+    out->y = y;
+    return true;
+  }
+
   // G2 from the `powers_in_g2` bytes of an arkworks URS file
   static bool g2_decode(const uint8_t *b, G2 *out) {
     constexpr int B = 8 * Fp::L;

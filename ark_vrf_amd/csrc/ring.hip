@@ -467,6 +467,8 @@ struct avrf_ring_setup {
   uint32_t *d_wit_table = nullptr;                    // same over [L_i(tau) G, i < N | prefix sums PS_k = sum_{i<k} L_i(tau) G, k <= N] (witness commits)
   G1Aff g1_0;                                         // powers_in_g1[0]
   std::vector<uint8_t> g2_raw;                        // powers_in_g2[0..2] exactly as in the SRS file
+  std::vector<uint8_t> g1_raw;                        // the n_srs powers_in_g1 this setup keeps, serialize_uncompressed encoding
+  std::vector<uint8_t> lag_raw;                       // L_i(tau) G, i < N (RingBuilderPcsParams), same encoding; filled by ensure_lagrange
   H256 w, w4;                                         // domain generators (Montgomery)
   uint32_t *d_tw_n = nullptr, *d_tw_n_inv = nullptr, *d_tw_4n = nullptr, *d_tw_4n_inv = nullptr;
   H256 ninv, n4inv;
@@ -581,6 +583,30 @@ template <class S, class G> struct Ring {
     if (len < 8) return AVRF_INVALID_DATA;
     uint64_t cnt; memcpy(&cnt, srs, 8);
     const size_t e1 = 2 * FQB, e2 = 4 * FQB;
+    // serialize_compressed form of the same object (RingSetup / PcsParams, src/ring.rs:484-521): decompress on the host pool
+    // and continue with the equivalent uncompressed bytes
+    std::vector<uint8_t> unc;
+    if (cnt <= (len - 8) / FQB && len >= 8 + cnt * FQB + 8) {
+      uint64_t c2; memcpy(&c2, srs + 8 + cnt * FQB, 8);
+      if (len == 8 + cnt * FQB + 8 + c2 * 2 * FQB && len != 8 + cnt * e1 + 8 + c2 * e2) {
+        if (cnt < pcs || c2 < 2) return AVRF_RING_CAPACITY_EXCEEDED;
+        using HP = HostPairing<G>;
+        std::vector<G1Aff> pts(pcs);
+        std::atomic<int> bad{0};
+        parallel_for(pcs, [&](size_t i) { if (!g1_decompress(srs + 8 + i * FQB, &pts[i])) bad = 1; });
+        if (bad) return AVRF_INVALID_DATA;
+        unc.resize(8);
+        { uint64_t v = pcs; memcpy(unc.data(), &v, 8); }
+        for (size_t i = 0; i < pcs; i++) g1_encode<G>(pts[i], false, unc);
+        { uint64_t v = 2; size_t o = unc.size(); unc.resize(o + 8); memcpy(&unc[o], &v, 8); }
+        for (int i = 0; i < 2; i++) {
+          typename HP::G2 q;
+          if (!HP::g2_decode_compressed(srs + 8 + cnt * FQB + 8 + (size_t)i * 2 * FQB, &q)) return AVRF_INVALID_DATA;
+          size_t o = unc.size(); unc.resize(o + e2); HP::g2_encode(q, &unc[o]);
+        }
+        srs = unc.data(); len = unc.size(); memcpy(&cnt, srs, 8);
+      }
+    }
     if (len < 8 + cnt * e1 + 8) return AVRF_INVALID_DATA;
     uint64_t cnt2; memcpy(&cnt2, srs + 8 + cnt * e1, 8);
     if (len != 8 + cnt * e1 + 8 + cnt2 * e2) return AVRF_INVALID_DATA;
@@ -596,6 +622,7 @@ template <class S, class G> struct Ring {
     }
     memcpy(su->g1_0.xy, le.data(), e1); su->g1_0.inf = false;
     su->g2_raw.assign(srs + 8 + cnt * e1 + 8, srs + 8 + cnt * e1 + 8 + 2 * e2);
+    su->g1_raw.assign(srs + 8, srs + 8 + pcs * e1);
     HIP_CHECK(hipSetDevice(su->device));
     uint8_t *d_le; uint32_t *d_flag; uint32_t flag = 0;
     HIP_CHECK(hipMalloc(&d_le, le.size())); HIP_CHECK(hipMalloc(&d_flag, 4)); HIP_CHECK(hipMalloc(&su->d_srs, pcs * e1));
@@ -834,6 +861,8 @@ template <class S, class G> struct Ring {
       std::vector<G1Aff> part; commit_device(su, d_mat, N, N, rows, part);
       lag.insert(lag.end(), part.begin(), part.end());
     }
+    su->lag_raw.clear();
+    for (size_t i = 0; i < N; i++) g1_encode<G>(lag[i], false, su->lag_raw);
     using HG = typename T::HG; using FqN = typename T::FqN;
     std::vector<typename HG::Pt> ps(N + 1);
     ps[0] = HG::identity();
@@ -1117,6 +1146,36 @@ template <class S, class G> struct Ring {
     if (bad_points) { uint32_t f = 0; HIP_CHECK(hipMemcpy(&f, d_flag, 4, hipMemcpyDeviceToHost)); *bad_points = f != 0; }
     r.inf = true; for (int i = 0; i < 2 * FQB; i++) if (r.xy[i]) r.inf = false;
     return r;
+  }
+
+  // ---- CanonicalSerialize of the setup objects (src/ring.rs:484-542): RingSetup = its PcsParams (URS { powers_in_g1,
+  // powers_in_g2 }), RingBuilderPcsParams = Vec<G1Affine> (the SRS in Lagrangian form); both in either ark-serialize mode
+  static G1Aff g1_from_raw(const uint8_t *p) {                         // one serialize_uncompressed G1 entry
+    G1Aff a; memset(&a, 0, sizeof a);
+    if (FQB == 48) { a.inf = p[0] & 0x40; if (!a.inf) for (int k = 0; k < FQB; k++) { a.xy[k] = p[FQB - 1 - k]; a.xy[FQB + k] = p[2 * FQB - 1 - k]; } }
+    else { a.inf = p[2 * FQB - 1] & 0x40; if (!a.inf) { memcpy(a.xy, p, 2 * FQB); a.xy[2 * FQB - 1] &= 0x3f; } }
+    return a;
+  }
+  static void put_points(const std::vector<uint8_t> &raw, size_t n, bool compress, std::vector<uint8_t> &o) {
+    { uint64_t v = n; size_t at = o.size(); o.resize(at + 8); memcpy(&o[at], &v, 8); }
+    if (!compress) { o.insert(o.end(), raw.begin(), raw.begin() + n * 2 * FQB); return; }
+    for (size_t i = 0; i < n; i++) g1_encode<G>(g1_from_raw(&raw[i * 2 * FQB]), true, o);
+  }
+  static int setup_serialize(avrf_ring_setup *su, bool compress, std::vector<uint8_t> &o) {
+    using HP = HostPairing<G>;
+    put_points(su->g1_raw, su->n_srs, compress, o);
+    { uint64_t v = 2; size_t at = o.size(); o.resize(at + 8); memcpy(&o[at], &v, 8); }
+    if (!compress) { o.insert(o.end(), su->g2_raw.begin(), su->g2_raw.end()); return AVRF_OK; }
+    for (int i = 0; i < 2; i++) {
+      typename HP::G2 q; HP::g2_decode(su->g2_raw.data() + (size_t)i * 4 * FQB, &q);
+      size_t at = o.size(); o.resize(at + 2 * FQB); HP::g2_encode_compressed(q, &o[at]);
+    }
+    return AVRF_OK;
+  }
+  static int builder_params_serialize(avrf_ring_setup *su, bool compress, std::vector<uint8_t> &o) {
+    ensure_lagrange(su);
+    put_points(su->lag_raw, su->N, compress, o);
+    return AVRF_OK;
   }
 
   // ---- n independent KZG pairing checks on the device: ok[i] = [ e(A_i, g2) * e(B_i, tau g2) == 1 ]   (pairing.hip)
@@ -1428,6 +1487,26 @@ int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const
   });
   for (auto &x : th) x.join();
   return status;
+}
+
+static int copy_out(const std::vector<uint8_t> &v, uint8_t *out, size_t cap, size_t *out_len) {
+  if (out_len) *out_len = v.size();
+  if (!out || cap < v.size()) return AVRF_ERR_BAD_ARG;
+  memcpy(out, v.data(), v.size());
+  return AVRF_OK;
+}
+int avrf_ring_setup_serialize(avrf_ring_setup *su, int compress, uint8_t *out, size_t out_cap, size_t *out_len) {
+  if (!su) return AVRF_ERR_BAD_ARG;
+  std::vector<uint8_t> v;
+  int st = guarded([&] { return su->suite == 0 ? RingB::setup_serialize(su, compress != 0, v) : RingJ::setup_serialize(su, compress != 0, v); });
+  return st ? st : copy_out(v, out, out_cap, out_len);
+}
+int avrf_ring_builder_params_serialize(avrf_ring_setup *su, int compress, uint8_t *out, size_t out_cap, size_t *out_len) {
+  if (!su) return AVRF_ERR_BAD_ARG;
+  if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
+  std::vector<uint8_t> v;
+  int st = guarded([&] { return su->suite == 0 ? RingB::builder_params_serialize(su, compress != 0, v) : RingJ::builder_params_serialize(su, compress != 0, v); });
+  return st ? st : copy_out(v, out, out_cap, out_len);
 }
 
 int avrf_ring_verify_each(avrf_ring_setup *su, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,

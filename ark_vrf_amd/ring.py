@@ -53,6 +53,23 @@ class RingSetup:
         self.proof_len = L.avrf_ring_proof_len(self._h)
         self.commitment_len = L.avrf_ring_commitment_len(self._h)
 
+    def _ser(self, fn, compress):
+        ln = C.c_size_t(0)
+        getattr(nat.lib(), fn)(self._h, int(compress), None, C.c_size_t(0), C.byref(ln))
+        out = (C.c_uint8 * max(1, ln.value))()
+        st = getattr(nat.lib(), fn)(self._h, int(compress), out, C.c_size_t(ln.value), C.byref(ln))
+        if st != nat.OK:
+            raise nat.AvrfError(f"{fn} -> {st}")
+        return bytes(out)[: ln.value]
+
+    def serialize(self, compress=False):
+        """CanonicalSerialize for RingSetup (src/ring.rs:484-521): the URS bytes this setup keeps."""
+        return self._ser("avrf_ring_setup_serialize", compress)
+
+    def builder_params(self, compress=False):
+        """RingBuilderPcsParams (src/ring.rs:523-529): the SRS in Lagrangian form, serialised."""
+        return self._ser("avrf_ring_builder_params_serialize", compress)
+
     def index(self, pks_xy):
         """pks_xy: list of 64-byte keys.  Returns a RingKey (its .commitment = compressed RingCommitment)."""
         h = C.c_void_p()

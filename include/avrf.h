@@ -187,6 +187,14 @@ void avrf_ring_setup_free(avrf_ring_setup *setup);
  * Insecure by construction (the caller knows tau) -- exactly like the reference's from_seed; for tests and benches. */
 int avrf_ring_srs_generate(avrf_ctx *ctx, const uint8_t *tau, const uint8_t *g1, const uint8_t *g2, size_t n_g1,
                            uint8_t *out, size_t out_cap, size_t *out_len);
+/* (avrf_ring_setup_load also accepts the serialize_compressed form of the same object: G1 / G2 points are decompressed on
+ * the host, curve membership checked, no G2 subgroup check -- the SRS is trusted-setup material, src/ring.rs:466-474.)
+ * CanonicalSerialize for RingSetup (= its PcsParams, truncated to the 3N+1 powers the setup keeps; src/ring.rs:484-521) and
+ * for RingBuilderPcsParams (Vec<G1Affine>: the SRS in Lagrangian form L_i(tau) g1, i < N; src/ring.rs:523-529, obtained in the
+ * reference from RingSetup::verifier_key_builder), compress = 0 / 1 for ark-serialize's two modes.  *out_len = bytes needed
+ * (also when `out` is NULL or too small -> AVRF_ERR_BAD_ARG). */
+int avrf_ring_setup_serialize(avrf_ring_setup *setup, int compress, uint8_t *out, size_t out_cap, size_t *out_len);
+int avrf_ring_builder_params_serialize(avrf_ring_setup *setup, int compress, uint8_t *out, size_t out_cap, size_t *out_len);
 size_t avrf_ring_pcs_domain_size(int suite, size_t ring_size);   /* pcs_domain_size, src/ring.rs:810-817 */
 size_t avrf_ring_max_ring_size(const avrf_ring_setup *setup);   /* RingContext::max_ring_size, src/ring.rs:298-300 */
 size_t avrf_ring_domain_size(const avrf_ring_setup *setup);     /* piop_domain_size, src/ring.rs:819-821 */

@@ -284,3 +284,33 @@ def g2_encode_zcash_uncompressed(q):
         return bytes(out)
     (x0, x1), (y0, y1) = q
     return b"".join(v.to_bytes(48, "big") for v in (x1, x0, y1, y0))
+
+
+def _f2_largest(y):
+    """y is the larger of {y, -y} with Fp2 ordered by (c1, c0) (ark-ff QuadExtField Ord; zcash 'lexicographically largest')."""
+    neg = ((-y[0]) % P, (-y[1]) % P)
+    return (y[1], y[0]) > (neg[1], neg[0])
+
+
+def g2_encode_compressed(q, zcash):
+    """serialize_compressed of a G2 point: zcash (BLS12-381) x.c1 || x.c0 big-endian with flag bits in byte 0
+    (0x80 compressed, 0x40 infinity, 0x20 largest y); arkworks (BN254) x.c0 || x.c1 little-endian, flags in the last byte
+    (0x80 largest y, 0x40 infinity)."""
+    n = 48 if zcash else 32
+    if q is None:
+        out = bytearray(2 * n)
+        if zcash:
+            out[0] = 0xC0
+        else:
+            out[-1] = 0x40
+        return bytes(out)
+    (x0, x1), y = q
+    if zcash:
+        out = bytearray(x1.to_bytes(n, "big") + x0.to_bytes(n, "big")); out[0] |= 0x80
+        if _f2_largest(y):
+            out[0] |= 0x20
+    else:
+        out = bytearray(x0.to_bytes(n, "little") + x1.to_bytes(n, "little"))
+        if _f2_largest(y):
+            out[-1] |= 0x80
+    return bytes(out)

@@ -330,6 +330,67 @@ def test_srs_generate(env, suite):
 
 
 @pytest.mark.parametrize("suite", [0, 1])
+def test_setup_serialisation(env, suite):
+    """CanonicalSerialize / Deserialize of RingSetup and RingBuilderPcsParams (src/ring.rs:484-542) in both ark-serialize modes:
+    uncompressed == the truncated SRS file; compressed == the oracle's encodings of the same points (G1 form pinned by the
+    `ring_pks_com` vectors); either form loads into a setup that reproduces the reference's ring commitment and proof."""
+    from oracle import pairing_py as PP
+    from ark_vrf_amd.ring import RingSetup
+    ctx, setup, vs, srs_bytes = env[suite]
+    s = R.SUITES[suite]
+    fq = s.fp_bytes
+    n = 3 * 512 + 1
+    cnt = int.from_bytes(srs_bytes[:8], "little")
+    g2off = 8 + cnt * 2 * fq + 8
+    unc = setup.serialize(False)
+    assert unc == n.to_bytes(8, "little") + srs_bytes[8: 8 + n * 2 * fq] + (2).to_bytes(8, "little") + srs_bytes[g2off: g2off + 8 * fq]
+    srs = R.Srs(s, srs_bytes)
+    PP.use_curve("bls12_381" if suite == 0 else "bn254")
+    try:
+        dec = PP.g2_decode_zcash_uncompressed if suite == 0 else PP.g2_decode_arkworks_uncompressed
+        g2c = b"".join(PP.g2_encode_compressed(dec(srs.g2_raw[i]), suite == 0) for i in range(2))
+    finally:
+        PP.use_curve("bls12_381")
+    want_c = n.to_bytes(8, "little") + b"".join(R.g1_encode(s, P, True) for P in srs.g1[:n]) + (2).to_bytes(8, "little") + g2c
+    comp = setup.serialize(True)
+    assert comp == want_c
+    v = vs[0]
+    raw = bytes.fromhex(v["ring_pks"])
+    pks = [xy(suite, raw[32 * i: 32 * i + 32]) for i in range(len(raw) // 32)]
+    idx = [raw[32 * i: 32 * i + 32].hex() for i in range(len(pks))].index(v["pk"])
+    for blob in (unc, comp):
+        su2 = RingSetup(ctx, blob, 8)
+        assert su2.serialize(False) == unc
+        key = su2.index(pks)
+        assert key.commitment.hex() == v["ring_pks_com"]
+        assert key.prove([idx], [bytes.fromhex(v["blinding"])])[0].hex() == v["ring_proof"]
+        key.close(); su2.close()
+    from ark_vrf_amd import _native as nat
+    x = srs.g1[0][0]
+    while R.sqrt_mod((x ** 3 + s.g1_b) % s.p, s.p) is not None:                     # an x with no point on the curve
+        x += 1
+    enc = bytearray(R.g1_encode(s, (x, 0), True))
+    bad = comp[:8] + bytes(enc) + comp[8 + fq:]
+    with pytest.raises(nat.AvrfError, match="-> 2"):
+        RingSetup(ctx, bad, 8)
+    # RingBuilderPcsParams: the SRS in Lagrangian form, L_i(tau) g1 = commit(iNTT(e_i))
+    N = 512
+    lag = setup.builder_params(False)
+    assert len(lag) == 8 + N * 2 * fq and int.from_bytes(lag[:8], "little") == N
+    pts = [R.g1_decode_uncompressed(s, lag[8 + 2 * fq * i: 8 + 2 * fq * (i + 1)]) for i in range(N)]
+    prm = R.Params(s, ring_size=8)
+    for i in (0, 1, 300, 511):
+        e = [0] * N; e[i] = 1
+        assert pts[i] == R.g1_affine(s.p, R.g1_msm(s.p, srs.g1[:N], R.ifft(s, e, prm.w)))
+    acc = None
+    for P in pts:
+        acc = R.g1_add(s.p, acc, P + (1,))
+    assert R.g1_affine(s.p, acc) == srs.g1[0]                                       # sum_i L_i = 1
+    lc = setup.builder_params(True)
+    assert lc == N.to_bytes(8, "little") + b"".join(R.g1_encode(s, P, True) for P in pts)
+
+
+@pytest.mark.parametrize("suite", [0, 1])
 def test_verifier_key_builder(env, suite):
     """VerifierKeyBuilder (src/ring.rs:539-637; reference test `verifier_key_builder`, src/ring.rs:1224-1290): keys appended
     in batches give the commitment of `verifier_key(keys)` -- here the reference vector's `ring_pks_com` and
