@@ -1,0 +1,151 @@
+// capi_wire.hip -- the wire-format flavour of the C ABI: the same verifier / prover entry points taking the
+// reference's `serialize_compressed` encodings (32-byte points, proofs exactly as `CanonicalSerialize` writes them) with a
+// `validate` flag, and ring::Prover::prove / ring::Verifier::verify as single calls.  Pure composition of the entry points
+// of capi.hip / ring.hip: points are decompressed (validated) by avrf_points_decompress on the device, then the xy entry
+// point runs.  No kernels of its own.
+//
+//   thin proof      R(32) || s(32)                          src/thin.rs:43-48
+//   tiny proof      c(16) || s(32)                          src/tiny.rs:60-78
+//   pedersen proof  Yb(32) || R(32) || Ok(32) || s || sb    src/pedersen.rs:69-75      (160 bytes)
+//   ring-VRF proof  pedersen proof || ring proof            src/ring.rs:160-166        (752 / 640 bytes)
+#include "../../include/avrf.h"
+#include <string.h>
+#include <vector>
+
+namespace {
+
+// decompress `count` points given as (pointer, stride) records into contiguous xy; returns AVRF_OK or the failing status
+struct Gather {
+  std::vector<uint8_t> comp;
+  void add(const uint8_t *p, size_t n, size_t stride) { for (size_t i = 0; i < n; i++) comp.insert(comp.end(), p + i * stride, p + i * stride + 32); }
+};
+int decompress_all(avrf_ctx *ctx, const Gather &g, int validate, std::vector<uint8_t> &xy, std::vector<int32_t> *per_point = nullptr) {
+  const size_t n = g.comp.size() / 32;
+  xy.assign(n * 64, 0);
+  std::vector<int32_t> st(n ? n : 1, 0);
+  int rc = avrf_points_decompress(ctx, n, g.comp.data(), xy.data(), validate, st.data());
+  if (rc != AVRF_OK) return rc;
+  if (per_point) { *per_point = st; return AVRF_OK; }
+  for (size_t i = 0; i < n; i++) if (st[i]) return AVRF_INVALID_DATA;
+  return AVRF_OK;
+}
+size_t sum_counts(const uint32_t *c, size_t n) { size_t t = 0; for (size_t i = 0; i < n; i++) t += c[i]; return t; }
+
+// shared by the thin / tiny / pedersen wire verifiers: kind 1 thin (64-byte proofs, 1 point), 3 tiny (48, 0 points), 2 pedersen (160, 3)
+int verify_wire(avrf_ctx *ctx, int kind, bool batch, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                const uint32_t *ad_lens, const uint8_t *proofs, int validate, int32_t *status_out) {
+  if (!ctx || (n && (!io_counts || !ad_lens || !proofs)) || (n && kind != 2 && !pks) || (!batch && n && !status_out)) return AVRF_ERR_BAD_ARG;
+  if (!n) return AVRF_OK;
+  const size_t tot = sum_counts(io_counts, n);
+  if (tot && !ios) return AVRF_ERR_BAD_ARG;
+  const size_t plen = kind == 1 ? 64 : kind == 3 ? 48 : 160, ppts = kind == 1 ? 1 : kind == 3 ? 0 : 3, xlen = kind == 1 ? 96 : kind == 3 ? 48 : 256;
+  Gather g;
+  if (kind != 2) g.add(pks, n, 32);
+  g.add(ios, 2 * tot, 32);
+  for (size_t p = 0; p < ppts; p++) g.add(proofs + 32 * p, n, plen);
+  std::vector<uint8_t> xy; std::vector<int32_t> pst;
+  int rc = decompress_all(ctx, g, validate, xy, batch ? nullptr : &pst);
+  if (rc != AVRF_OK) return rc;
+  const uint8_t *x_pks = xy.data(), *x_ios = xy.data() + (kind != 2 ? n * 64 : 0), *x_pp = x_ios + 2 * tot * 64;
+  std::vector<uint8_t> px(n * xlen);
+  for (size_t j = 0; j < n; j++) {
+    for (size_t p = 0; p < ppts; p++) memcpy(&px[j * xlen + 64 * p], x_pp + (p * n + j) * 64, 64);
+    memcpy(&px[j * xlen + 64 * ppts], proofs + j * plen + 32 * ppts, plen - 32 * ppts);
+  }
+  if (batch) {
+    if (kind == 1) return avrf_thin_batch_verify(ctx, n, x_pks, x_ios, io_counts, ads, ad_lens, px.data());
+    return avrf_pedersen_batch_verify(ctx, n, x_ios, io_counts, ads, ad_lens, px.data());
+  }
+  if (kind == 1) rc = avrf_thin_verify(ctx, n, x_pks, x_ios, io_counts, ads, ad_lens, px.data(), status_out);
+  else if (kind == 3) rc = avrf_tiny_verify(ctx, n, x_pks, x_ios, io_counts, ads, ad_lens, px.data(), status_out);
+  else rc = avrf_pedersen_verify(ctx, n, x_ios, io_counts, ads, ad_lens, px.data(), status_out);
+  if (rc != AVRF_OK) return rc;
+  // a point that does not decode (or fails validation) makes ITS item InvalidData
+  size_t at = 0, io_at = 0;
+  if (kind != 2) { for (size_t j = 0; j < n; j++) if (pst[j]) status_out[j] = AVRF_INVALID_DATA; at = n; }
+  for (size_t j = 0; j < n; j++) { for (size_t k = 0; k < 2 * (size_t)io_counts[j]; k++) if (pst[at + io_at + k]) status_out[j] = AVRF_INVALID_DATA; io_at += 2 * io_counts[j]; }
+  at += 2 * tot;
+  for (size_t p = 0; p < ppts; p++) for (size_t j = 0; j < n; j++) if (pst[at + p * n + j]) status_out[j] = AVRF_INVALID_DATA;
+  return AVRF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int avrf_thin_batch_verify_wire(avrf_ctx *ctx, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                                const uint32_t *ad_lens, const uint8_t *proofs, int validate) {
+  return verify_wire(ctx, 1, true, n, pks, ios, io_counts, ads, ad_lens, proofs, validate, nullptr);
+}
+int avrf_thin_verify_wire(avrf_ctx *ctx, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                          const uint32_t *ad_lens, const uint8_t *proofs, int validate, int32_t *status_out) {
+  return verify_wire(ctx, 1, false, n, pks, ios, io_counts, ads, ad_lens, proofs, validate, status_out);
+}
+int avrf_tiny_verify_wire(avrf_ctx *ctx, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                          const uint32_t *ad_lens, const uint8_t *proofs, int validate, int32_t *status_out) {
+  return verify_wire(ctx, 3, false, n, pks, ios, io_counts, ads, ad_lens, proofs, validate, status_out);
+}
+int avrf_pedersen_batch_verify_wire(avrf_ctx *ctx, size_t n, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                                    const uint32_t *ad_lens, const uint8_t *proofs, int validate) {
+  return verify_wire(ctx, 2, true, n, nullptr, ios, io_counts, ads, ad_lens, proofs, validate, nullptr);
+}
+int avrf_pedersen_verify_wire(avrf_ctx *ctx, size_t n, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                              const uint32_t *ad_lens, const uint8_t *proofs, int validate, int32_t *status_out) {
+  return verify_wire(ctx, 2, false, n, nullptr, ios, io_counts, ads, ad_lens, proofs, validate, status_out);
+}
+
+// ring::Prover::prove (src/ring.rs:211-226) for n provers of one ring: Pedersen proof + ring proof for its blinding, serialised
+// as ring::Proof (src/ring.rs:160-166)
+int avrf_ring_vrf_prove(avrf_ctx *ctx, avrf_ring_key *key, size_t ring_proof_len, size_t n, const uint8_t *sks, const uint32_t *key_index,
+                        const uint8_t *ios_xy, const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, int blinding_mode,
+                        uint8_t *proofs_out) {
+  if (!ctx || !key || (n && (!sks || !key_index || !io_counts || !ad_lens || !proofs_out))) return AVRF_ERR_BAD_ARG;
+  if (!n) return AVRF_OK;
+  std::vector<uint8_t> ped(n * 256), blind(n * 32), rp(n * ring_proof_len), comp(n * 3 * 32), pts(n * 3 * 64);
+  int rc = avrf_pedersen_prove(ctx, n, sks, nullptr, ios_xy, io_counts, ads, ad_lens, ped.data(), blind.data());
+  if (rc != AVRF_OK) return rc;
+  rc = avrf_ring_prove(key, n, key_index, blind.data(), blinding_mode, rp.data());
+  if (rc != AVRF_OK) return rc;
+  for (size_t j = 0; j < n; j++) memcpy(&pts[j * 192], &ped[j * 256], 192);
+  rc = avrf_points_compress(ctx, 3 * n, pts.data(), comp.data());
+  if (rc != AVRF_OK) return rc;
+  const size_t plen = 160 + ring_proof_len;
+  for (size_t j = 0; j < n; j++) {
+    uint8_t *o = proofs_out + j * plen;
+    memcpy(o, &comp[j * 96], 96); memcpy(o + 96, &ped[j * 256 + 192], 64); memcpy(o + 160, &rp[j * ring_proof_len], ring_proof_len);
+  }
+  return AVRF_OK;
+}
+
+// ring::Verifier::verify for every item (each != 0: per-item statuses, src/ring.rs:228-247) or ring::BatchVerifier over all of
+// them (each == 0: one status, src/ring.rs:693-735): Pedersen half + ring half on the key commitment Yb of the Pedersen proof
+int avrf_ring_vrf_verify(avrf_ctx *ctx, avrf_ring_setup *setup, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,
+                         const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs,
+                         int validate, int each, int32_t *status_out) {
+  if (!ctx || !setup || (n && (!ring_commitments || !n_rings || !io_counts || !ad_lens || !proofs)) || (each && n && !status_out)) return AVRF_ERR_BAD_ARG;
+  if (!n) return AVRF_OK;
+  const size_t rlen = avrf_ring_proof_len(setup), plen = 160 + rlen, tot = sum_counts(io_counts, n);
+  if (tot && !ios) return AVRF_ERR_BAD_ARG;
+  std::vector<uint8_t> ped(n * 160), rp(n * rlen);
+  for (size_t j = 0; j < n; j++) { memcpy(&ped[j * 160], proofs + j * plen, 160); memcpy(&rp[j * rlen], proofs + j * plen + 160, rlen); }
+  // Yb of every Pedersen proof as xy (the ring verifier's instance)
+  Gather g; g.add(ped.data(), n, 160);
+  std::vector<uint8_t> yb; std::vector<int32_t> yst;
+  int rc = decompress_all(ctx, g, validate, yb, &yst);
+  if (rc != AVRF_OK) return rc;
+  if (!each) {
+    for (size_t j = 0; j < n; j++) if (yst[j]) return AVRF_INVALID_DATA;
+    rc = avrf_pedersen_batch_verify_wire(ctx, n, ios, io_counts, ads, ad_lens, ped.data(), validate);
+    if (rc != AVRF_OK) return rc;
+    return avrf_ring_batch_verify(setup, n, ring_commitments, n_rings, ring_of_item, yb.data(), rp.data());
+  }
+  std::vector<int32_t> s1(n), s2(n);
+  rc = avrf_pedersen_verify_wire(ctx, n, ios, io_counts, ads, ad_lens, ped.data(), validate, s1.data());
+  if (rc != AVRF_OK) return rc;
+  rc = avrf_ring_verify_each(setup, n, ring_commitments, n_rings, ring_of_item, yb.data(), rp.data(), s2.data());
+  if (rc != AVRF_OK) return rc;
+  for (size_t j = 0; j < n; j++) status_out[j] = (yst[j] || s1[j] == AVRF_INVALID_DATA || s2[j] == AVRF_INVALID_DATA) ? AVRF_INVALID_DATA : (s1[j] || s2[j]) ? AVRF_VERIFICATION_FAILURE : AVRF_OK;
+  return AVRF_OK;
+}
+
+}  // extern "C"

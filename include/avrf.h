@@ -273,6 +273,40 @@ int avrf_points_compress(avrf_ctx *ctx, size_t n, const uint8_t *in_xy, uint8_t 
 int avrf_scalar_mul_base(avrf_ctx *ctx, size_t n, const uint8_t *sks, uint8_t *out_xy);
 int avrf_scalar_mul(avrf_ctx *ctx, size_t n, const uint8_t *scalars, const uint8_t *points_xy, uint8_t *out_xy);
 
+/* ---- Wire-format flavour: the reference's `serialize_compressed` encodings and a `validate` flag. ----
+ * Points are 32-byte compressed (pks: n x 32; ios: per pair input(32) || output(32)); proofs are the reference's byte strings:
+ * thin R(32) || s(32) (src/thin.rs:43-48), tiny c(16) || s(32) (src/tiny.rs:60-78), pedersen Yb || R || Ok || s || sb = 160
+ * (src/pedersen.rs:69-75), ring-VRF = pedersen proof || ring proof = 752 / 640 (src/ring.rs:160-166).
+ * validate = 0: CanonicalDeserialize with Validate::No (the point must decode, i.e. lie on the curve);
+ * validate = 1: Validate::Yes as in the checked constructors (src/lib.rs:410-433): also prime-order subgroup and not the identity.
+ * A point that fails gives AVRF_INVALID_DATA (for its item in the per-item calls) before any equation is evaluated.
+ * These calls decompress on the device (avrf_points_decompress) and then run the xy entry points above: the xy flavour is
+ * the fast path for callers that hold deserialised points, as the reference's own benches do (benches/thin.rs:46-90). */
+int avrf_thin_batch_verify_wire(avrf_ctx *ctx, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                                const uint32_t *ad_lens, const uint8_t *proofs, int validate);
+int avrf_thin_verify_wire(avrf_ctx *ctx, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                          const uint32_t *ad_lens, const uint8_t *proofs, int validate, int32_t *status_out);
+int avrf_tiny_verify_wire(avrf_ctx *ctx, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                          const uint32_t *ad_lens, const uint8_t *proofs, int validate, int32_t *status_out);
+int avrf_pedersen_batch_verify_wire(avrf_ctx *ctx, size_t n, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                                    const uint32_t *ad_lens, const uint8_t *proofs, int validate);
+int avrf_pedersen_verify_wire(avrf_ctx *ctx, size_t n, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                              const uint32_t *ad_lens, const uint8_t *proofs, int validate, int32_t *status_out);
+
+/* ring::Prover::prove (src/ring.rs:211-226) as ONE call for n provers of the ring behind `key` (avrf_pedersen_prove +
+ * avrf_ring_prove + serialisation): sks n x 32, key_index[i] = position of prover i's key in the ring, ios_xy as for
+ * avrf_pedersen_prove; proofs_out: n x (160 + ring_proof_len) bytes, ring::Proof's compressed serialisation.
+ * ring_proof_len = avrf_ring_proof_len(setup of the key). */
+int avrf_ring_vrf_prove(avrf_ctx *ctx, avrf_ring_key *key, size_t ring_proof_len, size_t n, const uint8_t *sks, const uint32_t *key_index,
+                        const uint8_t *ios_xy, const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, int blinding_mode,
+                        uint8_t *proofs_out);
+/* ring::Verifier::verify for every item (each != 0: status_out[i] per proof; src/ring.rs:228-247) or ring::BatchVerifier over
+ * all items (each == 0: the return value is the batch's status; src/ring.rs:693-735).  ios wire-format as above; proofs: n x
+ * (160 + avrf_ring_proof_len(setup)).  Pedersen half on the context, ring half on the setup (same suite). */
+int avrf_ring_vrf_verify(avrf_ctx *ctx, avrf_ring_setup *setup, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,
+                         const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs,
+                         int validate, int each, int32_t *status_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,125 @@
+"""GPU: the wire-format flavour of the C ABI (include/avrf.h "Wire-format flavour") -- the reference's vectors fed
+in exactly the bytes `CanonicalSerialize` produces (32-byte points, 64 / 48 / 160 / 752-byte proofs), with the validate flag."""
+import ctypes as C
+import json
+import os
+
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+NAMES = {0: "bandersnatch_sha-512_ell2", 1: "baby-jubjub_sha-512_tai"}
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    from ark_vrf_amd import _native as nat
+    return {s: nat.Context(s) for s in (0, 1)}
+
+
+def _call(fn, ctx, n, pks, ios, counts, ads, proofs, validate, per_item):
+    from ark_vrf_amd import _native as nat
+    args = [ctx._h, C.c_size_t(n)]
+    if pks is not None:
+        args.append(nat._u8(b"".join(pks)))
+    args += [nat._u8(b"".join(i + o for it in ios for i, o in it)), nat._u32(counts), nat._u8(b"".join(ads)), nat._u32([len(a) for a in ads]),
+             nat._u8(b"".join(proofs)), int(validate)]
+    if per_item:
+        out = (C.c_int32 * max(1, n))()
+        rc = getattr(nat.lib(), fn)(*args, out)
+        return rc, list(out)[:n]
+    return getattr(nat.lib(), fn)(*args), None
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+@pytest.mark.parametrize("validate", [0, 1])
+def test_thin_tiny_pedersen_vectors_wire(ctxs, golden_dir, suite, validate):
+    c = ctxs[suite]
+    load = lambda k: json.load(open(os.path.join(golden_dir, f"{NAMES[suite]}_{k}.json")))
+    th, ti, pe = load("thin"), load("tiny"), load("pedersen")
+    pks = [bytes.fromhex(v["pk"]) for v in th]
+    ios = [[(bytes.fromhex(v["h"]), bytes.fromhex(v["gamma"]))] for v in th]
+    ads = [bytes.fromhex(v["ad"]) for v in th]
+    one = [1] * 7
+    tp = [bytes.fromhex(v["proof_r"] + v["proof_s"]) for v in th]
+    assert _call("avrf_thin_batch_verify_wire", c, 7, pks, ios, one, ads, tp, validate, False)[0] == 0
+    assert _call("avrf_thin_verify_wire", c, 7, pks, ios, one, ads, tp, validate, True) == (0, [0] * 7)
+    yp = [bytes.fromhex(v["proof_c"] + v["proof_s"]) for v in ti]
+    assert _call("avrf_tiny_verify_wire", c, 7, pks, ios, one, ads, yp, validate, True) == (0, [0] * 7)
+    pp = [bytes.fromhex(v["proof_pk_com"] + v["proof_r"] + v["proof_ok"] + v["proof_s"] + v["proof_sb"]) for v in pe]
+    assert all(len(p) == 160 for p in pp)
+    assert _call("avrf_pedersen_batch_verify_wire", c, 7, None, ios, one, ads, pp, validate, False)[0] == 0
+    assert _call("avrf_pedersen_verify_wire", c, 7, None, ios, one, ads, pp, validate, True) == (0, [0] * 7)
+    # a point that does not decode: InvalidData for its item / for the batch
+    bad_y = None
+    for k in range(2, 300):                                                     # a y with no x on the curve
+        cand = k.to_bytes(32, "little")
+        if orc.point_decompress(suite, cand)[0] != 0:
+            bad_y = cand; break
+    pks_bad = pks[:2] + [bad_y] + pks[3:]
+    assert _call("avrf_thin_verify_wire", c, 7, pks_bad, ios, one, ads, tp, validate, True) == (0, [0, 0, 2, 0, 0, 0, 0])
+    assert _call("avrf_thin_batch_verify_wire", c, 7, pks_bad, ios, one, ads, tp, validate, False)[0] == 2
+    ios_bad = [list(x) for x in ios]; ios_bad[5] = [(ios[5][0][0], bad_y)]
+    assert _call("avrf_pedersen_verify_wire", c, 7, None, ios_bad, one, ads, pp, validate, True) == (0, [0, 0, 0, 0, 0, 2, 0])
+    assert _call("avrf_tiny_verify_wire", c, 7, pks, ios_bad, one, ads, yp, validate, True) == (0, [0, 0, 0, 0, 0, 2, 0])
+    pp_bad = [bad_y + pp[0][32:]] + pp[1:]
+    assert _call("avrf_pedersen_batch_verify_wire", c, 7, None, ios, one, ads, pp_bad, validate, False)[0] == 2
+    # tampered scalar: VerificationFailure
+    tp2 = tp[:4] + [tp[4][:40] + bytes([tp[4][40] ^ 1]) + tp[4][41:]] + tp[5:]
+    assert _call("avrf_thin_verify_wire", c, 7, pks, ios, one, ads, tp2, validate, True) == (0, [0, 0, 0, 0, 1, 0, 0])
+    # Validate::Yes rejects a point of small order (on the curve, outside the prime-order subgroup); Validate::No lets it decode
+    q = {0: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+         1: 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001}[suite]
+    order2 = (q - 1).to_bytes(32, "little")                                     # (0, -1)
+    st = _call("avrf_thin_verify_wire", c, 7, pks[:6] + [order2], ios, one, ads, tp, validate, True)[1]
+    assert st[:6] == [0] * 6 and st[6] == (2 if validate else 1)
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_ring_vrf_one_call(ctxs, golden_dir, suite):
+    """ring::Prover::prove / ring::Verifier::verify / ring::BatchVerifier as single calls on the reference's ring vectors:
+    with blinding disabled the 752 / 640-byte proof equals `proof_pk_com || proof_r || proof_ok || proof_s || proof_sb || ring_proof`."""
+    from ark_vrf_amd import _native as nat
+    from ark_vrf_amd.ring import RingSetup
+    from helpers import xy
+    c = ctxs[suite]
+    vs = json.load(open(os.path.join(golden_dir, NAMES[suite] + "_ring.json")))
+    srs = open(os.path.join(golden_dir, ["bls12-381-srs-2-11-uncompressed-zcash.bin", "bn254-testing-2-9-uncompressed.bin"][suite]), "rb").read()
+    setup = RingSetup(c, srs, 8)
+    rlen = setup.proof_len
+    L = nat.lib()
+    proofs, coms, ios_w, ads = [], [], [], []
+    for v in vs:
+        raw = bytes.fromhex(v["ring_pks"])
+        pks = [xy(suite, raw[32 * i: 32 * i + 32]) for i in range(len(raw) // 32)]
+        key = setup.index(pks)
+        idx = [raw[32 * i: 32 * i + 32].hex() for i in range(len(pks))].index(v["pk"])
+        io_xy = xy(suite, bytes.fromhex(v["h"])) + xy(suite, bytes.fromhex(v["gamma"]))
+        ad = bytes.fromhex(v["ad"])
+        out = (C.c_uint8 * (160 + rlen))()
+        rc = L.avrf_ring_vrf_prove(c._h, key._h, C.c_size_t(rlen), C.c_size_t(1), nat._u8(bytes.fromhex(v["sk"])), nat._u32([idx]), nat._u8(io_xy),
+                                   nat._u32([1]), nat._u8(ad), nat._u32([len(ad)]), 0, out)
+        assert rc == 0
+        want = bytes.fromhex(v["proof_pk_com"] + v["proof_r"] + v["proof_ok"] + v["proof_s"] + v["proof_sb"] + v["ring_proof"])
+        assert bytes(out) == want
+        proofs.append(want); coms.append(key.commitment); ads.append(ad)
+        ios_w.append(bytes.fromhex(v["h"]) + bytes.fromhex(v["gamma"]))
+        key.close()
+    n = len(vs)
+
+    def verify(prs, each, validate=1, ios=ios_w):
+        out = (C.c_int32 * n)()
+        rc = L.avrf_ring_vrf_verify(c._h, setup._h, C.c_size_t(n), nat._u8(b"".join(coms)), C.c_size_t(n), nat._u32(list(range(n))), nat._u8(b"".join(ios)),
+                                    nat._u32([1] * n), nat._u8(b"".join(ads)), nat._u32([len(a) for a in ads]), nat._u8(b"".join(prs)), validate, int(each), out)
+        return rc, list(out)
+    assert verify(proofs, True) == (0, [0] * n)
+    assert verify(proofs, False)[0] == 0
+    bad = list(proofs); bad[3] = bad[3][:100] + bytes([bad[3][100] ^ 1]) + bad[3][101:]           # Pedersen response
+    bad[5] = bad[5][:-10] + bytes([bad[5][-10] ^ 1]) + bad[5][-9:]                                   # ring opening proof
+    rc, st = verify(bad, True)
+    assert rc == 0 and st[3] == 1 and st[5] in (1, 2) and [st[i] for i in (0, 1, 2, 4, 6)] == [0] * 5
+    assert verify(bad, False)[0] in (1, 2)
+    ios_bad = list(ios_w); ios_bad[1] = ios_w[1][:32] + ios_w[2][32:]                                  # wrong output
+    assert verify(proofs, True, ios=ios_bad)[1] == [0, 1, 0, 0, 0, 0, 0]
+    setup.close()
