@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mont8_asm_gen.h"
 
 namespace avrf {
 
@@ -23,6 +24,12 @@ __device__ __forceinline__ void mac96_k(uint64_t &lo, uint32_t &ex, uint32_t a, 
 // conditional subtraction.  P: modulus limbs, NINV = -p^-1 mod 2^32.
 template <int N, class F>
 __device__ __forceinline__ void mont_mul_ps(uint32_t (&t)[N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
+#ifndef AVRF_NO_MONT_ASM
+  if constexpr (N == 8 && MontAsm8<F>::value) {      // the same algorithm as one asm block with a sliding accumulator (tools/gen_mont_asm.py)
+    MontAsm8<F>::mul(t, a, b);
+    return;
+  }
+#endif
   uint32_t m[N];
   uint64_t lo = 0; uint32_t ex = 0;
 #pragma unroll

@@ -527,9 +527,10 @@ k_wsum_blk(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t *__restri
 
 // tuning knobs from the environment, read once per process
 struct MsmEnv {
-  int c = 0, per_min = 8, wsum_wps = 0; bool window_sums = true;
+  int c = 0, per_min = 8, wsum_wps = 0, occ = 0; bool window_sums = true;
   MsmEnv() {
     if (const char *e = getenv("AVRF_MSM_C")) { int v = atoi(e); if (v >= 3 && v <= 15) c = v; }
+    if (const char *e = getenv("AVRF_MSM_OCC")) { int v = atoi(e); if (v >= 1 && v <= 8) occ = v; }   // resident k_accumulate waves per SIMD to fill
     if (const char *e = getenv("AVRF_MSM_PER_MIN")) { int v = atoi(e); if (v >= 1 && v <= 4096) per_min = v; }
     if (const char *e = getenv("AVRF_TE_WSUM_WPS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) wsum_wps = v; }
     if (const char *e = getenv("AVRF_TE_WINDOW_SUMS")) window_sums = atoi(e) != 0;
@@ -560,6 +561,7 @@ template <class CV> static size_t accumulate_lanes() {
     HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_accumulate<CV>, 256, 0));
     if (blocks < 1) blocks = 1;
+    if (msm_env().occ && msm_env().occ < blocks) blocks = msm_env().occ;      // a block of 256 lanes = one wave on each of a CU's 4 SIMDs
     cache[dev] = (size_t)cus * blocks * 256;
   }
   return cache[dev];

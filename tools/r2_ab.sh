@@ -8,6 +8,6 @@ for L in "$@"; do
   python - <<EOF
 import json
 for k in ("s1","s16"):
-    d=json.load(open("$OUT/${tag}_%s.json"%k)); print("$tag",k,"value %.1f M/s"%(d["value"]/1e6),"ms/step %.3f"%d["ms_per_step"],"acc_ms %.3f"%d["roofline"]["kernel_avg_ms"], d["config"]["msm_plan"], {a:round(b) for a,b in d["step_breakdown_us"].items()})
+    d=json.load(open("$OUT/${tag}_%s.json"%k)); print("$tag",k,"value %.1f M/s"%(d["value"]/1e6),"ms/step %.3f"%d["ms_per_step"],"acc_ms %.3f"%d["roofline"]["kernel_avg_ms"], d["config"]["msm_plan"], {a:round(b) for a,b in d["step_breakdown_us"]["one_context_alone"].items()})
 EOF
 done
