@@ -10,6 +10,7 @@
 #include "msm.h"
 #include "proto_dev.h"
 #include "vrf_batch.h"
+#include "suite_dispatch.h"
 #include <chrono>
 #include <new>
 #include <stdio.h>
@@ -144,7 +145,7 @@ int avrf_device_count(void) {
 }
 
 int avrf_ctx_create(int suite, int device, avrf_ctx **out) {
-  if (!out || suite < 0 || suite > 1) return AVRF_ERR_BAD_ARG;
+  if (!out || suite < 0 || suite >= AVRF_N_SUITES) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return AVRF_ERR_NO_DEVICE;
@@ -171,16 +172,15 @@ void avrf_ctx_destroy(avrf_ctx *c) {
 }
 
 static int finish_point(avrf_ctx *c, const HostExt &r, uint8_t out_xy[64]) {
-  if (c->suite == 0) HostTe<SuiteBandersnatch>::to_affine_bytes(r, out_xy);
-  else HostTe<SuiteBabyJubJub>::to_affine_bytes(r, out_xy);
+  with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; HostTe<S>::to_affine_bytes(r, out_xy); });
   return AVRF_OK;
 }
 static bool point_is_identity(avrf_ctx *c, const HostExt &r) {
-  return c->suite == 0 ? HostTe<SuiteBandersnatch>::is_identity(r) : HostTe<SuiteBabyJubJub>::is_identity(r);
+  return with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; return HostTe<S>::is_identity(r); });
 }
 static bool scalar_in_range(int suite, const uint8_t *s) {
   H256 v; memcpy(v.l, s, 32);
-  return suite == 0 ? !HostField<FrBandersnatch>::geq_p(v) : !HostField<FrBabyJubJub>::geq_p(v);
+  return with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return !HostField<typename S::Fr>::geq_p(v); });
 }
 
 int avrf_msm_te(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *scalars, uint8_t out_xy[64]) {
@@ -207,10 +207,11 @@ int avrf_msm_te(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *s
 int avrf_g1_msm(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *scalars, uint8_t *out_xy) {
   if (!c || !out_xy || (n && (!bases_xy || !scalars))) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
-  const size_t fqb = c->suite == 0 ? 48 : 32;
+  const int curve = pairing_curve_of(c->suite);
+  const size_t fqb = curve == 0 ? 48 : 32;
   for (size_t i = 0; i < n; i++) {
     H256 v; memcpy(v.l, scalars + 32 * i, 32);
-    bool ok = c->suite == 0 ? !HostField<FqBandersnatch>::geq_p(v) : !HostField<FqBabyJubJub>::geq_p(v);   // Fr of the pairing curve
+    bool ok = curve == 0 ? !HostField<FqBandersnatch>::geq_p(v) : !HostField<FqBabyJubJub>::geq_p(v);   // Fr of the pairing curve
     if (!ok) return AVRF_INVALID_DATA;
   }
   c->staged_kind = 0;
@@ -219,10 +220,10 @@ int avrf_g1_msm(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *s
     HIP_TRY(hipMemcpyAsync(c->d_misc.p, bases_xy, n * 2 * fqb, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
-    launch_g1_bases(c->suite, c->d_misc.as<uint8_t>(), n, c->d_pre.as<uint32_t>(), c->d_flags.as<uint32_t>(), c->stream);
+    launch_g1_bases(curve, c->d_misc.as<uint8_t>(), n, c->d_pre.as<uint32_t>(), c->d_flags.as<uint32_t>(), c->stream);
     HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
   }
-  if (int e = guarded([&] { return msm_g1_device(c->suite, c->d_pre.as<uint32_t>(), c->d_scalars.as<uint32_t>(), n, c->ws, c->stream, out_xy) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  if (int e = guarded([&] { return msm_g1_device(curve, c->d_pre.as<uint32_t>(), c->d_scalars.as<uint32_t>(), n, c->ws, c->stream, out_xy) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
   if (n && *c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;
   return AVRF_OK;
 }
@@ -304,8 +305,7 @@ static int batch_run(avrf_ctx *c, int kind) {
   // weight transcript (src/thin.rs:274-279, src/pedersen.rs:361-367):
   //   new(SUITE_ID); absorb [0x50]; per item absorb LE32(c) || LE32(s) [|| LE32(sb)]
   HostSha512 h;
-  if (c->suite == 0) h.update(SuiteBandersnatch::SUITE_ID, SuiteBandersnatch::SUITE_ID_LEN);
-  else h.update(SuiteBabyJubJub::SUITE_ID, SuiteBabyJubJub::SUITE_ID_LEN);
+  with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; h.update(S::SUITE_ID, S::SUITE_ID_LEN); });
   const uint8_t tag = DS_BATCH_VERIFY; h.update(&tag, 1);
   {
     const uint8_t *cs = c->h_c.as<uint8_t>();
@@ -350,10 +350,9 @@ int avrf_pedersen_batch_verify(avrf_ctx *c, size_t n, const uint8_t *ios_xy, con
 
 // weight transcript of src/thin.rs:274-279 / src/pedersen.rs:361-367 over ALL items of a batch (host only)
 int avrf_batch_weight_seed(int suite, int pedersen, size_t n, const uint8_t *c16, const uint8_t *resp, uint8_t seed_out[64]) {
-  if (suite < 0 || suite > 1 || !seed_out || (n && (!c16 || !resp))) return AVRF_ERR_BAD_ARG;
+  if (suite < 0 || suite >= AVRF_N_SUITES || !seed_out || (n && (!c16 || !resp))) return AVRF_ERR_BAD_ARG;
   HostSha512 h;
-  if (suite == 0) h.update(SuiteBandersnatch::SUITE_ID, SuiteBandersnatch::SUITE_ID_LEN);
-  else h.update(SuiteBabyJubJub::SUITE_ID, SuiteBabyJubJub::SUITE_ID_LEN);
+  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; h.update(S::SUITE_ID, S::SUITE_ID_LEN); });
   const uint8_t tag = DS_BATCH_VERIFY; h.update(&tag, 1);
   const size_t rsz = pedersen ? 64 : 32;
   uint8_t rec[96]; memset(rec, 0, sizeof rec);
@@ -387,7 +386,7 @@ int avrf_thin_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t firs
   if (c->n && c->chal_gen != c->stage_gen) return AVRF_ERR_BAD_ARG;     // avrf_thin_batch_challenges has not run on this staging (or it failed)
   HIP_TRY(hipSetDevice(c->device));
   HostExt r;
-  if (c->n == 0) { r = c->suite == 0 ? HostTe<SuiteBandersnatch>::identity() : HostTe<SuiteBabyJubJub>::identity(); return finish_point(c, r, out_xy); }
+  if (c->n == 0) { r = with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; return HostTe<S>::identity(); }); return finish_point(c, r, out_xy); }
   Seed64 seed;
   for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, seed64 + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
   BatchDev b = batch_of(c);
@@ -419,7 +418,7 @@ int avrf_pedersen_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t 
   if (c->n && c->chal_gen != c->stage_gen) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
   HostExt r;
-  if (c->n == 0) { r = c->suite == 0 ? HostTe<SuiteBandersnatch>::identity() : HostTe<SuiteBabyJubJub>::identity(); return finish_point(c, r, out_xy); }
+  if (c->n == 0) { r = with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; return HostTe<S>::identity(); }); return finish_point(c, r, out_xy); }
   Seed64 seed;
   for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, seed64 + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
   BatchDev b = batch_of(c);
@@ -431,16 +430,13 @@ int avrf_pedersen_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t 
 
 // sum of k affine points on the host (combining per-GPU partial MSM results)
 int avrf_points_sum(int suite, size_t k, const uint8_t *points_xy, uint8_t out_xy[64]) {
-  if (suite < 0 || suite > 1 || !out_xy || (k && !points_xy)) return AVRF_ERR_BAD_ARG;
-  if (suite == 0) {
-    using T = HostTe<SuiteBandersnatch>; HostExt acc = T::identity(), p;
-    for (size_t i = 0; i < k; i++) { if (!T::from_affine_bytes(points_xy + 64 * i, &p)) return AVRF_INVALID_DATA; acc = T::add(acc, p); }
-    T::to_affine_bytes(acc, out_xy);
-  } else {
-    using T = HostTe<SuiteBabyJubJub>; HostExt acc = T::identity(), p;
-    for (size_t i = 0; i < k; i++) { if (!T::from_affine_bytes(points_xy + 64 * i, &p)) return AVRF_INVALID_DATA; acc = T::add(acc, p); }
-    T::to_affine_bytes(acc, out_xy);
-  }
+  if (suite < 0 || suite >= AVRF_N_SUITES || !out_xy || (k && !points_xy)) return AVRF_ERR_BAD_ARG;
+  bool bad = false;
+  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; using T = HostTe<S>;
+    HostExt acc = T::identity(), p;
+    for (size_t i = 0; i < k && !bad; i++) { if (!T::from_affine_bytes(points_xy + 64 * i, &p)) bad = true; else acc = T::add(acc, p); }
+    if (!bad) T::to_affine_bytes(acc, out_xy); });
+  if (bad) return AVRF_INVALID_DATA;
   return AVRF_OK;
 }
 
@@ -454,8 +450,7 @@ size_t avrf_batch_last_terms(avrf_ctx *c, uint8_t *bases_xy, uint8_t *scalars) {
     if (hipMemcpy(pre.data(), c->d_pre.p, k * sizeof(te_pre_raw), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     for (size_t i = 0; i < k; i++) {
       H256 x, y; memcpy(x.l, pre[i].w, 32); memcpy(y.l, pre[i].w + 8, 32);
-      if (c->suite == 0) { x = HostField<FqBandersnatch>::from_mont(x); y = HostField<FqBandersnatch>::from_mont(y); }
-      else { x = HostField<FqBabyJubJub>::from_mont(x); y = HostField<FqBabyJubJub>::from_mont(y); }
+      with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; x = HostField<typename S::Fq>::from_mont(x); y = HostField<typename S::Fq>::from_mont(y); });
       memcpy(bases_xy + 64 * i, x.l, 32); memcpy(bases_xy + 64 * i + 32, y.l, 32);
     }
   }

@@ -76,6 +76,7 @@ template <class S> struct HostTe {
   using Fq = HostField<typename S::Fq>;
   static H256 mul_a(const H256 &v) {
     if (S::A_KIND == 1) { H256 t = Fq::add(v, v); t = Fq::add(t, t); t = Fq::add(t, v); return Fq::neg(t); }
+    if (S::A_KIND == 2) return Fq::neg(v);
     return v;
   }
   static HostExt identity() { HostExt r; memset(&r, 0, sizeof r); r.y = Fq::one(); r.z = Fq::one(); return r; }

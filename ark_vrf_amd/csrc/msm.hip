@@ -34,6 +34,7 @@
 // loads; keys/sorted SoA per window (coalesced); buckets AoS (te_ext 128 B; XYZZ 128 / 192 B).
 #include "msm.h"
 #include "curves.h"
+#include "suite_dispatch.h"
 #include "te_quad.h"
 #include "host_g1.h"
 #include <stdio.h>
@@ -66,8 +67,8 @@ void launch_pre_from_affine(int suite, const uint8_t *d_xy, size_t n, te_pre_raw
                             int check_curve, hipStream_t stream) {
   if (!n) return;
   dim3 g((unsigned)((n + 255) / 256)), b(256);
-  if (suite == 0) hipLaunchKernelGGL(k_pre_from_affine<SuiteBandersnatch>, g, b, 0, stream, d_xy, (uint32_t)n, (te_pre *)d_pre, d_flag, check_curve);
-  else hipLaunchKernelGGL(k_pre_from_affine<SuiteBabyJubJub>, g, b, 0, stream, d_xy, (uint32_t)n, (te_pre *)d_pre, d_flag, check_curve);
+  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type;
+    hipLaunchKernelGGL(k_pre_from_affine<S>, g, b, 0, stream, d_xy, (uint32_t)n, (te_pre *)d_pre, d_flag, check_curve); });
 }
 
 // ---------------------------------------------------------------- digits
@@ -776,9 +777,8 @@ static int msm_te_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_
 
 int msm_te_device(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n,
                   MsmWorkspace &ws, hipStream_t stream, HostExt *out) {
-  if (suite == 0) return msm_te_impl<SuiteBandersnatch>(d_pre, d_scalars, n, ws, stream, out);
-  if (suite == 1) return msm_te_impl<SuiteBabyJubJub>(d_pre, d_scalars, n, ws, stream, out);
-  return -1;
+  if (suite < 0 || suite >= AVRF_N_SUITES) return -1;
+  return with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return msm_te_impl<S>(d_pre, d_scalars, n, ws, stream, out); });
 }
 
 // ---------------------------------------------------------------- G1 (KZG) MSM

@@ -16,6 +16,7 @@
 #include "host_te.h"
 #include "msm.h"
 #include "pairing.h"
+#include "suite_dispatch.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -459,7 +460,7 @@ using namespace avrf;
 // handles
 
 struct avrf_ring_setup {
-  avrf_ctx *ctx; int suite; hipStream_t stream; int device;
+  avrf_ctx *ctx; int suite; int curve; hipStream_t stream; int device;   // curve: pairing curve of the suite (0 BLS12-381, 1 BN254)
   size_t N, cap, keyset, L, n_srs;
   uint32_t *d_srs = nullptr;                          // n_srs Montgomery affine points
   uint32_t *d_srs_table = nullptr; int table_c = 0, table_nwin = 0;   // fixed-base window table over the SRS (batched commits)
@@ -545,7 +546,7 @@ template <class S, class G> struct Ring {
     ensure_buf(su, n * 32);
     HIP_CHECK(hipMemcpyAsync(su->d_buf, plain.data(), n * 32, hipMemcpyHostToDevice, su->stream));
     G1Aff r; memset(&r, 0, sizeof r);
-    msm_g1_device(su->suite, su->d_srs, su->d_buf, n, su->ws, su->stream, r.xy);
+    msm_g1_device(su->curve, su->d_srs, su->d_buf, n, su->ws, su->stream, r.xy);
     r.inf = true; for (int i = 0; i < 2 * FQB; i++) if (r.xy[i]) r.inf = false;
     return r;
   }
@@ -556,7 +557,7 @@ template <class S, class G> struct Ring {
     ensure_buf(su, n * batch * 32);
     HIP_CHECK(hipMemcpyAsync(su->d_buf, plain.data(), n * batch * 32, hipMemcpyHostToDevice, su->stream));
     std::vector<uint8_t> xy(batch * 2 * FQB);
-    msm_g1_device(su->suite, su->d_srs, su->d_buf, n, su->ws, su->stream, xy.data(), batch);
+    msm_g1_device(su->curve, su->d_srs, su->d_buf, n, su->ws, su->stream, xy.data(), batch);
     for (size_t b = 0; b < batch; b++) {
       memset(&out[b], 0, sizeof(G1Aff)); memcpy(out[b].xy, &xy[b * 2 * FQB], 2 * FQB);
       out[b].inf = true; for (int i = 0; i < 2 * FQB; i++) if (out[b].xy[i]) out[b].inf = false;
@@ -612,7 +613,7 @@ template <class S, class G> struct Ring {
     if (len != 8 + cnt * e1 + 8 + cnt2 * e2) return AVRF_INVALID_DATA;
     if (cnt < pcs || cnt2 < 2) return AVRF_RING_CAPACITY_EXCEEDED;      // src/ring.rs:382-384
     avrf_ring_setup *su = new avrf_ring_setup();
-    su->ctx = ctx; su->suite = S::ID; su->stream = avrf_ctx_stream_(ctx); su->device = avrf_ctx_device_(ctx);
+    su->ctx = ctx; su->suite = S::ID; su->curve = pairing_curve_of(S::ID); su->stream = avrf_ctx_stream_(ctx); su->device = avrf_ctx_device_(ctx);
     su->N = N; su->cap = N - 3; su->L = L; su->keyset = su->cap - L - 1; su->n_srs = pcs;
     std::vector<uint8_t> le(pcs * e1);
     for (size_t i = 0; i < pcs; i++) {
@@ -627,7 +628,7 @@ template <class S, class G> struct Ring {
     uint8_t *d_le; uint32_t *d_flag; uint32_t flag = 0;
     HIP_CHECK(hipMalloc(&d_le, le.size())); HIP_CHECK(hipMalloc(&d_flag, 4)); HIP_CHECK(hipMalloc(&su->d_srs, pcs * e1));
     HIP_CHECK(hipMemcpy(d_le, le.data(), le.size(), hipMemcpyHostToDevice)); HIP_CHECK(hipMemset(d_flag, 0, 4));
-    launch_g1_bases(su->suite, d_le, pcs, su->d_srs, d_flag, su->stream);
+    launch_g1_bases(su->curve, d_le, pcs, su->d_srs, d_flag, su->stream);
     HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, su->stream)); HIP_CHECK(hipStreamSynchronize(su->stream));
     HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag));
     if (flag) { HIP_CHECK(hipFree(su->d_srs)); delete su; return AVRF_INVALID_DATA; }
@@ -637,7 +638,7 @@ template <class S, class G> struct Ring {
       {
         su->table_nwin = (G::Fr::BITS + 1 + su->table_c - 1) / su->table_c;
         HIP_CHECK(hipMalloc(&su->d_srs_table, (size_t)su->table_nwin * pcs * e1));
-        build_g1_table(su->suite, su->d_srs, pcs, su->table_c, su->table_nwin, su->d_srs_table, su->stream);
+        build_g1_table(su->curve, su->d_srs, pcs, su->table_c, su->table_nwin, su->d_srs_table, su->stream);
         HIP_CHECK(hipStreamSynchronize(su->stream));
       }
     }
@@ -693,15 +694,15 @@ template <class S, class G> struct Ring {
     HIP_CHECK(hipMalloc(&d_table, (size_t)nwin * e1)); HIP_CHECK(hipMalloc(&d_sc, n_g1 * 32));
     HIP_CHECK(hipMemcpy(d_le, le, e1, hipMemcpyHostToDevice)); HIP_CHECK(hipMemset(d_flag, 0, 4));
     HIP_CHECK(hipMemcpy(d_sc, pw.data(), n_g1 * 32, hipMemcpyHostToDevice));
-    launch_g1_bases(S::ID, d_le, 1, d_base, d_flag, stream);
+    launch_g1_bases(pairing_curve_of(S::ID), d_le, 1, d_base, d_flag, stream);
     HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, stream)); HIP_CHECK(hipStreamSynchronize(stream));
     int st = AVRF_OK;
     std::vector<uint8_t> xy(n_g1 * e1);
     if (flag) st = AVRF_INVALID_DATA;
     else {
-      build_g1_table(S::ID, d_base, 1, c, nwin, d_table, stream);
+      build_g1_table(pairing_curve_of(S::ID), d_base, 1, c, nwin, d_table, stream);
       MsmWorkspace ws;
-      msm_g1_fixed_device(S::ID, d_table, c, 1, d_sc, 1, 1, ws, stream, xy.data(), n_g1);
+      msm_g1_fixed_device(pairing_curve_of(S::ID), d_table, c, 1, d_sc, 1, 1, ws, stream, xy.data(), n_g1);
       ws.release();
     }
     HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag)); HIP_CHECK(hipFree(d_base)); HIP_CHECK(hipFree(d_table)); HIP_CHECK(hipFree(d_sc));
@@ -834,7 +835,7 @@ template <class S, class G> struct Ring {
     std::vector<uint8_t> xy(batch * 2 * FQB);
     static const bool trace = getenv("AVRF_RING_TRACE") != nullptr;
     struct timespec t0; if (trace) { HIP_CHECK(hipStreamSynchronize(su->stream)); clock_gettime(CLOCK_MONOTONIC, &t0); }
-    msm_g1_fixed_device(su->suite, su->d_srs_table, su->table_c, su->n_srs, su->d_buf, n, stride, su->ws, su->stream, xy.data(), batch);
+    msm_g1_fixed_device(su->curve, su->d_srs_table, su->table_c, su->n_srs, su->d_buf, n, stride, su->ws, su->stream, xy.data(), batch);
     if (trace) { struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
       fprintf(stderr, "    commit n=%zu batch=%zu: %.3f ms wall, accumulate %.3f ms (c=%d seg=%d)\n", n, batch,
               (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, su->ws.accum_ms_last, su->ws.last_plan.c, su->ws.last_plan.lpb); }
@@ -878,19 +879,19 @@ template <class S, class G> struct Ring {
     uint8_t *d_le; uint32_t *d_flag, *d_bases;
     HIP_CHECK(hipMalloc(&d_le, le.size())); HIP_CHECK(hipMalloc(&d_flag, 4)); HIP_CHECK(hipMalloc(&d_bases, nb * 2 * FQB));
     HIP_CHECK(hipMemcpy(d_le, le.data(), le.size(), hipMemcpyHostToDevice)); HIP_CHECK(hipMemset(d_flag, 0, 4));
-    launch_g1_bases(su->suite, d_le, nb, d_bases, d_flag, su->stream);
+    launch_g1_bases(su->curve, d_le, nb, d_bases, d_flag, su->stream);
     su->wit_c = 7;
     if (const char *e = getenv("AVRF_RING_WIT_C")) { int v = atoi(e); if (v >= 4 && v <= 14) su->wit_c = v; }
     su->wit_nwin = (G::Fr::BITS + 1 + su->wit_c - 1) / su->wit_c;
     HIP_CHECK(hipMalloc(&su->d_wit_table, (size_t)su->wit_nwin * nb * 2 * FQB));
-    build_g1_table(su->suite, d_bases, nb, su->wit_c, su->wit_nwin, su->d_wit_table, su->stream);
+    build_g1_table(su->curve, d_bases, nb, su->wit_c, su->wit_nwin, su->d_wit_table, su->stream);
     HIP_CHECK(hipStreamSynchronize(su->stream));
     HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag)); HIP_CHECK(hipFree(d_bases));
   }
   // `batch` sparse commits over the witness table: vector b = m (base index, plain scalar) pairs
   static void commit_sparse(avrf_ring_setup *su, const uint32_t *d_scalars_plain, const uint32_t *d_base_idx, size_t m, size_t batch, std::vector<G1Aff> &out) {
     std::vector<uint8_t> xy(batch * 2 * FQB);
-    msm_g1_fixed_device(su->suite, su->d_wit_table, su->wit_c, 2 * su->N + 1, d_scalars_plain, m, m, su->ws, su->stream, xy.data(), batch, d_base_idx);
+    msm_g1_fixed_device(su->curve, su->d_wit_table, su->wit_c, 2 * su->N + 1, d_scalars_plain, m, m, su->ws, su->stream, xy.data(), batch, d_base_idx);
     out.resize(batch);
     for (size_t b = 0; b < batch; b++) {
       memset(&out[b], 0, sizeof(G1Aff)); memcpy(out[b].xy, &xy[b * 2 * FQB], 2 * FQB);
@@ -1140,9 +1141,9 @@ template <class S, class G> struct Ring {
     HIP_CHECK(hipMemcpyAsync(d_xy, bases_xy.data(), n * 2 * FQB, hipMemcpyHostToDevice, su->stream));
     HIP_CHECK(hipMemcpyAsync(d_s, scalars_plain.data(), n * 32, hipMemcpyHostToDevice, su->stream));
     HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream));
-    launch_g1_bases(su->suite, d_xy, n, d_b, d_flag, su->stream);
-    if (check_subgroup) launch_g1_subgroup_check(su->suite, d_b, n, d_flag, su->stream);   // Validate::Yes of the deserialised points
-    msm_g1_device(su->suite, d_b, d_s, n, su->ws, su->stream, r.xy);       // (synchronises the stream)
+    launch_g1_bases(su->curve, d_xy, n, d_b, d_flag, su->stream);
+    if (check_subgroup) launch_g1_subgroup_check(su->curve, d_b, n, d_flag, su->stream);   // Validate::Yes of the deserialised points
+    msm_g1_device(su->curve, d_b, d_s, n, su->ws, su->stream, r.xy);       // (synchronises the stream)
     if (bad_points) { uint32_t f = 0; HIP_CHECK(hipMemcpy(&f, d_flag, 4, hipMemcpyDeviceToHost)); *bad_points = f != 0; }
     r.inf = true; for (int i = 0; i < 2 * FQB; i++) if (r.xy[i]) r.inf = false;
     return r;
@@ -1181,7 +1182,7 @@ template <class S, class G> struct Ring {
   // ---- n independent KZG pairing checks on the device: ok[i] = [ e(A_i, g2) * e(B_i, tau g2) == 1 ]   (pairing.hip)
   static void ensure_pairing(avrf_ring_setup *su) {
     if (su->ptab_ready) return;
-    su->ptab.build(su->suite, su->g2_raw.data(), 2, su->stream);
+    su->ptab.build(su->curve, su->g2_raw.data(), 2, su->stream);
     su->ptab_ready = true;
   }
   static int pairing_check(avrf_ring_setup *su, size_t n, const uint8_t *a_xy, const uint8_t *b_xy, int32_t *ok_out) {
@@ -1195,7 +1196,7 @@ template <class S, class G> struct Ring {
     uint8_t *d_le = base; uint32_t *d_pts = (uint32_t *)(base + pb); int32_t *d_ok = (int32_t *)(base + 2 * pb); uint32_t *d_flag = (uint32_t *)(base + 2 * pb + ob);
     HIP_CHECK(hipMemcpyAsync(d_le, le.data(), 2 * n * e1, hipMemcpyHostToDevice, su->stream));
     HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream));
-    launch_g1_bases(su->suite, d_le, 2 * n, d_pts, d_flag, su->stream);
+    launch_g1_bases(su->curve, d_le, 2 * n, d_pts, d_flag, su->stream);
     launch_pairing_check(su->ptab, d_pts, n, d_ok, su->stream);
     uint32_t flag = 0;
     HIP_CHECK(hipMemcpyAsync(ok_out, d_ok, n * 4, hipMemcpyDeviceToHost, su->stream));
@@ -1295,7 +1296,7 @@ template <class S, class G> struct Ring {
       H256 zk = one; for (int j = 0; j < 3; j++) zk = Fr::mul(zk, Fr::sub(zeta, wz[j]));
       const H256 qz = Fr::mul(Fr::mul(aggz, zk), Fr::inv(zn1));
       H256 vagg = Fr::mul(nu[7], qz); for (int i = 0; i < 7; i++) vagg = Fr::add(vagg, Fr::mul(nu[i], ev[i]));
-      const H256 a_coef = S::A_KIND == 1 ? Fr::neg(fr_small<F>(5)) : one;
+      const H256 a_coef = S::A_KIND == 1 ? Fr::neg(fr_small<F>(5)) : S::A_KIND == 2 ? Fr::neg(one) : one;
       const H256 k1 = Fr::add(Fr::mul(b, Fr::add(Fr::mul(y1, y2), Fr::mul(a_coef, Fr::mul(x1, x2)))), omb);
       const H256 k2 = Fr::add(Fr::mul(b, Fr::sub(Fr::mul(x1, y2), Fr::mul(x2, y1))), omb);
       const H256 zw = Fr::mul(zeta, su->w);
@@ -1337,9 +1338,9 @@ template <class S, class G> struct Ring {
       HIP_CHECK(hipMemcpyAsync(d_xy, bb.data(), nb * e1, hipMemcpyHostToDevice, su->stream));
       HIP_CHECK(hipMemcpyAsync(d_s, ss.data(), nb * 32, hipMemcpyHostToDevice, su->stream));
       HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream)); HIP_CHECK(hipMemsetAsync(d_rec, 0, n * 4, su->stream));
-      launch_g1_bases(su->suite, d_xy, nb, d_b, d_flag, su->stream);
-      launch_g1_subgroup_check(su->suite, d_b, nb, d_flag, su->stream, d_rec, (uint32_t)TPI);
-      launch_g1_lincomb(su->suite, d_b, d_s, n, (uint32_t)TPI, 11, d_pts, su->stream);
+      launch_g1_bases(su->curve, d_xy, nb, d_b, d_flag, su->stream);
+      launch_g1_subgroup_check(su->curve, d_b, nb, d_flag, su->stream, d_rec, (uint32_t)TPI);
+      launch_g1_lincomb(su->curve, d_b, d_s, n, (uint32_t)TPI, 11, d_pts, su->stream);
       launch_pairing_check(su->ptab, d_pts, n, d_ok, su->stream);
       std::vector<int32_t> okv(n), rec(n);
       HIP_CHECK(hipMemcpyAsync(okv.data(), d_ok, n * 4, hipMemcpyDeviceToHost, su->stream));
@@ -1375,6 +1376,11 @@ template <class S, class G> struct Ring {
 
 using RingB = Ring<SuiteBandersnatch, G1Bls12381>;
 using RingJ = Ring<SuiteBabyJubJub, G1Bn254>;
+using RingK = Ring<SuiteJubJub, G1Bls12381>;        // JubJub-SHA512-TAI over BLS12-381 (src/suites/jubjub.rs:76-95)
+template <class R> struct RingTag { using type = R; };
+template <class F> static auto with_ring(int suite, F &&f) {
+  switch (suite) { case 1: return f(RingTag<RingJ>{}); case 2: return f(RingTag<RingK>{}); default: return f(RingTag<RingB>{}); }
+}
 
 }  // namespace
 
@@ -1389,14 +1395,14 @@ extern "C" {
 int avrf_ring_setup_load(avrf_ctx *ctx, const uint8_t *srs, size_t srs_len, size_t ring_size, avrf_ring_setup **out) {
   if (!ctx || !srs || !out || ring_size == 0) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
-  return guarded([&] { return avrf_ctx_suite_(ctx) == 0 ? RingB::setup_load(ctx, srs, srs_len, ring_size, out) : RingJ::setup_load(ctx, srs, srs_len, ring_size, out); });
+  return guarded([&] { return with_ring(avrf_ctx_suite_(ctx), [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::setup_load(ctx, srs, srs_len, ring_size, out); }); });
 }
 int avrf_ring_srs_generate(avrf_ctx *ctx, const uint8_t *tau, const uint8_t *g1, const uint8_t *g2, size_t n_g1, uint8_t *out, size_t out_cap, size_t *out_len) {
   if (!ctx || !tau || !g1 || !g2) return AVRF_ERR_BAD_ARG;
-  return guarded([&] { return avrf_ctx_suite_(ctx) == 0 ? RingB::srs_generate(ctx, tau, g1, g2, n_g1, out, out_cap, out_len) : RingJ::srs_generate(ctx, tau, g1, g2, n_g1, out, out_cap, out_len); });
+  return guarded([&] { return with_ring(avrf_ctx_suite_(ctx), [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::srs_generate(ctx, tau, g1, g2, n_g1, out, out_cap, out_len); }); });
 }
 size_t avrf_ring_pcs_domain_size(int suite, size_t ring_size) {       /* pcs_domain_size, src/ring.rs:810-817: 3 * piop_domain + 1 */
-  const size_t L = suite == 0 ? (size_t)SuiteBandersnatch::Fr::BITS : (size_t)SuiteBabyJubJub::Fr::BITS;
+  const size_t L = with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return (size_t)S::Fr::BITS; });
   size_t need = ring_size + 4 + L, N = 1; while (N < need) N <<= 1;
   return 3 * N + 1;
 }
@@ -1419,17 +1425,17 @@ void avrf_ring_setup_free(avrf_ring_setup *su) {
 }
 size_t avrf_ring_max_ring_size(const avrf_ring_setup *su) { return su ? su->keyset : 0; }
 size_t avrf_ring_domain_size(const avrf_ring_setup *su) { return su ? su->N : 0; }
-size_t avrf_ring_proof_len(const avrf_ring_setup *su) { return su ? (su->suite == 0 ? 592 : 480) : 0; }
-size_t avrf_ring_commitment_len(const avrf_ring_setup *su) { return su ? (su->suite == 0 ? 144 : 96) : 0; }
+size_t avrf_ring_proof_len(const avrf_ring_setup *su) { return su ? (su->curve == 0 ? 592 : 480) : 0; }
+size_t avrf_ring_commitment_len(const avrf_ring_setup *su) { return su ? (su->curve == 0 ? 144 : 96) : 0; }
 
 int avrf_ring_index(avrf_ring_setup *su, const uint8_t *pks_xy, size_t n_keys, avrf_ring_key **out, uint8_t *commitment_out) {
   if (!su || !out || (n_keys && !pks_xy)) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
-  int st = guarded([&] { return su->suite == 0 ? RingB::index(su, pks_xy, n_keys, out) : RingJ::index(su, pks_xy, n_keys, out); });
+  int st = guarded([&] { return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::index(su, pks_xy, n_keys, out); }); });
   if (st == AVRF_OK && commitment_out) {
     std::vector<uint8_t> b;
-    for (int i = 0; i < 3; i++) { if (su->suite == 0) g1_encode<G1Bls12381>((*out)->C[i], true, b); else g1_encode<G1Bn254>((*out)->C[i], true, b); }
+    for (int i = 0; i < 3; i++) { if (su->curve == 0) g1_encode<G1Bls12381>((*out)->C[i], true, b); else g1_encode<G1Bn254>((*out)->C[i], true, b); }
     memcpy(commitment_out, b.data(), b.size());
   }
   return st;
@@ -1440,19 +1446,19 @@ int avrf_ring_vk_builder_new(avrf_ring_setup *su, avrf_ring_vk_builder **out) {
   if (!su || !out) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
-  return guarded([&] { return su->suite == 0 ? RingB::builder_new(su, out) : RingJ::builder_new(su, out); });
+  return guarded([&] { return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::builder_new(su, out); }); });
 }
 void avrf_ring_vk_builder_free(avrf_ring_vk_builder *b) { delete b; }
 size_t avrf_ring_vk_builder_free_slots(const avrf_ring_vk_builder *b) { return b ? b->setup->keyset - b->curr : 0; }
 int avrf_ring_vk_builder_append(avrf_ring_vk_builder *b, const uint8_t *pks_xy, size_t n) {
   if (!b || (n && !pks_xy)) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(b->setup->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
-  return guarded([&] { return b->setup->suite == 0 ? RingB::builder_append(b, pks_xy, n) : RingJ::builder_append(b, pks_xy, n); });
+  return guarded([&] { return with_ring(b->setup->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::builder_append(b, pks_xy, n); }); });
 }
 int avrf_ring_vk_builder_finalize(const avrf_ring_vk_builder *b, uint8_t *commitment_out) {
   if (!b || !commitment_out) return AVRF_ERR_BAD_ARG;
   std::vector<uint8_t> o;
-  for (int i = 0; i < 3; i++) { if (b->setup->suite == 0) g1_encode<G1Bls12381>(b->C[i], true, o); else g1_encode<G1Bn254>(b->C[i], true, o); }
+  for (int i = 0; i < 3; i++) { if (b->setup->curve == 0) g1_encode<G1Bls12381>(b->C[i], true, o); else g1_encode<G1Bn254>(b->C[i], true, o); }
   memcpy(commitment_out, o.data(), o.size());
   return AVRF_OK;
 }
@@ -1461,15 +1467,14 @@ int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const
   if (!k || (n && (!key_index || !blindings || !proofs_out))) return AVRF_ERR_BAD_ARG;
   if (blinding_mode != 0 && blinding_mode != 1) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(k->setup->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
-  const size_t plen = k->setup->suite == 0 ? 592 : 480;
+  const size_t plen = k->setup->curve == 0 ? 592 : 480;
   size_t chunk = 512;                                                  // proofs proved in lockstep per device round
   if (const char *e = getenv("AVRF_RING_CHUNK")) { long v = atol(e); if (v >= 1 && v <= 4096) chunk = (size_t)v; }   // (test hook: re-read per call)
   avrf_ring_setup *su = k->setup;
   auto run = [&](avrf_ring_setup *lane, size_t i) {
     const size_t m = n - i < chunk ? n - i : chunk;
     return guarded([&] {
-      return su->suite == 0 ? RingB::prove_chunk(k, lane, m, key_index + i, blindings + 32 * i, blinding_mode == 1, proofs_out + plen * i)
-                            : RingJ::prove_chunk(k, lane, m, key_index + i, blindings + 32 * i, blinding_mode == 1, proofs_out + plen * i); });
+      return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::prove_chunk(k, lane, m, key_index + i, blindings + 32 * i, blinding_mode == 1, proofs_out + plen * i); }); });
   };
   const char *le = getenv("AVRF_RING_LANES"); const bool one_lane = le && atoi(le) == 1;
   if (n <= chunk || one_lane) {
@@ -1478,7 +1483,7 @@ int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const
   }
   // two chunks in flight: chunks alternate between the setup's own stream/scratch and its second lane
   avrf_ring_setup *lanes[2] = {su, nullptr};
-  if (int st = guarded([&] { lanes[1] = su->suite == 0 ? RingB::second_lane(su) : RingJ::second_lane(su); return (int)AVRF_OK; })) return st;
+  if (int st = guarded([&] { lanes[1] = with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::second_lane(su); }); return (int)AVRF_OK; })) return st;
   std::atomic<int> status{AVRF_OK};
   std::thread th[2];
   for (int t = 0; t < 2; t++) th[t] = std::thread([&, t] {
@@ -1498,14 +1503,14 @@ static int copy_out(const std::vector<uint8_t> &v, uint8_t *out, size_t cap, siz
 int avrf_ring_setup_serialize(avrf_ring_setup *su, int compress, uint8_t *out, size_t out_cap, size_t *out_len) {
   if (!su) return AVRF_ERR_BAD_ARG;
   std::vector<uint8_t> v;
-  int st = guarded([&] { return su->suite == 0 ? RingB::setup_serialize(su, compress != 0, v) : RingJ::setup_serialize(su, compress != 0, v); });
+  int st = guarded([&] { return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::setup_serialize(su, compress != 0, v); }); });
   return st ? st : copy_out(v, out, out_cap, out_len);
 }
 int avrf_ring_builder_params_serialize(avrf_ring_setup *su, int compress, uint8_t *out, size_t out_cap, size_t *out_len) {
   if (!su) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   std::vector<uint8_t> v;
-  int st = guarded([&] { return su->suite == 0 ? RingB::builder_params_serialize(su, compress != 0, v) : RingJ::builder_params_serialize(su, compress != 0, v); });
+  int st = guarded([&] { return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::builder_params_serialize(su, compress != 0, v); }); });
   return st ? st : copy_out(v, out, out_cap, out_len);
 }
 
@@ -1514,14 +1519,13 @@ int avrf_ring_verify_each(avrf_ring_setup *su, size_t n, const uint8_t *ring_com
   if (!su || (n && (!ring_commitments || !n_rings || !instances_xy || !ring_proofs || !status_out))) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   return guarded([&] {
-    return su->suite == 0 ? RingB::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs, status_out)
-                          : RingJ::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs, status_out); });
+    return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs, status_out); }); });
 }
 
 int avrf_ring_pairing_check(avrf_ring_setup *su, size_t n, const uint8_t *a_xy, const uint8_t *b_xy, int32_t *ok_out) {
   if (!su || (n && (!a_xy || !b_xy || !ok_out))) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
-  return guarded([&] { return su->suite == 0 ? RingB::pairing_check(su, n, a_xy, b_xy, ok_out) : RingJ::pairing_check(su, n, a_xy, b_xy, ok_out); });
+  return guarded([&] { return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::pairing_check(su, n, a_xy, b_xy, ok_out); }); });
 }
 
 int avrf_ring_batch_verify(avrf_ring_setup *su, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,
@@ -1529,8 +1533,7 @@ int avrf_ring_batch_verify(avrf_ring_setup *su, size_t n, const uint8_t *ring_co
   if (!su || (n && (!ring_commitments || !n_rings || !instances_xy || !ring_proofs))) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   return guarded([&] {
-    return su->suite == 0 ? RingB::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs)
-                          : RingJ::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs); });
+    return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs); }); });
 }
 
 }  // extern "C"

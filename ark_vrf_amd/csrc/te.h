@@ -20,6 +20,7 @@ template <class S> AVRF_DI fp mul_a(const fp &v) {
   if (S::A_KIND == 1) {  // a = -5
     fp t = fp_dbl<Fq>(v); t = fp_dbl<Fq>(t); t = fp_add<Fq>(t, v); return fp_neg<Fq>(t);
   }
+  if (S::A_KIND == 2) return fp_neg<Fq>(v);  // a = -1 (JubJub)
   return v;  // a = 1
 }
 

@@ -9,6 +9,7 @@
 // 8 x u32 Montgomery form (fp256.h).
 #include "vrf_batch.h"
 #include "proto_dev.h"
+#include "suite_dispatch.h"
 
 namespace avrf {
 
@@ -236,43 +237,34 @@ k_ped_terms(BatchDev b, Seed64 seed, uint64_t j0, const uint32_t *__restrict__ c
 void launch_ped_prepare(int suite, const BatchDev &b, uint32_t *d_c, uint8_t *d_merged, uint32_t *d_flags, hipStream_t st) {
   if (!b.n) return;
   dim3 g((b.n + 127) / 128), blk(128);
-  if (suite == 0) hipLaunchKernelGGL(k_ped_prepare<SuiteBandersnatch>, g, blk, 0, st, b, d_c, d_merged, d_flags);
-  else hipLaunchKernelGGL(k_ped_prepare<SuiteBabyJubJub>, g, blk, 0, st, b, d_c, d_merged, d_flags);
+  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type;
+    hipLaunchKernelGGL(k_ped_prepare<S>, g, blk, 0, st, b, d_c, d_merged, d_flags); });
 }
 void launch_ped_terms(int suite, const BatchDev &b, const Seed64 &seed, uint64_t j0, const uint32_t *d_c, const uint8_t *d_merged,
                       uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st) {
   if (!b.n) return;
   dim3 g((b.n + 127) / 128), blk(128);
   uint32_t *bp = d_gpart + 8 * (size_t)g.x;
-  if (suite == 0) {
-    hipLaunchKernelGGL(k_ped_terms<SuiteBandersnatch>, g, blk, 0, st, b, seed, j0, d_c, d_merged, d_scalars, (te_pre *)d_pre, d_gpart, bp);
-    hipLaunchKernelGGL(k_g_final<SuiteBandersnatch>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 2, 0);
-    hipLaunchKernelGGL(k_g_final<SuiteBandersnatch>, dim3(1), dim3(256), 0, st, bp, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 1);
-  } else {
-    hipLaunchKernelGGL(k_ped_terms<SuiteBabyJubJub>, g, blk, 0, st, b, seed, j0, d_c, d_merged, d_scalars, (te_pre *)d_pre, d_gpart, bp);
-    hipLaunchKernelGGL(k_g_final<SuiteBabyJubJub>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 2, 0);
-    hipLaunchKernelGGL(k_g_final<SuiteBabyJubJub>, dim3(1), dim3(256), 0, st, bp, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 1);
-  }
+  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type;
+    hipLaunchKernelGGL(k_ped_terms<S>, g, blk, 0, st, b, seed, j0, d_c, d_merged, d_scalars, (te_pre *)d_pre, d_gpart, bp);
+    hipLaunchKernelGGL(k_g_final<S>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 2, 0);
+    hipLaunchKernelGGL(k_g_final<S>, dim3(1), dim3(256), 0, st, bp, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 1); });
 }
 
 void launch_thin_prepare(int suite, const BatchDev &b, uint32_t *d_c, uint32_t *d_z, uint32_t *d_flags, hipStream_t st) {
   if (!b.n) return;
   dim3 g((b.n + 127) / 128), blk(128);
-  if (suite == 0) hipLaunchKernelGGL(k_thin_prepare<SuiteBandersnatch>, g, blk, 0, st, b, d_c, d_z, d_flags);
-  else hipLaunchKernelGGL(k_thin_prepare<SuiteBabyJubJub>, g, blk, 0, st, b, d_c, d_z, d_flags);
+  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type;
+    hipLaunchKernelGGL(k_thin_prepare<S>, g, blk, 0, st, b, d_c, d_z, d_flags); });
 }
 
 void launch_thin_terms(int suite, const BatchDev &b, const Seed64 &seed, uint64_t j0, const uint32_t *d_c, const uint32_t *d_z,
                        uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st) {
   if (!b.n) return;
   dim3 g((b.n + 127) / 128), blk(128);
-  if (suite == 0) {
-    hipLaunchKernelGGL(k_thin_terms<SuiteBandersnatch>, g, blk, 0, st, b, seed, j0, d_c, d_z, d_scalars, (te_pre *)d_pre, d_gpart);
-    hipLaunchKernelGGL(k_g_final<SuiteBandersnatch>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 0);
-  } else {
-    hipLaunchKernelGGL(k_thin_terms<SuiteBabyJubJub>, g, blk, 0, st, b, seed, j0, d_c, d_z, d_scalars, (te_pre *)d_pre, d_gpart);
-    hipLaunchKernelGGL(k_g_final<SuiteBabyJubJub>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 0);
-  }
+  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type;
+    hipLaunchKernelGGL(k_thin_terms<S>, g, blk, 0, st, b, seed, j0, d_c, d_z, d_scalars, (te_pre *)d_pre, d_gpart);
+    hipLaunchKernelGGL(k_g_final<S>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 0); });
 }
 
 }  // namespace avrf

@@ -10,6 +10,7 @@
 // The merged I/O pair follows vrf_transcript_from_iter / merge_ios (src/utils/common.rs:181-202,
 // 389-419); any summation order gives the same group element.
 #include "proto_dev.h"
+#include "suite_dispatch.h"
 
 namespace avrf { struct te_pre_raw; }   // msm.h: the 96-byte storage form of te_pre
 
@@ -373,7 +374,7 @@ k_hash_to_curve(const uint8_t *__restrict__ data, const uint32_t *__restrict__ o
       y.v[7] &= 0xffffffffu >> (256 - Fq::BITS);
       if (ge_p<Fq>(y)) continue;
       fp ym = fp_to_mont<Fq>(y), y2 = fp_sqr<Fq>(ym), one = fp_one<Fq>();
-      fp a_const = S::A_KIND == 1 ? fp_neg<Fq>(fp_add<Fq>(fp_dbl<Fq>(fp_dbl<Fq>(one)), one)) : one;
+      fp a_const = mul_a<S>(one);   // the curve coefficient a (1, -5 or -1)
       fp den = fp_sub<Fq>(a_const, fp_mul<Fq>(fp_const<Fq>(S::D), y2)), xm;
       if (fp_is_zero(den) || !fp_sqrt_nf<Fq>(fp_mul<Fq>(fp_sub<Fq>(one, y2), fp_inv<Fq>(den)), &xm)) continue;
       if (fp_is_negative_mont<Fq>(xm) != neg) xm = fp_neg<Fq>(xm);
@@ -402,7 +403,7 @@ k_decompress(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ o
   else {
     fp ym = fp_to_mont<Fq>(y), y2 = fp_sqr<Fq>(ym), one = fp_one<Fq>();
     fp num = fp_sub<Fq>(one, y2);
-    fp a_const = S::A_KIND == 1 ? fp_neg<Fq>(fp_add<Fq>(fp_dbl<Fq>(fp_dbl<Fq>(one)), one)) : one;
+    fp a_const = mul_a<S>(one);   // the curve coefficient a (1, -5 or -1)
     fp den = fp_sub<Fq>(a_const, fp_mul<Fq>(fp_const<Fq>(S::D), y2));
     fp xm;
     if (fp_is_zero(den) || !fp_sqrt_nf<Fq>(fp_mul<Fq>(num, fp_inv<Fq>(den)), &xm)) st = 2;
@@ -463,10 +464,7 @@ k_compress(const uint8_t *__restrict__ in_xy, uint32_t n, uint8_t *__restrict__ 
 // ---------------------------------------------------------------- launchers
 
 #define AVRF_DISPATCH(suite, KERNEL, grid, block, st, ...)                                          \
-  do {                                                                                              \
-    if ((suite) == 0) hipLaunchKernelGGL(KERNEL<SuiteBandersnatch>, grid, block, 0, st, __VA_ARGS__); \
-    else hipLaunchKernelGGL(KERNEL<SuiteBabyJubJub>, grid, block, 0, st, __VA_ARGS__);                \
-  } while (0)
+  with_suite((suite), [&](auto tag_) { using S_ = typename decltype(tag_)::type; hipLaunchKernelGGL(KERNEL<S_>, grid, block, 0, st, __VA_ARGS__); })
 
 void launch_fixed_table(int suite, struct te_pre_raw *d_tab, hipStream_t st) {
   AVRF_DISPATCH(suite, k_fixed_table, dim3((FIXED_TABLE_POINTS + 127) / 128), dim3(128), st, (te_pre *)d_tab);
@@ -479,10 +477,9 @@ void launch_smul(int suite, const uint8_t *d_scalars, const uint8_t *d_points_xy
 void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny) {
   if (!b.n) return;
   const dim3 g((b.n + 127) / 128), bl(128);
-  if (suite == 0) { if (tiny) hipLaunchKernelGGL((k_thin_prove<SuiteBandersnatch, true>), g, bl, 0, st, b, d_proofs_out, d_flags);
-                    else hipLaunchKernelGGL((k_thin_prove<SuiteBandersnatch, false>), g, bl, 0, st, b, d_proofs_out, d_flags); }
-  else { if (tiny) hipLaunchKernelGGL((k_thin_prove<SuiteBabyJubJub, true>), g, bl, 0, st, b, d_proofs_out, d_flags);
-         else hipLaunchKernelGGL((k_thin_prove<SuiteBabyJubJub, false>), g, bl, 0, st, b, d_proofs_out, d_flags); }
+  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type;
+    if (tiny) hipLaunchKernelGGL((k_thin_prove<S, true>), g, bl, 0, st, b, d_proofs_out, d_flags);
+    else hipLaunchKernelGGL((k_thin_prove<S, false>), g, bl, 0, st, b, d_proofs_out, d_flags); });
 }
 void launch_tiny_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st) {
   if (!b.n) return;

@@ -14,6 +14,7 @@ _SO = os.path.join(_DIR, "_build", "liborc.so")
 
 BANDERSNATCH = 0
 BABYJUBJUB = 1
+JUBJUB = 2
 
 OK, VERIFICATION_FAILURE, INVALID_DATA = 0, 1, 2
 

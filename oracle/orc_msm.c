@@ -27,7 +27,7 @@ typedef struct { u256 x, y, k; } te_pre; /* k = d*x*y */
 
 static void mul_a(u256 *o, const u256 *v, const suite_t *s) {
     if (s->a_is_minus5) { u256 t; mont_add(&t, v, v, FQ); mont_add(&t, &t, &t, FQ); mont_add(&t, &t, v, FQ); mont_neg(o, &t, FQ); }
-    else *o = *v; /* a = 1 */
+    else mont_mul(o, &s->a, v, FQ); /* a = 1 (Baby-JubJub), a = -1 (JubJub) */
 }
 /* madd-2008-hwcd with precomputed k = d*x2*y2: 8M; neg != 0 adds -Q */
 static void madd_pre(te_ext *p, const te_pre *q, int neg, const suite_t *s) {

@@ -6,7 +6,7 @@
  * extended coordinates (X:Y:T:Z), add-2008-hwcd / dbl-2008-hwcd for general `a`.
  * Call sites in the reference: src/lib.rs:332,392 (sk*G, sk*I), src/thin.rs:119,158,
  * src/pedersen.rs:148-167,229-245, src/utils/common.rs:400-404,414.
- * Suite constants: src/suites/bandersnatch.rs:13-14,62-105, src/suites/baby_jubjub.rs:12-13,56-95.
+ * Suite constants: src/suites/bandersnatch.rs:13-14,62-105, src/suites/baby_jubjub.rs:12-13,56-95, src/suites/jubjub.rs:12-13,56-95.
  * Any correct group law yields the same group element; parity is defined on the
  * normalised affine result / its encoding.
  */
@@ -15,7 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-static suite_t g_suites[2];
+static suite_t g_suites[3];
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;      /* gen_batch() calls in from several threads at once */
 
 static void fq_dec(u256 *o, const char *dec, const mont_t *m) {
@@ -73,11 +73,32 @@ static void init_suites(void) {
     fq_dec(&s->ACC.y, "9735581299071570006712034490635195155689931359428941496570758703259384062170", &s->fq);
     fq_dec(&s->PAD.x, "11167490195257431015694161063225325511805242064780376648595733691987293447528", &s->fq);
     fq_dec(&s->PAD.y, "18403369502642103292159933062507105566469227524991433735553439433605496057425", &s->fq);
+
+    /* ---- JubJub-SHA512-TAI-v1 (src/suites/jubjub.rs:56-95; curve: ark-ed-on-bls12-381, a = -1, d = -(10240/10241)) ---- */
+    s = &g_suites[2];
+    memset(s, 0, sizeof *s);
+    s->id = ORC_SUITE_JUBJUB;
+    s->suite_id = "JubJub-SHA512-TAI-v1"; s->suite_id_len = 20;
+    u256_from_dec(&p, "52435875175126190479447740508185965837690552500527637822603658699938581184513");
+    mont_init(&s->fq, &p);
+    u256_from_dec(&p, "6554484396890773809930967563523245729705921265872317281365359162392183254199");
+    mont_init(&s->fr, &p);
+    { u256 one; fq_small(&one, 1, &s->fq); mont_neg(&s->a, &one, &s->fq); }
+    fq_dec(&s->d, "19257038036680949359750312669786877991949435402254120286184196891950884077233", &s->fq);
+    s->cofactor = 8; s->h2c = ORC_H2C_TAI;
+    fq_dec(&s->G.x, "8076246640662884909881801758704306714034609987455869804520522091855516602923", &s->fq);
+    fq_dec(&s->G.y, "13262374693698910701929044844600465831413122818447359594527400194675274060458", &s->fq);
+    fq_dec(&s->B.x, "38206460563694846719174258613922853630278999941532690543235578292520143148532", &s->fq);
+    fq_dec(&s->B.y, "34254498978062207918041301829525626783549813531091321004550549786528984401675", &s->fq);
+    fq_dec(&s->ACC.x, "48142684311216766702182564801462043940571084233680216669499475549492432046964", &s->fq);
+    fq_dec(&s->ACC.y, "34380560660182334518990118617091967209302636551264477863958902286043397647879", &s->fq);
+    fq_dec(&s->PAD.x, "17348704025397475127937572481155408456556065464328870407269802701696798733683", &s->fq);
+    fq_dec(&s->PAD.y, "24318278422173803457621119807961883607097742387673491974779969503617097905596", &s->fq);
 }
 
 const suite_t *orc_suite(int id) {
     pthread_once(&g_once, init_suites);
-    if (id < 0 || id > 1) return NULL;
+    if (id < 0 || id > 2) return NULL;
     return &g_suites[id];
 }
 

@@ -66,7 +66,24 @@ def _bjj():
     return s
 
 
-SUITES = {0: _bander(), 1: _bjj()}
+def _jubjub():
+    """JubJub-SHA512-TAI-v1 (src/suites/jubjub.rs:56-95): twisted Edwards a = -1 over Fr(BLS12-381), ring proofs over BLS12-381."""
+    s = _bander()
+    s.name = "jubjub"
+    s.suite_id = b"JubJub-SHA512-TAI-v1"
+    s.te_a = s.r - 1
+    s.te_d = 19257038036680949359750312669786877991949435402254120286184196891950884077233
+    s.te_order_bits = 252
+    s.blinding_base = (38206460563694846719174258613922853630278999941532690543235578292520143148532,
+                       34254498978062207918041301829525626783549813531091321004550549786528984401675)
+    s.accumulator_base = (48142684311216766702182564801462043940571084233680216669499475549492432046964,
+                          34380560660182334518990118617091967209302636551264477863958902286043397647879)
+    s.padding = (17348704025397475127937572481155408456556065464328870407269802701696798733683,
+                 24318278422173803457621119807961883607097742387673491974779969503617097905596)
+    return s
+
+
+SUITES = {0: _bander(), 1: _bjj(), 2: _jubjub()}
 
 # ---- twisted Edwards (affine, big-int)
 

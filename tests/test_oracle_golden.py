@@ -16,6 +16,7 @@ import oracle as orc
 SUITES = {
     "bandersnatch_sha-512_ell2": orc.BANDERSNATCH,
     "baby-jubjub_sha-512_tai": orc.BABYJUBJUB,
+    "jubjub_sha-512_tai": orc.JUBJUB,                 # src/suites/jubjub.rs
 }
 SEEDS = [1, 2, 3, 4, 5, 5, 6]
 
@@ -109,11 +110,11 @@ def test_suite_constants(golden_dir, name):
     assert orc.hash_to_curve(s, b"ring-padding") == orc.suite_point(s, 3)
 
 
-@pytest.mark.parametrize("name", ["bandersnatch_sha-512_ell2", "baby-jubjub_sha-512_tai"])
+@pytest.mark.parametrize("name", list(SUITES))
 def test_tiny_vectors(golden_dir, name):
     """Tiny VRF (src/tiny.rs:163-214): proof_c / proof_s of the reference's `*_tiny.json`, prove and verify."""
     import json, os
-    s = SUITES[name] if "SUITES" in globals() else (0 if name.startswith("bander") else 1)
+    s = SUITES[name]
     vs = json.load(open(os.path.join(golden_dir, name + "_tiny.json")))
     assert len(vs) == 7
     for v in vs:

@@ -10,7 +10,8 @@ import pytest
 from oracle import ring_py as R
 
 FILES = {0: ("bandersnatch_sha-512_ell2_ring.json", "bls12-381-srs-2-11-uncompressed-zcash.bin"),
-         1: ("baby-jubjub_sha-512_tai_ring.json", "bn254-testing-2-9-uncompressed.bin")}
+         1: ("baby-jubjub_sha-512_tai_ring.json", "bn254-testing-2-9-uncompressed.bin"),
+         2: ("jubjub_sha-512_tai_ring.json", "bls12-381-srs-2-11-uncompressed-zcash.bin")}
 
 
 @pytest.fixture(scope="module")
@@ -25,7 +26,7 @@ def setups(golden_dir):
 
 def test_domain_sizes(setups):
     # src/ring.rs:810-843: piop = next_pow2(ring + 4 + L); pcs = 3*piop + 1
-    for i, L in ((0, 253), (1, 251)):
+    for i, L in ((0, 253), (1, 251), (2, 252)):
         s = R.SUITES[i]
         assert R.Params(s, ring_size=8).N == 512
         assert R.Params(s, ring_size=1024).N == 2048
@@ -34,8 +35,7 @@ def test_domain_sizes(setups):
         assert p.keyset_part_size == 512 - 4 - L and p.capacity == 509
 
 
-@pytest.mark.parametrize("suite", [0, 1])
-@pytest.mark.parametrize("vec", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("suite,vec", [(s, v) for s in (0, 1) for v in range(7)] + [(2, 0), (2, 4)])
 def test_ring_commitment_and_proof(setups, suite, vec):
     s, srs, vs, prm = setups[suite]
     v = vs[vec]
