@@ -6,6 +6,7 @@
 //   ark_vrf::Suite                         -> avrf::Suite            (src/lib.rs:177-250)
 //   ark_vrf::{Secret, Public, VrfIo}       -> avrf::Secret / Public / VrfIo   (src/lib.rs:258-635)
 //   ark_vrf::Error                         -> avrf::Error            (src/lib.rs:135-147)
+//   tiny::{Proof, Prover, Verifier}                    -> avrf::tiny::...     (src/tiny.rs:48-214)
 //   thin::{Proof, Prover, Verifier, BatchVerifier}     -> avrf::thin::...     (src/thin.rs:43-326)
 //   pedersen::{Proof, Prover, Verifier, BatchVerifier} -> avrf::pedersen::... (src/pedersen.rs:69-426)
 //   ring::{RingSetup, RingProverKey, RingVerifierKey, RingProver, RingVerifier, Proof, Prover, Verifier,
@@ -35,7 +36,10 @@ struct VrfIo { Point input, output; };   // src/lib.rs:615-619
 // trait Suite: a context binds the suite parameterisation to one GPU stream.
 class Suite {
  public:
-  enum Id { BandersnatchSha512Ell2 = AVRF_SUITE_BANDERSNATCH_SHA512_ELL2, BabyJubJubSha512Tai = AVRF_SUITE_BABYJUBJUB_SHA512_TAI };
+  enum Id { BandersnatchSha512Ell2 = AVRF_SUITE_BANDERSNATCH_SHA512_ELL2, BabyJubJubSha512Tai = AVRF_SUITE_BABYJUBJUB_SHA512_TAI,
+            JubJubSha512Tai = AVRF_SUITE_JUBJUB_SHA512_TAI };
+  // whose job is Validate::Yes? 0: the caller's (typed-point contract of the reference), 1: on-curve check, 2: + subgroup check
+  void set_validation(int level) { if (avrf_ctx_set_validation(ctx_, level) != AVRF_OK) throw std::invalid_argument("avrf: validation level"); }
   explicit Suite(Id id, int device = 0) {
     if (avrf_ctx_create(id, device, &ctx_) != AVRF_OK) throw std::runtime_error("avrf: no MI355X device (there is no CPU fallback)");
   }
@@ -83,6 +87,30 @@ struct Packed {
   }
 };
 }  // namespace detail
+
+namespace tiny {
+
+struct Proof { std::array<uint8_t, 16> c; Scalar s; };     // src/tiny.rs:48-53  (wire: c(16) || s(32), src/tiny.rs:60-78)
+
+// tiny::Prover::prove for Secret (src/tiny.rs:163-176)
+inline Proof prove(const Suite &su, const Secret &sk, const std::vector<VrfIo> &ios, const std::string &ad) {
+  detail::Packed p; p.push(ios, ad);
+  uint8_t out[48];
+  if (avrf_tiny_prove(su.ctx(), 1, sk.scalar.data(), sk.public_key.point.data(), p.ios.data(), p.io_counts.data(), p.ads.data(), p.ad_lens.data(), out) != AVRF_OK)
+    throw std::invalid_argument("avrf: tiny prove");
+  Proof pr; std::copy(out, out + 16, pr.c.begin()); std::copy(out + 16, out + 48, pr.s.begin());
+  return pr;
+}
+// tiny::Verifier::verify for Public (src/tiny.rs:178-214)
+inline Status verify(const Suite &su, const Public &pk, const std::vector<VrfIo> &ios, const std::string &ad, const Proof &proof) {
+  detail::Packed p; p.push(ios, ad);
+  uint8_t pr[48]; std::copy(proof.c.begin(), proof.c.end(), pr); std::copy(proof.s.begin(), proof.s.end(), pr + 16);
+  int32_t st = 0;
+  int rc = avrf_tiny_verify(su.ctx(), 1, pk.point.data(), p.ios.data(), p.io_counts.data(), p.ads.data(), p.ad_lens.data(), pr, &st);
+  return rc != AVRF_OK ? rc : st;
+}
+
+}  // namespace tiny
 
 namespace thin {
 

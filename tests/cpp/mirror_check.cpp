@@ -28,6 +28,12 @@ int main(int argc, char **argv) {
   VrfIo io = secret.vrf_io(su, in);
   put("pk", pub.point); put("output", io.output);
 
+  tiny::Proof yp = tiny::prove(su, secret, {io}, ad);                    // src/tiny.rs tests: prove_verify
+  put("tiny_c", yp.c); put("tiny_s", yp.s);
+  printf("tiny_verify=%d\n", tiny::verify(su, pub, {io}, ad, yp));
+  printf("tiny_verify_bad_ad=%d\n", tiny::verify(su, pub, {io}, ad + "x", yp));
+  { tiny::Proof b = yp; b.c[3] ^= 1; printf("tiny_verify_bad_c=%d\n", tiny::verify(su, pub, {io}, ad, b)); }
+
   thin::Proof tp = thin::prove(su, secret, {io}, ad);
   put("thin_r", tp.r); put("thin_s", tp.s);
   printf("thin_verify=%d\n", thin::verify(su, pub, {io}, ad, tp));

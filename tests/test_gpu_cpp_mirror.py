@@ -11,7 +11,7 @@ from conftest import ROOT
 from helpers import xy
 
 pytestmark = pytest.mark.gpu
-NAMES = {0: "bandersnatch_sha-512_ell2", 1: "baby-jubjub_sha-512_tai"}
+NAMES = {0: "bandersnatch_sha-512_ell2", 1: "baby-jubjub_sha-512_tai", 2: "jubjub_sha-512_tai"}
 
 
 @pytest.fixture(scope="module")
@@ -23,16 +23,19 @@ def exe(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("suite", [0, 1])
+@pytest.mark.parametrize("suite", [0, 1, 2])
 def test_mirror_reproduces_vectors(exe, golden_dir, suite):
     vt = json.load(open(os.path.join(golden_dir, NAMES[suite] + "_thin.json")))
     vp = json.load(open(os.path.join(golden_dir, NAMES[suite] + "_pedersen.json")))
-    for t, p in list(zip(vt, vp))[:3]:
+    vy = json.load(open(os.path.join(golden_dir, NAMES[suite] + "_tiny.json")))
+    for t, p, y in list(zip(vt, vp, vy))[:3]:
         res = subprocess.run([exe, str(suite), t["sk"], xy(suite, bytes.fromhex(t["h"])).hex(), t["ad"] or ""],
                              capture_output=True, text=True, check=True).stdout
         kv = dict(line.split("=", 1) for line in res.strip().splitlines())
         comp = lambda k: orc.point_compress(suite, bytes.fromhex(kv[k])).hex()
         assert comp("pk") == t["pk"] and comp("output") == t["gamma"]
+        assert kv["tiny_c"] == y["proof_c"] and kv["tiny_s"] == y["proof_s"]
+        assert [kv[k] for k in ("tiny_verify", "tiny_verify_bad_ad", "tiny_verify_bad_c")] == ["0", "1", "1"]
         assert comp("thin_r") == t["proof_r"] and kv["thin_s"] == t["proof_s"]
         assert comp("ped_pk_com") == p["proof_pk_com"] and comp("ped_r") == p["proof_r"] and comp("ped_ok") == p["proof_ok"]
         assert kv["ped_s"] == p["proof_s"] and kv["ped_sb"] == p["proof_sb"] and kv["ped_blinding"] == p["blinding"]
@@ -40,12 +43,12 @@ def test_mirror_reproduces_vectors(exe, golden_dir, suite):
         assert [kv[k] for k in ("ped_verify", "ped_batch", "ped_batch_bad")] == ["0", "0", "1"]
 
 
-@pytest.mark.parametrize("suite", [0, 1])
+@pytest.mark.parametrize("suite", [0, 1, 2])
 def test_mirror_ring(exe, golden_dir, suite):
     """ring::{RingSetup, prover_key, Prover::prove, Verifier::verify, BatchVerifier} through the C++ mirror reproduce the
     reference's ring vector (commitment + deterministic ring proof) and its accept / reject behaviour."""
     v = json.load(open(os.path.join(golden_dir, NAMES[suite] + "_ring.json")))[0]
-    srs = os.path.join(golden_dir, ["bls12-381-srs-2-11-uncompressed-zcash.bin", "bn254-testing-2-9-uncompressed.bin"][suite])
+    srs = os.path.join(golden_dir, ["bls12-381-srs-2-11-uncompressed-zcash.bin", "bn254-testing-2-9-uncompressed.bin", "bls12-381-srs-2-11-uncompressed-zcash.bin"][suite])
     raw = bytes.fromhex(v["ring_pks"])
     pks = [xy(suite, raw[32 * i: 32 * i + 32]) for i in range(len(raw) // 32)]
     idx = pks.index(xy(suite, bytes.fromhex(v["pk"])))

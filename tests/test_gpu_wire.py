@@ -123,3 +123,31 @@ def test_ring_vrf_one_call(ctxs, golden_dir, suite):
     ios_bad = list(ios_w); ios_bad[1] = ios_w[1][:32] + ios_w[2][32:]                                  # wrong output
     assert verify(proofs, True, ios=ios_bad)[1] == [0, 1, 0, 0, 0, 0, 0]
     setup.close()
+
+
+def test_empty_and_bad_arguments(ctxs, golden_dir):
+    """Empty batches are Ok(()) everywhere (src/thin.rs:262-264, src/pedersen.rs:343-345); out-of-range ring indices and NULL
+    arguments are AVRF_ERR_BAD_ARG, never a crash."""
+    from ark_vrf_amd import _native as nat
+    from ark_vrf_amd.ring import RingSetup, pairing_check, ring_batch_verify, ring_verify_each
+    c = ctxs[0]
+    L = nat.lib()
+    z8, z32 = nat._u8(b""), nat._u32([])
+    assert L.avrf_thin_batch_verify_wire(c._h, C.c_size_t(0), z8, z8, z32, z8, z32, z8, 1) == 0
+    assert L.avrf_pedersen_batch_verify_wire(c._h, C.c_size_t(0), z8, z32, z8, z32, z8, 1) == 0
+    out = (C.c_int32 * 1)()
+    assert L.avrf_thin_verify_wire(c._h, C.c_size_t(0), z8, z8, z32, z8, z32, z8, 0, out) == 0
+    assert L.avrf_tiny_verify_wire(c._h, C.c_size_t(0), z8, z8, z32, z8, z32, z8, 0, out) == 0
+    assert L.avrf_thin_verify_wire(c._h, C.c_size_t(1), None, z8, z32, z8, z32, z8, 0, out) == nat.ERR_BAD_ARG
+    srs = open(os.path.join(golden_dir, "bls12-381-srs-2-11-uncompressed-zcash.bin"), "rb").read()
+    setup = RingSetup(c, srs, 8)
+    assert pairing_check(setup, [], []) == [] and ring_verify_each(setup, [], None, [], []) == []
+    v = json.load(open(os.path.join(golden_dir, NAMES[0] + "_ring.json")))[0]
+    from helpers import xy
+    com, inst, proof = bytes.fromhex(v["ring_pks_com"]), xy(0, bytes.fromhex(v["proof_pk_com"])), bytes.fromhex(v["ring_proof"])
+    assert ring_batch_verify(setup, [com], [5], [inst], [proof]) == nat.ERR_BAD_ARG           # ring index out of range
+    with pytest.raises(nat.AvrfError, match="-> -2"):
+        ring_verify_each(setup, [com], [1], [inst], [proof])
+    assert L.avrf_ring_vrf_verify(c._h, setup._h, C.c_size_t(0), None, C.c_size_t(0), None, None, None, None, None, None, 1, 1, None) == 0
+    assert L.avrf_ctx_set_validation(c._h, 7) == nat.ERR_BAD_ARG
+    setup.close()
