@@ -136,7 +136,7 @@ hipStream_t avrf_ctx_stream_(avrf_ctx *c) { return c->stream; }
 int avrf_ctx_suite_(avrf_ctx *c) { return c->suite; }
 int avrf_ctx_device_(avrf_ctx *c) { return c->device; }
 
-const char *avrf_version(void) { return "avrf 0.2 (gfx950; te-msm, thin/pedersen prove+verify+batch)"; }
+const char *avrf_version(void) { return "avrf 0.3 (gfx950; tiny/thin/pedersen/ring VRF over Bandersnatch, Baby-JubJub, JubJub; device pairing)"; }
 
 int avrf_device_count(void) {
   int n = 0;
