@@ -1129,6 +1129,25 @@ template <class S, class G> struct Ring {
     memcpy(out->xy, x.l, FQB); memcpy(out->xy + FQB, yp.l, FQB);
     return true;
   }
+  // The same subgroup test as k_g1_subgroup_bls (phi(P) = [-z^2] P) on the host, for small batches: one lane of the device
+  // needs 2.8 ms for the two 64-bit ladders however few points there are; a host core does them in ~0.1 ms per point.
+  static bool g1_in_subgroup_host(const G1Aff &a) {
+    if (FQB != 48 || a.inf) return true;                              // BN254 G1 has cofactor 1
+    using HG = typename T::HG;
+    static const uint32_t BETA[12] = {0x798a64e8, 0x30f1361b, 0x7ece5a2a, 0xf3b8ddab, 0xc61577f7, 0x16a8ca3a,
+                                      0x74fd029b, 0xc26a2ff8, 0x60701c6e, 0x3636b766, 0x241b6160, 0x051ba4ab};
+    QEl beta; memcpy(beta.l, BETA, sizeof BETA > sizeof beta.l ? sizeof beta.l : sizeof BETA);
+    QEl x, y; memset(&x, 0, sizeof x); memset(&y, 0, sizeof y); memcpy(x.l, a.xy, FQB); memcpy(y.l, a.xy + FQB, FQB);
+    typename HG::Pt p; p.x = FqN::to_mont(x); p.y = FqN::to_mont(y); p.zz = FqN::one(); p.zzz = FqN::one();
+    const uint64_t z = 0xd201000000010000ull;
+    typename HG::Pt q = p;
+    for (int b = 62; b >= 0; b--) { q = HG::dbl(q); if ((z >> b) & 1) q = HG::add(q, p); }
+    const typename HG::Pt q1 = q;
+    for (int b = 62; b >= 0; b--) { q = HG::dbl(q); if ((z >> b) & 1) q = HG::add(q, q1); }
+    if (HG::is_identity(q)) return false;
+    return FqN::eq(q.x, FqN::mul(FqN::mul(beta, p.x), q.zz)) && FqN::eq(q.y, FqN::neg(FqN::mul(p.y, q.zzz)));
+  }
+
   static G1Aff g1_msm(avrf_ring_setup *su, const std::vector<uint8_t> &bases_xy, const std::vector<H256> &scalars_plain,
                       bool check_subgroup = false, bool *bad_points = nullptr) {
     const size_t n = scalars_plain.size();
@@ -1222,6 +1241,13 @@ template <class S, class G> struct Ring {
     const H256 one = Fr::one();
     std::vector<G1Aff> fixed(3 * n_rings);
     for (size_t i = 0; i < 3 * n_rings; i++) if (!g1_decompress(commitments + FQB * i, &fixed[i])) return AVRF_INVALID_DATA;
+    // Validate::Yes (subgroup) of the deserialised G1 points: on the host pool for small batches, on the device otherwise
+    const bool host_subgroup = FQB == 48 && 10 * n + 3 * n_rings <= 512;
+    if (host_subgroup) {
+      std::atomic<int> badc{0};
+      parallel_for(3 * n_rings, [&](size_t i) { if (!g1_in_subgroup_host(fixed[i])) badc = 1; });
+      if (badc) return AVRF_INVALID_DATA;
+    }
     (void)clen;
     // randomisers: SHAKE128 over everything the batch contains
     // (the statement is bound in full: sizes, the verifier key, which ring every proof is checked against)
@@ -1243,19 +1269,30 @@ template <class S, class G> struct Ring {
     H256 seedx = Fr::from32(S::ACC_X), seedy = Fr::from32(S::ACC_Y);
     std::vector<int32_t> item_st(each_status ? n : 0, 0);
     auto fail = [&](size_t it, int st) { if (each_status) item_st[it] = st; else status = st; };
+    // the 7 G1 points of every proof: decompression (a 381-bit square root each) and, for small batches, the subgroup test,
+    // one host task per POINT so that a single verification spreads over the pool
+    const size_t g1_off[7] = {0, (size_t)FQB, 2 * (size_t)FQB, 3 * (size_t)FQB, 4 * (size_t)FQB + 7 * 32, 5 * (size_t)FQB + 8 * 32, 6 * (size_t)FQB + 8 * 32};
+    std::vector<G1Aff> dec(7 * n); std::vector<uint8_t> dec_ok(7 * n, 0);
+    parallel_for(7 * n, [&](size_t k) {
+      const size_t it = k / 7, j = k % 7;
+      bool ok = g1_decompress(proofs + plen * it + g1_off[j], &dec[k]);
+      if (ok && host_subgroup) ok = g1_in_subgroup_host(dec[k]);
+      dec_ok[k] = ok;
+    });
     parallel_for(n, [&](size_t it) {
       const uint8_t *pr = proofs + plen * it;
       const uint32_t ring = ring_of_item ? ring_of_item[it] : 0;
       if (ring >= n_rings) { status = AVRF_ERR_BAD_ARG; return; }
       const G1Aff *fx = &fixed[3 * ring];
       G1Aff C[4], Cq, pi1, pi2; H256 ev[7], lin_zw;
+      for (int j = 0; j < 7; j++) if (!dec_ok[7 * it + j]) { fail(it, AVRF_INVALID_DATA); return; }
       size_t off = 0;
-      for (int i = 0; i < 4; i++) { if (!g1_decompress(pr + off, &C[i])) { fail(it, AVRF_INVALID_DATA); return; } off += FQB; }
+      for (int i = 0; i < 4; i++) { C[i] = dec[7 * it + i]; off += FQB; }
       for (int i = 0; i < 7; i++) { H256 v = Fr::load_le(pr + off); if (Fr::geq_p(v)) { fail(it, AVRF_INVALID_DATA); return; } ev[i] = Fr::to_mont(v); off += 32; }
-      if (!g1_decompress(pr + off, &Cq)) { fail(it, AVRF_INVALID_DATA); return; } off += FQB;
+      Cq = dec[7 * it + 4]; off += FQB;
       { H256 v = Fr::load_le(pr + off); if (Fr::geq_p(v)) { fail(it, AVRF_INVALID_DATA); return; } lin_zw = Fr::to_mont(v); off += 32; }
-      if (!g1_decompress(pr + off, &pi1)) { fail(it, AVRF_INVALID_DATA); return; } off += FQB;
-      if (!g1_decompress(pr + off, &pi2)) { fail(it, AVRF_INVALID_DATA); return; } off += FQB;
+      pi1 = dec[7 * it + 5]; off += FQB;
+      pi2 = dec[7 * it + 6]; off += FQB;
       H256 ix = Fr::load_le(instances_xy + 64 * it), iy = Fr::load_le(instances_xy + 64 * it + 32);
       if (Fr::geq_p(ix) || Fr::geq_p(iy)) { fail(it, AVRF_INVALID_DATA); return; }
       H256 ixm = Fr::to_mont(ix), iym = Fr::to_mont(iy);
@@ -1339,7 +1376,7 @@ template <class S, class G> struct Ring {
       HIP_CHECK(hipMemcpyAsync(d_s, ss.data(), nb * 32, hipMemcpyHostToDevice, su->stream));
       HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream)); HIP_CHECK(hipMemsetAsync(d_rec, 0, n * 4, su->stream));
       launch_g1_bases(su->curve, d_xy, nb, d_b, d_flag, su->stream);
-      launch_g1_subgroup_check(su->curve, d_b, nb, d_flag, su->stream, d_rec, (uint32_t)TPI);
+      if (!host_subgroup) launch_g1_subgroup_check(su->curve, d_b, nb, d_flag, su->stream, d_rec, (uint32_t)TPI);
       launch_g1_lincomb(su->curve, d_b, d_s, n, (uint32_t)TPI, 11, d_pts, su->stream);
       launch_pairing_check(su->ptab, d_pts, n, d_ok, su->stream);
       std::vector<int32_t> okv(n), rec(n);
@@ -1357,7 +1394,7 @@ template <class S, class G> struct Ring {
     // b1 holds every deserialised G1 point of the batch (ring commitments, proof commitments, opening proofs): its bases are
     // subgroup-checked on the device before they are used (ark-serialize Validate::Yes; BLS12-381 G1 has a large cofactor)
     bool bad = false;
-    G1Aff acc1 = g1_msm(su, b1, s1, true, &bad);
+    G1Aff acc1 = g1_msm(su, b1, s1, !host_subgroup, &bad);
     if (bad) return AVRF_INVALID_DATA;
     G1Aff acc2 = g1_msm(su, b2, s2);
     lap("two G1 MSMs (device)");
