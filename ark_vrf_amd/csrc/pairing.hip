@@ -11,7 +11,8 @@
 // (the same model as the oracle, oracle/pairing_py.py; lanes 12..15 of a group idle).  A wave carries four checks.
 // One lane could not hold an Fp12 (144 limbs for BLS12-381) next to the temporaries of its multiplication; spread over
 // lanes, a multiplication is 12 wide (2N-limb) products per lane accumulated lazily into two 2N-limb sums (raw coefficients
-// k and k + 12), two Montgomery reductions, and one exchange with lane k +- 6 for the reduction by the modulus of w.
+// k and k + 12), two Montgomery reductions, and one exchange with lane k +- 6 for the reduction by the modulus of w; a
+// squaring needs 8 product slots (symmetry), a multiplication by a line 5 (its five non-zero coefficients).
 // Operands move with ds_bpermute inside the 16-lane group; no LDS allocation, no tower bookkeeping.
 //
 // Miller loop: the G2 arguments are fixed, so the line coefficients (slope lam and c = lam x_T - y_T per doubling /
@@ -104,6 +105,19 @@ template <class C> struct Cst {
   AVRF_DI fe<F> at(int idx) const { return fn_load<N>(p + (size_t)idx * N); }
 };
 
+// the reduction of the two raw sums (coefficients k and k + 12) shared by the three multiplication forms
+// w^12 = 2 xi0 w^6 - kappa:  c_k = r_k - kappa r_(k+12) - 2 xi0 kappa r_(k+18)            (k < 6)
+//                            c_k = r_k + 2 xi0 r_(k+6) + (4 xi0^2 - kappa) r_(k+12)       (k >= 6)
+template <class C> AVRF_DI fpn<C::Fq::N> f12_finish(uint32_t (&lo_acc)[2 * C::Fq::N], uint32_t (&hi_acc)[2 * C::Fq::N], int k, const uint32_t *cst) {
+  using F = typename C::Fq; constexpr int N = F::N;
+  const fe<F> L = redc<F>(lo_acc), H = redc<F>(hi_acc);
+  const bool lowk = k < 6;
+  const fe<F> Hp = grp_shfl<N>(H, lowk ? k + 6 : k - 6);
+  Cst<C> K{cst};
+  const fe<F> c1 = K.at(lowk ? PC_KAPPA : PC_4XI2_MINUS_KAPPA), c2 = K.at(lowk ? PC_2XI_KAPPA : PC_2XI);
+  const fe<F> t1 = fn_mul<F>(H, c1), t2 = fn_mul<F>(Hp, c2);
+  return lowk ? fn_sub<F>(fn_sub<F>(L, t1), t2) : fn_add<F>(fn_add<F>(L, t1), t2);
+}
 // product of two Fp12 elements; k = this lane's coefficient index (lanes 12..15 produce garbage that nobody reads)
 template <class C> __device__ __noinline__ static fpn<C::Fq::N> f12_mul(fpn<C::Fq::N> a, fpn<C::Fq::N> b, int k, const uint32_t *cst) {
   using F = typename C::Fq; constexpr int N = F::N;
@@ -121,16 +135,76 @@ template <class C> __device__ __noinline__ static fpn<C::Fq::N> f12_mul(fpn<C::F
     wide_add_if<N>(hi_acc, w, !low);
     if ((i & 3) == 3) { wide_fold<F>(lo_acc); wide_fold<F>(hi_acc); }
   }
-  const fe<F> L = redc<F>(lo_acc), H = redc<F>(hi_acc);
-  // w^12 = 2 xi0 w^6 - kappa:  c_k = r_k - kappa r_(k+12) - 2 xi0 kappa r_(k+18)            (k < 6)
-  //                            c_k = r_k + 2 xi0 r_(k+6) + (4 xi0^2 - kappa) r_(k+12)       (k >= 6)
-  const bool lowk = k < 6;
-  const fe<F> Hp = grp_shfl<N>(H, lowk ? k + 6 : k - 6);       // r_(k+18) resp. r_(k+6)
-  Cst<C> K{cst};
-  const fe<F> c1 = K.at(lowk ? PC_KAPPA : PC_4XI2_MINUS_KAPPA), c2 = K.at(lowk ? PC_2XI_KAPPA : PC_2XI);
-  const fe<F> t1 = fn_mul<F>(H, c1), t2 = fn_mul<F>(Hp, c2);
-  return lowk ? fn_sub<F>(fn_sub<F>(L, t1), t2) : fn_add<F>(fn_add<F>(L, t1), t2);
+  return f12_finish<C>(lo_acc, hi_acc, k, cst);
 }
+// acc *= 2 (acc < p R on entry), folded back below p R
+template <class F> AVRF_DI void wide_double(uint32_t (&acc)[2 * F::N]) {
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 2 * F::N; i++) { const uint32_t v = acc[i]; acc[i] = (v << 1) | c; c = v >> 31; }
+  wide_fold<F>(acc);
+}
+
+// a^2 with the symmetry of the schoolbook square: raw coefficient m = 2 * sum_{i<j, i+j=m} a_i a_j + [m even] a_(m/2)^2.
+// Lane k owns m = k and m = k + 12: at most 6 cross products (5 on even lanes) and, on even lanes, the two squares
+// a_(k/2)^2 and a_(k/2+6)^2 -- 8 product slots instead of the 12 of the general multiplication.
+template <class C> __device__ __noinline__ static fpn<C::Fq::N> f12_sqr(fpn<C::Fq::N> a, int k, const uint32_t *cst) {
+  using F = typename C::Fq; constexpr int N = F::N;
+  uint32_t lo_acc[2 * N], hi_acc[2 * N], w[2 * N];
+#pragma unroll
+  for (int i = 0; i < 2 * N; i++) { lo_acc[i] = 0; hi_acc[i] = 0; }
+  const int kk = k < 12 ? k : 0;
+  const int nlow = (kk + 1) >> 1, nhigh = (11 - kk) >> 1;        // cross products of m = k (i < k - i) and of m = k + 12
+#pragma unroll 1
+  for (int t = 0; t < 6; t++) {
+    const bool low = t < nlow;
+    const int u = t - nlow;
+    const bool live = low || u < nhigh;
+    const int i = low ? t : kk + 1 + u, j = low ? kk - t : 11 - u;
+    const fpn<N> ai = grp_shfl<N>(a, live ? i : 0), aj = grp_shfl<N>(a, live ? j : 0);
+    mul_wide<N>(w, ai.v, aj.v);
+    wide_add_if<N>(lo_acc, w, live && low);
+    wide_add_if<N>(hi_acc, w, live && !low);
+    if (t == 3) { wide_fold<F>(lo_acc); wide_fold<F>(hi_acc); }
+  }
+  wide_fold<F>(lo_acc); wide_fold<F>(hi_acc);
+  wide_double<F>(lo_acc); wide_double<F>(hi_acc);
+  const bool even = (kk & 1) == 0;
+  {
+    const fpn<N> s0 = grp_shfl<N>(a, kk >> 1);
+    mul_wide<N>(w, s0.v, s0.v);
+    wide_add_if<N>(lo_acc, w, even);
+    const fpn<N> s1 = grp_shfl<N>(a, even ? (kk >> 1) + 6 : 0);       // k even <= 10: (k + 12) / 2 <= 11
+    mul_wide<N>(w, s1.v, s1.v);
+    wide_add_if<N>(hi_acc, w, even);
+    wide_fold<F>(lo_acc); wide_fold<F>(hi_acc);
+  }
+  return f12_finish<C>(lo_acc, hi_acc, k, cst);
+}
+
+// f * l for a line l whose only non-zero coefficients sit at the five positions of the twist type (M: 0, 2, 3, 6, 8;
+// D: 0, 1, 3, 7, 9): five product slots per lane instead of twelve
+template <class C> __device__ __noinline__ static fpn<C::Fq::N> f12_mul_line(fpn<C::Fq::N> f, fpn<C::Fq::N> l, int k, const uint32_t *cst) {
+  using F = typename C::Fq; constexpr int N = F::N;
+  uint32_t lo_acc[2 * N], hi_acc[2 * N], w[2 * N];
+#pragma unroll
+  for (int i = 0; i < 2 * N; i++) { lo_acc[i] = 0; hi_acc[i] = 0; }
+  const int kk = k < 12 ? k : 0;
+#pragma unroll 1
+  for (int t = 0; t < 5; t++) {
+    const int j = C::MTWIST ? (t == 0 ? 0 : t == 1 ? 2 : t == 2 ? 3 : t == 3 ? 6 : 8) : (t == 0 ? 0 : t == 1 ? 1 : t == 2 ? 3 : t == 3 ? 7 : 9);
+    const bool low = j <= kk;                                    // i + j = k, else i + j = k + 12
+    const int i = low ? kk - j : kk + 12 - j;
+    const fpn<N> fi = grp_shfl<N>(f, i), lj = grp_shfl<N>(l, j);
+    mul_wide<N>(w, fi.v, lj.v);
+    wide_add_if<N>(lo_acc, w, low);
+    wide_add_if<N>(hi_acc, w, !low);
+    if (t == 3) { wide_fold<F>(lo_acc); wide_fold<F>(hi_acc); }
+  }
+  wide_fold<F>(lo_acc); wide_fold<F>(hi_acc);
+  return f12_finish<C>(lo_acc, hi_acc, k, cst);
+}
+
 template <class C> AVRF_DI fpn<C::Fq::N> f12_one(int k) { return k == 0 ? fn_one<typename C::Fq>() : fn_zero<C::Fq::N>(); }
 template <class C> AVRF_DI fpn<C::Fq::N> f12_conj(const fpn<C::Fq::N> &a, int k) { return (k & 1) ? fn_neg<typename C::Fq>(a) : a; }   // a^(p^6)
 // a^(p^2), a^(p^4): the Fp2 coefficient of w^(k mod 6) is scaled by gamma^(k mod 6), gamma = xi^((p^2-1)/6) in Fp
@@ -175,7 +249,7 @@ template <class C> __device__ __noinline__ static fpn<C::Fq::N> f12_pow_x(fpn<C:
   fpn<C::Fq::N> r = a;
   int top = 63; while (!((C::X_ABS >> top) & 1)) top--;
 #pragma unroll 1
-  for (int bit = top - 1; bit >= 0; bit--) { r = f12_mul<C>(r, r, k, cst); if ((C::X_ABS >> bit) & 1) r = f12_mul<C>(r, a, k, cst); }
+  for (int bit = top - 1; bit >= 0; bit--) { r = f12_sqr<C>(r, k, cst); if ((C::X_ABS >> bit) & 1) r = f12_mul<C>(r, a, k, cst); }
   return C::X_NEG ? f12_conj<C>(r, k) : r;
 }
 
@@ -184,7 +258,7 @@ template <class C> __device__ __noinline__ static fpn<C::Fq::N> f12_pow_x(fpn<C:
 // pts: n x np affine G1 points (Montgomery x | y, N words each; (0, 0) = infinity: that pair contributes 1);
 // tab: np line tables of `steps` entries {T0[12], TX[12], TY[12]} (Fp each); ok[i] = 1 iff the product is one.
 template <class C>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2)       // 256 VGPRs: two waves per SIMD hide each other's ds_bpermute / scratch latencies
 k_pairing_check(const uint32_t *__restrict__ pts, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ cst, uint32_t n, uint32_t np,
                 uint32_t steps, int32_t *__restrict__ ok) {
   using F = typename C::Fq; constexpr int N = F::N;
@@ -197,7 +271,7 @@ k_pairing_check(const uint32_t *__restrict__ pts, const uint32_t *__restrict__ t
   uint32_t s = 0;
 #pragma unroll 1
   for (int bit = C::ATE_LOOP_BITS - 2; bit >= 0; bit--) {
-    f = f12_mul<C>(f, f, k, cst);
+    f = f12_sqr<C>(f, k, cst);
     const int nadd = ((C::ATE_LOOP[bit >> 6] >> (bit & 63)) & 1) ? 2 : 1;
 #pragma unroll 1
     for (int rep = 0; rep < nadd; rep++, s++) {
@@ -209,7 +283,7 @@ k_pairing_check(const uint32_t *__restrict__ pts, const uint32_t *__restrict__ t
         const uint32_t *tp = tab + (((size_t)q * steps + s) * 36 + kc) * N;
         fe<F> l = fn_add<F>(fn_load<N>(tp), fn_add<F>(fn_mul<F>(fn_load<N>(tp + 12 * N), xp), fn_mul<F>(fn_load<N>(tp + 24 * N), yp)));
         if (k >= 12) l = fn_zero<N>();
-        f = f12_mul<C>(f, l, k, cst);
+        f = f12_mul_line<C>(f, l, k, cst);
       }
     }
   }
@@ -223,12 +297,12 @@ k_pairing_check(const uint32_t *__restrict__ pts, const uint32_t *__restrict__ t
     const fe<F> c = f12_mul<C>(f12_pow_x<C>(b, k, cst), f12_frob1<C>(b, k, cst), k, cst);            // ^(x+p)
     fe<F> d = f12_pow_x<C>(f12_pow_x<C>(c, k, cst), k, cst);
     d = f12_mul<C>(f12_mul<C>(d, f12_frob2<C>(c, k, cst), k, cst), f12_conj<C>(c, k), k, cst);       // ^(x^2+p^2-1)
-    out = f12_mul<C>(d, f12_mul<C>(t, f12_mul<C>(t, t, k, cst), k, cst), k, cst);                    // * t^3
+    out = f12_mul<C>(d, f12_mul<C>(t, f12_sqr<C>(t, k, cst), k, cst), k, cst);                    // * t^3
   } else {
     out = t;
 #pragma unroll 1
     for (int bit = C::HARD_EXP_BITS - 2; bit >= 0; bit--) {
-      out = f12_mul<C>(out, out, k, cst);
+      out = f12_sqr<C>(out, k, cst);
       if ((C::HARD_EXP[bit >> 6] >> (bit & 63)) & 1) out = f12_mul<C>(out, t, k, cst);
     }
   }
