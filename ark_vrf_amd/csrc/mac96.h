@@ -29,6 +29,9 @@ __device__ __forceinline__ void mont_mul_ps(uint32_t (&t)[N], const uint32_t (&a
     MontAsm8<F>::mul(t, a, b);
     return;
   }
+#ifndef AVRF_NO_MONT_ASM12
+  if constexpr (N == 12 && MontAsm12<F>::value) { MontAsm12<F>::mul(t, a, b); return; }
+#endif
 #endif
   uint32_t m[N];
   uint64_t lo = 0; uint32_t ex = 0;

@@ -1,27 +1,35 @@
 #!/usr/bin/env python3
-"""Generates ark_vrf_amd/csrc/mont8_asm_gen.h: the 8-limb Montgomery multiplication (product scanning with interleaved
-reduction, see mac96.h) as ONE inline-asm block per field, with the column accumulator sliding over a block of consecutive
-VGPRs -- column k accumulates in the pair (A[k], A[k+1]) with carries in A[k+2], so the result limb of a column simply stays
-where it is and the next column starts one register up: no shifts and no moves between columns (the C++ form, where the
-accumulator is a uint64_t + uint32_t, costs ~8 move / shift instructions per column: ~1000 of the ~4500 instructions of one
-twisted-Edwards mixed addition).  The modulus limbs live in SGPRs (a VOP3 instruction on gfx9 takes no 32-bit literal).
+"""Generates ark_vrf_amd/csrc/mont8_asm_gen.h: the 8- and 12-limb Montgomery multiplications (product scanning with
+interleaved reduction, see mac96.h) as ONE inline-asm block per field.  The column accumulators live in a block of consecutive
+VGPRs A[0..2N]: an EVEN column k accumulates in place in the 64-bit aligned pair (A[k], A[k+1]) with its carries in A[k+2], so
+its result limb simply stays where it is and the next column starts one register up -- no shifts and no moves between columns
+(the C++ form, whose accumulator is a uint64_t + uint32_t, spends ~8 move / shift instructions per column).  gfx950 wants
+64-bit VGPR operands on even registers, so an ODD column accumulates in an aligned scratch triple and is folded into
+(A[k], A[k+1], A[k+2]) by three add-with-carry instructions.  The modulus limbs live in SGPRs (a VOP3 instruction on gfx9
+takes no 32-bit literal).
 
-  python tools/gen_mont_asm.py        # rewrites the header from consts_gen.h
+  python tools/gen_mont_asm.py          # rewrites the header from consts_gen.h
+  python tools/gen_mont_asm.py --check  # also runs the generated instruction streams in a small emulator against
+                                        # a * b * 2^(-32 N) mod p on random operands
 
-Registers: A = v[96:112], odd-column scratch v[114:117], m = v[118:125], modulus s[36:43], -p^-1 s44, carries through vcc (all
-declared as clobbers).
+Registers (all declared as clobbers): A = v[A0 : A0 + 2N], odd-column scratch T (4), m (N), modulus s[36 : 36 + N), -p^-1 next,
+carries through vcc.  An asm statement takes at most 30 operands: the 12-limb form (12 + 12 inputs) returns its result as six
+64-bit operands written by v_mov_b64.
 """
 import os
+import random
 import re
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONSTS = os.path.join(ROOT, "ark_vrf_amd", "csrc", "consts_gen.h")
 OUT = os.path.join(ROOT, "ark_vrf_amd", "csrc", "mont8_asm_gen.h")
-A0, T_BASE, M0, S0 = 96, 114, 118, 36
-N = 8
+S0 = 36
+# per limb count: first accumulator register (even), odd-column scratch (even), m registers
+LAYOUT = {8: dict(A0=96, T=114, M0=118), 12: dict(A0=100, T=126, M0=130)}
 
 
-def fields():
+def fields(N):
     txt = open(CONSTS).read()
     out = []
     for m in re.finditer(r"struct (F[qr]\w+) \{(.*?)\n\};", txt, re.S):
@@ -35,11 +43,12 @@ def fields():
     return out
 
 
-def body():
-    """the instruction list; %0..%7 = t (out), %8..%15 = a, %16..%23 = b.
-    gfx950 wants 64-bit VGPR operands on even registers, so only EVEN columns accumulate in place, in the aligned pair
-    (A[k], A[k+1]) with carries in A[k+2]; an ODD column accumulates in the aligned scratch triple T and is folded into
-    (A[k], A[k+1], A[k+2]) by three add-with-carry instructions once it is complete."""
+def body(N):
+    """the instruction list.  N = 8: %0..%7 = t (out, 32-bit), %8.. = a, %16.. = b.  N = 12: %0..%5 = t (out, 64-bit pairs),
+    %6.. = a, %18.. = b."""
+    lay = LAYOUT[N]
+    A0, T_BASE, M0 = lay["A0"], lay["T"], lay["M0"]
+    n_out = N if N == 8 else N // 2
     L = []
     A = lambda i: f"v{A0 + i}"
     pair = lambda k: f"v[{A0 + k}:{A0 + k + 1}]"
@@ -65,7 +74,7 @@ def body():
                 L.append(f"v_mov_b32 {r}, 0")
         lo, hi = (0, k) if k < N else (k - N + 1, N - 1)
         for i in range(lo, hi + 1):
-            mac(k, f"%{8 + i}", f"%{16 + k - i}")
+            mac(k, f"%{n_out + i}", f"%{n_out + N + k - i}")
         for i in range(lo, min(hi, k - 1) + 1):
             mac(k, M(i), P(k - i))
         if k < N:
@@ -79,39 +88,125 @@ def body():
             L.append(f"v_add_co_u32 {A(k)}, vcc, {A(k)}, {T0}")
             L.append(f"v_addc_co_u32 {A(k + 1)}, vcc, {A(k + 1)}, {T1}, vcc")
             L.append(f"v_addc_co_u32 {A(k + 2)}, vcc, {A(k + 2)}, {T2}, vcc")
-    for i in range(N):
-        L.append(f"v_mov_b32 %{i}, {A(N + i)}")
+    if N == 8:
+        for i in range(N):
+            L.append(f"v_mov_b32 %{i}, {A(N + i)}")
+    else:
+        for i in range(N // 2):
+            L.append(f"v_mov_b64 %{i}, {pair(N + 2 * i)}")
     return L
 
 
-def main():
-    fs = fields()
-    ins = body()
-    clob = [f"v{A0 + i}" for i in range(2 * N + 1)] + [f"v{T_BASE + i}" for i in range(4)] + [f"v{M0 + i}" for i in range(N)] + [f"s{S0 + i}" for i in range(N + 1)] + ["vcc"]
-    o = ["// mont8_asm_gen.h -- GENERATED by tools/gen_mont_asm.py from consts_gen.h; do not edit.",
-         "// 8-limb Montgomery multiplication as one inline-asm block per field (see the generator's docstring).",
-         "#pragma once", "#include <hip/hip_runtime.h>", "#include <stdint.h>", '#include "consts_gen.h"', "",
-         "namespace avrf {", "",
-         "template <class F> struct MontAsm8 { static constexpr bool value = false; };", ""]
-    n_valu = sum(1 for x in ins)
-    o.append(f"// {n_valu} VALU instructions per multiplication ({sum(1 for x in ins if x.startswith('v_mad'))} v_mad_u64_u32) + {N + 1} s_mov_b32")
+def clobbers(N):
+    lay = LAYOUT[N]
+    return ([f"v{lay['A0'] + i}" for i in range(2 * N + 1)] + [f"v{lay['T'] + i}" for i in range(4)] + [f"v{lay['M0'] + i}" for i in range(N)]
+            + [f"s{S0 + i}" for i in range(N + 1)] + ["vcc"])
+
+
+def emulate(N, ins, limbs, ninv, a, b):
+    """runs the instruction stream on one lane; returns the output limbs"""
+    n_out = N if N == 8 else N // 2
+    reg = {}
+    for i in range(N):
+        reg[f"s{S0 + i}"] = limbs[i]
+        reg[f"%{n_out + i}"] = a[i]; reg[f"%{n_out + N + i}"] = b[i]
+    reg[f"s{S0 + N}"] = ninv
+    vcc = 0
+    MASK = 0xffffffff
+
+    def rd(x):
+        return 0 if x == "0" else reg[x]
+
+    def prd(x):   # v[a:b]
+        lo = int(x[2:x.index(":")]); return reg[f"v{lo}"] | (reg[f"v{lo + 1}"] << 32)
+
+    def pwr(x, v):
+        lo = int(x[2:x.index(":")]); reg[f"v{lo}"] = v & MASK; reg[f"v{lo + 1}"] = (v >> 32) & MASK
+
+    for line in ins:
+        op, rest = line.split(" ", 1)
+        o = [x.strip() for x in rest.split(",")]
+        if op == "v_mov_b32":
+            reg[o[0]] = rd(o[1])
+        elif op == "v_mov_b64":
+            reg[o[0]] = prd(o[1])
+        elif op == "v_mad_u64_u32":
+            assert o[1] == "vcc" and int(o[0][2:o[0].index(":")]) % 2 == 0
+            v = rd(o[2]) * rd(o[3]) + prd(o[4]); vcc = v >> 64; pwr(o[0], v & ((1 << 64) - 1))
+        elif op == "v_addc_co_u32":
+            assert o[1] == "vcc" and o[4] == "vcc"
+            v = rd(o[2]) + rd(o[3]) + vcc; reg[o[0]] = v & MASK; vcc = v >> 32
+        elif op == "v_add_co_u32":
+            v = rd(o[2]) + rd(o[3]); reg[o[0]] = v & MASK; vcc = v >> 32
+        elif op == "v_add_u32":
+            reg[o[0]] = (rd(o[1]) + rd(o[2])) & MASK
+        elif op == "v_mul_lo_u32":
+            reg[o[0]] = (rd(o[1]) * rd(o[2])) & MASK
+        else:
+            raise ValueError(line)
+    if N == 8:
+        return [reg[f"%{i}"] for i in range(N)]
+    return [x for i in range(N // 2) for x in (reg[f"%{i}"] & MASK, reg[f"%{i}"] >> 32)]
+
+
+def check(N, ins, fs, rounds=200):
+    rng = random.Random(1)
+    for name, limbs, ninv in fs:
+        p = sum(l << (32 * i) for i, l in enumerate(limbs))
+        rinv = pow(1 << (32 * N), -1, p)
+        for r in range(rounds):
+            a, b = (rng.randrange(p) if r > 3 else p - 1 - r), (rng.randrange(p) if r > 1 else p - 1)
+            t = emulate(N, ins, limbs, ninv, [(a >> (32 * i)) & 0xffffffff for i in range(N)], [(b >> (32 * i)) & 0xffffffff for i in range(N)])
+            tv = sum(l << (32 * i) for i, l in enumerate(t))
+            assert tv < 2 * p and tv % p == a * b * rinv % p, (name, hex(a), hex(b))
+        print(f"  emulator: {name} ({N} limbs) ok on {rounds} operand pairs")
+
+
+def emit(o, N, fs, ins):
+    cl = clobbers(N)
+    n_valu = len(ins)
+    o.append(f"template <class F> struct MontAsm{N} {{ static constexpr bool value = false; }};")
+    o.append("")
+    o.append(f"// {N} limbs: {n_valu} VALU instructions per multiplication ({sum(1 for x in ins if x.startswith('v_mad'))} v_mad_u64_u32) + {N + 1} s_mov_b32")
     for name, limbs, ninv in fs:
         pre = [f"s_mov_b32 s{S0 + i}, 0x{limbs[i]:08x}" for i in range(N)] + [f"s_mov_b32 s{S0 + N}, 0x{ninv:08x}"]
         text = "\\n\\t".join(pre + ins)
-        o.append(f"template <> struct MontAsm8<{name}> {{")
+        o.append(f"template <> struct MontAsm{N}<{name}> {{")
         o.append("  static constexpr bool value = true;")
-        o.append("  // t = a * b / 2^256 mod p, t < 2p (the caller subtracts p once)")
-        o.append("  static __device__ __forceinline__ void mul(uint32_t (&t)[8], const uint32_t (&a)[8], const uint32_t (&b)[8]) {")
-        o.append(f'    asm("{text}"')
-        o.append("        : " + ", ".join(f'"=v"(t[{i}])' for i in range(N)))
+        o.append(f"  // t = a * b / 2^{32 * N} mod p, t < 2p (the caller subtracts p once)")
+        o.append(f"  static __device__ __forceinline__ void mul(uint32_t (&t)[{N}], const uint32_t (&a)[{N}], const uint32_t (&b)[{N}]) {{")
+        if N == 8:
+            o.append(f'    asm("{text}"')
+            o.append("        : " + ", ".join(f'"=v"(t[{i}])' for i in range(N)))
+        else:
+            o.append(f"    uint64_t o[{N // 2}];")
+            o.append(f'    asm("{text}"')
+            o.append("        : " + ", ".join(f'"=v"(o[{i}])' for i in range(N // 2)))
         o.append("        : " + ", ".join(f'"v"(a[{i}])' for i in range(N)) + ", " + ", ".join(f'"v"(b[{i}])' for i in range(N)))
-        o.append("        : " + ", ".join(f'"{c}"' for c in clob) + ");")
+        o.append("        : " + ", ".join(f'"{c}"' for c in cl) + ");")
+        if N != 8:
+            o.append("#pragma unroll")
+            o.append(f"    for (int i = 0; i < {N // 2}; i++) {{ t[2 * i] = (uint32_t)o[i]; t[2 * i + 1] = (uint32_t)(o[i] >> 32); }}")
         o.append("  }")
         o.append("};")
         o.append("")
+
+
+def main():
+    o = ["// mont8_asm_gen.h -- GENERATED by tools/gen_mont_asm.py from consts_gen.h; do not edit.",
+         "// 8- and 12-limb Montgomery multiplications as one inline-asm block per field (see the generator's docstring).",
+         "#pragma once", "#include <hip/hip_runtime.h>", "#include <stdint.h>", '#include "consts_gen.h"', "",
+         "namespace avrf {", ""]
+    for N in (8, 12):
+        fs = fields(N)
+        ins = body(N)
+        if "--check" in sys.argv:
+            check(N, ins, fs)
+        emit(o, N, fs, ins)
+        print(f"{N} limbs: fields", [f[0] for f in fs], "instructions:", len(ins))
     o.append("}  // namespace avrf")
     open(OUT, "w").write("\n".join(o) + "\n")
-    print("wrote", OUT, "fields:", [f[0] for f in fs], "instructions:", n_valu)
+    print("wrote", OUT)
 
 
 if __name__ == "__main__":
