@@ -568,6 +568,7 @@ int avrf_pedersen_verify(avrf_ctx *c, size_t n, const uint8_t *ios_xy, const uin
   if (n && (!proofs || !status_out)) return AVRF_ERR_BAD_ARG;
   int st = stage(c, 2, n, nullptr, nullptr, ios_xy, io_counts, ads, ad_lens, proofs);
   if (st || !n) return st;
+  if (int fs = ensure_fixed(c)) return fs;
   HIP_TRY(c->d_status.ensure(n * 4));
   double t0 = now_us();
   launch_ped_verify(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream);

@@ -96,7 +96,14 @@ template <class F> AVRF_DI fp fp_mul(const fp &a, const fp &b) {
   for (int i = 0; i < 8; i++) r.v[i] = br ? r.v[i] : u.v[i];
   return r;
 }
-template <class F> AVRF_DI fp fp_sqr(const fp &a) { return fp_mul<F>(a, a); }
+template <class F> AVRF_DI fp fp_sqr(const fp &a) {
+  fp r, u;
+  mont_sqr_ps<8, F>(r.v, a.v);
+  uint32_t br = sub_p<F>(u, r);
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = br ? r.v[i] : u.v[i];
+  return r;
+}
 
 template <class F> AVRF_DI fp fp_to_mont(const fp &a) { return fp_mul<F>(a, fp_const<F>(F::R2)); }
 template <class F> AVRF_DI fp fp_from_mont(const fp &a) {

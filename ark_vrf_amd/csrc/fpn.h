@@ -109,7 +109,15 @@ template <class F> AVRF_DI fe<F> fn_mul_cios(const fe<F> &a, const fe<F> &b) {
   for (int i = 0; i < N; i++) r.v[i] = br ? r.v[i] : u.v[i];
   return r;
 }
-template <class F> AVRF_DI fe<F> fn_sqr(const fe<F> &a) { return fn_mul<F>(a, a); }
+template <class F> AVRF_DI fe<F> fn_sqr(const fe<F> &a) {
+  constexpr int N = F::N;
+  fe<F> r, u;
+  mont_sqr_ps<N, F>(r.v, a.v);
+  uint32_t br = fn_sub_p<F>(u, r);
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = br ? r.v[i] : u.v[i];
+  return r;
+}
 template <class F> AVRF_DI fe<F> fn_to_mont(const fe<F> &a) { return fn_mul<F>(a, fn_const<F>(F::R2)); }
 template <class F> AVRF_DI fe<F> fn_from_mont(const fe<F> &a) { fe<F> one = fn_zero<F::N>(); one.v[0] = 1; return fn_mul<F>(a, one); }
 

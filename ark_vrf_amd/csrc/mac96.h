@@ -57,4 +57,16 @@ __device__ __forceinline__ void mont_mul_ps(uint32_t (&t)[N], const uint32_t (&a
   t[N - 1] = (uint32_t)lo;
 }
 
+// a * a / 2^(32 N) mod p: the asm blocks with N (N + 1) / 2 limb products where there is one (tools/gen_mont_asm.py)
+template <int N, class F>
+__device__ __forceinline__ void mont_sqr_ps(uint32_t (&t)[N], const uint32_t (&a)[N]) {
+#if !defined(AVRF_NO_MONT_ASM) && !defined(AVRF_NO_MONT_SQR)
+  if constexpr (N == 8 && MontAsm8<F>::value) { MontAsm8<F>::sqr(t, a); return; }
+#ifndef AVRF_NO_MONT_ASM12
+  if constexpr (N == 12 && MontAsm12<F>::value) { MontAsm12<F>::sqr(t, a); return; }
+#endif
+#endif
+  mont_mul_ps<N, F>(t, a, a);
+}
+
 }  // namespace avrf

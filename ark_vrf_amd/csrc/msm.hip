@@ -49,7 +49,7 @@ namespace avrf {
 // ---------------------------------------------------------------- conversions
 
 template <class S>
-__global__ void k_pre_from_affine(const uint8_t *__restrict__ xy, uint32_t n, te_pre *__restrict__ out,
+__global__ void __launch_bounds__(256) k_pre_from_affine(const uint8_t *__restrict__ xy, uint32_t n, te_pre *__restrict__ out,
                                   uint32_t *__restrict__ flag, int check_curve) {
   using Fq = typename S::Fq;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -79,7 +79,7 @@ void launch_pre_from_affine(int suite, const uint8_t *d_xy, size_t n, te_pre_raw
 // v = batch * nwin + w everywhere downstream)
 // (With fixed-base window tables the nwin digit rows of one vector are simply consumed as ONE window of
 // n * nwin keys: same layout, different interpretation downstream.)
-__global__ void k_digits(const uint32_t *__restrict__ scalars, uint32_t n, uint32_t stride, int c, int nwin, uint16_t *__restrict__ keys) {
+__global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ scalars, uint32_t n, uint32_t stride, int c, int nwin, uint16_t *__restrict__ keys) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t bat = blockIdx.y;
@@ -227,12 +227,12 @@ k_scatter(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int 
 template <class CV> __device__ __noinline__ void cv_add_nf(typename CV::acc_t *r, const typename CV::acc_t *a, const typename CV::acc_t *b) { *r = CV::add(*a, *b); }
 template <class CV> __device__ __noinline__ void cv_dbl_nf(typename CV::acc_t *r, const typename CV::acc_t *a) { *r = CV::dbl(*a); }
 template <class CV> AVRF_DI typename CV::acc_t cv_add(const typename CV::acc_t &a, const typename CV::acc_t &b) {
-  if (CV::INLINE_REDUCE_OPS) return CV::add(a, b);
-  typename CV::acc_t r; cv_add_nf<CV>(&r, &a, &b); return r;
+  if constexpr (CV::INLINE_REDUCE_OPS) return CV::add(a, b);
+  else { typename CV::acc_t r; cv_add_nf<CV>(&r, &a, &b); return r; }
 }
 template <class CV> AVRF_DI typename CV::acc_t cv_dbl(const typename CV::acc_t &a) {
-  if (CV::INLINE_REDUCE_OPS) return CV::dbl(a);
-  typename CV::acc_t r; cv_dbl_nf<CV>(&r, &a); return r;
+  if constexpr (CV::INLINE_REDUCE_OPS) return CV::dbl(a);
+  else { typename CV::acc_t r; cv_dbl_nf<CV>(&r, &a); return r; }
 }
 
 
@@ -785,7 +785,7 @@ int msm_te_device(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars,
 
 // canonical affine coordinates (x || y, FQ_BYTES little-endian each; (0,0) = infinity) -> Montgomery bases
 template <class C>
-__global__ void k_g1_bases(const uint8_t *__restrict__ xy, uint32_t n, uint32_t *__restrict__ out, uint32_t *__restrict__ flag) {
+__global__ void __launch_bounds__(256) k_g1_bases(const uint8_t *__restrict__ xy, uint32_t n, uint32_t *__restrict__ out, uint32_t *__restrict__ flag) {
   using Fq = typename C::Fq; constexpr int N = Fq::N;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

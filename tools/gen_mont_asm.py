@@ -26,7 +26,8 @@ CONSTS = os.path.join(ROOT, "ark_vrf_amd", "csrc", "consts_gen.h")
 OUT = os.path.join(ROOT, "ark_vrf_amd", "csrc", "mont8_asm_gen.h")
 S0 = 36
 # per limb count: first accumulator register (even), odd-column scratch (even), m registers
-LAYOUT = {8: dict(A0=96, T=114, M0=118), 12: dict(A0=100, T=126, M0=130)}
+# squaring only: D = the limbs of 2a, L = the limbs a_j << 1 (no carry-in)
+LAYOUT = {8: dict(A0=96, T=114, M0=118, D0=80, L0=87), 12: dict(A0=100, T=126, M0=130, D0=142, L0=154)}
 
 
 def fields(N):
@@ -43,9 +44,12 @@ def fields(N):
     return out
 
 
-def body(N):
+def body(N, sqr=False):
     """the instruction list.  N = 8: %0..%7 = t (out, 32-bit), %8.. = a, %16.. = b.  N = 12: %0..%5 = t (out, 64-bit pairs),
-    %6.. = a, %18.. = b."""
+    %6.. = a, %18.. = b.
+    sqr: a only.  a^2 = sum_i a_i^2 B^2i + sum_i a_i B^i (2 A_>i) with A_>i = sum_{j>i} a_j B^j: the limbs of 2 A_>i are
+    L_{i+1} = a_{i+1} << 1 at j = i + 1 and D_j = (a_j << 1) | (a_{j-1} >> 31) above (limb N is a_{N-1} >> 31 = 0: the top bit
+    of the modulus is clear), so the N (N - 1) / 2 cross products are single multiply-adds: N (N + 1) / 2 products instead of N^2."""
     lay = LAYOUT[N]
     A0, T_BASE, M0 = lay["A0"], lay["T"], lay["M0"]
     n_out = N if N == 8 else N // 2
@@ -65,6 +69,14 @@ def body(N):
             L.append(f"v_mad_u64_u32 {TP}, vcc, {x}, {y}, {TP}")
             L.append(f"v_addc_co_u32 {T2}, vcc, 0, {T2}, vcc")
 
+    av = lambda i: f"%{n_out + i}"
+    if sqr:
+        D = lambda j: f"v{lay['D0'] + j}"
+        LL = lambda j: f"v{lay['L0'] + j}"
+        for j in range(1, N):
+            L.append(f"v_lshlrev_b32 {LL(j)}, 1, {av(j)}")
+            if j >= 2:
+                L.append(f"v_alignbit_b32 {D(j)}, {av(j)}, {av(j - 1)}, 31")
     for i in range(2):
         L.append(f"v_mov_b32 {A(i)}, 0")
     for k in range(2 * N - 1):
@@ -74,7 +86,13 @@ def body(N):
                 L.append(f"v_mov_b32 {r}, 0")
         lo, hi = (0, k) if k < N else (k - N + 1, N - 1)
         for i in range(lo, hi + 1):
-            mac(k, f"%{n_out + i}", f"%{n_out + N + k - i}")
+            j = k - i
+            if not sqr:
+                mac(k, av(i), f"%{n_out + N + j}")
+            elif i == j:
+                mac(k, av(i), av(i))
+            elif i < j:
+                mac(k, av(i), LL(j) if j == i + 1 else D(j))
         for i in range(lo, min(hi, k - 1) + 1):
             mac(k, M(i), P(k - i))
         if k < N:
@@ -97,10 +115,11 @@ def body(N):
     return L
 
 
-def clobbers(N):
+def clobbers(N, sqr=False):
     lay = LAYOUT[N]
+    extra = [f"v{lay['D0'] + j}" for j in range(2, N)] + [f"v{lay['L0'] + j}" for j in range(1, N)] if sqr else []
     return ([f"v{lay['A0'] + i}" for i in range(2 * N + 1)] + [f"v{lay['T'] + i}" for i in range(4)] + [f"v{lay['M0'] + i}" for i in range(N)]
-            + [f"s{S0 + i}" for i in range(N + 1)] + ["vcc"])
+            + extra + [f"s{S0 + i}" for i in range(N + 1)] + ["vcc"])
 
 
 def emulate(N, ins, limbs, ninv, a, b):
@@ -109,7 +128,9 @@ def emulate(N, ins, limbs, ninv, a, b):
     reg = {}
     for i in range(N):
         reg[f"s{S0 + i}"] = limbs[i]
-        reg[f"%{n_out + i}"] = a[i]; reg[f"%{n_out + N + i}"] = b[i]
+        reg[f"%{n_out + i}"] = a[i]
+        if b is not None:
+            reg[f"%{n_out + N + i}"] = b[i]
     reg[f"s{S0 + N}"] = ninv
     vcc = 0
     MASK = 0xffffffff
@@ -138,6 +159,10 @@ def emulate(N, ins, limbs, ninv, a, b):
             v = rd(o[2]) + rd(o[3]) + vcc; reg[o[0]] = v & MASK; vcc = v >> 32
         elif op == "v_add_co_u32":
             v = rd(o[2]) + rd(o[3]); reg[o[0]] = v & MASK; vcc = v >> 32
+        elif op == "v_lshlrev_b32":
+            reg[o[0]] = (rd(o[2]) << int(o[1])) & MASK
+        elif op == "v_alignbit_b32":
+            reg[o[0]] = (((rd(o[1]) << 32) | rd(o[2])) >> int(o[3])) & MASK
         elif op == "v_add_u32":
             reg[o[0]] = (rd(o[1]) + rd(o[2])) & MASK
         elif op == "v_mul_lo_u32":
@@ -149,45 +174,57 @@ def emulate(N, ins, limbs, ninv, a, b):
     return [x for i in range(N // 2) for x in (reg[f"%{i}"] & MASK, reg[f"%{i}"] >> 32)]
 
 
-def check(N, ins, fs, rounds=200):
+def check(N, ins, fs, sqr=False, rounds=200):
     rng = random.Random(1)
+    split = lambda v: [(v >> (32 * i)) & 0xffffffff for i in range(N)]
     for name, limbs, ninv in fs:
         p = sum(l << (32 * i) for i, l in enumerate(limbs))
+        assert p < 1 << (32 * N - 1)
         rinv = pow(1 << (32 * N), -1, p)
         for r in range(rounds):
             a, b = (rng.randrange(p) if r > 3 else p - 1 - r), (rng.randrange(p) if r > 1 else p - 1)
-            t = emulate(N, ins, limbs, ninv, [(a >> (32 * i)) & 0xffffffff for i in range(N)], [(b >> (32 * i)) & 0xffffffff for i in range(N)])
+            if r == 4:
+                a = sum(0x80000000 << (32 * i) for i in range(N - 1))           # every carry-in bit of D set
+            if sqr:
+                b = a
+            t = emulate(N, ins, limbs, ninv, split(a), None if sqr else split(b))
             tv = sum(l << (32 * i) for i, l in enumerate(t))
             assert tv < 2 * p and tv % p == a * b * rinv % p, (name, hex(a), hex(b))
-        print(f"  emulator: {name} ({N} limbs) ok on {rounds} operand pairs")
+        print(f"  emulator: {name} ({N} limbs, {'square' if sqr else 'product'}) ok on {rounds} operands")
 
 
-def emit(o, N, fs, ins):
-    cl = clobbers(N)
-    n_valu = len(ins)
+def asm_fn(o, N, fname, pre, ins, cl, two):
+    text = "\\n\\t".join(pre + ins)
+    args = f"const uint32_t (&a)[{N}], const uint32_t (&b)[{N}]" if two else f"const uint32_t (&a)[{N}]"
+    o.append(f"  static __device__ __forceinline__ void {fname}(uint32_t (&t)[{N}], {args}) {{")
+    if N == 8:
+        o.append(f'    asm("{text}"')
+        o.append("        : " + ", ".join(f'"=v"(t[{i}])' for i in range(N)))
+    else:
+        o.append(f"    uint64_t o[{N // 2}];")
+        o.append(f'    asm("{text}"')
+        o.append("        : " + ", ".join(f'"=v"(o[{i}])' for i in range(N // 2)))
+    o.append("        : " + ", ".join(f'"v"(a[{i}])' for i in range(N)) + (", " + ", ".join(f'"v"(b[{i}])' for i in range(N)) if two else ""))
+    o.append("        : " + ", ".join(f'"{c}"' for c in cl) + ");")
+    if N != 8:
+        o.append("#pragma unroll")
+        o.append(f"    for (int i = 0; i < {N // 2}; i++) {{ t[2 * i] = (uint32_t)o[i]; t[2 * i + 1] = (uint32_t)(o[i] >> 32); }}")
+    o.append("  }")
+
+
+def emit(o, N, fs, ins, ins_sqr):
     o.append(f"template <class F> struct MontAsm{N} {{ static constexpr bool value = false; }};")
     o.append("")
-    o.append(f"// {N} limbs: {n_valu} VALU instructions per multiplication ({sum(1 for x in ins if x.startswith('v_mad'))} v_mad_u64_u32) + {N + 1} s_mov_b32")
+    cnt = lambda x: f"{len(x)} VALU instructions ({sum(1 for y in x if y.startswith('v_mad'))} v_mad_u64_u32)"
+    o.append(f"// {N} limbs: product {cnt(ins)}, square {cnt(ins_sqr)}, + {N + 1} s_mov_b32 each")
     for name, limbs, ninv in fs:
         pre = [f"s_mov_b32 s{S0 + i}, 0x{limbs[i]:08x}" for i in range(N)] + [f"s_mov_b32 s{S0 + N}, 0x{ninv:08x}"]
-        text = "\\n\\t".join(pre + ins)
         o.append(f"template <> struct MontAsm{N}<{name}> {{")
         o.append("  static constexpr bool value = true;")
         o.append(f"  // t = a * b / 2^{32 * N} mod p, t < 2p (the caller subtracts p once)")
-        o.append(f"  static __device__ __forceinline__ void mul(uint32_t (&t)[{N}], const uint32_t (&a)[{N}], const uint32_t (&b)[{N}]) {{")
-        if N == 8:
-            o.append(f'    asm("{text}"')
-            o.append("        : " + ", ".join(f'"=v"(t[{i}])' for i in range(N)))
-        else:
-            o.append(f"    uint64_t o[{N // 2}];")
-            o.append(f'    asm("{text}"')
-            o.append("        : " + ", ".join(f'"=v"(o[{i}])' for i in range(N // 2)))
-        o.append("        : " + ", ".join(f'"v"(a[{i}])' for i in range(N)) + ", " + ", ".join(f'"v"(b[{i}])' for i in range(N)))
-        o.append("        : " + ", ".join(f'"{c}"' for c in cl) + ");")
-        if N != 8:
-            o.append("#pragma unroll")
-            o.append(f"    for (int i = 0; i < {N // 2}; i++) {{ t[2 * i] = (uint32_t)o[i]; t[2 * i + 1] = (uint32_t)(o[i] >> 32); }}")
-        o.append("  }")
+        asm_fn(o, N, "mul", pre, ins, clobbers(N), True)
+        o.append(f"  // t = a * a / 2^{32 * N} mod p, t < 2p")
+        asm_fn(o, N, "sqr", pre, ins_sqr, clobbers(N, True), False)
         o.append("};")
         o.append("")
 
@@ -199,11 +236,12 @@ def main():
          "namespace avrf {", ""]
     for N in (8, 12):
         fs = fields(N)
-        ins = body(N)
+        ins, ins_sqr = body(N), body(N, True)
         if "--check" in sys.argv:
             check(N, ins, fs)
-        emit(o, N, fs, ins)
-        print(f"{N} limbs: fields", [f[0] for f in fs], "instructions:", len(ins))
+            check(N, ins_sqr, fs, True)
+        emit(o, N, fs, ins, ins_sqr)
+        print(f"{N} limbs: fields", [f[0] for f in fs], "instructions:", len(ins), "/", len(ins_sqr))
     o.append("}  // namespace avrf")
     open(OUT, "w").write("\n".join(o) + "\n")
     print("wrote", OUT)
