@@ -201,6 +201,20 @@ class Context:
             raise AvrfError(f"avrf_pedersen_verify -> {st}")
         return list(out)[: b.n]
 
+    # -- the same calls into caller-owned ctypes buffers (what a binding that keeps its buffers would do; no Python copies):
+    # out: c_uint8 * (256 n) / (96 n); blindings: c_uint8 * (32 n) or None; status: c_int32 * n.  Return the call's status.
+    def pedersen_prove_into(self, b, out, blindings=None):
+        return lib().avrf_pedersen_prove(self._h, C.c_size_t(b.n), b.sks, b.pks_xy, b.ios_xy, b.io_counts, b.ads, b.ad_lens, out, blindings)
+
+    def pedersen_verify_into(self, b, status):
+        return lib().avrf_pedersen_verify(self._h, C.c_size_t(b.n), b.ios_xy, b.io_counts, b.ads, b.ad_lens, b.proofs, status)
+
+    def thin_prove_into(self, b, out):
+        return lib().avrf_thin_prove(self._h, C.c_size_t(b.n), b.sks, b.pks_xy, b.ios_xy, b.io_counts, b.ads, b.ad_lens, out)
+
+    def thin_verify_into(self, b, status):
+        return lib().avrf_thin_verify(self._h, C.c_size_t(b.n), b.pks_xy, b.ios_xy, b.io_counts, b.ads, b.ad_lens, b.proofs, status)
+
     def scalar_mul_base(self, scalars):
         n = len(scalars) // 32
         out = (C.c_uint8 * max(1, 64 * n))()

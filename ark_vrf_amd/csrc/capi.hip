@@ -502,6 +502,7 @@ int avrf_thin_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t
   if (n && (!pks_xy || !proofs || !status_out)) return AVRF_ERR_BAD_ARG;
   int st = stage(c, 1, n, nullptr, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs);
   if (st || !n) return st;
+  if (int fs = ensure_fixed(c)) return fs;
   HIP_TRY(c->d_status.ensure(n * 4));
   double t0 = now_us();
   launch_thin_verify(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream);
@@ -533,6 +534,7 @@ int avrf_tiny_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t
   if (n && (!pks_xy || !proofs || !status_out)) return AVRF_ERR_BAD_ARG;
   int st = stage(c, 3, n, nullptr, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs);
   if (st || !n) return st;
+  if (int fs = ensure_fixed(c)) return fs;
   HIP_TRY(c->d_status.ensure(n * 4));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
   launch_tiny_verify(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream);

@@ -81,6 +81,29 @@ k_smul(const uint8_t *__restrict__ scalars, const uint8_t *__restrict__ points_x
   if (f) atomicOr(flags, f);
 }
 
+// s * I_m - c * O_m for the Thin / Tiny verifiers, I_m = G + sum z_i I_i, O_m = pk + sum z_i O_i (thin.rs:158-161, tiny.rs:207).
+// One caller pair (the common case): expanded to s G + (s z) I - c pk - (c z) O -- the generator term comes from the fixed-base
+// table and no merged pair has to be normalised: 253 + 128 doublings instead of 2 x 128 + 253 and an inversion.  More pairs:
+// merge first (one 128-bit multiplication per point), then the two-point form.  Any order gives the same group element.
+template <class S>
+AVRF_DI te_ext schnorr_lhs(const BatchDev &b, const uint8_t *ios, const uint8_t *pk_xy, uint32_t m, const Sha512 &t, const fp &s, const fp &c) {
+  using Fr = typename S::Fr;
+  te_pre op = pre_from_xy<S>(pk_xy);
+  if (m == 0) return te_add<S>(te_smul_fixed<S>(b.fixed, FIXED_G, s), te_smul<S>(te_pre_neg<S>(op), c, 128));
+  uint64_t dseed[8]; delin_seed(t, dseed);
+  if (m == 1) {
+    const fp z = xof128(dseed, 0);
+    const fp sz = fp_mul<Fr>(fp_to_mont<Fr>(s), z), cz = fp_mul<Fr>(fp_to_mont<Fr>(c), z);   // plain products mod r
+    te_ext acc = te_smul2<S>(pre_from_xy<S>(ios), sz, te_pre_neg<S>(pre_from_xy<S>(ios + 64)), cz, Fr::BITS);
+    acc = te_add<S>(acc, te_smul<S>(te_pre_neg<S>(op), c, 128));
+    return te_add<S>(acc, te_smul_fixed<S>(b.fixed, FIXED_G, s));
+  }
+  te_ext im = te_from_pre<S>(g_pre<S>()), om = te_from_pre<S>(op);
+  merge_pairs<S>(ios, m, dseed, false, im, om);
+  te_aff ia, oa; to_aff2<S>(im, om, ia, oa);
+  return te_smul2<S>(pre_from_aff<S>(ia), s, te_pre_neg<S>(pre_from_aff<S>(oa)), c, Fr::BITS);
+}
+
 // ---------------------------------------------------------------- Thin VRF
 
 // TINY: tiny::Prover::prove (src/tiny.rs:163-176) -- the same steps under scheme tag 0x00; the proof keeps the challenge
@@ -147,15 +170,7 @@ k_tiny_verify(BatchDev b, int32_t *__restrict__ status) {
   fp s = fp_load_le(pr + 16);
   if (ge_p<Fr>(s)) f |= FLAG_SCALAR;
   if (f) { status[j] = 2; return; }                                             // InvalidData, tiny.rs:186-198
-  te_pre ip = g_pre<S>(), op = pre_from_xy<S>(pk_xy);
-  if (m) {
-    uint64_t dseed[8]; delin_seed(t, dseed);
-    te_ext im = te_from_pre<S>(ip), om = te_from_pre<S>(op);
-    merge_pairs<S>(ios, m, dseed, false, im, om);
-    te_aff ia, oa; to_aff2<S>(im, om, ia, oa);
-    ip = pre_from_aff<S>(ia); op = pre_from_aff<S>(oa);
-  }
-  te_aff r = te_to_aff<S>(te_smul2<S>(ip, s, te_pre_neg<S>(op), c, Fr::BITS));  // tiny.rs:207
+  te_aff r = te_to_aff<S>(schnorr_lhs<S>(b, ios, pk_xy, m, t, s, c));            // tiny.rs:207
   Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);
   const fp c_exp = challenge_finish(tc);                                        // plain, 128 bits
   status[j] = fp_eq(c_exp, c) ? 0 : 1;
@@ -175,18 +190,10 @@ k_thin_verify(BatchDev b, int32_t *__restrict__ status) {
   if (point_flags<S>(rx, ry) & FLAG_RANGE) f |= FLAG_RANGE;
   if (ge_p<Fr>(s)) f |= FLAG_SCALAR;
   if (f) { status[j] = 2; return; }                                             // InvalidData, thin.rs:140-149
-  te_pre ip = g_pre<S>(), op = pre_from_xy<S>(pk_xy);
-  if (m) {
-    uint64_t dseed[8]; delin_seed(t, dseed);
-    te_ext im = te_from_pre<S>(ip), om = te_from_pre<S>(op);
-    merge_pairs<S>(ios, m, dseed, false, im, om);
-    te_aff ia, oa; to_aff2<S>(im, om, ia, oa);
-    ip = pre_from_aff<S>(ia); op = pre_from_aff<S>(oa);
-  }
   Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_xy<S>(tc, rx, ry);
   fp c = challenge_finish(tc);                                                  // plain, 128 bits
   // s*I_m - c*O_m == R   (thin.rs:158-161)
-  te_ext lhs = te_smul2<S>(ip, s, te_pre_neg<S>(op), c, Fr::BITS);
+  te_ext lhs = schnorr_lhs<S>(b, ios, pk_xy, m, t, s, c);
   te_pre rp = te_make_pre<S>(fp_to_mont<Fq>(rx), fp_to_mont<Fq>(ry));
   status[j] = ext_eq_aff<S>(lhs, rp) ? 0 : 1;
 }

@@ -29,17 +29,24 @@ def timed(f, reps=3):
     return (time.perf_counter() - t) / reps, r
 
 
+import ctypes as C  # noqa: E402
+o256, o96, o32, st32 = (C.c_uint8 * (256 * n))(), (C.c_uint8 * (96 * n))(), (C.c_uint8 * (32 * n))(), (C.c_int32 * n)()
+dev = lambda: ctx.last_timing()[0] / 1e3                            # launch .. results on the host, ms
 pb = nat.Batch(n, ios, [1] * n, adb, adl, pks_xy=pks, sks=sks)
-t, (ped, blind) = timed(lambda: ctx.pedersen_prove(pb))
-print(f"pedersen prove        {n / t:12.0f} /s  ({t * 1e3:.2f} ms per {n})")
+ped, blind = ctx.pedersen_prove(pb)
+t, rc = timed(lambda: ctx.pedersen_prove_into(pb, o256, o32))
+assert rc == 0 and bytes(o256) == ped
+print(f"pedersen prove        {n / t:12.0f} /s  ({t * 1e3:.2f} ms per {n} from host buffers; {dev():.2f} ms after staging)")
 vb = nat.Batch(n, ios, [1] * n, adb, adl, proofs=ped)
-t, st = timed(lambda: ctx.pedersen_verify(vb))
-print(f"pedersen verify       {n / t:12.0f} /s  ({t * 1e3:.2f} ms), all ok: {all(s == 0 for s in st) if hasattr(st, '__iter__') else st}")
+t, rc = timed(lambda: ctx.pedersen_verify_into(vb, st32))
+print(f"pedersen verify       {n / t:12.0f} /s  ({t * 1e3:.2f} ms; {dev():.2f} ms after staging), all ok: {rc == 0 and not any(st32)}")
 ctx.pedersen_batch_stage(vb)
 t, st = timed(lambda: ctx.pedersen_batch_run())
 print(f"pedersen batch verify {n / t:12.0f} /s  ({t * 1e3:.2f} ms), status {st}")
-t, proofs = timed(lambda: ctx.thin_prove(pb))
-print(f"thin prove            {n / t:12.0f} /s  ({t * 1e3:.2f} ms)")
+proofs = ctx.thin_prove(pb)
+t, rc = timed(lambda: ctx.thin_prove_into(pb, o96))
+assert rc == 0 and bytes(o96) == proofs
+print(f"thin prove            {n / t:12.0f} /s  ({t * 1e3:.2f} ms; {dev():.2f} ms after staging)")
 tb = nat.Batch(n, ios, [1] * n, adb, adl, pks_xy=pks, proofs=proofs)
-t, st = timed(lambda: ctx.thin_verify(tb))
-print(f"thin verify           {n / t:12.0f} /s  ({t * 1e3:.2f} ms)")
+t, rc = timed(lambda: ctx.thin_verify_into(tb, st32))
+print(f"thin verify           {n / t:12.0f} /s  ({t * 1e3:.2f} ms; {dev():.2f} ms after staging), all ok: {rc == 0 and not any(st32)}")
