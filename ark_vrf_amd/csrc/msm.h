@@ -71,6 +71,8 @@ void build_g1_table(int curve, const uint32_t *d_bases, size_t n, int c, int nwi
 int msm_g1_fixed_device(int curve, const uint32_t *d_table, int table_c, size_t table_stride, const uint32_t *d_scalars, size_t n,
                         size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch,
                         const uint32_t *d_base_idx = nullptr);
+// n compressed G1 points (FQ_BYTES each, ark-serialize) -> canonical x || y little-endian + ok[i] (0 invalid, 1 point, 2 infinity)
+void launch_g1_decompress(int curve, const uint8_t *d_comp, size_t n, uint8_t *d_out_xy, uint8_t *d_ok, hipStream_t stream);
 void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, uint32_t *d_flag, hipStream_t stream);
 // sets bit 1 of *d_flag when one of the n Montgomery affine bases (as launch_g1_bases writes them) is outside the prime-order
 // subgroup (BLS12-381: endomorphism test; BN254: cofactor 1, no-op)

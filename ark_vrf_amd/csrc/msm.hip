@@ -795,6 +795,58 @@ __global__ void __launch_bounds__(256) k_g1_bases(const uint8_t *__restrict__ xy
   fn_store<N>(out + (size_t)i * 2 * N, fn_to_mont<Fq>(x)); fn_store<N>(out + (size_t)i * 2 * N + N, fn_to_mont<Fq>(y));
 }
 
+// CanonicalDeserialize of compressed G1 points (ark-serialize; the zcash big-endian form for BLS12-381, little-endian with the
+// flags in the last byte for BN254 -- SURVEY.md A.1), one lane per point: x from the bytes, y = (x^3 + b)^((p + 1) / 4)
+// (p = 3 mod 4 for both fields), sign by the "lexicographically largest" flag.  out_xy = x || y canonical little-endian
+// ((0, 0) for the point at infinity), ok[i] = 0 undecodable / not on the curve, 1 a point, 2 infinity.  The ring verifiers
+// need the y coordinates on the HOST too (their transcript absorbs uncompressed points), so the result goes back; a 381-bit
+// square root is ~570 field multiplications, 60 us on a host core.
+template <class C>
+__global__ void __launch_bounds__(64) k_g1_decompress(const uint8_t *__restrict__ comp, uint32_t n, uint8_t *__restrict__ out_xy, uint8_t *__restrict__ ok) {
+  using Fq = typename C::Fq; constexpr int N = Fq::N, FQB = 4 * N;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t *b = comp + (size_t)i * FQB;
+  uint8_t le[FQB]; bool big, inf;
+  if (FQB == 48) {
+    inf = b[0] & 0x40; big = b[0] & 0x20;
+    if (!(b[0] & 0x80)) { ok[i] = 0; return; }
+    for (int k = 0; k < FQB; k++) le[k] = b[FQB - 1 - k];
+    le[FQB - 1] &= 0x1f;
+  } else {
+    inf = b[FQB - 1] & 0x40; big = b[FQB - 1] & 0x80;
+    for (int k = 0; k < FQB; k++) le[k] = b[k];
+    le[FQB - 1] &= 0x3f;
+  }
+  fpn<N> x;
+  for (int k = 0; k < N; k++) x.v[k] = (uint32_t)le[4 * k] | ((uint32_t)le[4 * k + 1] << 8) | ((uint32_t)le[4 * k + 2] << 16) | ((uint32_t)le[4 * k + 3] << 24);
+  uint32_t *o = reinterpret_cast<uint32_t *>(out_xy + (size_t)i * 2 * FQB);
+  if (inf) {                                                          // canonical encoding only: no sort flag, every other bit zero
+    const bool good = !big && fn_is_zero(x);
+    fn_store<N>(o, fn_zero<N>()); fn_store<N>(o + N, fn_zero<N>());
+    ok[i] = good ? 2 : 0; return;
+  }
+  if (fn_ge_p<Fq>(x)) { ok[i] = 0; return; }
+  const fpn<N> xm = fn_to_mont<Fq>(x);
+  const fpn<N> rhs = fn_add<Fq>(fn_mul<Fq>(fn_sqr<Fq>(xm), xm), fn_const<Fq>(C::B));
+  uint32_t e[N];                                                      // (p + 1) / 4 = ((p - 1) / 2 + 1) / 2
+  { uint64_t c = 1; for (int k = 0; k < N; k++) { c += Fq::HALF[k]; e[k] = (uint32_t)c; c >>= 32; } }
+  for (int k = 0; k < N; k++) e[k] = (e[k] >> 1) | (k + 1 < N ? e[k + 1] << 31 : 0u);
+  fpn<N> y = fn_one<Fq>();
+#pragma unroll 1
+  for (int k = 32 * N - 1; k >= 0; k--) {
+    y = fn_sqr<Fq>(y);
+    if ((e[k >> 5] >> (k & 31)) & 1) y = fn_mul<Fq>(y, rhs);
+  }
+  if (!fn_eq(fn_sqr<Fq>(y), rhs)) { ok[i] = 0; return; }             // not on the curve
+  fpn<N> yp = fn_from_mont<Fq>(y);
+  bool is_big = false;                                                // yp > (p - 1) / 2 ?
+  for (int k = N - 1; k >= 0; k--) if (yp.v[k] != Fq::HALF[k]) { is_big = yp.v[k] > Fq::HALF[k]; break; }
+  if (is_big != big) yp = fn_from_mont<Fq>(fn_neg<Fq>(y));
+  fn_store<N>(o, x); fn_store<N>(o + N, yp);
+  ok[i] = 1;
+}
+
 // Fixed-base window table over `n` affine bases: table[w * n + i] = 2^(c w) * P_i, w < nwin, affine Montgomery.
 template <class C>
 __global__ void __launch_bounds__(64)
@@ -935,6 +987,13 @@ void launch_g1_lincomb(int curve, const uint32_t *d_bases, const uint32_t *d_sca
   const dim3 grid((unsigned)((n_items * 16 + 63) / 64)), block(64);
   if (curve == 0) hipLaunchKernelGGL(k_g1_lincomb<G1Bls12381>, grid, block, 0, stream, d_bases, d_scalars, (uint32_t)n_items, tpi, split, d_out);
   else hipLaunchKernelGGL(k_g1_lincomb<G1Bn254>, grid, block, 0, stream, d_bases, d_scalars, (uint32_t)n_items, tpi, split, d_out);
+}
+
+void launch_g1_decompress(int curve, const uint8_t *d_comp, size_t n, uint8_t *d_out_xy, uint8_t *d_ok, hipStream_t stream) {
+  if (!n) return;
+  dim3 g((unsigned)((n + 63) / 64)), b(64);
+  if (curve == 0) hipLaunchKernelGGL(k_g1_decompress<G1Bls12381>, g, b, 0, stream, d_comp, (uint32_t)n, d_out_xy, d_ok);
+  else hipLaunchKernelGGL(k_g1_decompress<G1Bn254>, g, b, 0, stream, d_comp, (uint32_t)n, d_out_xy, d_ok);
 }
 
 void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, uint32_t *d_flag, hipStream_t stream) {

@@ -1230,6 +1230,7 @@ template <class S, class G> struct Ring {
   // two G1 MSMs on the GPU (10 n + 1 and 2 n terms) and one 2-pairing check on the host.
   // each_status != nullptr: the n items are verified INDEPENDENTLY (n x RingVerifier::verify): per-item status, one 2-pairing
   // check per item on the device (k_g1_lincomb + pairing.hip) instead of one randomised check for the whole batch.
+  static constexpr size_t DEVICE_DECOMPRESS_MIN = 128;   // items; below, the pool's cores finish sooner than a device round trip
   static int verify_batch(avrf_ring_setup *su, size_t n, const uint8_t *commitments, const uint32_t *ring_of_item, size_t n_rings,
                           const uint8_t *instances_xy, const uint8_t *proofs, int32_t *each_status = nullptr) {
     if (n == 0) return AVRF_OK;
@@ -1273,6 +1274,24 @@ template <class S, class G> struct Ring {
     // one host task per POINT so that a single verification spreads over the pool
     const size_t g1_off[7] = {0, (size_t)FQB, 2 * (size_t)FQB, 3 * (size_t)FQB, 4 * (size_t)FQB + 7 * 32, 5 * (size_t)FQB + 8 * 32, 6 * (size_t)FQB + 8 * 32};
     std::vector<G1Aff> dec(7 * n); std::vector<uint8_t> dec_ok(7 * n, 0);
+    if (n >= DEVICE_DECOMPRESS_MIN) {
+      // large batches: the square roots on the device (k_g1_decompress), one lane per point; the y coordinates come back
+      // because the transcript replay below absorbs the uncompressed points
+      const size_t np = 7 * n, cb = (np * FQB + 255) / 256 * 256, xb = (np * 2 * FQB + 255) / 256 * 256;
+      std::vector<uint8_t> comp(np * FQB), xy(np * 2 * FQB);
+      for (size_t k = 0; k < np; k++) memcpy(&comp[k * FQB], proofs + plen * (k / 7) + g1_off[k % 7], FQB);
+      uint8_t *base = (uint8_t *)dev_scratch(su, 1, cb + xb + np + 256);
+      HIP_CHECK(hipMemcpyAsync(base, comp.data(), np * FQB, hipMemcpyHostToDevice, su->stream));
+      launch_g1_decompress(su->curve, base, np, base + cb, base + cb + xb, su->stream);
+      HIP_CHECK(hipMemcpyAsync(xy.data(), base + cb, np * 2 * FQB, hipMemcpyDeviceToHost, su->stream));
+      HIP_CHECK(hipMemcpyAsync(dec_ok.data(), base + cb + xb, np, hipMemcpyDeviceToHost, su->stream));
+      HIP_CHECK(hipStreamSynchronize(su->stream)); HIP_CHECK(hipGetLastError());
+      for (size_t k = 0; k < np; k++) {
+        memset(&dec[k], 0, sizeof dec[k]);
+        if (dec_ok[k] == 2) dec[k].inf = true; else memcpy(dec[k].xy, &xy[k * 2 * FQB], 2 * FQB);
+      }
+      lap("G1 decompression (device)");
+    } else
     parallel_for(7 * n, [&](size_t k) {
       const size_t it = k / 7, j = k % 7;
       bool ok = g1_decompress(proofs + plen * it + g1_off[j], &dec[k]);

@@ -170,6 +170,64 @@ def test_ring_verify_each(env, suite):
         assert ring_verify_each(setup, coms, list(range(7)), insts, bad) == [0, 0, 0, 0, 2, 0, 0]
 
 
+@pytest.mark.parametrize("suite", [0, 1])
+def test_ring_verify_large_batch_device_decompression(env, suite):
+    """Batches of >= 128 proofs take the G1 square roots on the device (k_g1_decompress): the reference's seven vectors repeated
+    to 140 items must give the verdicts the small-batch (host decode) path gives item by item -- valid, a perturbed
+    evaluation, an x with no curve point, a flipped sort flag (the other root: a valid point, wrong equation), the canonical
+    and a non-canonical infinity, an x >= p, and (BLS12-381) a point outside the prime-order subgroup."""
+    from ark_vrf_amd.ring import ring_batch_verify, ring_verify_each
+    ctx, setup, vs, srs = env[suite]
+    s = R.SUITES[suite]
+    fq = 48 if suite == 0 else 32
+    reps = 20
+    coms = [bytes.fromhex(v["ring_pks_com"]) for v in vs]
+    insts = [xy(suite, bytes.fromhex(v["proof_pk_com"])) for v in vs] * reps
+    proofs = [bytes.fromhex(v["ring_proof"]) for v in vs] * reps
+    rings = list(range(7)) * reps
+    n = len(proofs)
+    assert n >= 128
+    assert ring_batch_verify(setup, coms, rings, insts, proofs) == 0
+    assert ring_verify_each(setup, coms, rings, insts, proofs) == [0] * n
+
+    def x_without_point():
+        x = 5
+        while R.sqrt_mod((x * x * x + s.g1_b) % s.p, s.p) is not None:
+            x += 1
+        return x
+
+    def enc_x(x, flags):                                   # the compressed form with the given flag bits
+        if suite == 0:
+            b = bytearray(x.to_bytes(48, "big")); b[0] |= flags; return bytes(b)
+        b = bytearray(x.to_bytes(32, "little")); b[31] |= flags; return bytes(b)
+
+    bad = list(proofs)
+    exp = [0] * n
+    b = bytearray(bad[9]); b[4 * fq + 5] ^= 1; bad[9] = bytes(b); exp[9] = 1                        # an evaluation
+    bad[17] = enc_x(x_without_point(), 0x80 if suite == 0 else 0) + bad[17][fq:]; exp[17] = 2       # not on the curve
+    b = bytearray(bad[30]); b[0 if suite == 0 else fq - 1] ^= (0x20 if suite == 0 else 0x80); bad[30] = bytes(b); exp[30] = 1   # -P
+    inf = (bytes([0xC0]) + bytes(47)) if suite == 0 else (bytes(31) + bytes([0x40]))
+    bad[44] = inf + bad[44][fq:]; exp[44] = 1                                                       # canonical infinity decodes
+    bad[51] = (bytes([0xC0]) + bytes(46) + b"\x01" if suite == 0 else b"\x01" + bytes(30) + bytes([0x40])) + bad[51][fq:]; exp[51] = 2
+    bad[66] = enc_x(s.p + 1, 0x80 if suite == 0 else 0) + bad[66][fq:]; exp[66] = 2                # x >= p
+    if suite == 0:
+        x = 0x13c60d23238642ea126a1e48cc11d357c30d8b7628dbd25e63b229f1c4069545de11cc9dea959c212e9c82b1478c281d
+        y = 0x173eb497b4648ea412daae1e11fa194e01a1d4bf7376e7bad3ef138322e23c3c5114b8a96c915d51db072395e4ad9649
+        bad[100] = bad[100][:-48] + R.g1_encode(s, (x, y), True); exp[100] = 2                     # opening proof outside G1
+    got = ring_verify_each(setup, coms, rings, insts, bad)
+    assert got == exp
+    # the same items through the small-batch path (host decode), seven at a time
+    small = []
+    for k in range(0, n, 7):
+        small += ring_verify_each(setup, coms, rings[k: k + 7], insts[k: k + 7], bad[k: k + 7])
+    assert small == exp
+    assert ring_batch_verify(setup, coms, rings, insts, bad) in (1, 2)
+    only_eq = list(proofs); only_eq[9] = bad[9]
+    assert ring_batch_verify(setup, coms, rings, insts, only_eq) == 1
+    only_dec = list(proofs); only_dec[17] = bad[17]
+    assert ring_batch_verify(setup, coms, rings, insts, only_dec) == 2
+
+
 def test_ring_verify_validates_g1_points(env):
     """Validate::Yes of the deserialised RingProof / RingCommitment points (ADVICE r1): a BLS12-381 G1 point ON the curve but
     OUTSIDE the prime-order subgroup (cofactor ~2^126) and a non-canonical encoding of infinity are InvalidData, not merely
