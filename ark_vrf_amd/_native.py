@@ -16,6 +16,7 @@ ERR_NO_DEVICE, ERR_BAD_ARG = -1, -2
 BANDERSNATCH_SHA512_ELL2 = 0
 BABYJUBJUB_SHA512_TAI = 1
 JUBJUB_SHA512_TAI = 2
+ED25519_SHA512_TAI = 3          # Tiny / Thin / Pedersen only (no ring suite)
 
 THIN_PROOF_LEN = 96       # R_xy || s
 PEDERSEN_PROOF_LEN = 256  # Yb_xy || R_xy || Ok_xy || s || sb

@@ -1451,10 +1451,11 @@ extern "C" {
 int avrf_ring_setup_load(avrf_ctx *ctx, const uint8_t *srs, size_t srs_len, size_t ring_size, avrf_ring_setup **out) {
   if (!ctx || !srs || !out || ring_size == 0) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
+  if (!ring_suite(avrf_ctx_suite_(ctx))) return AVRF_ERR_BAD_ARG;      // not a RingSuite (Ed25519)
   return guarded([&] { return with_ring(avrf_ctx_suite_(ctx), [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::setup_load(ctx, srs, srs_len, ring_size, out); }); });
 }
 int avrf_ring_srs_generate(avrf_ctx *ctx, const uint8_t *tau, const uint8_t *g1, const uint8_t *g2, size_t n_g1, uint8_t *out, size_t out_cap, size_t *out_len) {
-  if (!ctx || !tau || !g1 || !g2) return AVRF_ERR_BAD_ARG;
+  if (!ctx || !tau || !g1 || !g2 || !ring_suite(avrf_ctx_suite_(ctx))) return AVRF_ERR_BAD_ARG;
   return guarded([&] { return with_ring(avrf_ctx_suite_(ctx), [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::srs_generate(ctx, tau, g1, g2, n_g1, out, out_cap, out_len); }); });
 }
 size_t avrf_ring_pcs_domain_size(int suite, size_t ring_size) {       /* pcs_domain_size, src/ring.rs:810-817: 3 * piop_domain + 1 */

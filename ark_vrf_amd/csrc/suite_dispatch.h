@@ -4,17 +4,20 @@
 
 namespace avrf {
 
-constexpr int AVRF_N_SUITES = 3;   // 0 Bandersnatch-SHA512-ELL2, 1 BabyJubJub-SHA512-TAI, 2 JubJub-SHA512-TAI
+constexpr int AVRF_N_SUITES = 4;   // 0 Bandersnatch-SHA512-ELL2, 1 BabyJubJub-SHA512-TAI, 2 JubJub-SHA512-TAI, 3 Ed25519-SHA512-TAI
 template <class S> struct SuiteTag { using type = S; };
 
 template <class F> inline auto with_suite(int suite, F &&f) {
   switch (suite) {
     case 1: return f(SuiteTag<SuiteBabyJubJub>{});
     case 2: return f(SuiteTag<SuiteJubJub>{});
+    case 3: return f(SuiteTag<SuiteEd25519>{});
     default: return f(SuiteTag<SuiteBandersnatch>{});
   }
 }
 // RingSuite::Pairing (src/suites/{bandersnatch,jubjub}.rs: BLS12-381; baby_jubjub.rs: BN254): 0 BLS12-381, 1 BN254
 inline int pairing_curve_of(int suite) { return suite == 1 ? 1 : 0; }
+// trait RingSuite (src/ring.rs:97-150) is implemented for the suites whose base field is a pairing curve's scalar field
+inline bool ring_suite(int suite) { return suite >= 0 && suite <= 2; }
 
 }  // namespace avrf

@@ -41,7 +41,8 @@ enum {
 enum {
   AVRF_SUITE_BANDERSNATCH_SHA512_ELL2 = 0, /* src/suites/bandersnatch.rs:62-105 */
   AVRF_SUITE_BABYJUBJUB_SHA512_TAI = 1,    /* src/suites/baby_jubjub.rs:56-95   */
-  AVRF_SUITE_JUBJUB_SHA512_TAI = 2         /* src/suites/jubjub.rs:56-95 (ring proofs over BLS12-381) */
+  AVRF_SUITE_JUBJUB_SHA512_TAI = 2,        /* src/suites/jubjub.rs:56-95 (ring proofs over BLS12-381) */
+  AVRF_SUITE_ED25519_SHA512_TAI = 3        /* src/suites/ed25519.rs:44-66 (Tiny / Thin / Pedersen; no RingSuite: avrf_ring_* -> BAD_ARG) */
 };
 
 typedef struct avrf_ctx avrf_ctx;

@@ -15,6 +15,7 @@ _SO = os.path.join(_DIR, "_build", "liborc.so")
 BANDERSNATCH = 0
 BABYJUBJUB = 1
 JUBJUB = 2
+ED25519 = 3
 
 OK, VERIFICATION_FAILURE, INVALID_DATA = 0, 1, 2
 

@@ -47,7 +47,7 @@ typedef struct {
 typedef struct { u256 x, y; } te_aff;        /* Montgomery-form coordinates */
 typedef struct { u256 x, y, t, z; } te_ext;  /* extended twisted Edwards */
 
-enum { ORC_SUITE_BANDERSNATCH = 0, ORC_SUITE_BABYJUBJUB = 1, ORC_SUITE_JUBJUB = 2 };
+enum { ORC_SUITE_BANDERSNATCH = 0, ORC_SUITE_BABYJUBJUB = 1, ORC_SUITE_JUBJUB = 2, ORC_SUITE_ED25519 = 3 };
 enum { ORC_H2C_ELL2 = 0, ORC_H2C_TAI = 1 };
 
 typedef struct {

@@ -15,7 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-static suite_t g_suites[3];
+static suite_t g_suites[4];
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;      /* gen_batch() calls in from several threads at once */
 
 static void fq_dec(u256 *o, const char *dec, const mont_t *m) {
@@ -94,11 +94,30 @@ static void init_suites(void) {
     fq_dec(&s->ACC.y, "34380560660182334518990118617091967209302636551264477863958902286043397647879", &s->fq);
     fq_dec(&s->PAD.x, "17348704025397475127937572481155408456556065464328870407269802701696798733683", &s->fq);
     fq_dec(&s->PAD.y, "24318278422173803457621119807961883607097742387673491974779969503617097905596", &s->fq);
+
+    /* ---- Ed25519-SHA512-TAI-v1 (src/suites/ed25519.rs:44-66; curve: ark-ed25519 = edwards25519, a = -1, d = -121665/121666).
+     * Tiny / Thin / Pedersen only: the reference implements no RingSuite for it; ACC / PAD are unused placeholders. ---- */
+    s = &g_suites[3];
+    memset(s, 0, sizeof *s);
+    s->id = ORC_SUITE_ED25519;
+    s->suite_id = "Ed25519-SHA512-TAI-v1"; s->suite_id_len = 21;
+    u256_from_dec(&p, "57896044618658097711785492504343953926634992332820282019728792003956564819949");
+    mont_init(&s->fq, &p);
+    u256_from_dec(&p, "7237005577332262213973186563042994240857116359379907606001950938285454250989");
+    mont_init(&s->fr, &p);
+    { u256 one; fq_small(&one, 1, &s->fq); mont_neg(&s->a, &one, &s->fq); }
+    fq_dec(&s->d, "37095705934669439343138083508754565189542113879843219016388785533085940283555", &s->fq);
+    s->cofactor = 8; s->h2c = ORC_H2C_TAI;
+    fq_dec(&s->G.x, "15112221349535400772501151409588531511454012693041857206046113283949847762202", &s->fq);
+    fq_dec(&s->G.y, "46316835694926478169428394003475163141307993866256225615783033603165251855960", &s->fq);
+    fq_dec(&s->B.x, "45003173884697328536089278691112838614164406922820087464913813433380838325453", &s->fq);
+    fq_dec(&s->B.y, "31256014272390301975555524011230972931324093235775711248505761870355310252869", &s->fq);
+    s->ACC = s->G; s->PAD = s->G;
 }
 
 const suite_t *orc_suite(int id) {
     pthread_once(&g_once, init_suites);
-    if (id < 0 || id > 2) return NULL;
+    if (id < 0 || id > 3) return NULL;
     return &g_suites[id];
 }
 

@@ -17,6 +17,7 @@ SUITES = {
     "bandersnatch_sha-512_ell2": orc.BANDERSNATCH,
     "baby-jubjub_sha-512_tai": orc.BABYJUBJUB,
     "jubjub_sha-512_tai": orc.JUBJUB,                 # src/suites/jubjub.rs
+    "ed25519_sha-512_tai": orc.ED25519,               # src/suites/ed25519.rs (Tiny / Thin / Pedersen; no ring suite)
 }
 SEEDS = [1, 2, 3, 4, 5, 5, 6]
 
@@ -106,6 +107,8 @@ def test_suite_constants(golden_dir, name):
     (src/pedersen.rs:39,568-579 `blinding_base_check`; src/ring.rs:66-69 `padding_check`, `accumulator_base_check`)."""
     s = SUITES[name]
     assert orc.hash_to_curve(s, b"pedersen-blinding") == orc.suite_point(s, 1)
+    if s == orc.ED25519:                                   # not a RingSuite: no accumulator base / padding point
+        return
     assert orc.hash_to_curve(s, b"ring-accumulator") == orc.suite_point(s, 2)
     assert orc.hash_to_curve(s, b"ring-padding") == orc.suite_point(s, 3)
 
