@@ -461,7 +461,7 @@ using namespace avrf;
 
 struct avrf_ring_setup {
   avrf_ctx *ctx; int suite; int curve; hipStream_t stream; int device;   // curve: pairing curve of the suite (0 BLS12-381, 1 BN254)
-  size_t N, cap, keyset, L, n_srs;
+  size_t N, cap, keyset, L, n_srs;                    // n_srs = 0: verifier-only setup (PcsVerifierParams), no SRS on the device
   uint32_t *d_srs = nullptr;                          // n_srs Montgomery affine points
   uint32_t *d_srs_table = nullptr; int table_c = 0, table_nwin = 0;   // fixed-base window table over the SRS (batched commits)
   int wit_c = 0, wit_nwin = 0;                        // window width of the witness table (sparse MSMs: few entries, small buckets)
@@ -667,6 +667,52 @@ template <class S, class G> struct Ring {
       h = Te::dbl(h);
     }
     *out = su;
+    return AVRF_OK;
+  }
+
+  // ---- verifier-only setup (src/ring.rs:466-482 verifier_key_from_commitment: "verifier-only users: no SRS required"):
+  // built from PcsVerifierParams = RawKzgVerifierKey { g1, g2, tau_in_g2 } (RingSetup::pcs_verifier_params, src/ring.rs:435)
+  // in either ark-serialize mode.  Carries what the verifiers use -- domain, g1, (g2, tau g2) -- and no SRS: index / prove /
+  // builder / serialisation of the full setup answer AVRF_SRS_LOOKUP_FAILED on such a handle.
+  static int verifier_setup_load(avrf_ctx *ctx, const uint8_t *vp, size_t len, size_t ring_size, avrf_ring_setup **out) {
+    using HP = HostPairing<G>;
+    const size_t L = S::Fr::BITS, e1 = 2 * FQB, e2 = 4 * FQB;
+    size_t need = ring_size + 4 + L, N = 1; while (N < need) N <<= 1;
+    G1Aff g1; std::vector<uint8_t> g2(2 * e2);
+    if (len == e1 + 2 * e2) {
+      g1 = g1_from_raw(vp);
+      memcpy(g2.data(), vp + e1, 2 * e2);
+      typename HP::G2 q;
+      for (int i = 0; i < 2; i++) if (!HP::g2_decode(g2.data() + (size_t)i * e2, &q)) return AVRF_INVALID_DATA;
+    } else if (len == FQB + 2 * 2 * FQB) {
+      if (!g1_decompress(vp, &g1)) return AVRF_INVALID_DATA;
+      for (int i = 0; i < 2; i++) {
+        typename HP::G2 q;
+        if (!HP::g2_decode_compressed(vp + FQB + (size_t)i * 2 * FQB, &q)) return AVRF_INVALID_DATA;
+        HP::g2_encode(q, g2.data() + (size_t)i * e2);
+      }
+    } else return AVRF_INVALID_DATA;
+    if (g1.inf || !g1_in_subgroup_host(g1)) return AVRF_INVALID_DATA;
+    avrf_ring_setup *su = new avrf_ring_setup();
+    su->ctx = ctx; su->suite = S::ID; su->curve = pairing_curve_of(S::ID); su->stream = avrf_ctx_stream_(ctx); su->device = avrf_ctx_device_(ctx);
+    su->N = N; su->cap = N - 3; su->L = L; su->keyset = su->cap - L - 1; su->n_srs = 0;
+    su->g1_0 = g1; su->g2_raw = g2;
+    H256 root = Fr::from32(G::ROOT_OF_UNITY);
+    int lg = 0; while (((size_t)1 << lg) < N) lg++;
+    H256 w4 = root; for (int i = 0; i < G::TWO_ADICITY - (lg + 2); i++) w4 = Fr::sqr(w4);
+    su->w4 = w4; su->w = Fr::sqr(Fr::sqr(w4));
+    su->ninv = Fr::inv(fr_small<F>(N)); su->n4inv = Fr::inv(fr_small<F>(4 * N));
+    *out = su;
+    return AVRF_OK;
+  }
+  static int verifier_params_serialize(avrf_ring_setup *su, bool compress, std::vector<uint8_t> &o) {
+    using HP = HostPairing<G>;
+    g1_encode<G>(su->g1_0, compress, o);
+    if (!compress) { o.insert(o.end(), su->g2_raw.begin(), su->g2_raw.end()); return AVRF_OK; }
+    for (int i = 0; i < 2; i++) {
+      typename HP::G2 q; HP::g2_decode(su->g2_raw.data() + (size_t)i * 4 * FQB, &q);
+      size_t at = o.size(); o.resize(at + 2 * FQB); HP::g2_encode_compressed(q, &o[at]);
+    }
     return AVRF_OK;
   }
 
@@ -1488,6 +1534,7 @@ size_t avrf_ring_commitment_len(const avrf_ring_setup *su) { return su ? (su->cu
 int avrf_ring_index(avrf_ring_setup *su, const uint8_t *pks_xy, size_t n_keys, avrf_ring_key **out, uint8_t *commitment_out) {
   if (!su || !out || (n_keys && !pks_xy)) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
+  if (!su->n_srs) return AVRF_SRS_LOOKUP_FAILED;                       // verifier-only setup
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   int st = guarded([&] { return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::index(su, pks_xy, n_keys, out); }); });
   if (st == AVRF_OK && commitment_out) {
@@ -1502,6 +1549,7 @@ void avrf_ring_key_free(avrf_ring_key *k) { if (!k) return; if (k->d_fixed4) (vo
 int avrf_ring_vk_builder_new(avrf_ring_setup *su, avrf_ring_vk_builder **out) {
   if (!su || !out) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
+  if (!su->n_srs) return AVRF_SRS_LOOKUP_FAILED;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   return guarded([&] { return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::builder_new(su, out); }); });
 }
@@ -1557,14 +1605,28 @@ static int copy_out(const std::vector<uint8_t> &v, uint8_t *out, size_t cap, siz
   memcpy(out, v.data(), v.size());
   return AVRF_OK;
 }
+int avrf_ring_verifier_setup_load(avrf_ctx *ctx, const uint8_t *params, size_t params_len, size_t ring_size, avrf_ring_setup **out) {
+  if (!ctx || !params || !out || ring_size == 0) return AVRF_ERR_BAD_ARG;
+  *out = nullptr;
+  if (!ring_suite(avrf_ctx_suite_(ctx))) return AVRF_ERR_BAD_ARG;
+  return guarded([&] { return with_ring(avrf_ctx_suite_(ctx), [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::verifier_setup_load(ctx, params, params_len, ring_size, out); }); });
+}
+int avrf_ring_pcs_verifier_params_serialize(avrf_ring_setup *su, int compress, uint8_t *out, size_t out_cap, size_t *out_len) {
+  if (!su) return AVRF_ERR_BAD_ARG;
+  std::vector<uint8_t> v;
+  int st = guarded([&] { return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::verifier_params_serialize(su, compress != 0, v); }); });
+  return st ? st : copy_out(v, out, out_cap, out_len);
+}
 int avrf_ring_setup_serialize(avrf_ring_setup *su, int compress, uint8_t *out, size_t out_cap, size_t *out_len) {
   if (!su) return AVRF_ERR_BAD_ARG;
+  if (!su->n_srs) return AVRF_SRS_LOOKUP_FAILED;
   std::vector<uint8_t> v;
   int st = guarded([&] { return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::setup_serialize(su, compress != 0, v); }); });
   return st ? st : copy_out(v, out, out_cap, out_len);
 }
 int avrf_ring_builder_params_serialize(avrf_ring_setup *su, int compress, uint8_t *out, size_t out_cap, size_t *out_len) {
   if (!su) return AVRF_ERR_BAD_ARG;
+  if (!su->n_srs) return AVRF_SRS_LOOKUP_FAILED;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   std::vector<uint8_t> v;
   int st = guarded([&] { return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::builder_params_serialize(su, compress != 0, v); }); });

@@ -37,17 +37,20 @@ class RingKey:
 
 
 class RingSetup:
-    def __init__(self, ctx, srs_bytes, ring_size):
+    def __init__(self, ctx, srs_bytes, ring_size, verifier_only=False):
+        """srs_bytes: the URS (RingSetup / PcsParams, either ark-serialize mode); with verifier_only=True the serialised
+        PcsVerifierParams (g1, g2, tau g2) instead -- a setup that verifies but holds no SRS (src/ring.rs:466-482)."""
         L = nat.lib()
         for f in ("avrf_ring_max_ring_size", "avrf_ring_domain_size", "avrf_ring_proof_len", "avrf_ring_commitment_len"):
             getattr(L, f).restype = C.c_size_t
         self.ctx = ctx
         self._h = C.c_void_p()
-        st = L.avrf_ring_setup_load(ctx._h, nat._u8(srs_bytes), C.c_size_t(len(srs_bytes)), C.c_size_t(ring_size), C.byref(self._h))
+        fn = "avrf_ring_verifier_setup_load" if verifier_only else "avrf_ring_setup_load"
+        st = getattr(L, fn)(ctx._h, nat._u8(srs_bytes), C.c_size_t(len(srs_bytes)), C.c_size_t(ring_size), C.byref(self._h))
         self.status = st
         if st != nat.OK:
             self._h = None
-            raise nat.AvrfError(f"avrf_ring_setup_load -> {st}")
+            raise nat.AvrfError(f"{fn} -> {st}")
         self.max_ring_size = L.avrf_ring_max_ring_size(self._h)
         self.domain_size = L.avrf_ring_domain_size(self._h)
         self.proof_len = L.avrf_ring_proof_len(self._h)
@@ -65,6 +68,10 @@ class RingSetup:
     def serialize(self, compress=False):
         """CanonicalSerialize for RingSetup (src/ring.rs:484-521): the URS bytes this setup keeps."""
         return self._ser("avrf_ring_setup_serialize", compress)
+
+    def pcs_verifier_params(self, compress=False):
+        """RingSetup::pcs_verifier_params (src/ring.rs:435): RawKzgVerifierKey { g1, g2, tau_in_g2 }, serialised."""
+        return self._ser("avrf_ring_pcs_verifier_params_serialize", compress)
 
     def builder_params(self, compress=False):
         """RingBuilderPcsParams (src/ring.rs:523-529): the SRS in Lagrangian form, serialised."""

@@ -196,6 +196,14 @@ int avrf_ring_srs_generate(avrf_ctx *ctx, const uint8_t *tau, const uint8_t *g1,
  * reference from RingSetup::verifier_key_builder), compress = 0 / 1 for ark-serialize's two modes.  *out_len = bytes needed
  * (also when `out` is NULL or too small -> AVRF_ERR_BAD_ARG). */
 int avrf_ring_setup_serialize(avrf_ring_setup *setup, int compress, uint8_t *out, size_t out_cap, size_t *out_len);
+/* Verifier-only setup (src/ring.rs:466-482, verifier_key_from_commitment: "verifier-only users: no SRS required"):
+ * avrf_ring_pcs_verifier_params_serialize writes RingSetup::pcs_verifier_params() (src/ring.rs:435) =
+ * RawKzgVerifierKey { g1, g2, tau_in_g2 } in either ark-serialize mode; avrf_ring_verifier_setup_load builds from those bytes
+ * (points validated) a setup handle that serves avrf_ring_batch_verify / avrf_ring_verify_each / avrf_ring_vrf_verify /
+ * avrf_ring_pairing_check and nothing that needs the SRS (index, prove, builder, setup serialisation ->
+ * AVRF_SRS_LOOKUP_FAILED). */
+int avrf_ring_pcs_verifier_params_serialize(avrf_ring_setup *setup, int compress, uint8_t *out, size_t out_cap, size_t *out_len);
+int avrf_ring_verifier_setup_load(avrf_ctx *ctx, const uint8_t *params, size_t params_len, size_t ring_size, avrf_ring_setup **out);
 int avrf_ring_builder_params_serialize(avrf_ring_setup *setup, int compress, uint8_t *out, size_t out_cap, size_t *out_len);
 size_t avrf_ring_pcs_domain_size(int suite, size_t ring_size);   /* pcs_domain_size, src/ring.rs:810-817 */
 size_t avrf_ring_max_ring_size(const avrf_ring_setup *setup);   /* RingContext::max_ring_size, src/ring.rs:298-300 */

@@ -449,6 +449,49 @@ def test_setup_serialisation(env, suite):
 
 
 @pytest.mark.parametrize("suite", [0, 1])
+def test_verifier_only_setup(env, suite):
+    """verifier_key_from_commitment with independently distributed PcsVerifierParams (src/ring.rs:435,466-482): a setup built
+    from the serialised (g1, g2, tau g2) alone verifies exactly like the full one and refuses everything that needs the SRS."""
+    from ark_vrf_amd import _native as nat
+    from ark_vrf_amd.ring import RingSetup, VerifierKeyBuilder, ring_batch_verify, ring_verify_each
+    ctx, setup, vs, srs = env[suite]
+    s = R.SUITES[suite]
+    fq = 48 if suite == 0 else 32
+    coms = [bytes.fromhex(v["ring_pks_com"]) for v in vs]
+    insts = [xy(suite, bytes.fromhex(v["proof_pk_com"])) for v in vs]
+    proofs = [bytes.fromhex(v["ring_proof"]) for v in vs]
+    raw, comp = setup.pcs_verifier_params(False), setup.pcs_verifier_params(True)
+    assert (len(raw), len(comp)) == (2 * fq + 2 * 4 * fq, fq + 2 * 2 * fq)
+    n1 = int.from_bytes(srs[:8], "little")
+    assert raw == srs[8: 8 + 2 * fq] + srs[8 + n1 * 2 * fq + 8:]                    # powers_in_g1[0] || powers_in_g2[0..2] of the file
+    for blob in (raw, comp):
+        vo = RingSetup(ctx, blob, 8, verifier_only=True)
+        assert (vo.domain_size, vo.max_ring_size, vo.proof_len) == (setup.domain_size, setup.max_ring_size, setup.proof_len)
+        assert vo.pcs_verifier_params(True) == comp
+        assert ring_batch_verify(vo, coms, list(range(7)), insts, proofs) == 0
+        assert ring_verify_each(vo, coms, list(range(7)), insts, proofs) == [0] * 7
+        bad = list(proofs); b = bytearray(bad[3]); b[4 * fq + 9] ^= 2; bad[3] = bytes(b)
+        assert ring_batch_verify(vo, coms, list(range(7)), insts, bad) == 1
+        assert ring_verify_each(vo, coms, list(range(7)), insts, bad) == [0, 0, 0, 1, 0, 0, 0]
+        big = 20
+        assert ring_verify_each(vo, coms, list(range(7)) * big, insts * big, proofs * big) == [0] * (7 * big)   # device decompression path
+        pk = xy(suite, bytes.fromhex(vs[0]["pk"]))
+        for call in (lambda: vo.index([pk]), lambda: VerifierKeyBuilder(vo), lambda: vo.serialize(), lambda: vo.builder_params()):
+            with pytest.raises(nat.AvrfError, match="-> 4"):                      # SrsLookupFailed
+                call()
+        vo.close()
+    with pytest.raises(nat.AvrfError, match="-> 2"):
+        RingSetup(ctx, raw[:-1], 8, verifier_only=True)
+    flipped = bytearray(comp); flipped[1] ^= 1                                    # another x: off the curve or outside the subgroup
+    try:
+        RingSetup(ctx, bytes(flipped), 8, verifier_only=True).close()
+        ok = suite == 1                                                           # BN254 G1 has cofactor 1: every curve point is valid
+    except nat.AvrfError:
+        ok = True
+    assert ok
+
+
+@pytest.mark.parametrize("suite", [0, 1])
 def test_verifier_key_builder(env, suite):
     """VerifierKeyBuilder (src/ring.rs:539-637; reference test `verifier_key_builder`, src/ring.rs:1224-1290): keys appended
     in batches give the commitment of `verifier_key(keys)` -- here the reference vector's `ring_pks_com` and
