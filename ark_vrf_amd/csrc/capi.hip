@@ -485,6 +485,7 @@ int avrf_thin_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pk
   int st = stage(c, 1, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, nullptr);
   if (st || !n) return st;
   c->staged_kind = 0;
+  if (int fs = ensure_fixed(c)) return fs;
   BatchDev b = batch_of(c); if (!pks_xy) b.pks_xy = nullptr;
   HIP_TRY(c->d_out.ensure(n * 96));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
@@ -520,6 +521,7 @@ int avrf_tiny_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pk
   int st = stage(c, 3, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, nullptr);
   if (st || !n) return st;
   c->staged_kind = 0;
+  if (int fs = ensure_fixed(c)) return fs;
   BatchDev b = batch_of(c); if (!pks_xy) b.pks_xy = nullptr;
   HIP_TRY(c->d_out.ensure(n * 48));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));

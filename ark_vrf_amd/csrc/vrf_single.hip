@@ -125,20 +125,29 @@ k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict_
   Sha512 t; uint32_t pf = 0;
   tr_base<S>(t, TINY ? DS_TINY : DS_THIN, true, pk_xy, ios, m, b.ads + ad0, adl, &pf);   // thin.rs:112, tiny.rs:164
   f |= pf & FLAG_RANGE;
-  // merged input I_m = G + sum z_i I_i  (only the input is needed by the prover)
-  te_pre im_pre = g_pre<S>();
-  if (m) {
+  // R = k I_m with the merged input I_m = G + sum z_i I_i (only the input is needed by the prover; thin.rs:115-119).
+  // No pair: k G from the fixed-base table.  One pair: k G + (k z) I -- table + ONE 253-bit multiplication, nothing to merge or
+  // normalise.  More: merge (a 128-bit multiplication per input), then k I_m.
+  fp k = nonce<S>(sk, t);                                                       // thin.rs:115
+  const fp k_plain = fp_from_mont<Fr>(k);
+  te_ext rr;
+  if (m <= 1) {
+    rr = te_smul_fixed<S>(b.fixed, FIXED_G, k_plain);
+    if (m) {
+      uint64_t dseed[8]; delin_seed(t, dseed);
+      const fp kz = fp_mul<Fr>(k, xof128(dseed, 0));                            // Montgomery k times plain z: plain k z mod r
+      rr = te_add<S>(rr, te_smul<S>(pre_from_xy<S>(ios), kz, Fr::BITS));
+    }
+  } else {
     uint64_t dseed[8]; delin_seed(t, dseed);
-    te_ext im = te_from_pre<S>(g_pre<S>()), om = te_identity<S>();
+    te_ext im = te_from_pre<S>(g_pre<S>());
     for (uint32_t i = 0; i < m; i++) {
       te_pre pi = pre_from_xy<S>(ios + 128 * (size_t)i);
       im = te_add<S>(im, te_smul<S>(pi, xof128(dseed, i), 128));
     }
-    (void)om;
-    im_pre = pre_from_aff<S>(te_to_aff<S>(im));
+    rr = te_smul<S>(pre_from_aff<S>(te_to_aff<S>(im)), k_plain, Fr::BITS);
   }
-  fp k = nonce<S>(sk, t);                                                       // thin.rs:115
-  te_aff r = te_to_aff<S>(te_smul<S>(im_pre, fp_from_mont<Fr>(k), Fr::BITS));   // thin.rs:119
+  te_aff r = te_to_aff<S>(rr);                                                  // thin.rs:119
   Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);    // thin.rs:122
   fp c = fp_to_mont<Fr>(challenge_finish(tc));
   fp s = fp_add<Fr>(k, fp_mul<Fr>(c, fp_to_mont<Fr>(sk)));                      // thin.rs:125
