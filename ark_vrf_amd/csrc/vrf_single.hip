@@ -10,6 +10,7 @@
 // The merged I/O pair follows vrf_transcript_from_iter / merge_ios (src/utils/common.rs:181-202,
 // 389-419); any summation order gives the same group element.
 #include "proto_dev.h"
+#include "glv.h"
 #include "suite_dispatch.h"
 
 namespace avrf { struct te_pre_raw; }   // msm.h: the 96-byte storage form of te_pre
@@ -76,7 +77,7 @@ k_smul(const uint8_t *__restrict__ scalars, const uint8_t *__restrict__ points_x
     f |= point_flags<S>(x, y) & FLAG_RANGE;
     p = pre_from_xy<S>(points_xy + 64 * (size_t)j);
   }
-  te_aff r = te_to_aff<S>(points_xy ? te_smul<S>(p, k, Fr::BITS) : te_smul_fixed<S>(fixed, FIXED_G, k));
+  te_aff r = te_to_aff<S>(points_xy ? te_smul_glv<S>(p, k) : te_smul_fixed<S>(fixed, FIXED_G, k));
   store_xy<S>(out_xy + 64 * (size_t)j, r);
   if (f) atomicOr(flags, f);
 }
@@ -94,14 +95,13 @@ AVRF_DI te_ext schnorr_lhs(const BatchDev &b, const uint8_t *ios, const uint8_t 
   if (m == 1) {
     const fp z = xof128(dseed, 0);
     const fp sz = fp_mul<Fr>(fp_to_mont<Fr>(s), z), cz = fp_mul<Fr>(fp_to_mont<Fr>(c), z);   // plain products mod r
-    te_ext acc = te_smul2<S>(pre_from_xy<S>(ios), sz, te_pre_neg<S>(pre_from_xy<S>(ios + 64)), cz, Fr::BITS);
-    acc = te_add<S>(acc, te_smul<S>(te_pre_neg<S>(op), c, 128));
+    te_ext acc = te_smul_multi_glv<S, true>(pre_from_xy<S>(ios), sz, te_pre_neg<S>(pre_from_xy<S>(ios + 64)), cz, te_pre_neg<S>(op), c);
     return te_add<S>(acc, te_smul_fixed<S>(b.fixed, FIXED_G, s));
   }
   te_ext im = te_from_pre<S>(g_pre<S>()), om = te_from_pre<S>(op);
   merge_pairs<S>(ios, m, dseed, false, im, om);
   te_aff ia, oa; to_aff2<S>(im, om, ia, oa);
-  return te_smul2<S>(pre_from_aff<S>(ia), s, te_pre_neg<S>(pre_from_aff<S>(oa)), c, Fr::BITS);
+  return te_smul_multi_glv<S, false>(pre_from_aff<S>(ia), s, pre_from_aff<S>(ia), fp_zero(), te_pre_neg<S>(pre_from_aff<S>(oa)), c);
 }
 
 // ---------------------------------------------------------------- Thin VRF
@@ -136,7 +136,7 @@ k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict_
     if (m) {
       uint64_t dseed[8]; delin_seed(t, dseed);
       const fp kz = fp_mul<Fr>(k, xof128(dseed, 0));                            // Montgomery k times plain z: plain k z mod r
-      rr = te_add<S>(rr, te_smul<S>(pre_from_xy<S>(ios), kz, Fr::BITS));
+      rr = te_add<S>(rr, te_smul_glv<S>(pre_from_xy<S>(ios), kz));
     }
   } else {
     uint64_t dseed[8]; delin_seed(t, dseed);
@@ -145,7 +145,7 @@ k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict_
       te_pre pi = pre_from_xy<S>(ios + 128 * (size_t)i);
       im = te_add<S>(im, te_smul<S>(pi, xof128(dseed, i), 128));
     }
-    rr = te_smul<S>(pre_from_aff<S>(te_to_aff<S>(im)), k_plain, Fr::BITS);
+    rr = te_smul_glv<S>(pre_from_aff<S>(te_to_aff<S>(im)), k_plain);
   }
   te_aff r = te_to_aff<S>(rr);                                                  // thin.rs:119
   Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);    // thin.rs:122
@@ -246,7 +246,7 @@ k_ped_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ 
   fp k = nonce<S>(sk, t), kb = nonce<S>(bl_plain, t);                           // :155-156
   fp k_plain = fp_from_mont<Fr>(k);
   te_ext R = te_add<S>(te_smul_fixed<S>(b.fixed, FIXED_G, k_plain), te_smul_fixed<S>(b.fixed, FIXED_B, fp_from_mont<Fr>(kb)));   // :159-161
-  te_ext OK = have_input ? te_smul<S>(ip, k_plain, Fr::BITS) : te_identity<S>();             // :164
+  te_ext OK = have_input ? te_smul_glv<S>(ip, k_plain) : te_identity<S>();                   // :164
   te_aff ra, oka; to_aff2<S>(R, OK, ra, oka);                                   // :166-167
   Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, ra); absorb_point_mont<S>(tc, oka);
   fp c = fp_to_mont<Fr>(challenge_finish(tc));                                  // :170
@@ -288,7 +288,7 @@ k_ped_verify(BatchDev b, int32_t *__restrict__ status) {
   sha512_byte(t, DS_CHALLENGE); absorb_point_xy<S>(t, rx, ry); absorb_point_xy<S>(t, okx, oky);
   fp c = challenge_finish(t);                                                  // :222
   // Eq1: s*I - c*O == Ok   (:229-232)
-  te_ext lhs1 = have_io ? te_smul2<S>(ip, s, te_pre_neg<S>(op), c, Fr::BITS) : te_identity<S>();
+  te_ext lhs1 = have_io ? te_smul_multi_glv<S, false>(ip, s, ip, fp_zero(), te_pre_neg<S>(op), c) : te_identity<S>();
   te_pre okp = te_make_pre<S>(fp_to_mont<Fq>(okx), fp_to_mont<Fq>(oky));
   if (!ext_eq_aff<S>(lhs1, okp)) { status[j] = 1; return; }
   // Eq2: s*G + sb*B - c*Yb == R   (:238-245)

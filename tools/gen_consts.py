@@ -63,7 +63,7 @@ def field_n(name, p, nl):
     return "\n".join(s)
 
 
-def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None):
+def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=None):
     sid_bytes = ", ".join(str(b) for b in sid_str.encode())
     s = [f"struct {name} {{", f"  using Fq = {fq}; using Fr = {fr};",
          f"  static constexpr int SUITE_ID_LEN = {len(sid_str)};",
@@ -85,8 +85,67 @@ def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None):
     s.append(f"  static constexpr uint32_t ELL2_JK[8] = {{{limbs(mont(j * kinv % q, q))}}};     /* J / K */")
     s.append(f"  static constexpr uint32_t ELL2_K[8] = {{{limbs(mont(k, q))}}};")
     s.append(f"  static constexpr uint32_t ELL2_KINV2[8] = {{{limbs(mont(kinv * kinv % q, q))}}};  /* 1 / K^2 */")
+    # GLV (per-item scalar multiplications): k = k1 + k2 * lambda (mod r), |k1|, |k2| < 2^127, psi = [lambda] as a rational map
+    s.append(f"  static constexpr bool HAS_GLV = {'true' if glv else 'false'};")
+    if glv:
+        lw = lambda v, n: ", ".join(f"0x{(v >> (32 * i)) & 0xffffffff:08x}u" for i in range(n))
+        for nm, v, n in (("GLV_G1", glv["g1"], 4), ("GLV_G2", glv["g2"], 5), ("GLV_A1", glv["a1"], 4), ("GLV_A2", glv["a2"], 4),
+                         ("GLV_B1N", glv["b1n"], 4), ("GLV_B2", glv["b2"], 4)):
+            assert 0 <= v < 1 << (32 * n)
+            s.append(f"  static constexpr uint32_t {nm}[{n}] = {{{lw(v, n)}}};")
+        s.append(f"  static constexpr uint32_t ENDO_B[8] = {{{limbs(mont(glv['eb'], q))}}};  /* psi(x, y) = (c (1 - y^2) / (x y), b (y^2 + b) / (y^2 - b)) */")
+        s.append(f"  static constexpr uint32_t ENDO_C[8] = {{{limbs(mont(glv['ec'], q))}}};")
     s.append("};")
     return "\n".join(s)
+
+
+def glv_bandersnatch(q, r):
+    """Lattice basis of {(a, b): a + b lambda = 0 mod r} for lambda = sqrt(-2) mod r (the eigenvalue of the degree-2 endomorphism
+    psi of Bandersnatch, Masson-Sanso-Zhang 2021), the rounding multipliers g_i = round(2^256 b_i' / r) of the decomposition
+    c1 = (k g1) >> 256, c2 = (k g2) >> 256, k1 = k - c1 a1 - c2 a2, k2 = c1 |b1| - c2 b2, and the two constants of psi in
+    twisted-Edwards coordinates.  Everything is re-derived here and checked: lambda^2 = -2, psi(G) = [lambda] G (affine
+    arithmetic below), |k1|, |k2| < 2^127 on random scalars."""
+    import math
+    import random
+    lam = 0x13b4f3dc4a39a493edf849562b38c72bcfc49db970a5056ed13d21408783df05
+    assert (lam * lam + 2) % r == 0
+    r0, r1, t0, t1, rows = r, lam, 0, 1, []
+    while r1:
+        qq = r0 // r1; r0, r1 = r1, r0 - qq * r1; t0, t1 = t1, t0 - qq * t1
+        rows.append((r0, -t0))
+    sq = math.isqrt(r)
+    l = next(i for i in range(len(rows) - 1) if rows[i][0] >= sq > rows[i + 1][0])
+    v1, c0, c2 = rows[l + 1], rows[l], rows[l + 2]
+    v2 = c0 if c0[0] ** 2 + c0[1] ** 2 <= c2[0] ** 2 + c2[1] ** 2 else c2
+    (a1, b1), (a2, b2) = v1, v2
+    if a1 * b2 - a2 * b1 < 0:
+        (a1, b1), (a2, b2) = (a2, b2), (a1, b1)
+    assert a1 * b2 - a2 * b1 == r and (a1 + b1 * lam) % r == 0 and (a2 + b2 * lam) % r == 0
+    assert a1 > 0 and a2 > 0 and b1 < 0 and b2 > 0
+    g1, g2 = (b2 << 256) // r, (-b1 << 256) // r
+    rng = random.Random(7)
+    for i in range(20000):
+        k = rng.randrange(r) if i > 5 else [0, 1, r - 1, r - 2, lam, r // 2][i]
+        c1, c2_ = (k * g1 + (1 << 255)) >> 256, (k * g2 + (1 << 255)) >> 256
+        k1, k2 = k - c1 * a1 - c2_ * a2, c1 * (-b1) - c2_ * b2
+        assert (k1 + k2 * lam - k) % r == 0 and abs(k1) < 1 << 127 and abs(k2) < 1 << 127
+    eb = 0x52c9f28b828426a561f00d3a63511a882ea712770d9af4d6ee0f014d172510b4
+    ec = 0x6cc624cf865457c3a97c6efd6c17d1078456abcfff36f4e9515c806cdf650b3d
+    return dict(lam=lam, a1=a1, a2=a2, b1n=-b1, b2=b2, g1=g1, g2=g2, eb=eb, ec=ec)
+
+
+def te_affine_mul(q, a, d, pt, k):
+    """k * pt on a x^2 + y^2 = 1 + d x^2 y^2 (affine, unified addition) -- generator-side check of psi only"""
+    def add(p1, p2):
+        x1, y1 = p1; x2, y2 = p2
+        t = d * x1 * x2 * y1 * y2 % q
+        return ((x1 * y2 + y1 * x2) * pow(1 + t, -1, q) % q, (y1 * y2 - a * x1 * x2) * pow(1 - t, -1, q) % q)
+    acc = (0, 1)
+    for bit in bin(k)[2:]:
+        acc = add(acc, acc)
+        if bit == "1":
+            acc = add(acc, pt)
+    return acc
 
 
 def main():
@@ -161,6 +220,14 @@ def main():
         out.append(f"  static constexpr uint64_t X_ABS = 0x{(0xd201000000010000 if bls else 4965661367192848881):x}ULL;  static constexpr bool X_NEG = {'true' if bls else 'false'};")
         out.append("};")
     out.append("")
+    glv_b = glv_bandersnatch(q_b, r_b)
+    {   # psi(G) = [lambda] G: checks the two constants of the rational map against plain affine arithmetic
+        "check": (lambda G, d: (lambda x, y, L: (
+            (glv_b["ec"] * (1 - y * y) * pow(x * y, -1, q_b) % q_b, glv_b["eb"] * (y * y + glv_b["eb"]) * pow(y * y - glv_b["eb"], -1, q_b) % q_b) == L
+            or (_ for _ in ()).throw(AssertionError("psi(G) != [lambda] G"))))(G[0], G[1], te_affine_mul(q_b, q_b - 5, d, G, glv_b["lam"])))(
+                (18886178867200960497001835917649091219057080094937609519140440539760939937304,
+                 19188667384257783945677642223292697773471335439753913231509108946878080696678),
+                45022363124591815672509500913686876175488063829319466900776701791074614335719)}
     out.append(suite("SuiteBandersnatch", 0, "Bandersnatch-SHA512-ELL2-v1", "FqBandersnatch", "FrBandersnatch", q_b, r_b, 1,
                      45022363124591815672509500913686876175488063829319466900776701791074614335719,
                      {"G": (18886178867200960497001835917649091219057080094937609519140440539760939937304,
@@ -172,7 +239,8 @@ def main():
                       "PAD": (26913883415342152801331916189968962157924271221160514298872262294143390094043,
                               30874728313203001508631936119690348239461579770372782660098261717479009115354)}, 4,
                      ell2=(29978822694968839326280996386011761570173833766074948509196803838190355340952,
-                           25465760566081946422412445027709227188579564747101592991722834452325077642517)))
+                           25465760566081946422412445027709227188579564747101592991722834452325077642517),
+                     glv=glv_b))
     out.append(suite("SuiteBabyJubJub", 1, "BabyJubJub-SHA512-TAI-v1", "FqBabyJubJub", "FrBabyJubJub", q_j, r_j, 0,
                      9706598848417545097372247223557719406784115219466060233080913168975159366771,
                      {"G": (19698561148652590122159747500897617769866003486955115824547446575314762165298,
