@@ -80,9 +80,12 @@ void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, 
 void launch_g1_subgroup_check(int curve, const uint32_t *d_bases, size_t n, uint32_t *d_flag, hipStream_t stream, int32_t *d_rec_status = nullptr,
                               uint32_t ppr = 1);
 // per item (16-lane group): point 0 = sum_{t < split} s_t P_t, point 1 = sum_{split <= t < tpi} s_t P_t over the item's tpi <= 16
-// (base, scalar) pairs; out: n_items x 2 Montgomery affine points
+// (base, scalar) pairs; out: n_items x 2 Montgomery affine points.  glv_split_scalars (BLS12-381 only): every 32-byte scalar slot
+// holds k mod z^2 | (k div z^2) << 128 (g1_glv_split_bls) and the kernel takes the 128-doubling GLV chain.
 void launch_g1_lincomb(int curve, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n_items, uint32_t tpi, uint32_t split, uint32_t *d_out,
-                       hipStream_t stream);
+                       hipStream_t stream, bool glv_split_scalars = false);
+// k (256-bit little-endian limbs, < 2^255) -> k mod z^2 in limbs 0..1, k div z^2 in limbs 2..3, z = 0xd201000000010000 (host)
+void g1_glv_split_bls(uint64_t k[4]);
 
 // canonical affine bytes (x||y LE32) -> te_pre (device); flags[i] |= 1 if a coordinate >= q, |= 2 if off-curve (when check_curve)
 void launch_pre_from_affine(int suite, const uint8_t *d_xy, size_t n, te_pre_raw *d_pre, uint32_t *d_flag,

@@ -931,11 +931,15 @@ void launch_g1_subgroup_check(int curve, const uint32_t *d_bases, size_t n, uint
   hipLaunchKernelGGL(k_g1_subgroup_bls, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_bases, (uint32_t)n, d_flag, d_rec_status, ppr ? ppr : 1u);
 }
 
-// Small linear combinations, one 16-lane group per item: lane t < tpi computes scalar_t * P_t (255-bit double-and-add), lanes
-// [0, split) are summed into point 0, lanes [split, tpi) into point 1; both leave as Montgomery affine x | y ((0, 0) =
-// infinity) at out[(2 item + q) * 2N] -- the two G1 arguments of an independent KZG pairing check (RingVerifier::verify,
-// src/ring.rs:242), whose bases differ per item so that no bucket method applies.
-template <class C>
+// Small linear combinations, one 16-lane group per item: lane t < tpi computes scalar_t * P_t, lanes [0, split) are summed into
+// point 0, lanes [split, tpi) into point 1; both leave as Montgomery affine x | y ((0, 0) = infinity) at
+// out[(2 item + q) * 2N] -- the two G1 arguments of an independent KZG pairing check (RingVerifier::verify, src/ring.rs:242),
+// whose bases differ per item so that no bucket method applies.
+// GLV (BLS12-381): phi(x, y) = (beta x, y) multiplies by -z^2 on G1 (the relation k_g1_subgroup_bls tests), so with
+// k = k1 + k2 z^2 (k1 = k mod z^2, k2 = k div z^2, both < 2^128; the caller splits, scalars arrive as k1 | k2 << 128)
+// k P = k1 P + k2 (-phi(P)): one chain of 128 doublings over the joint 2-bit table {i P + j (beta x, -y)} instead of 255
+// doublings with a wave-divergent addition behind each.  Without GLV: 255-bit double-and-add.
+template <class C, bool GLV>
 __global__ void __launch_bounds__(64)
 k_g1_lincomb(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ scalars, uint32_t n_items, uint32_t tpi, uint32_t split,
              uint32_t *__restrict__ out) {
@@ -951,10 +955,32 @@ k_g1_lincomb(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ sc
     uint32_t sc[8];
     { const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + t * 8); uint4 a = sp[0], b = sp[1];
       sc[0] = a.x; sc[1] = a.y; sc[2] = a.z; sc[3] = a.w; sc[4] = b.x; sc[5] = b.y; sc[6] = b.z; sc[7] = b.w; }
+    if constexpr (GLV && N == 12) {
+      typename CV::base_t Q;                                           // -phi(P)
+      { fpn<N> beta;
+#pragma unroll
+        for (int i = 0; i < N; i++) beta.v[i] = BLS12_381_BETA_MONT[i];
+        Q.x = fn_mul<Fq>(beta, P.x); Q.y = fn_neg<Fq>(P.y);
+        if (fn_is_zero(P.x) && fn_is_zero(P.y)) Q = P; }               // infinity stays infinity
+      typename CV::acc_t tab[16];                                      // tab[4 j + i] = i P + j Q (per-lane scratch)
+      tab[0] = CV::identity(); tab[4] = CV::from_affine(Q);
+      tab[8] = CV::madd(tab[4], Q, false); tab[12] = CV::madd(tab[8], Q, false);
 #pragma unroll 1
-    for (int bit = 255; bit >= 0; bit--) {
-      acc = CV::dbl(acc);
-      if ((sc[bit >> 5] >> (bit & 31)) & 1) acc = CV::madd(acc, P, false);
+      for (int j = 0; j < 4; j++)
+#pragma unroll 1
+        for (int i = 1; i < 4; i++) tab[4 * j + i] = CV::madd(tab[4 * j + i - 1], P, false);
+#pragma unroll 1
+      for (int w = 63; w >= 0; w--) {
+        acc = CV::dbl(CV::dbl(acc));
+        const uint32_t d1 = (sc[w >> 4] >> (2 * (w & 15))) & 3u, d2 = (sc[4 + (w >> 4)] >> (2 * (w & 15))) & 3u;
+        if (d1 | d2) acc = CV::add(acc, tab[4 * d2 + d1]);
+      }
+    } else {
+#pragma unroll 1
+      for (int bit = 255; bit >= 0; bit--) {
+        acc = CV::dbl(acc);
+        if ((sc[bit >> 5] >> (bit & 31)) & 1) acc = CV::madd(acc, P, false);
+      }
     }
   }
   // lanes 0 and `split` gather their segment (the other lanes add along and are ignored)
@@ -982,11 +1008,26 @@ k_g1_lincomb(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ sc
   }
 }
 void launch_g1_lincomb(int curve, const uint32_t *d_bases, const uint32_t *d_scalars, size_t n_items, uint32_t tpi, uint32_t split, uint32_t *d_out,
-                       hipStream_t stream) {
+                       hipStream_t stream, bool glv_split_scalars) {
   if (!n_items) return;
   const dim3 grid((unsigned)((n_items * 16 + 63) / 64)), block(64);
-  if (curve == 0) hipLaunchKernelGGL(k_g1_lincomb<G1Bls12381>, grid, block, 0, stream, d_bases, d_scalars, (uint32_t)n_items, tpi, split, d_out);
-  else hipLaunchKernelGGL(k_g1_lincomb<G1Bn254>, grid, block, 0, stream, d_bases, d_scalars, (uint32_t)n_items, tpi, split, d_out);
+  if (curve == 0 && glv_split_scalars) hipLaunchKernelGGL((k_g1_lincomb<G1Bls12381, true>), grid, block, 0, stream, d_bases, d_scalars, (uint32_t)n_items, tpi, split, d_out);
+  else if (curve == 0) hipLaunchKernelGGL((k_g1_lincomb<G1Bls12381, false>), grid, block, 0, stream, d_bases, d_scalars, (uint32_t)n_items, tpi, split, d_out);
+  else hipLaunchKernelGGL((k_g1_lincomb<G1Bn254, false>), grid, block, 0, stream, d_bases, d_scalars, (uint32_t)n_items, tpi, split, d_out);
+}
+
+void g1_glv_split_bls(uint64_t k[4]) {
+  const uint64_t z = 0xd201000000010000ull;
+  uint64_t q1[4], q2[4];                                            // q1 = k div z, q2 = q1 div z; floor(floor(k / z) / z) = floor(k / z^2)
+  unsigned __int128 rem = 0;
+  for (int i = 3; i >= 0; i--) { unsigned __int128 cur = (rem << 64) | k[i]; q1[i] = (uint64_t)(cur / z); rem = cur % z; }
+  rem = 0;
+  for (int i = 3; i >= 0; i--) { unsigned __int128 cur = (rem << 64) | q1[i]; q2[i] = (uint64_t)(cur / z); rem = cur % z; }
+  // k1 = k - q2 z^2 (fits 128 bits): low 128 bits of the difference
+  const unsigned __int128 z2 = (unsigned __int128)z * z, q = ((unsigned __int128)q2[1] << 64) | q2[0];
+  const unsigned __int128 klo = ((unsigned __int128)k[1] << 64) | k[0];
+  const unsigned __int128 k1 = klo - q * z2;                         // mod 2^128; exact because k1 < z^2 < 2^128
+  k[0] = (uint64_t)k1; k[1] = (uint64_t)(k1 >> 64); k[2] = q2[0]; k[3] = q2[1];
 }
 
 void launch_g1_decompress(int curve, const uint8_t *d_comp, size_t n, uint8_t *d_out_xy, uint8_t *d_ok, hipStream_t stream) {

@@ -1438,11 +1438,12 @@ template <class S, class G> struct Ring {
       int32_t *d_ok = (int32_t *)(base + 2 * pb + sb + ob), *d_rec = (int32_t *)(base + 2 * pb + sb + ob + kb);
       uint32_t *d_flag = (uint32_t *)(base + 2 * pb + sb + ob + 2 * kb);
       HIP_CHECK(hipMemcpyAsync(d_xy, bb.data(), nb * e1, hipMemcpyHostToDevice, su->stream));
+      if (su->curve == 0) parallel_for(n, [&](size_t it) { for (size_t j = 0; j < TPI; j++) g1_glv_split_bls(ss[it * TPI + j].l); });   // k -> (k mod z^2, k div z^2)
       HIP_CHECK(hipMemcpyAsync(d_s, ss.data(), nb * 32, hipMemcpyHostToDevice, su->stream));
       HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream)); HIP_CHECK(hipMemsetAsync(d_rec, 0, n * 4, su->stream));
       launch_g1_bases(su->curve, d_xy, nb, d_b, d_flag, su->stream);
       if (!host_subgroup) launch_g1_subgroup_check(su->curve, d_b, nb, d_flag, su->stream, d_rec, (uint32_t)TPI);
-      launch_g1_lincomb(su->curve, d_b, d_s, n, (uint32_t)TPI, 11, d_pts, su->stream);
+      launch_g1_lincomb(su->curve, d_b, d_s, n, (uint32_t)TPI, 11, d_pts, su->stream, su->curve == 0);
       launch_pairing_check(su->ptab, d_pts, n, d_ok, su->stream);
       std::vector<int32_t> okv(n), rec(n);
       HIP_CHECK(hipMemcpyAsync(okv.data(), d_ok, n * 4, hipMemcpyDeviceToHost, su->stream));
