@@ -79,6 +79,46 @@ def test_multi_io(ctxs, suite):
     assert c.thin_verify(Batch.from_items(ios, ads, pks_xy=pkl, proofs=pl)) == [0, 0, 0, 1, 1, 0, 1, 1, 0]
 
 
+def test_points_without_endomorphism_image_take_the_plain_path(ctxs):
+    """Bandersnatch runs its variable-base multiplications through the endomorphism (glv.h); psi has no finite image in these
+    coordinates for points with x y = 0 -- the identity and the points of order 2 and 4 -- and the kernels must fall back to
+    the plain window form for exactly those lanes, inside a batch whose other lanes take the GLV path.
+    * k_smul computes k P literally: also for the order-2 point (0, -1) it must equal the oracle.
+    * The provers (one-pair form R = k G + (k z) I, scalars reduced mod r) are specified on the prime-order subgroup, like the
+      reference's own batch verifier (src/thin.rs:78-94: subgroup membership is the caller's contract); inside the subgroup the
+      only point without an image is the identity, which must give the oracle's proof bytes."""
+    from ark_vrf_amd._native import Batch
+    suite = 0
+    c = ctxs[suite]
+    q = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    p2 = (q - 1).to_bytes(32, "little")                                   # compressed (0, -1): order 2
+    ident = (1).to_bytes(32, "little")
+    st, p2_xy = orc.point_decompress(suite, p2)
+    assert st == 0 and p2_xy == bytes(32) + p2
+    sks, pks, ios_c, ads = [], [], [], []
+    for j in range(6):
+        sk, pk = orc.from_seed(suite, bytes([j + 90]) + bytes(31))
+        h = ident if j in (1, 4) else orc.hash_to_curve(suite, b"so-%d" % j)
+        sks.append(sk); pks.append(pk); ios_c.append([(h, orc.vrf_output(suite, sk, h))]); ads.append(b"so%d" % j)
+    pts = [p2, ident] + [io[0][0] for io in ios_c]
+    ks = [sks[0], sks[1]] + sks
+    assert c.scalar_mul(b"".join(ks), b"".join(xy(suite, p) for p in pts)) == b"".join(xy(suite, orc.smul(suite, k, p)) for k, p in zip(ks, pts))
+    ios = [[(xy(suite, i), xy(suite, o)) for i, o in io] for io in ios_c]
+    pkl = [xy(suite, p) for p in pks]
+    want = [orc.thin_prove(suite, sk, io, ad) for sk, io, ad in zip(sks, ios_c, ads)]
+    proofs = c.thin_prove(Batch.from_items(ios, ads, sks=sks, pks_xy=pkl))
+    pl = [proofs[96 * j: 96 * j + 96] for j in range(6)]
+    assert [proof_comp(suite, p, 0) for p in pl] == want
+    exp = [orc.thin_verify(suite, pk, io, ad, w) for pk, io, ad, w in zip(pks, ios_c, ads, want)]
+    assert exp == [0, 2, 0, 0, 2, 0]                                       # identity io: InvalidData before any arithmetic
+    assert c.thin_verify(Batch.from_items(ios, ads, pks_xy=pkl, proofs=pl)) == exp
+    pw = [orc.pedersen_prove(suite, sk, io, ad) for sk, io, ad in zip(sks, ios_c, ads)]
+    pr, bl = c.pedersen_prove(Batch.from_items(ios, ads, sks=sks, pks_xy=pkl))
+    pp = [pr[256 * j: 256 * j + 256] for j in range(6)]
+    assert [proof_comp(suite, p, 1) for p in pp] == [w[0] for w in pw]
+    assert c.pedersen_verify(Batch.from_items(ios, ads, proofs=pp)) == [orc.pedersen_verify(suite, io, ad, w[0]) for io, ad, w in zip(ios_c, ads, pw)]
+
+
 @pytest.mark.parametrize("suite,n", [(0, 600), (1, 200)])
 def test_synthetic(ctxs, suite, n):
     b = orc.gen_batch(suite, 0, n)
