@@ -17,6 +17,7 @@ BANDERSNATCH_SHA512_ELL2 = 0
 BABYJUBJUB_SHA512_TAI = 1
 JUBJUB_SHA512_TAI = 2
 ED25519_SHA512_TAI = 3          # Tiny / Thin / Pedersen only (no ring suite)
+BANDERSNATCH_SW_SHA512_TAI = 4  # Bandersnatch, short-Weierstrass presentation: 33-byte compressed points (Context.point_len)
 
 THIN_PROOF_LEN = 96       # R_xy || s
 PEDERSEN_PROOF_LEN = 256  # Yb_xy || R_xy || Ok_xy || s || sb
@@ -87,6 +88,8 @@ class Context:
         if st != OK:
             raise AvrfError(f"avrf_ctx_create failed with {st} (no MI355X visible? there is no CPU fallback)")
         self.suite = suite
+        lib().avrf_point_len.restype = C.c_size_t
+        self.point_len = lib().avrf_point_len(int(suite))      # serialize_compressed size of the suite's points: 32, or 33 (SW form)
 
     def set_validation(self, level):
         """0: caller guarantees on-curve subgroup points (reference's typed-point contract); 1: on-curve check; 2: + subgroup."""
@@ -243,7 +246,7 @@ class Context:
         return bytes(out)[: n * 64], list(st)[:n]
 
     def points_decompress(self, comp, validate=False):
-        n = len(comp) // 32
+        n = len(comp) // self.point_len
         out, st_out = (C.c_uint8 * max(1, 64 * n))(), (C.c_int32 * max(1, n))()
         st = lib().avrf_points_decompress(self._h, C.c_size_t(n), _u8(comp), out, int(validate), st_out)
         if st != OK:
@@ -252,8 +255,8 @@ class Context:
 
     def points_compress(self, xy):
         n = len(xy) // 64
-        out = (C.c_uint8 * max(1, 32 * n))()
+        out = (C.c_uint8 * max(1, self.point_len * n))()
         st = lib().avrf_points_compress(self._h, C.c_size_t(n), _u8(xy), out)
         if st != OK:
             raise AvrfError(f"avrf_points_compress -> {st}")
-        return bytes(out)[: 32 * n]
+        return bytes(out)[: self.point_len * n]

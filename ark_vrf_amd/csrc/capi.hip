@@ -607,14 +607,17 @@ int avrf_scalar_mul(avrf_ctx *c, size_t n, const uint8_t *scalars, const uint8_t
   return smul_common(c, n, scalars, points_xy, out_xy);
 }
 
+size_t avrf_point_len(int suite) { return (suite < 0 || suite >= AVRF_N_SUITES) ? 0 : (size_t)point_len_of(suite); }
+
 int avrf_points_decompress(avrf_ctx *c, size_t n, const uint8_t *in, uint8_t *out_xy, int validate, int32_t *status_out) {
   if (!c || (n && (!in || !out_xy || !status_out))) return AVRF_ERR_BAD_ARG;
   if (!n) return AVRF_OK;
   if (n > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
   c->staged_kind = 0;
-  HIP_TRY(c->d_misc.ensure(n * 32)); HIP_TRY(c->d_out.ensure(n * 64)); HIP_TRY(c->d_status.ensure(n * 4));
-  HIP_TRY(hipMemcpyAsync(c->d_misc.p, in, n * 32, hipMemcpyHostToDevice, c->stream));
+  const size_t pl = (size_t)point_len_of(c->suite);
+  HIP_TRY(c->d_misc.ensure(n * pl)); HIP_TRY(c->d_out.ensure(n * 64)); HIP_TRY(c->d_status.ensure(n * 4));
+  HIP_TRY(hipMemcpyAsync(c->d_misc.p, in, n * pl, hipMemcpyHostToDevice, c->stream));
   launch_decompress(c->suite, c->d_misc.as<uint8_t>(), (uint32_t)n, c->d_out.as<uint8_t>(), validate, c->d_status.as<int32_t>(), c->stream);
   HIP_TRY(hipMemcpyAsync(out_xy, c->d_out.p, n * 64, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -646,10 +649,11 @@ int avrf_points_compress(avrf_ctx *c, size_t n, const uint8_t *in_xy, uint8_t *o
   if (n > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
   c->staged_kind = 0;
-  HIP_TRY(c->d_misc.ensure(n * 64)); HIP_TRY(c->d_out.ensure(n * 32));
+  HIP_TRY(c->d_misc.ensure(n * 64)); const size_t pl = (size_t)point_len_of(c->suite);
+  HIP_TRY(c->d_out.ensure(n * pl));
   HIP_TRY(hipMemcpyAsync(c->d_misc.p, in_xy, n * 64, hipMemcpyHostToDevice, c->stream));
   launch_compress(c->suite, c->d_misc.as<uint8_t>(), (uint32_t)n, c->d_out.as<uint8_t>(), c->stream);
-  HIP_TRY(hipMemcpyAsync(out, c->d_out.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(out, c->d_out.p, n * pl, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
   return AVRF_OK;
 }

@@ -12,15 +12,19 @@
 #include <string.h>
 #include <vector>
 
+extern "C" int avrf_ctx_suite_(avrf_ctx *c);
+
 namespace {
 
 // decompress `count` points given as (pointer, stride) records into contiguous xy; returns AVRF_OK or the failing status
 struct Gather {
+  size_t L;                                  // avrf_point_len of the context's suite
   std::vector<uint8_t> comp;
-  void add(const uint8_t *p, size_t n, size_t stride) { for (size_t i = 0; i < n; i++) comp.insert(comp.end(), p + i * stride, p + i * stride + 32); }
+  explicit Gather(size_t l) : L(l) {}
+  void add(const uint8_t *p, size_t n, size_t stride) { for (size_t i = 0; i < n; i++) comp.insert(comp.end(), p + i * stride, p + i * stride + L); }
 };
 int decompress_all(avrf_ctx *ctx, const Gather &g, int validate, std::vector<uint8_t> &xy, std::vector<int32_t> *per_point = nullptr) {
-  const size_t n = g.comp.size() / 32;
+  const size_t n = g.comp.size() / g.L;
   xy.assign(n * 64, 0);
   std::vector<int32_t> st(n ? n : 1, 0);
   int rc = avrf_points_decompress(ctx, n, g.comp.data(), xy.data(), validate, st.data());
@@ -38,11 +42,12 @@ int verify_wire(avrf_ctx *ctx, int kind, bool batch, size_t n, const uint8_t *pk
   if (!n) return AVRF_OK;
   const size_t tot = sum_counts(io_counts, n);
   if (tot && !ios) return AVRF_ERR_BAD_ARG;
-  const size_t plen = kind == 1 ? 64 : kind == 3 ? 48 : 160, ppts = kind == 1 ? 1 : kind == 3 ? 0 : 3, xlen = kind == 1 ? 96 : kind == 3 ? 48 : 256;
-  Gather g;
-  if (kind != 2) g.add(pks, n, 32);
-  g.add(ios, 2 * tot, 32);
-  for (size_t p = 0; p < ppts; p++) g.add(proofs + 32 * p, n, plen);
+  const size_t L = avrf_point_len(avrf_ctx_suite_(ctx));
+  const size_t ppts = kind == 1 ? 1 : kind == 3 ? 0 : 3, plen = ppts * L + (kind == 1 ? 32 : kind == 3 ? 48 : 64), xlen = kind == 1 ? 96 : kind == 3 ? 48 : 256;
+  Gather g(L);
+  if (kind != 2) g.add(pks, n, L);
+  g.add(ios, 2 * tot, L);
+  for (size_t p = 0; p < ppts; p++) g.add(proofs + L * p, n, plen);
   std::vector<uint8_t> xy; std::vector<int32_t> pst;
   int rc = decompress_all(ctx, g, validate, xy, batch ? nullptr : &pst);
   if (rc != AVRF_OK) return rc;
@@ -50,7 +55,7 @@ int verify_wire(avrf_ctx *ctx, int kind, bool batch, size_t n, const uint8_t *pk
   std::vector<uint8_t> px(n * xlen);
   for (size_t j = 0; j < n; j++) {
     for (size_t p = 0; p < ppts; p++) memcpy(&px[j * xlen + 64 * p], x_pp + (p * n + j) * 64, 64);
-    memcpy(&px[j * xlen + 64 * ppts], proofs + j * plen + 32 * ppts, plen - 32 * ppts);
+    memcpy(&px[j * xlen + 64 * ppts], proofs + j * plen + L * ppts, plen - L * ppts);
   }
   if (batch) {
     if (kind == 1) return avrf_thin_batch_verify(ctx, n, x_pks, x_ios, io_counts, ads, ad_lens, px.data());
@@ -101,7 +106,8 @@ int avrf_ring_vrf_prove(avrf_ctx *ctx, avrf_ring_key *key, size_t ring_proof_len
                         uint8_t *proofs_out) {
   if (!ctx || !key || (n && (!sks || !key_index || !io_counts || !ad_lens || !proofs_out))) return AVRF_ERR_BAD_ARG;
   if (!n) return AVRF_OK;
-  std::vector<uint8_t> ped(n * 256), blind(n * 32), rp(n * ring_proof_len), comp(n * 3 * 32), pts(n * 3 * 64);
+  const size_t L = avrf_point_len(avrf_ctx_suite_(ctx)), pedlen = 3 * L + 64;
+  std::vector<uint8_t> ped(n * 256), blind(n * 32), rp(n * ring_proof_len), comp(n * 3 * L), pts(n * 3 * 64);
   int rc = avrf_pedersen_prove(ctx, n, sks, nullptr, ios_xy, io_counts, ads, ad_lens, ped.data(), blind.data());
   if (rc != AVRF_OK) return rc;
   rc = avrf_ring_prove(key, n, key_index, blind.data(), blinding_mode, rp.data());
@@ -109,10 +115,10 @@ int avrf_ring_vrf_prove(avrf_ctx *ctx, avrf_ring_key *key, size_t ring_proof_len
   for (size_t j = 0; j < n; j++) memcpy(&pts[j * 192], &ped[j * 256], 192);
   rc = avrf_points_compress(ctx, 3 * n, pts.data(), comp.data());
   if (rc != AVRF_OK) return rc;
-  const size_t plen = 160 + ring_proof_len;
+  const size_t plen = pedlen + ring_proof_len;
   for (size_t j = 0; j < n; j++) {
     uint8_t *o = proofs_out + j * plen;
-    memcpy(o, &comp[j * 96], 96); memcpy(o + 96, &ped[j * 256 + 192], 64); memcpy(o + 160, &rp[j * ring_proof_len], ring_proof_len);
+    memcpy(o, &comp[j * 3 * L], 3 * L); memcpy(o + 3 * L, &ped[j * 256 + 192], 64); memcpy(o + pedlen, &rp[j * ring_proof_len], ring_proof_len);
   }
   return AVRF_OK;
 }
@@ -124,12 +130,13 @@ int avrf_ring_vrf_verify(avrf_ctx *ctx, avrf_ring_setup *setup, size_t n, const 
                          int validate, int each, int32_t *status_out) {
   if (!ctx || !setup || (n && (!ring_commitments || !n_rings || !io_counts || !ad_lens || !proofs)) || (each && n && !status_out)) return AVRF_ERR_BAD_ARG;
   if (!n) return AVRF_OK;
-  const size_t rlen = avrf_ring_proof_len(setup), plen = 160 + rlen, tot = sum_counts(io_counts, n);
+  const size_t L = avrf_point_len(avrf_ctx_suite_(ctx)), pedlen = 3 * L + 64;
+  const size_t rlen = avrf_ring_proof_len(setup), plen = pedlen + rlen, tot = sum_counts(io_counts, n);
   if (tot && !ios) return AVRF_ERR_BAD_ARG;
-  std::vector<uint8_t> ped(n * 160), rp(n * rlen);
-  for (size_t j = 0; j < n; j++) { memcpy(&ped[j * 160], proofs + j * plen, 160); memcpy(&rp[j * rlen], proofs + j * plen + 160, rlen); }
+  std::vector<uint8_t> ped(n * pedlen), rp(n * rlen);
+  for (size_t j = 0; j < n; j++) { memcpy(&ped[j * pedlen], proofs + j * plen, pedlen); memcpy(&rp[j * rlen], proofs + j * plen + pedlen, rlen); }
   // Yb of every Pedersen proof as xy (the ring verifier's instance)
-  Gather g; g.add(ped.data(), n, 160);
+  Gather g(L); g.add(ped.data(), n, pedlen);
   std::vector<uint8_t> yb; std::vector<int32_t> yst;
   int rc = decompress_all(ctx, g, validate, yb, &yst);
   if (rc != AVRF_OK) return rc;

@@ -24,6 +24,7 @@
 #define fp_from_wide_mont fp_from_wide_mont_nf
 #define te_to_aff te_to_aff_nf
 #define te_make_pre te_make_pre_nf
+#include "sw_map.h"      // (after the routing above: its maps use the out-of-line field operations too)
 
 namespace avrf {
 
@@ -51,9 +52,20 @@ struct Seed64 { uint64_t w[8]; };  // a SHA-512 digest as big-endian words
 // (LE32 each): LE32(y) with bit 255 set iff x > (q-1)/2   
 template <class S> AVRF_DI void absorb_point_xy(Sha512 &h, const fp &x, const fp &y) {
   using Fq = typename S::Fq;
+  if constexpr (S::SW_CODEC) {           // the suite's Affine is SWAffine: 33-byte form, LE32(x_sw) || flags (sw_map.h)
+    const sw_enc e = sw_encode_te<S>(fp_to_mont<Fq>(x), fp_to_mont<Fq>(y));
+#pragma unroll
+    for (int i = 0; i < 8; i++) sha512_u32le(h, e.x.v[i]);
+    sha512_byte(h, e.flag);
+    return;
+  }
   uint32_t sign = fp_is_negative_plain<Fq>(x) ? 0x80000000u : 0u;
 #pragma unroll
   for (int i = 0; i < 8; i++) sha512_u32le(h, y.v[i] | (i == 7 ? sign : 0u));
+}
+// the serialised generator (chain_ios, src/utils/common.rs:231-240), a per-suite constant
+template <class S> AVRF_DI void absorb_generator(Sha512 &h) {
+  for (int i = 0; i < S::POINT_LEN; i++) sha512_byte(h, S::G_ENC[i]);
 }
 AVRF_DI void absorb_fp_le(Sha512 &h, const fp &a) {
 #pragma unroll
@@ -78,8 +90,7 @@ template <class S> AVRF_DI void tr_base(Sha512 &h, uint8_t scheme, bool schnorr,
   sha512_u64le(h, (uint64_t)m + (schnorr ? 1 : 0));
   uint32_t f = 0;
   if (schnorr) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) sha512_u32le(h, S::G_C[i]);
+    absorb_generator<S>(h);
     fp x = fp_load_le(pk_xy), y = fp_load_le(pk_xy + 32);
     f |= point_flags<S>(x, y);
     absorb_point_xy<S>(h, x, y);

@@ -1480,9 +1480,10 @@ template <class S, class G> struct Ring {
 using RingB = Ring<SuiteBandersnatch, G1Bls12381>;
 using RingJ = Ring<SuiteBabyJubJub, G1Bn254>;
 using RingK = Ring<SuiteJubJub, G1Bls12381>;        // JubJub-SHA512-TAI over BLS12-381 (src/suites/jubjub.rs:76-95)
+using RingW = Ring<SuiteBandersnatchSW, G1Bls12381>;   // Bandersnatch-SW: the ring proof runs on the TEMapping of the keys (src/ring.rs:75-81)
 template <class R> struct RingTag { using type = R; };
 template <class F> static auto with_ring(int suite, F &&f) {
-  switch (suite) { case 1: return f(RingTag<RingJ>{}); case 2: return f(RingTag<RingK>{}); default: return f(RingTag<RingB>{}); }
+  switch (suite) { case 1: return f(RingTag<RingJ>{}); case 2: return f(RingTag<RingK>{}); case 4: return f(RingTag<RingW>{}); default: return f(RingTag<RingB>{}); }
 }
 
 }  // namespace

@@ -26,8 +26,7 @@ k_thin_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint32_t *__restrict__ 
   for (int i = 0; i < S::SUITE_ID_LEN; i++) sha512_byte(h, S::SUITE_ID[i]);   // Transcript::new(SUITE_ID)
   sha512_byte(h, DS_THIN);                                                     // common.rs:166
   sha512_u64le(h, (uint64_t)m + 1);                                            // absorb_ios :377-383, Schnorr pair first
-#pragma unroll
-  for (int i = 0; i < 8; i++) sha512_u32le(h, S::G_C[i]);                      // chain_ios :231-240: (G, pk)
+  absorb_generator<S>(h);                                                    // chain_ios :231-240: (G, pk)
   {
     fp x = fp_load_le(b.pks_xy + 64 * (size_t)j), y = fp_load_le(b.pks_xy + 64 * (size_t)j + 32);
     f |= point_flags<S>(x, y);                                                 // thin.rs:266-271

@@ -390,6 +390,18 @@ k_hash_to_curve(const uint8_t *__restrict__ data, const uint32_t *__restrict__ o
       const bool neg = (y.v[7] >> 31) != 0;
       y.v[7] &= 0xffffffffu >> (256 - Fq::BITS);
       if (ge_p<Fq>(y)) continue;
+      if constexpr (S::SW_CODEC) {
+        // SWAffine::from_random_bytes on the 32 squeezed bytes: they are the x-coordinate; the flag byte of the 33-byte buffer
+        // is absent, i.e. zero, and the root taken is the LARGER one (pinned by the alpha -> h entries of the reference's
+        // bandersnatch_sw vectors); then the map to the twisted-Edwards model, cofactor clearing there
+        fp xm, ym;
+        if (!sw_decode_te<S>(y, true, xm, ym)) continue;
+        acc = te_from_pre<S>(te_make_pre<S>(xm, ym));
+        for (int c = S::COFACTOR; c > 1; c >>= 1) acc = te_dbl<S>(acc);
+        if (te_is_identity<S>(acc)) continue;
+        ok = true;
+        continue;
+      }
       fp ym = fp_to_mont<Fq>(y), y2 = fp_sqr<Fq>(ym), one = fp_one<Fq>();
       fp a_const = mul_a<S>(one);   // the curve coefficient a (1, -5 or -1)
       fp den = fp_sub<Fq>(a_const, fp_mul<Fq>(fp_const<Fq>(S::D), y2)), xm;
@@ -412,6 +424,23 @@ k_decompress(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ o
   using Fq = typename S::Fq; using Fr = typename S::Fr;
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
+  if constexpr (S::SW_CODEC) {
+    // SWAffine::deserialize_compressed (33 bytes; unused flag bits and the infinity flag are rejected: the point at infinity has
+    // no twisted-Edwards image, sw_to_te -> None, and the reference's verifiers refuse the identity anyway)
+    const uint8_t *src = in + 33 * (size_t)j;
+    fp xs;
+    for (int i = 0; i < 8; i++) xs.v[i] = (uint32_t)src[4 * i] | ((uint32_t)src[4 * i + 1] << 8) | ((uint32_t)src[4 * i + 2] << 16) | ((uint32_t)src[4 * i + 3] << 24);
+    const uint8_t flag = src[32];
+    int32_t st = 0; fp xm = fp_zero(), ym = fp_one<Fq>();
+    if ((flag & 0x7f) || ge_p<Fq>(xs) || !sw_decode_te<S>(xs, (flag & 0x80) != 0, xm, ym)) { st = 2; xm = fp_zero(); ym = fp_one<Fq>(); }
+    else if (validate) {
+      te_ext rp = te_smul<S>(te_make_pre<S>(xm, ym), fp_const<Fr>(Fr::P), Fr::BITS);   // r * P == 0
+      if (!te_is_identity<S>(rp)) st = 2;
+    }
+    fp_store_le(out_xy + 64 * (size_t)j, fp_from_mont<Fq>(xm)); fp_store_le(out_xy + 64 * (size_t)j + 32, fp_from_mont<Fq>(ym));
+    status[j] = st;
+    return;
+  }
   fp y = fp_load_le(in + 32 * (size_t)j);
   bool neg = (y.v[7] >> 31) != 0; y.v[7] &= 0x7fffffffu;
   int32_t st = 0;
@@ -474,6 +503,13 @@ k_compress(const uint8_t *__restrict__ in_xy, uint32_t n, uint8_t *__restrict__ 
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   fp x = fp_load_le(in_xy + 64 * (size_t)j), y = fp_load_le(in_xy + 64 * (size_t)j + 32);
+  if constexpr (S::SW_CODEC) {                                        // 33-byte SW form of the suite's Affine (sw_map.h)
+    const sw_enc e = sw_encode_te<S>(fp_to_mont<Fq>(x), fp_to_mont<Fq>(y));
+    uint8_t *o = out + 33 * (size_t)j;
+    for (int i = 0; i < 8; i++) for (int b = 0; b < 4; b++) o[4 * i + b] = (uint8_t)(e.x.v[i] >> (8 * b));
+    o[32] = e.flag;
+    return;
+  }
   if (fp_is_negative_plain<Fq>(x)) y.v[7] |= 0x80000000u;
   fp_store_le(out + 32 * (size_t)j, y);
 }

@@ -42,7 +42,10 @@ enum {
   AVRF_SUITE_BANDERSNATCH_SHA512_ELL2 = 0, /* src/suites/bandersnatch.rs:62-105 */
   AVRF_SUITE_BABYJUBJUB_SHA512_TAI = 1,    /* src/suites/baby_jubjub.rs:56-95   */
   AVRF_SUITE_JUBJUB_SHA512_TAI = 2,        /* src/suites/jubjub.rs:56-95 (ring proofs over BLS12-381) */
-  AVRF_SUITE_ED25519_SHA512_TAI = 3        /* src/suites/ed25519.rs:44-66 (Tiny / Thin / Pedersen; no RingSuite: avrf_ring_* -> BAD_ARG) */
+  AVRF_SUITE_ED25519_SHA512_TAI = 3,       /* src/suites/ed25519.rs:44-66 (Tiny / Thin / Pedersen; no RingSuite: avrf_ring_* -> BAD_ARG) */
+  AVRF_SUITE_BANDERSNATCH_SW_SHA512_TAI = 4 /* src/suites/bandersnatch_sw.rs:60-112: Bandersnatch in its short-Weierstrass presentation.
+                                             * xy points are the TEMapping (src/utils/te_sw_map.rs) of the suite's SWAffine; the compressed
+                                             * form (avrf_points_*, *_wire) is its 33-byte serialize_compressed: see avrf_point_len */
 };
 
 typedef struct avrf_ctx avrf_ctx;
@@ -274,8 +277,11 @@ int avrf_hash_to_curve(avrf_ctx *ctx, size_t n, const uint8_t *data, const uint3
 
 /* CanonicalSerialize / CanonicalDeserialize of curve points, batched on the device
  * (ark-serialize compressed form; checked constructors src/lib.rs:410-494).
- * decompress: in n x 32 -> out n x 64; status_out[j] = AVRF_OK / AVRF_INVALID_DATA.
+ * decompress: in n x L -> out n x 64; status_out[j] = AVRF_OK / AVRF_INVALID_DATA; L = avrf_point_len(suite) = 32 for the
+ * twisted-Edwards suites (LE32(y), sign of x in bit 255), 33 for the short-Weierstrass presentation (LE32(x) || flags; the
+ * xy side is then the TEMapping of the point, src/utils/te_sw_map.rs:32-47).
  * validate != 0 additionally requires prime-order-subgroup membership and non-identity. */
+size_t avrf_point_len(int suite);
 int avrf_points_decompress(avrf_ctx *ctx, size_t n, const uint8_t *in, uint8_t *out_xy, int validate, int32_t *status_out);
 int avrf_points_compress(avrf_ctx *ctx, size_t n, const uint8_t *in_xy, uint8_t *out);
 
@@ -284,9 +290,10 @@ int avrf_scalar_mul_base(avrf_ctx *ctx, size_t n, const uint8_t *sks, uint8_t *o
 int avrf_scalar_mul(avrf_ctx *ctx, size_t n, const uint8_t *scalars, const uint8_t *points_xy, uint8_t *out_xy);
 
 /* ---- Wire-format flavour: the reference's `serialize_compressed` encodings and a `validate` flag. ----
- * Points are 32-byte compressed (pks: n x 32; ios: per pair input(32) || output(32)); proofs are the reference's byte strings:
- * thin R(32) || s(32) (src/thin.rs:43-48), tiny c(16) || s(32) (src/tiny.rs:60-78), pedersen Yb || R || Ok || s || sb = 160
- * (src/pedersen.rs:69-75), ring-VRF = pedersen proof || ring proof = 752 / 640 (src/ring.rs:160-166).
+ * Points are L-byte compressed, L = avrf_point_len(suite) (pks: n x L; ios: per pair input(L) || output(L)); proofs are the
+ * reference's byte strings: thin R(L) || s(32) (src/thin.rs:43-48), tiny c(16) || s(32) (src/tiny.rs:60-78), pedersen
+ * Yb || R || Ok || s || sb = 3 L + 64 (src/pedersen.rs:69-75), ring-VRF = pedersen proof || ring proof = 752 / 640 at L = 32,
+ * 755 for Bandersnatch-SW (src/ring.rs:160-166).
  * validate = 0: CanonicalDeserialize with Validate::No (the point must decode, i.e. lie on the curve);
  * validate = 1: Validate::Yes as in the checked constructors (src/lib.rs:410-433): also prime-order subgroup and not the identity.
  * A point that fails gives AVRF_INVALID_DATA (for its item in the per-item calls) before any equation is evaluated.

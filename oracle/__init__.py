@@ -16,6 +16,7 @@ BANDERSNATCH = 0
 BABYJUBJUB = 1
 JUBJUB = 2
 ED25519 = 3
+BANDERSNATCH_SW = 4    # Bandersnatch in its short-Weierstrass presentation: 33-byte serialised points (sw_encode / sw_decode)
 
 OK, VERIFICATION_FAILURE, INVALID_DATA = 0, 1, 2
 
@@ -280,3 +281,17 @@ def pedersen_batch_terms_xy(suite, b):
     st = lib().orc_pedersen_batch_terms_xy(suite, C.c_size_t(n), _u8(b["ios_xy"]), _u32(b["io_counts"]), _u8(b["ads"]),
                                            _u32(b["ad_lens"]), _u8(b["proofs"]), bases, sc, C.byref(k))
     return st, _b(bases)[: 64 * k.value], _b(sc)[: 32 * k.value]
+
+
+def sw_encode(suite, te32):
+    """twisted-Edwards 32-byte form (what every oracle entry point takes) -> the suite's 33-byte SW wire form"""
+    out = _buf(33)
+    st = lib().orc_sw_encode(suite, _u8(te32), out)
+    assert st == 0, st
+    return _b(out)
+
+
+def sw_decode(suite, sw33):
+    out = _buf(32)
+    st = lib().orc_sw_decode(suite, _u8(sw33), out)
+    return st, _b(out)

@@ -47,8 +47,8 @@ typedef struct {
 typedef struct { u256 x, y; } te_aff;        /* Montgomery-form coordinates */
 typedef struct { u256 x, y, t, z; } te_ext;  /* extended twisted Edwards */
 
-enum { ORC_SUITE_BANDERSNATCH = 0, ORC_SUITE_BABYJUBJUB = 1, ORC_SUITE_JUBJUB = 2, ORC_SUITE_ED25519 = 3 };
-enum { ORC_H2C_ELL2 = 0, ORC_H2C_TAI = 1 };
+enum { ORC_SUITE_BANDERSNATCH = 0, ORC_SUITE_BABYJUBJUB = 1, ORC_SUITE_JUBJUB = 2, ORC_SUITE_ED25519 = 3, ORC_SUITE_BANDERSNATCH_SW = 4 };
+enum { ORC_H2C_ELL2 = 0, ORC_H2C_TAI = 1, ORC_H2C_TAI_SW = 2 };
 
 typedef struct {
     int id;
@@ -66,6 +66,11 @@ typedef struct {
     te_aff PAD;             /* RingSuite::PADDING */
     /* Elligator2 (Montgomery model) constants, Montgomery form */
     u256 ell2_j, ell2_k, ell2_z;
+    /* short-Weierstrass presentation of the same curve (src/suites/bandersnatch_sw.rs, src/utils/te_sw_map.rs): the suite's
+     * Affine type is SWAffine, so every point that is serialised -- into a transcript, a proof, a hash -- takes the 33-byte
+     * ark-serialize SW form; the group arithmetic stays in the twisted-Edwards model through the maps. */
+    int sw_codec;
+    u256 mont_b, mont_a3, mont_binv, sw_a, sw_b;   /* Montgomery-model B, A/3, 1/B; SW coefficients; all in Montgomery form */
 } suite_t;
 
 /* status codes mirror ark_vrf::Error (src/lib.rs:135-147) */
@@ -133,6 +138,10 @@ int  te_decode(te_aff *o, const uint8_t in[32], const suite_t *s);  /* 0 ok, els
 /* canonical uncompressed x||y (LE32 each), non-Montgomery */
 void te_encode_xy(uint8_t out[64], const te_aff *p, const suite_t *s);
 int  te_decode_xy(te_aff *o, const uint8_t in[64], const suite_t *s);
+/* SW presentation (suites with sw_codec): 33-byte ark-serialize compressed form <-> twisted-Edwards point */
+void sw_encode(uint8_t out[33], const te_aff *p, const suite_t *s);
+int  sw_decode(te_aff *o, const uint8_t in[33], const suite_t *s);   /* 0 ok; identity and undecodable -> ORC_INVALID_DATA */
+int  sw_from_x(te_aff *o, const u256 *x_plain, int greatest, const suite_t *s);   /* SWAffine::get_point_from_x_unchecked + sw_to_te; 0 ok */
 
 /* ---- MSM (orc_msm.c) ---- */
 void orc_msm_naive(te_ext *o, const te_aff *bases, const u256 *scalars_plain, size_t n, const suite_t *s);

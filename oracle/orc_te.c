@@ -15,7 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-static suite_t g_suites[4];
+static suite_t g_suites[5];
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;      /* gen_batch() calls in from several threads at once */
 
 static void fq_dec(u256 *o, const char *dec, const mont_t *m) {
@@ -113,11 +113,50 @@ static void init_suites(void) {
     fq_dec(&s->B.x, "45003173884697328536089278691112838614164406922820087464913813433380838325453", &s->fq);
     fq_dec(&s->B.y, "31256014272390301975555524011230972931324093235775711248505761870355310252869", &s->fq);
     s->ACC = s->G; s->PAD = s->G;
+
+    /* ---- Bandersnatch-SW-SHA512-TAI-v1 (src/suites/bandersnatch_sw.rs:60-112): the SAME curve as suite 0 in its
+     * short-Weierstrass presentation (Affine = SWAffine).  The maps of src/utils/te_sw_map.rs are group isomorphisms and take
+     * the SW generator to the TE generator, so the arithmetic is suite 0's; what differs is every serialised point (33-byte SW
+     * form), try-and-increment on SW x-coordinates, and the suite points, given in the reference as SW coordinates. ---- */
+    s = &g_suites[4];
+    *s = g_suites[0];
+    s->id = ORC_SUITE_BANDERSNATCH_SW;
+    s->suite_id = "Bandersnatch-SW-SHA512-TAI-v1"; s->suite_id_len = 29;
+    s->h2c = ORC_H2C_TAI_SW; s->sw_codec = 1;
+    s->mont_b = s->ell2_k;                                                 /* MontCurveConfig::COEFF_B */
+    fq_dec(&s->mont_a3, "9992940898322946442093665462003920523391277922024982836398934612730118446984", &s->fq);   /* :104-111 */
+    fq_dec(&s->mont_binv, "41180284393978236561320365279764246793818536543197771097409483252169927600582", &s->fq);
+    {   /* y^2 = x^3 + a x + b with a = (3 - A^2) / (3 B^2), b = (2 A^3 - 9 A) / (27 B^3) */
+        u256 A, A2, A3c, B2, B3, t, u, three, nine, c27, two;
+        A = s->ell2_j; fq_small(&three, 3, &s->fq); fq_small(&nine, 9, &s->fq); fq_small(&c27, 27, &s->fq); fq_small(&two, 2, &s->fq);
+        mont_sqr(&A2, &A, &s->fq); mont_mul(&A3c, &A2, &A, &s->fq);
+        mont_sqr(&B2, &s->mont_b, &s->fq); mont_mul(&B3, &B2, &s->mont_b, &s->fq);
+        mont_sub(&t, &three, &A2, &s->fq); mont_mul(&u, &three, &B2, &s->fq); mont_inv(&u, &u, &s->fq); mont_mul(&s->sw_a, &t, &u, &s->fq);
+        mont_mul(&t, &two, &A3c, &s->fq); mont_mul(&u, &nine, &A, &s->fq); mont_sub(&t, &t, &u, &s->fq);
+        mont_mul(&u, &c27, &B3, &s->fq); mont_inv(&u, &u, &s->fq); mont_mul(&s->sw_b, &t, &u, &s->fq);
+    }
+    {   /* suite points: SW coordinates of the reference -> TE */
+        static const char *sw_pts[3][2] = {
+            {"28115362618644671219696075022370511395136332234538034358311199318506963235315",      /* BLINDING_BASE :71-79 */
+             "3900851469868158154936962463930962496000252801946757953905982128670530185313"},
+            {"13189182432637108534251278524663360416811744717379968387043749958796254980045",      /* ACCUMULATOR_BASE :87-95 */
+             "14483286006782706188671626508232161325054303360192563232232823772738911894793"},
+            {"20496180070424734470560955314776462366297546779079302509428101119888111900885",      /* PADDING :97-104 */
+             "8839106592405352067483360946162273985142890146060814748321063063028225641813"}};
+        te_aff *dst[3] = {&s->B, &s->ACC, &s->PAD};
+        for (int i = 0; i < 3; i++) {
+            u256 x, y, mx, my, one = s->fq.r1, t, w;
+            fq_dec(&x, sw_pts[i][0], &s->fq); fq_dec(&y, sw_pts[i][1], &s->fq);
+            mont_mul(&mx, &s->mont_b, &x, &s->fq); mont_sub(&mx, &mx, &s->mont_a3, &s->fq); mont_mul(&my, &s->mont_b, &y, &s->fq);
+            mont_inv(&t, &my, &s->fq); mont_mul(&dst[i]->x, &mx, &t, &s->fq);
+            mont_add(&t, &mx, &one, &s->fq); mont_inv(&t, &t, &s->fq); mont_sub(&w, &mx, &one, &s->fq); mont_mul(&dst[i]->y, &w, &t, &s->fq);
+        }
+    }
 }
 
 const suite_t *orc_suite(int id) {
     pthread_once(&g_once, init_suites);
-    if (id < 0 || id > 3) return NULL;
+    if (id < 0 || id > 4) return NULL;
     return &g_suites[id];
 }
 
@@ -244,6 +283,49 @@ int te_decode(te_aff *o, const uint8_t in[32], const suite_t *s) {
 void te_encode_xy(uint8_t out[64], const te_aff *p, const suite_t *s) {
     u256 t; mont_from(&t, &p->x, FQ); u256_to_le(out, &t);
     mont_from(&t, &p->y, FQ); u256_to_le(out + 32, &t);
+}
+/* ---- SW presentation (src/utils/te_sw_map.rs:32-68; ark-serialize SWFlags: the flag byte follows the 32-byte x because
+ * a 255-bit modulus leaves one spare bit and the two flags need two: bit 7 = y is the larger root, bit 6 = infinity) ---- */
+static void sw_xy_from_te(u256 *x, u256 *y, const te_aff *p, const suite_t *s) {   /* te_to_sw; p not the identity, x != 0 */
+    u256 one = s->fq.r1, vd, wd, num, v, w;
+    mont_sub(&vd, &one, &p->y, FQ);                       /* 1 - y */
+    mont_mul(&wd, &p->x, &vd, FQ);                        /* x (1 - y) */
+    mont_inv(&vd, &vd, FQ); mont_inv(&wd, &wd, FQ);
+    mont_add(&num, &one, &p->y, FQ);
+    mont_mul(&v, &num, &vd, FQ); mont_mul(&w, &num, &wd, FQ);
+    mont_add(&v, &v, &s->mont_a3, FQ); mont_mul(x, &s->mont_binv, &v, FQ);
+    mont_mul(y, &s->mont_binv, &w, FQ);
+}
+static int te_from_sw_xy(te_aff *o, const u256 *x, const u256 *y, const suite_t *s) {   /* sw_to_te; 0 ok */
+    u256 one = s->fq.r1, mx, my, t, w;
+    mont_mul(&mx, &s->mont_b, x, FQ); mont_sub(&mx, &mx, &s->mont_a3, FQ); mont_mul(&my, &s->mont_b, y, FQ);
+    mont_add(&t, &mx, &one, FQ);
+    if (u256_is_zero(&my) || u256_is_zero(&t)) return ORC_INVALID_DATA;
+    mont_inv(&my, &my, FQ); mont_mul(&o->x, &mx, &my, FQ);
+    mont_inv(&t, &t, FQ); mont_sub(&w, &mx, &one, FQ); mont_mul(&o->y, &w, &t, FQ);
+    return ORC_OK;
+}
+void sw_encode(uint8_t out[33], const te_aff *p, const suite_t *s) {
+    memset(out, 0, 33);
+    if (te_is_identity_aff(p, s) || u256_is_zero(&p->x)) { out[32] = 0x40; return; }     /* infinity (the maps are undefined there) */
+    u256 x, y, t; sw_xy_from_te(&x, &y, p, s);
+    mont_from(&t, &x, FQ); u256_to_le(out, &t);
+    if (fq_is_negative(&y, s)) out[32] = 0x80;
+}
+int sw_from_x(te_aff *o, const u256 *x_plain, int greatest, const suite_t *s) {
+    u256 x, rhs, t, y;
+    if (u256_cmp(x_plain, &s->fq.p) >= 0) return ORC_INVALID_DATA;
+    mont_to(&x, x_plain, FQ);
+    mont_sqr(&t, &x, FQ); mont_add(&t, &t, &s->sw_a, FQ); mont_mul(&rhs, &t, &x, FQ); mont_add(&rhs, &rhs, &s->sw_b, FQ);
+    if (!mont_sqrt(&y, &rhs, FQ)) return ORC_INVALID_DATA;
+    if (fq_is_negative(&y, s) != (greatest != 0)) mont_neg(&y, &y, FQ);
+    return te_from_sw_xy(o, &x, &y, s);
+}
+int sw_decode(te_aff *o, const uint8_t in[33], const suite_t *s) {
+    if (in[32] & 0x3f) return ORC_INVALID_DATA;
+    if (in[32] & 0x40) return ORC_INVALID_DATA;          /* infinity: no twisted-Edwards image (sw_to_te -> None) */
+    u256 x; u256_from_le(&x, in);
+    return sw_from_x(o, &x, (in[32] & 0x80) != 0, s);
 }
 int te_decode_xy(te_aff *o, const uint8_t in[64], const suite_t *s) {
     u256 x, y; u256_from_le(&x, in); u256_from_le(&y, in + 32);

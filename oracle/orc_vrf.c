@@ -31,6 +31,7 @@ static void absorb_u64(transcript_t *t, uint64_t v) {
     uint8_t b[8]; for (int i = 0; i < 8; i++) b[i] = (uint8_t)(v >> (8 * i)); tr_absorb(t, b, 8);
 }
 static void absorb_point(transcript_t *t, const te_aff *p, const suite_t *s) {
+    if (s->sw_codec) { uint8_t b[33]; sw_encode(b, p, s); tr_absorb(t, b, 33); return; }   /* Affine = SWAffine: 33-byte form */
     uint8_t b[32]; te_encode(b, p, s); tr_absorb(t, b, 32);
 }
 static void absorb_scalar(transcript_t *t, const u256 *k_mont, const suite_t *s) {
@@ -164,8 +165,22 @@ int orc_vrf_output(int suite, const uint8_t sk[32], const uint8_t input[32], uin
 int orc_point_to_hash(int suite, const uint8_t pt[32], uint8_t *out, size_t n) {
     const suite_t *s = orc_suite(suite); if (!s) return -1;
     transcript_t t; tr_new(&t, s->suite_id, s->suite_id_len);
-    absorb_u8(&t, DS_POINT_TO_HASH); tr_absorb(&t, pt, 32); tr_squeeze(&t, out, n);
+    absorb_u8(&t, DS_POINT_TO_HASH);
+    if (s->sw_codec) { te_aff p; if (te_decode(&p, pt, s)) return ORC_INVALID_DATA; absorb_point(&t, &p, s); }
+    else tr_absorb(&t, pt, 32);
+    tr_squeeze(&t, out, n);
     return 0;
+}
+/* the suite's own wire form of a point <-> the 32-byte twisted-Edwards form every other oracle entry point takes */
+int orc_sw_encode(int suite, const uint8_t te32[32], uint8_t out33[33]) {
+    const suite_t *s = orc_suite(suite); if (!s || !s->sw_codec) return -1;
+    te_aff p; if (te_decode(&p, te32, s)) return ORC_INVALID_DATA;
+    sw_encode(out33, &p, s); return 0;
+}
+int orc_sw_decode(int suite, const uint8_t in33[33], uint8_t te32[32]) {
+    const suite_t *s = orc_suite(suite); if (!s || !s->sw_codec) return -1;
+    te_aff p; if (sw_decode(&p, in33, s)) return ORC_INVALID_DATA;
+    te_encode(te32, &p, s); return 0;
 }
 
 /* ------------------------------------------------------------------ hash to curve */
@@ -249,6 +264,19 @@ int orc_hash_to_curve(int suite, const uint8_t *data, size_t n, uint8_t out[32])
     for (int ctr = 0; ctr <= 255; ctr++) {
         transcript_t t = prefix; absorb_u8(&t, (uint8_t)ctr);
         uint8_t buf[32]; tr_squeeze(&t, buf, 32);
+        if (s->h2c == ORC_H2C_TAI_SW) {
+            /* SWAffine::from_random_bytes on base_len = 32 bytes: Fp::from_random_bytes_with_flags::<SWFlags> copies them into
+             * its 33-byte buffer, so the flag byte is always zero and the root is fixed: the LARGER one (pinned by the
+             * alpha -> h entries of the reference's bandersnatch_sw vectors: the smaller root gives another point); the
+             * bits above MODULUS_BIT_SIZE are cleared; x >= p -> next counter */
+            buf[31] &= (uint8_t)(0xff >> (256 - s->fq.bits));
+            u256 x; u256_from_le(&x, buf);
+            te_aff p; if (sw_from_x(&p, &x, 1, s)) continue;
+            te_ext e; te_from_aff(&e, &p, s); clear_cofactor(&e, s);
+            if (te_is_identity_ext(&e, s)) continue;
+            te_aff r; te_to_aff(&r, &e, s); te_encode(out, &r, s);
+            return 0;
+        }
         /* TE Affine::from_random_bytes: top bit = x-sign flag, bits above MODULUS_BIT_SIZE cleared */
         int flag = buf[31] >> 7;
         buf[31] &= (uint8_t)(0xff >> (256 - s->fq.bits));

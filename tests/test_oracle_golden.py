@@ -130,3 +130,42 @@ def test_tiny_vectors(golden_dir, name):
         bad = bytearray(proof); bad[17] ^= 1
         assert orc.tiny_verify(s, pk, io, ad, bytes(bad)) == orc.VERIFICATION_FAILURE
         assert orc.tiny_verify(s, pk, io, ad + b"x", proof) == orc.VERIFICATION_FAILURE
+
+
+@pytest.mark.parametrize("scheme", ["thin", "tiny", "pedersen"])
+def test_bandersnatch_sw_vectors(golden_dir, scheme):
+    """Bandersnatch-SW-SHA512-TAI (src/suites/bandersnatch_sw.rs): the same curve in its short-Weierstrass presentation -- every
+    serialised point is the 33-byte SW form (orc.sw_encode / sw_decode, src/utils/te_sw_map.rs), try-and-increment runs on SW
+    x-coordinates, transcripts absorb the 33-byte forms.  All 21 vectors: sk -> pk, alpha -> h, gamma, beta, proofs."""
+    s = orc.BANDERSNATCH_SW
+    te = lambda h: (lambda r: (r[1] if r[0] == 0 else None))(orc.sw_decode(s, bytes.fromhex(h)))
+    for i, v in enumerate(load(golden_dir, "bandersnatch_sw_sha-512_tai", scheme)):
+        sk, pk = bytes.fromhex(v["sk"]), te(v["pk"])
+        assert orc.from_seed(s, bytes([SEEDS[i]]) + bytes(31)) == (sk, pk)
+        assert orc.sw_encode(s, pk).hex() == v["pk"]
+        h = orc.hash_to_curve(s, bytes.fromhex(v["alpha"]))
+        assert orc.sw_encode(s, h).hex() == v["h"]
+        gamma = orc.vrf_output(s, sk, h)
+        assert orc.sw_encode(s, gamma).hex() == v["gamma"] and orc.point_to_hash(s, gamma).hex() == v["beta"]
+        io, ad = [(h, gamma)], bytes.fromhex(v["ad"])
+        if scheme == "thin":
+            pr = orc.thin_prove(s, sk, io, ad)
+            assert orc.sw_encode(s, pr[:32]).hex() + pr[32:].hex() == v["proof_r"] + v["proof_s"]
+            assert orc.thin_verify(s, pk, io, ad, pr) == orc.OK
+            assert orc.thin_verify(s, pk, io, ad + b"x", pr) == orc.VERIFICATION_FAILURE
+        elif scheme == "tiny":
+            pr = orc.tiny_prove(s, sk, io, ad)
+            assert pr.hex() == v["proof_c"] + v["proof_s"] and orc.tiny_verify(s, pk, io, ad, pr) == orc.OK
+        else:
+            pr, bl = orc.pedersen_prove(s, sk, io, ad)
+            assert bl.hex() == v["blinding"]
+            assert "".join(orc.sw_encode(s, pr[32 * k: 32 * k + 32]).hex() for k in range(3)) + pr[96:].hex() == \
+                v["proof_pk_com"] + v["proof_r"] + v["proof_ok"] + v["proof_s"] + v["proof_sb"]
+            assert orc.pedersen_verify(s, io, ad, pr) == orc.OK
+    # BLINDING_BASE and PADDING are hash-to-curve outputs; ACCUMULATOR_BASE is NOT for an SW suite (the reference adds a point
+    # outside the prime-order subgroup, src/ring.rs:896-910) -- it is the reference's constant, mapped
+    assert orc.hash_to_curve(s, b"pedersen-blinding") == orc.suite_point(s, 1)
+    assert orc.hash_to_curve(s, b"ring-padding") == orc.suite_point(s, 3)
+    assert orc.hash_to_curve(s, b"ring-accumulator") != orc.suite_point(s, 2)
+    # infinity and unused flag bits do not decode; the round trip keeps the flag byte
+    assert orc.sw_decode(s, bytes(32) + b"\x40")[0] != 0 and orc.sw_decode(s, bytes.fromhex(v["pk"])[:32] + b"\x01")[0] != 0

@@ -63,7 +63,7 @@ def field_n(name, p, nl):
     return "\n".join(s)
 
 
-def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=None):
+def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=None, sw=None):
     sid_bytes = ", ".join(str(b) for b in sid_str.encode())
     s = [f"struct {name} {{", f"  using Fq = {fq}; using Fr = {fr};",
          f"  static constexpr int SUITE_ID_LEN = {len(sid_str)};",
@@ -78,6 +78,16 @@ def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=
         s.append(f"  static constexpr uint32_t {nm}_K[8] = {{{limbs(mont(d * x * y % q, q))}}};  /* d*x*y */")
         comp = y | ((1 << 255) if x > (q - 1) // 2 else 0)
         s.append(f"  static constexpr uint32_t {nm}_C[8] = {{{limbs(comp)}}};  /* ark-serialize compressed encoding, LE words */")
+    gx, gy = pts["G"]
+    if sw:                                    # te_to_sw(G): 33-byte compressed SW form
+        u = (1 + gy) * pow(1 - gy, -1, q) % q
+        v = (1 + gy) * pow(gx * (1 - gy), -1, q) % q
+        xs, ys = sw["MONT_BINV"] * (u + sw["MONT_A3"]) % q, sw["MONT_BINV"] * v % q
+        assert (ys * ys - xs ** 3 - sw["SW_A"] * xs - sw["SW_B"]) % q == 0
+        enc = xs.to_bytes(32, "little") + bytes([0x80 if ys > (q - 1) // 2 else 0])
+    else:
+        enc = (gy | ((1 << 255) if gx > (q - 1) // 2 else 0)).to_bytes(32, "little")
+    s.append(f"  static constexpr uint8_t G_ENC[{len(enc)}] = {{{', '.join(str(b) for b in enc)}}};  /* serialize_compressed(generator) */")
     # hash-to-curve (src/utils/hash_to_curve.rs): Elligator2 over the Montgomery model (J, K), Z = 5; or try-and-increment
     s.append(f"  static constexpr int H2C_ELL2 = {1 if ell2 else 0};")
     j, k = ell2 if ell2 else (0, 1)
@@ -85,6 +95,13 @@ def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=
     s.append(f"  static constexpr uint32_t ELL2_JK[8] = {{{limbs(mont(j * kinv % q, q))}}};     /* J / K */")
     s.append(f"  static constexpr uint32_t ELL2_K[8] = {{{limbs(mont(k, q))}}};")
     s.append(f"  static constexpr uint32_t ELL2_KINV2[8] = {{{limbs(mont(kinv * kinv % q, q))}}};  /* 1 / K^2 */")
+    # short-Weierstrass presentation (src/suites/bandersnatch_sw.rs, src/utils/te_sw_map.rs): serialised points are 33-byte SW
+    # forms; arithmetic stays twisted-Edwards through the maps (x, y) -> (B x - A/3, B y) -> (u / v, (u - 1) / (u + 1))
+    s.append(f"  static constexpr bool SW_CODEC = {'true' if sw else 'false'};")
+    s.append(f"  static constexpr int POINT_LEN = {33 if sw else 32};  /* serialize_compressed size of the suite's Affine */")
+    if sw:
+        for nm in ("MONT_B", "MONT_A3", "MONT_BINV", "SW_A", "SW_B"):
+            s.append(f"  static constexpr uint32_t {nm}[8] = {{{limbs(mont(sw[nm], q))}}};")
     # GLV (per-item scalar multiplications): k = k1 + k2 * lambda (mod r), |k1|, |k2| < 2^127, psi = [lambda] as a rational map
     s.append(f"  static constexpr bool HAS_GLV = {'true' if glv else 'false'};")
     if glv:
@@ -272,6 +289,33 @@ def main():
                       "B": (45003173884697328536089278691112838614164406922820087464913813433380838325453,
                             31256014272390301975555524011230972931324093235775711248505761870355310252869),
                       "ACC": g_e, "PAD": g_e}, 8))
+    # Bandersnatch-SW-SHA512-TAI-v1 (src/suites/bandersnatch_sw.rs:60-112): suite 0's curve in its short-Weierstrass presentation.
+    # The maps take the SW generator to the TE generator, so G, D, the GLV data are suite 0's; the suite points are given as SW
+    # coordinates in the reference and mapped here.
+    A_m = 29978822694968839326280996386011761570173833766074948509196803838190355340952
+    B_m = 25465760566081946422412445027709227188579564747101592991722834452325077642517
+    a3 = 9992940898322946442093665462003920523391277922024982836398934612730118446984
+    binv = 41180284393978236561320365279764246793818536543197771097409483252169927600582
+    assert a3 * 3 % q_b == A_m and binv * B_m % q_b == 1
+    sw_a = (3 - A_m * A_m) * pow(3 * B_m * B_m, -1, q_b) % q_b
+    sw_b = (2 * A_m ** 3 - 9 * A_m) * pow(27 * B_m ** 3, -1, q_b) % q_b
+
+    def sw_to_te(x, y):
+        assert (y * y - x ** 3 - sw_a * x - sw_b) % q_b == 0
+        mx, my = (B_m * x - a3) % q_b, B_m * y % q_b
+        return mx * pow(my, -1, q_b) % q_b, (mx - 1) * pow(mx + 1, -1, q_b) % q_b
+    g0 = (18886178867200960497001835917649091219057080094937609519140440539760939937304,
+          19188667384257783945677642223292697773471335439753913231509108946878080696678)
+    out.append(suite("SuiteBandersnatchSW", 4, "Bandersnatch-SW-SHA512-TAI-v1", "FqBandersnatch", "FrBandersnatch", q_b, r_b, 1,
+                     45022363124591815672509500913686876175488063829319466900776701791074614335719,
+                     {"G": g0,
+                      "B": sw_to_te(28115362618644671219696075022370511395136332234538034358311199318506963235315,
+                                    3900851469868158154936962463930962496000252801946757953905982128670530185313),
+                      "ACC": sw_to_te(13189182432637108534251278524663360416811744717379968387043749958796254980045,
+                                      14483286006782706188671626508232161325054303360192563232232823772738911894793),
+                      "PAD": sw_to_te(20496180070424734470560955314776462366297546779079302509428101119888111900885,
+                                      8839106592405352067483360946162273985142890146060814748321063063028225641813)}, 4,
+                     glv=glv_b, sw=dict(MONT_B=B_m, MONT_A3=a3, MONT_BINV=binv, SW_A=sw_a, SW_B=sw_b)))
     out += ["", "}  // namespace avrf", ""]
     with open(OUT, "w") as f:
         f.write("\n".join(out))
