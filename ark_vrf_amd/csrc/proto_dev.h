@@ -53,15 +53,17 @@ struct Seed64 { uint64_t w[8]; };  // a SHA-512 digest as big-endian words
 template <class S> AVRF_DI void absorb_point_xy(Sha512 &h, const fp &x, const fp &y) {
   using Fq = typename S::Fq;
   if constexpr (S::SW_CODEC) {           // the suite's Affine is SWAffine: 33-byte form, LE32(x_sw) || flags (sw_map.h)
-    const sw_enc e = sw_encode_te<S>(fp_to_mont<Fq>(x), fp_to_mont<Fq>(y));
-#pragma unroll
-    for (int i = 0; i < 8; i++) sha512_u32le(h, e.x.v[i]);
-    sha512_byte(h, e.flag);
+    absorb_sw_enc(h, sw_encode_te<S>(fp_to_mont<Fq>(x), fp_to_mont<Fq>(y)));
     return;
   }
   uint32_t sign = fp_is_negative_plain<Fq>(x) ? 0x80000000u : 0u;
 #pragma unroll
   for (int i = 0; i < 8; i++) sha512_u32le(h, y.v[i] | (i == 7 ? sign : 0u));
+}
+AVRF_DI void absorb_sw_enc(Sha512 &h, const sw_enc &e) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) sha512_u32le(h, e.x.v[i]);
+  sha512_byte(h, e.flag);
 }
 // the serialised generator (chain_ios, src/utils/common.rs:231-240), a per-suite constant
 template <class S> AVRF_DI void absorb_generator(Sha512 &h) {

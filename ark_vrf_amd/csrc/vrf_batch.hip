@@ -27,17 +27,25 @@ k_thin_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint32_t *__restrict__ 
   sha512_byte(h, DS_THIN);                                                     // common.rs:166
   sha512_u64le(h, (uint64_t)m + 1);                                            // absorb_ios :377-383, Schnorr pair first
   absorb_generator<S>(h);                                                    // chain_ios :231-240: (G, pk)
+  // short-Weierstrass presentation, one pair (the common shape): the 33-byte forms of pk, I, O and R with ONE inversion
+  sw_enc enc[4]; bool have_enc = false;
+  if constexpr (S::SW_CODEC) if (m == 1) {
+    const uint8_t *p = b.ios_xy + 128 * (size_t)io0, *pr = b.proofs + 96 * (size_t)j, *pk = b.pks_xy + 64 * (size_t)j;
+    const fp xs[4] = {fp_load_le(pk), fp_load_le(p), fp_load_le(p + 64), fp_load_le(pr)};
+    const fp ys[4] = {fp_load_le(pk + 32), fp_load_le(p + 32), fp_load_le(p + 96), fp_load_le(pr + 32)};
+    sw_encode_te_many<S, 4>(xs, ys, enc); have_enc = true;
+  }
   {
     fp x = fp_load_le(b.pks_xy + 64 * (size_t)j), y = fp_load_le(b.pks_xy + 64 * (size_t)j + 32);
     f |= point_flags<S>(x, y);                                                 // thin.rs:266-271
-    absorb_point_xy<S>(h, x, y);
+    if (have_enc) absorb_sw_enc(h, enc[0]); else absorb_point_xy<S>(h, x, y);
   }
   for (uint32_t i = 0; i < m; i++) {
     const uint8_t *p = b.ios_xy + 128 * (size_t)(io0 + i);
     fp x = fp_load_le(p), y = fp_load_le(p + 32);
-    f |= point_flags<S>(x, y); absorb_point_xy<S>(h, x, y);
+    f |= point_flags<S>(x, y); if (have_enc) absorb_sw_enc(h, enc[1]); else absorb_point_xy<S>(h, x, y);
     x = fp_load_le(p + 64); y = fp_load_le(p + 96);
-    f |= point_flags<S>(x, y); absorb_point_xy<S>(h, x, y);
+    f |= point_flags<S>(x, y); if (have_enc) absorb_sw_enc(h, enc[2]); else absorb_point_xy<S>(h, x, y);
   }
   sha512_u64le(h, (uint64_t)adl);                                              // common.rs:169-170
   sha512_bytes(h, b.ads + ad0, adl);
@@ -58,7 +66,7 @@ k_thin_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint32_t *__restrict__ 
     if (point_flags<S>(x, y) & FLAG_RANGE) f |= FLAG_RANGE;                    // R may be the identity (thin.rs:95-99)
     if (ge_p<Fr>(s)) f |= FLAG_SCALAR;
     sha512_byte(h, DS_CHALLENGE);
-    absorb_point_xy<S>(h, x, y);
+    if (have_enc) absorb_sw_enc(h, enc[3]); else absorb_point_xy<S>(h, x, y);
     sha512_final(h, seed);
     sha512_xof_block(seed, 0, blk);
     uint32_t w[4]; digest_le128(blk, 0, w);
@@ -184,8 +192,14 @@ k_ped_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint8_t *__restrict__ me
   f |= point_flags<S>(ybx, yby);                                               // pk_com.is_zero() (:348-353)
   f |= (point_flags<S>(rx, ry) | point_flags<S>(okx, oky)) & FLAG_RANGE;
   if (ge_p<Fr>(fp_load_le(pr + 192)) || ge_p<Fr>(fp_load_le(pr + 224))) f |= FLAG_SCALAR;
-  absorb_point_xy<S>(t, ybx, yby);                                             // :280
-  sha512_byte(t, DS_CHALLENGE); absorb_point_xy<S>(t, rx, ry); absorb_point_xy<S>(t, okx, oky);
+  if constexpr (S::SW_CODEC) {                                                 // the three proof points' 33-byte forms, one inversion
+    const fp xs[3] = {ybx, rx, okx}, ys[3] = {yby, ry, oky};
+    sw_enc enc[3]; sw_encode_te_many<S, 3>(xs, ys, enc);
+    absorb_sw_enc(t, enc[0]); sha512_byte(t, DS_CHALLENGE); absorb_sw_enc(t, enc[1]); absorb_sw_enc(t, enc[2]);
+  } else {
+    absorb_point_xy<S>(t, ybx, yby);                                           // :280
+    sha512_byte(t, DS_CHALLENGE); absorb_point_xy<S>(t, rx, ry); absorb_point_xy<S>(t, okx, oky);
+  }
   fp c = challenge_finish(t);                                                  // :281
   *reinterpret_cast<uint4 *>(c_out + 4 * (size_t)j) = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
   if (f) atomicOr(flags, f);
