@@ -91,6 +91,20 @@ template <class S> AVRF_DI void tr_base(Sha512 &h, uint8_t scheme, bool schnorr,
   sha512_byte(h, scheme);
   sha512_u64le(h, (uint64_t)m + (schnorr ? 1 : 0));
   uint32_t f = 0;
+  if constexpr (S::SW_CODEC) if (m == 1) {
+    // short-Weierstrass presentation, one pair: the 33-byte forms of (pk,) I, O with ONE inversion (sw_map.h)
+    fp xs[3], ys[3]; sw_enc enc[3];
+    xs[0] = fp_load_le(ios_xy); ys[0] = fp_load_le(ios_xy + 32); xs[1] = fp_load_le(ios_xy + 64); ys[1] = fp_load_le(ios_xy + 96);
+    if (schnorr) { xs[2] = fp_load_le(pk_xy); ys[2] = fp_load_le(pk_xy + 32); } else { xs[2] = xs[0]; ys[2] = ys[0]; }
+    sw_encode_te_many<S, 3>(xs, ys, enc);
+    if (schnorr) { absorb_generator<S>(h); f |= point_flags<S>(xs[2], ys[2]); absorb_sw_enc(h, enc[2]); }
+    f |= point_flags<S>(xs[0], ys[0]) | point_flags<S>(xs[1], ys[1]);
+    absorb_sw_enc(h, enc[0]); absorb_sw_enc(h, enc[1]);
+    sha512_u64le(h, (uint64_t)adl);
+    sha512_bytes(h, ad, adl);
+    *flags |= f;
+    return;
+  }
   if (schnorr) {
     absorb_generator<S>(h);
     fp x = fp_load_le(pk_xy), y = fp_load_le(pk_xy + 32);

@@ -284,8 +284,14 @@ k_ped_verify(BatchDev b, int32_t *__restrict__ status) {
     te_aff ia, oa; to_aff2<S>(im, om, ia, oa);
     ip = pre_from_aff<S>(ia); op = pre_from_aff<S>(oa);
   }
-  absorb_point_xy<S>(t, ybx, yby);                                             // :219
-  sha512_byte(t, DS_CHALLENGE); absorb_point_xy<S>(t, rx, ry); absorb_point_xy<S>(t, okx, oky);
+  if constexpr (S::SW_CODEC) {                                                 // three 33-byte SW forms, one inversion
+    const fp xs[3] = {ybx, rx, okx}, ys[3] = {yby, ry, oky};
+    sw_enc enc[3]; sw_encode_te_many<S, 3>(xs, ys, enc);
+    absorb_sw_enc(t, enc[0]); sha512_byte(t, DS_CHALLENGE); absorb_sw_enc(t, enc[1]); absorb_sw_enc(t, enc[2]);
+  } else {
+    absorb_point_xy<S>(t, ybx, yby);                                           // :219
+    sha512_byte(t, DS_CHALLENGE); absorb_point_xy<S>(t, rx, ry); absorb_point_xy<S>(t, okx, oky);
+  }
   fp c = challenge_finish(t);                                                  // :222
   // Eq1: s*I - c*O == Ok   (:229-232)
   te_ext lhs1 = have_io ? te_smul_multi_glv<S, false>(ip, s, ip, fp_zero(), te_pre_neg<S>(op), c) : te_identity<S>();

@@ -11,7 +11,13 @@ import bench  # noqa: E402
 from ark_vrf_amd import _native as nat  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-ctx = nat.Context(0)
+suite = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+R_ORDER = {0: bench.R_BANDERSNATCH, 1: 2736030358979909402780800718157159386076813972158567259200215660948447373041,
+           2: 6554484396890773809930967563523245729705921265872317281365359162392183254199, 3: 2 ** 252 + 27742317777372353535851937790883648493,
+           4: bench.R_BANDERSNATCH}
+bench.R_BANDERSNATCH = R_ORDER[suite]
+ctx = nat.Context(suite)
+print(f"suite {suite}, {n} items, one context")
 sks = bench.derive_scalars(b"ped-bench-sk", 0, n, bench.R_BANDERSNATCH)
 pks = ctx.scalar_mul_base(sks)
 inputs = ctx.scalar_mul_base(bench.derive_scalars(b"ped-bench-in", 0, n, bench.R_BANDERSNATCH))
