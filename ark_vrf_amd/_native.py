@@ -17,6 +17,7 @@ BANDERSNATCH_SHA512_ELL2 = 0
 BABYJUBJUB_SHA512_TAI = 1
 JUBJUB_SHA512_TAI = 2
 ED25519_SHA512_TAI = 3          # Tiny / Thin / Pedersen only (no ring suite)
+BANDERSNATCH_SHAKE128_ELL2 = 5   # suite 0's curve with the SHAKE128 sponge as transcript
 BANDERSNATCH_SW_SHA512_TAI = 4  # Bandersnatch, short-Weierstrass presentation: 33-byte compressed points (Context.point_len)
 
 THIN_PROOF_LEN = 96       # R_xy || s
@@ -88,8 +89,11 @@ class Context:
         if st != OK:
             raise AvrfError(f"avrf_ctx_create failed with {st} (no MI355X visible? there is no CPU fallback)")
         self.suite = suite
-        lib().avrf_point_len.restype = C.c_size_t
-        self.point_len = lib().avrf_point_len(int(suite))      # serialize_compressed size of the suite's points: 32, or 33 (SW form)
+        try:
+            lib().avrf_point_len.restype = C.c_size_t
+            self.point_len = lib().avrf_point_len(int(suite))  # serialize_compressed size of the suite's points: 32, or 33 (SW form)
+        except AttributeError:                                 # an older build loaded through AVRF_LIB_PATH (A/B runs)
+            self.point_len = 32
 
     def set_validation(self, level):
         """0: caller guarantees on-curve subgroup points (reference's typed-point contract); 1: on-curve check; 2: + subgroup."""

@@ -6,6 +6,7 @@
 // transcript (host_sha512.h), (2) finishes the MSM's O(256)-step window Horner (host_te.h).
 #include "../../include/avrf.h"
 #include "host_sha512.h"
+#include "host_shake128.h"
 #include "host_te.h"
 #include "msm.h"
 #include "proto_dev.h"
@@ -75,6 +76,7 @@ struct avrf_ctx {
   size_t n = 0, tot_io = 0, n_terms = 0;
   DevBuf d_pks, d_ios, d_io_off, d_ads, d_ad_off, d_proofs, d_sks;
   std::vector<uint8_t> h_resp;    // host copy of the response scalars (s [, sb]) for the weight transcript
+  std::vector<uint8_t> h_weights; DevBuf d_weights;   // sponge transcripts: the squeezed weight stream of the staged batch
   DevBuf d_c, d_z, d_flags, d_scalars, d_pre, d_gpart, d_misc, d_out, d_status;
   DevBuf d_fixed; bool fixed_ready = false;   // fixed-base tables of G and BLINDING_BASE (provers, scalar_mul_base), built on first use
   PinBuf h_c, h_flags, h_io;
@@ -96,6 +98,7 @@ static BatchDev batch_of(avrf_ctx *c) {
   b.ads = c->d_ads.as<uint8_t>(); b.ad_off = c->d_ad_off.as<uint32_t>(); b.proofs = c->d_proofs.as<uint8_t>();
   b.sks = c->d_sks.as<uint8_t>(); b.n = (uint32_t)c->n;
   b.fixed = (const te_pre *)c->d_fixed.p;
+  b.weights = nullptr;
   return b;
 }
 
@@ -164,7 +167,7 @@ void avrf_ctx_destroy(avrf_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   c->ws.release();
   DevBuf *bufs[] = {&c->d_pks, &c->d_ios, &c->d_io_off, &c->d_ads, &c->d_ad_off, &c->d_proofs, &c->d_sks, &c->d_c, &c->d_z,
-                    &c->d_flags, &c->d_scalars, &c->d_pre, &c->d_gpart, &c->d_misc, &c->d_out, &c->d_status, &c->d_fixed};
+                    &c->d_flags, &c->d_scalars, &c->d_pre, &c->d_gpart, &c->d_misc, &c->d_out, &c->d_status, &c->d_fixed, &c->d_weights};
   for (DevBuf *b : bufs) b->release();
   c->h_c.release(); c->h_flags.release(); c->h_io.release();
   (void)hipStreamDestroy(c->stream);
@@ -304,19 +307,34 @@ static int batch_run(avrf_ctx *c, int kind) {
   if (*c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;            // src/thin.rs:266-271, src/pedersen.rs:348-353
   // weight transcript (src/thin.rs:274-279, src/pedersen.rs:361-367):
   //   new(SUITE_ID); absorb [0x50]; per item absorb LE32(c) || LE32(s) [|| LE32(sb)]
-  HostSha512 h;
-  with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; h.update(S::SUITE_ID, S::SUITE_ID_LEN); });
-  const uint8_t tag = DS_BATCH_VERIFY; h.update(&tag, 1);
-  {
-    const uint8_t *cs = c->h_c.as<uint8_t>();
-    const size_t rsz = kind == 1 ? 32 : 64;
-    uint8_t rec[96];
-    memset(rec, 0, sizeof rec);
+  Seed64 seed; memset(&seed, 0, sizeof seed);
+  const bool sponge = with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; return (bool)S::XOF_SHAKE; });
+  const uint8_t tag = DS_BATCH_VERIFY;
+  const uint8_t *cs = c->h_c.as<uint8_t>();
+  const size_t rsz = kind == 1 ? 32 : 64;
+  uint8_t rec[96];
+  memset(rec, 0, sizeof rec);
+  if (sponge) {
+    // Shake128Transcript: the weights are the sponge's OUTPUT STREAM (16 bytes per item, 32 for Pedersen) -- sequential, so the
+    // host squeezes it and the terms kernel reads it from HBM instead of deriving block j / 4 from a seed
+    HostShake128 h;
+    with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; h.update(S::SUITE_ID, S::SUITE_ID_LEN); });
+    h.update(&tag, 1);
     for (size_t j = 0; j < n; j++) { memcpy(rec, cs + 16 * j, 16); memcpy(rec + 32, &c->h_resp[rsz * j], rsz); h.update(rec, 32 + rsz); }
+    const size_t wsz = kind == 1 ? 16 : 32;
+    c->h_weights.resize(n * wsz);
+    h.squeeze_copy(c->h_weights.data(), n * wsz);
+    HIP_TRY(c->d_weights.ensure(n * wsz));
+    HIP_TRY(hipMemcpyAsync(c->d_weights.p, c->h_weights.data(), n * wsz, hipMemcpyHostToDevice, c->stream));
+    b.weights = c->d_weights.as<uint8_t>();
+  } else {
+    HostSha512 h;
+    with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; h.update(S::SUITE_ID, S::SUITE_ID_LEN); });
+    h.update(&tag, 1);
+    for (size_t j = 0; j < n; j++) { memcpy(rec, cs + 16 * j, 16); memcpy(rec + 32, &c->h_resp[rsz * j], rsz); h.update(rec, 32 + rsz); }
+    uint8_t dg[64]; h.final(dg);
+    for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, dg + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
   }
-  uint8_t dg[64]; h.final(dg);
-  Seed64 seed;
-  for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, dg + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
   double t2 = now_us();
   if (kind == 1) launch_thin_terms(c->suite, b, seed, 0, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_scalars.as<uint32_t>(),
                                    c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
@@ -351,6 +369,9 @@ int avrf_pedersen_batch_verify(avrf_ctx *c, size_t n, const uint8_t *ios_xy, con
 // weight transcript of src/thin.rs:274-279 / src/pedersen.rs:361-367 over ALL items of a batch (host only)
 int avrf_batch_weight_seed(int suite, int pedersen, size_t n, const uint8_t *c16, const uint8_t *resp, uint8_t seed_out[64]) {
   if (suite < 0 || suite >= AVRF_N_SUITES || !seed_out || (n && (!c16 || !resp))) return AVRF_ERR_BAD_ARG;
+  // a sponge transcript has no seed to hand to the shards (its weight stream is sequential): the split-one-batch mode is for the
+  // counter-mode (HashTranscript) suites; whole batches shard over GPUs for every suite
+  if (with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return (bool)S::XOF_SHAKE; })) return AVRF_ERR_BAD_ARG;
   HostSha512 h;
   with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; h.update(S::SUITE_ID, S::SUITE_ID_LEN); });
   const uint8_t tag = DS_BATCH_VERIFY; h.update(&tag, 1);
@@ -476,6 +497,8 @@ int avrf_kernel_stats(avrf_ctx *c, int reset, double *accum_ms_total, uint64_t *
 static int read_flags(avrf_ctx *c) {
   if (hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
   if (hipStreamSynchronize(c->stream) != hipSuccess || hipGetLastError() != hipSuccess) return -1;
+  static const bool trace = getenv("AVRF_TRACE_FLAGS") != nullptr;   // which check refused the input: 1 range, 2 identity, 4 scalar, 8 curve
+  if (trace && *c->h_flags.as<uint32_t>()) fprintf(stderr, "avrf: input flags 0x%x (suite %d)\n", *c->h_flags.as<uint32_t>(), c->suite);
   return (int)*c->h_flags.as<uint32_t>();
 }
 

@@ -9,7 +9,9 @@
 //   challenge_scalar      common.rs:72-76, nonce_scalar :57-70
 #pragma once
 #include "sha512_dev.h"
+#include "shake_dev.h"
 #include "te.h"
+#include <type_traits>
 
 // Everything that includes this header is a per-item protocol kernel: route the field / curve
 // calls to their out-of-line forms (fp256.h, te.h) so that each kernel holds ONE copy of the
@@ -45,12 +47,16 @@ struct BatchDev {
   const uint8_t *sks;       // n x 32 (provers only)
   uint32_t n;
   const te_pre *fixed;      // fixed-base tables of the suite's G and BLINDING_BASE: [2][32][256] (provers only)
+  const uint8_t *weights;   // batch verifiers, sponge transcripts only: the squeezed weight stream of THIS batch (16 / 32 bytes per
+                            // item), produced by the host -- a sponge's output is sequential; nullptr: counter-mode stream from the seed
 };
 struct Seed64 { uint64_t w[8]; };  // a SHA-512 digest as big-endian words
+// Suite::Transcript (src/lib.rs:177-250): HashTranscript<Sha512>, or the SHAKE128 sponge for the suites that say so
+template <class S> using suite_tr = std::conditional_t<S::XOF_SHAKE, Shake128, Sha512>;
 
 // absorb the ark-serialize compressed encoding of an affine point given as canonical x||y
 // (LE32 each): LE32(y) with bit 255 set iff x > (q-1)/2   
-template <class S> AVRF_DI void absorb_point_xy(Sha512 &h, const fp &x, const fp &y) {
+template <class S, class T> AVRF_DI void absorb_point_xy(T &h, const fp &x, const fp &y) {
   using Fq = typename S::Fq;
   if constexpr (S::SW_CODEC) {           // the suite's Affine is SWAffine: 33-byte form, LE32(x_sw) || flags (sw_map.h)
     absorb_sw_enc(h, sw_encode_te<S>(fp_to_mont<Fq>(x), fp_to_mont<Fq>(y)));
@@ -58,20 +64,20 @@ template <class S> AVRF_DI void absorb_point_xy(Sha512 &h, const fp &x, const fp
   }
   uint32_t sign = fp_is_negative_plain<Fq>(x) ? 0x80000000u : 0u;
 #pragma unroll
-  for (int i = 0; i < 8; i++) sha512_u32le(h, y.v[i] | (i == 7 ? sign : 0u));
+  for (int i = 0; i < 8; i++) tr_u32le(h, y.v[i] | (i == 7 ? sign : 0u));
 }
-AVRF_DI void absorb_sw_enc(Sha512 &h, const sw_enc &e) {
+template <class T> AVRF_DI void absorb_sw_enc(T &h, const sw_enc &e) {
 #pragma unroll
-  for (int i = 0; i < 8; i++) sha512_u32le(h, e.x.v[i]);
-  sha512_byte(h, e.flag);
+  for (int i = 0; i < 8; i++) tr_u32le(h, e.x.v[i]);
+  tr_byte(h, e.flag);
 }
 // the serialised generator (chain_ios, src/utils/common.rs:231-240), a per-suite constant
-template <class S> AVRF_DI void absorb_generator(Sha512 &h) {
-  for (int i = 0; i < S::POINT_LEN; i++) sha512_byte(h, S::G_ENC[i]);
+template <class S, class T> AVRF_DI void absorb_generator(T &h) {
+  for (int i = 0; i < S::POINT_LEN; i++) tr_byte(h, S::G_ENC[i]);
 }
-AVRF_DI void absorb_fp_le(Sha512 &h, const fp &a) {
+template <class T> AVRF_DI void absorb_fp_le(T &h, const fp &a) {
 #pragma unroll
-  for (int i = 0; i < 8; i++) sha512_u32le(h, a.v[i]);
+  for (int i = 0; i < 8; i++) tr_u32le(h, a.v[i]);
 }
 template <class S> AVRF_DI uint32_t point_flags(const fp &x, const fp &y) {
   using Fq = typename S::Fq;
@@ -84,32 +90,32 @@ template <class S> AVRF_DI uint32_t point_flags(const fp &x, const fp &y) {
 
 // Transcript after vrf_transcript_base: SUITE_ID, scheme tag, io count + pairs (optionally the
 // Schnorr pair (G, pk) first), ad length + ad.  Accumulates point flags of pk / ios into *flags.
-template <class S> AVRF_DI void tr_base(Sha512 &h, uint8_t scheme, bool schnorr, const uint8_t *pk_xy,
+// (the public key comes as two field elements in registers: a prover that derives it never spills it to a private byte array)
+template <class S, class T> AVRF_DI void tr_base(T &h, uint8_t scheme, bool schnorr, const fp &pkx, const fp &pky,
                                         const uint8_t *ios_xy, uint32_t m, const uint8_t *ad, uint32_t adl, uint32_t *flags) {
-  sha512_init(h);
-  for (int i = 0; i < S::SUITE_ID_LEN; i++) sha512_byte(h, S::SUITE_ID[i]);
-  sha512_byte(h, scheme);
-  sha512_u64le(h, (uint64_t)m + (schnorr ? 1 : 0));
+  tr_init(h);
+  for (int i = 0; i < S::SUITE_ID_LEN; i++) tr_byte(h, S::SUITE_ID[i]);
+  tr_byte(h, scheme);
+  tr_u64le(h, (uint64_t)m + (schnorr ? 1 : 0));
   uint32_t f = 0;
   if constexpr (S::SW_CODEC) if (m == 1) {
     // short-Weierstrass presentation, one pair: the 33-byte forms of (pk,) I, O with ONE inversion (sw_map.h)
     fp xs[3], ys[3]; sw_enc enc[3];
     xs[0] = fp_load_le(ios_xy); ys[0] = fp_load_le(ios_xy + 32); xs[1] = fp_load_le(ios_xy + 64); ys[1] = fp_load_le(ios_xy + 96);
-    if (schnorr) { xs[2] = fp_load_le(pk_xy); ys[2] = fp_load_le(pk_xy + 32); } else { xs[2] = xs[0]; ys[2] = ys[0]; }
+    if (schnorr) { xs[2] = pkx; ys[2] = pky; } else { xs[2] = xs[0]; ys[2] = ys[0]; }
     sw_encode_te_many<S, 3>(xs, ys, enc);
     if (schnorr) { absorb_generator<S>(h); f |= point_flags<S>(xs[2], ys[2]); absorb_sw_enc(h, enc[2]); }
     f |= point_flags<S>(xs[0], ys[0]) | point_flags<S>(xs[1], ys[1]);
     absorb_sw_enc(h, enc[0]); absorb_sw_enc(h, enc[1]);
-    sha512_u64le(h, (uint64_t)adl);
-    sha512_bytes(h, ad, adl);
+    tr_u64le(h, (uint64_t)adl);
+    tr_bytes(h, ad, adl);
     *flags |= f;
     return;
   }
   if (schnorr) {
     absorb_generator<S>(h);
-    fp x = fp_load_le(pk_xy), y = fp_load_le(pk_xy + 32);
-    f |= point_flags<S>(x, y);
-    absorb_point_xy<S>(h, x, y);
+    f |= point_flags<S>(pkx, pky);
+    absorb_point_xy<S>(h, pkx, pky);
   }
   for (uint32_t i = 0; i < m; i++) {
     const uint8_t *p = ios_xy + 128 * (size_t)i;
@@ -118,47 +124,49 @@ template <class S> AVRF_DI void tr_base(Sha512 &h, uint8_t scheme, bool schnorr,
     x = fp_load_le(p + 64); y = fp_load_le(p + 96);
     f |= point_flags<S>(x, y); absorb_point_xy<S>(h, x, y);
   }
-  sha512_u64le(h, (uint64_t)adl);
-  sha512_bytes(h, ad, adl);
+  tr_u64le(h, (uint64_t)adl);
+  tr_bytes(h, ad, adl);
   *flags |= f;
 }
-// seed of the delinearisation stream: fork + [0x30] + finalize
-AVRF_DI void delin_seed(const Sha512 &h, uint64_t (&seed)[8]) {
-  Sha512 hd = h; sha512_byte(hd, DS_DELINEARIZE); sha512_final(hd, seed);
+template <class S, class T> AVRF_DI void tr_base(T &h, uint8_t scheme, bool schnorr, const uint8_t *pk_xy,
+                                        const uint8_t *ios_xy, uint32_t m, const uint8_t *ad, uint32_t adl, uint32_t *flags) {
+  fp x = fp_zero(), y = fp_zero();
+  if (schnorr) { x = fp_load_le(pk_xy); y = fp_load_le(pk_xy + 32); }        // pk_xy: global memory (staged batch)
+  tr_base<S>(h, scheme, schnorr, x, y, ios_xy, m, ad, adl, flags);
 }
-// i-th 16-byte chunk of a squeeze stream as a 128-bit plain integer
-AVRF_DI fp xof128(const uint64_t (&seed)[8], uint32_t i) {
-  uint64_t blk[8]; sha512_xof_block(seed, i >> 2, blk);
-  uint32_t w[4]; digest_le128(blk, i & 3, w);
+// reader of the delinearisation stream: fork + [0x30] + finalize (DelinearizeScalars, common.rs:335-369)
+template <class T> AVRF_DI auto delin_seed(const T &h) {
+  T hd = h; tr_byte(hd, DS_DELINEARIZE); return tr_reader(hd);
+}
+// i-th 16-byte chunk of a squeeze stream as a 128-bit plain integer (readers only move forward)
+template <class R> AVRF_DI fp xof128(R &rd, uint32_t i) {
+  uint32_t w[4]; rd_chunk16(rd, i, w);
   fp a = fp_zero(); a.v[0] = w[0]; a.v[1] = w[1]; a.v[2] = w[2]; a.v[3] = w[3]; return a;
 }
 // challenge_scalar of a finished transcript: first 16 squeezed bytes (plain 128-bit integer < r)
-AVRF_DI fp challenge_finish(const Sha512 &h) {
-  uint64_t seed[8]; sha512_final(h, seed); return xof128(seed, 0);
+template <class T> AVRF_DI fp challenge_finish(const T &h) {
+  auto rd = tr_reader(h); return xof128(rd, 0);
 }
-// first `nbytes` (<= 64) squeezed bytes as little-endian integer pieces lo (bytes 0..31), hi (32..63)
-AVRF_DI void squeeze64(const Sha512 &h, fp &lo, fp &hi, uint64_t (&blk)[8]) {
-  uint64_t seed[8]; sha512_final(h, seed); sha512_xof_block(seed, 0, blk);
+// the first 64 squeezed bytes as little-endian integers lo (bytes 0..31), hi (32..63)
+template <class T> AVRF_DI void squeeze64(const T &h, fp &lo, fp &hi) {
+  auto rd = tr_reader(h);
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    uint64_t b = __builtin_bswap64(blk[i]); lo.v[2 * i] = (uint32_t)b; lo.v[2 * i + 1] = (uint32_t)(b >> 32);
-    uint64_t c = __builtin_bswap64(blk[4 + i]); hi.v[2 * i] = (uint32_t)c; hi.v[2 * i + 1] = (uint32_t)(c >> 32);
+  for (int k = 0; k < 4; k++) {
+    uint32_t w[4]; rd_chunk16(rd, (uint32_t)k, w);
+    fp &dst = k < 2 ? lo : hi;
+#pragma unroll
+    for (int i = 0; i < 4; i++) dst.v[4 * (k & 1) + i] = w[i];
   }
 }
 // nonce(sk, transcript): returns the nonce in Montgomery form over Fr.  `sk_plain` canonical.
-template <class S> AVRF_DN fp nonce(fp sk_plain, Sha512 t) {
+template <class S, class T> AVRF_DN fp nonce(fp sk_plain, T t) {
   using Fr = typename S::Fr;
-  Sha512 te = t; sha512_byte(te, DS_NONCE_EXPAND); absorb_fp_le(te, sk_plain);
-  fp lo, hi; uint64_t skh[8];
-  squeeze64(te, lo, hi, skh);                       // sk_hash = 64 squeezed bytes = block 0
-  Sha512 tn = t; sha512_byte(tn, DS_NONCE);
-#pragma unroll
-  for (int i = 0; i < 8; i++) {                     // absorb the 64 bytes of sk_hash in order
-    uint64_t w = skh[i];
-#pragma unroll
-    for (int k = 0; k < 8; k++) sha512_byte(tn, (uint8_t)(w >> (56 - 8 * k)));
-  }
-  uint64_t blk[8]; squeeze64(tn, lo, hi, blk);
+  T te = t; tr_byte(te, DS_NONCE_EXPAND); absorb_fp_le(te, sk_plain);
+  fp lo, hi;
+  squeeze64(te, lo, hi);                            // sk_hash = 64 squeezed bytes
+  T tn = t; tr_byte(tn, DS_NONCE);
+  absorb_fp_le(tn, lo); absorb_fp_le(tn, hi);       // absorb the 64 bytes of sk_hash in order
+  squeeze64(tn, lo, hi);
   // nonce_scalar: ceil((bits+128)/8) = 48 bytes for both suites (253 / 251 bits)
   static_assert((Fr::BITS + 128 + 7) / 8 == 48, "nonce length");
 #pragma unroll
@@ -217,7 +225,7 @@ template <class S> AVRF_DI void store_xy(uint8_t *out, const te_aff &a) {
   using Fq = typename S::Fq;
   fp_store_le(out, fp_from_mont<Fq>(a.x)); fp_store_le(out + 32, fp_from_mont<Fq>(a.y));
 }
-template <class S> AVRF_DI void absorb_point_mont(Sha512 &h, const te_aff &a) {
+template <class S, class T> AVRF_DI void absorb_point_mont(T &h, const te_aff &a) {
   using Fq = typename S::Fq;
   absorb_point_xy<S>(h, fp_from_mont<Fq>(a.x), fp_from_mont<Fq>(a.y));
 }

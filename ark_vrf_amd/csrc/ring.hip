@@ -17,6 +17,7 @@
 #include "msm.h"
 #include "pairing.h"
 #include "suite_dispatch.h"
+#include "host_shake128.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -351,39 +352,8 @@ __global__ void k_mont_to_plain(const uint32_t *__restrict__ src, uint32_t *__re
 // ------------------------------------------------------------------------------------------------
 // SHAKE128 + ark-transcript
 
-struct Shake128 {
-  uint64_t s[25]; uint8_t buf[168]; size_t fill = 0;
-  Shake128() { memset(s, 0, sizeof s); }
-  static void keccakf(uint64_t st[25]) {
-    static const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
-      0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL,
-      0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL,
-      0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL,
-      0x8000000080008008ULL};
-    static const int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
-    static const int PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
-    for (int r = 0; r < 24; r++) {
-      uint64_t bc[5];
-      for (int i = 0; i < 5; i++) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
-      for (int i = 0; i < 5; i++) { uint64_t t = bc[(i + 4) % 5] ^ ((bc[(i + 1) % 5] << 1) | (bc[(i + 1) % 5] >> 63)); for (int j = 0; j < 25; j += 5) st[j + i] ^= t; }
-      uint64_t t = st[1];
-      for (int i = 0; i < 24; i++) { int j = PIL[i]; uint64_t b = st[j]; st[j] = (t << ROT[i]) | (t >> (64 - ROT[i])); t = b; }
-      for (int j = 0; j < 25; j += 5) { for (int i = 0; i < 5; i++) bc[i] = st[j + i]; for (int i = 0; i < 5; i++) st[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5]; }
-      st[0] ^= RC[r];
-    }
-  }
-  void absorb_block() { for (int i = 0; i < 21; i++) { uint64_t v; memcpy(&v, buf + 8 * i, 8); s[i] ^= v; } keccakf(s); fill = 0; }
-  void update(const void *d, size_t n) { const uint8_t *p = (const uint8_t *)d; while (n) { size_t k = 168 - fill; if (k > n) k = n; memcpy(buf + fill, p, k); fill += k; p += k; n -= k; if (fill == 168) absorb_block(); } }
-  // squeeze the first `n` bytes of the XOF output of a COPY of the state (the transcript continues)
-  void squeeze_copy(uint8_t *out, size_t n) const {
-    Shake128 c = *this;
-    memset(c.buf + c.fill, 0, 168 - c.fill); c.buf[c.fill] ^= 0x1f; c.buf[167] ^= 0x80; c.absorb_block();
-    while (n) { size_t k = n < 168 ? n : 168; memcpy(out, c.s, k); out += k; n -= k; if (n) keccakf(c.s); }
-  }
-};
-
 struct ArkTranscript {
-  Shake128 h; bool has_len = false; uint32_t len = 0;
+  HostShake128 h; bool has_len = false; uint32_t len = 0;
   void write(const void *d, size_t n) { h.update(d, n); len = (has_len ? len : 0) + (uint32_t)n; has_len = true; }
   void separate() { if (has_len) { uint8_t b[4] = {(uint8_t)(len >> 24), (uint8_t)(len >> 16), (uint8_t)(len >> 8), (uint8_t)len}; h.update(b, 4); has_len = false; } }
   void label(const char *l) { separate(); write(l, strlen(l)); separate(); }
@@ -1298,7 +1268,7 @@ template <class S, class G> struct Ring {
     (void)clen;
     // randomisers: SHAKE128 over everything the batch contains
     // (the statement is bound in full: sizes, the verifier key, which ring every proof is checked against)
-    Shake128 rh; rh.update("avrf-ring-batch", 15);
+    HostShake128 rh; rh.update("avrf-ring-batch", 15);
     { uint64_t hdr[3] = {(uint64_t)n, (uint64_t)n_rings, (uint64_t)N}; rh.update(hdr, sizeof hdr); }
     rh.update(su->g1_0.xy, 2 * FQB); rh.update(su->g2_raw.data(), su->g2_raw.size());
     for (size_t i = 0; i < n; i++) { uint32_t ri = ring_of_item ? ring_of_item[i] : 0; rh.update(&ri, 4); }
@@ -1480,10 +1450,11 @@ template <class S, class G> struct Ring {
 using RingB = Ring<SuiteBandersnatch, G1Bls12381>;
 using RingJ = Ring<SuiteBabyJubJub, G1Bn254>;
 using RingK = Ring<SuiteJubJub, G1Bls12381>;        // JubJub-SHA512-TAI over BLS12-381 (src/suites/jubjub.rs:76-95)
+using RingX = Ring<SuiteBandersnatchShake, G1Bls12381>;   // Bandersnatch with the SHAKE128 transcript (src/suites/bandersnatch_shake128.rs)
 using RingW = Ring<SuiteBandersnatchSW, G1Bls12381>;   // Bandersnatch-SW: the ring proof runs on the TEMapping of the keys (src/ring.rs:75-81)
 template <class R> struct RingTag { using type = R; };
 template <class F> static auto with_ring(int suite, F &&f) {
-  switch (suite) { case 1: return f(RingTag<RingJ>{}); case 2: return f(RingTag<RingK>{}); case 4: return f(RingTag<RingW>{}); default: return f(RingTag<RingB>{}); }
+  switch (suite) { case 1: return f(RingTag<RingJ>{}); case 2: return f(RingTag<RingK>{}); case 4: return f(RingTag<RingW>{}); case 5: return f(RingTag<RingX>{}); default: return f(RingTag<RingB>{}); }
 }
 
 }  // namespace

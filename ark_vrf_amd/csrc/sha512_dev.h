@@ -159,4 +159,24 @@ AVRF_DI void digest_le128(const uint64_t (&dg)[8], int off16, uint32_t (&w)[4]) 
   w[0] = (uint32_t)b0; w[1] = (uint32_t)(b0 >> 32); w[2] = (uint32_t)b1; w[3] = (uint32_t)(b1 >> 32);
 }
 
+// ---- the transcript interface shared with shake_dev.h (XofTranscript<H>, src/utils/transcript.rs:103-195): kernels are
+// generic over the state type T (Sha512 = HashTranscript<Sha512>, Shake128 = Shake128Transcript) through
+//   tr_init(T&), tr_byte(T&, b)                      absorb
+//   tr_reader(const T&) -> reader R                  finalise a COPY into its squeeze reader (the transcript continues)
+//   rd_chunk16(R&, i, w[4])                          bytes [16 i, 16 i + 16) of the squeeze stream, read forward
+AVRF_DI void tr_init(Sha512 &s) { sha512_init(s); }
+AVRF_DI void tr_byte(Sha512 &s, uint8_t b) { sha512_byte(s, b); }
+struct ShaReader { uint64_t seed[8]; uint64_t blk[8]; uint32_t have; };   // DigestXof: block i = H(seed || LE64(i)); `have` = cached block + 1
+AVRF_DI ShaReader tr_reader(const Sha512 &s) { ShaReader r; sha512_final(s, r.seed); r.have = 0; return r; }
+AVRF_DI void rd_chunk16(ShaReader &r, uint32_t i, uint32_t (&w)[4]) {
+  if (r.have != (i >> 2) + 1) { sha512_xof_block(r.seed, i >> 2, r.blk); r.have = (i >> 2) + 1; }
+  digest_le128(r.blk, (int)(i & 3), w);
+}
+template <class T> AVRF_DI void tr_bytes(T &s, const uint8_t *p, uint32_t n) { for (uint32_t i = 0; i < n; i++) tr_byte(s, p[i]); }
+template <class T> AVRF_DI void tr_u32le(T &s, uint32_t v) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) tr_byte(s, (uint8_t)(v >> (8 * i)));
+}
+template <class T> AVRF_DI void tr_u64le(T &s, uint64_t v) { tr_u32le(s, (uint32_t)v); tr_u32le(s, (uint32_t)(v >> 32)); }
+
 }  // namespace avrf

@@ -22,10 +22,10 @@ k_thin_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint32_t *__restrict__ 
   uint32_t io0 = b.io_off[j], io1 = b.io_off[j + 1], m = io1 - io0;
   uint32_t ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
   uint32_t f = 0;
-  Sha512 h; sha512_init(h);
-  for (int i = 0; i < S::SUITE_ID_LEN; i++) sha512_byte(h, S::SUITE_ID[i]);   // Transcript::new(SUITE_ID)
-  sha512_byte(h, DS_THIN);                                                     // common.rs:166
-  sha512_u64le(h, (uint64_t)m + 1);                                            // absorb_ios :377-383, Schnorr pair first
+  suite_tr<S> h; tr_init(h);
+  for (int i = 0; i < S::SUITE_ID_LEN; i++) tr_byte(h, S::SUITE_ID[i]);       // Transcript::new(SUITE_ID)
+  tr_byte(h, DS_THIN);                                                         // common.rs:166
+  tr_u64le(h, (uint64_t)m + 1);                                                // absorb_ios :377-383, Schnorr pair first
   absorb_generator<S>(h);                                                    // chain_ios :231-240: (G, pk)
   // short-Weierstrass presentation, one pair (the common shape): the 33-byte forms of pk, I, O and R with ONE inversion
   sw_enc enc[4]; bool have_enc = false;
@@ -47,15 +47,12 @@ k_thin_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint32_t *__restrict__ 
     x = fp_load_le(p + 64); y = fp_load_le(p + 96);
     f |= point_flags<S>(x, y); if (have_enc) absorb_sw_enc(h, enc[2]); else absorb_point_xy<S>(h, x, y);
   }
-  sha512_u64le(h, (uint64_t)adl);                                              // common.rs:169-170
-  sha512_bytes(h, b.ads + ad0, adl);
-  uint64_t seed[8], blk[8];
+  tr_u64le(h, (uint64_t)adl);                                                  // common.rs:169-170
+  tr_bytes(h, b.ads + ad0, adl);
   if (m) {                                                                     // DelinearizeScalars :345-363
-    Sha512 hd = h; sha512_byte(hd, DS_DELINEARIZE);
-    sha512_final(hd, seed);
+    auto rd = delin_seed(h);
     for (uint32_t i = 0; i < m; i++) {
-      if ((i & 3) == 0) sha512_xof_block(seed, i >> 2, blk);
-      uint32_t w[4]; digest_le128(blk, i & 3, w);
+      uint32_t w[4]; rd_chunk16(rd, i, w);
       uint4 *o = reinterpret_cast<uint4 *>(z_out + 4 * (size_t)(io0 + i));
       *o = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -65,11 +62,10 @@ k_thin_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint32_t *__restrict__ 
     fp x = fp_load_le(pr), y = fp_load_le(pr + 32), s = fp_load_le(pr + 64);
     if (point_flags<S>(x, y) & FLAG_RANGE) f |= FLAG_RANGE;                    // R may be the identity (thin.rs:95-99)
     if (ge_p<Fr>(s)) f |= FLAG_SCALAR;
-    sha512_byte(h, DS_CHALLENGE);
+    tr_byte(h, DS_CHALLENGE);
     if (have_enc) absorb_sw_enc(h, enc[3]); else absorb_point_xy<S>(h, x, y);
-    sha512_final(h, seed);
-    sha512_xof_block(seed, 0, blk);
-    uint32_t w[4]; digest_le128(blk, 0, w);
+    auto rd = tr_reader(h);
+    uint32_t w[4]; rd_chunk16(rd, 0, w);
     uint4 *o = reinterpret_cast<uint4 *>(c_out + 4 * (size_t)j);
     *o = make_uint4(w[0], w[1], w[2], w[3]);
   }
@@ -100,8 +96,9 @@ k_thin_terms(BatchDev b, Seed64 seed, uint64_t j0, const uint32_t *__restrict__ 
     // w_j = challenge_scalar(&mut t): 16 bytes of the weight stream (thin.rs:289, common.rs:72-76)
     // (j0 = global index of this shard's first item when one batch is split over several GPUs)
     uint64_t gj = j0 + j;
-    uint64_t blk[8]; sha512_xof_block(seed.w, gj >> 2, blk);
-    uint32_t ww[4]; digest_le128(blk, (int)(gj & 3), ww);
+    uint32_t ww[4];
+    if (b.weights) { const uint4 v = *reinterpret_cast<const uint4 *>(b.weights + 16 * (size_t)j); ww[0] = v.x; ww[1] = v.y; ww[2] = v.z; ww[3] = v.w; }
+    else { uint64_t blk[8]; sha512_xof_block(seed.w, gj >> 2, blk); digest_le128(blk, (int)(gj & 3), ww); }
     fp w_plain = fp_zero(); w_plain.v[0] = ww[0]; w_plain.v[1] = ww[1]; w_plain.v[2] = ww[2]; w_plain.v[3] = ww[3];
     fp w = fp_to_mont<Fr>(w_plain);
     fp c = fp_to_mont<Fr>(fp_from_u128(c_in + 4 * (size_t)j));
@@ -166,7 +163,7 @@ k_ped_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint8_t *__restrict__ me
   if (j >= b.n) return;
   uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
   const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pr = b.proofs + 256 * (size_t)j;
-  Sha512 t; uint32_t f = 0;
+  suite_tr<S> t; uint32_t f = 0;
   tr_base<S>(t, DS_PEDERSEN, false, nullptr, ios, m, b.ads + ad0, adl, &f);   // io identity -> io_identity flag (:278)
   uint8_t *mo = merged_xy + 128 * (size_t)j;
   if (m == 1) {
@@ -177,7 +174,7 @@ k_ped_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint8_t *__restrict__ me
     fp zero = fp_zero(), one = fp_zero(); one.v[0] = 1;
     fp_store_le(mo, zero); fp_store_le(mo + 32, one); fp_store_le(mo + 64, zero); fp_store_le(mo + 96, one);
   } else {                                                                     // merge_ios, common.rs:389-419
-    uint64_t dseed[8]; delin_seed(t, dseed);
+    auto dseed = delin_seed(t);
     te_ext im = te_identity<S>(), om = te_identity<S>();
     for (uint32_t i = 0; i < m; i++) {
       te_pre pi = pre_from_xy<S>(ios + 128 * (size_t)i), po = pre_from_xy<S>(ios + 128 * (size_t)i + 64);
@@ -195,10 +192,10 @@ k_ped_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint8_t *__restrict__ me
   if constexpr (S::SW_CODEC) {                                                 // the three proof points' 33-byte forms, one inversion
     const fp xs[3] = {ybx, rx, okx}, ys[3] = {yby, ry, oky};
     sw_enc enc[3]; sw_encode_te_many<S, 3>(xs, ys, enc);
-    absorb_sw_enc(t, enc[0]); sha512_byte(t, DS_CHALLENGE); absorb_sw_enc(t, enc[1]); absorb_sw_enc(t, enc[2]);
+    absorb_sw_enc(t, enc[0]); tr_byte(t, DS_CHALLENGE); absorb_sw_enc(t, enc[1]); absorb_sw_enc(t, enc[2]);
   } else {
     absorb_point_xy<S>(t, ybx, yby);                                           // :280
-    sha512_byte(t, DS_CHALLENGE); absorb_point_xy<S>(t, rx, ry); absorb_point_xy<S>(t, okx, oky);
+    tr_byte(t, DS_CHALLENGE); absorb_point_xy<S>(t, rx, ry); absorb_point_xy<S>(t, okx, oky);
   }
   fp c = challenge_finish(t);                                                  // :281
   *reinterpret_cast<uint4 *>(c_out + 4 * (size_t)j) = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
@@ -217,7 +214,12 @@ k_ped_terms(BatchDev b, Seed64 seed, uint64_t j0, const uint32_t *__restrict__ c
   if (j < b.n) {
     // 32 squeezed bytes per item: t = bytes[0..16], u = bytes[16..32]   (:373-381)
     // (j0: global index of the shard's first item when one batch is split over several GPUs)
-    fp t_plain = xof128(seed.w, 2 * (j0 + j)), u_plain = xof128(seed.w, 2 * (j0 + j) + 1);
+    fp t_plain, u_plain;
+    if (b.weights) { t_plain = fp_from_u128(reinterpret_cast<const uint32_t *>(b.weights + 32 * (size_t)j)); u_plain = fp_from_u128(reinterpret_cast<const uint32_t *>(b.weights + 32 * (size_t)j + 16)); }
+    else {
+      ShaReader rd; for (int i = 0; i < 8; i++) rd.seed[i] = seed.w[i]; rd.have = 0;
+      t_plain = xof128(rd, (uint32_t)(2 * (j0 + j))); u_plain = xof128(rd, (uint32_t)(2 * (j0 + j) + 1));
+    }
     fp tt = fp_to_mont<Fr>(t_plain), uu = fp_to_mont<Fr>(u_plain);
     fp c = fp_to_mont<Fr>(fp_from_u128(c_in + 4 * (size_t)j));
     const uint8_t *pr = b.proofs + 256 * (size_t)j, *mo = merged_xy + 128 * (size_t)j;

@@ -20,8 +20,8 @@ namespace avrf {
 // (I_m, O_m) = sum_i z_i * (I_i, O_i) over `m` caller pairs; z stream from `dseed`.
 // first_is_one: the first caller pair takes z = 1 (Pedersen); otherwise pair i takes chunk i (Thin,
 // whose z_0 = 1 belongs to the Schnorr pair handled by the caller).
-template <class S>
-AVRF_DI void merge_pairs(const uint8_t *ios_xy, uint32_t m, const uint64_t (&dseed)[8], bool first_is_one,
+template <class S, class R>
+AVRF_DI void merge_pairs(const uint8_t *ios_xy, uint32_t m, R &dseed, bool first_is_one,
                          te_ext &im, te_ext &om) {
   for (uint32_t i = 0; i < m; i++) {
     te_pre pi = pre_from_xy<S>(ios_xy + 128 * (size_t)i), po = pre_from_xy<S>(ios_xy + 128 * (size_t)i + 64);
@@ -87,11 +87,11 @@ k_smul(const uint8_t *__restrict__ scalars, const uint8_t *__restrict__ points_x
 // table and no merged pair has to be normalised: 253 + 128 doublings instead of 2 x 128 + 253 and an inversion.  More pairs:
 // merge first (one 128-bit multiplication per point), then the two-point form.  Any order gives the same group element.
 template <class S>
-AVRF_DI te_ext schnorr_lhs(const BatchDev &b, const uint8_t *ios, const uint8_t *pk_xy, uint32_t m, const Sha512 &t, const fp &s, const fp &c) {
+AVRF_DI te_ext schnorr_lhs(const BatchDev &b, const uint8_t *ios, const uint8_t *pk_xy, uint32_t m, const suite_tr<S> &t, const fp &s, const fp &c) {
   using Fr = typename S::Fr;
   te_pre op = pre_from_xy<S>(pk_xy);
   if (m == 0) return te_add<S>(te_smul_fixed<S>(b.fixed, FIXED_G, s), te_smul<S>(te_pre_neg<S>(op), c, 128));
-  uint64_t dseed[8]; delin_seed(t, dseed);
+  auto dseed = delin_seed(t);
   if (m == 1) {
     const fp z = xof128(dseed, 0);
     const fp sz = fp_mul<Fr>(fp_to_mont<Fr>(s), z), cz = fp_mul<Fr>(fp_to_mont<Fr>(c), z);   // plain products mod r
@@ -119,11 +119,11 @@ k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict_
   fp sk = fp_load_le(b.sks + 32 * (size_t)j);
   uint32_t f = ge_p<Fr>(sk) ? FLAG_SCALAR : 0;
   // public key: cached by Secret in the reference (src/lib.rs:331-334)
-  uint8_t pk_xy[64];
-  if (b.pks_xy) { for (int i = 0; i < 64; i++) pk_xy[i] = b.pks_xy[64 * (size_t)j + i]; }
-  else { te_aff pk = te_to_aff<S>(te_smul<S>(g_pre<S>(), sk, Fr::BITS)); store_xy<S>(pk_xy, pk); }
-  Sha512 t; uint32_t pf = 0;
-  tr_base<S>(t, TINY ? DS_TINY : DS_THIN, true, pk_xy, ios, m, b.ads + ad0, adl, &pf);   // thin.rs:112, tiny.rs:164
+  fp pkx, pky;                                                                  // canonical coordinates of the public key
+  if (b.pks_xy) { pkx = fp_load_le(b.pks_xy + 64 * (size_t)j); pky = fp_load_le(b.pks_xy + 64 * (size_t)j + 32); }
+  else { using Fq = typename S::Fq; te_aff pk = te_to_aff<S>(te_smul_fixed<S>(b.fixed, FIXED_G, sk)); pkx = fp_from_mont<Fq>(pk.x); pky = fp_from_mont<Fq>(pk.y); }
+  suite_tr<S> t; uint32_t pf = 0;
+  tr_base<S>(t, TINY ? DS_TINY : DS_THIN, true, pkx, pky, ios, m, b.ads + ad0, adl, &pf);   // thin.rs:112, tiny.rs:164
   f |= pf & FLAG_RANGE;
   // R = k I_m with the merged input I_m = G + sum z_i I_i (only the input is needed by the prover; thin.rs:115-119).
   // No pair: k G from the fixed-base table.  One pair: k G + (k z) I -- table + ONE 253-bit multiplication, nothing to merge or
@@ -134,12 +134,12 @@ k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict_
   if (m <= 1) {
     rr = te_smul_fixed<S>(b.fixed, FIXED_G, k_plain);
     if (m) {
-      uint64_t dseed[8]; delin_seed(t, dseed);
+      auto dseed = delin_seed(t);
       const fp kz = fp_mul<Fr>(k, xof128(dseed, 0));                            // Montgomery k times plain z: plain k z mod r
       rr = te_add<S>(rr, te_smul_glv<S>(pre_from_xy<S>(ios), kz));
     }
   } else {
-    uint64_t dseed[8]; delin_seed(t, dseed);
+    auto dseed = delin_seed(t);
     te_ext im = te_from_pre<S>(g_pre<S>());
     for (uint32_t i = 0; i < m; i++) {
       te_pre pi = pre_from_xy<S>(ios + 128 * (size_t)i);
@@ -148,7 +148,7 @@ k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict_
     rr = te_smul_glv<S>(pre_from_aff<S>(te_to_aff<S>(im)), k_plain);
   }
   te_aff r = te_to_aff<S>(rr);                                                  // thin.rs:119
-  Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);    // thin.rs:122
+  suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);    // thin.rs:122
   fp c = fp_to_mont<Fr>(challenge_finish(tc));
   fp s = fp_add<Fr>(k, fp_mul<Fr>(c, fp_to_mont<Fr>(sk)));                      // thin.rs:125
   if (TINY) {
@@ -172,7 +172,7 @@ k_tiny_verify(BatchDev b, int32_t *__restrict__ status) {
   if (j >= b.n) return;
   uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
   const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pk_xy = b.pks_xy + 64 * (size_t)j, *pr = b.proofs + 48 * (size_t)j;
-  Sha512 t; uint32_t f = 0;
+  suite_tr<S> t; uint32_t f = 0;
   tr_base<S>(t, DS_TINY, true, pk_xy, ios, m, b.ads + ad0, adl, &f);
   fp c = fp_zero();
   for (int i = 0; i < 4; i++) c.v[i] = (uint32_t)pr[4 * i] | ((uint32_t)pr[4 * i + 1] << 8) | ((uint32_t)pr[4 * i + 2] << 16) | ((uint32_t)pr[4 * i + 3] << 24);
@@ -180,7 +180,7 @@ k_tiny_verify(BatchDev b, int32_t *__restrict__ status) {
   if (ge_p<Fr>(s)) f |= FLAG_SCALAR;
   if (f) { status[j] = 2; return; }                                             // InvalidData, tiny.rs:186-198
   te_aff r = te_to_aff<S>(schnorr_lhs<S>(b, ios, pk_xy, m, t, s, c));            // tiny.rs:207
-  Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);
+  suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);
   const fp c_exp = challenge_finish(tc);                                        // plain, 128 bits
   status[j] = fp_eq(c_exp, c) ? 0 : 1;
 }
@@ -193,13 +193,13 @@ k_thin_verify(BatchDev b, int32_t *__restrict__ status) {
   if (j >= b.n) return;
   uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
   const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pk_xy = b.pks_xy + 64 * (size_t)j, *pr = b.proofs + 96 * (size_t)j;
-  Sha512 t; uint32_t f = 0;
+  suite_tr<S> t; uint32_t f = 0;
   tr_base<S>(t, DS_THIN, true, pk_xy, ios, m, b.ads + ad0, adl, &f);
   fp rx = fp_load_le(pr), ry = fp_load_le(pr + 32), s = fp_load_le(pr + 64);
   if (point_flags<S>(rx, ry) & FLAG_RANGE) f |= FLAG_RANGE;
   if (ge_p<Fr>(s)) f |= FLAG_SCALAR;
   if (f) { status[j] = 2; return; }                                             // InvalidData, thin.rs:140-149
-  Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_xy<S>(tc, rx, ry);
+  suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_xy<S>(tc, rx, ry);
   fp c = challenge_finish(tc);                                                  // plain, 128 bits
   // s*I_m - c*O_m == R   (thin.rs:158-161)
   te_ext lhs = schnorr_lhs<S>(b, ios, pk_xy, m, t, s, c);
@@ -219,14 +219,14 @@ k_ped_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ 
   const uint8_t *ios = b.ios_xy + 128 * (size_t)io0;
   fp sk = fp_load_le(b.sks + 32 * (size_t)j);
   uint32_t f = ge_p<Fr>(sk) ? FLAG_SCALAR : 0, pf = 0;
-  Sha512 t;
+  suite_tr<S> t;
   tr_base<S>(t, DS_PEDERSEN, false, nullptr, ios, m, b.ads + ad0, adl, &pf);   // pedersen.rs:142
   f |= pf & FLAG_RANGE;
   // merged input (common.rs:186-199): identity for m = 0, the pair itself for m = 1
   te_pre ip; bool have_input = m > 0;
   if (m == 1) ip = pre_from_xy<S>(ios);
   else if (m > 1) {
-    uint64_t dseed[8]; delin_seed(t, dseed);
+    auto dseed = delin_seed(t);
     te_ext im = te_identity<S>(), om = te_identity<S>();
     for (uint32_t i = 0; i < m; i++) {
       te_pre pi = pre_from_xy<S>(ios + 128 * (size_t)i);
@@ -235,7 +235,7 @@ k_ped_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ 
     (void)om;
     ip = pre_from_aff<S>(te_to_aff<S>(im));
   }
-  Sha512 tb = t; sha512_byte(tb, DS_PEDERSEN_BLINDING);
+  suite_tr<S> tb = t; tr_byte(tb, DS_PEDERSEN_BLINDING);
   fp bl = nonce<S>(sk, tb);                                                     // pedersen.rs:51-54,145
   fp bl_plain = fp_from_mont<Fr>(bl);
   te_pre pkp;
@@ -248,7 +248,7 @@ k_ped_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ 
   te_ext R = te_add<S>(te_smul_fixed<S>(b.fixed, FIXED_G, k_plain), te_smul_fixed<S>(b.fixed, FIXED_B, fp_from_mont<Fr>(kb)));   // :159-161
   te_ext OK = have_input ? te_smul_glv<S>(ip, k_plain) : te_identity<S>();                   // :164
   te_aff ra, oka; to_aff2<S>(R, OK, ra, oka);                                   // :166-167
-  Sha512 tc = t; sha512_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, ra); absorb_point_mont<S>(tc, oka);
+  suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, ra); absorb_point_mont<S>(tc, oka);
   fp c = fp_to_mont<Fr>(challenge_finish(tc));                                  // :170
   fp s = fp_add<Fr>(k, fp_mul<Fr>(c, fp_to_mont<Fr>(sk)));                      // :173
   fp sb = fp_add<Fr>(kb, fp_mul<Fr>(c, bl));                                    // :175
@@ -267,7 +267,7 @@ k_ped_verify(BatchDev b, int32_t *__restrict__ status) {
   if (j >= b.n) return;
   uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
   const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pr = b.proofs + 256 * (size_t)j;
-  Sha512 t; uint32_t f = 0;
+  suite_tr<S> t; uint32_t f = 0;
   tr_base<S>(t, DS_PEDERSEN, false, nullptr, ios, m, b.ads + ad0, adl, &f);
   fp ybx = fp_load_le(pr), yby = fp_load_le(pr + 32), rx = fp_load_le(pr + 64), ry = fp_load_le(pr + 96);
   fp okx = fp_load_le(pr + 128), oky = fp_load_le(pr + 160), s = fp_load_le(pr + 192), sb = fp_load_le(pr + 224);
@@ -278,7 +278,7 @@ k_ped_verify(BatchDev b, int32_t *__restrict__ status) {
   te_pre ip, op; bool have_io = m > 0;
   if (m == 1) { ip = pre_from_xy<S>(ios); op = pre_from_xy<S>(ios + 64); }
   else if (m > 1) {
-    uint64_t dseed[8]; delin_seed(t, dseed);
+    auto dseed = delin_seed(t);
     te_ext im = te_identity<S>(), om = te_identity<S>();
     merge_pairs<S>(ios, m, dseed, true, im, om);
     te_aff ia, oa; to_aff2<S>(im, om, ia, oa);
@@ -287,10 +287,10 @@ k_ped_verify(BatchDev b, int32_t *__restrict__ status) {
   if constexpr (S::SW_CODEC) {                                                 // three 33-byte SW forms, one inversion
     const fp xs[3] = {ybx, rx, okx}, ys[3] = {yby, ry, oky};
     sw_enc enc[3]; sw_encode_te_many<S, 3>(xs, ys, enc);
-    absorb_sw_enc(t, enc[0]); sha512_byte(t, DS_CHALLENGE); absorb_sw_enc(t, enc[1]); absorb_sw_enc(t, enc[2]);
+    absorb_sw_enc(t, enc[0]); tr_byte(t, DS_CHALLENGE); absorb_sw_enc(t, enc[1]); absorb_sw_enc(t, enc[2]);
   } else {
     absorb_point_xy<S>(t, ybx, yby);                                           // :219
-    sha512_byte(t, DS_CHALLENGE); absorb_point_xy<S>(t, rx, ry); absorb_point_xy<S>(t, okx, oky);
+    tr_byte(t, DS_CHALLENGE); absorb_point_xy<S>(t, rx, ry); absorb_point_xy<S>(t, okx, oky);
   }
   fp c = challenge_finish(t);                                                  // :222
   // Eq1: s*I - c*O == Ok   (:229-232)
@@ -360,7 +360,27 @@ k_hash_to_curve(const uint8_t *__restrict__ data, const uint32_t *__restrict__ o
   const uint8_t *msg = data + off[j]; const uint32_t len = off[j + 1] - off[j];
   constexpr uint8_t DS_H2C = 0x60;
   te_ext acc; bool ok = false;
-  if (S::H2C_ELL2) {
+  if constexpr (S::H2C_ELL2 && S::XOF_SHAKE) {
+    // XofFieldHasher (src/utils/hash_to_curve.rs:103-150), RFC 9380 expand_message_xof with SHAKE128:
+    // uniform = SHAKE128(msg || I2OSP(96, 2) || DST || I2OSP(len(DST), 1))[0..96], DST = suite id || 0x60;
+    // two field elements of 48 big-endian bytes each
+    Shake128 h; tr_init(h);
+    tr_bytes(h, msg, len);
+    tr_byte(h, 0); tr_byte(h, 96);
+    for (int i = 0; i < S::SUITE_ID_LEN; i++) tr_byte(h, S::SUITE_ID[i]);
+    tr_byte(h, DS_H2C); tr_byte(h, (uint8_t)(S::SUITE_ID_LEN + 1));
+    ShakeReader rd = tr_reader(h);
+    uint64_t w[12];
+    for (int i = 0; i < 12; i++) w[i] = __builtin_bswap64(rd_word(rd, (uint32_t)i));   // stream bytes as big-endian words
+    uint64_t w0[6] = {w[0], w[1], w[2], w[3], w[4], w[5]}, w1[6] = {w[6], w[7], w[8], w[9], w[10], w[11]};
+    fp lo, hi;
+    be384_split(w0, lo, hi); fp u0 = fp_from_wide_mont<Fq>(lo, hi);
+    be384_split(w1, lo, hi); fp u1 = fp_from_wide_mont<Fq>(lo, hi);
+    te_aff q0 = ell2_map<S>(u0), q1 = ell2_map<S>(u1);
+    acc = te_madd<S>(te_from_pre<S>(te_make_pre<S>(q0.x, q0.y)), te_make_pre<S>(q1.x, q1.y));
+    for (int c = S::COFACTOR; c > 1; c >>= 1) acc = te_dbl<S>(acc);
+    ok = true;
+  } else if (S::H2C_ELL2) {
     // RFC 9380 expand_message_xmd(SHA-512) as instantiated by ark-ff's DefaultFieldHasher: Z_pad = 48 zero bytes,
     // DST = suite id || 0x60, 96 uniform bytes -> two field elements of 48 big-endian bytes each
     Sha512 h; uint64_t b0[8], b1[8], b2[8];
@@ -384,15 +404,15 @@ k_hash_to_curve(const uint8_t *__restrict__ data, const uint32_t *__restrict__ o
   } else {
     // try-and-increment (src/utils/hash_to_curve.rs:34-57): transcript(suite id, 0x60, LE64(len), data, ctr) -> 32 bytes
     // -> Affine::from_random_bytes (top bit = sign of x, bits above the modulus size cleared)
-    Sha512 pre; sha512_init(pre);
-    for (int i = 0; i < S::SUITE_ID_LEN; i++) sha512_byte(pre, S::SUITE_ID[i]);
-    sha512_byte(pre, DS_H2C); sha512_u64le(pre, (uint64_t)len); sha512_bytes(pre, msg, len);
+    suite_tr<S> pre; tr_init(pre);
+    for (int i = 0; i < S::SUITE_ID_LEN; i++) tr_byte(pre, S::SUITE_ID[i]);
+    tr_byte(pre, DS_H2C); tr_u64le(pre, (uint64_t)len); tr_bytes(pre, msg, len);
     for (int ctr = 0; ctr <= 255 && !ok; ctr++) {
-      Sha512 t = pre; sha512_byte(t, (uint8_t)ctr);
-      uint64_t seed[8], blk[8]; sha512_final(t, seed); sha512_xof_block(seed, 0, blk);
+      suite_tr<S> t = pre; tr_byte(t, (uint8_t)ctr);
+      auto rd = tr_reader(t);
       fp y; uint32_t w4[4];
-      digest_le128(blk, 0, w4); for (int i = 0; i < 4; i++) y.v[i] = w4[i];
-      digest_le128(blk, 1, w4); for (int i = 0; i < 4; i++) y.v[4 + i] = w4[i];
+      rd_chunk16(rd, 0, w4); for (int i = 0; i < 4; i++) y.v[i] = w4[i];
+      rd_chunk16(rd, 1, w4); for (int i = 0; i < 4; i++) y.v[4 + i] = w4[i];
       const bool neg = (y.v[7] >> 31) != 0;
       y.v[7] &= 0xffffffffu >> (256 - Fq::BITS);
       if (ge_p<Fq>(y)) continue;

@@ -47,7 +47,7 @@ typedef struct {
 typedef struct { u256 x, y; } te_aff;        /* Montgomery-form coordinates */
 typedef struct { u256 x, y, t, z; } te_ext;  /* extended twisted Edwards */
 
-enum { ORC_SUITE_BANDERSNATCH = 0, ORC_SUITE_BABYJUBJUB = 1, ORC_SUITE_JUBJUB = 2, ORC_SUITE_ED25519 = 3, ORC_SUITE_BANDERSNATCH_SW = 4 };
+enum { ORC_SUITE_BANDERSNATCH = 0, ORC_SUITE_BABYJUBJUB = 1, ORC_SUITE_JUBJUB = 2, ORC_SUITE_ED25519 = 3, ORC_SUITE_BANDERSNATCH_SW = 4, ORC_SUITE_BANDERSNATCH_SHAKE128 = 5 };
 enum { ORC_H2C_ELL2 = 0, ORC_H2C_TAI = 1, ORC_H2C_TAI_SW = 2 };
 
 typedef struct {
@@ -69,6 +69,7 @@ typedef struct {
     /* short-Weierstrass presentation of the same curve (src/suites/bandersnatch_sw.rs, src/utils/te_sw_map.rs): the suite's
      * Affine type is SWAffine, so every point that is serialised -- into a transcript, a proof, a hash -- takes the 33-byte
      * ark-serialize SW form; the group arithmetic stays in the twisted-Edwards model through the maps. */
+    int xof_shake;          /* Suite::Transcript = Shake128Transcript (src/suites/bandersnatch_shake128.rs) */
     int sw_codec;
     u256 mont_b, mont_a3, mont_binv, sw_a, sw_b;   /* Montgomery-model B, A/3, 1/B; SW coefficients; all in Montgomery form */
 } suite_t;
@@ -109,8 +110,12 @@ void sha512_final(const sha512_t *c, uint8_t out[64]); /* does not mutate c */
 typedef struct {
     sha512_t h; int squeezing;
     uint8_t seed[64], block[64]; uint64_t counter; size_t off;
+    /* XofTranscript<Shake128> (src/utils/transcript.rs:292-293; suites with xof_shake): the sponge itself */
+    int shake; uint64_t ks[25]; size_t kpos;
 } transcript_t;
-void tr_new(transcript_t *t, const void *label, size_t n);
+void tr_new(transcript_t *t, const void *label, size_t n);                  /* HashTranscript<Sha512> */
+void tr_new_mode(transcript_t *t, const void *label, size_t n, int shake);  /* shake != 0: Shake128Transcript */
+void shake128(uint8_t *out, size_t out_len, const uint8_t *const *parts, const size_t *lens, int n_parts);   /* one-shot XOF */
 void tr_absorb(transcript_t *t, const void *d, size_t n);
 void tr_squeeze(transcript_t *t, void *out, size_t n);
 

@@ -93,12 +93,62 @@ void sha512_final(const sha512_t *cc, uint8_t out[64]) {
 }
 
 /* ---- HashTranscript<Sha512> ---- */
+/* ---- Keccak-f[1600] / SHAKE128 (FIPS 202): rate 168 bytes, domain suffix 0x1f, final bit 0x80 ---- */
+static const uint64_t KRC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL, 0x0000000080000001ULL,
+    0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL,
+    0x000000000000800aULL, 0x800000008000000aULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+static const int KROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+static uint64_t rol64(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+static void keccak_f(uint64_t a[25]) {
+    for (int r = 0; r < 24; r++) {
+        uint64_t c[5], d[5], b[25];
+        for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+        for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rol64(c[(x + 1) % 5], 1);
+        for (int i = 0; i < 25; i++) a[i] ^= d[i % 5];
+        for (int x = 0; x < 5; x++) for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rol64(a[x + 5 * y], KROT[x + 5 * y]);
+        for (int y = 0; y < 5; y++) for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        a[0] ^= KRC[r];
+    }
+}
+#define SHAKE_RATE 168
+static void shake_absorb(uint64_t ks[25], size_t *pos, const uint8_t *d, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        ks[*pos >> 3] ^= (uint64_t)d[i] << (8 * (*pos & 7));
+        if (++*pos == SHAKE_RATE) { keccak_f(ks); *pos = 0; }
+    }
+}
+static void shake_pad(uint64_t ks[25], size_t *pos) {
+    ks[*pos >> 3] ^= (uint64_t)0x1f << (8 * (*pos & 7));
+    ks[(SHAKE_RATE - 1) >> 3] ^= (uint64_t)0x80 << (8 * ((SHAKE_RATE - 1) & 7));
+    keccak_f(ks); *pos = 0;
+}
+static void shake_read(uint64_t ks[25], size_t *pos, uint8_t *o, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        if (*pos == SHAKE_RATE) { keccak_f(ks); *pos = 0; }
+        o[i] = (uint8_t)(ks[*pos >> 3] >> (8 * (*pos & 7))); ++*pos;
+    }
+}
+void shake128(uint8_t *out, size_t out_len, const uint8_t *const *parts, const size_t *lens, int n_parts) {
+    uint64_t ks[25]; size_t pos = 0; memset(ks, 0, sizeof ks);
+    for (int i = 0; i < n_parts; i++) shake_absorb(ks, &pos, parts[i], lens[i]);
+    shake_pad(ks, &pos); shake_read(ks, &pos, out, out_len);
+}
+
+void tr_new_mode(transcript_t *t, const void *label, size_t n, int shake) {
+    tr_new(t, label, n);
+    t->shake = shake;
+    if (shake) { memset(t->ks, 0, sizeof t->ks); t->kpos = 0; shake_absorb(t->ks, &t->kpos, (const uint8_t *)label, n); }
+}
 void tr_new(transcript_t *t, const void *label, size_t n) {
+    t->shake = 0;
     sha512_init(&t->h); t->squeezing = 0; t->counter = 0; t->off = 64;
     sha512_update(&t->h, label, n);
 }
 void tr_absorb(transcript_t *t, const void *d, size_t n) {
     if (t->squeezing) { t->squeezing = 2; return; } /* reference panics (transcript.rs:187) */
+    if (t->shake) { shake_absorb(t->ks, &t->kpos, (const uint8_t *)d, n); return; }
     sha512_update(&t->h, d, n);
 }
 static void tr_block(transcript_t *t) {
@@ -110,6 +160,11 @@ static void tr_block(transcript_t *t) {
 }
 void tr_squeeze(transcript_t *t, void *out, size_t n) {
     uint8_t *o = (uint8_t *)out;
+    if (t->shake) {
+        if (!t->squeezing) { shake_pad(t->ks, &t->kpos); t->squeezing = 1; }
+        shake_read(t->ks, &t->kpos, o, n);
+        return;
+    }
     if (!t->squeezing) { sha512_final(&t->h, t->seed); t->squeezing = 1; t->counter = 0; t->off = 64; }
     while (n) {
         if (t->off >= 64) tr_block(t);

@@ -15,7 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-static suite_t g_suites[5];
+static suite_t g_suites[6];
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;      /* gen_batch() calls in from several threads at once */
 
 static void fq_dec(u256 *o, const char *dec, const mont_t *m) {
@@ -152,11 +152,25 @@ static void init_suites(void) {
             mont_add(&t, &mx, &one, &s->fq); mont_inv(&t, &t, &s->fq); mont_sub(&w, &mx, &one, &s->fq); mont_mul(&dst[i]->y, &w, &t, &s->fq);
         }
     }
+
+    /* ---- Bandersnatch-SHAKE128-ELL2-v1 (src/suites/bandersnatch_shake128.rs): suite 0's curve and Elligator2 map with the
+     * SHAKE128 sponge as the transcript (XofTranscript<Shake128>) and expand_message_xof in hash-to-curve ---- */
+    s = &g_suites[5];
+    *s = g_suites[0];
+    s->id = ORC_SUITE_BANDERSNATCH_SHAKE128;
+    s->suite_id = "Bandersnatch-SHAKE128-ELL2-v1"; s->suite_id_len = 29;
+    s->xof_shake = 1;
+    fq_dec(&s->B.x, "6153734995852631824944342602386415873379775188383988340041079006556670120775", &s->fq);
+    fq_dec(&s->B.y, "27204351599954061630605768787803524395123895650061061132592995395630473050754", &s->fq);
+    fq_dec(&s->ACC.x, "27631238720955528589004064829276283990465032040945349648037876197995278250917", &s->fq);
+    fq_dec(&s->ACC.y, "37605358688136619817560700742505556266961225274493904038881144193539047100140", &s->fq);
+    fq_dec(&s->PAD.x, "1834402953989431481748983728202937234471322740714585873803966488035889514523", &s->fq);
+    fq_dec(&s->PAD.y, "52100941849053769665273763352270294131006971127418863694682093199651869272752", &s->fq);
 }
 
 const suite_t *orc_suite(int id) {
     pthread_once(&g_once, init_suites);
-    if (id < 0 || id > 4) return NULL;
+    if (id < 0 || id > 5) return NULL;
     return &g_suites[id];
 }
 

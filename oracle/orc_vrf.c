@@ -65,7 +65,7 @@ typedef struct { te_aff in, out; } vrf_io;
 /* common.rs:159-173: returns the transcript (ad absorbed) and the delinearisation fork */
 static void transcript_base(transcript_t *t, transcript_t *delin, uint8_t scheme, const vrf_io *ios, size_t n,
                             const uint8_t *ad, size_t ad_len, const suite_t *s) {
-    tr_new(t, s->suite_id, s->suite_id_len);
+    tr_new_mode(t, s->suite_id, s->suite_id_len, s->xof_shake);
     absorb_u8(t, scheme);
     absorb_u64(t, (uint64_t)n);                                    /* absorb_ios :377-383 */
     for (size_t i = 0; i < n; i++) { absorb_point(t, &ios[i].in, s); absorb_point(t, &ios[i].out, s); }
@@ -137,7 +137,7 @@ int orc_from_seed(int suite, const uint8_t seed[32], uint8_t sk_out[32], uint8_t
     u256 sk0, sk; mont_from_le_bytes_mod_order(&sk0, seed, 32, FR);
     for (unsigned cnt = 0;; cnt++) {
         if (cnt > 255) return -1;
-        transcript_t t; tr_new(&t, s->suite_id, s->suite_id_len);
+        transcript_t t; tr_new_mode(&t, s->suite_id, s->suite_id_len, s->xof_shake);
         tr_absorb(&t, seed, 32);
         if (cnt > 0) absorb_u8(&t, (uint8_t)cnt);
         nonce(&sk, &sk0, t, s);
@@ -164,7 +164,7 @@ int orc_vrf_output(int suite, const uint8_t sk[32], const uint8_t input[32], uin
 /* src/utils/common.rs:290-305 (mul_by_cofactor = false, src/lib.rs:247-249) */
 int orc_point_to_hash(int suite, const uint8_t pt[32], uint8_t *out, size_t n) {
     const suite_t *s = orc_suite(suite); if (!s) return -1;
-    transcript_t t; tr_new(&t, s->suite_id, s->suite_id_len);
+    transcript_t t; tr_new_mode(&t, s->suite_id, s->suite_id_len, s->xof_shake);
     absorb_u8(&t, DS_POINT_TO_HASH);
     if (s->sw_codec) { te_aff p; if (te_decode(&p, pt, s)) return ORC_INVALID_DATA; absorb_point(&t, &p, s); }
     else tr_absorb(&t, pt, 32);
@@ -250,7 +250,12 @@ int orc_hash_to_curve(int suite, const uint8_t *data, size_t n, uint8_t out[32])
         uint8_t dst[64]; size_t dl = s->suite_id_len;
         memcpy(dst, s->suite_id, dl); dst[dl++] = DS_HASH_TO_CURVE;
         size_t L = (size_t)(s->fq.bits + 128 + 7) / 8; /* 48 */
-        uint8_t ub[128]; expand_xmd(ub, 2 * L, data, n, dst, dl, L);
+        uint8_t ub[128];
+        if (s->xof_shake) {   /* XofFieldHasher, expand_message_xof (src/utils/hash_to_curve.rs:103-150): H(msg || I2OSP(len, 2) || DST || I2OSP(len(DST), 1)) */
+            uint8_t lib[2] = {(uint8_t)((2 * L) >> 8), (uint8_t)(2 * L)}, dlb = (uint8_t)dl;
+            const uint8_t *parts[4] = {data, lib, dst, &dlb}; size_t lens[4] = {n, 2, dl, 1};
+            shake128(ub, 2 * L, parts, lens, 4);
+        } else expand_xmd(ub, 2 * L, data, n, dst, dl, L);
         u256 u0, u1; mont_from_be_bytes_mod_order(&u0, ub, L, FQ); mont_from_be_bytes_mod_order(&u1, ub + L, L, FQ);
         te_aff q0, q1; ell2_map(&q0, &u0, s); ell2_map(&q1, &u1, s);
         te_ext e0, e1; te_from_aff(&e0, &q0, s); te_from_aff(&e1, &q1, s);
@@ -259,7 +264,7 @@ int orc_hash_to_curve(int suite, const uint8_t *data, size_t n, uint8_t out[32])
         return 0;
     }
     /* TAI */
-    transcript_t prefix; tr_new(&prefix, s->suite_id, s->suite_id_len);
+    transcript_t prefix; tr_new_mode(&prefix, s->suite_id, s->suite_id_len, s->xof_shake);
     absorb_u8(&prefix, DS_HASH_TO_CURVE); absorb_u64(&prefix, (uint64_t)n); tr_absorb(&prefix, data, n);
     for (int ctr = 0; ctr <= 255; ctr++) {
         transcript_t t = prefix; absorb_u8(&t, (uint8_t)ctr);
@@ -422,7 +427,7 @@ int orc_thin_batch_terms(int suite, size_t n, const uint8_t *pks, const uint8_t 
         if (!st && io_has_identity(ios, tot_io, s)) st = ORC_INVALID_DATA;
     }
     if (!st) {
-        transcript_t tw; tr_new(&tw, s->suite_id, s->suite_id_len); absorb_u8(&tw, DS_BATCH_VERIFY); /* :274-279 */
+        transcript_t tw; tr_new_mode(&tw, s->suite_id, s->suite_id_len, s->xof_shake); absorb_u8(&tw, DS_BATCH_VERIFY); /* :274-279 */
         for (size_t j = 0; j < n; j++) { absorb_scalar(&tw, &c[j], s); absorb_scalar(&tw, &sv[j], s); }
         size_t k = 0, io_off = 0, z_off = 0; u256 g = {{0, 0, 0, 0}};
         for (size_t j = 0; j < n; j++) {                           /* :287-313 */
@@ -554,7 +559,7 @@ int orc_pedersen_batch_terms(int suite, size_t n, const uint8_t *ios_b, const ui
         if (any_io_identity) st = ORC_INVALID_DATA;
     }
     if (!st) {
-        transcript_t tw; tr_new(&tw, s->suite_id, s->suite_id_len); absorb_u8(&tw, DS_BATCH_VERIFY); /* :361-367 */
+        transcript_t tw; tr_new_mode(&tw, s->suite_id, s->suite_id_len, s->xof_shake); absorb_u8(&tw, DS_BATCH_VERIFY); /* :361-367 */
         for (size_t j = 0; j < n; j++) { absorb_scalar(&tw, &c[j], s); absorb_scalar(&tw, &pp[j].s, s); absorb_scalar(&tw, &pp[j].sb, s); }
         u256 g = {{0, 0, 0, 0}}, bsc = {{0, 0, 0, 0}}; size_t k = 0;
         for (size_t j = 0; j < n; j++) {

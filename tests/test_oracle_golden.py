@@ -18,6 +18,7 @@ SUITES = {
     "baby-jubjub_sha-512_tai": orc.BABYJUBJUB,
     "jubjub_sha-512_tai": orc.JUBJUB,                 # src/suites/jubjub.rs
     "ed25519_sha-512_tai": orc.ED25519,               # src/suites/ed25519.rs (Tiny / Thin / Pedersen; no ring suite)
+    "bandersnatch_shake128_ell2": orc.BANDERSNATCH_SHAKE128,   # src/suites/bandersnatch_shake128.rs: SHAKE128 sponge transcript, expand_message_xof
 }
 SEEDS = [1, 2, 3, 4, 5, 5, 6]
 

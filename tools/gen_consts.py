@@ -63,7 +63,7 @@ def field_n(name, p, nl):
     return "\n".join(s)
 
 
-def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=None, sw=None):
+def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=None, sw=None, shake=False):
     sid_bytes = ", ".join(str(b) for b in sid_str.encode())
     s = [f"struct {name} {{", f"  using Fq = {fq}; using Fr = {fr};",
          f"  static constexpr int SUITE_ID_LEN = {len(sid_str)};",
@@ -95,6 +95,7 @@ def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=
     s.append(f"  static constexpr uint32_t ELL2_JK[8] = {{{limbs(mont(j * kinv % q, q))}}};     /* J / K */")
     s.append(f"  static constexpr uint32_t ELL2_K[8] = {{{limbs(mont(k, q))}}};")
     s.append(f"  static constexpr uint32_t ELL2_KINV2[8] = {{{limbs(mont(kinv * kinv % q, q))}}};  /* 1 / K^2 */")
+    s.append(f"  static constexpr bool XOF_SHAKE = {'true' if shake else 'false'};  /* Suite::Transcript = Shake128Transcript instead of HashTranscript<Sha512> */")
     # short-Weierstrass presentation (src/suites/bandersnatch_sw.rs, src/utils/te_sw_map.rs): serialised points are 33-byte SW
     # forms; arithmetic stays twisted-Edwards through the maps (x, y) -> (B x - A/3, B y) -> (u / v, (u - 1) / (u + 1))
     s.append(f"  static constexpr bool SW_CODEC = {'true' if sw else 'false'};")
@@ -316,6 +317,20 @@ def main():
                       "PAD": sw_to_te(20496180070424734470560955314776462366297546779079302509428101119888111900885,
                                       8839106592405352067483360946162273985142890146060814748321063063028225641813)}, 4,
                      glv=glv_b, sw=dict(MONT_B=B_m, MONT_A3=a3, MONT_BINV=binv, SW_A=sw_a, SW_B=sw_b)))
+    # Bandersnatch-SHAKE128-ELL2-v1 (src/suites/bandersnatch_shake128.rs): suite 0's curve and Elligator2 map, the SHAKE128 sponge
+    # as the transcript and expand_message_xof in hash-to-curve
+    out.append(suite("SuiteBandersnatchShake", 5, "Bandersnatch-SHAKE128-ELL2-v1", "FqBandersnatch", "FrBandersnatch", q_b, r_b, 1,
+                     45022363124591815672509500913686876175488063829319466900776701791074614335719,
+                     {"G": g0,
+                      "B": (6153734995852631824944342602386415873379775188383988340041079006556670120775,
+                            27204351599954061630605768787803524395123895650061061132592995395630473050754),
+                      "ACC": (27631238720955528589004064829276283990465032040945349648037876197995278250917,
+                              37605358688136619817560700742505556266961225274493904038881144193539047100140),
+                      "PAD": (1834402953989431481748983728202937234471322740714585873803966488035889514523,
+                              52100941849053769665273763352270294131006971127418863694682093199651869272752)}, 4,
+                     ell2=(29978822694968839326280996386011761570173833766074948509196803838190355340952,
+                           25465760566081946422412445027709227188579564747101592991722834452325077642517),
+                     glv=glv_b, shake=True))
     out += ["", "}  // namespace avrf", ""]
     with open(OUT, "w") as f:
         f.write("\n".join(out))
