@@ -1,0 +1,43 @@
+"""GPU: the same valid inputs must give the same verdicts and bytes every time.  Guards a failure that was sporadic by nature
+(DESIGN.md section 7, item 6): with interprocedural register allocation the input-flag word of `k_thin_prove<SuiteBabyJubJub>`,
+live across dozens of calls into out-of-line field functions whose asm multipliers clobber fixed registers, came back
+corrupted on SOME launches -- InvalidData for valid input, in one suite, depending on what ran before.  Contexts of all suites
+are alive at once and their provers / verifiers are interleaved for many rounds."""
+import json
+import os
+
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+NAMES = {0: "bandersnatch_sha-512_ell2", 1: "baby-jubjub_sha-512_tai", 2: "jubjub_sha-512_tai", 3: "ed25519_sha-512_tai",
+         5: "bandersnatch_shake128_ell2"}
+
+
+def test_interleaved_suites_repeat(golden_dir):
+    from ark_vrf_amd import _native as nat
+    from ark_vrf_amd._native import Batch
+    from helpers import xy
+    work = {}
+    for s, name in NAMES.items():
+        vs = json.load(open(os.path.join(golden_dir, name + "_thin.json")))
+        c = nat.Context(s)
+        sks = [bytes.fromhex(v["sk"]) for v in vs]
+        pks = [xy(s, bytes.fromhex(v["pk"])) for v in vs]
+        ios = [[(xy(s, bytes.fromhex(v["h"])), xy(s, bytes.fromhex(v["gamma"])))] for v in vs]
+        ads = [bytes.fromhex(v["ad"]) for v in vs]
+        first = c.thin_prove(Batch.from_items(ios, ads, sks=sks, pks_xy=pks))
+        assert [orc.point_compress(s, first[96 * j: 96 * j + 64]).hex() + first[96 * j + 64: 96 * j + 96].hex() for j in range(7)] == \
+            [v["proof_r"] + v["proof_s"] for v in vs]
+        work[s] = (c, sks, pks, ios, ads, first)
+    for rnd in range(25):
+        for s, (c, sks, pks, ios, ads, first) in work.items():
+            assert c.thin_prove(Batch.from_items(ios, ads, sks=sks, pks_xy=pks)) == first, (rnd, s, "given")
+            assert c.thin_prove(Batch.from_items(ios, ads, sks=sks)) == first, (rnd, s, "derived")
+            tp = [first[96 * j: 96 * j + 96] for j in range(7)]
+            assert c.thin_verify(Batch.from_items(ios, ads, pks_xy=pks, proofs=tp)) == [0] * 7, (rnd, s)
+            pr, _ = c.pedersen_prove(Batch.from_items(ios, ads, sks=sks, pks_xy=pks))
+            assert c.pedersen_verify(Batch.from_items(ios, ads, proofs=[pr[256 * j: 256 * j + 256] for j in range(7)])) == [0] * 7, (rnd, s)
+    for c, *_ in work.values():
+        c.close()
