@@ -7,6 +7,7 @@
 #include "../../include/avrf.h"
 #include "host_sha512.h"
 #include "host_shake128.h"
+#include "host_sha256.h"
 #include "host_te.h"
 #include "msm.h"
 #include "proto_dev.h"
@@ -308,22 +309,25 @@ static int batch_run(avrf_ctx *c, int kind) {
   // weight transcript (src/thin.rs:274-279, src/pedersen.rs:361-367):
   //   new(SUITE_ID); absorb [0x50]; per item absorb LE32(c) || LE32(s) [|| LE32(sb)]
   Seed64 seed; memset(&seed, 0, sizeof seed);
-  const bool sponge = with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; return (bool)S::XOF_SHAKE; });
+  const int host_stream = with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; return S::XOF_SHAKE ? 1 : S::TR_SHA256 ? 2 : 0; });
   const uint8_t tag = DS_BATCH_VERIFY;
   const uint8_t *cs = c->h_c.as<uint8_t>();
   const size_t rsz = kind == 1 ? 32 : 64;
   uint8_t rec[96];
   memset(rec, 0, sizeof rec);
-  if (sponge) {
+  if (host_stream) {
     // Shake128Transcript: the weights are the sponge's OUTPUT STREAM (16 bytes per item, 32 for Pedersen) -- sequential, so the
-    // host squeezes it and the terms kernel reads it from HBM instead of deriving block j / 4 from a seed
-    HostShake128 h;
-    with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; h.update(S::SUITE_ID, S::SUITE_ID_LEN); });
-    h.update(&tag, 1);
-    for (size_t j = 0; j < n; j++) { memcpy(rec, cs + 16 * j, 16); memcpy(rec + 32, &c->h_resp[rsz * j], rsz); h.update(rec, 32 + rsz); }
+    // host squeezes it and the terms kernel reads it from HBM instead of deriving block j / 4 from a seed.  (HashTranscript<Sha256>
+    // of the test suite takes the same route: its counter-mode blocks are cheap to produce here.)
     const size_t wsz = kind == 1 ? 16 : 32;
     c->h_weights.resize(n * wsz);
-    h.squeeze_copy(c->h_weights.data(), n * wsz);
+    auto run = [&](auto &h) {
+      with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; h.update(S::SUITE_ID, S::SUITE_ID_LEN); });
+      h.update(&tag, 1);
+      for (size_t j = 0; j < n; j++) { memcpy(rec, cs + 16 * j, 16); memcpy(rec + 32, &c->h_resp[rsz * j], rsz); h.update(rec, 32 + rsz); }
+      h.squeeze_copy(c->h_weights.data(), n * wsz);
+    };
+    if (host_stream == 1) { HostShake128 h; run(h); } else { HostSha256 h; run(h); }
     HIP_TRY(c->d_weights.ensure(n * wsz));
     HIP_TRY(hipMemcpyAsync(c->d_weights.p, c->h_weights.data(), n * wsz, hipMemcpyHostToDevice, c->stream));
     b.weights = c->d_weights.as<uint8_t>();
@@ -371,7 +375,7 @@ int avrf_batch_weight_seed(int suite, int pedersen, size_t n, const uint8_t *c16
   if (suite < 0 || suite >= AVRF_N_SUITES || !seed_out || (n && (!c16 || !resp))) return AVRF_ERR_BAD_ARG;
   // a sponge transcript has no seed to hand to the shards (its weight stream is sequential): the split-one-batch mode is for the
   // counter-mode (HashTranscript) suites; whole batches shard over GPUs for every suite
-  if (with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return (bool)S::XOF_SHAKE; })) return AVRF_ERR_BAD_ARG;
+  if (with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return (bool)S::HOST_WEIGHTS; })) return AVRF_ERR_BAD_ARG;
   HostSha512 h;
   with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; h.update(S::SUITE_ID, S::SUITE_ID_LEN); });
   const uint8_t tag = DS_BATCH_VERIFY; h.update(&tag, 1);

@@ -10,6 +10,7 @@
 #pragma once
 #include "sha512_dev.h"
 #include "shake_dev.h"
+#include "sha256_dev.h"
 #include "te.h"
 #include <type_traits>
 
@@ -52,7 +53,7 @@ struct BatchDev {
 };
 struct Seed64 { uint64_t w[8]; };  // a SHA-512 digest as big-endian words
 // Suite::Transcript (src/lib.rs:177-250): HashTranscript<Sha512>, or the SHAKE128 sponge for the suites that say so
-template <class S> using suite_tr = std::conditional_t<S::XOF_SHAKE, Shake128, Sha512>;
+template <class S> using suite_tr = std::conditional_t<S::XOF_SHAKE, Shake128, std::conditional_t<S::TR_SHA256, Sha256, Sha512>>;
 
 // absorb the ark-serialize compressed encoding of an affine point given as canonical x||y
 // (LE32 each): LE32(y) with bit 255 set iff x > (q-1)/2   

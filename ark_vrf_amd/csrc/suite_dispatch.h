@@ -4,7 +4,7 @@
 
 namespace avrf {
 
-constexpr int AVRF_N_SUITES = 6;   // 0 Bandersnatch-SHA512-ELL2, 1 BabyJubJub-SHA512-TAI, 2 JubJub-SHA512-TAI, 3 Ed25519-SHA512-TAI, 4 Bandersnatch-SW-SHA512-TAI, 5 Bandersnatch-SHAKE128-ELL2
+constexpr int AVRF_N_SUITES = 7;   // 0 Bandersnatch-SHA512-ELL2, 1 BabyJubJub-SHA512-TAI, 2 JubJub-SHA512-TAI, 3 Ed25519-SHA512-TAI, 4 Bandersnatch-SW-SHA512-TAI, 5 Bandersnatch-SHAKE128-ELL2, 6 Testing-SHA256-TAI
 template <class S> struct SuiteTag { using type = S; };
 
 template <class F> inline auto with_suite(int suite, F &&f) {
@@ -14,6 +14,7 @@ template <class F> inline auto with_suite(int suite, F &&f) {
     case 3: return f(SuiteTag<SuiteEd25519>{});
     case 4: return f(SuiteTag<SuiteBandersnatchSW>{});
     case 5: return f(SuiteTag<SuiteBandersnatchShake>{});
+    case 6: return f(SuiteTag<SuiteTesting>{});
     default: return f(SuiteTag<SuiteBandersnatch>{});
   }
 }

@@ -16,6 +16,7 @@ BANDERSNATCH = 0
 BABYJUBJUB = 1
 JUBJUB = 2
 ED25519 = 3
+TESTING_SHA256 = 6            # the crate's test suite: edwards25519 with HashTranscript<Sha256>
 BANDERSNATCH_SHAKE128 = 5     # Bandersnatch with the SHAKE128 transcript (XofTranscript<Shake128>)
 BANDERSNATCH_SW = 4    # Bandersnatch in its short-Weierstrass presentation: 33-byte serialised points (sw_encode / sw_decode)
 

@@ -47,7 +47,7 @@ typedef struct {
 typedef struct { u256 x, y; } te_aff;        /* Montgomery-form coordinates */
 typedef struct { u256 x, y, t, z; } te_ext;  /* extended twisted Edwards */
 
-enum { ORC_SUITE_BANDERSNATCH = 0, ORC_SUITE_BABYJUBJUB = 1, ORC_SUITE_JUBJUB = 2, ORC_SUITE_ED25519 = 3, ORC_SUITE_BANDERSNATCH_SW = 4, ORC_SUITE_BANDERSNATCH_SHAKE128 = 5 };
+enum { ORC_SUITE_BANDERSNATCH = 0, ORC_SUITE_BABYJUBJUB = 1, ORC_SUITE_JUBJUB = 2, ORC_SUITE_ED25519 = 3, ORC_SUITE_BANDERSNATCH_SW = 4, ORC_SUITE_BANDERSNATCH_SHAKE128 = 5, ORC_SUITE_TESTING_SHA256 = 6 };
 enum { ORC_H2C_ELL2 = 0, ORC_H2C_TAI = 1, ORC_H2C_TAI_SW = 2 };
 
 typedef struct {
@@ -111,7 +111,8 @@ typedef struct {
     sha512_t h; int squeezing;
     uint8_t seed[64], block[64]; uint64_t counter; size_t off;
     /* XofTranscript<Shake128> (src/utils/transcript.rs:292-293; suites with xof_shake): the sponge itself */
-    int shake; uint64_t ks[25]; size_t kpos;
+    int shake; uint64_t ks[25]; size_t kpos;   /* shake: 0 SHA-512 counter mode, 1 SHAKE128 sponge, 2 SHA-256 counter mode */
+    uint32_t h2[8]; uint8_t buf2[64]; uint64_t len2;   /* HashTranscript<Sha256> (src/suites/testing.rs) */
 } transcript_t;
 void tr_new(transcript_t *t, const void *label, size_t n);                  /* HashTranscript<Sha512> */
 void tr_new_mode(transcript_t *t, const void *label, size_t n, int shake);  /* shake != 0: Shake128Transcript */

@@ -136,10 +136,54 @@ void shake128(uint8_t *out, size_t out_len, const uint8_t *const *parts, const s
     shake_pad(ks, &pos); shake_read(ks, &pos, out, out_len);
 }
 
+/* ---- SHA-256 (FIPS 180-4), for HashTranscript<Sha256>: seed = H(label || absorbed), block_i = H(seed || LE64(i)), 32-byte blocks ---- */
+static const uint32_t K256[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3,
+    0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da,
+    0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13,
+    0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070,
+    0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static uint32_t ror32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+static void sha256_block(uint32_t h[8], const uint8_t b[64]) {
+    uint32_t w[64], a[8];
+    for (int i = 0; i < 16; i++) w[i] = ((uint32_t)b[4 * i] << 24) | ((uint32_t)b[4 * i + 1] << 16) | ((uint32_t)b[4 * i + 2] << 8) | b[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+        uint32_t s0 = ror32(w[i - 15], 7) ^ ror32(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ror32(w[i - 2], 17) ^ ror32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    memcpy(a, h, sizeof a);
+    for (int i = 0; i < 64; i++) {
+        uint32_t S1 = ror32(a[4], 6) ^ ror32(a[4], 11) ^ ror32(a[4], 25), ch = (a[4] & a[5]) ^ (~a[4] & a[6]);
+        uint32_t t1 = a[7] + S1 + ch + K256[i] + w[i];
+        uint32_t S0 = ror32(a[0], 2) ^ ror32(a[0], 13) ^ ror32(a[0], 22), mj = (a[0] & a[1]) ^ (a[0] & a[2]) ^ (a[1] & a[2]);
+        uint32_t t2 = S0 + mj;
+        a[7] = a[6]; a[6] = a[5]; a[5] = a[4]; a[4] = a[3] + t1; a[3] = a[2]; a[2] = a[1]; a[1] = a[0]; a[0] = t1 + t2;
+    }
+    for (int i = 0; i < 8; i++) h[i] += a[i];
+}
+static void sha256_init_(uint32_t h[8], uint64_t *len) {
+    static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    memcpy(h, iv, sizeof iv); *len = 0;
+}
+static void sha256_update_(uint32_t h[8], uint8_t buf[64], uint64_t *len, const uint8_t *d, size_t n) {
+    for (size_t i = 0; i < n; i++) { buf[*len & 63] = d[i]; if ((++*len & 63) == 0) sha256_block(h, buf); }
+}
+static void sha256_final_(const uint32_t hin[8], const uint8_t bufin[64], uint64_t len, uint8_t out[32]) {
+    uint32_t h[8]; uint8_t buf[64]; memcpy(h, hin, sizeof h); memcpy(buf, bufin, 64);
+    uint64_t l = len; uint8_t pad = 0x80, z = 0;
+    sha256_update_(h, buf, &l, &pad, 1);
+    while ((l & 63) != 56) sha256_update_(h, buf, &l, &z, 1);
+    uint8_t lb[8]; for (int i = 0; i < 8; i++) lb[i] = (uint8_t)((len * 8) >> (56 - 8 * i));
+    sha256_update_(h, buf, &l, lb, 8);
+    for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
+}
+
 void tr_new_mode(transcript_t *t, const void *label, size_t n, int shake) {
     tr_new(t, label, n);
     t->shake = shake;
-    if (shake) { memset(t->ks, 0, sizeof t->ks); t->kpos = 0; shake_absorb(t->ks, &t->kpos, (const uint8_t *)label, n); }
+    if (shake == 1) { memset(t->ks, 0, sizeof t->ks); t->kpos = 0; shake_absorb(t->ks, &t->kpos, (const uint8_t *)label, n); }
+    if (shake == 2) { sha256_init_(t->h2, &t->len2); sha256_update_(t->h2, t->buf2, &t->len2, (const uint8_t *)label, n); }
 }
 void tr_new(transcript_t *t, const void *label, size_t n) {
     t->shake = 0;
@@ -148,7 +192,8 @@ void tr_new(transcript_t *t, const void *label, size_t n) {
 }
 void tr_absorb(transcript_t *t, const void *d, size_t n) {
     if (t->squeezing) { t->squeezing = 2; return; } /* reference panics (transcript.rs:187) */
-    if (t->shake) { shake_absorb(t->ks, &t->kpos, (const uint8_t *)d, n); return; }
+    if (t->shake == 1) { shake_absorb(t->ks, &t->kpos, (const uint8_t *)d, n); return; }
+    if (t->shake == 2) { sha256_update_(t->h2, t->buf2, &t->len2, (const uint8_t *)d, n); return; }
     sha512_update(&t->h, d, n);
 }
 static void tr_block(transcript_t *t) {
@@ -160,9 +205,23 @@ static void tr_block(transcript_t *t) {
 }
 void tr_squeeze(transcript_t *t, void *out, size_t n) {
     uint8_t *o = (uint8_t *)out;
-    if (t->shake) {
+    if (t->shake == 1) {
         if (!t->squeezing) { shake_pad(t->ks, &t->kpos); t->squeezing = 1; }
         shake_read(t->ks, &t->kpos, o, n);
+        return;
+    }
+    if (t->shake == 2) {   /* DigestXof<Sha256>: 32-byte seed and blocks */
+        if (!t->squeezing) { sha256_final_(t->h2, t->buf2, t->len2, t->seed); t->squeezing = 1; t->counter = 0; t->off = 32; }
+        while (n) {
+            if (t->off >= 32) {
+                uint32_t h[8]; uint8_t buf[64]; uint64_t l; uint8_t ctr[8];
+                for (int i = 0; i < 8; i++) ctr[i] = (uint8_t)(t->counter >> (8 * i));
+                sha256_init_(h, &l); sha256_update_(h, buf, &l, t->seed, 32); sha256_update_(h, buf, &l, ctr, 8);
+                sha256_final_(h, buf, l, t->block); t->counter++; t->off = 0;
+            }
+            size_t take = 32 - t->off; if (take > n) take = n;
+            memcpy(o, t->block + t->off, take); t->off += take; o += take; n -= take;
+        }
         return;
     }
     if (!t->squeezing) { sha512_final(&t->h, t->seed); t->squeezing = 1; t->counter = 0; t->off = 64; }

@@ -15,7 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-static suite_t g_suites[6];
+static suite_t g_suites[7];
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;      /* gen_batch() calls in from several threads at once */
 
 static void fq_dec(u256 *o, const char *dec, const mont_t *m) {
@@ -166,11 +166,20 @@ static void init_suites(void) {
     fq_dec(&s->ACC.y, "37605358688136619817560700742505556266961225274493904038881144193539047100140", &s->fq);
     fq_dec(&s->PAD.x, "1834402953989431481748983728202937234471322740714585873803966488035889514523", &s->fq);
     fq_dec(&s->PAD.y, "52100941849053769665273763352270294131006971127418863694682093199651869272752", &s->fq);
+
+    /* ---- Testing-SHA256-TAI-v1 (src/suites/testing.rs): the crate's own test suite -- edwards25519 with HashTranscript<Sha256> ---- */
+    s = &g_suites[6];
+    *s = g_suites[3];
+    s->id = ORC_SUITE_TESTING_SHA256;
+    s->suite_id = "Testing-SHA256-TAI-v1"; s->suite_id_len = 21;
+    s->xof_shake = 2;
+    fq_dec(&s->B.x, "3310617998588019043596181043598335786888094217571323926547956053100032777190", &s->fq);
+    fq_dec(&s->B.y, "16824531136491949759823061604778551593864344614632277377095388820423530178202", &s->fq);
 }
 
 const suite_t *orc_suite(int id) {
     pthread_once(&g_once, init_suites);
-    if (id < 0 || id > 5) return NULL;
+    if (id < 0 || id > 6) return NULL;
     return &g_suites[id];
 }
 

@@ -251,7 +251,7 @@ int orc_hash_to_curve(int suite, const uint8_t *data, size_t n, uint8_t out[32])
         memcpy(dst, s->suite_id, dl); dst[dl++] = DS_HASH_TO_CURVE;
         size_t L = (size_t)(s->fq.bits + 128 + 7) / 8; /* 48 */
         uint8_t ub[128];
-        if (s->xof_shake) {   /* XofFieldHasher, expand_message_xof (src/utils/hash_to_curve.rs:103-150): H(msg || I2OSP(len, 2) || DST || I2OSP(len(DST), 1)) */
+        if (s->xof_shake == 1) {   /* XofFieldHasher, expand_message_xof (src/utils/hash_to_curve.rs:103-150): H(msg || I2OSP(len, 2) || DST || I2OSP(len(DST), 1)) */
             uint8_t lib[2] = {(uint8_t)((2 * L) >> 8), (uint8_t)(2 * L)}, dlb = (uint8_t)dl;
             const uint8_t *parts[4] = {data, lib, dst, &dlb}; size_t lens[4] = {n, 2, dl, 1};
             shake128(ub, 2 * L, parts, lens, 4);

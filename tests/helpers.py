@@ -9,6 +9,7 @@ R_ORDER = {
     orc.BABYJUBJUB: 2736030358979909402780800718157159386076813972158567259200215660948447373041,
     orc.JUBJUB: 6554484396890773809930967563523245729705921265872317281365359162392183254199,
     orc.ED25519: 2 ** 252 + 27742317777372353535851937790883648493,
+    orc.TESTING_SHA256: 2 ** 252 + 27742317777372353535851937790883648493,
     orc.BANDERSNATCH_SW: 0x1cfb69d4ca675f520cce760202687600ff8f87007419047174fd06b52876e7e1,
     orc.BANDERSNATCH_SHAKE128: 0x1cfb69d4ca675f520cce760202687600ff8f87007419047174fd06b52876e7e1,
 }

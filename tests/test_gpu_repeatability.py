@@ -12,7 +12,7 @@ import oracle as orc
 
 pytestmark = pytest.mark.gpu
 NAMES = {0: "bandersnatch_sha-512_ell2", 1: "baby-jubjub_sha-512_tai", 2: "jubjub_sha-512_tai", 3: "ed25519_sha-512_tai",
-         5: "bandersnatch_shake128_ell2"}
+         5: "bandersnatch_shake128_ell2", 6: "testing_sha-256_tai"}
 
 
 def test_interleaved_suites_repeat(golden_dir):

@@ -18,6 +18,7 @@ SUITES = {
     "baby-jubjub_sha-512_tai": orc.BABYJUBJUB,
     "jubjub_sha-512_tai": orc.JUBJUB,                 # src/suites/jubjub.rs
     "ed25519_sha-512_tai": orc.ED25519,               # src/suites/ed25519.rs (Tiny / Thin / Pedersen; no ring suite)
+    "testing_sha-256_tai": orc.TESTING_SHA256,        # src/suites/testing.rs: edwards25519, HashTranscript<Sha256>
     "bandersnatch_shake128_ell2": orc.BANDERSNATCH_SHAKE128,   # src/suites/bandersnatch_shake128.rs: SHAKE128 sponge transcript, expand_message_xof
 }
 SEEDS = [1, 2, 3, 4, 5, 5, 6]
@@ -108,7 +109,7 @@ def test_suite_constants(golden_dir, name):
     (src/pedersen.rs:39,568-579 `blinding_base_check`; src/ring.rs:66-69 `padding_check`, `accumulator_base_check`)."""
     s = SUITES[name]
     assert orc.hash_to_curve(s, b"pedersen-blinding") == orc.suite_point(s, 1)
-    if s == orc.ED25519:                                   # not a RingSuite: no accumulator base / padding point
+    if s in (orc.ED25519, orc.TESTING_SHA256):             # not a RingSuite: no accumulator base / padding point
         return
     assert orc.hash_to_curve(s, b"ring-accumulator") == orc.suite_point(s, 2)
     assert orc.hash_to_curve(s, b"ring-padding") == orc.suite_point(s, 3)

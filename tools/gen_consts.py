@@ -63,7 +63,7 @@ def field_n(name, p, nl):
     return "\n".join(s)
 
 
-def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=None, sw=None, shake=False):
+def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=None, sw=None, shake=False, sha256=False):
     sid_bytes = ", ".join(str(b) for b in sid_str.encode())
     s = [f"struct {name} {{", f"  using Fq = {fq}; using Fr = {fr};",
          f"  static constexpr int SUITE_ID_LEN = {len(sid_str)};",
@@ -96,6 +96,8 @@ def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=
     s.append(f"  static constexpr uint32_t ELL2_K[8] = {{{limbs(mont(k, q))}}};")
     s.append(f"  static constexpr uint32_t ELL2_KINV2[8] = {{{limbs(mont(kinv * kinv % q, q))}}};  /* 1 / K^2 */")
     s.append(f"  static constexpr bool XOF_SHAKE = {'true' if shake else 'false'};  /* Suite::Transcript = Shake128Transcript instead of HashTranscript<Sha512> */")
+    s.append(f"  static constexpr bool TR_SHA256 = {'true' if sha256 else 'false'};  /* Suite::Transcript = HashTranscript<Sha256> */")
+    s.append(f"  static constexpr bool HOST_WEIGHTS = {'true' if (shake or sha256) else 'false'};  /* batch verifiers: the host squeezes the weight stream */")
     # short-Weierstrass presentation (src/suites/bandersnatch_sw.rs, src/utils/te_sw_map.rs): serialised points are 33-byte SW
     # forms; arithmetic stays twisted-Edwards through the maps (x, y) -> (B x - A/3, B y) -> (u / v, (u - 1) / (u + 1))
     s.append(f"  static constexpr bool SW_CODEC = {'true' if sw else 'false'};")
@@ -331,6 +333,12 @@ def main():
                      ell2=(29978822694968839326280996386011761570173833766074948509196803838190355340952,
                            25465760566081946422412445027709227188579564747101592991722834452325077642517),
                      glv=glv_b, shake=True))
+    # Testing-SHA256-TAI-v1 (src/suites/testing.rs): the crate's own test suite -- edwards25519 with HashTranscript<Sha256>
+    out.append(suite("SuiteTesting", 6, "Testing-SHA256-TAI-v1", "FqEd25519", "FrEd25519", q_e, r_e, 2, d_e,
+                     {"G": g_e,
+                      "B": (3310617998588019043596181043598335786888094217571323926547956053100032777190,
+                            16824531136491949759823061604778551593864344614632277377095388820423530178202),
+                      "ACC": g_e, "PAD": g_e}, 8, sha256=True))
     out += ["", "}  // namespace avrf", ""]
     with open(OUT, "w") as f:
         f.write("\n".join(out))
