@@ -172,6 +172,22 @@ AVRF_DI void rd_chunk16(ShaReader &r, uint32_t i, uint32_t (&w)[4]) {
   if (r.have != (i >> 2) + 1) { sha512_xof_block(r.seed, i >> 2, r.blk); r.have = (i >> 2) + 1; }
   digest_le128(r.blk, (int)(i & 3), w);
 }
+// a 32-bit little-endian word at a 4-byte-aligned position: ONE select chain over the block words instead of four (field
+// elements, counts and lengths are absorbed as such words; the positions stay aligned until a variable-length string -- the
+// additional data -- has gone in)
+AVRF_DI void tr_u32le(Sha512 &s, uint32_t v) {
+  if ((s.fill & 3) == 0) {
+    const uint64_t x = (uint64_t)__builtin_bswap32(v) << ((s.fill & 4) ? 0 : 32);
+    const uint32_t wi = s.fill >> 3;
+#pragma unroll
+    for (int i = 0; i < 16; i++) s.w[i] |= (wi == (uint32_t)i) ? x : 0ULL;
+    s.fill += 4; s.total += 4;
+    if (s.fill == 128) sha512_flush(s);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) sha512_byte(s, (uint8_t)(v >> (8 * i)));
+  }
+}
 template <class T> AVRF_DI void tr_bytes(T &s, const uint8_t *p, uint32_t n) { for (uint32_t i = 0; i < n; i++) tr_byte(s, p[i]); }
 template <class T> AVRF_DI void tr_u32le(T &s, uint32_t v) {
 #pragma unroll
