@@ -8,6 +8,11 @@
 #include "host_sha512.h"
 #include "host_shake128.h"
 #include "host_sha256.h"
+#include "host_sha512_mb.h"
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include "host_te.h"
 #include "msm.h"
 #include "proto_dev.h"
@@ -77,6 +82,7 @@ struct avrf_ctx {
   size_t n = 0, tot_io = 0, n_terms = 0;
   DevBuf d_pks, d_ios, d_io_off, d_ads, d_ad_off, d_proofs, d_sks;
   std::vector<uint8_t> h_resp;    // host copy of the response scalars (s [, sb]) for the weight transcript
+  DevBuf d_rec; PinBuf h_msg;     // counter-mode transcripts: the records written by the prepare kernel, and prefix || records on the host
   std::vector<uint8_t> h_weights; DevBuf d_weights;   // sponge transcripts: the squeezed weight stream of the staged batch
   DevBuf d_c, d_z, d_flags, d_scalars, d_pre, d_gpart, d_misc, d_out, d_status;
   DevBuf d_fixed; bool fixed_ready = false;   // fixed-base tables of G and BLINDING_BASE (provers, scalar_mul_base), built on first use
@@ -99,7 +105,7 @@ static BatchDev batch_of(avrf_ctx *c) {
   b.ads = c->d_ads.as<uint8_t>(); b.ad_off = c->d_ad_off.as<uint32_t>(); b.proofs = c->d_proofs.as<uint8_t>();
   b.sks = c->d_sks.as<uint8_t>(); b.n = (uint32_t)c->n;
   b.fixed = (const te_pre *)c->d_fixed.p;
-  b.weights = nullptr;
+  b.weights = nullptr; b.records = nullptr;
   return b;
 }
 
@@ -168,9 +174,9 @@ void avrf_ctx_destroy(avrf_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   c->ws.release();
   DevBuf *bufs[] = {&c->d_pks, &c->d_ios, &c->d_io_off, &c->d_ads, &c->d_ad_off, &c->d_proofs, &c->d_sks, &c->d_c, &c->d_z,
-                    &c->d_flags, &c->d_scalars, &c->d_pre, &c->d_gpart, &c->d_misc, &c->d_out, &c->d_status, &c->d_fixed, &c->d_weights};
+                    &c->d_flags, &c->d_scalars, &c->d_pre, &c->d_gpart, &c->d_misc, &c->d_out, &c->d_status, &c->d_fixed, &c->d_weights, &c->d_rec};
   for (DevBuf *b : bufs) b->release();
-  c->h_c.release(); c->h_flags.release(); c->h_io.release();
+  c->h_c.release(); c->h_flags.release(); c->h_io.release(); c->h_msg.release();
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -288,6 +294,68 @@ int avrf_pedersen_batch_stage(avrf_ctx *c, size_t n, const uint8_t *ios_xy, cons
   return stage(c, 2, n, nullptr, nullptr, ios_xy, io_counts, ads, ad_lens, proofs);
 }
 
+// ---- the weight transcripts of the contexts in flight, hashed together (host_sha512_mb.h)
+static void weight_digest_scalar(WeightJob &j) {
+  HostSha512 h;
+  if (j.msg) { h.update(j.msg, j.msg_len); h.final(j.digest); return; }
+  h.update(j.prefix, j.prefix_len);
+  uint8_t rec[96]; memset(rec, 0, sizeof rec);
+  for (size_t k = 0; k < j.n; k++) { memcpy(rec, j.c16 + 16 * k, 16); memcpy(rec + 32, j.resp + j.rsz * k, j.rsz); h.update(rec, 32 + j.rsz); }
+  h.final(j.digest);
+}
+namespace {
+// OPT-IN (AVRF_HASH_THREADS = number of workers; default 0 = every context hashes its own transcript on its own thread).
+// Contexts hand their transcript to a small pool; a worker takes up to eight pending ones and advances them in the eight lanes
+// of a 512-bit register (a lone request goes through the scalar code).  Measured on the bench host (16-CPU quota): one 8-lane
+// pass takes ~10 ms against 4.4 ms for one scalar chain, i.e. 3.6x the hashes per core-second but twice the latency per batch;
+// the contexts form a closed loop, so with 16 of them the longer wait costs more than the saved cycles return (55-68 M/s with
+// 2-4 workers against 76-81 M/s), and 48 contexts with 8 workers only draw level (74 M/s).  Kept for hosts with fewer cores per GPU.
+class WeightHashService {
+ public:
+  static WeightHashService &get() { static WeightHashService s; return s; }
+  bool enabled() const { return !workers_.empty(); }
+  void run(WeightJob &job) {
+    Item it{&job, false};
+    std::unique_lock<std::mutex> lk(m_);
+    q_.push_back(&it);
+    cv_work_.notify_one();
+    cv_done_.wait(lk, [&] { return it.done; });
+  }
+ private:
+  struct Item { WeightJob *job; bool done; };
+  WeightHashService() {
+    int n = 0;
+    if (const char *e = getenv("AVRF_HASH_THREADS")) n = atoi(e);
+    if (n < 0) n = 0; if (n > 16) n = 16;
+    if (!sha512_mb_available()) n = 0;
+    for (int i = 0; i < n; i++) workers_.emplace_back([this] { loop(); });
+  }
+  ~WeightHashService() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+    cv_work_.notify_all();
+    for (auto &t : workers_) t.join();
+  }
+  void loop() {
+    for (;;) {
+      Item *take[8]; int cnt = 0;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_work_.wait(lk, [&] { return stop_ || !q_.empty(); });
+        if (stop_) return;
+        if (q_.size() == 1) cv_work_.wait_for(lk, std::chrono::microseconds(40), [&] { return stop_ || q_.size() >= 2; });   // companions on their way?
+        if (stop_) return;
+        while (cnt < 8 && !q_.empty()) { take[cnt++] = q_.front(); q_.pop_front(); }
+      }
+      if (cnt == 1) weight_digest_scalar(*take[0]->job);
+      else if (cnt > 1) { WeightJob *jobs[8]; for (int i = 0; i < cnt; i++) jobs[i] = take[i]->job; sha512_weights_x8(jobs, cnt); }
+      { std::lock_guard<std::mutex> lk(m_); for (int i = 0; i < cnt; i++) take[i]->done = true; }
+      cv_done_.notify_all();
+    }
+  }
+  std::mutex m_; std::condition_variable cv_work_, cv_done_; std::deque<Item *> q_; std::vector<std::thread> workers_; bool stop_ = false;
+};
+}  // namespace
+
 // shared tail of both batch verifiers: weight transcript on the host, terms + MSM on the device
 static int batch_run(avrf_ctx *c, int kind) {
   if (!c || c->staged_kind != kind) return AVRF_ERR_BAD_ARG;
@@ -299,9 +367,22 @@ static int batch_run(avrf_ctx *c, int kind) {
   BatchDev b = batch_of(c);
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
   validate_staged(c, kind, nullptr);
+  const int host_stream = with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; return S::XOF_SHAKE ? 1 : S::TR_SHA256 ? 2 : 0; });
+  // the weight transcript's message, prefix || records: the prepare kernel writes the records, one copy brings them back
+  const size_t recsz = kind == 1 ? 64 : 96;
+  uint8_t prefix[64]; size_t pl = 0;
+  with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; memcpy(prefix, S::SUITE_ID, S::SUITE_ID_LEN); pl = S::SUITE_ID_LEN; });
+  prefix[pl++] = DS_BATCH_VERIFY;
+  if (!host_stream) {
+    HIP_TRY(c->d_rec.ensure(n * recsz)); HIP_TRY(c->h_msg.ensure(pl + n * recsz));
+    b.records = c->d_rec.as<uint8_t>();
+  }
   if (kind == 1) launch_thin_prepare(c->suite, b, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_flags.as<uint32_t>(), c->stream);
   else launch_ped_prepare(c->suite, b, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream);
-  HIP_TRY(hipMemcpyAsync(c->h_c.p, c->d_c.p, n * 16, hipMemcpyDeviceToHost, c->stream));
+  if (!host_stream) {
+    memcpy(c->h_msg.p, prefix, pl);
+    HIP_TRY(hipMemcpyAsync(c->h_msg.as<uint8_t>() + pl, c->d_rec.p, n * recsz, hipMemcpyDeviceToHost, c->stream));
+  } else HIP_TRY(hipMemcpyAsync(c->h_c.p, c->d_c.p, n * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   double t1 = now_us();
@@ -309,7 +390,6 @@ static int batch_run(avrf_ctx *c, int kind) {
   // weight transcript (src/thin.rs:274-279, src/pedersen.rs:361-367):
   //   new(SUITE_ID); absorb [0x50]; per item absorb LE32(c) || LE32(s) [|| LE32(sb)]
   Seed64 seed; memset(&seed, 0, sizeof seed);
-  const int host_stream = with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; return S::XOF_SHAKE ? 1 : S::TR_SHA256 ? 2 : 0; });
   const uint8_t tag = DS_BATCH_VERIFY;
   const uint8_t *cs = c->h_c.as<uint8_t>();
   const size_t rsz = kind == 1 ? 32 : 64;
@@ -332,12 +412,12 @@ static int batch_run(avrf_ctx *c, int kind) {
     HIP_TRY(hipMemcpyAsync(c->d_weights.p, c->h_weights.data(), n * wsz, hipMemcpyHostToDevice, c->stream));
     b.weights = c->d_weights.as<uint8_t>();
   } else {
-    HostSha512 h;
-    with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; h.update(S::SUITE_ID, S::SUITE_ID_LEN); });
-    h.update(&tag, 1);
-    for (size_t j = 0; j < n; j++) { memcpy(rec, cs + 16 * j, 16); memcpy(rec + 32, &c->h_resp[rsz * j], rsz); h.update(rec, 32 + rsz); }
-    uint8_t dg[64]; h.final(dg);
-    for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, dg + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
+    static const bool skip_hash = getenv("AVRF_EXPERIMENT_SKIP_HASH") != nullptr;   // timing experiment only: wrong weights, wrong verdict
+    WeightJob job; job.prefix = prefix; job.prefix_len = pl; job.c16 = cs; job.resp = c->h_resp.data(); job.n = n; job.rsz = rsz;
+    job.msg = c->h_msg.as<uint8_t>(); job.msg_len = skip_hash ? pl + recsz : pl + n * recsz;
+    WeightHashService &svc = WeightHashService::get();
+    if (svc.enabled()) svc.run(job); else weight_digest_scalar(job);
+    for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, job.digest + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
   }
   double t2 = now_us();
   if (kind == 1) launch_thin_terms(c->suite, b, seed, 0, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_scalars.as<uint32_t>(),
@@ -383,6 +463,41 @@ int avrf_batch_weight_seed(int suite, int pedersen, size_t n, const uint8_t *c16
   uint8_t rec[96]; memset(rec, 0, sizeof rec);
   for (size_t j = 0; j < n; j++) { memcpy(rec, c16 + 16 * j, 16); memcpy(rec + 32, resp + rsz * j, rsz); h.update(rec, 32 + rsz); }
   h.final(seed_out);
+  return AVRF_OK;
+}
+
+// the same for up to eight batches at once through the multi-buffer hash (host_sha512_mb.h); AVRF_ERR_NO_DEVICE when the host
+// CPU has no AVX-512 (the library then hashes every transcript on its context's thread)
+int avrf_batch_weight_seeds_x8(int suite, int pedersen, int count, const size_t *n, const uint8_t *const *c16, const uint8_t *const *resp, uint8_t *seeds_out) {
+  if (suite < 0 || suite >= AVRF_N_SUITES || count < 1 || count > 8 || !n || !c16 || !resp || !seeds_out) return AVRF_ERR_BAD_ARG;
+  if (with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return (bool)S::HOST_WEIGHTS; })) return AVRF_ERR_BAD_ARG;
+  if (!sha512_mb_available()) return AVRF_ERR_NO_DEVICE;
+  uint8_t prefix[64]; size_t pl = 0;
+  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; memcpy(prefix, S::SUITE_ID, S::SUITE_ID_LEN); pl = S::SUITE_ID_LEN; });
+  prefix[pl++] = DS_BATCH_VERIFY;
+  WeightJob jobs[8]; WeightJob *pj[8];
+  for (int i = 0; i < count; i++) {
+    if (n[i] && (!c16[i] || !resp[i])) return AVRF_ERR_BAD_ARG;
+    jobs[i].prefix = prefix; jobs[i].prefix_len = pl; jobs[i].c16 = c16[i]; jobs[i].resp = resp[i]; jobs[i].n = n[i]; jobs[i].rsz = pedersen ? 64 : 32; pj[i] = &jobs[i];
+  }
+  const bool tr = getenv("AVRF_TRACE_HASH") != nullptr;
+  double ta = now_us();
+  sha512_weights_x8(pj, count);
+  double tb = now_us();
+  for (int i = 0; i < count; i++) memcpy(seeds_out + 64 * i, jobs[i].digest, 64);
+  // the contiguous form (what avrf_*_batch_run hands over: prefix || records in one buffer) must agree
+  std::vector<std::vector<uint8_t>> msgs(count);
+  for (int i = 0; i < count; i++) {
+    const size_t rsz = jobs[i].rsz; msgs[i].assign(pl + n[i] * (32 + rsz), 0);
+    memcpy(msgs[i].data(), prefix, pl);
+    for (size_t k = 0; k < n[i]; k++) { uint8_t *r = &msgs[i][pl + k * (32 + rsz)]; memcpy(r, c16[i] + 16 * k, 16); memcpy(r + 32, resp[i] + rsz * k, rsz); }
+    jobs[i].msg = msgs[i].data(); jobs[i].msg_len = msgs[i].size();
+  }
+  double tc = now_us();
+  sha512_weights_x8(pj, count);
+  double td = now_us();
+  if (tr) { double te = now_us(); weight_digest_scalar(jobs[0]); fprintf(stderr, "avrf: %d lanes: record form %.2f ms, contiguous form %.2f ms, one lane scalar %.2f ms\n", count, (tb - ta) / 1e3, (td - tc) / 1e3, (now_us() - te) / 1e3); }
+  for (int i = 0; i < count; i++) if (memcmp(seeds_out + 64 * i, jobs[i].digest, 64)) return AVRF_VERIFICATION_FAILURE;
   return AVRF_OK;
 }
 

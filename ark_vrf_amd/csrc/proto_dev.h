@@ -48,6 +48,9 @@ struct BatchDev {
   const uint8_t *sks;       // n x 32 (provers only)
   uint32_t n;
   const te_pre *fixed;      // fixed-base tables of the suite's G and BLINDING_BASE: [2][32][256] (provers only)
+  uint8_t *records;         // batch verifiers, counter-mode transcripts: the prepare kernel also writes item j's record of the weight
+                            // transcript, c(16) || 0(16) || s(32) [|| sb(32)], to records + (64 | 96) j -- the host then hashes
+                            // one contiguous buffer that came back in a single copy; nullptr: not wanted
   const uint8_t *weights;   // batch verifiers, sponge transcripts only: the squeezed weight stream of THIS batch (16 / 32 bytes per
                             // item), produced by the host -- a sponge's output is sequential; nullptr: counter-mode stream from the seed
 };

@@ -68,6 +68,11 @@ k_thin_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint32_t *__restrict__ 
     uint32_t w[4]; rd_chunk16(rd, 0, w);
     uint4 *o = reinterpret_cast<uint4 *>(c_out + 4 * (size_t)j);
     *o = make_uint4(w[0], w[1], w[2], w[3]);
+    if (b.records) {                                                           // LE32(c) || LE32(s) of the weight transcript, thin.rs:274-279
+      uint4 *r = reinterpret_cast<uint4 *>(b.records + 64 * (size_t)j);
+      const uint4 *sp = reinterpret_cast<const uint4 *>(pr + 64);
+      r[0] = make_uint4(w[0], w[1], w[2], w[3]); r[1] = make_uint4(0, 0, 0, 0); r[2] = sp[0]; r[3] = sp[1];
+    }
   }
   if (f) atomicOr(flags, f);
 }
@@ -199,6 +204,11 @@ k_ped_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint8_t *__restrict__ me
   }
   fp c = challenge_finish(t);                                                  // :281
   *reinterpret_cast<uint4 *>(c_out + 4 * (size_t)j) = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]);
+  if (b.records) {                                                             // LE32(c) || LE32(s) || LE32(sb), pedersen.rs:361-367
+    uint4 *r = reinterpret_cast<uint4 *>(b.records + 96 * (size_t)j);
+    const uint4 *sp = reinterpret_cast<const uint4 *>(pr + 192);
+    r[0] = make_uint4(c.v[0], c.v[1], c.v[2], c.v[3]); r[1] = make_uint4(0, 0, 0, 0); r[2] = sp[0]; r[3] = sp[1]; r[4] = sp[2]; r[5] = sp[3];
+  }
   if (f) atomicOr(flags, f);
 }
 

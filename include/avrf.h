@@ -119,6 +119,11 @@ int avrf_pedersen_batch_partial(avrf_ctx *ctx, const uint8_t seed64[64], uint64_
  * iff the sum is the identity (0, 1). */
 int avrf_thin_batch_challenges(avrf_ctx *ctx, uint8_t *c_out);
 int avrf_batch_weight_seed(int suite, int pedersen, size_t n, const uint8_t *c16, const uint8_t *resp, uint8_t seed_out[64]);
+/* The same for `count` <= 8 batches in one pass: the chains of different batches are independent, so the library hashes the
+ * transcripts can be hashed together, one batch per lane of an AVX-512 register (host_sha512_mb.h; inside avrf_*_batch_run
+ * this is opt-in: AVRF_HASH_THREADS service threads, default 0 -- see capi.hip for the measurement).  seeds_out: count x 64 bytes.
+ * AVRF_ERR_NO_DEVICE when the host CPU lacks AVX-512. */
+int avrf_batch_weight_seeds_x8(int suite, int pedersen, int count, const size_t *n, const uint8_t *const *c16, const uint8_t *const *resp, uint8_t *seeds_out);
 /* (AVRF_ERR_BAD_ARG unless avrf_thin_batch_challenges succeeded on the CURRENT staging: re-staging or any other call that
  * stages -- avrf_thin_verify, a prover -- invalidates the challenges) */
 int avrf_thin_batch_partial(avrf_ctx *ctx, const uint8_t seed[64], uint64_t first_index, uint8_t out_xy[64]);

@@ -80,3 +80,36 @@ def test_host_pairing_on_reference_srs(tmp_path, golden_dir, curve, srs):
     out = subprocess.run([exe, str(curve), os.path.join(golden_dir, srs)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip() == "consistent=1 negative=0 consistent_high=1 g2_codec=1 g2_law=1 cyclo_sqr=1 f12_inv=1"
+
+
+def test_multibuffer_weight_hash_matches_scalar():
+    """host_sha512_mb.h: eight weight transcripts in the lanes of an AVX-512 register must give the digests of the scalar
+    chain (avrf_batch_weight_seed), for equal and unequal batch sizes, empty batches, both record sizes and every lane count."""
+    import ctypes as C
+    import random
+    from ark_vrf_amd import _native as nat
+    L = nat.lib()
+    rng = random.Random(11)
+    for pedersen in (0, 1):
+        rsz = 64 if pedersen else 32
+        for sizes in ([5], [0, 1], [3, 3, 3, 3, 3, 3, 3, 3], [0, 1, 2, 3, 4, 5, 6, 700], [129, 64, 1000, 2, 0, 17, 333], [2048] * 8):
+            cs = [bytes(rng.getrandbits(8) for _ in range(16 * n)) for n in sizes]
+            rs = [bytes(rng.getrandbits(8) for _ in range(rsz * n)) for n in sizes]
+            want = []
+            for n, c, r in zip(sizes, cs, rs):
+                out = (C.c_uint8 * 64)()
+                assert L.avrf_batch_weight_seed(0, pedersen, C.c_size_t(n), nat._u8(c or b"\0"), nat._u8(r or b"\0"), out) == 0
+                want.append(bytes(out))
+            k = len(sizes)
+            cbuf = [C.create_string_buffer(c or b"\0", max(1, len(c))) for c in cs]
+            rbuf = [C.create_string_buffer(r or b"\0", max(1, len(r))) for r in rs]
+            cp = (C.c_void_p * k)(*[C.cast(b, C.c_void_p) for b in cbuf])
+            rp = (C.c_void_p * k)(*[C.cast(b, C.c_void_p) for b in rbuf])
+            ns = (C.c_size_t * k)(*sizes)
+            out = (C.c_uint8 * (64 * k))()
+            rc = L.avrf_batch_weight_seeds_x8(0, pedersen, k, ns, cp, rp, out)
+            if rc == nat.ERR_NO_DEVICE:
+                import pytest
+                pytest.skip("host CPU without AVX-512")
+            assert rc == 0
+            assert [bytes(out)[64 * i: 64 * i + 64] for i in range(k)] == want
