@@ -412,7 +412,11 @@ static int batch_run(avrf_ctx *c, int kind) {
     HIP_TRY(hipMemcpyAsync(c->d_weights.p, c->h_weights.data(), n * wsz, hipMemcpyHostToDevice, c->stream));
     b.weights = c->d_weights.as<uint8_t>();
   } else {
-    static const bool skip_hash = getenv("AVRF_EXPERIMENT_SKIP_HASH") != nullptr;   // timing experiment only: wrong weights, wrong verdict
+#ifdef AVRF_EXPERIMENTS   // timing experiment only (tools/gpu_only_rate.py): wrong weights, wrong verdict; never in the shipped build
+    static const bool skip_hash = getenv("AVRF_EXPERIMENT_SKIP_HASH") != nullptr;
+#else
+    constexpr bool skip_hash = false;
+#endif
     WeightJob job; job.prefix = prefix; job.prefix_len = pl; job.c16 = cs; job.resp = c->h_resp.data(); job.n = n; job.rsz = rsz;
     job.msg = c->h_msg.as<uint8_t>(); job.msg_len = skip_hash ? pl + recsz : pl + n * recsz;
     WeightHashService &svc = WeightHashService::get();

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Experiment: the headline workload with the host weight hash switched off (AVRF_EXPERIMENT_SKIP_HASH=1: wrong weights, the
-verdicts are ignored) -- what the GPU side alone sustains with S contexts.  Tells how far the host hash is from mattering."""
+verdicts are ignored) -- what the GPU side alone sustains with S contexts.  Tells how far the host hash is from mattering.
+The switch exists only in an experiment build of the library: `make -C ark_vrf_amd/csrc clean all EXTRA=-DAVRF_EXPERIMENTS`
+(rebuild without EXTRA afterwards); against the shipped build this script measures the ordinary pipeline."""
 import os
 import sys
 import threading
