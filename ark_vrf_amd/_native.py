@@ -63,6 +63,11 @@ def device_count():
     return lib().avrf_device_count()
 
 
+def set_blocking_sync(device=0, on=True):
+    """avrf_device_set_blocking_sync: waiting host threads sleep instead of spinning (device-wide)."""
+    return lib().avrf_device_set_blocking_sync(int(device), 1 if on else 0)
+
+
 class Batch:
     """Host-side packed batch in the C-ABI layout (see include/avrf.h)."""
 

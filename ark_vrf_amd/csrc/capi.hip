@@ -154,6 +154,14 @@ int avrf_device_count(void) {
   return n;
 }
 
+int avrf_device_set_blocking_sync(int device, int on) {
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
+  const hipError_t e = hipSetDeviceFlags(on ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto);
+  (void)hipSetDevice(prev);
+  return e == hipSuccess ? AVRF_OK : AVRF_ERR_NO_DEVICE;
+}
+
 int avrf_ctx_create(int suite, int device, avrf_ctx **out) {
   if (!out || suite < 0 || suite >= AVRF_N_SUITES) return AVRF_ERR_BAD_ARG;
   *out = nullptr;

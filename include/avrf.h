@@ -56,6 +56,10 @@ typedef struct avrf_ctx avrf_ctx;
 const char *avrf_version(void);
 /* Number of visible HIP devices (0 when there is none; never initialises a context). */
 int avrf_device_count(void);
+/* How host threads wait for `device`: on = 1 sleeps in the driver until the stream is done (hipDeviceScheduleBlockingSync), on = 0
+ * restores the runtime's default (a yielding spin).  A process that runs many contexts under a CPU quota wants 1: a spinning waiter
+ * burns the cores the weight hashes of the other contexts need.  Device-wide, so the caller decides; AVRF_OK / AVRF_ERR_NO_DEVICE. */
+int avrf_device_set_blocking_sync(int device, int on);
 
 /* One engine instance: suite parameterisation (trait Suite, src/lib.rs:177-250) + one HIP
  * stream + device workspace on `device`. */

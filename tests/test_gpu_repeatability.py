@@ -41,3 +41,30 @@ def test_interleaved_suites_repeat(golden_dir):
             assert c.pedersen_verify(Batch.from_items(ios, ads, proofs=[pr[256 * j: 256 * j + 256] for j in range(7)])) == [0] * 7, (rnd, s)
     for c, *_ in work.values():
         c.close()
+
+
+def test_blocking_wait_changes_nothing_but_the_wait(golden_dir):
+    """avrf_device_set_blocking_sync: the host threads sleep while they wait; verdicts and bytes are those of the default mode."""
+    from ark_vrf_amd import _native as nat
+    from ark_vrf_amd._native import Batch
+    from helpers import xy
+    s = 0
+    vs = json.load(open(os.path.join(golden_dir, NAMES[s] + "_thin.json")))
+    sks = [bytes.fromhex(v["sk"]) for v in vs]
+    pks = [xy(s, bytes.fromhex(v["pk"])) for v in vs]
+    ios = [[(xy(s, bytes.fromhex(v["h"])), xy(s, bytes.fromhex(v["gamma"])))] for v in vs]
+    ads = [bytes.fromhex(v["ad"]) for v in vs]
+    c = nat.Context(s)
+    spin = c.thin_prove(Batch.from_items(ios, ads, sks=sks, pks_xy=pks))
+    assert nat.set_blocking_sync(0, True) == 0
+    try:
+        assert c.thin_prove(Batch.from_items(ios, ads, sks=sks, pks_xy=pks)) == spin
+        tp = [spin[96 * j: 96 * j + 96] for j in range(len(vs))]
+        assert c.thin_verify(Batch.from_items(ios, ads, pks_xy=pks, proofs=tp)) == [0] * len(vs)
+        assert c.thin_batch_verify(pks, ios, ads, tp) == 0
+        bad = [tp[0][:95] + bytes([tp[0][95] ^ 1])] + tp[1:]
+        assert c.thin_batch_verify(pks, ios, ads, bad) != 0
+    finally:
+        assert nat.set_blocking_sync(0, False) == 0
+    assert nat.set_blocking_sync(99, True) != 0          # no such device
+    c.close()
