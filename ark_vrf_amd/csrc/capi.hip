@@ -156,9 +156,10 @@ int avrf_device_count(void) {
 
 int avrf_device_set_blocking_sync(int device, int on) {
   int prev = 0;
-  if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
+  if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return AVRF_ERR_NO_DEVICE; }
   const hipError_t e = hipSetDeviceFlags(on ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto);
   (void)hipSetDevice(prev);
+  if (e != hipSuccess) (void)hipGetLastError();          // the runtime's last-error slot is sticky: later calls of this thread poll it
   return e == hipSuccess ? AVRF_OK : AVRF_ERR_NO_DEVICE;
 }
 

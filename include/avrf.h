@@ -58,7 +58,8 @@ const char *avrf_version(void);
 int avrf_device_count(void);
 /* How host threads wait for `device`: on = 1 sleeps in the driver until the stream is done (hipDeviceScheduleBlockingSync), on = 0
  * restores the runtime's default (a yielding spin).  A process that runs many contexts under a CPU quota wants 1: a spinning waiter
- * burns the cores the weight hashes of the other contexts need.  Device-wide, so the caller decides; AVRF_OK / AVRF_ERR_NO_DEVICE. */
+ * burns the cores the weight hashes of the other contexts need.  Device-wide, so the caller decides -- once, early, before the
+ * contexts are created (that is the tested use); AVRF_OK / AVRF_ERR_NO_DEVICE. */
 int avrf_device_set_blocking_sync(int device, int on);
 
 /* One engine instance: suite parameterisation (trait Suite, src/lib.rs:177-250) + one HIP
