@@ -105,6 +105,9 @@ int avrf_ring_vrf_prove(avrf_ctx *ctx, avrf_ring_key *key, size_t ring_proof_len
                         const uint8_t *ios_xy, const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, int blinding_mode,
                         uint8_t *proofs_out) {
   if (!ctx || !key || (n && (!sks || !key_index || !io_counts || !ad_lens || !proofs_out))) return AVRF_ERR_BAD_ARG;
+  // the ring proof's length is a property of the key's setup: the argument only states the caller's layout and must agree
+  avrf_ring_setup *setup = avrf_ring_key_setup(key);
+  if (!setup || avrf_ring_setup_suite(setup) != avrf_ctx_suite_(ctx) || ring_proof_len != avrf_ring_proof_len(setup)) return AVRF_ERR_BAD_ARG;
   if (!n) return AVRF_OK;
   const size_t L = avrf_point_len(avrf_ctx_suite_(ctx)), pedlen = 3 * L + 64;
   std::vector<uint8_t> ped(n * 256), blind(n * 32), rp(n * ring_proof_len), comp(n * 3 * L), pts(n * 3 * 64);
@@ -129,6 +132,7 @@ int avrf_ring_vrf_verify(avrf_ctx *ctx, avrf_ring_setup *setup, size_t n, const 
                          const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs,
                          int validate, int each, int32_t *status_out) {
   if (!ctx || !setup || (n && (!ring_commitments || !n_rings || !io_counts || !ad_lens || !proofs)) || (each && n && !status_out)) return AVRF_ERR_BAD_ARG;
+  if (avrf_ring_setup_suite(setup) != avrf_ctx_suite_(ctx)) return AVRF_ERR_BAD_ARG;
   if (!n) return AVRF_OK;
   const size_t L = avrf_point_len(avrf_ctx_suite_(ctx)), pedlen = 3 * L + 64;
   const size_t rlen = avrf_ring_proof_len(setup), plen = pedlen + rlen, tot = sum_counts(io_counts, n);

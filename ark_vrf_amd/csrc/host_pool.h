@@ -1,0 +1,105 @@
+// host_pool.h -- one bounded, persistent pool of host worker threads for the per-proof bookkeeping between device rounds
+// (ring prover / verifiers: transcripts, witness accumulators, decompression; the reference runs the same per-item
+// preparation under rayon, src/ring.rs:1081-1086).
+//
+// Every context of the process shares the pool.  Its size is the CPU quota of the job (cgroup v2 `cpu.max`, else the
+// affinity mask / hardware concurrency), capped at 32 -- a box of the GPU pool reports 256 hardware threads and grants
+// 16 CPUs, and N ranks x several contexts each spawning 32 threads per call (what this replaced) oversubscribed exactly the
+// cores the other contexts' hashes needed.  AVRF_HOST_THREADS overrides the size.
+// The calling thread works on its own job too, so a job always makes progress even when every worker is busy elsewhere.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <sched.h>
+
+namespace avrf {
+
+// CPUs this process may use at once: cgroup v2 quota / period (rounded up), bounded by the affinity mask
+inline size_t host_cpu_quota() {
+  size_t n = std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) { int c = CPU_COUNT(&set); if (c > 0 && (size_t)c < n) n = (size_t)c; }
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64] = {0}; long long period = 0;
+    if (fscanf(f, "%63s %lld", q, &period) == 2 && period > 0 && q[0] != 'm') {
+      long long quota = atoll(q);
+      if (quota > 0) { size_t c = (size_t)((quota + period - 1) / period); if (c >= 1 && c < n) n = c; }
+    }
+    fclose(f);
+  }
+  return n ? n : 1;
+}
+
+class HostPool {
+  struct Job {
+    const std::function<void(size_t)> *fn; size_t n;
+    std::atomic<size_t> next{0}, done{0};
+  };
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_done_;
+  std::deque<std::shared_ptr<Job>> jobs_;
+  std::vector<std::thread> workers_;
+
+  // take items of `j` until none is left; true when this call finished the job's last item
+  bool drain(Job &j) {
+    bool last = false;
+    for (size_t i; (i = j.next.fetch_add(1, std::memory_order_relaxed)) < j.n;) {
+      (*j.fn)(i);
+      if (j.done.fetch_add(1, std::memory_order_acq_rel) + 1 == j.n) last = true;
+    }
+    return last;
+  }
+  void worker() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      while (!jobs_.empty() && jobs_.front()->next.load(std::memory_order_relaxed) >= jobs_.front()->n) jobs_.pop_front();
+      if (jobs_.empty()) { cv_work_.wait(lk); continue; }
+      std::shared_ptr<Job> j = jobs_.front();
+      lk.unlock();
+      const bool last = drain(*j);
+      lk.lock();
+      if (last) cv_done_.notify_all();
+    }
+  }
+  explicit HostPool(size_t nthreads) {
+    for (size_t t = 0; t < nthreads; t++) workers_.emplace_back([this] { worker(); });
+    for (auto &w : workers_) w.detach();      // the pool lives as long as the process
+  }
+
+ public:
+  size_t size() const { return workers_.size() + 1; }
+  static HostPool &get() {
+    static HostPool *p = [] {
+      size_t nt = host_cpu_quota(); if (nt > 32) nt = 32;
+      if (const char *e = getenv("AVRF_HOST_THREADS")) { long v = atol(e); if (v >= 1 && v <= 256) nt = (size_t)v; }
+      return new HostPool(nt > 1 ? nt - 1 : 0);   // + the calling thread
+    }();
+    return *p;
+  }
+  // fn(i) for every i < n, on the pool and the calling thread; returns when all are done
+  void run(size_t n, const std::function<void(size_t)> &fn) {
+    if (n == 0) return;
+    if (n == 1 || workers_.empty()) { for (size_t i = 0; i < n; i++) fn(i); return; }
+    auto j = std::make_shared<Job>(); j->fn = &fn; j->n = n;
+    { std::lock_guard<std::mutex> lk(mu_); jobs_.push_back(j); }
+    cv_work_.notify_all();
+    drain(*j);
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return j->done.load(std::memory_order_acquire) == j->n; });
+  }
+};
+
+template <class Fn> static void parallel_for(size_t n, Fn fn) {
+  const std::function<void(size_t)> f = [&](size_t i) { fn(i); };
+  HostPool::get().run(n, f);
+}
+
+}  // namespace avrf

@@ -18,6 +18,7 @@
 #include "pairing.h"
 #include "suite_dispatch.h"
 #include "host_shake128.h"
+#include "host_pool.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -373,16 +374,7 @@ template <class S, class G> struct RingTypes {
   static constexpr int FQB = G::Fq::N * 4;            // bytes of a G1 coordinate
 };
 
-// host-side data parallelism over the proofs of a chunk (the per-proof O(N) bookkeeping between device rounds)
-template <class Fn> static void parallel_for(size_t n, Fn fn) {
-  size_t nt = std::thread::hardware_concurrency(); if (nt > 32) nt = 32; if (nt > n) nt = n;
-  if (const char *e = getenv("AVRF_HOST_THREADS")) { long v = atol(e); if (v >= 1 && v <= 256) nt = (size_t)v < n ? (size_t)v : n; }
-  if (nt <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
-  std::atomic<size_t> next{0};
-  std::vector<std::thread> th;
-  for (size_t t = 0; t < nt; t++) th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) fn(i); });
-  for (auto &x : th) x.join();
-}
+// host-side data parallelism over the proofs of a chunk: parallel_for of host_pool.h (one bounded persistent pool per process)
 
 // int_BE(48 bytes) mod r, Montgomery form
 template <class F> static H256 fr_from_be48(const uint8_t b[48]) {
@@ -1503,6 +1495,13 @@ size_t avrf_ring_max_ring_size(const avrf_ring_setup *su) { return su ? su->keys
 size_t avrf_ring_domain_size(const avrf_ring_setup *su) { return su ? su->N : 0; }
 size_t avrf_ring_proof_len(const avrf_ring_setup *su) { return su ? (su->curve == 0 ? 592 : 480) : 0; }
 size_t avrf_ring_commitment_len(const avrf_ring_setup *su) { return su ? (su->curve == 0 ? 144 : 96) : 0; }
+int avrf_ring_setup_suite(const avrf_ring_setup *su) { return su ? su->suite : -1; }
+avrf_ring_setup *avrf_ring_key_setup(const avrf_ring_key *key) { return key ? key->setup : nullptr; }
+int avrf_ring_setup_plan(const avrf_ring_setup *su, int32_t out[4]) {
+  if (!su || !out) return AVRF_ERR_BAD_ARG;
+  out[0] = su->table_c; out[1] = su->table_nwin; out[2] = su->wit_c; out[3] = su->wit_nwin;   // the witness table is built on first proof
+  return AVRF_OK;
+}
 
 int avrf_ring_index(avrf_ring_setup *su, const uint8_t *pks_xy, size_t n_keys, avrf_ring_key **out, uint8_t *commitment_out) {
   if (!su || !out || (n_keys && !pks_xy)) return AVRF_ERR_BAD_ARG;

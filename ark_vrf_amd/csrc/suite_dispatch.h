@@ -18,6 +18,15 @@ template <class F> inline auto with_suite(int suite, F &&f) {
     default: return f(SuiteTag<SuiteBandersnatch>{});
   }
 }
+// compile-time id -> Suite (the per-suite translation units, -DAVRF_TU_SUITE=<id>)
+template <int K> struct suite_by_id;
+template <> struct suite_by_id<0> { using type = SuiteBandersnatch; };
+template <> struct suite_by_id<1> { using type = SuiteBabyJubJub; };
+template <> struct suite_by_id<2> { using type = SuiteJubJub; };
+template <> struct suite_by_id<3> { using type = SuiteEd25519; };
+template <> struct suite_by_id<4> { using type = SuiteBandersnatchSW; };
+template <> struct suite_by_id<5> { using type = SuiteBandersnatchShake; };
+template <> struct suite_by_id<6> { using type = SuiteTesting; };
 // RingSuite::Pairing (src/suites/{bandersnatch,jubjub}.rs: BLS12-381; baby_jubjub.rs: BN254): 0 BLS12-381, 1 BN254
 inline int pairing_curve_of(int suite) { return suite == 1 ? 1 : 0; }
 // trait RingSuite (src/ring.rs:97-150) is implemented for the suites whose base field is a pairing curve's scalar field

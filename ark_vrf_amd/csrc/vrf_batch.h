@@ -42,4 +42,31 @@ void launch_compress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out,
 void launch_validate_xy(int suite, const uint8_t *d_base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *d_flags,
                         int32_t *d_rec_status, hipStream_t st);
 
+// Per-suite launch tables.  vrf_batch.hip / vrf_single.hip are compiled once per suite (-DAVRF_TU_SUITE=<id>), each such unit
+// holding the kernels of one suite and the explicit instantiation of these two structs for it; the unit compiled without
+// the macro holds only the launch_* dispatchers above, which resolve to the instantiations at link time (csrc/Makefile).
+template <class S> struct BatchOps {
+  static void thin_prepare(const BatchDev &b, uint32_t *d_c, uint32_t *d_z, uint32_t *d_flags, hipStream_t st);
+  static void thin_terms(const BatchDev &b, const Seed64 &seed, uint64_t j0, const uint32_t *d_c, const uint32_t *d_z,
+                         uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st);
+  static void ped_prepare(const BatchDev &b, uint32_t *d_c, uint8_t *d_merged, uint32_t *d_flags, hipStream_t st);
+  static void ped_terms(const BatchDev &b, const Seed64 &seed, uint64_t j0, const uint32_t *d_c, const uint8_t *d_merged,
+                        uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st);
+};
+template <class S> struct SingleOps {
+  static void fixed_table(te_pre_raw *d_tab, hipStream_t st);
+  static void smul(const uint8_t *d_scalars, const uint8_t *d_points_xy, uint32_t n, uint8_t *d_out, uint32_t *d_flags,
+                   const te_pre_raw *d_fixed, hipStream_t st);
+  static void thin_prove(const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny);
+  static void tiny_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
+  static void thin_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
+  static void ped_prove(const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st);
+  static void ped_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
+  static void hash_to_curve(const uint8_t *d_data, const uint32_t *d_off, uint32_t n, uint8_t *d_out, int32_t *d_status, hipStream_t st);
+  static void decompress(const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st);
+  static void validate_xy(const uint8_t *d_base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *d_flags,
+                          int32_t *d_rec_status, hipStream_t st);
+  static void compress(const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st);
+};
+
 }  // namespace avrf

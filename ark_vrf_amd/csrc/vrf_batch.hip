@@ -12,6 +12,7 @@
 #include "suite_dispatch.h"
 
 namespace avrf {
+#ifdef AVRF_TU_SUITE      // per-suite unit: the kernels of one suite + BatchOps<S> (vrf_batch.h)
 
 template <class S>
 __global__ void __launch_bounds__(128)
@@ -259,37 +260,52 @@ k_ped_terms(BatchDev b, Seed64 seed, uint64_t j0, const uint32_t *__restrict__ c
   if (threadIdx.x == 0) store_fp(bpart + 8 * (size_t)blockIdx.x, red[0]);
 }
 
+template <class S> void BatchOps<S>::ped_prepare(const BatchDev &b, uint32_t *d_c, uint8_t *d_merged, uint32_t *d_flags, hipStream_t st) {
+  dim3 g((b.n + 127) / 128), blk(128);
+  hipLaunchKernelGGL(k_ped_prepare<S>, g, blk, 0, st, b, d_c, d_merged, d_flags);
+}
+template <class S> void BatchOps<S>::ped_terms(const BatchDev &b, const Seed64 &seed, uint64_t j0, const uint32_t *d_c, const uint8_t *d_merged,
+                                               uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st) {
+  dim3 g((b.n + 127) / 128), blk(128);
+  uint32_t *bp = d_gpart + 8 * (size_t)g.x;
+  hipLaunchKernelGGL(k_ped_terms<S>, g, blk, 0, st, b, seed, j0, d_c, d_merged, d_scalars, (te_pre *)d_pre, d_gpart, bp);
+  hipLaunchKernelGGL(k_g_final<S>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 2, 0);
+  hipLaunchKernelGGL(k_g_final<S>, dim3(1), dim3(256), 0, st, bp, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 1);
+}
+template <class S> void BatchOps<S>::thin_prepare(const BatchDev &b, uint32_t *d_c, uint32_t *d_z, uint32_t *d_flags, hipStream_t st) {
+  dim3 g((b.n + 127) / 128), blk(128);
+  hipLaunchKernelGGL(k_thin_prepare<S>, g, blk, 0, st, b, d_c, d_z, d_flags);
+}
+template <class S> void BatchOps<S>::thin_terms(const BatchDev &b, const Seed64 &seed, uint64_t j0, const uint32_t *d_c, const uint32_t *d_z,
+                                                uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st) {
+  dim3 g((b.n + 127) / 128), blk(128);
+  hipLaunchKernelGGL(k_thin_terms<S>, g, blk, 0, st, b, seed, j0, d_c, d_z, d_scalars, (te_pre *)d_pre, d_gpart);
+  hipLaunchKernelGGL(k_g_final<S>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 0);
+}
+template struct BatchOps<suite_by_id<AVRF_TU_SUITE>::type>;
+
+#else   // run-time dispatch unit
+
+#define AVRF_BATCH(suite, CALL) with_suite((suite), [&](auto tag_) { using S_ = typename decltype(tag_)::type; BatchOps<S_>::CALL; })
+
 void launch_ped_prepare(int suite, const BatchDev &b, uint32_t *d_c, uint8_t *d_merged, uint32_t *d_flags, hipStream_t st) {
   if (!b.n) return;
-  dim3 g((b.n + 127) / 128), blk(128);
-  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type;
-    hipLaunchKernelGGL(k_ped_prepare<S>, g, blk, 0, st, b, d_c, d_merged, d_flags); });
+  AVRF_BATCH(suite, ped_prepare(b, d_c, d_merged, d_flags, st));
 }
 void launch_ped_terms(int suite, const BatchDev &b, const Seed64 &seed, uint64_t j0, const uint32_t *d_c, const uint8_t *d_merged,
                       uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st) {
   if (!b.n) return;
-  dim3 g((b.n + 127) / 128), blk(128);
-  uint32_t *bp = d_gpart + 8 * (size_t)g.x;
-  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type;
-    hipLaunchKernelGGL(k_ped_terms<S>, g, blk, 0, st, b, seed, j0, d_c, d_merged, d_scalars, (te_pre *)d_pre, d_gpart, bp);
-    hipLaunchKernelGGL(k_g_final<S>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 2, 0);
-    hipLaunchKernelGGL(k_g_final<S>, dim3(1), dim3(256), 0, st, bp, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 1); });
+  AVRF_BATCH(suite, ped_terms(b, seed, j0, d_c, d_merged, d_scalars, d_pre, d_gpart, n_terms, st));
 }
-
 void launch_thin_prepare(int suite, const BatchDev &b, uint32_t *d_c, uint32_t *d_z, uint32_t *d_flags, hipStream_t st) {
   if (!b.n) return;
-  dim3 g((b.n + 127) / 128), blk(128);
-  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type;
-    hipLaunchKernelGGL(k_thin_prepare<S>, g, blk, 0, st, b, d_c, d_z, d_flags); });
+  AVRF_BATCH(suite, thin_prepare(b, d_c, d_z, d_flags, st));
 }
-
 void launch_thin_terms(int suite, const BatchDev &b, const Seed64 &seed, uint64_t j0, const uint32_t *d_c, const uint32_t *d_z,
                        uint32_t *d_scalars, te_pre_raw *d_pre, uint32_t *d_gpart, uint32_t n_terms, hipStream_t st) {
   if (!b.n) return;
-  dim3 g((b.n + 127) / 128), blk(128);
-  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type;
-    hipLaunchKernelGGL(k_thin_terms<S>, g, blk, 0, st, b, seed, j0, d_c, d_z, d_scalars, (te_pre *)d_pre, d_gpart);
-    hipLaunchKernelGGL(k_g_final<S>, dim3(1), dim3(256), 0, st, d_gpart, g.x, d_scalars, (te_pre *)d_pre, n_terms - 1, 0); });
+  AVRF_BATCH(suite, thin_terms(b, seed, j0, d_c, d_z, d_scalars, d_pre, d_gpart, n_terms, st));
 }
+#endif
 
 }  // namespace avrf

@@ -9,13 +9,15 @@
 //   k_smul           Secret::from_scalar / Secret::output  src/lib.rs:331-334,391-393
 // The merged I/O pair follows vrf_transcript_from_iter / merge_ios (src/utils/common.rs:181-202,
 // 389-419); any summation order gives the same group element.
+#include "vrf_batch.h"
 #include "proto_dev.h"
 #include "glv.h"
 #include "suite_dispatch.h"
 
-namespace avrf { struct te_pre_raw; }   // msm.h: the 96-byte storage form of te_pre
-
+// Built once per suite (-DAVRF_TU_SUITE=<id>: the kernels of that suite and the explicit instantiation of SingleOps<S>) and
+// once without it (the run-time dispatch below); csrc/Makefile.  One translation unit for all suites took eight minutes.
 namespace avrf {
+#ifdef AVRF_TU_SUITE
 
 // (I_m, O_m) = sum_i z_i * (I_i, O_i) over `m` caller pairs; z stream from `dseed`.
 // first_is_one: the first caller pair takes z = 1 (Pedersen); otherwise pair i takes chunk i (Thin,
@@ -77,7 +79,9 @@ k_smul(const uint8_t *__restrict__ scalars, const uint8_t *__restrict__ points_x
     f |= point_flags<S>(x, y) & FLAG_RANGE;
     p = pre_from_xy<S>(points_xy + 64 * (size_t)j);
   }
-  te_aff r = te_to_aff<S>(points_xy ? te_smul_glv<S>(p, k) : te_smul_fixed<S>(fixed, FIXED_G, k));
+  // a variable base may be ANY curve point here (this is plain `P * k`, src/lib.rs:391-393): the literal 4-bit-window product, not
+  // the endomorphism split, which equals k P only inside the prime-order subgroup (glv.h)
+  te_aff r = te_to_aff<S>(points_xy ? te_smul<S>(p, k, Fr::BITS) : te_smul_fixed<S>(fixed, FIXED_G, k));
   store_xy<S>(out_xy + 64 * (size_t)j, r);
   if (f) atomicOr(flags, f);
 }
@@ -540,60 +544,97 @@ k_compress(const uint8_t *__restrict__ in_xy, uint32_t n, uint8_t *__restrict__ 
   fp_store_le(out + 32 * (size_t)j, y);
 }
 
-// ---------------------------------------------------------------- launchers
+// ---------------------------------------------------------------- launchers (per-suite unit)
 
-#define AVRF_DISPATCH(suite, KERNEL, grid, block, st, ...)                                          \
-  with_suite((suite), [&](auto tag_) { using S_ = typename decltype(tag_)::type; hipLaunchKernelGGL(KERNEL<S_>, grid, block, 0, st, __VA_ARGS__); })
-
-void launch_fixed_table(int suite, struct te_pre_raw *d_tab, hipStream_t st) {
-  AVRF_DISPATCH(suite, k_fixed_table, dim3((FIXED_TABLE_POINTS + 127) / 128), dim3(128), st, (te_pre *)d_tab);
+template <class S> void SingleOps<S>::fixed_table(struct te_pre_raw *d_tab, hipStream_t st) {
+  hipLaunchKernelGGL(k_fixed_table<S>, dim3((FIXED_TABLE_POINTS + 127) / 128), dim3(128), 0, st, (te_pre *)d_tab);
 }
+template <class S> void SingleOps<S>::smul(const uint8_t *d_scalars, const uint8_t *d_points_xy, uint32_t n, uint8_t *d_out, uint32_t *d_flags,
+                                           const struct te_pre_raw *d_fixed, hipStream_t st) {
+  hipLaunchKernelGGL(k_smul<S>, dim3((n + 127) / 128), dim3(128), 0, st, d_scalars, d_points_xy, n, d_out, d_flags, (const te_pre *)d_fixed);
+}
+template <class S> void SingleOps<S>::thin_prove(const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny) {
+  const dim3 g((b.n + 127) / 128), bl(128);
+  if (tiny) hipLaunchKernelGGL((k_thin_prove<S, true>), g, bl, 0, st, b, d_proofs_out, d_flags);
+  else hipLaunchKernelGGL((k_thin_prove<S, false>), g, bl, 0, st, b, d_proofs_out, d_flags);
+}
+template <class S> void SingleOps<S>::tiny_verify(const BatchDev &b, int32_t *d_status, hipStream_t st) {
+  hipLaunchKernelGGL(k_tiny_verify<S>, dim3((b.n + 127) / 128), dim3(128), 0, st, b, d_status);
+}
+template <class S> void SingleOps<S>::thin_verify(const BatchDev &b, int32_t *d_status, hipStream_t st) {
+  hipLaunchKernelGGL(k_thin_verify<S>, dim3((b.n + 127) / 128), dim3(128), 0, st, b, d_status);
+}
+template <class S> void SingleOps<S>::ped_prove(const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st) {
+  hipLaunchKernelGGL(k_ped_prove<S>, dim3((b.n + 127) / 128), dim3(128), 0, st, b, d_proofs_out, d_blind, d_flags);
+}
+template <class S> void SingleOps<S>::ped_verify(const BatchDev &b, int32_t *d_status, hipStream_t st) {
+  hipLaunchKernelGGL(k_ped_verify<S>, dim3((b.n + 127) / 128), dim3(128), 0, st, b, d_status);
+}
+template <class S> void SingleOps<S>::hash_to_curve(const uint8_t *d_data, const uint32_t *d_off, uint32_t n, uint8_t *d_out, int32_t *d_status, hipStream_t st) {
+  hipLaunchKernelGGL(k_hash_to_curve<S>, dim3((n + 127) / 128), dim3(128), 0, st, d_data, d_off, n, d_out, d_status);
+}
+template <class S> void SingleOps<S>::decompress(const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st) {
+  hipLaunchKernelGGL(k_decompress<S>, dim3((n + 127) / 128), dim3(128), 0, st, d_in, n, d_out, validate, d_status);
+}
+template <class S> void SingleOps<S>::validate_xy(const uint8_t *d_base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *d_flags,
+                                                  int32_t *d_rec_status, hipStream_t st) {
+  const uint32_t tot = nrec * ppr;
+  hipLaunchKernelGGL(k_validate_xy<S>, dim3((tot + 127) / 128), dim3(128), 0, st, d_base, stride, ppr, nrec, level, d_flags, d_rec_status);
+}
+template <class S> void SingleOps<S>::compress(const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st) {
+  hipLaunchKernelGGL(k_compress<S>, dim3((n + 255) / 256), dim3(256), 0, st, d_in, n, d_out);
+}
+template struct SingleOps<suite_by_id<AVRF_TU_SUITE>::type>;
+
+}  // namespace avrf
+
+#else   // ---------------------------------------------------------------- run-time dispatch unit
+
+#define AVRF_SINGLE(suite, CALL) with_suite((suite), [&](auto tag_) { using S_ = typename decltype(tag_)::type; SingleOps<S_>::CALL; })
+
+void launch_fixed_table(int suite, struct te_pre_raw *d_tab, hipStream_t st) { AVRF_SINGLE(suite, fixed_table(d_tab, st)); }
 void launch_smul(int suite, const uint8_t *d_scalars, const uint8_t *d_points_xy, uint32_t n, uint8_t *d_out, uint32_t *d_flags,
                  const struct te_pre_raw *d_fixed, hipStream_t st) {
   if (!n) return;
-  AVRF_DISPATCH(suite, k_smul, dim3((n + 127) / 128), dim3(128), st, d_scalars, d_points_xy, n, d_out, d_flags, (const te_pre *)d_fixed);
+  AVRF_SINGLE(suite, smul(d_scalars, d_points_xy, n, d_out, d_flags, d_fixed, st));
 }
 void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny) {
   if (!b.n) return;
-  const dim3 g((b.n + 127) / 128), bl(128);
-  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type;
-    if (tiny) hipLaunchKernelGGL((k_thin_prove<S, true>), g, bl, 0, st, b, d_proofs_out, d_flags);
-    else hipLaunchKernelGGL((k_thin_prove<S, false>), g, bl, 0, st, b, d_proofs_out, d_flags); });
+  AVRF_SINGLE(suite, thin_prove(b, d_proofs_out, d_flags, st, tiny));
 }
 void launch_tiny_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st) {
   if (!b.n) return;
-  AVRF_DISPATCH(suite, k_tiny_verify, dim3((b.n + 127) / 128), dim3(128), st, b, d_status);
+  AVRF_SINGLE(suite, tiny_verify(b, d_status, st));
 }
 void launch_thin_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st) {
   if (!b.n) return;
-  AVRF_DISPATCH(suite, k_thin_verify, dim3((b.n + 127) / 128), dim3(128), st, b, d_status);
+  AVRF_SINGLE(suite, thin_verify(b, d_status, st));
 }
 void launch_ped_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st) {
   if (!b.n) return;
-  AVRF_DISPATCH(suite, k_ped_prove, dim3((b.n + 127) / 128), dim3(128), st, b, d_proofs_out, d_blind, d_flags);
+  AVRF_SINGLE(suite, ped_prove(b, d_proofs_out, d_blind, d_flags, st));
 }
 void launch_ped_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st) {
   if (!b.n) return;
-  AVRF_DISPATCH(suite, k_ped_verify, dim3((b.n + 127) / 128), dim3(128), st, b, d_status);
+  AVRF_SINGLE(suite, ped_verify(b, d_status, st));
 }
-
 void launch_hash_to_curve(int suite, const uint8_t *d_data, const uint32_t *d_off, uint32_t n, uint8_t *d_out, int32_t *d_status, hipStream_t st) {
   if (!n) return;
-  AVRF_DISPATCH(suite, k_hash_to_curve, dim3((n + 127) / 128), dim3(128), st, d_data, d_off, n, d_out, d_status);
+  AVRF_SINGLE(suite, hash_to_curve(d_data, d_off, n, d_out, d_status, st));
 }
 void launch_decompress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st) {
   if (!n) return;
-  AVRF_DISPATCH(suite, k_decompress, dim3((n + 127) / 128), dim3(128), st, d_in, n, d_out, validate, d_status);
+  AVRF_SINGLE(suite, decompress(d_in, n, d_out, validate, d_status, st));
 }
 void launch_validate_xy(int suite, const uint8_t *d_base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *d_flags,
                         int32_t *d_rec_status, hipStream_t st) {
   if (!nrec || !ppr || level <= 0) return;
-  const uint32_t tot = nrec * ppr;
-  AVRF_DISPATCH(suite, k_validate_xy, dim3((tot + 127) / 128), dim3(128), st, d_base, stride, ppr, nrec, level, d_flags, d_rec_status);
+  AVRF_SINGLE(suite, validate_xy(d_base, stride, ppr, nrec, level, d_flags, d_rec_status, st));
 }
 void launch_compress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st) {
   if (!n) return;
-  AVRF_DISPATCH(suite, k_compress, dim3((n + 255) / 256), dim3(256), st, d_in, n, d_out);
+  AVRF_SINGLE(suite, compress(d_in, n, d_out, st));
 }
 
 }  // namespace avrf
+#endif

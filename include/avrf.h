@@ -76,7 +76,17 @@ void avrf_ctx_destroy(avrf_ctx *ctx);
  *   level 1            every pk / I/O / proof point of avrf_{thin,pedersen}_{verify,batch_verify,batch_run,batch_challenges} must
  *                      be on the curve, else AVRF_INVALID_DATA (per item for the *_verify calls) before any equation is evaluated;
  *   level 2            additionally r * P = O for every point (one 253-bit scalar multiplication per point: opt-in).
- * The identity checks of the verifiers (src/thin.rs:140-149,266-271, src/pedersen.rs:204-213,348-353) are unconditional. */
+ * The identity checks of the verifiers (src/thin.rs:140-149,266-271, src/pedersen.rs:204-213,348-353) are unconditional.
+ *
+ * PRIME-ORDER-SUBGROUP MEMBERSHIP IS A HARD PRECONDITION of every prove / verify / batch-verify entry point at levels 0 and 1
+ * and of the wire flavour with validate = 0 -- exactly where the reference says "the caller must ensure ... otherwise the
+ * behaviour is undefined" (src/thin.rs:78-94).  The kernels exploit it: scalars are reduced mod r before they meet a point
+ * (one-pair forms (s z) I, (c z) O) and Bandersnatch multiplies through the GLV endomorphism, k P = k1 P + k2 psi(P) (glv.h),
+ * both of which equal the reference's literal products only inside the subgroup.  For an on-curve point with a 2- or
+ * 4-torsion component the verdict is unspecified and MAY DIFFER from the reference's: a consensus-critical caller that does
+ * not hold validated points must use level 2 / validate = 1, which answers AVRF_INVALID_DATA for such a point before any
+ * equation (tests/test_gpu_wire.py::test_torsion_points).  avrf_scalar_mul and avrf_msm_te compute literal products for
+ * any curve point. */
 int avrf_ctx_set_validation(avrf_ctx *ctx, int level);
 
 /* <S::Affine as AffineRepr>::Group::msm_unchecked(&bases, &scalars)
@@ -124,11 +134,15 @@ int avrf_pedersen_batch_partial(avrf_ctx *ctx, const uint8_t seed64[64], uint64_
  * iff the sum is the identity (0, 1). */
 int avrf_thin_batch_challenges(avrf_ctx *ctx, uint8_t *c_out);
 int avrf_batch_weight_seed(int suite, int pedersen, size_t n, const uint8_t *c16, const uint8_t *resp, uint8_t seed_out[64]);
-/* The same for `count` <= 8 batches in one pass: the chains of different batches are independent, so the library hashes the
- * transcripts can be hashed together, one batch per lane of an AVX-512 register (host_sha512_mb.h; inside avrf_*_batch_run
- * this is opt-in: AVRF_HASH_THREADS service threads, default 0 -- see capi.hip for the measurement).  seeds_out: count x 64 bytes.
- * AVRF_ERR_NO_DEVICE when the host CPU lacks AVX-512. */
+/* The same for `count` <= 8 batches in one pass: the chains of different batches are independent, so their transcripts are
+ * hashed together, one batch per lane of an AVX-512 register (host_sha512_mb.h: 3.6 x the hashes per core-second at twice
+ * the latency of one scalar chain).  Inside avrf_*_batch_run the same code runs behind AVRF_HASH_THREADS service threads
+ * (default 0; for hosts that grant a GPU fewer cores than its contexts have transcripts to hash -- bench.py turns it on
+ * from the CPU quota).  seeds_out: count x 64 bytes.  AVRF_ERR_NO_DEVICE when the host CPU lacks AVX-512. */
 int avrf_batch_weight_seeds_x8(int suite, int pedersen, int count, const size_t *n, const uint8_t *const *c16, const uint8_t *const *resp, uint8_t *seeds_out);
+/* SHA-512 of `count` <= 8 contiguous messages through that multi-buffer code (the form avrf_*_batch_run hands to the service:
+ * prefix || records in one buffer); digests_out: count x 64 bytes. */
+int avrf_sha512_x8(int count, const uint8_t *const *msgs, const size_t *lens, uint8_t *digests_out);
 /* (AVRF_ERR_BAD_ARG unless avrf_thin_batch_challenges succeeded on the CURRENT staging: re-staging or any other call that
  * stages -- avrf_thin_verify, a prover -- invalidates the challenges) */
 int avrf_thin_batch_partial(avrf_ctx *ctx, const uint8_t seed[64], uint64_t first_index, uint8_t out_xy[64]);
@@ -225,6 +239,12 @@ size_t avrf_ring_max_ring_size(const avrf_ring_setup *setup);   /* RingContext::
 size_t avrf_ring_domain_size(const avrf_ring_setup *setup);     /* piop_domain_size, src/ring.rs:819-821 */
 size_t avrf_ring_proof_len(const avrf_ring_setup *setup);       /* 592 (BLS12-381) / 480 (BN254) */
 size_t avrf_ring_commitment_len(const avrf_ring_setup *setup);  /* 144 / 96 */
+/* the suite a setup was loaded for (-1: NULL) and the setup a prover key was indexed on (owned by the caller as before) */
+int avrf_ring_setup_suite(const avrf_ring_setup *setup);
+avrf_ring_setup *avrf_ring_key_setup(const avrf_ring_key *key);
+/* how the prover's KZG commitments are laid out as fixed-base MSMs (for op counts in reports): out = { window bits and rows of
+ * the SRS window table, window bits and rows of the Lagrange-basis witness table (0 until the first proof builds it) } */
+int avrf_ring_setup_plan(const avrf_ring_setup *setup, int32_t out[4]);
 
 /* RingSetup::prover_key / verifier_key -> ring_proof::index (src/ring.rs:399-417): fixed columns of the
  * ring `pks_xy` (n_keys x 64) and their three KZG commitments.  commitment_out (may be NULL) receives the
@@ -325,13 +345,14 @@ int avrf_pedersen_verify_wire(avrf_ctx *ctx, size_t n, const uint8_t *ios, const
 /* ring::Prover::prove (src/ring.rs:211-226) as ONE call for n provers of the ring behind `key` (avrf_pedersen_prove +
  * avrf_ring_prove + serialisation): sks n x 32, key_index[i] = position of prover i's key in the ring, ios_xy as for
  * avrf_pedersen_prove; proofs_out: n x (160 + ring_proof_len) bytes, ring::Proof's compressed serialisation.
- * ring_proof_len = avrf_ring_proof_len(setup of the key). */
+ * ring_proof_len must equal avrf_ring_proof_len(avrf_ring_key_setup(key)) -- it states the caller's buffer layout and is
+ * checked, not trusted (AVRF_ERR_BAD_ARG otherwise, also when ctx and the key's setup are of different suites). */
 int avrf_ring_vrf_prove(avrf_ctx *ctx, avrf_ring_key *key, size_t ring_proof_len, size_t n, const uint8_t *sks, const uint32_t *key_index,
                         const uint8_t *ios_xy, const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, int blinding_mode,
                         uint8_t *proofs_out);
 /* ring::Verifier::verify for every item (each != 0: status_out[i] per proof; src/ring.rs:228-247) or ring::BatchVerifier over
  * all items (each == 0: the return value is the batch's status; src/ring.rs:693-735).  ios wire-format as above; proofs: n x
- * (160 + avrf_ring_proof_len(setup)).  Pedersen half on the context, ring half on the setup (same suite). */
+ * (160 + avrf_ring_proof_len(setup)).  Pedersen half on the context, ring half on the setup (same suite, else AVRF_ERR_BAD_ARG). */
 int avrf_ring_vrf_verify(avrf_ctx *ctx, avrf_ring_setup *setup, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,
                          const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs,
                          int validate, int each, int32_t *status_out);

@@ -202,3 +202,24 @@ def test_rccl_path_world_size_one():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_whole_path_on_rccl_world_size_one():
+    """bench.py as a RANK with a process group (AVRF_FORCE_DIST=1: backend nccl at world size 1): the headline loop, the
+    split-ONE-batch leg (sharded_thin_batch_verify) and BASELINE configs[3] sharded by index (sharded_ring_prove /
+    sharded_ring_batch_verify) -- the code an 8-GPU run executes, at sizes that take seconds."""
+    import json, subprocess, sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(AVRF_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--min-seconds", "0.2",
+                        "--items", "4096", "--ring-proofs", "64", "--ring-size", "64", "--no-cpu-baseline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["host"]["host_cpu_quota"] >= 1
+    m = out["multi_gpu"]
+    assert m["split_one_batch"]["value"] > 0, m
+    assert m["ring_sharded"]["ring_vrf_proofs_per_sec"] > 0 and m["ring_sharded"]["ranks"] == 1, m
+    assert out["additional_metrics"]["ring_vrf_batch_verifications_per_sec"] > 0

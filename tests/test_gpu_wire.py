@@ -77,6 +77,44 @@ def test_thin_tiny_pedersen_vectors_wire(ctxs, golden_dir, suite, validate):
 
 
 @pytest.mark.parametrize("suite", [0, 1])
+def test_torsion_points(ctxs, golden_dir, suite):
+    """Points with a torsion component, P' = P + (0, -1) = (-x, -y): on the curve, outside the prime-order subgroup
+    (include/avrf.h "PRIME-ORDER-SUBGROUP MEMBERSHIP IS A HARD PRECONDITION").
+    * avrf_scalar_mul is the literal product k P' for any curve point (Bandersnatch: NOT the GLV split, which is k P' only
+      inside the subgroup) -- equal to the oracle's double-and-add;
+    * Validate::Yes answers InvalidData for exactly the item that carries such a point, before any equation;
+    * Validate::No: that item's verdict is unspecified (it is some status), every other item is unaffected."""
+    c = ctxs[suite]
+    q = {0: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+         1: 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001}[suite]
+    th = json.load(open(os.path.join(golden_dir, f"{NAMES[suite]}_thin.json")))
+    pks = [bytes.fromhex(v["pk"]) for v in th]
+    ios = [[(bytes.fromhex(v["h"]), bytes.fromhex(v["gamma"]))] for v in th]
+    ads = [bytes.fromhex(v["ad"]) for v in th]
+    tp = [bytes.fromhex(v["proof_r"] + v["proof_s"]) for v in th]
+
+    def tweak(comp):
+        st, pxy = orc.point_decompress(suite, comp)
+        assert st == 0
+        x, y = int.from_bytes(pxy[:32], "little"), int.from_bytes(pxy[32:], "little")
+        txy = ((q - x) % q).to_bytes(32, "little") + ((q - y) % q).to_bytes(32, "little")
+        return orc.point_compress(suite, txy), txy
+    tw = [tweak(p) for p in pks]
+    ks = [bytes.fromhex(v["sk"]) for v in th]
+    got = c.scalar_mul(b"".join(ks), b"".join(t[1] for t in tw))
+    want = b"".join(orc.point_decompress(suite, orc.smul(suite, k, t[0]))[1] for k, t in zip(ks, tw))
+    assert got == want
+    one = [1] * 7
+    pks_t = pks[:4] + [tw[4][0]] + pks[5:]
+    assert _call("avrf_thin_verify_wire", c, 7, pks_t, ios, one, ads, tp, 1, True) == (0, [0, 0, 0, 0, 2, 0, 0])
+    assert _call("avrf_thin_batch_verify_wire", c, 7, pks_t, ios, one, ads, tp, 1, False)[0] == 2
+    rc, st = _call("avrf_thin_verify_wire", c, 7, pks_t, ios, one, ads, tp, 0, True)
+    assert rc == 0 and st[:4] + st[5:] == [0] * 6 and st[4] in (0, 1, 2)
+    ios_t = [list(x) for x in ios]; ios_t[2] = [(ios[2][0][0], tweak(ios[2][0][1])[0])]
+    assert _call("avrf_thin_verify_wire", c, 7, pks, ios_t, one, ads, tp, 1, True) == (0, [0, 0, 2, 0, 0, 0, 0])
+
+
+@pytest.mark.parametrize("suite", [0, 1])
 def test_ring_vrf_one_call(ctxs, golden_dir, suite):
     """ring::Prover::prove / ring::Verifier::verify / ring::BatchVerifier as single calls on the reference's ring vectors:
     with blinding disabled the 752 / 640-byte proof equals `proof_pk_com || proof_r || proof_ok || proof_s || proof_sb || ring_proof`."""
@@ -103,6 +141,13 @@ def test_ring_vrf_one_call(ctxs, golden_dir, suite):
         assert rc == 0
         want = bytes.fromhex(v["proof_pk_com"] + v["proof_r"] + v["proof_ok"] + v["proof_s"] + v["proof_sb"] + v["ring_proof"])
         assert bytes(out) == want
+        # the length argument is checked against the key's setup, a context of another suite is refused (nothing is written)
+        for bad_len in (rlen - 1, rlen + 16, 0):
+            assert L.avrf_ring_vrf_prove(c._h, key._h, C.c_size_t(bad_len), C.c_size_t(1), nat._u8(bytes.fromhex(v["sk"])), nat._u32([idx]), nat._u8(io_xy),
+                                         nat._u32([1]), nat._u8(ad), nat._u32([len(ad)]), 0, out) == nat.ERR_BAD_ARG
+        assert L.avrf_ring_vrf_prove(ctxs[1 - suite]._h, key._h, C.c_size_t(rlen), C.c_size_t(1), nat._u8(bytes.fromhex(v["sk"])), nat._u32([idx]), nat._u8(io_xy),
+                                     nat._u32([1]), nat._u8(ad), nat._u32([len(ad)]), 0, out) == nat.ERR_BAD_ARG
+        assert bytes(out) == want
         proofs.append(want); coms.append(key.commitment); ads.append(ad)
         ios_w.append(bytes.fromhex(v["h"]) + bytes.fromhex(v["gamma"]))
         key.close()
@@ -115,6 +160,8 @@ def test_ring_vrf_one_call(ctxs, golden_dir, suite):
         return rc, list(out)
     assert verify(proofs, True) == (0, [0] * n)
     assert verify(proofs, False)[0] == 0
+    assert L.avrf_ring_vrf_verify(ctxs[1 - suite]._h, setup._h, C.c_size_t(n), nat._u8(b"".join(coms)), C.c_size_t(n), nat._u32(list(range(n))), nat._u8(b"".join(ios_w)),
+                                  nat._u32([1] * n), nat._u8(b"".join(ads)), nat._u32([len(a) for a in ads]), nat._u8(b"".join(proofs)), 1, 1, (C.c_int32 * n)()) == nat.ERR_BAD_ARG
     bad = list(proofs); bad[3] = bad[3][:100] + bytes([bad[3][100] ^ 1]) + bad[3][101:]           # Pedersen response
     bad[5] = bad[5][:-10] + bytes([bad[5][-10] ^ 1]) + bad[5][-9:]                                   # ring opening proof
     rc, st = verify(bad, True)

@@ -113,3 +113,13 @@ def test_multibuffer_weight_hash_matches_scalar():
                 pytest.skip("host CPU without AVX-512")
             assert rc == 0
             assert [bytes(out)[64 * i: 64 * i + 64] for i in range(k)] == want
+            # the contiguous form the batch verifiers hand to the hash service, against an independent SHA-512
+            import hashlib
+            prefix = b"Bandersnatch-SHA512-ELL2-v1" + bytes([0x50])
+            msgs = [prefix + b"".join(c[16 * i: 16 * i + 16] + bytes(16) + r[rsz * i: rsz * i + rsz] for i in range(n)) for n, c, r in zip(sizes, cs, rs)]
+            mbuf = [C.create_string_buffer(m, len(m)) for m in msgs]
+            mp = (C.c_void_p * k)(*[C.cast(b, C.c_void_p) for b in mbuf])
+            ls = (C.c_size_t * k)(*[len(m) for m in msgs])
+            out2 = (C.c_uint8 * (64 * k))()
+            assert L.avrf_sha512_x8(k, mp, ls, out2) == 0
+            assert [bytes(out2)[64 * i: 64 * i + 64] for i in range(k)] == [hashlib.sha512(m).digest() for m in msgs] == want

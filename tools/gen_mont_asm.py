@@ -44,12 +44,20 @@ def fields(N):
     return out
 
 
-def body(N, sqr=False):
+def body(N, sqr=False, limbs=None, ninv=None):
     """the instruction list.  N = 8: %0..%7 = t (out, 32-bit), %8.. = a, %16.. = b.  N = 12: %0..%5 = t (out, 64-bit pairs),
     %6.. = a, %18.. = b.
     sqr: a only.  a^2 = sum_i a_i^2 B^2i + sum_i a_i B^i (2 A_>i) with A_>i = sum_{j>i} a_j B^j: the limbs of 2 A_>i are
     L_{i+1} = a_{i+1} << 1 at j = i + 1 and D_j = (a_j << 1) | (a_{j-1} >> 31) above (limb N is a_{N-1} >> 31 = 0: the top bit
-    of the modulus is clear), so the N (N - 1) / 2 cross products are single multiply-adds: N (N + 1) / 2 products instead of N^2."""
+    of the modulus is clear), so the N (N - 1) / 2 cross products are single multiply-adds: N (N + 1) / 2 products instead of N^2.
+
+    limbs / ninv given: the stream is specialised to the modulus.  P[0] = 1 (hence -p^-1 = 2^32 - 1; the BLS12-381 scalar field
+    = the Bandersnatch / JubJub base field): m_k = -lo is one subtraction instead of a multiplication, and m_k * P[0] = m_k only
+    has to turn the column's low word into zero with the carry [lo != 0] -- a compare and two add-with-carry instead of a
+    quarter-rate v_mad_u64_u32 + v_mul_lo_u32.  (P[1] = 2^32 - 1 of the same modulus is NOT special-cased: m * (2^32 - 1) =
+    (m << 32) - m into a 96-bit accumulator is five full-rate carry instructions against one multiply-add + one carry, a wash at
+    the measured 4.5 : 1 issue cost of v_mad_u64_u32 : v_add -- profiles/r2_ubench.txt.)"""
+    p0_is_one = limbs is not None and limbs[0] == 1 and ninv == 0xffffffff
     lay = LAYOUT[N]
     A0, T_BASE, M0 = lay["A0"], lay["T"], lay["M0"]
     n_out = N if N == 8 else N // 2
@@ -95,6 +103,17 @@ def body(N, sqr=False):
                 mac(k, av(i), LL(j) if j == i + 1 else D(j))
         for i in range(lo, min(hi, k - 1) + 1):
             mac(k, M(i), P(k - i))
+        fold = [f"v_add_co_u32 {A(k)}, vcc, {A(k)}, {T0}",
+                f"v_addc_co_u32 {A(k + 1)}, vcc, {A(k + 1)}, {T1}, vcc",
+                f"v_addc_co_u32 {A(k + 2)}, vcc, {A(k + 2)}, {T2}, vcc"]
+        if k < N and p0_is_one:
+            if k % 2:
+                L.extend(fold)                                           # the odd column's sum first: its low word is A(k)
+            L.append(f"v_sub_u32 {M(k)}, 0, {A(k)}")                      # m_k = -lo mod 2^32
+            L.append(f"v_cmp_ne_u32 vcc, 0, {A(k)}")                      # lo + m_k = 2^32 [lo != 0]: the word is done, its carry moves up
+            L.append(f"v_addc_co_u32 {A(k + 1)}, vcc, 0, {A(k + 1)}, vcc")
+            L.append(f"v_addc_co_u32 {A(k + 2)}, vcc, 0, {A(k + 2)}, vcc")
+            continue
         if k < N:
             if k % 2 == 0:
                 L.append(f"v_mul_lo_u32 {M(k)}, {A(k)}, s{S0 + N}")
@@ -103,9 +122,7 @@ def body(N, sqr=False):
                 L.append(f"v_mul_lo_u32 {M(k)}, {TMP}, s{S0 + N}")
             mac(k, M(k), P(0))
         if k % 2:
-            L.append(f"v_add_co_u32 {A(k)}, vcc, {A(k)}, {T0}")
-            L.append(f"v_addc_co_u32 {A(k + 1)}, vcc, {A(k + 1)}, {T1}, vcc")
-            L.append(f"v_addc_co_u32 {A(k + 2)}, vcc, {A(k + 2)}, {T2}, vcc")
+            L.extend(fold)
     if N == 8:
         for i in range(N):
             L.append(f"v_mov_b32 %{i}, {A(N + i)}")
@@ -120,6 +137,54 @@ def clobbers(N, sqr=False):
     extra = [f"v{lay['D0'] + j}" for j in range(2, N)] + [f"v{lay['L0'] + j}" for j in range(1, N)] if sqr else []
     return ([f"v{lay['A0'] + i}" for i in range(2 * N + 1)] + [f"v{lay['T'] + i}" for i in range(4)] + [f"v{lay['M0'] + i}" for i in range(N)]
             + extra + [f"s{S0 + i}" for i in range(N + 1)] + ["vcc"])
+
+
+def written_registers(ins):
+    """every register an instruction of the stream writes (destination operands incl. both halves of a pair, vcc)"""
+    w = set()
+    for line in ins:
+        op, rest = line.split(" ", 1)
+        o = [x.strip() for x in rest.split(",")]
+        dst = [o[0]] + (["vcc"] if len(o) > 1 and o[1] == "vcc" and op.endswith(("_co_u32", "u64_u32")) else [])
+        for d in dst:
+            if d.startswith("v["):
+                lo = int(d[2:d.index(":")]); hi = int(d[d.index(":") + 1:-1])
+                w.update(f"v{r}" for r in range(lo, hi + 1))
+            else:
+                w.add(d)
+    return w
+
+
+def check_clobbers(N, pre, ins, cl, n_out, label):
+    """the asm statement's contract with the register allocator: every physical register the stream writes is a declared
+    clobber, every %n it writes is an output operand, no input operand (%n >= n_out) is written, and an output is not written
+    before the last read of an input (outputs are not early-clobber, so the allocator may give an output an input's register)"""
+    w = written_registers(pre + ins)
+    phys = {r for r in w if not r.startswith("%")}
+    undeclared = phys - set(cl)
+    assert not undeclared, (label, "written but not in the clobber list", sorted(undeclared))
+    outs = {r for r in w if r.startswith("%")}
+    assert all(int(r[1:]) < n_out for r in outs), (label, "input operand written", sorted(outs))
+    first_out = min(i for i, line in enumerate(ins) if line.split(" ", 1)[1].split(",")[0].strip().startswith("%"))
+    import re as _re
+    last_in = max(i for i, line in enumerate(ins) if any(int(x) >= n_out for x in _re.findall(r"%(\d+)", line.split(" ", 1)[1].split(",", 1)[1] if "," in line else "")))
+    assert first_out > last_in, (label, "an output is written while inputs are still live", first_out, last_in)
+    # reads of physical registers must have been written earlier in the stream (no dependence on the caller's values)
+    seen = set()
+    for line in pre + ins:
+        op, rest = line.split(" ", 1)
+        o = [x.strip() for x in rest.split(",")]
+        srcs = o[1:] if not (len(o) > 1 and o[1] == "vcc" and op.endswith(("_co_u32", "u64_u32"))) else o[2:]
+        for x in srcs:
+            regs = []
+            if x.startswith("v["):
+                lo = int(x[2:x.index(":")]); hi = int(x[x.index(":") + 1:-1]); regs = [f"v{r}" for r in range(lo, hi + 1)]
+            elif _re.fullmatch(r"[vs]\d+", x) or x == "vcc":
+                regs = [x]
+            for r in regs:
+                assert r in seen, (label, "reads a register the stream has not written", r, line)
+        seen |= written_registers([line])
+    return len(phys)
 
 
 def emulate(N, ins, limbs, ninv, a, b):
@@ -165,6 +230,11 @@ def emulate(N, ins, limbs, ninv, a, b):
             reg[o[0]] = (((rd(o[1]) << 32) | rd(o[2])) >> int(o[3])) & MASK
         elif op == "v_add_u32":
             reg[o[0]] = (rd(o[1]) + rd(o[2])) & MASK
+        elif op == "v_sub_u32":
+            reg[o[0]] = (rd(o[1]) - rd(o[2])) & MASK
+        elif op == "v_cmp_ne_u32":
+            assert o[0] == "vcc"
+            vcc = 1 if rd(o[1]) != rd(o[2]) else 0
         elif op == "v_mul_lo_u32":
             reg[o[0]] = (rd(o[1]) * rd(o[2])) & MASK
         else:
@@ -174,10 +244,13 @@ def emulate(N, ins, limbs, ninv, a, b):
     return [x for i in range(N // 2) for x in (reg[f"%{i}"] & MASK, reg[f"%{i}"] >> 32)]
 
 
-def check(N, ins, fs, sqr=False, rounds=200):
+def check(N, fs, sqr=False, rounds=200):
     rng = random.Random(1)
     split = lambda v: [(v >> (32 * i)) & 0xffffffff for i in range(N)]
     for name, limbs, ninv in fs:
+        ins = body(N, sqr, limbs, ninv)
+        pre = prologue(N, limbs, ninv)
+        nreg = check_clobbers(N, pre, ins, clobbers(N, sqr), N if N == 8 else N // 2, name)
         p = sum(l << (32 * i) for i, l in enumerate(limbs))
         assert p < 1 << (32 * N - 1)
         rinv = pow(1 << (32 * N), -1, p)
@@ -185,12 +258,19 @@ def check(N, ins, fs, sqr=False, rounds=200):
             a, b = (rng.randrange(p) if r > 3 else p - 1 - r), (rng.randrange(p) if r > 1 else p - 1)
             if r == 4:
                 a = sum(0x80000000 << (32 * i) for i in range(N - 1))           # every carry-in bit of D set
+            if r == 5:
+                a = 0                                                            # every m_k = 0: no carry out of a finished word
+            if r == 6:
+                a, b = 1, 1
+            if r == 7:
+                a, b = (1 << (32 * N)) % p, rng.randrange(p)                     # Montgomery one: low words cancel exactly
             if sqr:
                 b = a
             t = emulate(N, ins, limbs, ninv, split(a), None if sqr else split(b))
             tv = sum(l << (32 * i) for i, l in enumerate(t))
             assert tv < 2 * p and tv % p == a * b * rinv % p, (name, hex(a), hex(b))
-        print(f"  emulator: {name} ({N} limbs, {'square' if sqr else 'product'}) ok on {rounds} operands")
+        print(f"  emulator: {name} ({N} limbs, {'square' if sqr else 'product'}) ok on {rounds} operands; {len(ins)} instructions, "
+              f"{sum(1 for y in ins if y.startswith('v_mad'))} v_mad_u64_u32; {nreg} physical registers written, all declared")
 
 
 def asm_fn(o, N, fname, pre, ins, cl, two):
@@ -212,13 +292,18 @@ def asm_fn(o, N, fname, pre, ins, cl, two):
     o.append("  }")
 
 
-def emit(o, N, fs, ins, ins_sqr):
+def prologue(N, limbs, ninv):
+    return [f"s_mov_b32 s{S0 + i}, 0x{limbs[i]:08x}" for i in range(N)] + [f"s_mov_b32 s{S0 + N}, 0x{ninv:08x}"]
+
+
+def emit(o, N, fs):
     o.append(f"template <class F> struct MontAsm{N} {{ static constexpr bool value = false; }};")
     o.append("")
     cnt = lambda x: f"{len(x)} VALU instructions ({sum(1 for y in x if y.startswith('v_mad'))} v_mad_u64_u32)"
-    o.append(f"// {N} limbs: product {cnt(ins)}, square {cnt(ins_sqr)}, + {N + 1} s_mov_b32 each")
     for name, limbs, ninv in fs:
-        pre = [f"s_mov_b32 s{S0 + i}, 0x{limbs[i]:08x}" for i in range(N)] + [f"s_mov_b32 s{S0 + N}, 0x{ninv:08x}"]
+        ins, ins_sqr = body(N, False, limbs, ninv), body(N, True, limbs, ninv)
+        pre = prologue(N, limbs, ninv)
+        o.append(f"// {name}: product {cnt(ins)}, square {cnt(ins_sqr)}, + {N + 1} s_mov_b32 each")
         o.append(f"template <> struct MontAsm{N}<{name}> {{")
         o.append("  static constexpr bool value = true;")
         o.append(f"  // t = a * b / 2^{32 * N} mod p, t < 2p (the caller subtracts p once)")
@@ -236,12 +321,11 @@ def main():
          "namespace avrf {", ""]
     for N in (8, 12):
         fs = fields(N)
-        ins, ins_sqr = body(N), body(N, True)
         if "--check" in sys.argv:
-            check(N, ins, fs)
-            check(N, ins_sqr, fs, True)
-        emit(o, N, fs, ins, ins_sqr)
-        print(f"{N} limbs: fields", [f[0] for f in fs], "instructions:", len(ins), "/", len(ins_sqr))
+            check(N, fs)
+            check(N, fs, True)
+        emit(o, N, fs)
+        print(f"{N} limbs: fields", [f[0] for f in fs])
     o.append("}  // namespace avrf")
     open(OUT, "w").write("\n".join(o) + "\n")
     print("wrote", OUT)
