@@ -2,10 +2,13 @@
 // (ring prover / verifiers: transcripts, witness accumulators, decompression; the reference runs the same per-item
 // preparation under rayon, src/ring.rs:1081-1086).
 //
-// Every context of the process shares the pool.  Its size is the CPU quota of the job (cgroup v2 `cpu.max`, else the
-// affinity mask / hardware concurrency), capped at 32 -- a box of the GPU pool reports 256 hardware threads and grants
-// 16 CPUs, and N ranks x several contexts each spawning 32 threads per call (what this replaced) oversubscribed exactly the
-// cores the other contexts' hashes needed.  AVRF_HOST_THREADS overrides the size.
+// Every context of the process shares the pool: min(64, CPUs in the affinity mask) threads, created once (what this replaced
+// spawned up to 32 std::threads per parallel_for call, several times per chunk, per context).  The size deliberately follows
+// the hardware threads the process may run on, NOT the cgroup CPU quota: the work between device rounds comes in short
+// bursts, and a CFS quota meters CPU time per period, not parallelism -- a burst spread over 32 hardware threads ends sooner
+// than the same burst on 16 and costs the same quota (measured on a 256-thread box with a 16-CPU quota, 4 contexts x 1024
+// proofs, gpurun_out/r3b: ring batch verification 135 / 183 / 201 k/s and independent verification 74 / 87 / 103 k/s with
+// 16 / 32 / 64 threads; the prover does not move: 11.2-11.3 k proofs/s).  AVRF_HOST_THREADS overrides the size.
 // The calling thread works on its own job too, so a job always makes progress even when every worker is busy elsewhere.
 #pragma once
 #include <atomic>
@@ -22,11 +25,16 @@
 
 namespace avrf {
 
-// CPUs this process may use at once: cgroup v2 quota / period (rounded up), bounded by the affinity mask
-inline size_t host_cpu_quota() {
+// hardware threads this process may run on
+inline size_t host_cpu_affinity() {
   size_t n = std::thread::hardware_concurrency();
   cpu_set_t set;
   if (sched_getaffinity(0, sizeof(set), &set) == 0) { int c = CPU_COUNT(&set); if (c > 0 && (size_t)c < n) n = (size_t)c; }
+  return n ? n : 1;
+}
+// CPU time this process may use, in CPUs: cgroup v2 quota / period (rounded up), bounded by the affinity mask
+inline size_t host_cpu_quota() {
+  size_t n = host_cpu_affinity();
   if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
     char q[64] = {0}; long long period = 0;
     if (fscanf(f, "%63s %lld", q, &period) == 2 && period > 0 && q[0] != 'm') {
@@ -78,7 +86,7 @@ class HostPool {
   size_t size() const { return workers_.size() + 1; }
   static HostPool &get() {
     static HostPool *p = [] {
-      size_t nt = host_cpu_quota(); if (nt > 32) nt = 32;
+      size_t nt = host_cpu_affinity(); if (nt > 64) nt = 64;
       if (const char *e = getenv("AVRF_HOST_THREADS")) { long v = atol(e); if (v >= 1 && v <= 256) nt = (size_t)v; }
       return new HostPool(nt > 1 ? nt - 1 : 0);   // + the calling thread
     }();
