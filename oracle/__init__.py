@@ -18,6 +18,7 @@ JUBJUB = 2
 ED25519 = 3
 TESTING_SHA256 = 6            # the crate's test suite: edwards25519 with HashTranscript<Sha256>
 BANDERSNATCH_SHAKE128 = 5     # Bandersnatch with the SHAKE128 transcript (XofTranscript<Shake128>)
+SECP256R1 = 7          # NIST P-256 with HashTranscript<Sha256>: a short-Weierstrass suite, compressed points are 33 bytes
 BANDERSNATCH_SW = 4    # Bandersnatch in its short-Weierstrass presentation: 33-byte serialised points (sw_encode / sw_decode)
 
 OK, VERIFICATION_FAILURE, INVALID_DATA = 0, 1, 2
@@ -59,27 +60,32 @@ def _u32(vals):
     return (C.c_uint32 * max(1, len(vals)))(*vals)
 
 
+def pt_len(suite):
+    """bytes of a compressed point at the oracle's entry points (suite_t.pt_len)"""
+    return 33 if suite == SECP256R1 else 32
+
+
 def from_seed(suite, seed):
-    sk, pk = _buf(32), _buf(32)
+    sk, pk = _buf(32), _buf(pt_len(suite))
     assert lib().orc_from_seed(suite, _u8(seed), sk, pk) == 0
     return _b(sk), _b(pk)
 
 
 def sk_to_pk(suite, sk):
-    pk = _buf(32)
+    pk = _buf(pt_len(suite))
     assert lib().orc_sk_to_pk(suite, _u8(sk), pk) == 0
     return _b(pk)
 
 
 def hash_to_curve(suite, data):
-    out = _buf(32)
+    out = _buf(pt_len(suite))
     st = lib().orc_hash_to_curve(suite, _u8(data), C.c_size_t(len(data)), out)
     assert st == 0, st
     return _b(out)
 
 
 def vrf_output(suite, sk, inp):
-    out = _buf(32)
+    out = _buf(pt_len(suite))
     assert lib().orc_vrf_output(suite, _u8(sk), _u8(inp), out) == 0
     return _b(out)
 
@@ -93,7 +99,7 @@ def point_to_hash(suite, pt, n=32):
 def thin_prove(suite, sk, ios, ad):
     """ios: list of (input32, output32)."""
     iob = b"".join(i + o for i, o in ios)
-    proof = _buf(64)
+    proof = _buf(pt_len(suite) + 32)
     st = lib().orc_thin_prove(suite, _u8(sk), _u8(iob), C.c_size_t(len(ios)), _u8(ad), C.c_size_t(len(ad)), proof)
     assert st == 0, st
     return _b(proof)
@@ -146,7 +152,7 @@ def thin_batch_terms(suite, pks, items_ios, ads, proofs):
 
 def pedersen_prove(suite, sk, ios, ad):
     iob = b"".join(i + o for i, o in ios)
-    proof, bl = _buf(160), _buf(32)
+    proof, bl = _buf(3 * pt_len(suite) + 64), _buf(32)
     st = lib().orc_pedersen_prove(suite, _u8(sk), _u8(iob), C.c_size_t(len(ios)), _u8(ad), C.c_size_t(len(ad)), proof, bl)
     assert st == 0, st
     return _b(proof), _b(bl)
@@ -190,19 +196,19 @@ def point_decompress(suite, pt, validate=False):
 
 
 def point_compress(suite, xy):
-    out = _buf(32)
+    out = _buf(pt_len(suite))
     assert lib().orc_point_compress(suite, _u8(xy), out) == 0
     return _b(out)
 
 
 def suite_point(suite, which):
-    out = _buf(32)
+    out = _buf(pt_len(suite))
     lib().orc_suite_point(suite, which, out)
     return _b(out)
 
 
 def smul(suite, k, pt):
-    out = _buf(32)
+    out = _buf(pt_len(suite))
     assert lib().orc_smul(suite, _u8(k), _u8(pt), out) == 0
     return _b(out)
 

@@ -47,7 +47,7 @@ typedef struct {
 typedef struct { u256 x, y; } te_aff;        /* Montgomery-form coordinates */
 typedef struct { u256 x, y, t, z; } te_ext;  /* extended twisted Edwards */
 
-enum { ORC_SUITE_BANDERSNATCH = 0, ORC_SUITE_BABYJUBJUB = 1, ORC_SUITE_JUBJUB = 2, ORC_SUITE_ED25519 = 3, ORC_SUITE_BANDERSNATCH_SW = 4, ORC_SUITE_BANDERSNATCH_SHAKE128 = 5, ORC_SUITE_TESTING_SHA256 = 6 };
+enum { ORC_SUITE_BANDERSNATCH = 0, ORC_SUITE_BABYJUBJUB = 1, ORC_SUITE_JUBJUB = 2, ORC_SUITE_ED25519 = 3, ORC_SUITE_BANDERSNATCH_SW = 4, ORC_SUITE_BANDERSNATCH_SHAKE128 = 5, ORC_SUITE_TESTING_SHA256 = 6, ORC_SUITE_SECP256R1 = 7 };
 enum { ORC_H2C_ELL2 = 0, ORC_H2C_TAI = 1, ORC_H2C_TAI_SW = 2 };
 
 typedef struct {
@@ -71,6 +71,12 @@ typedef struct {
      * ark-serialize SW form; the group arithmetic stays in the twisted-Edwards model through the maps. */
     int xof_shake;          /* Suite::Transcript = Shake128Transcript (src/suites/bandersnatch_shake128.rs) */
     int sw_codec;
+    /* a genuinely short-Weierstrass suite (src/suites/secp256r1.rs:49-70: NIST P-256, y^2 = x^3 - 3x + b, cofactor 1): no
+     * twisted-Edwards model exists, so the te_* group functions below compute in JACOBIAN coordinates for it (te_ext.x/y/z =
+     * X/Y/Z, identity Z = 0; te_aff = the SW affine point, (0, 0) = infinity) and the compressed form of a point is the
+     * 33-byte ark-serialize SW encoding.  Every protocol function above the group law is shared with the other suites. */
+    int sw_native;
+    int pt_len;             /* bytes of a compressed point at the oracle's entry points: 32, or 33 for sw_native */
     u256 mont_b, mont_a3, mont_binv, sw_a, sw_b;   /* Montgomery-model B, A/3, 1/B; SW coefficients; all in Montgomery form */
 } suite_t;
 
@@ -139,8 +145,8 @@ int  te_on_curve(const te_aff *p, const suite_t *s);
 int  te_in_subgroup(const te_aff *p, const suite_t *s);
 void te_smul(te_ext *o, const te_aff *p, const u256 *k_plain, const suite_t *s);
 /* ark-serialize compressed TE codec */
-void te_encode(uint8_t out[32], const te_aff *p, const suite_t *s);
-int  te_decode(te_aff *o, const uint8_t in[32], const suite_t *s);  /* 0 ok, else ORC_INVALID_DATA; no subgroup check */
+void te_encode(uint8_t *out /* pt_len */, const te_aff *p, const suite_t *s);
+int  te_decode(te_aff *o, const uint8_t *in /* pt_len */, const suite_t *s);  /* 0 ok, else ORC_INVALID_DATA; no subgroup check */
 /* canonical uncompressed x||y (LE32 each), non-Montgomery */
 void te_encode_xy(uint8_t out[64], const te_aff *p, const suite_t *s);
 int  te_decode_xy(te_aff *o, const uint8_t in[64], const suite_t *s);

@@ -62,6 +62,7 @@ void orc_msm_pippenger(te_ext *o, const te_aff *bases, const u256 *sc, size_t n,
     te_pre *pre = (te_pre *)malloc(n * sizeof(te_pre));
     for (size_t i = 0; i < n; i++) {
         pre[i].x = bases[i].x; pre[i].y = bases[i].y;
+        if (s->sw_native) continue;                                /* short-Weierstrass suite: te_madd below */
         mont_mul(&pre[i].k, &bases[i].x, &bases[i].y, FQ); mont_mul(&pre[i].k, &pre[i].k, &s->d, FQ);
     }
     /* signed digits: d in (-2^(c-1), 2^(c-1)] */
@@ -87,7 +88,11 @@ void orc_msm_pippenger(te_ext *o, const te_aff *bases, const u256 *sc, size_t n,
         for (size_t b = 0; b < nb; b++) te_identity(&bk[b], s);
         for (size_t i = 0; i < n; i++) {
             int32_t d = dig[i * nwin + w];
-            if (d > 0) madd_pre(&bk[d - 1], &pre[i], 0, s);
+            if (s->sw_native) {
+                te_aff q = bases[i]; if (d < 0) te_neg_aff(&q, &q, s);
+                if (d) { te_ext *b = &bk[(d > 0 ? d : -d) - 1]; te_madd(b, b, &q, s); }
+            }
+            else if (d > 0) madd_pre(&bk[d - 1], &pre[i], 0, s);
             else if (d < 0) madd_pre(&bk[-d - 1], &pre[i], 1, s);
         }
         te_ext run, sum; te_identity(&run, s); te_identity(&sum, s);

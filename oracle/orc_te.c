@@ -15,7 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-static suite_t g_suites[7];
+static suite_t g_suites[8];
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;      /* gen_batch() calls in from several threads at once */
 
 static void fq_dec(u256 *o, const char *dec, const mont_t *m) {
@@ -175,25 +175,91 @@ static void init_suites(void) {
     s->xof_shake = 2;
     fq_dec(&s->B.x, "3310617998588019043596181043598335786888094217571323926547956053100032777190", &s->fq);
     fq_dec(&s->B.y, "16824531136491949759823061604778551593864344614632277377095388820423530178202", &s->fq);
+
+    /* ---- Secp256r1-SHA256-TAI-v1 (src/suites/secp256r1.rs:49-70; curve: ark-secp256r1 = NIST P-256, SP 800-186 3.2.1.3):
+     * short Weierstrass a = -3, prime order (cofactor 1), 256-bit base and scalar fields with the top bit set,
+     * HashTranscript<Sha256>, try-and-increment on SW x-coordinates, 33-byte points ---- */
+    s = &g_suites[7];
+    memset(s, 0, sizeof *s);
+    s->id = ORC_SUITE_SECP256R1;
+    s->suite_id = "Secp256r1-SHA256-TAI-v1"; s->suite_id_len = 23;
+    u256_from_dec(&p, "115792089210356248762697446949407573530086143415290314195533631308867097853951");
+    mont_init(&s->fq, &p);
+    u256_from_dec(&p, "115792089210356248762697446949407573529996955224135760342422259061068512044369");
+    mont_init(&s->fr, &p);
+    s->cofactor = 1; s->h2c = ORC_H2C_TAI_SW; s->xof_shake = 2; s->sw_native = 1; s->pt_len = 33;
+    { u256 three; fq_small(&three, 3, &s->fq); mont_neg(&s->sw_a, &three, &s->fq); }
+    fq_dec(&s->sw_b, "41058363725152142129326129780047268409114441015993725554835256314039467401291", &s->fq);
+    fq_dec(&s->G.x, "48439561293906451759052585252797914202762949526041747995844080717082404635286", &s->fq);
+    fq_dec(&s->G.y, "36134250956749795798585127919587881956611106672985015071877198253568414405109", &s->fq);
+    fq_dec(&s->B.x, "100063053743935619201936855760019111820847755970243670581468062459849338000", &s->fq);     /* secp256r1.rs:57-65 */
+    fq_dec(&s->B.y, "113675507039234898358330549589155441528265243038226986303017485279501143145422", &s->fq);
+    for (int i = 0; i < 7; i++) if (!g_suites[i].pt_len) g_suites[i].pt_len = 32;
 }
 
 const suite_t *orc_suite(int id) {
     pthread_once(&g_once, init_suites);
-    if (id < 0 || id > 6) return NULL;
+    if (id < 0 || id > 7) return NULL;
     return &g_suites[id];
 }
+
+/* ---- short-Weierstrass group law for sw_native suites (a = -3), Jacobian coordinates.  Restates what the reference gets from
+ * ark_ec::short_weierstrass::{Affine, Projective} for ark_secp256r1 (third-party); formulas dbl-2001-b / add-2007-bl (EFD).
+ * Any correct group law yields the same group element; parity is on normalised encodings. ---- */
+#define FQ (&s->fq)
+static void swn_dbl(te_ext *o, const te_ext *p, const suite_t *s) {
+    u256 delta, gamma, beta, alpha, t0, t1, x3, y3, z3;
+    mont_sqr(&delta, &p->z, FQ); mont_sqr(&gamma, &p->y, FQ); mont_mul(&beta, &p->x, &gamma, FQ);
+    mont_sub(&t0, &p->x, &delta, FQ); mont_add(&t1, &p->x, &delta, FQ); mont_mul(&alpha, &t0, &t1, FQ);
+    mont_add(&t0, &alpha, &alpha, FQ); mont_add(&alpha, &t0, &alpha, FQ);                     /* 3 (X - delta)(X + delta) */
+    mont_add(&t0, &beta, &beta, FQ); mont_add(&t0, &t0, &t0, FQ);                             /* 4 beta */
+    mont_sqr(&x3, &alpha, FQ); mont_sub(&x3, &x3, &t0, FQ); mont_sub(&x3, &x3, &t0, FQ);
+    mont_add(&t1, &p->y, &p->z, FQ); mont_sqr(&z3, &t1, FQ); mont_sub(&z3, &z3, &gamma, FQ); mont_sub(&z3, &z3, &delta, FQ);
+    mont_sub(&t0, &t0, &x3, FQ); mont_mul(&y3, &alpha, &t0, FQ);
+    mont_sqr(&t1, &gamma, FQ); mont_add(&t1, &t1, &t1, FQ); mont_add(&t1, &t1, &t1, FQ); mont_add(&t1, &t1, &t1, FQ);   /* 8 gamma^2 */
+    mont_sub(&y3, &y3, &t1, FQ);
+    o->x = x3; o->y = y3; o->z = z3; memset(&o->t, 0, sizeof o->t);
+}
+static void swn_add(te_ext *o, const te_ext *p, const te_ext *q, const suite_t *s) {
+    if (u256_is_zero(&p->z)) { *o = *q; return; }
+    if (u256_is_zero(&q->z)) { *o = *p; return; }
+    u256 z1z1, z2z2, u1, u2, s1, s2, h, i, j, r, v, t0, x3, y3, z3;
+    mont_sqr(&z1z1, &p->z, FQ); mont_sqr(&z2z2, &q->z, FQ);
+    mont_mul(&u1, &p->x, &z2z2, FQ); mont_mul(&u2, &q->x, &z1z1, FQ);
+    mont_mul(&s1, &p->y, &q->z, FQ); mont_mul(&s1, &s1, &z2z2, FQ);
+    mont_mul(&s2, &q->y, &p->z, FQ); mont_mul(&s2, &s2, &z1z1, FQ);
+    mont_sub(&h, &u2, &u1, FQ); mont_sub(&r, &s2, &s1, FQ);
+    if (u256_is_zero(&h)) {
+        if (u256_is_zero(&r)) { swn_dbl(o, p, s); return; }
+        memset(o, 0, sizeof *o); o->x = s->fq.r1; o->y = s->fq.r1; return;                   /* P + (-P) */
+    }
+    mont_add(&r, &r, &r, FQ);
+    mont_add(&i, &h, &h, FQ); mont_sqr(&i, &i, FQ); mont_mul(&j, &h, &i, FQ); mont_mul(&v, &u1, &i, FQ);
+    mont_sqr(&x3, &r, FQ); mont_sub(&x3, &x3, &j, FQ); mont_sub(&x3, &x3, &v, FQ); mont_sub(&x3, &x3, &v, FQ);
+    mont_sub(&t0, &v, &x3, FQ); mont_mul(&y3, &r, &t0, FQ); mont_mul(&t0, &s1, &j, FQ); mont_add(&t0, &t0, &t0, FQ); mont_sub(&y3, &y3, &t0, FQ);
+    mont_add(&t0, &p->z, &q->z, FQ); mont_sqr(&t0, &t0, FQ); mont_sub(&t0, &t0, &z1z1, FQ); mont_sub(&t0, &t0, &z2z2, FQ); mont_mul(&z3, &t0, &h, FQ);
+    o->x = x3; o->y = y3; o->z = z3; memset(&o->t, 0, sizeof o->t);
+}
+#undef FQ
 
 /* ---- group law ---- */
 #define FQ (&s->fq)
 
 void te_identity(te_ext *o, const suite_t *s) {
-    memset(o, 0, sizeof *o); o->y = s->fq.r1; o->z = s->fq.r1;
+    memset(o, 0, sizeof *o); o->y = s->fq.r1;
+    if (s->sw_native) { o->x = s->fq.r1; return; }                 /* (1 : 1 : 0) */
+    o->z = s->fq.r1;
 }
 void te_from_aff(te_ext *o, const te_aff *a, const suite_t *s) {
+    if (s->sw_native) {
+        if (te_is_identity_aff(a, s)) { te_identity(o, s); return; }
+        memset(o, 0, sizeof *o); o->x = a->x; o->y = a->y; o->z = s->fq.r1; return;
+    }
     o->x = a->x; o->y = a->y; o->z = s->fq.r1; mont_mul(&o->t, &a->x, &a->y, FQ);
 }
 /* add-2008-hwcd (general a): 9M + 1*a + 1*d */
 void te_add(te_ext *o, const te_ext *p, const te_ext *q, const suite_t *s) {
+    if (s->sw_native) { swn_add(o, p, q, s); return; }
     u256 A, B, C, D, E, F, G, H, t0, t1;
     mont_mul(&A, &p->x, &q->x, FQ);
     mont_mul(&B, &p->y, &q->y, FQ);
@@ -211,6 +277,7 @@ void te_madd(te_ext *o, const te_ext *p, const te_aff *q, const suite_t *s) {
 }
 /* dbl-2008-hwcd */
 void te_dbl(te_ext *o, const te_ext *p, const suite_t *s) {
+    if (s->sw_native) { swn_dbl(o, p, s); return; }
     u256 A, B, C, D, E, F, G, H, t0;
     mont_sqr(&A, &p->x, FQ); mont_sqr(&B, &p->y, FQ);
     mont_sqr(&C, &p->z, FQ); mont_add(&C, &C, &C, FQ);
@@ -220,15 +287,24 @@ void te_dbl(te_ext *o, const te_ext *p, const suite_t *s) {
     mont_mul(&o->x, &E, &F, FQ); mont_mul(&o->y, &G, &H, FQ);
     mont_mul(&o->t, &E, &H, FQ); mont_mul(&o->z, &F, &G, FQ);
 }
-void te_neg_aff(te_aff *o, const te_aff *p, const suite_t *s) { mont_neg(&o->x, &p->x, FQ); o->y = p->y; }
+void te_neg_aff(te_aff *o, const te_aff *p, const suite_t *s) {
+    if (s->sw_native) { o->x = p->x; mont_neg(&o->y, &p->y, FQ); return; }
+    mont_neg(&o->x, &p->x, FQ); o->y = p->y;
+}
 
 void te_to_aff(te_aff *o, const te_ext *p, const suite_t *s) {
+    if (s->sw_native) {
+        if (u256_is_zero(&p->z)) { memset(o, 0, sizeof *o); return; }
+        u256 zi, zi2; mont_inv(&zi, &p->z, FQ); mont_sqr(&zi2, &zi, FQ);
+        mont_mul(&o->x, &p->x, &zi2, FQ); mont_mul(&zi2, &zi2, &zi, FQ); mont_mul(&o->y, &p->y, &zi2, FQ); return;
+    }
     u256 zi; mont_inv(&zi, &p->z, FQ);
     mont_mul(&o->x, &p->x, &zi, FQ); mont_mul(&o->y, &p->y, &zi, FQ);
 }
 /* CurveGroup::normalize_batch (Montgomery's trick), src/utils/common.rs:414 */
 void te_batch_to_aff(te_aff *o, const te_ext *p, size_t n, const suite_t *s) {
     if (!n) return;
+    if (s->sw_native) { for (size_t i = 0; i < n; i++) te_to_aff(&o[i], &p[i], s); return; }   /* (the oracle is not timed on this suite) */
     u256 *pre = (u256 *)malloc(n * sizeof(u256));
     u256 acc = s->fq.r1;
     for (size_t i = 0; i < n; i++) { pre[i] = acc; mont_mul(&acc, &acc, &p[i].z, FQ); }
@@ -241,13 +317,24 @@ void te_batch_to_aff(te_aff *o, const te_ext *p, size_t n, const suite_t *s) {
     free(pre);
 }
 int te_is_identity_ext(const te_ext *p, const suite_t *s) {
-    (void)s; return u256_is_zero(&p->x) && u256_cmp(&p->y, &p->z) == 0;
+    if (s->sw_native) return u256_is_zero(&p->z);
+    return u256_is_zero(&p->x) && u256_cmp(&p->y, &p->z) == 0;
 }
 int te_is_identity_aff(const te_aff *p, const suite_t *s) {
+    if (s->sw_native) return u256_is_zero(&p->x) && u256_is_zero(&p->y);
     return u256_is_zero(&p->x) && u256_cmp(&p->y, &s->fq.r1) == 0;
 }
 int te_eq_ext(const te_ext *p, const te_ext *q, const suite_t *s) {
     u256 a, b;
+    if (s->sw_native) {
+        int pi = u256_is_zero(&p->z), qi = u256_is_zero(&q->z);
+        if (pi || qi) return pi && qi;
+        u256 z1z1, z2z2; mont_sqr(&z1z1, &p->z, FQ); mont_sqr(&z2z2, &q->z, FQ);
+        mont_mul(&a, &p->x, &z2z2, FQ); mont_mul(&b, &q->x, &z1z1, FQ);
+        if (u256_cmp(&a, &b)) return 0;
+        mont_mul(&a, &p->y, &z2z2, FQ); mont_mul(&a, &a, &q->z, FQ); mont_mul(&b, &q->y, &z1z1, FQ); mont_mul(&b, &b, &p->z, FQ);
+        return u256_cmp(&a, &b) == 0;
+    }
     mont_mul(&a, &p->x, &q->z, FQ); mont_mul(&b, &q->x, &p->z, FQ);
     if (u256_cmp(&a, &b)) return 0;
     mont_mul(&a, &p->y, &q->z, FQ); mont_mul(&b, &q->y, &p->z, FQ);
@@ -255,6 +342,10 @@ int te_eq_ext(const te_ext *p, const te_ext *q, const suite_t *s) {
 }
 int te_on_curve(const te_aff *p, const suite_t *s) {
     u256 x2, y2, l, r;
+    if (s->sw_native) {                                            /* y^2 = x^3 + a x + b */
+        mont_sqr(&y2, &p->y, FQ); mont_sqr(&x2, &p->x, FQ); mont_add(&x2, &x2, &s->sw_a, FQ); mont_mul(&r, &x2, &p->x, FQ); mont_add(&r, &r, &s->sw_b, FQ);
+        return u256_cmp(&y2, &r) == 0;
+    }
     mont_sqr(&x2, &p->x, FQ); mont_sqr(&y2, &p->y, FQ);
     mont_mul(&l, &s->a, &x2, FQ); mont_add(&l, &l, &y2, FQ);
     mont_mul(&r, &x2, &y2, FQ); mont_mul(&r, &r, &s->d, FQ); mont_add(&r, &r, &s->fq.r1, FQ);
@@ -279,11 +370,13 @@ int te_in_subgroup(const te_aff *p, const suite_t *s) {
 static int fq_is_negative(const u256 *x_mont, const suite_t *s) { /* x > (q-1)/2 */
     u256 x; mont_from(&x, x_mont, FQ); return u256_cmp(&x, &s->fq.pm1_half) > 0;
 }
-void te_encode(uint8_t out[32], const te_aff *p, const suite_t *s) {
+void te_encode(uint8_t *out, const te_aff *p, const suite_t *s) {
+    if (s->sw_native) { sw_encode(out, p, s); return; }
     u256 y; mont_from(&y, &p->y, FQ); u256_to_le(out, &y);
     if (fq_is_negative(&p->x, s)) out[31] |= 0x80;
 }
-int te_decode(te_aff *o, const uint8_t in[32], const suite_t *s) {
+int te_decode(te_aff *o, const uint8_t *in, const suite_t *s) {
+    if (s->sw_native) return sw_decode(o, in, s);
     uint8_t b[32]; memcpy(b, in, 32);
     int neg = b[31] >> 7; b[31] &= 0x7f;
     u256 y; u256_from_le(&y, b);
@@ -330,6 +423,12 @@ static int te_from_sw_xy(te_aff *o, const u256 *x, const u256 *y, const suite_t 
 }
 void sw_encode(uint8_t out[33], const te_aff *p, const suite_t *s) {
     memset(out, 0, 33);
+    if (s->sw_native) {                                            /* the point IS the SW point: LE32(x) || flags */
+        if (te_is_identity_aff(p, s)) { out[32] = 0x40; return; }
+        u256 t; mont_from(&t, &p->x, FQ); u256_to_le(out, &t);
+        if (fq_is_negative(&p->y, s)) out[32] = 0x80;
+        return;
+    }
     if (te_is_identity_aff(p, s) || u256_is_zero(&p->x)) { out[32] = 0x40; return; }     /* infinity (the maps are undefined there) */
     u256 x, y, t; sw_xy_from_te(&x, &y, p, s);
     mont_from(&t, &x, FQ); u256_to_le(out, &t);
@@ -342,10 +441,16 @@ int sw_from_x(te_aff *o, const u256 *x_plain, int greatest, const suite_t *s) {
     mont_sqr(&t, &x, FQ); mont_add(&t, &t, &s->sw_a, FQ); mont_mul(&rhs, &t, &x, FQ); mont_add(&rhs, &rhs, &s->sw_b, FQ);
     if (!mont_sqrt(&y, &rhs, FQ)) return ORC_INVALID_DATA;
     if (fq_is_negative(&y, s) != (greatest != 0)) mont_neg(&y, &y, FQ);
+    if (s->sw_native) { o->x = x; o->y = y; return ORC_OK; }
     return te_from_sw_xy(o, &x, &y, s);
 }
 int sw_decode(te_aff *o, const uint8_t in[33], const suite_t *s) {
     if (in[32] & 0x3f) return ORC_INVALID_DATA;
+    if ((in[32] & 0x40) && s->sw_native) {              /* SWFlags::PointAtInfinity: x must be zero, no sign bit */
+        for (int i = 0; i < 32; i++) if (in[i]) return ORC_INVALID_DATA;
+        if (in[32] & 0x80) return ORC_INVALID_DATA;
+        memset(o, 0, sizeof *o); return ORC_OK;
+    }
     if (in[32] & 0x40) return ORC_INVALID_DATA;          /* infinity: no twisted-Edwards image (sw_to_te -> None) */
     u256 x; u256_from_le(&x, in);
     return sw_from_x(o, &x, (in[32] & 0x80) != 0, s);

@@ -31,7 +31,7 @@ static void absorb_u64(transcript_t *t, uint64_t v) {
     uint8_t b[8]; for (int i = 0; i < 8; i++) b[i] = (uint8_t)(v >> (8 * i)); tr_absorb(t, b, 8);
 }
 static void absorb_point(transcript_t *t, const te_aff *p, const suite_t *s) {
-    if (s->sw_codec) { uint8_t b[33]; sw_encode(b, p, s); tr_absorb(t, b, 33); return; }   /* Affine = SWAffine: 33-byte form */
+    if (s->sw_codec || s->sw_native) { uint8_t b[33]; sw_encode(b, p, s); tr_absorb(t, b, 33); return; }   /* Affine = SWAffine: 33-byte form */
     uint8_t b[32]; te_encode(b, p, s); tr_absorb(t, b, 32);
 }
 static void absorb_scalar(transcript_t *t, const u256 *k_mont, const suite_t *s) {
@@ -80,7 +80,7 @@ static void delin_take(u256 *zs, size_t n, transcript_t *delin, const suite_t *s
 static void transcript_merged(transcript_t *t, vrf_io *merged, uint8_t scheme, const vrf_io *ios, size_t n,
                               const uint8_t *ad, size_t ad_len, const suite_t *s) {
     transcript_t delin; transcript_base(t, &delin, scheme, ios, n, ad, ad_len, s);
-    if (n == 0) { memset(merged, 0, sizeof *merged); merged->in.y = s->fq.r1; merged->out.y = s->fq.r1; return; }
+    if (n == 0) { memset(merged, 0, sizeof *merged); if (!s->sw_native) { merged->in.y = s->fq.r1; merged->out.y = s->fq.r1; } return; }
     if (n == 1) { *merged = ios[0]; return; }
     te_ext acc[2]; te_identity(&acc[0], s); te_identity(&acc[1], s);
     if (n < 16) {                                                  /* MSM_THRESHOLD, common.rs:397; fold :400-404 */
@@ -109,7 +109,8 @@ static void transcript_merged(transcript_t *t, vrf_io *merged, uint8_t scheme, c
  * reference holds AFTER deserialisation (the reference's BatchVerifier takes typed points, so
  * decompression is outside `prepare`/`verify`; benches/thin.rs:46-90). */
 static __thread int g_xy = 0;
-#define PSZ ((size_t)(g_xy ? 64 : 32))
+#define PL ((size_t)s->pt_len)                 /* compressed point at the entry points: 32, or 33 for a short-Weierstrass suite */
+#define PSZ ((size_t)(g_xy ? 64 : s->pt_len))
 static int pt_dec(te_aff *o, const uint8_t *b, const suite_t *s) { return g_xy ? te_decode_xy(o, b, s) : te_decode(o, b, s); }
 static int decode_ios(vrf_io *o, const uint8_t *b, size_t n, const suite_t *s) {
     for (size_t i = 0; i < n; i++) {
@@ -167,7 +168,7 @@ int orc_point_to_hash(int suite, const uint8_t pt[32], uint8_t *out, size_t n) {
     transcript_t t; tr_new_mode(&t, s->suite_id, s->suite_id_len, s->xof_shake);
     absorb_u8(&t, DS_POINT_TO_HASH);
     if (s->sw_codec) { te_aff p; if (te_decode(&p, pt, s)) return ORC_INVALID_DATA; absorb_point(&t, &p, s); }
-    else tr_absorb(&t, pt, 32);
+    else tr_absorb(&t, pt, PL);
     tr_squeeze(&t, out, n);
     return 0;
 }
@@ -274,7 +275,7 @@ int orc_hash_to_curve(int suite, const uint8_t *data, size_t n, uint8_t out[32])
              * its 33-byte buffer, so the flag byte is always zero and the root is fixed: the LARGER one (pinned by the
              * alpha -> h entries of the reference's bandersnatch_sw vectors: the smaller root gives another point); the
              * bits above MODULUS_BIT_SIZE are cleared; x >= p -> next counter */
-            buf[31] &= (uint8_t)(0xff >> (256 - s->fq.bits));
+            if (s->fq.bits < 256) buf[31] &= (uint8_t)(0xff >> (256 - s->fq.bits));
             u256 x; u256_from_le(&x, buf);
             te_aff p; if (sw_from_x(&p, &x, 1, s)) continue;
             te_ext e; te_from_aff(&e, &p, s); clear_cofactor(&e, s);
@@ -324,7 +325,7 @@ int orc_thin_prove(int suite, const uint8_t sk_b[32], const uint8_t *ios_b, size
     te_ext R; smul_mont(&R, &m.in, &k, s); te_aff r; te_to_aff(&r, &R, s);
     const te_aff *pts[1] = {&r}; challenge(&c, pts, 1, t, s);
     mont_mul(&sres, &c, &sk, FR); mont_add(&sres, &sres, &k, FR);
-    te_encode(proof, &r, s); encode_scalar(proof + 32, &sres, s);
+    te_encode(proof, &r, s); encode_scalar(proof + PL, &sres, s);
     free(ch); free(ios); return ORC_OK;
 }
 
@@ -335,7 +336,7 @@ int orc_thin_verify(int suite, const uint8_t pk_b[32], const uint8_t *ios_b, siz
     te_aff pk, r; u256 sres, c, negc;
     vrf_io *ios = (vrf_io *)malloc((n_ios + 1) * sizeof(vrf_io));
     if (te_decode(&pk, pk_b, s) || decode_ios(ios, ios_b, n_ios, s) || te_decode(&r, proof, s) ||
-        decode_scalar(&sres, proof + 32, s)) { free(ios); return ORC_INVALID_DATA; }
+        decode_scalar(&sres, proof + PL, s)) { free(ios); return ORC_INVALID_DATA; }
     if (te_is_identity_aff(&pk, s) || io_has_identity(ios, n_ios, s)) { free(ios); return ORC_INVALID_DATA; }
     vrf_io *ch = chain_schnorr(&pk, ios, n_ios, s);
     transcript_t t; vrf_io m; transcript_merged(&t, &m, DS_THIN, ch, n_ios + 1, ad, ad_len, s);
@@ -495,8 +496,8 @@ int orc_pedersen_prove(int suite, const uint8_t sk_b[32], const uint8_t *ios_b, 
     const te_aff *pts[2] = {&ro[0], &ro[1]}; challenge(&c, pts, 2, t, s);
     mont_mul(&sres, &c, &sk, FR); mont_add(&sres, &sres, &k, FR);
     mont_mul(&sbres, &c, &b, FR); mont_add(&sbres, &sbres, &kb, FR);
-    te_encode(proof, &yb, s); te_encode(proof + 32, &ro[0], s); te_encode(proof + 64, &ro[1], s);
-    encode_scalar(proof + 96, &sres, s); encode_scalar(proof + 128, &sbres, s);
+    te_encode(proof, &yb, s); te_encode(proof + PL, &ro[0], s); te_encode(proof + 2 * PL, &ro[1], s);
+    encode_scalar(proof + 3 * PL, &sres, s); encode_scalar(proof + 3 * PL + 32, &sbres, s);
     if (blinding_out) encode_scalar(blinding_out, &b, s);
     free(ios); return ORC_OK;
 }
@@ -691,7 +692,7 @@ int orc_gen_batch(int suite, int kind, const uint8_t run_seed[32], uint64_t star
     size_t ad_off = 0;
     for (size_t q = 0; q < count; q++) {
         uint64_t j = start + q;
-        uint8_t seed[32], sk[32], pk[32], msg[24], in_c[32], out_c[32], io_c[64];
+        uint8_t seed[32], sk[32], pk[33], msg[24], in_c[33], out_c[33], io_c[66];
         memcpy(seed, run_seed, 32);
         for (int i = 0; i < 8; i++) seed[i] ^= (uint8_t)(j >> (8 * i));
         if (orc_from_seed(suite, seed, sk, pk)) return -1;
@@ -699,7 +700,7 @@ int orc_gen_batch(int suite, int kind, const uint8_t run_seed[32], uint64_t star
         for (int i = 0; i < 8; i++) msg[16 + i] = (uint8_t)(j >> (8 * i));
         if (orc_hash_to_curve(suite, msg, 24, in_c)) return -1;
         if (orc_vrf_output(suite, sk, in_c, out_c)) return -1;
-        memcpy(io_c, in_c, 32); memcpy(io_c + 32, out_c, 32);
+        memcpy(io_c, in_c, PL); memcpy(io_c + PL, out_c, PL);
         /* "ad-<j>" */
         char adb[24]; int al = 0; { char tmp[24]; int tl = 0; uint64_t v = j; do { tmp[tl++] = (char)('0' + v % 10); v /= 10; } while (v);
             adb[al++] = 'a'; adb[al++] = 'd'; adb[al++] = '-'; while (tl) adb[al++] = tmp[--tl]; }
@@ -709,17 +710,17 @@ int orc_gen_batch(int suite, int kind, const uint8_t run_seed[32], uint64_t star
         te_decode(&p, in_c, s); te_encode_xy(ios_xy + 128 * q, &p, s);
         te_decode(&p, out_c, s); te_encode_xy(ios_xy + 128 * q + 64, &p, s);
         if (kind == 0) {
-            uint8_t pr[64];
+            uint8_t pr[65];
             if (orc_thin_prove(suite, sk, io_c, 1, (const uint8_t *)adb, (size_t)al, pr)) return -1;
             te_decode(&p, pk, s); te_encode_xy(pks_xy + 64 * q, &p, s);
             te_decode(&p, pr, s); te_encode_xy(proofs + 96 * q, &p, s);
-            memcpy(proofs + 96 * q + 64, pr + 32, 32);
+            memcpy(proofs + 96 * q + 64, pr + PL, 32);
         } else {
-            uint8_t pr[160];
+            uint8_t pr[163];
             if (orc_pedersen_prove(suite, sk, io_c, 1, (const uint8_t *)adb, (size_t)al, pr, NULL)) return -1;
             if (pks_xy) { te_decode(&p, pk, s); te_encode_xy(pks_xy + 64 * q, &p, s); }
-            for (int k = 0; k < 3; k++) { te_decode(&p, pr + 32 * k, s); te_encode_xy(proofs + 256 * q + 64 * k, &p, s); }
-            memcpy(proofs + 256 * q + 192, pr + 96, 64);
+            for (int k = 0; k < 3; k++) { te_decode(&p, pr + PL * k, s); te_encode_xy(proofs + 256 * q + 64 * k, &p, s); }
+            memcpy(proofs + 256 * q + 192, pr + 3 * PL, 64);
         }
     }
     return 0;

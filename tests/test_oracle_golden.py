@@ -171,3 +171,66 @@ def test_bandersnatch_sw_vectors(golden_dir, scheme):
     assert orc.hash_to_curve(s, b"ring-accumulator") != orc.suite_point(s, 2)
     # infinity and unused flag bits do not decode; the round trip keeps the flag byte
     assert orc.sw_decode(s, bytes(32) + b"\x40")[0] != 0 and orc.sw_decode(s, bytes.fromhex(v["pk"])[:32] + b"\x01")[0] != 0
+
+
+@pytest.mark.parametrize("scheme", ["thin", "tiny", "pedersen"])
+def test_secp256r1_vectors(golden_dir, scheme):
+    """Secp256r1-SHA256-TAI (src/suites/secp256r1.rs:49-70): NIST P-256, a genuinely short-Weierstrass suite -- a = -3 Jacobian
+    group law, 256-bit base / scalar fields with the top bit set, HashTranscript<Sha256>, try-and-increment on SW x-coordinates,
+    33-byte points (LE32(x) || flags).  All 21 vectors: sk -> pk, alpha -> h, gamma, beta, proofs; then the batch verifiers'
+    MSMs on the reference's proofs (identity of a short-Weierstrass group in the xy flavour: all zero bytes)."""
+    s = orc.SECP256R1
+    vs = load(golden_dir, "secp256r1_sha-256_tai", scheme)
+    assert len(vs) == 7
+    pks, ios, ads, proofs = [], [], [], []
+    for i, v in enumerate(vs):
+        sk, pk = bytes.fromhex(v["sk"]), bytes.fromhex(v["pk"])
+        assert len(pk) == 33
+        assert orc.from_seed(s, bytes([SEEDS[i]]) + bytes(31)) == (sk, pk)
+        assert orc.sk_to_pk(s, sk) == pk
+        h = orc.hash_to_curve(s, bytes.fromhex(v["alpha"]))
+        assert h.hex() == v["h"]
+        gamma = orc.vrf_output(s, sk, h)
+        assert gamma.hex() == v["gamma"] and orc.point_to_hash(s, gamma).hex() == v["beta"]
+        io, ad = [(h, gamma)], bytes.fromhex(v["ad"])
+        if scheme == "thin":
+            pr = orc.thin_prove(s, sk, io, ad)
+            assert pr.hex() == v["proof_r"] + v["proof_s"] and len(pr) == 65
+            assert orc.thin_verify(s, pk, io, ad, pr) == orc.OK
+            bad = bytearray(pr); bad[40] ^= 1
+            assert orc.thin_verify(s, pk, io, ad, bytes(bad)) == orc.VERIFICATION_FAILURE
+            assert orc.thin_verify(s, pk, io, ad + b"x", pr) == orc.VERIFICATION_FAILURE
+        elif scheme == "tiny":
+            pr = orc.tiny_prove(s, sk, io, ad)
+            assert pr.hex() == v["proof_c"] + v["proof_s"] and orc.tiny_verify(s, pk, io, ad, pr) == orc.OK
+            bad = bytearray(pr); bad[17] ^= 1
+            assert orc.tiny_verify(s, pk, io, ad, bytes(bad)) == orc.VERIFICATION_FAILURE
+        else:
+            pr, bl = orc.pedersen_prove(s, sk, io, ad)
+            assert bl.hex() == v["blinding"] and len(pr) == 163
+            assert pr.hex() == v["proof_pk_com"] + v["proof_r"] + v["proof_ok"] + v["proof_s"] + v["proof_sb"]
+            assert orc.pedersen_verify(s, io, ad, pr) == orc.OK
+            bad = bytearray(pr); bad[110] ^= 1
+            assert orc.pedersen_verify(s, io, ad, bytes(bad)) == orc.VERIFICATION_FAILURE
+        pks.append(pk); ios.append(io); ads.append(ad); proofs.append(pr)
+    ident = bytes(64)
+    if scheme == "thin":
+        st, bases, sc = orc.thin_batch_terms(s, pks, ios, ads, proofs)
+        assert st == orc.OK and len(sc) == 32 * 29
+        assert orc.msm(s, bases, sc, algo=1) == ident and orc.msm(s, bases, sc, algo=0) == ident
+        assert orc.thin_batch_verify(s, pks, ios, ads, proofs) == orc.OK
+        bad = bytearray(proofs[3]); bad[34] ^= 4
+        assert orc.thin_batch_verify(s, pks, ios, ads, proofs[:3] + [bytes(bad)] + proofs[4:]) == orc.VERIFICATION_FAILURE
+    elif scheme == "pedersen":
+        st, bases, sc = orc.pedersen_batch_terms(s, ios, ads, proofs)
+        assert st == orc.OK and len(sc) == 32 * 37
+        assert orc.msm(s, bases, sc, algo=1) == ident
+        assert orc.pedersen_batch_verify(s, ios, ads, proofs) == orc.OK
+        bad = bytearray(proofs[2]); bad[135] ^= 4
+        assert orc.pedersen_batch_verify(s, ios, ads, proofs[:2] + [bytes(bad)] + proofs[3:]) == orc.VERIFICATION_FAILURE
+    # BLINDING_BASE is a hash-to-curve output (src/pedersen.rs:568-579 `blinding_base_check`); the codec: infinity, unused flag bits
+    assert orc.hash_to_curve(s, b"pedersen-blinding") == orc.suite_point(s, 1)
+    assert orc.point_decompress(s, bytes(32) + b"\x40")[0] == 0 and orc.point_decompress(s, bytes(32) + b"\x40")[1] == bytes(64)
+    assert orc.point_decompress(s, pks[0][:32] + b"\x01")[0] != 0
+    st, pxy = orc.point_decompress(s, pks[0], validate=True)
+    assert st == 0 and orc.point_compress(s, pxy) == pks[0]
