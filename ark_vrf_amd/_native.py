@@ -19,6 +19,7 @@ JUBJUB_SHA512_TAI = 2
 ED25519_SHA512_TAI = 3          # Tiny / Thin / Pedersen only (no ring suite)
 TESTING_SHA256_TAI = 6           # the crate's own test suite: edwards25519 with HashTranscript<Sha256> (no ring)
 BANDERSNATCH_SHAKE128_ELL2 = 5   # suite 0's curve with the SHAKE128 sponge as transcript
+SECP256R1_SHA256_TAI = 7        # NIST P-256, a genuinely short-Weierstrass suite (Tiny / Thin / Pedersen; no ring): 33-byte points, identity xy = zeros
 BANDERSNATCH_SW_SHA512_TAI = 4  # Bandersnatch, short-Weierstrass presentation: 33-byte compressed points (Context.point_len)
 
 THIN_PROOF_LEN = 96       # R_xy || s

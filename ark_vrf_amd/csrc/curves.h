@@ -17,23 +17,23 @@ namespace avrf {
 template <class S> struct TeCurve {
   using base_t = te_pre; using acc_t = te_ext; using suite = S;
   static constexpr int BASE_WORDS = 24, ACC_WORDS = 32;
-  static constexpr bool QUAD = true;                  // reduction tails use the four-lanes-per-point addition (te_quad.h)
+  // (S::SW_NATIVE, secp256r1: the policy's types hold XYZZ coordinates, te.h; the twisted-Edwards-only reduction kernels
+  // -- te_quad.h, window triples -- are switched off and the generic row / column + bit-sum reduction of the G1 MSMs runs)
+  static constexpr bool QUAD = !S::SW_NATIVE;         // reduction tails use the four-lanes-per-point addition (te_quad.h)
   static constexpr bool PREFETCH = true;
-  static constexpr bool ZERO_IS_IDENTITY = false;     // (0, 1, 0, 1)
+  static constexpr bool ZERO_IS_IDENTITY = S::SW_NATIVE;   // twisted Edwards: (0, 1, 0, 1); XYZZ: ZZ = 0
   static constexpr bool FIXED_TABLE = false;          // no fixed-base window-table mode (bases change per batch)
   static constexpr int MIN_WAVES = AVRF_TE_ACC_WAVES; // waves per SIMD asked of the register allocator in k_accumulate
   static constexpr int RED_WAVES = 1;                 // reduction kernels (general additions, several points live): latency-bound, full register file
   static constexpr bool INLINE_REDUCE_OPS = true;
-  static constexpr bool WINDOW_SUMS = true;           // single MSMs: one weighted bucket sum per window (k_wsum_blk) instead of row/column + bit sums
+  static constexpr bool WINDOW_SUMS = !S::SW_NATIVE;  // single MSMs: one weighted bucket sum per window (k_wsum_q1/q2) instead of row/column + bit sums
   static AVRF_DI acc_t identity() { return te_identity<S>(); }
   static AVRF_DI acc_t madd(const acc_t &a, base_t q, bool neg) {
-    using Fq = typename S::Fq;
-    if (neg) { q.x = fp_neg<Fq>(q.x); q.k = fp_neg<Fq>(q.k); }
+    if (neg) q = te_pre_neg<S>(q);
     return te_madd<S>(a, q);
   }
   static AVRF_DI acc_t from_base(base_t q, bool neg) {
-    using Fq = typename S::Fq;
-    if (neg) q.x = fp_neg<Fq>(q.x);
+    if (neg) q = te_pre_neg<S>(q);
     return te_from_pre<S>(q);
   }
   static AVRF_DI acc_t add(const acc_t &a, const acc_t &b) { return te_add<S>(a, b); }

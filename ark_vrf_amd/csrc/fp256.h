@@ -3,8 +3,9 @@
 // Device counterpart of what the reference gets from arkworks `Fp<MontBackend<_,4>>`
 // (third-party ark-ff 0.6; reached from src/thin.rs:289-311, src/pedersen.rs:373-410 for the
 // scalar field and from every group operation for the base field).  One field element per
-// lane, limbs in VGPRs; products through v_mad_u64_u32.  All moduli on the path have their
-// top bit clear (253..255 bits), which admits the carry-free CIOS form used below.
+// lane, limbs in VGPRs; products through v_mad_u64_u32.  The twisted-Edwards suites' moduli have their
+// top bit clear (251..255 bits), which admits the carry-free forms; the two 256-bit fields of secp256r1
+// (F::FULL) keep the 257th bit of a sum or a Montgomery product and fold it into the conditional subtraction.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -66,8 +67,9 @@ template <class F> AVRF_DI uint32_t sub_p(fp &r, const fp &a) {
 template <class F> AVRF_DI bool ge_p(const fp &a) { fp t; return sub_p<F>(t, a) == 0; }
 
 template <class F> AVRF_DI fp fp_add(const fp &a, const fp &b) {
-  fp t, u; add8(t, a, b);               // < 2p < 2^256: no carry out
+  fp t, u; uint32_t c = add8(t, a, b);  // < 2p; a carry out only when the top bit of p is set (F::FULL)
   uint32_t br = sub_p<F>(u, t);
+  if constexpr (F::FULL) br = br && !c; else (void)c;
 #pragma unroll
   for (int i = 0; i < 8; i++) t.v[i] = br ? t.v[i] : u.v[i];
   return t;
@@ -90,16 +92,18 @@ template <class F> AVRF_DI fp fp_dbl(const fp &a) { return fp_add<F>(a, a); }
 // Montgomery product a*b/R mod p (top bit of p clear), product scanning (mac96.h)
 template <class F> AVRF_DI fp fp_mul(const fp &a, const fp &b) {
   fp r, u;
-  mont_mul_ps<8, F>(r.v, a.v, b.v);
+  uint32_t c = mont_mul_ps<8, F>(r.v, a.v, b.v);
   uint32_t br = sub_p<F>(u, r);
+  if constexpr (F::FULL) br = br && !c; else (void)c;
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = br ? r.v[i] : u.v[i];
   return r;
 }
 template <class F> AVRF_DI fp fp_sqr(const fp &a) {
   fp r, u;
-  mont_sqr_ps<8, F>(r.v, a.v);
+  uint32_t c = mont_sqr_ps<8, F>(r.v, a.v);
   uint32_t br = sub_p<F>(u, r);
+  if constexpr (F::FULL) br = br && !c; else (void)c;
 #pragma unroll
   for (int i = 0; i < 8; i++) r.v[i] = br ? r.v[i] : u.v[i];
   return r;

@@ -161,6 +161,81 @@ template <class C> struct HostPairing {
     return r;
   }
 
+  // ---- fixed G2 arguments: the verifier's two G2 points (g2, tau g2) never change for a setup, so the whole G2 side of the
+  // Miller loop -- the affine doublings / additions with their Fp2 inversions (an Fp inversion costs as much as ten Fp12
+  // products) -- is done once: per step the slope lam and c = lam x' - y' of the line.  With the table a step is one Fp12
+  // squaring and one sparse product per pair (device counterpart: k_g2_lines, pairing.hip).
+  struct G2Lines { std::vector<F2> lam, c; size_t live_steps = 0; bool inf = true; };
+  static G2Lines g2_lines(const G2 &q) {
+    G2Lines t; t.inf = q.inf;
+    if (q.inf) return t;
+    static const El three = small(3), two = small(2);
+    F2 rx = q.x, ry = q.y;
+    bool live = true;
+    auto push = [&](const F2 &lam) { t.lam.push_back(lam); t.c.push_back(f2_sub(f2_mul(lam, rx), ry)); };
+    for (int bit = C::ATE_LOOP_BITS - 2; bit >= 0 && live; bit--) {
+      if (f2_is_zero(ry)) { live = false; break; }
+      F2 lam = f2_mul(f2_scale(f2_sqr(rx), three), f2_inv(f2_scale(ry, two)));
+      push(lam);
+      F2 nx = f2_sub(f2_sqr(lam), f2_add(rx, rx));
+      ry = f2_sub(f2_mul(lam, f2_sub(rx, nx)), ry); rx = nx;
+      if ((C::ATE_LOOP[bit >> 6] >> (bit & 63)) & 1) {
+        if (f2_eq(rx, q.x)) { live = false; break; }                 // cannot happen for points of order r
+        lam = f2_mul(f2_sub(q.y, ry), f2_inv(f2_sub(q.x, rx)));
+        push(lam);
+        nx = f2_sub(f2_sub(f2_sqr(lam), rx), q.x);
+        ry = f2_sub(f2_mul(lam, f2_sub(rx, nx)), ry); rx = nx;
+      }
+    }
+    t.live_steps = t.lam.size();
+    return t;
+  }
+  // (a + b w)^2 = (a + b)(a + v b) - ab - v ab + 2 ab w: two Fp6 products
+  static F12 f12_sqr(const F12 &x) {
+    F6 ab = f6_mul(x.c0, x.c1);
+    F6 t = f6_mul(f6_add(x.c0, x.c1), f6_add(x.c0, f6_mul_v(x.c1)));
+    F12 r; r.c0 = f6_sub(f6_sub(t, ab), f6_mul_v(ab)); r.c1 = f6_add(ab, ab);
+    return r;
+  }
+  // x * (u0 + u1 v) and x * (u1 v) in Fp6 (v^3 = xi)
+  static F6 f6_mul_01(const F6 &x, const F2 &u0, const F2 &u1) {
+    F2 a = f2_mul(x.c0, u0), b = f2_mul(x.c1, u1);
+    F2 c1 = f2_sub(f2_sub(f2_mul(f2_add(x.c0, x.c1), f2_add(u0, u1)), a), b);
+    return f6(f2_add(a, f2_mul_xi(f2_mul(x.c2, u1))), c1, f2_add(f2_mul(x.c2, u0), b));
+  }
+  static F6 f6_mul_1(const F6 &x, const F2 &u1) { return f6(f2_mul_xi(f2_mul(x.c2, u1)), f2_mul(x.c0, u1), f2_mul(x.c1, u1)); }
+  // f * line, the line in the sparse shape `line()` builds: M-twist (c + m v) + (yP v) w, D-twist (yP) + (m + c v) w
+  static F12 f12_mul_line(const F12 &f, const F2 &c, const F2 &m, const El &py) {
+    const F2 yp = f2(py, Fp::zero());
+    F12 r;
+    if (C::MTWIST) {
+      F6 v0 = f6_mul_01(f.c0, c, m), v1 = f6_mul_1(f.c1, yp);
+      F6 t = f6_mul_01(f6_add(f.c0, f.c1), c, f2_add(m, yp));
+      r.c1 = f6_sub(f6_sub(t, v0), v1); r.c0 = f6_add(v0, f6_mul_v(v1));
+    } else {
+      F6 v0 = f6(f2_scale(f.c0.c0, py), f2_scale(f.c0.c1, py), f2_scale(f.c0.c2, py)), v1 = f6_mul_01(f.c1, m, c);
+      F6 t = f6_mul_01(f6_add(f.c0, f.c1), f2_add(yp, m), c);
+      r.c1 = f6_sub(f6_sub(t, v0), v1); r.c0 = f6_add(v0, f6_mul_v(v1));
+    }
+    return r;
+  }
+  // prod_i e(P_i, Q_i) == 1 with the Q_i given as line tables
+  static bool product_is_one_lines(const El *px, const El *py, const bool *pinf, const G2Lines *tabs, int n) {
+    F12 f = f12_one();
+    std::vector<size_t> pos(n, 0);
+    for (int bit = C::ATE_LOOP_BITS - 2; bit >= 0; bit--) {
+      f = f12_sqr(f);
+      const int steps = 1 + (int)((C::ATE_LOOP[bit >> 6] >> (bit & 63)) & 1);
+      for (int st = 0; st < steps; st++)
+        for (int i = 0; i < n; i++) {
+          if (pinf[i] || tabs[i].inf || pos[i] >= tabs[i].live_steps) continue;
+          const size_t k = pos[i]++;
+          f = f12_mul_line(f, tabs[i].c[k], f2_neg(f2_scale(tabs[i].lam[k], px[i])), py[i]);
+        }
+    }
+    return f12_is_one(final_exp(f));
+  }
+
   // prod_i e(P_i, Q_i) == 1 ?   P_i affine G1 (Montgomery x, y; inf flag), Q_i affine G2 on the twist
   static bool product_is_one(const El *px, const El *py, const bool *pinf, const G2 *q, int n) {
     std::vector<F2> rx(n), ry(n);

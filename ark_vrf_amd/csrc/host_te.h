@@ -79,9 +79,40 @@ template <class S> struct HostTe {
     if (S::A_KIND == 2) return Fq::neg(v);
     return v;
   }
-  static HostExt identity() { HostExt r; memset(&r, 0, sizeof r); r.y = Fq::one(); r.z = Fq::one(); return r; }
-  static bool is_identity(const HostExt &p) { return Fq::is_zero(p.x) && Fq::eq(p.y, p.z); }
+  // S::SW_NATIVE (secp256r1): the same struct holds XYZZ coordinates (X, Y, ZZ = t, ZZZ = z), identity ZZ = 0 -- te.h
+  static HostExt identity() {
+    HostExt r; memset(&r, 0, sizeof r); r.y = Fq::one();
+    if constexpr (S::SW_NATIVE) r.x = Fq::one(); else r.z = Fq::one();
+    return r;
+  }
+  static bool is_identity(const HostExt &p) {
+    if constexpr (S::SW_NATIVE) return Fq::is_zero(p.t);
+    return Fq::is_zero(p.x) && Fq::eq(p.y, p.z);
+  }
+  static HostExt sw_dbl(const HostExt &a) {            // dbl-2008-s-1, a = -3
+    H256 U = Fq::add(a.y, a.y), V = Fq::sqr(U), W = Fq::mul(U, V), Sx = Fq::mul(a.x, V);
+    H256 M = Fq::mul(Fq::sub(a.x, a.t), Fq::add(a.x, a.t)); M = Fq::add(Fq::add(M, M), M);
+    HostExt r;
+    r.x = Fq::sub(Fq::sqr(M), Fq::add(Sx, Sx));
+    r.y = Fq::sub(Fq::mul(M, Fq::sub(Sx, r.x)), Fq::mul(W, a.y));
+    r.t = Fq::mul(V, a.t); r.z = Fq::mul(W, a.z);
+    return r;
+  }
+  static HostExt sw_add(const HostExt &a, const HostExt &b) {   // add-2008-s with its exceptional cases
+    if (Fq::is_zero(a.t)) return b;
+    if (Fq::is_zero(b.t)) return a;
+    H256 U1 = Fq::mul(a.x, b.t), P = Fq::sub(Fq::mul(b.x, a.t), U1);
+    H256 S1 = Fq::mul(a.y, b.z), R = Fq::sub(Fq::mul(b.y, a.z), S1);
+    if (Fq::is_zero(P)) return Fq::is_zero(R) ? sw_dbl(a) : identity();
+    H256 PP = Fq::sqr(P), Q = Fq::mul(U1, PP), PPP = Fq::mul(P, PP), T = Fq::mul(S1, PPP);
+    HostExt r;
+    r.t = Fq::mul(Fq::mul(a.t, b.t), PP); r.z = Fq::mul(Fq::mul(a.z, b.z), PPP);
+    r.x = Fq::sub(Fq::sub(Fq::sqr(R), PPP), Fq::add(Q, Q));
+    r.y = Fq::sub(Fq::mul(R, Fq::sub(Q, r.x)), T);
+    return r;
+  }
   static HostExt add(const HostExt &p, const HostExt &q) {
+    if constexpr (S::SW_NATIVE) return sw_add(p, q);
     static const H256 d = Fq::from32(S::D);
     H256 A = Fq::mul(p.x, q.x), B = Fq::mul(p.y, q.y), C = Fq::mul(Fq::mul(p.t, q.t), d), D = Fq::mul(p.z, q.z);
     H256 E = Fq::sub(Fq::sub(Fq::mul(Fq::add(p.x, p.y), Fq::add(q.x, q.y)), A), B);
@@ -89,6 +120,7 @@ template <class S> struct HostTe {
     HostExt r; r.x = Fq::mul(E, F); r.y = Fq::mul(G, H); r.t = Fq::mul(E, H); r.z = Fq::mul(F, G); return r;
   }
   static HostExt dbl(const HostExt &p) {
+    if constexpr (S::SW_NATIVE) return sw_dbl(p);
     H256 A = Fq::sqr(p.x), B = Fq::sqr(p.y), C = Fq::sqr(p.z); C = Fq::add(C, C);
     H256 D = mul_a(A), E = Fq::sub(Fq::sub(Fq::sqr(Fq::add(p.x, p.y)), A), B);
     H256 G = Fq::add(D, B), F = Fq::sub(G, C), H = Fq::sub(D, B);
@@ -96,6 +128,11 @@ template <class S> struct HostTe {
   }
   // canonical affine bytes x||y (LE32 each)
   static void to_affine_bytes(const HostExt &p, uint8_t out[64]) {
+    if constexpr (S::SW_NATIVE) {                       // the identity: all-zero bytes
+      H256 i = Fq::inv(Fq::mul(p.t, p.z));
+      H256 x = Fq::from_mont(Fq::mul(p.x, Fq::mul(i, p.z))), y = Fq::from_mont(Fq::mul(p.y, Fq::mul(i, p.t)));
+      Fq::store_le(out, x); Fq::store_le(out + 32, y); return;
+    }
     H256 zi = Fq::inv(p.z);
     H256 x = Fq::from_mont(Fq::mul(p.x, zi)), y = Fq::from_mont(Fq::mul(p.y, zi));
     Fq::store_le(out, x); Fq::store_le(out + 32, y);
@@ -103,6 +140,10 @@ template <class S> struct HostTe {
   static bool from_affine_bytes(const uint8_t in[64], HostExt *o) {
     H256 x = Fq::load_le(in), y = Fq::load_le(in + 32);
     if (Fq::geq_p(x) || Fq::geq_p(y)) return false;
+    if constexpr (S::SW_NATIVE) {
+      if (Fq::is_zero(x) && Fq::is_zero(y)) { *o = identity(); return true; }
+      o->x = Fq::to_mont(x); o->y = Fq::to_mont(y); o->t = Fq::one(); o->z = Fq::one(); return true;
+    }
     o->x = Fq::to_mont(x); o->y = Fq::to_mont(y); o->t = Fq::mul(o->x, o->y); o->z = Fq::one();
     return true;
   }

@@ -20,17 +20,18 @@ __device__ __forceinline__ void mac96_k(uint64_t &lo, uint32_t &ex, uint32_t a, 
   asm("v_mad_u64_u32 %0, %1, %3, %4, %0\n\tv_addc_co_u32 %2, %1, 0, %2, %1" : "+v"(lo), "=&s"(cy), "+v"(ex) : "v"(a), "s"(k));
 }
 
-// a * b / 2^(32 N) mod p for N-limb operands < p (p's top bit clear); result in t[0..N), < 2p before the caller's
-// conditional subtraction.  P: modulus limbs, NINV = -p^-1 mod 2^32.
+// a * b / 2^(32 N) mod p for N-limb operands < p; result in t[0..N) plus the returned bit 32 N, < 2p before the caller's
+// conditional subtraction.  The returned bit is zero unless the top bit of p is set (F::FULL: secp256r1's two fields, which
+// have no asm block).  P: modulus limbs, NINV = -p^-1 mod 2^32.
 template <int N, class F>
-__device__ __forceinline__ void mont_mul_ps(uint32_t (&t)[N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
+__device__ __forceinline__ uint32_t mont_mul_ps(uint32_t (&t)[N], const uint32_t (&a)[N], const uint32_t (&b)[N]) {
 #ifndef AVRF_NO_MONT_ASM
   if constexpr (N == 8 && MontAsm8<F>::value) {      // the same algorithm as one asm block with a sliding accumulator (tools/gen_mont_asm.py)
     MontAsm8<F>::mul(t, a, b);
-    return;
+    return 0;
   }
 #ifndef AVRF_NO_MONT_ASM12
-  if constexpr (N == 12 && MontAsm12<F>::value) { MontAsm12<F>::mul(t, a, b); return; }
+  if constexpr (N == 12 && MontAsm12<F>::value) { MontAsm12<F>::mul(t, a, b); return 0; }
 #endif
 #endif
   uint32_t m[N];
@@ -55,18 +56,19 @@ __device__ __forceinline__ void mont_mul_ps(uint32_t (&t)[N], const uint32_t (&a
     lo = (lo >> 32) | ((uint64_t)ex << 32); ex = 0;
   }
   t[N - 1] = (uint32_t)lo;
+  return (uint32_t)(lo >> 32);
 }
 
 // a * a / 2^(32 N) mod p: the asm blocks with N (N + 1) / 2 limb products where there is one (tools/gen_mont_asm.py)
 template <int N, class F>
-__device__ __forceinline__ void mont_sqr_ps(uint32_t (&t)[N], const uint32_t (&a)[N]) {
+__device__ __forceinline__ uint32_t mont_sqr_ps(uint32_t (&t)[N], const uint32_t (&a)[N]) {
 #if !defined(AVRF_NO_MONT_ASM) && !defined(AVRF_NO_MONT_SQR)
-  if constexpr (N == 8 && MontAsm8<F>::value) { MontAsm8<F>::sqr(t, a); return; }
+  if constexpr (N == 8 && MontAsm8<F>::value) { MontAsm8<F>::sqr(t, a); return 0; }
 #ifndef AVRF_NO_MONT_ASM12
-  if constexpr (N == 12 && MontAsm12<F>::value) { MontAsm12<F>::sqr(t, a); return; }
+  if constexpr (N == 12 && MontAsm12<F>::value) { MontAsm12<F>::sqr(t, a); return 0; }
 #endif
 #endif
-  mont_mul_ps<N, F>(t, a, a);
+  return mont_mul_ps<N, F>(t, a, a);
 }
 
 }  // namespace avrf

@@ -88,7 +88,8 @@ template <class S> AVRF_DI uint32_t point_flags(const fp &x, const fp &y) {
   uint32_t f = 0;
   if (ge_p<Fq>(x) || ge_p<Fq>(y)) f |= FLAG_RANGE;
   fp one = fp_zero(); one.v[0] = 1;
-  if (fp_is_zero(x) && fp_eq(y, one)) f |= FLAG_IDENTITY;
+  if constexpr (S::SW_NATIVE) { if (fp_is_zero(x) && fp_is_zero(y)) f |= FLAG_IDENTITY; }   // (0, 0): the point at infinity
+  else if (fp_is_zero(x) && fp_eq(y, one)) f |= FLAG_IDENTITY;
   return f;
 }
 
@@ -235,6 +236,11 @@ template <class S, class T> AVRF_DI void absorb_point_mont(T &h, const te_aff &a
 }
 template <class S> AVRF_DI bool ext_eq_aff(const te_ext &p, const te_pre &q) {   // p == q ?
   using Fq = typename S::Fq;
+  if constexpr (S::SW_NATIVE) {                                                  // X = x ZZ, Y = y ZZZ; infinity only equals infinity
+    const bool qi = fp_is_zero(q.x) && fp_is_zero(q.y);
+    if (fp_is_zero(p.t) || qi) return fp_is_zero(p.t) && qi;
+    return fp_eq(p.x, fp_mul<Fq>(q.x, p.t)) && fp_eq(p.y, fp_mul<Fq>(q.y, p.z));
+  }
   return fp_eq(p.x, fp_mul<Fq>(q.x, p.z)) && fp_eq(p.y, fp_mul<Fq>(q.y, p.z));
 }
 

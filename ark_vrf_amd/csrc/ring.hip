@@ -25,6 +25,7 @@
 #include <time.h>
 #include <sys/random.h>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -428,6 +429,7 @@ struct avrf_ring_setup {
   uint32_t *d_srs_table = nullptr; int table_c = 0, table_nwin = 0;   // fixed-base window table over the SRS (batched commits)
   int wit_c = 0, wit_nwin = 0;                        // window width of the witness table (sparse MSMs: few entries, small buckets)
   uint32_t *d_wit_table = nullptr;                    // same over [L_i(tau) G, i < N | prefix sums PS_k = sum_{i<k} L_i(tau) G, k <= N] (witness commits)
+  void *host_lines = nullptr; void (*host_lines_free)(void *) = nullptr;   // host Miller-loop line tables of (g2, tau g2), built on first use
   G1Aff g1_0;                                         // powers_in_g1[0]
   std::vector<uint8_t> g2_raw;                        // powers_in_g2[0..2] exactly as in the SRS file
   std::vector<uint8_t> g1_raw;                        // the n_srs powers_in_g1 this setup keeps, serialize_uncompressed encoding
@@ -912,7 +914,7 @@ template <class S, class G> struct Ring {
     if (su->lane1) return su->lane1;
     ensure_lagrange(su);                                               // so that the copy sees the witness table
     avrf_ring_setup *l = new avrf_ring_setup(*su);
-    l->lane1 = nullptr; l->d_buf = nullptr; l->buf_cap = 0; l->ws = MsmWorkspace();
+    l->lane1 = nullptr; l->d_buf = nullptr; l->buf_cap = 0; l->ws = MsmWorkspace(); l->host_lines = nullptr; l->host_lines_free = nullptr;
     for (int i = 0; i < 6; i++) { l->d_scr[i] = nullptr; l->scr_cap[i] = 0; }
     HIP_CHECK(hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking));
     su->lane1 = l;
@@ -1427,13 +1429,22 @@ template <class S, class G> struct Ring {
     G1Aff acc2 = g1_msm(su, b2, s2);
     lap("two G1 MSMs (device)");
     using HP = HostPairing<G>;
-    typename HP::G2 q[2];
-    const size_t g2len = su->g2_raw.size() / 2;
-    HP::g2_decode(su->g2_raw.data(), &q[0]); HP::g2_decode(su->g2_raw.data() + g2len, &q[1]);
+    // the two G2 arguments are the setup's: their Miller-loop lines are tabulated once (host_pairing.h G2Lines)
+    static std::mutex lines_mu;
+    if (std::lock_guard<std::mutex> lk(lines_mu); !su->host_lines) {
+      typename HP::G2 q[2];
+      const size_t g2len = su->g2_raw.size() / 2;
+      HP::g2_decode(su->g2_raw.data(), &q[0]); HP::g2_decode(su->g2_raw.data() + g2len, &q[1]);
+      auto *t = new typename HP::G2Lines[2];
+      t[0] = HP::g2_lines(q[0]); t[1] = HP::g2_lines(q[1]);
+      su->host_lines = t;
+      su->host_lines_free = [](void *p) { delete[] static_cast<typename HP::G2Lines *>(p); };
+    }
+    const typename HP::G2Lines *lines = static_cast<const typename HP::G2Lines *>(su->host_lines);
     QEl px[2], py[2]; bool pinf[2] = {acc1.inf, acc2.inf};
     const G1Aff *accs[2] = {&acc1, &acc2};
     for (int i = 0; i < 2; i++) { QEl x, y; memset(&x, 0, sizeof x); memset(&y, 0, sizeof y); memcpy(x.l, accs[i]->xy, FQB); memcpy(y.l, accs[i]->xy + FQB, FQB); px[i] = FqN::to_mont(x); py[i] = FqN::to_mont(y); }
-    const bool ok = HP::product_is_one(px, py, pinf, q, 2);
+    const bool ok = HP::product_is_one_lines(px, py, pinf, lines, 2);
     lap("2-pairing check (host)");
     return ok ? AVRF_OK : AVRF_VERIFICATION_FAILURE;
   }
@@ -1482,6 +1493,7 @@ void avrf_ring_setup_free(avrf_ring_setup *su) {
   for (void *p : d) if (p) (void)hipFree(p);
   su->ws.release();
   su->ptab.release();
+  if (su->host_lines && su->host_lines_free) su->host_lines_free(su->host_lines);
   if (avrf_ring_setup *l = su->lane1) {                                // only what the lane owns
     void *o[] = {l->d_buf, l->d_scr[0], l->d_scr[1], l->d_scr[2], l->d_scr[3], l->d_scr[4], l->d_scr[5]};
     for (void *p : o) if (p) (void)hipFree(p);

@@ -18,6 +18,11 @@ struct sw_enc { fp x; uint8_t flag; };     // x: plain little-endian integer
 template <class S> AVRF_DI sw_enc sw_encode_te(const fp &xm, const fp &ym) {
   using Fq = typename S::Fq;
   sw_enc r; r.x = fp_zero(); r.flag = 0x40;
+  if constexpr (S::SW_NATIVE) {            // the point IS the short-Weierstrass point: LE32(x) || sign of y; (0, 0) = infinity
+    if (fp_is_zero(xm) && fp_is_zero(ym)) return r;
+    r.x = fp_from_mont<Fq>(xm); r.flag = fp_is_negative_mont<Fq>(ym) ? 0x80 : 0x00;
+    return r;
+  }
   const fp one = fp_one<Fq>();
   const fp vd = fp_sub<Fq>(one, ym), wd = fp_mul<Fq>(xm, vd);
   const fp den = fp_mul<Fq>(vd, wd);
@@ -35,6 +40,13 @@ template <class S> AVRF_DI sw_enc sw_encode_te(const fp &xm, const fp &ym) {
 // kernels absorb 4 - 5 points per item, and a field inversion is ~400 multiplications
 template <class S, int K> AVRF_DI void sw_encode_te_many(const fp (&xp)[K], const fp (&yp)[K], sw_enc (&out)[K]) {
   using Fq = typename S::Fq;
+  if constexpr (S::SW_NATIVE) {            // nothing to invert: the encoding reads the canonical coordinates
+    for (int k = 0; k < K; k++) {
+      out[k].x = xp[k];
+      out[k].flag = (fp_is_zero(xp[k]) && fp_is_zero(yp[k])) ? 0x40 : fp_is_negative_plain<Fq>(yp[k]) ? 0x80 : 0x00;
+    }
+    return;
+  }
   const fp one = fp_one<Fq>();
   fp vd[K], wd[K], den[K], pre[K], ym[K];
   bool inf[K];
@@ -68,6 +80,7 @@ template <class S> AVRF_DI bool sw_decode_te(const fp &x_plain, bool greatest, f
   fp y;
   if (!fp_sqrt_nf<Fq>(rhs, &y)) return false;
   if (fp_is_negative_mont<Fq>(y) != greatest) y = fp_neg<Fq>(y);
+  if constexpr (S::SW_NATIVE) { xm_out = x; ym_out = y; return true; }
   const fp b = fp_const<Fq>(S::MONT_B);
   const fp mx = fp_sub<Fq>(fp_mul<Fq>(b, x), fp_const<Fq>(S::MONT_A3)), my = fp_mul<Fq>(b, y);
   const fp up1 = fp_add<Fq>(mx, one), den = fp_mul<Fq>(my, up1);

@@ -24,14 +24,80 @@ template <class S> AVRF_DI fp mul_a(const fp &v) {
   return v;  // a = 1
 }
 
+// ---- S::SW_NATIVE (secp256r1, src/suites/secp256r1.rs:49-70; ark_ec::short_weierstrass arithmetic of ark-secp256r1): a curve
+// y^2 = x^3 - 3x + b with no twisted-Edwards model.  The SAME types carry it through every kernel of the engine:
+//   te_ext {x, y, t, z} = XYZZ coordinates (X, Y, ZZ, ZZZ): x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2; identity <=> ZZ = 0
+//                         (so all-zero memory reads as the identity);
+//   te_pre {x, y, k}    = the affine point (x, y), k unused; (0, 0) = the point at infinity (not on the curve: b != 0);
+// and the te_* functions below dispatch to the sw_* forms.  The twisted-Edwards law is complete; these formulas are not, and the
+// kernels rely on completeness (window tables add P to P, sums meet their negatives), so every exceptional case is handled here.
+template <class S> AVRF_DI te_ext sw_identity() {
+  te_ext r; r.x = fp_one<typename S::Fq>(); r.y = r.x; r.t = fp_zero(); r.z = fp_zero(); return r;
+}
+// 2 a (dbl-2008-s-1 with a = -3: M = 3 (X - ZZ)(X + ZZ)); the identity and points of order 2 come out with ZZ = 0
+template <class S> AVRF_DI te_ext sw_dbl(const te_ext &a) {
+  using Fq = typename S::Fq;
+  fp U = fp_dbl<Fq>(a.y), V = fp_sqr<Fq>(U), W = fp_mul<Fq>(U, V), Sx = fp_mul<Fq>(a.x, V);
+  fp M = fp_mul<Fq>(fp_sub<Fq>(a.x, a.t), fp_add<Fq>(a.x, a.t)); M = fp_add<Fq>(fp_dbl<Fq>(M), M);
+  te_ext r;
+  r.x = fp_sub<Fq>(fp_sqr<Fq>(M), fp_dbl<Fq>(Sx));
+  r.y = fp_sub<Fq>(fp_mul<Fq>(M, fp_sub<Fq>(Sx, r.x)), fp_mul<Fq>(W, a.y));
+  r.t = fp_mul<Fq>(V, a.t); r.z = fp_mul<Fq>(W, a.z);
+  return r;
+}
+template <class S> AVRF_DI te_ext sw_from_affine(const fp &x, const fp &y) {
+  if (fp_is_zero(x) && fp_is_zero(y)) return sw_identity<S>();
+  te_ext r; r.x = x; r.y = y; r.t = fp_one<typename S::Fq>(); r.z = r.t; return r;
+}
+// a + (x, y) (madd-2008-s: 8M + 2S)
+template <class S> AVRF_DI te_ext sw_madd(const te_ext &a, const fp &qx, const fp &qy) {
+  using Fq = typename S::Fq;
+  if (fp_is_zero(qx) && fp_is_zero(qy)) return a;
+  if (fp_is_zero(a.t)) return sw_from_affine<S>(qx, qy);
+  fp P = fp_sub<Fq>(fp_mul<Fq>(qx, a.t), a.x), R = fp_sub<Fq>(fp_mul<Fq>(qy, a.z), a.y);
+  if (fp_is_zero(P)) return fp_is_zero(R) ? sw_dbl<S>(sw_from_affine<S>(qx, qy)) : sw_identity<S>();
+  te_ext r;
+  fp PP = fp_sqr<Fq>(P);
+  r.t = fp_mul<Fq>(a.t, PP);
+  fp Q = fp_mul<Fq>(a.x, PP), PPP = fp_mul<Fq>(P, PP);
+  r.z = fp_mul<Fq>(a.z, PPP);
+  fp T = fp_mul<Fq>(a.y, PPP);
+  r.x = fp_sub<Fq>(fp_sub<Fq>(fp_sqr<Fq>(R), PPP), fp_dbl<Fq>(Q));
+  r.y = fp_sub<Fq>(fp_mul<Fq>(R, fp_sub<Fq>(Q, r.x)), T);
+  return r;
+}
+// a + b (add-2008-s: 12M + 2S)
+template <class S> AVRF_DI te_ext sw_add(const te_ext &a, const te_ext &b) {
+  using Fq = typename S::Fq;
+  if (fp_is_zero(a.t)) return b;
+  if (fp_is_zero(b.t)) return a;
+  fp U1 = fp_mul<Fq>(a.x, b.t), P = fp_sub<Fq>(fp_mul<Fq>(b.x, a.t), U1);
+  fp S1 = fp_mul<Fq>(a.y, b.z), R = fp_sub<Fq>(fp_mul<Fq>(b.y, a.z), S1);
+  if (fp_is_zero(P)) return fp_is_zero(R) ? sw_dbl<S>(a) : sw_identity<S>();
+  te_ext r;
+  fp PP = fp_sqr<Fq>(P);
+  r.t = fp_mul<Fq>(fp_mul<Fq>(a.t, b.t), PP);
+  fp Q = fp_mul<Fq>(U1, PP), PPP = fp_mul<Fq>(P, PP);
+  r.z = fp_mul<Fq>(fp_mul<Fq>(a.z, b.z), PPP);
+  fp T = fp_mul<Fq>(S1, PPP);
+  r.x = fp_sub<Fq>(fp_sub<Fq>(fp_sqr<Fq>(R), PPP), fp_dbl<Fq>(Q));
+  r.y = fp_sub<Fq>(fp_mul<Fq>(R, fp_sub<Fq>(Q, r.x)), T);
+  return r;
+}
+
 template <class S> AVRF_DI te_ext te_identity() {
+  if constexpr (S::SW_NATIVE) return sw_identity<S>();
   te_ext r; r.x = fp_zero(); r.y = fp_one<typename S::Fq>(); r.t = fp_zero(); r.z = fp_one<typename S::Fq>(); return r;
 }
-template <class S> AVRF_DI bool te_is_identity(const te_ext &p) { return fp_is_zero(p.x) && fp_eq(p.y, p.z); }
+template <class S> AVRF_DI bool te_is_identity(const te_ext &p) {
+  if constexpr (S::SW_NATIVE) return fp_is_zero(p.t);
+  return fp_is_zero(p.x) && fp_eq(p.y, p.z);
+}
 
 // p + q, q precomputed affine (8M)
 template <class S> AVRF_DI te_ext te_madd(const te_ext &p, const te_pre &q) {
   using Fq = typename S::Fq;
+  if constexpr (S::SW_NATIVE) return sw_madd<S>(p, q.x, q.y);
   fp A = fp_mul<Fq>(p.x, q.x);
   fp B = fp_mul<Fq>(p.y, q.y);
   fp C = fp_mul<Fq>(p.t, q.k);
@@ -46,11 +112,13 @@ template <class S> AVRF_DI te_ext te_madd(const te_ext &p, const te_pre &q) {
 // p - q
 template <class S> AVRF_DI te_pre te_pre_neg(const te_pre &q) {
   using Fq = typename S::Fq;
+  if constexpr (S::SW_NATIVE) { te_pre r; r.x = q.x; r.y = fp_neg<Fq>(q.y); r.k = q.k; return r; }
   te_pre r; r.x = fp_neg<Fq>(q.x); r.y = q.y; r.k = fp_neg<Fq>(q.k); return r;
 }
 // p + q, both extended (9M + 1 mul by d)
 template <class S> AVRF_DI te_ext te_add(const te_ext &p, const te_ext &q) {
   using Fq = typename S::Fq;
+  if constexpr (S::SW_NATIVE) return sw_add<S>(p, q);
   fp A = fp_mul<Fq>(p.x, q.x);
   fp B = fp_mul<Fq>(p.y, q.y);
   fp C = fp_mul<Fq>(fp_mul<Fq>(p.t, q.t), fp_const<Fq>(S::D));
@@ -66,6 +134,7 @@ template <class S> AVRF_DI te_ext te_add(const te_ext &p, const te_ext &q) {
 // 2p (4M + 4S)
 template <class S> AVRF_DI te_ext te_dbl(const te_ext &p) {
   using Fq = typename S::Fq;
+  if constexpr (S::SW_NATIVE) return sw_dbl<S>(p);
   fp A = fp_sqr<Fq>(p.x), B = fp_sqr<Fq>(p.y);
   fp C = fp_dbl<Fq>(fp_sqr<Fq>(p.z));
   fp D = mul_a<S>(A);
@@ -77,22 +146,30 @@ template <class S> AVRF_DI te_ext te_dbl(const te_ext &p) {
 }
 template <class S> AVRF_DI te_ext te_from_pre(const te_pre &q) {
   using Fq = typename S::Fq;
+  if constexpr (S::SW_NATIVE) return sw_from_affine<S>(q.x, q.y);
   te_ext r; r.x = q.x; r.y = q.y; r.t = fp_mul<Fq>(q.x, q.y); r.z = fp_one<Fq>(); return r;
 }
 template <class S> AVRF_DI te_pre te_make_pre(const fp &x_mont, const fp &y_mont) {
   using Fq = typename S::Fq;
   te_pre r; r.x = x_mont; r.y = y_mont;
+  if constexpr (S::SW_NATIVE) { r.k = fp_zero(); return r; }
   r.k = fp_mul<Fq>(fp_mul<Fq>(x_mont, y_mont), fp_const<Fq>(S::D));
   return r;
 }
 template <class S> AVRF_DI te_aff te_to_aff(const te_ext &p) {
   using Fq = typename S::Fq;
+  if constexpr (S::SW_NATIVE) {                        // 1 / (ZZ ZZZ) gives both 1 / ZZ and 1 / ZZZ; the identity -> (0, 0)
+    fp i = fp_inv<Fq>(fp_mul<Fq>(p.t, p.z));           // (0^(p-2) = 0)
+    te_aff r; r.x = fp_mul<Fq>(p.x, fp_mul<Fq>(i, p.z)); r.y = fp_mul<Fq>(p.y, fp_mul<Fq>(i, p.t)); return r;
+  }
   fp zi = fp_inv<Fq>(p.z);
   te_aff r; r.x = fp_mul<Fq>(p.x, zi); r.y = fp_mul<Fq>(p.y, zi); return r;
 }
 // a*x^2 + y^2 == 1 + d*x^2*y^2
 template <class S> AVRF_DI bool te_on_curve(const fp &x, const fp &y) {
   using Fq = typename S::Fq;
+  if constexpr (S::SW_NATIVE)                          // y^2 = x^3 + a x + b, or the point at infinity (0, 0)
+    return (fp_is_zero(x) && fp_is_zero(y)) || fp_eq(fp_sqr<Fq>(y), fp_add<Fq>(fp_mul<Fq>(fp_add<Fq>(fp_sqr<Fq>(x), fp_const<Fq>(S::SW_A)), x), fp_const<Fq>(S::SW_B)));
   fp x2 = fp_sqr<Fq>(x), y2 = fp_sqr<Fq>(y);
   fp l = fp_add<Fq>(mul_a<S>(x2), y2);
   fp r = fp_add<Fq>(fp_one<Fq>(), fp_mul<Fq>(fp_mul<Fq>(x2, y2), fp_const<Fq>(S::D)));
@@ -105,6 +182,10 @@ template <class S> AVRF_DN te_ext te_add_nf(te_ext p, te_ext q) { return te_add<
 template <class S> AVRF_DN te_ext te_dbl_nf(te_ext p) { return te_dbl<S>(p); }
 template <class S> AVRF_DN te_aff te_to_aff_nf(te_ext p) {
   using Fq = typename S::Fq;
+  if constexpr (S::SW_NATIVE) {
+    fp i = fp_inv_nf<Fq>(fp_mul_nf<Fq>(p.t, p.z));
+    te_aff r; r.x = fp_mul_nf<Fq>(p.x, fp_mul_nf<Fq>(i, p.z)); r.y = fp_mul_nf<Fq>(p.y, fp_mul_nf<Fq>(i, p.t)); return r;
+  }
   fp zi = fp_inv_nf<Fq>(p.z);
   te_aff r; r.x = fp_mul_nf<Fq>(p.x, zi); r.y = fp_mul_nf<Fq>(p.y, zi); return r;
 }

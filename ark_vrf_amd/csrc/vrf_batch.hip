@@ -177,7 +177,7 @@ k_ped_prepare(BatchDev b, uint32_t *__restrict__ c_out, uint8_t *__restrict__ me
 #pragma unroll
     for (int i = 0; i < 8; i++) dst[i] = src[i];
   } else if (m == 0) {
-    fp zero = fp_zero(), one = fp_zero(); one.v[0] = 1;
+    fp zero = fp_zero(), one = fp_zero(); one.v[0] = S::SW_NATIVE ? 0 : 1;      // identity: (0, 1), or (0, 0) for a short-Weierstrass suite
     fp_store_le(mo, zero); fp_store_le(mo + 32, one); fp_store_le(mo + 64, zero); fp_store_le(mo + 96, one);
   } else {                                                                     // merge_ios, common.rs:389-419
     auto dseed = delin_seed(t);

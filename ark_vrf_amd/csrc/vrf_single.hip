@@ -43,6 +43,7 @@ template <class S> AVRF_DI te_pre pre_from_aff(const te_aff &a) { return te_make
 // normalise two points with one inversion
 template <class S> AVRF_DI void to_aff2(const te_ext &p, const te_ext &q, te_aff &pa, te_aff &qa) {
   using Fq = typename S::Fq;
+  if constexpr (S::SW_NATIVE) { pa = te_to_aff<S>(p); qa = te_to_aff<S>(q); return; }   // (either may be the point at infinity)
   fp zz = fp_mul<Fq>(p.z, q.z), inv = fp_inv<Fq>(zz);
   fp pi = fp_mul<Fq>(inv, q.z), qi = fp_mul<Fq>(inv, p.z);
   pa.x = fp_mul<Fq>(p.x, pi); pa.y = fp_mul<Fq>(p.y, pi); qa.x = fp_mul<Fq>(q.x, qi); qa.y = fp_mul<Fq>(q.y, qi);
@@ -461,8 +462,9 @@ k_decompress(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ o
     fp xs;
     for (int i = 0; i < 8; i++) xs.v[i] = (uint32_t)src[4 * i] | ((uint32_t)src[4 * i + 1] << 8) | ((uint32_t)src[4 * i + 2] << 16) | ((uint32_t)src[4 * i + 3] << 24);
     const uint8_t flag = src[32];
-    int32_t st = 0; fp xm = fp_zero(), ym = fp_one<Fq>();
-    if ((flag & 0x7f) || ge_p<Fq>(xs) || !sw_decode_te<S>(xs, (flag & 0x80) != 0, xm, ym)) { st = 2; xm = fp_zero(); ym = fp_one<Fq>(); }
+    const fp idy = S::SW_NATIVE ? fp_zero() : fp_one<Fq>();      // y of the identity in the xy flavour
+    int32_t st = 0; fp xm = fp_zero(), ym = idy;
+    if ((flag & 0x7f) || ge_p<Fq>(xs) || !sw_decode_te<S>(xs, (flag & 0x80) != 0, xm, ym)) { st = 2; xm = fp_zero(); ym = idy; }
     else if (validate) {
       te_ext rp = te_smul<S>(te_make_pre<S>(xm, ym), fp_const<Fr>(Fr::P), Fr::BITS);   // r * P == 0
       if (!te_is_identity<S>(rp)) st = 2;

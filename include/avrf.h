@@ -45,6 +45,9 @@ enum {
   AVRF_SUITE_ED25519_SHA512_TAI = 3,       /* src/suites/ed25519.rs:44-66 (Tiny / Thin / Pedersen; no RingSuite: avrf_ring_* -> BAD_ARG) */
   AVRF_SUITE_BANDERSNATCH_SHAKE128_ELL2 = 5, /* src/suites/bandersnatch_shake128.rs: suite 0's curve, Shake128Transcript, expand_message_xof */
   AVRF_SUITE_TESTING_SHA256_TAI = 6,        /* src/suites/testing.rs: the crate's own test suite (edwards25519, HashTranscript<Sha256>; no ring) */
+  AVRF_SUITE_SECP256R1_SHA256_TAI = 7,      /* src/suites/secp256r1.rs:49-70: NIST P-256 (a = -3 short Weierstrass, cofactor 1, 256-bit fields with the
+                                             * top bit set), HashTranscript<Sha256>; Tiny / Thin / Pedersen, no RingSuite.  xy points are the curve's own
+                                             * affine points, the identity is the all-zero 64 bytes; compressed form: 33 bytes (avrf_point_len) */
   AVRF_SUITE_BANDERSNATCH_SW_SHA512_TAI = 4 /* src/suites/bandersnatch_sw.rs:60-112: Bandersnatch in its short-Weierstrass presentation.
                                              * xy points are the TEMapping (src/utils/te_sw_map.rs) of the suite's SWAffine; the compressed
                                              * form (avrf_points_*, *_wire) is its 33-byte serialize_compressed: see avrf_point_len */

@@ -39,7 +39,8 @@ class Suite {
   enum Id { BandersnatchSha512Ell2 = AVRF_SUITE_BANDERSNATCH_SHA512_ELL2, BabyJubJubSha512Tai = AVRF_SUITE_BABYJUBJUB_SHA512_TAI,
             JubJubSha512Tai = AVRF_SUITE_JUBJUB_SHA512_TAI, Ed25519Sha512Tai = AVRF_SUITE_ED25519_SHA512_TAI,
             BandersnatchSwSha512Tai = AVRF_SUITE_BANDERSNATCH_SW_SHA512_TAI,
-            BandersnatchShake128Ell2 = AVRF_SUITE_BANDERSNATCH_SHAKE128_ELL2, TestingSha256Tai = AVRF_SUITE_TESTING_SHA256_TAI };
+            BandersnatchShake128Ell2 = AVRF_SUITE_BANDERSNATCH_SHAKE128_ELL2, TestingSha256Tai = AVRF_SUITE_TESTING_SHA256_TAI,
+            Secp256r1Sha256Tai = AVRF_SUITE_SECP256R1_SHA256_TAI };
   // whose job is Validate::Yes? 0: the caller's (typed-point contract of the reference), 1: on-curve check, 2: + subgroup check
   void set_validation(int level) { if (avrf_ctx_set_validation(ctx_, level) != AVRF_OK) throw std::invalid_argument("avrf: validation level"); }
   explicit Suite(Id id, int device = 0) {

@@ -12,6 +12,7 @@ R_ORDER = {
     orc.TESTING_SHA256: 2 ** 252 + 27742317777372353535851937790883648493,
     orc.BANDERSNATCH_SW: 0x1cfb69d4ca675f520cce760202687600ff8f87007419047174fd06b52876e7e1,
     orc.BANDERSNATCH_SHAKE128: 0x1cfb69d4ca675f520cce760202687600ff8f87007419047174fd06b52876e7e1,
+    orc.SECP256R1: 0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551,
 }
 IDENTITY_XY = bytes(32) + (1).to_bytes(32, "little")
 

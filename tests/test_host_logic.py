@@ -79,7 +79,7 @@ def test_host_pairing_on_reference_srs(tmp_path, golden_dir, curve, srs):
     subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(ROOT, "tests", "cpp", "host_pairing_check.cpp"), "-o", exe])
     out = subprocess.run([exe, str(curve), os.path.join(golden_dir, srs)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.strip() == "consistent=1 negative=0 consistent_high=1 g2_codec=1 g2_law=1 cyclo_sqr=1 f12_inv=1"
+    assert out.stdout.strip() == "consistent=1 negative=0 consistent_high=1 g2_codec=1 g2_law=1 cyclo_sqr=1 f12_inv=1 line_tables=1"
 
 
 def test_multibuffer_weight_hash_matches_scalar():

@@ -27,6 +27,7 @@ def field(name, p):
     s.append(f"  static constexpr uint32_t HALF[8] = {{{limbs((p - 1) // 2)}}};  /* (p-1)/2, plain */")
     s.append(f"  static constexpr uint32_t NINV = 0x{ninv:08x}u;  /* -p^-1 mod 2^32 */")
     s.append(f"  static constexpr int BITS = {p.bit_length()};")
+    s.append(f"  static constexpr bool FULL = {'true' if p.bit_length() == 256 else 'false'};  /* top bit of the modulus set: sums and Montgomery products carry into bit 256 (fp256.h) */")
     # Tonelli-Shanks data
     t, tw = p - 1, 0
     while t % 2 == 0:
@@ -59,7 +60,8 @@ def field_n(name, p, nl):
          f"  static constexpr uint32_t HALF[{nl}] = {{{lim((p - 1) // 2)}}};",
          f"  static constexpr uint32_t PM2[{nl}] = {{{lim(p - 2)}}};",
          f"  static constexpr uint32_t NINV = 0x{ninv:08x}u;",
-         f"  static constexpr int BITS = {p.bit_length()};", "};"]
+         f"  static constexpr int BITS = {p.bit_length()};",
+         f"  static constexpr bool FULL = {'true' if p.bit_length() == 32 * nl else 'false'};", "};"]
     return "\n".join(s)
 
 
@@ -101,6 +103,7 @@ def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=
     # short-Weierstrass presentation (src/suites/bandersnatch_sw.rs, src/utils/te_sw_map.rs): serialised points are 33-byte SW
     # forms; arithmetic stays twisted-Edwards through the maps (x, y) -> (B x - A/3, B y) -> (u / v, (u - 1) / (u + 1))
     s.append(f"  static constexpr bool SW_CODEC = {'true' if sw else 'false'};")
+    s.append("  static constexpr bool SW_NATIVE = false;  /* a twisted-Edwards curve (possibly presented as short Weierstrass) */")
     s.append(f"  static constexpr int POINT_LEN = {33 if sw else 32};  /* serialize_compressed size of the suite's Affine */")
     if sw:
         for nm in ("MONT_B", "MONT_A3", "MONT_BINV", "SW_A", "SW_B"):
@@ -115,6 +118,46 @@ def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=
             s.append(f"  static constexpr uint32_t {nm}[{n}] = {{{lw(v, n)}}};")
         s.append(f"  static constexpr uint32_t ENDO_B[8] = {{{limbs(mont(glv['eb'], q))}}};  /* psi(x, y) = (c (1 - y^2) / (x y), b (y^2 + b) / (y^2 - b)) */")
         s.append(f"  static constexpr uint32_t ENDO_C[8] = {{{limbs(mont(glv['ec'], q))}}};")
+    s.append("};")
+    return "\n".join(s)
+
+
+def suite_sw_native(name, sid, sid_str, fq, fr, q, a, b, pts, sha256=True):
+    """a genuinely short-Weierstrass suite (src/suites/secp256r1.rs:49-70): y^2 = x^3 + a x + b with a = -3, cofactor 1.  The
+    kernels are the twisted-Edwards suites' kernels: te.h gives te_ext / te_pre / te_aff a second meaning for S::SW_NATIVE (XYZZ
+    coordinates, affine (x, y), (0, 0) = infinity), sw_map.h's 33-byte codec becomes the identity map."""
+    assert a % q == q - 3
+    sid_bytes = ", ".join(str(c) for c in sid_str.encode())
+    zero = limbs(0)
+    s = [f"struct {name} {{", f"  using Fq = {fq}; using Fr = {fr};",
+         f"  static constexpr int SUITE_ID_LEN = {len(sid_str)};",
+         f"  static constexpr uint8_t SUITE_ID[{len(sid_str)}] = {{{sid_bytes}}};  /* {sid_str} */",
+         f"  static constexpr int ID = {sid};",
+         "  static constexpr int A_KIND = 0;  /* unused (twisted-Edwards coefficient) */",
+         "  static constexpr int COFACTOR = 1;",
+         f"  static constexpr uint32_t D[8] = {{{zero}}};  /* unused */"]
+    for nm, (x, y) in pts.items():
+        assert (y * y - x ** 3 - a * x - b) % q == 0
+        s.append(f"  static constexpr uint32_t {nm}_X[8] = {{{limbs(mont(x, q))}}};")
+        s.append(f"  static constexpr uint32_t {nm}_Y[8] = {{{limbs(mont(y, q))}}};")
+        s.append(f"  static constexpr uint32_t {nm}_K[8] = {{{zero}}};  /* unused */")
+    gx, gy = pts["G"]
+    enc = gx.to_bytes(32, "little") + bytes([0x80 if gy > (q - 1) // 2 else 0])
+    s.append(f"  static constexpr uint8_t G_ENC[33] = {{{', '.join(str(c) for c in enc)}}};  /* serialize_compressed(generator) */")
+    s.append("  static constexpr int H2C_ELL2 = 0;")
+    for nm in ("ELL2_JK", "ELL2_K", "ELL2_KINV2"):
+        s.append(f"  static constexpr uint32_t {nm}[8] = {{{zero}}};  /* unused */")
+    s.append("  static constexpr bool XOF_SHAKE = false;")
+    s.append(f"  static constexpr bool TR_SHA256 = {'true' if sha256 else 'false'};  /* Suite::Transcript = HashTranscript<Sha256> */")
+    s.append(f"  static constexpr bool HOST_WEIGHTS = {'true' if sha256 else 'false'};")
+    s.append("  static constexpr bool SW_CODEC = true;   /* serialised points: 33-byte SWAffine form */")
+    s.append("  static constexpr bool SW_NATIVE = true;  /* ... of the curve's own points: no twisted-Edwards model behind it */")
+    s.append("  static constexpr int POINT_LEN = 33;")
+    for nm in ("MONT_B", "MONT_A3", "MONT_BINV"):
+        s.append(f"  static constexpr uint32_t {nm}[8] = {{{zero}}};  /* unused */")
+    s.append(f"  static constexpr uint32_t SW_A[8] = {{{limbs(mont(a % q, q))}}};")
+    s.append(f"  static constexpr uint32_t SW_B[8] = {{{limbs(mont(b, q))}}};")
+    s.append("  static constexpr bool HAS_GLV = false;")
     s.append("};")
     return "\n".join(s)
 
@@ -339,6 +382,18 @@ def main():
                       "B": (3310617998588019043596181043598335786888094217571323926547956053100032777190,
                             16824531136491949759823061604778551593864344614632277377095388820423530178202),
                       "ACC": g_e, "PAD": g_e}, 8, sha256=True))
+    # Secp256r1-SHA256-TAI-v1 (src/suites/secp256r1.rs:49-70): NIST P-256 (SP 800-186 3.2.1.3), both fields 256 bits with the top bit set
+    q_p = 0xffffffff00000001000000000000000000000000ffffffffffffffffffffffff
+    r_p = 0xffffffff00000000ffffffffffffffffbce6faada7179e84f3b9cac2fc632551
+    out.insert(out.index(next(x for x in out if x.startswith("struct FqBls12381"))), field("FqSecp256r1", q_p))
+    out.insert(out.index(next(x for x in out if x.startswith("struct FqBls12381"))), field("FrSecp256r1", r_p))
+    g_p = (0x6b17d1f2e12c4247f8bce6e563a440f277037d812deb33a0f4a13945d898c296, 0x4fe342e2fe1a7f9b8ee7eb4a7c0f9e162bce33576b315ececbb6406837bf51f5)
+    out.append(suite_sw_native("SuiteSecp256r1", 7, "Secp256r1-SHA256-TAI-v1", "FqSecp256r1", "FrSecp256r1", q_p, q_p - 3,
+                               0x5ac635d8aa3a93e7b3ebbd55769886bc651d06b0cc53b0f63bce3c3e27d2604b,
+                               {"G": g_p,
+                                "B": (100063053743935619201936855760019111820847755970243670581468062459849338000,
+                                      113675507039234898358330549589155441528265243038226986303017485279501143145422),
+                                "ACC": g_p, "PAD": g_p}))
     out += ["", "}  // namespace avrf", ""]
     with open(OUT, "w") as f:
         f.write("\n".join(out))

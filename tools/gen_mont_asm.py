@@ -40,6 +40,8 @@ def fields(N):
         if not pm or not nm or int(pm.group(1)) != N:
             continue
         limbs = [int(x.strip().rstrip("u"), 16) for x in pm.group(2).split(",")]
+        if limbs[-1] >> 31:
+            continue          # top bit of the modulus set (secp256r1): t < 2p needs a 257th bit -- those fields take mac96.h's C++ form
         out.append((name, limbs, int(nm.group(1), 16)))
     return out
 
