@@ -31,57 +31,63 @@ template <class S> AVRF_DI fp mul_a(const fp &v) {
 //   te_pre {x, y, k}    = the affine point (x, y), k unused; (0, 0) = the point at infinity (not on the curve: b != 0);
 // and the te_* functions below dispatch to the sw_* forms.  The twisted-Edwards law is complete; these formulas are not, and the
 // kernels rely on completeness (window tables add P to P, sums meet their negatives), so every exceptional case is handled here.
+// The multiplications go through the OUT-OF-LINE multiplier (fp_mul_nf): these fields have no asm block, and forty inlined copies
+// of the generic 128-statement form inside one non-kernel function (te_smul) produced code that faulted on the device -- the
+// same function body inlined into its kernel, or calling one shared multiplier, is correct (tools/secp_probe.hip).
 template <class S> AVRF_DI te_ext sw_identity() {
   te_ext r; r.x = fp_one<typename S::Fq>(); r.y = r.x; r.t = fp_zero(); r.z = fp_zero(); return r;
 }
 // 2 a (dbl-2008-s-1 with a = -3: M = 3 (X - ZZ)(X + ZZ)); the identity and points of order 2 come out with ZZ = 0
 template <class S> AVRF_DI te_ext sw_dbl(const te_ext &a) {
   using Fq = typename S::Fq;
-  fp U = fp_dbl<Fq>(a.y), V = fp_sqr<Fq>(U), W = fp_mul<Fq>(U, V), Sx = fp_mul<Fq>(a.x, V);
-  fp M = fp_mul<Fq>(fp_sub<Fq>(a.x, a.t), fp_add<Fq>(a.x, a.t)); M = fp_add<Fq>(fp_dbl<Fq>(M), M);
+  fp U = fp_dbl<Fq>(a.y), V = fp_sqr_nf<Fq>(U), W = fp_mul_nf<Fq>(U, V), Sx = fp_mul_nf<Fq>(a.x, V);
+  fp M = fp_mul_nf<Fq>(fp_sub<Fq>(a.x, a.t), fp_add<Fq>(a.x, a.t)); M = fp_add<Fq>(fp_dbl<Fq>(M), M);
   te_ext r;
-  r.x = fp_sub<Fq>(fp_sqr<Fq>(M), fp_dbl<Fq>(Sx));
-  r.y = fp_sub<Fq>(fp_mul<Fq>(M, fp_sub<Fq>(Sx, r.x)), fp_mul<Fq>(W, a.y));
-  r.t = fp_mul<Fq>(V, a.t); r.z = fp_mul<Fq>(W, a.z);
+  r.x = fp_sub<Fq>(fp_sqr_nf<Fq>(M), fp_dbl<Fq>(Sx));
+  r.y = fp_sub<Fq>(fp_mul_nf<Fq>(M, fp_sub<Fq>(Sx, r.x)), fp_mul_nf<Fq>(W, a.y));
+  r.t = fp_mul_nf<Fq>(V, a.t); r.z = fp_mul_nf<Fq>(W, a.z);
   return r;
 }
 template <class S> AVRF_DI te_ext sw_from_affine(const fp &x, const fp &y) {
   if (fp_is_zero(x) && fp_is_zero(y)) return sw_identity<S>();
   te_ext r; r.x = x; r.y = y; r.t = fp_one<typename S::Fq>(); r.z = r.t; return r;
 }
-// a + (x, y) (madd-2008-s: 8M + 2S)
+// a + (x, y) (madd-2008-s: 8M + 2S).  Single exit: the exceptional cases (a or the base at infinity, equal or opposite points)
+// overwrite the result of the main sequence, which is computed for every lane and harmless on their inputs.
 template <class S> AVRF_DI te_ext sw_madd(const te_ext &a, const fp &qx, const fp &qy) {
   using Fq = typename S::Fq;
-  if (fp_is_zero(qx) && fp_is_zero(qy)) return a;
-  if (fp_is_zero(a.t)) return sw_from_affine<S>(qx, qy);
-  fp P = fp_sub<Fq>(fp_mul<Fq>(qx, a.t), a.x), R = fp_sub<Fq>(fp_mul<Fq>(qy, a.z), a.y);
-  if (fp_is_zero(P)) return fp_is_zero(R) ? sw_dbl<S>(sw_from_affine<S>(qx, qy)) : sw_identity<S>();
+  const bool q_inf = fp_is_zero(qx) && fp_is_zero(qy), a_inf = fp_is_zero(a.t);
+  fp P = fp_sub<Fq>(fp_mul_nf<Fq>(qx, a.t), a.x), R = fp_sub<Fq>(fp_mul_nf<Fq>(qy, a.z), a.y);
   te_ext r;
-  fp PP = fp_sqr<Fq>(P);
-  r.t = fp_mul<Fq>(a.t, PP);
-  fp Q = fp_mul<Fq>(a.x, PP), PPP = fp_mul<Fq>(P, PP);
-  r.z = fp_mul<Fq>(a.z, PPP);
-  fp T = fp_mul<Fq>(a.y, PPP);
-  r.x = fp_sub<Fq>(fp_sub<Fq>(fp_sqr<Fq>(R), PPP), fp_dbl<Fq>(Q));
-  r.y = fp_sub<Fq>(fp_mul<Fq>(R, fp_sub<Fq>(Q, r.x)), T);
+  fp PP = fp_sqr_nf<Fq>(P);
+  r.t = fp_mul_nf<Fq>(a.t, PP);
+  fp Q = fp_mul_nf<Fq>(a.x, PP), PPP = fp_mul_nf<Fq>(P, PP);
+  r.z = fp_mul_nf<Fq>(a.z, PPP);
+  fp T = fp_mul_nf<Fq>(a.y, PPP);
+  r.x = fp_sub<Fq>(fp_sub<Fq>(fp_sqr_nf<Fq>(R), PPP), fp_dbl<Fq>(Q));
+  r.y = fp_sub<Fq>(fp_mul_nf<Fq>(R, fp_sub<Fq>(Q, r.x)), T);
+  if (q_inf) r = a;
+  else if (a_inf) r = sw_from_affine<S>(qx, qy);
+  else if (fp_is_zero(P)) { if (fp_is_zero(R)) r = sw_dbl<S>(sw_from_affine<S>(qx, qy)); else r = sw_identity<S>(); }
   return r;
 }
-// a + b (add-2008-s: 12M + 2S)
+// a + b (add-2008-s: 12M + 2S), same structure
 template <class S> AVRF_DI te_ext sw_add(const te_ext &a, const te_ext &b) {
   using Fq = typename S::Fq;
-  if (fp_is_zero(a.t)) return b;
-  if (fp_is_zero(b.t)) return a;
-  fp U1 = fp_mul<Fq>(a.x, b.t), P = fp_sub<Fq>(fp_mul<Fq>(b.x, a.t), U1);
-  fp S1 = fp_mul<Fq>(a.y, b.z), R = fp_sub<Fq>(fp_mul<Fq>(b.y, a.z), S1);
-  if (fp_is_zero(P)) return fp_is_zero(R) ? sw_dbl<S>(a) : sw_identity<S>();
+  const bool a_inf = fp_is_zero(a.t), b_inf = fp_is_zero(b.t);
+  fp U1 = fp_mul_nf<Fq>(a.x, b.t), P = fp_sub<Fq>(fp_mul_nf<Fq>(b.x, a.t), U1);
+  fp S1 = fp_mul_nf<Fq>(a.y, b.z), R = fp_sub<Fq>(fp_mul_nf<Fq>(b.y, a.z), S1);
   te_ext r;
-  fp PP = fp_sqr<Fq>(P);
-  r.t = fp_mul<Fq>(fp_mul<Fq>(a.t, b.t), PP);
-  fp Q = fp_mul<Fq>(U1, PP), PPP = fp_mul<Fq>(P, PP);
-  r.z = fp_mul<Fq>(fp_mul<Fq>(a.z, b.z), PPP);
-  fp T = fp_mul<Fq>(S1, PPP);
-  r.x = fp_sub<Fq>(fp_sub<Fq>(fp_sqr<Fq>(R), PPP), fp_dbl<Fq>(Q));
-  r.y = fp_sub<Fq>(fp_mul<Fq>(R, fp_sub<Fq>(Q, r.x)), T);
+  fp PP = fp_sqr_nf<Fq>(P);
+  r.t = fp_mul_nf<Fq>(fp_mul_nf<Fq>(a.t, b.t), PP);
+  fp Q = fp_mul_nf<Fq>(U1, PP), PPP = fp_mul_nf<Fq>(P, PP);
+  r.z = fp_mul_nf<Fq>(fp_mul_nf<Fq>(a.z, b.z), PPP);
+  fp T = fp_mul_nf<Fq>(S1, PPP);
+  r.x = fp_sub<Fq>(fp_sub<Fq>(fp_sqr_nf<Fq>(R), PPP), fp_dbl<Fq>(Q));
+  r.y = fp_sub<Fq>(fp_mul_nf<Fq>(R, fp_sub<Fq>(Q, r.x)), T);
+  if (a_inf) r = b;
+  else if (b_inf) r = a;
+  else if (fp_is_zero(P)) { if (fp_is_zero(R)) r = sw_dbl<S>(a); else r = sw_identity<S>(); }
   return r;
 }
 

@@ -18,6 +18,10 @@
 // once without it (the run-time dispatch below); csrc/Makefile.  One translation unit for all suites took eight minutes.
 namespace avrf {
 #ifdef AVRF_TU_SUITE
+// waves per SIMD the register allocator must leave room for in the per-item protocol kernels (1: the whole register file)
+#ifndef AVRF_ITEM_WAVES
+#define AVRF_ITEM_WAVES 1
+#endif
 
 // (I_m, O_m) = sum_i z_i * (I_i, O_i) over `m` caller pairs; z stream from `dseed`.
 // first_is_one: the first caller pair takes z = 1 (Pedersen); otherwise pair i takes chunk i (Thin,
@@ -114,7 +118,7 @@ AVRF_DI te_ext schnorr_lhs(const BatchDev &b, const uint8_t *ios, const uint8_t 
 // TINY: tiny::Prover::prove (src/tiny.rs:163-176) -- the same steps under scheme tag 0x00; the proof keeps the challenge
 // instead of the nonce commitment: LE16(c) || LE32(s), 48 bytes (src/tiny.rs:60-78)
 template <class S, bool TINY>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128, AVRF_ITEM_WAVES)
 k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict__ flags) {
   using Fr = typename S::Fr;
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -170,7 +174,7 @@ k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict_
 
 // tiny::Verifier::verify (src/tiny.rs:178-214): R = s I_m - c O_m, recompute the challenge, compare with c
 template <class S>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128, AVRF_ITEM_WAVES)
 k_tiny_verify(BatchDev b, int32_t *__restrict__ status) {
   using Fr = typename S::Fr;
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -191,7 +195,7 @@ k_tiny_verify(BatchDev b, int32_t *__restrict__ status) {
 }
 
 template <class S>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128, AVRF_ITEM_WAVES)
 k_thin_verify(BatchDev b, int32_t *__restrict__ status) {
   using Fr = typename S::Fr; using Fq = typename S::Fq;
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,7 +219,7 @@ k_thin_verify(BatchDev b, int32_t *__restrict__ status) {
 // ---------------------------------------------------------------- Pedersen VRF
 
 template <class S>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128, AVRF_ITEM_WAVES)
 k_ped_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ blindings_out, uint32_t *__restrict__ flags) {
   using Fr = typename S::Fr;
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -265,7 +269,7 @@ k_ped_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ 
 }
 
 template <class S>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128, AVRF_ITEM_WAVES)
 k_ped_verify(BatchDev b, int32_t *__restrict__ status) {
   using Fr = typename S::Fr; using Fq = typename S::Fq;
   uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
