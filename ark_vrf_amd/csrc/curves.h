@@ -11,6 +11,17 @@
 #ifndef AVRF_TE_ACC_WAVES
 #define AVRF_TE_ACC_WAVES 2
 #endif
+// 12-limb G1 accumulate: 2 waves per SIMD = 192 VGPRs, no scratch; 3 = 168 VGPRs + 44 spilled registers.  A/B on one box
+// (tools/r3_run4.sh, ring 1024): 4 contexts 11.49 k proofs/s against 11.05-11.11 k, one context 8.0-9.3 k against 7.4-7.8 k,
+// and the window-table build of a setup 82 ms against 96-118 ms.
+#ifndef AVRF_G1_ACC_WAVES
+#define AVRF_G1_ACC_WAVES 2
+#endif
+// reduction kernels of the 12-limb curve (general additions, two accumulators live): the whole register file, no scratch
+// (at 2 waves per SIMD k_wsum spilled 94 registers and k_wsum_blk 458; same A/B: 11.48-11.63 k proofs/s against 11.19-11.51 k)
+#ifndef AVRF_G1_RED_WAVES
+#define AVRF_G1_RED_WAVES 1
+#endif
 
 namespace avrf {
 
@@ -71,8 +82,8 @@ template <class C> struct G1Curve {
   static constexpr int BASE_WORDS = 2 * N, ACC_WORDS = 4 * N;
   static constexpr bool QUAD = false;
   static constexpr bool PREFETCH = (N <= 8);
-  static constexpr int MIN_WAVES = 3;                 // k_accumulate holds one accumulator + one base: 184 VGPRs at N = 12
-  static constexpr int RED_WAVES = 2;                 // the general addition (two accumulators live) needs the 256-register budget
+  static constexpr int MIN_WAVES = N > 8 ? AVRF_G1_ACC_WAVES : 3;   // k_accumulate holds one accumulator + one base
+  static constexpr int RED_WAVES = N > 8 ? AVRF_G1_RED_WAVES : 2;   // the general addition (two accumulators live) needs the 256-register budget
   static constexpr bool INLINE_REDUCE_OPS = true;     // k_wsum*: additions inlined (the asm multiplier keeps the code small)
   static constexpr bool WINDOW_SUMS = false;
   static constexpr bool ZERO_IS_IDENTITY = true;      // zz = 0; all-zero memory reads as the identity
