@@ -85,6 +85,7 @@ struct avrf_ctx {
   DevBuf d_rec; PinBuf h_msg;     // counter-mode transcripts: the records written by the prepare kernel, and prefix || records on the host
   std::vector<uint8_t> h_weights; DevBuf d_weights;   // sponge transcripts: the squeezed weight stream of the staged batch
   DevBuf d_c, d_z, d_flags, d_scalars, d_pre, d_gpart, d_misc, d_out, d_status;
+  DevBuf d_tabs;                               // per-item window tables of the independent prove / verify kernels
   DevBuf d_fixed; bool fixed_ready = false;   // fixed-base tables of G and BLINDING_BASE (provers, scalar_mul_base), built on first use
   PinBuf h_c, h_flags, h_io;
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -92,6 +93,8 @@ struct avrf_ctx {
 
 // fixed-base tables for the provers: built once per context, on the context's stream
 static int ensure_fixed(avrf_ctx *c) {
+  // window tables of the staged items (proto_dev.h te_smul_ws): ITEM_TAB_SLOTS x 128 bytes each, 5 KB per item, kept by the context
+  if (c->n && c->d_tabs.ensure(c->n * (size_t)ITEM_TAB_SLOTS * sizeof(te_ext_raw)) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   if (c->fixed_ready) return AVRF_OK;
   if (c->d_fixed.ensure((size_t)2 * 32 * 256 * sizeof(te_pre_raw)) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   launch_fixed_table(c->suite, c->d_fixed.as<te_pre_raw>(), c->stream);
@@ -105,6 +108,7 @@ static BatchDev batch_of(avrf_ctx *c) {
   b.ads = c->d_ads.as<uint8_t>(); b.ad_off = c->d_ad_off.as<uint32_t>(); b.proofs = c->d_proofs.as<uint8_t>();
   b.sks = c->d_sks.as<uint8_t>(); b.n = (uint32_t)c->n;
   b.fixed = (const te_pre *)c->d_fixed.p;
+  b.tabs = (te_ext *)c->d_tabs.p;                  // per-item window tables (sized by ensure_fixed for the staged batch)
   b.weights = nullptr; b.records = nullptr;
   return b;
 }
@@ -183,7 +187,7 @@ void avrf_ctx_destroy(avrf_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   c->ws.release();
   DevBuf *bufs[] = {&c->d_pks, &c->d_ios, &c->d_io_off, &c->d_ads, &c->d_ad_off, &c->d_proofs, &c->d_sks, &c->d_c, &c->d_z,
-                    &c->d_flags, &c->d_scalars, &c->d_pre, &c->d_gpart, &c->d_misc, &c->d_out, &c->d_status, &c->d_fixed, &c->d_weights, &c->d_rec};
+                    &c->d_flags, &c->d_scalars, &c->d_pre, &c->d_gpart, &c->d_misc, &c->d_out, &c->d_status, &c->d_fixed, &c->d_weights, &c->d_rec, &c->d_tabs};
   for (DevBuf *b : bufs) b->release();
   c->h_c.release(); c->h_flags.release(); c->h_io.release(); c->h_msg.release();
   (void)hipStreamDestroy(c->stream);

@@ -104,6 +104,71 @@ template <class S> AVRF_DI void glv_table(te_ext (&tab)[16], const te_pre &p, co
 }
 AVRF_DI uint32_t digit2(const fp &k, int w) { return (k.v[w >> 4] >> (2 * (w & 15))) & 3u; }
 
+// the same table written to the item's workspace slots (proto_dev.h te_smul_ws): tab[4 j + i] = i P + j Q
+template <class S> AVRF_DI void glv_table_ws(te_ext *tab, const te_pre &p, const te_ext &q) {
+  te_ext row = q;
+  for (int j = 0; j < 4; j++) {
+    if (j == 2) row = te_dbl<S>(q); else if (j == 3) row = te_add<S>(row, q);
+    te_ext cur = j ? row : te_identity<S>();
+    if (j) store_ext(tab + 4 * j, cur);
+    for (int i = 1; i < 4; i++) { cur = te_madd<S>(cur, p); store_ext(tab + 4 * j + i, cur); }
+  }
+}
+// k * P with the table in the workspace (ws: ITEM_TAB_SLOTS entries of this item, or nullptr = private memory)
+template <class S> AVRF_DN te_ext te_smul_glv_ws_nf(te_ext *ws, te_pre p, fp k) {
+  using Fr = typename S::Fr;
+  te_ext q;
+  if (!te_endo<S>(p, q)) return te_smul_ws<S>(ws, p, k, Fr::BITS);
+  const glv_scalars g = glv_decompose<S>(k);
+  if (g.n1) p = te_pre_neg<S>(p);
+  if (g.n2) q = te_ext_neg<S>(q);
+  glv_table_ws<S>(ws, p, q);
+  te_ext acc = te_identity<S>();
+  for (int w = 63; w >= 0; w--) {
+    const uint32_t d = 4 * digit2(g.k2, w) + digit2(g.k1, w);
+    te_ext e; if (d) e = load_ext(ws + d);
+    acc = te_dbl<S>(te_dbl<S>(acc));
+    if (d) acc = te_add<S>(acc, e);
+  }
+  return acc;
+}
+template <class S, bool HAVE_Q> AVRF_DN te_ext te_smul_multi_glv_ws_nf(te_ext *ws, te_pre p, fp a, te_pre q, fp b, te_pre r, fp c) {
+  using Fr = typename S::Fr;
+  te_ext pe, qe;
+  bool ok = te_endo<S>(p, pe);
+  if (HAVE_Q) ok = te_endo<S>(q, qe) && ok;
+  if (!ok) {                                                        // a degenerate point: the plain forms
+    te_ext acc = HAVE_Q ? te_smul2_ws<S>(ws, p, a, q, b, Fr::BITS) : te_smul_ws<S>(ws, p, a, Fr::BITS);
+    return te_add<S>(acc, te_smul_ws<S>(ws + 16, r, c, 128));
+  }
+  const glv_scalars ga = glv_decompose<S>(a);
+  if (ga.n1) p = te_pre_neg<S>(p);
+  if (ga.n2) pe = te_ext_neg<S>(pe);
+  te_ext *tp = ws, *tq = ws + 16, *tr = ws + 32;
+  glv_table_ws<S>(tp, p, pe);
+  glv_scalars gb = ga;
+  if (HAVE_Q) {
+    gb = glv_decompose<S>(b);
+    if (gb.n1) q = te_pre_neg<S>(q);
+    if (gb.n2) qe = te_ext_neg<S>(qe);
+    glv_table_ws<S>(tq, q, qe);
+  }
+  { te_ext cur = te_from_pre<S>(r); store_ext(tr + 1, cur); cur = te_madd<S>(cur, r); store_ext(tr + 2, cur); cur = te_madd<S>(cur, r); store_ext(tr + 3, cur); }
+  te_ext acc = te_identity<S>();
+  for (int w = 63; w >= 0; w--) {
+    const uint32_t d = 4 * digit2(ga.k2, w) + digit2(ga.k1, w), e = HAVE_Q ? 4 * digit2(gb.k2, w) + digit2(gb.k1, w) : 0u, f = digit2(c, w);
+    te_ext e1, e2, e3;                                              // the window's entries: loads issued ahead of the doublings
+    if (d) e1 = load_ext(tp + d);
+    if (HAVE_Q) if (e) e2 = load_ext(tq + e);
+    if (f) e3 = load_ext(tr + f);
+    acc = te_dbl<S>(te_dbl<S>(acc));
+    if (d) acc = te_add<S>(acc, e1);
+    if (HAVE_Q) if (e) acc = te_add<S>(acc, e2);
+    if (f) acc = te_add<S>(acc, e3);
+  }
+  return acc;
+}
+
 // k * P, k a plain integer < r.  Suites without the endomorphism: the 4-bit window form.
 template <class S> AVRF_DN te_ext te_smul_glv_nf(te_pre p, fp k) {
   using Fr = typename S::Fr;
@@ -125,6 +190,10 @@ template <class S> AVRF_DN te_ext te_smul_glv_nf(te_pre p, fp k) {
 template <class S> AVRF_DI te_ext te_smul_glv(const te_pre &p, const fp &k) {
   if constexpr (S::HAS_GLV) return te_smul_glv_nf<S>(p, k);
   else return te_smul<S>(p, k, S::Fr::BITS);
+}
+template <class S> AVRF_DI te_ext te_smul_glv(te_ext *ws, const te_pre &p, const fp &k) {
+  if constexpr (S::HAS_GLV) return te_smul_glv_ws_nf<S>(ws, p, k);
+  else return te_smul_ws<S>(ws, p, k, S::Fr::BITS);
 }
 
 // a * P [+ b * Q] + c * R with a, b plain integers < r and c < 2^128: one chain of 128 doublings over the GLV tables of P
@@ -165,11 +234,20 @@ template <class S, bool HAVE_Q> AVRF_DN te_ext te_smul_multi_glv_nf(te_pre p, fp
   }
   return acc;
 }
+template <class S, bool HAVE_Q> AVRF_DI te_ext te_smul_multi_glv(te_ext *ws, const te_pre &p, const fp &a, const te_pre &q, const fp &b, const te_pre &r, const fp &c);
 template <class S, bool HAVE_Q> AVRF_DI te_ext te_smul_multi_glv(const te_pre &p, const fp &a, const te_pre &q, const fp &b, const te_pre &r, const fp &c) {
   if constexpr (S::HAS_GLV) return te_smul_multi_glv_nf<S, HAVE_Q>(p, a, q, b, r, c);
   else {                                                            // exactly the pre-GLV forms
     te_ext acc = HAVE_Q ? te_smul2<S>(p, a, q, b, S::Fr::BITS) : te_smul2<S>(p, a, r, c, S::Fr::BITS);
     return HAVE_Q ? te_add<S>(acc, te_smul<S>(r, c, 128)) : acc;
+  }
+}
+
+template <class S, bool HAVE_Q> AVRF_DI te_ext te_smul_multi_glv(te_ext *ws, const te_pre &p, const fp &a, const te_pre &q, const fp &b, const te_pre &r, const fp &c) {
+  if constexpr (S::HAS_GLV) return te_smul_multi_glv_ws_nf<S, HAVE_Q>(ws, p, a, q, b, r, c);
+  else {
+    te_ext acc = HAVE_Q ? te_smul2_ws<S>(ws, p, a, q, b, S::Fr::BITS) : te_smul2_ws<S>(ws, p, a, r, c, S::Fr::BITS);
+    return HAVE_Q ? te_add<S>(acc, te_smul_ws<S>(ws + 16, r, c, 128)) : acc;
   }
 }
 

@@ -53,6 +53,8 @@ struct BatchDev {
                             // one contiguous buffer that came back in a single copy; nullptr: not wanted
   const uint8_t *weights;   // batch verifiers, sponge transcripts only: the squeezed weight stream of THIS batch (16 / 32 bytes per
                             // item), produced by the host -- a sponge's output is sequential; nullptr: counter-mode stream from the seed
+  te_ext *tabs;             // per-item kernels: ITEM_TAB_SLOTS window-table entries per item, item j's at tabs + j * ITEM_TAB_SLOTS
+                            // (te_smul_ws below)
 };
 struct Seed64 { uint64_t w[8]; };  // a SHA-512 digest as big-endian words
 // Suite::Transcript (src/lib.rs:177-250): HashTranscript<Sha512>, or the SHAKE128 sponge for the suites that say so
@@ -197,6 +199,45 @@ template <class S> AVRF_DN te_ext te_smul(te_pre p, fp k, int nbits) {
     acc = te_dbl<S>(te_dbl<S>(te_dbl<S>(te_dbl<S>(acc))));
     uint32_t d = (k.v[w >> 3] >> (4 * (w & 7))) & 15u;
     if (d) acc = te_add<S>(acc, tab[d]);
+  }
+  return acc;
+}
+// ---- the same with the window table in the CONTEXT'S WORKSPACE instead of private memory.
+// A per-lane array indexed by a runtime digit cannot live in registers; the compiler puts it in scratch, whose layout
+// interleaves the lanes dword by dword -- lane L's entry d then touches 32 different 256-byte rows per lookup, and round 2's
+// PMC pass measured 250 x the algorithmic bytes (3.5 GB fetched per 65 536 proofs) with the kernels at one wave per SIMD.
+// Here item j owns ITEM_TAB_SLOTS consecutive 128-byte entries: a lookup reads two whole 64-byte lines, a table build writes
+// them once, and nothing of the table counts against the kernel's private segment.  (One wave's writes followed by its own
+// reads of the same addresses are ordered by the memory pipeline.)
+enum { ITEM_TAB_SLOTS = 40 };    // 16 + 16 + 4 entries of the three-term verifier chain, rounded up
+template <class S> AVRF_DN te_ext te_smul_ws(te_ext *tab, te_pre p, fp k, int nbits) {
+  te_ext cur = te_from_pre<S>(p);
+  store_ext(tab + 1, cur);
+  for (int i = 2; i < 16; i++) { cur = te_madd<S>(cur, p); store_ext(tab + i, cur); }
+  te_ext acc = te_identity<S>();
+  for (int w = (nbits + 3) / 4 - 1; w >= 0; w--) {
+    const uint32_t d = (k.v[w >> 3] >> (4 * (w & 7))) & 15u;
+    te_ext e; if (d) e = load_ext(tab + d);                      // issued ahead of the doublings
+    acc = te_dbl<S>(te_dbl<S>(te_dbl<S>(te_dbl<S>(acc))));
+    if (d) acc = te_add<S>(acc, e);
+  }
+  return acc;
+}
+// a*P + b*Q, joint 2-bit windows, table i*P + j*Q (i, j < 4) in the workspace
+template <class S> AVRF_DN te_ext te_smul2_ws(te_ext *tab, te_pre p, fp a, te_pre q, fp b, int nbits) {
+  te_ext row = te_identity<S>();
+  for (int j = 0; j < 4; j++) {
+    if (j) row = te_madd<S>(row, q);
+    te_ext cur = row;
+    if (j) store_ext(tab + 4 * j, cur);
+    for (int i = 1; i < 4; i++) { cur = te_madd<S>(cur, p); store_ext(tab + 4 * j + i, cur); }
+  }
+  te_ext acc = te_identity<S>();
+  for (int w = (nbits + 1) / 2 - 1; w >= 0; w--) {
+    const uint32_t da = (a.v[w >> 4] >> (2 * (w & 15))) & 3u, db = (b.v[w >> 4] >> (2 * (w & 15))) & 3u;
+    te_ext e; if (da | db) e = load_ext(tab + 4 * db + da);
+    acc = te_dbl<S>(te_dbl<S>(acc));
+    if (da | db) acc = te_add<S>(acc, e);
   }
   return acc;
 }

@@ -27,14 +27,14 @@ namespace avrf {
 // first_is_one: the first caller pair takes z = 1 (Pedersen); otherwise pair i takes chunk i (Thin,
 // whose z_0 = 1 belongs to the Schnorr pair handled by the caller).
 template <class S, class R>
-AVRF_DI void merge_pairs(const uint8_t *ios_xy, uint32_t m, R &dseed, bool first_is_one,
+AVRF_DI void merge_pairs(te_ext *ws, const uint8_t *ios_xy, uint32_t m, R &dseed, bool first_is_one,
                          te_ext &im, te_ext &om) {
   for (uint32_t i = 0; i < m; i++) {
     te_pre pi = pre_from_xy<S>(ios_xy + 128 * (size_t)i), po = pre_from_xy<S>(ios_xy + 128 * (size_t)i + 64);
     if (first_is_one && i == 0) { im = te_madd<S>(im, pi); om = te_madd<S>(om, po); continue; }
     fp z = xof128(dseed, first_is_one ? i - 1 : i);
-    im = te_add<S>(im, te_smul<S>(pi, z, 128));
-    om = te_add<S>(om, te_smul<S>(po, z, 128));
+    im = te_add<S>(im, te_smul_ws<S>(ws, pi, z, 128));
+    om = te_add<S>(om, te_smul_ws<S>(ws, po, z, 128));
   }
 }
 template <class S> AVRF_DI te_pre g_pre() {
@@ -96,22 +96,24 @@ k_smul(const uint8_t *__restrict__ scalars, const uint8_t *__restrict__ points_x
 // table and no merged pair has to be normalised: 253 + 128 doublings instead of 2 x 128 + 253 and an inversion.  More pairs:
 // merge first (one 128-bit multiplication per point), then the two-point form.  Any order gives the same group element.
 template <class S>
-AVRF_DI te_ext schnorr_lhs(const BatchDev &b, const uint8_t *ios, const uint8_t *pk_xy, uint32_t m, const suite_tr<S> &t, const fp &s, const fp &c) {
+AVRF_DI te_ext schnorr_lhs(const BatchDev &b, te_ext *ws, const uint8_t *ios, const uint8_t *pk_xy, uint32_t m, const suite_tr<S> &t, const fp &s, const fp &c) {
   using Fr = typename S::Fr;
   te_pre op = pre_from_xy<S>(pk_xy);
-  if (m == 0) return te_add<S>(te_smul_fixed<S>(b.fixed, FIXED_G, s), te_smul<S>(te_pre_neg<S>(op), c, 128));
+  if (m == 0) return te_add<S>(te_smul_fixed<S>(b.fixed, FIXED_G, s), te_smul_ws<S>(ws, te_pre_neg<S>(op), c, 128));
   auto dseed = delin_seed(t);
   if (m == 1) {
     const fp z = xof128(dseed, 0);
     const fp sz = fp_mul<Fr>(fp_to_mont<Fr>(s), z), cz = fp_mul<Fr>(fp_to_mont<Fr>(c), z);   // plain products mod r
-    te_ext acc = te_smul_multi_glv<S, true>(pre_from_xy<S>(ios), sz, te_pre_neg<S>(pre_from_xy<S>(ios + 64)), cz, te_pre_neg<S>(op), c);
+    te_ext acc = te_smul_multi_glv<S, true>(ws, pre_from_xy<S>(ios), sz, te_pre_neg<S>(pre_from_xy<S>(ios + 64)), cz, te_pre_neg<S>(op), c);
     return te_add<S>(acc, te_smul_fixed<S>(b.fixed, FIXED_G, s));
   }
   te_ext im = te_from_pre<S>(g_pre<S>()), om = te_from_pre<S>(op);
-  merge_pairs<S>(ios, m, dseed, false, im, om);
+  merge_pairs<S>(ws, ios, m, dseed, false, im, om);
   te_aff ia, oa; to_aff2<S>(im, om, ia, oa);
-  return te_smul_multi_glv<S, false>(pre_from_aff<S>(ia), s, pre_from_aff<S>(ia), fp_zero(), te_pre_neg<S>(pre_from_aff<S>(oa)), c);
+  return te_smul_multi_glv<S, false>(ws, pre_from_aff<S>(ia), s, pre_from_aff<S>(ia), fp_zero(), te_pre_neg<S>(pre_from_aff<S>(oa)), c);
 }
+// the item's window-table slots in the context's workspace (proto_dev.h te_smul_ws)
+AVRF_DI te_ext *item_ws(const BatchDev &b, uint32_t j) { return b.tabs + (size_t)j * ITEM_TAB_SLOTS; }
 
 // ---------------------------------------------------------------- Thin VRF
 
@@ -145,16 +147,16 @@ k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict_
     if (m) {
       auto dseed = delin_seed(t);
       const fp kz = fp_mul<Fr>(k, xof128(dseed, 0));                            // Montgomery k times plain z: plain k z mod r
-      rr = te_add<S>(rr, te_smul_glv<S>(pre_from_xy<S>(ios), kz));
+      rr = te_add<S>(rr, te_smul_glv<S>(item_ws(b, j), pre_from_xy<S>(ios), kz));
     }
   } else {
     auto dseed = delin_seed(t);
     te_ext im = te_from_pre<S>(g_pre<S>());
     for (uint32_t i = 0; i < m; i++) {
       te_pre pi = pre_from_xy<S>(ios + 128 * (size_t)i);
-      im = te_add<S>(im, te_smul<S>(pi, xof128(dseed, i), 128));
+      im = te_add<S>(im, te_smul_ws<S>(item_ws(b, j), pi, xof128(dseed, i), 128));
     }
-    rr = te_smul_glv<S>(pre_from_aff<S>(te_to_aff<S>(im)), k_plain);
+    rr = te_smul_glv<S>(item_ws(b, j), pre_from_aff<S>(te_to_aff<S>(im)), k_plain);
   }
   te_aff r = te_to_aff<S>(rr);                                                  // thin.rs:119
   suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);    // thin.rs:122
@@ -188,7 +190,7 @@ k_tiny_verify(BatchDev b, int32_t *__restrict__ status) {
   fp s = fp_load_le(pr + 16);
   if (ge_p<Fr>(s)) f |= FLAG_SCALAR;
   if (f) { status[j] = 2; return; }                                             // InvalidData, tiny.rs:186-198
-  te_aff r = te_to_aff<S>(schnorr_lhs<S>(b, ios, pk_xy, m, t, s, c));            // tiny.rs:207
+  te_aff r = te_to_aff<S>(schnorr_lhs<S>(b, item_ws(b, j), ios, pk_xy, m, t, s, c));            // tiny.rs:207
   suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);
   const fp c_exp = challenge_finish(tc);                                        // plain, 128 bits
   status[j] = fp_eq(c_exp, c) ? 0 : 1;
@@ -211,7 +213,7 @@ k_thin_verify(BatchDev b, int32_t *__restrict__ status) {
   suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_xy<S>(tc, rx, ry);
   fp c = challenge_finish(tc);                                                  // plain, 128 bits
   // s*I_m - c*O_m == R   (thin.rs:158-161)
-  te_ext lhs = schnorr_lhs<S>(b, ios, pk_xy, m, t, s, c);
+  te_ext lhs = schnorr_lhs<S>(b, item_ws(b, j), ios, pk_xy, m, t, s, c);
   te_pre rp = te_make_pre<S>(fp_to_mont<Fq>(rx), fp_to_mont<Fq>(ry));
   status[j] = ext_eq_aff<S>(lhs, rp) ? 0 : 1;
 }
@@ -239,7 +241,7 @@ k_ped_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ 
     te_ext im = te_identity<S>(), om = te_identity<S>();
     for (uint32_t i = 0; i < m; i++) {
       te_pre pi = pre_from_xy<S>(ios + 128 * (size_t)i);
-      if (i == 0) im = te_madd<S>(im, pi); else im = te_add<S>(im, te_smul<S>(pi, xof128(dseed, i - 1), 128));
+      if (i == 0) im = te_madd<S>(im, pi); else im = te_add<S>(im, te_smul_ws<S>(item_ws(b, j), pi, xof128(dseed, i - 1), 128));
     }
     (void)om;
     ip = pre_from_aff<S>(te_to_aff<S>(im));
@@ -255,7 +257,7 @@ k_ped_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ 
   fp k = nonce<S>(sk, t), kb = nonce<S>(bl_plain, t);                           // :155-156
   fp k_plain = fp_from_mont<Fr>(k);
   te_ext R = te_add<S>(te_smul_fixed<S>(b.fixed, FIXED_G, k_plain), te_smul_fixed<S>(b.fixed, FIXED_B, fp_from_mont<Fr>(kb)));   // :159-161
-  te_ext OK = have_input ? te_smul_glv<S>(ip, k_plain) : te_identity<S>();                   // :164
+  te_ext OK = have_input ? te_smul_glv<S>(item_ws(b, j), ip, k_plain) : te_identity<S>();     // :164
   te_aff ra, oka; to_aff2<S>(R, OK, ra, oka);                                   // :166-167
   suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, ra); absorb_point_mont<S>(tc, oka);
   fp c = fp_to_mont<Fr>(challenge_finish(tc));                                  // :170
@@ -289,7 +291,7 @@ k_ped_verify(BatchDev b, int32_t *__restrict__ status) {
   else if (m > 1) {
     auto dseed = delin_seed(t);
     te_ext im = te_identity<S>(), om = te_identity<S>();
-    merge_pairs<S>(ios, m, dseed, true, im, om);
+    merge_pairs<S>(item_ws(b, j), ios, m, dseed, true, im, om);
     te_aff ia, oa; to_aff2<S>(im, om, ia, oa);
     ip = pre_from_aff<S>(ia); op = pre_from_aff<S>(oa);
   }
@@ -303,14 +305,14 @@ k_ped_verify(BatchDev b, int32_t *__restrict__ status) {
   }
   fp c = challenge_finish(t);                                                  // :222
   // Eq1: s*I - c*O == Ok   (:229-232)
-  te_ext lhs1 = have_io ? te_smul_multi_glv<S, false>(ip, s, ip, fp_zero(), te_pre_neg<S>(op), c) : te_identity<S>();
+  te_ext lhs1 = have_io ? te_smul_multi_glv<S, false>(item_ws(b, j), ip, s, ip, fp_zero(), te_pre_neg<S>(op), c) : te_identity<S>();
   te_pre okp = te_make_pre<S>(fp_to_mont<Fq>(okx), fp_to_mont<Fq>(oky));
   if (!ext_eq_aff<S>(lhs1, okp)) { status[j] = 1; return; }
   // Eq2: s*G + sb*B - c*Yb == R   (:238-245)
   te_pre ybp = te_make_pre<S>(fp_to_mont<Fq>(ybx), fp_to_mont<Fq>(yby));
   // G and BLINDING_BASE are fixed: 2 x 32 table additions instead of a 253-bit joint double-and-add
   te_ext lhs2 = te_add<S>(te_smul_fixed<S>(b.fixed, FIXED_G, s), te_smul_fixed<S>(b.fixed, FIXED_B, sb));
-  lhs2 = te_add<S>(lhs2, te_smul<S>(te_pre_neg<S>(ybp), c, 128));
+  lhs2 = te_add<S>(lhs2, te_smul_ws<S>(item_ws(b, j), te_pre_neg<S>(ybp), c, 128));
   te_pre rp = te_make_pre<S>(fp_to_mont<Fq>(rx), fp_to_mont<Fq>(ry));
   status[j] = ext_eq_aff<S>(lhs2, rp) ? 0 : 1;
 }
