@@ -129,10 +129,8 @@ static void validate_staged(avrf_ctx *c, int kind, int32_t *d_rec_status) {
       bool uniform = c->tot_io == c->n;
       for (size_t j = 0; uniform && j < c->n; j++) uniform = io_off[j] == j;
       if (uniform) launch_validate_xy(c->suite, c->d_ios.as<uint8_t>(), 128, 2, n, c->validate, fl, d_rec_status, c->stream);
-      else for (size_t j = 0; j < c->n; j++) {
-        const uint32_t m = io_off[j + 1] - io_off[j];
-        if (m) launch_validate_xy(c->suite, c->d_ios.as<uint8_t>() + 128 * (size_t)io_off[j], 0, 2 * m, 1, c->validate, fl, d_rec_status + j, c->stream);
-      }
+      else launch_validate_xy(c->suite, c->d_ios.as<uint8_t>(), 128, 2, (uint32_t)c->tot_io, c->validate, fl, d_rec_status, c->stream,
+                              c->d_io_off.as<uint32_t>(), n);     // one launch: every lane looks its item up in the staged offsets
     }
   }
 }
@@ -540,6 +538,8 @@ int avrf_thin_batch_challenges(avrf_ctx *c, uint8_t *c_out) {
 // so the partial points of all shards add up to the batch MSM of src/thin.rs:319.
 int avrf_thin_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t first_index, uint8_t out_xy[64]) {
   if (!c || c->staged_kind != 1 || !seed64 || !out_xy) return AVRF_ERR_BAD_ARG;
+  // a sponge / SHA-256 transcript has no seed to hand to the shards (avrf_batch_weight_seed refuses those suites too)
+  if (with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; return (bool)S::HOST_WEIGHTS; })) return AVRF_ERR_BAD_ARG;
   if (c->n && c->chal_gen != c->stage_gen) return AVRF_ERR_BAD_ARG;     // avrf_thin_batch_challenges has not run on this staging (or it failed)
   HIP_TRY(hipSetDevice(c->device));
   HostExt r;
@@ -572,6 +572,8 @@ int avrf_pedersen_batch_challenges(avrf_ctx *c, uint8_t *c_out) {
 }
 int avrf_pedersen_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t first_index, uint8_t out_xy[64]) {
   if (!c || c->staged_kind != 2 || !seed64 || !out_xy) return AVRF_ERR_BAD_ARG;
+  // a sponge / SHA-256 transcript has no seed to hand to the shards (avrf_batch_weight_seed refuses those suites too)
+  if (with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; return (bool)S::HOST_WEIGHTS; })) return AVRF_ERR_BAD_ARG;
   if (c->n && c->chal_gen != c->stage_gen) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
   HostExt r;

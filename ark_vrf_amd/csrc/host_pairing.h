@@ -402,7 +402,15 @@ template <class C> struct HostPairing {
       for (int k = 0; k < 4; k++) { uint8_t le[32]; memcpy(le, b + k * B, B); if (k == 3) le[B - 1] &= 0x3f; memcpy(v[k].l, le, B); }
       out->x = f2(Fp::to_mont(v[0]), Fp::to_mont(v[1])); out->y = f2(Fp::to_mont(v[2]), Fp::to_mont(v[3]));
     }
+    for (int k = 0; k < 4; k++) if (Fp::geq(v[k], Fp::P())) return false;   // non-canonical coordinate
     return true;
+  }
+  // y^2 = x^3 + b' on the twist (b' = b xi for the M-type twist of BLS12-381, b / xi for the D-type twist of BN254)
+  static bool g2_on_twist(const G2 &q) {
+    if (q.inf) return true;
+    const F2 b = f2(Fp::from32(C::B), Fp::zero());
+    const F2 bt = C::MTWIST ? f2_mul_xi(b) : f2_mul(b, f2_inv(f2_mul_xi(f2_one())));
+    return f2_eq(f2_sqr(q.y), f2_add(f2_mul(f2_sqr(q.x), q.x), bt));
   }
 };
 

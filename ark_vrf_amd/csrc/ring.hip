@@ -647,7 +647,7 @@ template <class S, class G> struct Ring {
       g1 = g1_from_raw(vp);
       memcpy(g2.data(), vp + e1, 2 * e2);
       typename HP::G2 q;
-      for (int i = 0; i < 2; i++) if (!HP::g2_decode(g2.data() + (size_t)i * e2, &q)) return AVRF_INVALID_DATA;
+      for (int i = 0; i < 2; i++) if (!HP::g2_decode(g2.data() + (size_t)i * e2, &q) || q.inf || !HP::g2_on_twist(q)) return AVRF_INVALID_DATA;
     } else if (len == FQB + 2 * 2 * FQB) {
       if (!g1_decompress(vp, &g1)) return AVRF_INVALID_DATA;
       for (int i = 0; i < 2; i++) {
@@ -656,7 +656,11 @@ template <class S, class G> struct Ring {
         HP::g2_encode(q, g2.data() + (size_t)i * e2);
       }
     } else return AVRF_INVALID_DATA;
-    if (g1.inf || !g1_in_subgroup_host(g1)) return AVRF_INVALID_DATA;
+    // g1: in range, on the curve, in the prime-order subgroup, not the point at infinity (the uncompressed form carries both
+    // coordinates, so the curve equation is checked here; BN254 G1 has cofactor 1).  The two G2 points are decoded and checked to
+    // lie on the twist; like the reference's RingSetup deserialisation they get no G2 subgroup test -- PcsVerifierParams are
+    // trusted-setup material published with the ring parameters, not per-proof input (src/ring.rs:466-474).
+    if (g1.inf || !g1_on_curve_host(g1) || !g1_in_subgroup_host(g1)) return AVRF_INVALID_DATA;
     avrf_ring_setup *su = new avrf_ring_setup();
     su->ctx = ctx; su->suite = S::ID; su->curve = pairing_curve_of(S::ID); su->stream = avrf_ctx_stream_(ctx); su->device = avrf_ctx_device_(ctx);
     su->N = N; su->cap = N - 3; su->L = L; su->keyset = su->cap - L - 1; su->n_srs = 0;
@@ -1158,6 +1162,16 @@ template <class S, class G> struct Ring {
     return FqN::eq(q.x, FqN::mul(FqN::mul(beta, p.x), q.zz)) && FqN::eq(q.y, FqN::neg(FqN::mul(p.y, q.zzz)));
   }
 
+  // coordinates < p and y^2 = x^3 + b (the point at infinity passes): the check of an UNCOMPRESSED G1 entry that ark-serialize's
+  // Validate::Yes makes before the subgroup test (a decompressed point is on the curve by construction)
+  static bool g1_on_curve_host(const G1Aff &a) {
+    if (a.inf) return true;
+    QEl x, y; memset(&x, 0, sizeof x); memset(&y, 0, sizeof y); memcpy(x.l, a.xy, FQB); memcpy(y.l, a.xy + FQB, FQB);
+    if (FqN::geq(x, FqN::P()) || FqN::geq(y, FqN::P())) return false;
+    const QEl xm = FqN::to_mont(x), ym = FqN::to_mont(y);
+    return FqN::eq(FqN::sqr(ym), FqN::add(FqN::mul(FqN::sqr(xm), xm), FqN::from32(G::B)));
+  }
+
   static G1Aff g1_msm(avrf_ring_setup *su, const std::vector<uint8_t> &bases_xy, const std::vector<H256> &scalars_plain,
                       bool check_subgroup = false, bool *bad_points = nullptr) {
     const size_t n = scalars_plain.size();
@@ -1409,11 +1423,13 @@ template <class S, class G> struct Ring {
       if (!host_subgroup) launch_g1_subgroup_check(su->curve, d_b, nb, d_flag, su->stream, d_rec, (uint32_t)TPI);
       launch_g1_lincomb(su->curve, d_b, d_s, n, (uint32_t)TPI, 11, d_pts, su->stream, su->curve == 0);
       launch_pairing_check(su->ptab, d_pts, n, d_ok, su->stream);
-      std::vector<int32_t> okv(n), rec(n);
+      std::vector<int32_t> okv(n), rec(n); uint32_t range_flag = 0;
       HIP_CHECK(hipMemcpyAsync(okv.data(), d_ok, n * 4, hipMemcpyDeviceToHost, su->stream));
       HIP_CHECK(hipMemcpyAsync(rec.data(), d_rec, n * 4, hipMemcpyDeviceToHost, su->stream));
+      HIP_CHECK(hipMemcpyAsync(&range_flag, d_flag, 4, hipMemcpyDeviceToHost, su->stream));
       HIP_CHECK(hipStreamSynchronize(su->stream)); HIP_CHECK(hipGetLastError());
       lap("per-item G1 sums + pairing checks (device)");
+      if (range_flag & 1) return AVRF_INVALID_DATA;      // a base with a coordinate >= p (launch_g1_bases): no item to pin it on
       for (size_t it = 0; it < n; it++)
         each_status[it] = item_st[it] ? item_st[it] : rec[it] ? AVRF_INVALID_DATA : okv[it] ? AVRF_OK : AVRF_VERIFICATION_FAILURE;
       return AVRF_OK;

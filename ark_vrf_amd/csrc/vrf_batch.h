@@ -39,8 +39,10 @@ void launch_hash_to_curve(int suite, const uint8_t *d_data, const uint32_t *d_of
 void launch_decompress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st);
 void launch_compress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st);
 // Validate::Yes on xy points laid out as records (see k_validate_xy): level 1 on-curve, 2 + prime-order subgroup
+// d_item_off (device, n_items + 1 exclusive prefix sums): the records are I/O pairs of items with different pair counts and
+// d_rec_status is indexed by ITEM -- each lane finds the item of its pair by binary search (one launch whatever the counts)
 void launch_validate_xy(int suite, const uint8_t *d_base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *d_flags,
-                        int32_t *d_rec_status, hipStream_t st);
+                        int32_t *d_rec_status, hipStream_t st, const uint32_t *d_item_off = nullptr, uint32_t n_items = 0);
 
 // Per-suite launch tables.  vrf_batch.hip / vrf_single.hip are compiled once per suite (-DAVRF_TU_SUITE=<id>), each such unit
 // holding the kernels of one suite and the explicit instantiation of these two structs for it; the unit compiled without
@@ -65,7 +67,7 @@ template <class S> struct SingleOps {
   static void hash_to_curve(const uint8_t *d_data, const uint32_t *d_off, uint32_t n, uint8_t *d_out, int32_t *d_status, hipStream_t st);
   static void decompress(const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st);
   static void validate_xy(const uint8_t *d_base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *d_flags,
-                          int32_t *d_rec_status, hipStream_t st);
+                          int32_t *d_rec_status, hipStream_t st, const uint32_t *d_item_off, uint32_t n_items);
   static void compress(const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st);
 };
 

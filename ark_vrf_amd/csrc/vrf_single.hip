@@ -515,12 +515,17 @@ k_decompress(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ o
 template <class S>
 __global__ void __launch_bounds__(128)
 k_validate_xy(const uint8_t *__restrict__ base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *__restrict__ flags,
-              int32_t *__restrict__ rec_status) {
+              int32_t *__restrict__ rec_status, const uint32_t *__restrict__ item_off, uint32_t n_items) {
   using Fq = typename S::Fq; using Fr = typename S::Fr;
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nrec * ppr) return;
-  const uint32_t j = t / ppr, p = t - j * ppr;
+  uint32_t j = t / ppr; const uint32_t p = t - j * ppr;
   const uint8_t *src = base + (size_t)j * stride + 64 * (size_t)p;
+  if (item_off) {                                   // records are I/O pairs of items with different pair counts: item of pair j
+    uint32_t lo = 0, hi = n_items;                  // the last i with item_off[i] <= j (item_off: n_items + 1 exclusive prefix sums)
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (item_off[mid] <= j) lo = mid; else hi = mid; }
+    j = lo;
+  }
   fp x = fp_load_le(src), y = fp_load_le(src + 32);
   bool bad = ge_p<Fq>(x) || ge_p<Fq>(y);
   if (!bad) {
@@ -585,9 +590,9 @@ template <class S> void SingleOps<S>::decompress(const uint8_t *d_in, uint32_t n
   hipLaunchKernelGGL(k_decompress<S>, dim3((n + 127) / 128), dim3(128), 0, st, d_in, n, d_out, validate, d_status);
 }
 template <class S> void SingleOps<S>::validate_xy(const uint8_t *d_base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *d_flags,
-                                                  int32_t *d_rec_status, hipStream_t st) {
+                                                  int32_t *d_rec_status, hipStream_t st, const uint32_t *d_item_off, uint32_t n_items) {
   const uint32_t tot = nrec * ppr;
-  hipLaunchKernelGGL(k_validate_xy<S>, dim3((tot + 127) / 128), dim3(128), 0, st, d_base, stride, ppr, nrec, level, d_flags, d_rec_status);
+  hipLaunchKernelGGL(k_validate_xy<S>, dim3((tot + 127) / 128), dim3(128), 0, st, d_base, stride, ppr, nrec, level, d_flags, d_rec_status, d_item_off, n_items);
 }
 template <class S> void SingleOps<S>::compress(const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st) {
   hipLaunchKernelGGL(k_compress<S>, dim3((n + 255) / 256), dim3(256), 0, st, d_in, n, d_out);
@@ -635,9 +640,9 @@ void launch_decompress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_ou
   AVRF_SINGLE(suite, decompress(d_in, n, d_out, validate, d_status, st));
 }
 void launch_validate_xy(int suite, const uint8_t *d_base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *d_flags,
-                        int32_t *d_rec_status, hipStream_t st) {
+                        int32_t *d_rec_status, hipStream_t st, const uint32_t *d_item_off, uint32_t n_items) {
   if (!nrec || !ppr || level <= 0) return;
-  AVRF_SINGLE(suite, validate_xy(d_base, stride, ppr, nrec, level, d_flags, d_rec_status, st));
+  AVRF_SINGLE(suite, validate_xy(d_base, stride, ppr, nrec, level, d_flags, d_rec_status, st, d_item_off, n_items));
 }
 void launch_compress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st) {
   if (!n) return;

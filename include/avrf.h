@@ -18,6 +18,10 @@
  *  - status codes mirror `ark_vrf::Error` (src/lib.rs:135-147).
  *  - every call runs on the context's own HIP stream; one context per host thread.
  *  - no CPU fallback: creating a context fails (AVRF_ERR_NO_DEVICE) without a gfx950 device.
+ *  - host requirement: the library's host code is built for x86-64-v3 (AVX2, BMI2 -- the sequential SHA-512 weight transcript
+ *    runs twice as fast with rorx / mulx); every MI355X host platform has it, an older CPU dies with SIGILL at load, not with
+ *    a status code.  (The optional 8-lane multi-buffer hash additionally needs AVX-512 and IS checked at run time.)
+ *  - short-Weierstrass suite (AVRF_SUITE_SECP256R1_SHA256_TAI): xy points are the curve's affine points, identity = 64 zero bytes.
  */
 #ifndef AVRF_H
 #define AVRF_H

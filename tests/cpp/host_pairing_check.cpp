@@ -54,7 +54,10 @@ template <class G> static int run(const std::vector<uint8_t> &srs) {
   bool tok2 = HP::product_is_one_lines(px, py, inf, tabs, 2);
   typename HP::F12 q1 = HP::f12_sqr(f), q2 = HP::f12_mul(f, f);
   bool sqr = memcmp(&q1, &q2, sizeof q1) == 0;
-  bool lines = tok && !tbad && tok2 && sqr;
+  // the twist equation holds for the file's G2 points and fails for a perturbed one (verifier-only setups check it)
+  typename HP::G2 qb = q[1]; qb.y = HP::f2_add(qb.y, HP::f2_one());
+  bool twist = HP::g2_on_twist(q[0]) && HP::g2_on_twist(q[1]) && !HP::g2_on_twist(qb);
+  bool lines = tok && !tbad && tok2 && sqr && twist;
   if (getenv("AVRF_PAIRING_TIMING")) {
     struct timespec t0, t1, t2;
     clock_gettime(CLOCK_MONOTONIC, &t0);

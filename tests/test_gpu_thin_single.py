@@ -195,3 +195,35 @@ def test_validation_levels(ctxs, golden_dir, suite):
                 assert st[3] in (1, 2)                                       # level 1 does not look at the subgroup: some failure
     finally:
         c.set_validation(0)
+
+
+def test_validation_with_mixed_pair_counts(ctxs):
+    """avrf_ctx_set_validation with per-item statuses on a batch whose items carry DIFFERENT numbers of I/O pairs (0, 1, 2, 3): the
+    pairs are validated in one launch, each lane finding its item in the staged offsets (capi.hip validate_staged) -- a bad
+    point must mark exactly its own item, whichever pair it sits in."""
+    from ark_vrf_amd._native import Batch
+    suite = 0
+    c = ctxs[suite]
+    counts = (1, 3, 0, 2, 1, 2)
+    sks, pks, ios_c, ads = [], [], [], []
+    for j, m in enumerate(counts):
+        sk, pk = orc.from_seed(suite, bytes([j + 120]) + bytes(31))
+        io = []
+        for i in range(m):
+            h = orc.hash_to_curve(suite, b"vm-%d-%d" % (j, i))
+            io.append((h, orc.vrf_output(suite, sk, h)))
+        sks.append(sk); pks.append(pk); ios_c.append(io); ads.append(b"vm%d" % j)
+    ios = [[(xy(suite, i), xy(suite, o)) for i, o in io] for io in ios_c]
+    pkl = [xy(suite, p) for p in pks]
+    proofs = [proof_xy(suite, orc.thin_prove(suite, sk, io, ad), 0) for sk, io, ad in zip(sks, ios_c, ads)]
+    off_curve = (5).to_bytes(32, "little") + (7).to_bytes(32, "little")
+    try:
+        c.set_validation(1)
+        assert c.thin_verify(Batch.from_items(ios, ads, pks_xy=pkl, proofs=proofs)) == [0] * 6
+        for item, pair, which in ((1, 2, 1), (3, 0, 0), (5, 1, 1), (0, 0, 0)):
+            bad = [list(x) for x in ios]
+            pr = list(bad[item][pair]); pr[which] = off_curve; bad[item][pair] = tuple(pr)
+            st = c.thin_verify(Batch.from_items(bad, ads, pks_xy=pkl, proofs=proofs))
+            assert st[item] == 2 and [s for k, s in enumerate(st) if k != item] == [0] * 5, (item, pair, st)
+    finally:
+        c.set_validation(0)
