@@ -223,6 +223,34 @@ int avrf_msm_te(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *s
   return finish_point(c, r, out_xy);
 }
 
+// The same MSM on arkworks' IN-MEMORY values (SURVEY.md 8b "zero-copy option"): bases = n x Affine { x, y } with each coordinate
+// an Fp<MontBackend, 4> (four little-endian u64 limbs, Montgomery form R = 2^256), scalars = n x ScalarField in the same form
+// -- what `msm_unchecked(&[Affine], &[ScalarField])` is handed (src/thin.rs:319) -- and the result as Montgomery x || y.  The
+// canonical <-> Montgomery conversions of avrf_msm_te disappear on the host side; the device converts the scalars (one
+// multiplication each) and takes the bases as they are.
+int avrf_msm_te_mont(avrf_ctx *c, size_t n, const uint8_t *bases_mont_xy, const uint8_t *scalars_mont, uint8_t out_mont_xy[64]) {
+  if (!c || !out_mont_xy || (n && (!bases_mont_xy || !scalars_mont))) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  HostExt r;
+  if (n) {
+    HIP_TRY(c->d_misc.ensure(n * 64)); HIP_TRY(c->d_scalars.ensure(n * 32)); HIP_TRY(c->d_pre.ensure(n * sizeof(te_pre_raw)));
+    HIP_TRY(hipMemcpyAsync(c->d_misc.p, bases_mont_xy, n * 64, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_scalars.p, scalars_mont, n * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+    launch_pre_from_affine(c->suite, c->d_misc.as<uint8_t>(), n, c->d_pre.as<te_pre_raw>(), c->d_flags.as<uint32_t>(), 0, c->stream, 1);
+    launch_scalars_from_mont(c->suite, c->d_scalars.as<uint32_t>(), n, c->d_flags.as<uint32_t>(), c->stream);
+    HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  c->staged_kind = 0;
+  if (int e = guarded([&] { return msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), n, c->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  if (n && *c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;
+  uint8_t canon[64];
+  finish_point(c, r, canon);
+  with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; using Fq = HostField<typename S::Fq>;
+    Fq::store_le(out_mont_xy, Fq::to_mont(Fq::load_le(canon))); Fq::store_le(out_mont_xy + 32, Fq::to_mont(Fq::load_le(canon + 32))); });
+  return AVRF_OK;
+}
+
 // G1 MSM of the suite's pairing curve (KZG commit / open): bases as canonical little-endian x || y
 // (48+48 bytes BLS12-381, 32+32 bytes BN254; all-zero = infinity), scalars LE32 < r.
 int avrf_g1_msm(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *scalars, uint8_t *out_xy) {

@@ -88,7 +88,10 @@ void launch_g1_lincomb(int curve, const uint32_t *d_bases, const uint32_t *d_sca
 void g1_glv_split_bls(uint64_t k[4]);
 
 // canonical affine bytes (x||y LE32) -> te_pre (device); flags[i] |= 1 if a coordinate >= q, |= 2 if off-curve (when check_curve)
+// (mont_in: the coordinates are Montgomery limbs already -- avrf_msm_te_mont)
 void launch_pre_from_affine(int suite, const uint8_t *d_xy, size_t n, te_pre_raw *d_pre, uint32_t *d_flag,
-                            int check_curve, hipStream_t stream);
+                            int check_curve, hipStream_t stream, int mont_in = 0);
+// n scalars as Montgomery limbs of the suite's Fr -> plain 256-bit integers, in place; *d_flag |= 4 for a limb value >= r
+void launch_scalars_from_mont(int suite, uint32_t *d_scalars, size_t n, uint32_t *d_flag, hipStream_t stream);
 
 }  // namespace avrf

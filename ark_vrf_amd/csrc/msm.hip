@@ -48,27 +48,43 @@ namespace avrf {
 
 // ---------------------------------------------------------------- conversions
 
+// mont_in: the coordinates are ALREADY Montgomery limbs (arkworks' in-memory Fp; the zero-copy flavour of SURVEY.md 8b)
 template <class S>
 __global__ void __launch_bounds__(256) k_pre_from_affine(const uint8_t *__restrict__ xy, uint32_t n, te_pre *__restrict__ out,
-                                  uint32_t *__restrict__ flag, int check_curve) {
+                                  uint32_t *__restrict__ flag, int check_curve, int mont_in) {
   using Fq = typename S::Fq;
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   fp x = fp_load_le(xy + 64 * (size_t)i), y = fp_load_le(xy + 64 * (size_t)i + 32);
   uint32_t f = 0;
   if (ge_p<Fq>(x) || ge_p<Fq>(y)) f |= 1;
-  fp xm = fp_to_mont<Fq>(x), ym = fp_to_mont<Fq>(y);
+  fp xm = mont_in ? x : fp_to_mont<Fq>(x), ym = mont_in ? y : fp_to_mont<Fq>(y);
   if (check_curve && !te_on_curve<S>(xm, ym)) f |= 2;
   store_pre(out + i, te_make_pre<S>(xm, ym));
   if (f) atomicOr(flag, f);
 }
 
 void launch_pre_from_affine(int suite, const uint8_t *d_xy, size_t n, te_pre_raw *d_pre, uint32_t *d_flag,
-                            int check_curve, hipStream_t stream) {
+                            int check_curve, hipStream_t stream, int mont_in) {
   if (!n) return;
   dim3 g((unsigned)((n + 255) / 256)), b(256);
   with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type;
-    hipLaunchKernelGGL(k_pre_from_affine<S>, g, b, 0, stream, d_xy, (uint32_t)n, (te_pre *)d_pre, d_flag, check_curve); });
+    hipLaunchKernelGGL(k_pre_from_affine<S>, g, b, 0, stream, d_xy, (uint32_t)n, (te_pre *)d_pre, d_flag, check_curve, mont_in); });
+}
+// scalars held as Montgomery limbs of Fr (arkworks' in-memory ScalarField) -> plain integers, in place; flag |= 4 when >= r
+template <class S>
+__global__ void __launch_bounds__(256) k_scalars_from_mont(uint32_t *__restrict__ sc, uint32_t n, uint32_t *__restrict__ flag) {
+  using Fr = typename S::Fr;
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fp k = load_fp(sc + 8 * (size_t)i);
+  if (ge_p<Fr>(k)) atomicOr(flag, 4u);
+  store_fp(sc + 8 * (size_t)i, fp_from_mont<Fr>(k));
+}
+void launch_scalars_from_mont(int suite, uint32_t *d_scalars, size_t n, uint32_t *d_flag, hipStream_t stream) {
+  if (!n) return;
+  with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type;
+    hipLaunchKernelGGL(k_scalars_from_mont<S>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_scalars, (uint32_t)n, d_flag); });
 }
 
 // ---------------------------------------------------------------- digits

@@ -101,6 +101,13 @@ int avrf_ctx_set_validation(avrf_ctx *ctx, int level);
  * bases_xy: n x 64, scalars: n x 32, out_xy: normalised result (64 bytes).
  * "unchecked": no subgroup check; off-range coordinates / scalars give AVRF_INVALID_DATA. */
 int avrf_msm_te(avrf_ctx *ctx, size_t n, const uint8_t *bases_xy, const uint8_t *scalars, uint8_t out_xy[64]);
+/* The zero-copy flavour of the same call: everything as arkworks keeps it IN MEMORY -- bases n x Affine { x, y },
+ * each coordinate an Fp<MontBackend, 4> (four little-endian u64 limbs, Montgomery form, R = 2^256); scalars n x ScalarField in
+ * the same form; result Montgomery x || y.  A shim can pass `bases.as_ptr()` / `scalars.as_ptr()` of the slices handed to
+ * `msm_unchecked` (the crate's Affine / Fp structs are plain limb arrays; the shim asserts their size: 64 / 32 bytes).
+ * A limb value >= the modulus gives AVRF_INVALID_DATA.  The canonical-bytes flavour above remains the tested contract of the
+ * other entry points (it is what the reference's vectors pin). */
+int avrf_msm_te_mont(avrf_ctx *ctx, size_t n, const uint8_t *bases_mont_xy, const uint8_t *scalars_mont, uint8_t out_mont_xy[64]);
 
 /* <E::G1 as VariableBaseMSM>::msm on the suite's pairing curve (BLS12-381 for Bandersnatch, BN254 for
  * Baby-JubJub) -- the KZG commit/open MSMs inside w3f-ring-proof reached from src/ring.rs:220,404,416,731.

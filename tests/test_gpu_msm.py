@@ -66,3 +66,36 @@ def test_msm_rejects_noncanonical(ctxs):
     bad_pt = b"\xff" * 32 + (1).to_bytes(32, "little")
     with pytest.raises(nat.AvrfError):
         ctxs[0].msm(bad_pt, (1).to_bytes(32, "little"))
+
+
+@pytest.mark.parametrize("suite", [0, 1])
+def test_msm_montgomery_limbs_flavour(suite):
+    """avrf_msm_te_mont (SURVEY.md 8b zero-copy option): bases and scalars as arkworks holds them in memory -- Montgomery limbs,
+    R = 2^256 -- and the result in the same form; must equal the canonical flavour / the oracle after conversion."""
+    import ctypes as C
+    import random
+    from ark_vrf_amd import _native as nat
+    from helpers import R_ORDER, rand_points_xy, rand_scalar
+    q = {0: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+         1: 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001}[suite]
+    r = R_ORDER[suite]
+    R = 1 << 256
+    to_m = lambda b, m: (int.from_bytes(b, "little") * R % m).to_bytes(32, "little")
+    from_m = lambda b, m: (int.from_bytes(b, "little") * pow(R, -1, m) % m).to_bytes(32, "little")
+    rng = random.Random(5 + suite)
+    c = nat.Context(suite)
+    pts = rand_points_xy(rng, suite, 50)
+    for n in (1, 37, 3000):
+        bases = [pts[i % 50] for i in range(n)]
+        sc = [rand_scalar(rng, suite) for _ in range(n)]
+        want = orc.msm(suite, b"".join(bases), b"".join(sc))
+        bm = b"".join(to_m(p[:32], q) + to_m(p[32:], q) for p in bases)
+        sm = b"".join(to_m(k, r) for k in sc)
+        out = (C.c_uint8 * 64)()
+        assert nat.lib().avrf_msm_te_mont(c._h, C.c_size_t(n), nat._u8(bm), nat._u8(sm), out) == 0
+        got = bytes(out)
+        assert from_m(got[:32], q) + from_m(got[32:], q) == want == c.msm(b"".join(bases), b"".join(sc))
+    # a limb value >= the modulus is refused
+    bad = (q).to_bytes(32, "little") + bytes(32)
+    assert nat.lib().avrf_msm_te_mont(c._h, C.c_size_t(1), nat._u8(bad), nat._u8(to_m(rand_scalar(rng, suite), r)), out) == nat.INVALID_DATA
+    c.close()
