@@ -73,6 +73,31 @@ def test_pedersen_batch_65536_terms_msm_verdict(ctx):
     assert ctx.pedersen_batch_stage(nat_batch(b2)) == 0 and ctx.pedersen_batch_run() == 1
 
 
+@pytest.mark.parametrize("kind", [0, 1])
+def test_independent_prove_verify_65536_vs_oracle(ctx, kind):
+    """configs[2] / the per-item kernels at the benchmarked size: 65 536 INDEPENDENT Thin (kind 0) / Pedersen (kind 1) proofs
+    equal the oracle's byte for byte (src/thin.rs:111-129, src/pedersen.rs:136-186), every one verifies independently
+    (src/thin.rs:131-165, src/pedersen.rs:188-249), and tampered items -- first, last and a few inside, across workgroup and
+    workspace-slot boundaries -- are the only ones reported."""
+    b = orc.gen_batch(0, kind, N_FULL, threads=THREADS)
+    psz = 96 if kind == 0 else 256
+    if kind == 0:
+        assert ctx.thin_prove(nat_batch(b, with_sks=True, with_proofs=False)) == b["proofs"]
+        assert ctx.thin_verify(nat_batch(b)) == [0] * N_FULL
+    else:
+        pr, _ = ctx.pedersen_prove(nat_batch(b, with_sks=True, with_proofs=False))
+        assert pr == b["proofs"]
+        b["pks_xy"] = b""
+        assert ctx.pedersen_verify(nat_batch(b)) == [0] * N_FULL
+    bad_items = [0, 1, 63, 64, 127, 128, 4095, 40000, N_FULL - 1]
+    p2 = bytearray(b["proofs"])
+    for j in bad_items:
+        p2[psz * j + (64 if kind == 0 else 200)] ^= 1                        # a bit of s
+    b2 = dict(b); b2["proofs"] = bytes(p2)
+    st = ctx.thin_verify(nat_batch(b2)) if kind == 0 else ctx.pedersen_verify(nat_batch(b2))
+    assert [j for j, v in enumerate(st) if v != 0] == bad_items and all(st[j] == 1 for j in bad_items)
+
+
 @pytest.mark.parametrize("suite", [0, 1])
 def test_msm_2pow18_adversarial(suite):
     """n = 2^18 + 3 -> c = 13, 33 tiles: random scalars and the skewed distributions of test_gpu_msm.py at full size."""
