@@ -123,3 +123,20 @@ def test_multibuffer_weight_hash_matches_scalar():
             out2 = (C.c_uint8 * (64 * k))()
             assert L.avrf_sha512_x8(k, mp, ls, out2) == 0
             assert [bytes(out2)[64 * i: 64 * i + 64] for i in range(k)] == [hashlib.sha512(m).digest() for m in msgs] == want
+
+
+def test_host_sha512_long_message_path(tmp_path):
+    """host_sha512.h: inputs of >= 4096 bytes in one update take the four-blocks-per-step path (message schedule of the next
+    four blocks on the vector pipes, AVX-512VL; the scalar rounds read K + W from a buffer).  The digest must not depend on how
+    the message is cut into updates, and must be SHA-512 (hashlib) -- lengths around the switch and the 4 MiB weight transcript."""
+    import hashlib
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "hs")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-march=x86-64-v3", os.path.join(ROOT, "tests", "cpp", "host_sha512_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "consistent=1" in out.stdout, out.stdout + out.stderr
+    n = (4 << 20) + 28
+    d = bytes((((i * 2654435761) & 0xffffffff) >> 13) & 0xff for i in range(0, n))
+    assert out.stdout.strip().split()[-1] == hashlib.sha512(d).hexdigest()[:8]
