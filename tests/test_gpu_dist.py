@@ -223,3 +223,27 @@ def test_bench_whole_path_on_rccl_world_size_one():
     assert m["split_one_batch"]["value"] > 0, m
     assert m["ring_sharded"]["ring_vrf_proofs_per_sec"] > 0 and m["ring_sharded"]["ranks"] == 1, m
     assert out["additional_metrics"]["ring_vrf_batch_verifications_per_sec"] > 0
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` for real: the launcher starts two ranks (torch.distributed.run), which here share the one
+    visible GPU and meet over gloo (AVRF_BENCH_SHARE_GPU / AVRF_BENCH_BACKEND -- RCCL refuses two ranks on a device).  Every step
+    of the N > 1 flow runs with world size 2: per-rank batches, the barriers and reductions of the timed region, ONE batch split
+    over two ranks (challenges and partial points all-gathered), configs[3] sharded by index with the proofs all-gathered and the
+    verdicts reduced, one JSON line with n_gpus = 2.  The figures of such a run mean nothing; the verdicts must."""
+    import json, subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AVRF_BENCH_SHARE_GPU="1", AVRF_BENCH_BACKEND="gloo")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--min-seconds", "0.2",
+                        "--items", "4096", "--ring-proofs", "96", "--ring-size", "64", "--streams", "2", "--no-cpu-baseline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["timed_steps_all_gpus"] >= 2 * out["timed_steps_per_gpu"] * 0.5
+    m = out["multi_gpu"]
+    assert m["split_one_batch"]["value"] > 0, m
+    assert m["ring_sharded"]["ranks"] == 2 and m["ring_sharded"]["ring_vrf_proofs_per_sec"] > 0, m
+    assert m["ring_sharded"]["ring_vrf_batch_verifications_per_sec"] > 0 and m["ring_sharded"]["ring_vrf_independent_verifications_per_sec"] > 0
