@@ -11,6 +11,12 @@
 #ifndef AVRF_TE_ACC_WAVES
 #define AVRF_TE_ACC_WAVES 2
 #endif
+// k_accumulate<TeCurve> needs 141 VGPRs: three waves per SIMD fit.  Alone the kernel is 2 % faster with three (0.429 ms against
+// 0.440 ms per 262 145-term batch), with 20 contexts in flight the batch rate is 2-4 % higher with two (103.6-107.5 M/s against
+// 101.4-103.5 M/s, same box, tools/r3_run11.sh): the third wave takes the registers the other contexts' kernels overlap in.
+#ifndef AVRF_TE_ACC_MAX_WAVES
+#define AVRF_TE_ACC_MAX_WAVES 2
+#endif
 // 12-limb G1 accumulate: 2 waves per SIMD = 192 VGPRs, no scratch; 3 = 168 VGPRs + 44 spilled registers.  A/B on one box
 // (tools/r3_run4.sh, ring 1024): 4 contexts 11.49 k proofs/s against 11.05-11.11 k, one context 8.0-9.3 k against 7.4-7.8 k,
 // and the window-table build of a setup 82 ms against 96-118 ms.
@@ -35,6 +41,7 @@ template <class S> struct TeCurve {
   static constexpr bool ZERO_IS_IDENTITY = S::SW_NATIVE;   // twisted Edwards: (0, 1, 0, 1); XYZZ: ZZ = 0
   static constexpr bool FIXED_TABLE = false;          // no fixed-base window-table mode (bases change per batch)
   static constexpr int MIN_WAVES = AVRF_TE_ACC_WAVES; // waves per SIMD asked of the register allocator in k_accumulate
+  static constexpr int MAX_WAVES = AVRF_TE_ACC_MAX_WAVES;   // resident k_accumulate waves per SIMD at most (0 = what the registers allow), msm.hip accumulate_shape
   static constexpr int RED_WAVES = 1;                 // reduction kernels (general additions, several points live): latency-bound, full register file
   static constexpr bool INLINE_REDUCE_OPS = true;
   static constexpr bool WINDOW_SUMS = !S::SW_NATIVE;  // single MSMs: one weighted bucket sum per window (k_wsum_q1/q2) instead of row/column + bit sums
@@ -83,6 +90,7 @@ template <class C> struct G1Curve {
   static constexpr bool QUAD = false;
   static constexpr bool PREFETCH = (N <= 8);
   static constexpr int MIN_WAVES = N > 8 ? AVRF_G1_ACC_WAVES : 3;   // k_accumulate holds one accumulator + one base
+  static constexpr int MAX_WAVES = 0;
   static constexpr int RED_WAVES = N > 8 ? AVRF_G1_RED_WAVES : 2;   // the general addition (two accumulators live) needs the 256-register budget
   static constexpr bool INLINE_REDUCE_OPS = true;     // k_wsum*: additions inlined (the asm multiplier keeps the code small)
   static constexpr bool WINDOW_SUMS = false;

@@ -44,24 +44,27 @@ AVRF_DI bool fp_eq(const fp &a, const fp &b) {
 }
 
 // r = a + b, returns carry
+// (carry chains through __builtin_addc / __builtin_subc: one v_addc_co_u32 / v_subb_co_u32 per limb.  The uint64_t / int64_t
+// accumulator idiom compiled to ~90 instructions per field addition -- 64-bit adds, arithmetic shifts and the moves that build
+// their register pairs -- against ~30 in this form; a mixed addition has eleven of them.)
 AVRF_DI uint32_t add8(fp &r, const fp &a, const fp &b) {
-  uint64_t c = 0;
+  unsigned c = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) { c += (uint64_t)a.v[i] + b.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
-  return (uint32_t)c;
+  for (int i = 0; i < 8; i++) r.v[i] = __builtin_addc(a.v[i], b.v[i], c, &c);
+  return c;
 }
 // r = a - b, returns borrow (0/1)
 AVRF_DI uint32_t sub8(fp &r, const fp &a, const fp &b) {
-  int64_t c = 0;
+  unsigned br = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) { c += (int64_t)a.v[i] - (int64_t)b.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
-  return (uint32_t)(c & 1);
+  for (int i = 0; i < 8; i++) r.v[i] = __builtin_subc(a.v[i], b.v[i], br, &br);
+  return br;
 }
 template <class F> AVRF_DI uint32_t sub_p(fp &r, const fp &a) {
-  int64_t c = 0;
+  unsigned br = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) { c += (int64_t)a.v[i] - (int64_t)F::P[i]; r.v[i] = (uint32_t)c; c >>= 32; }
-  return (uint32_t)(c & 1);
+  for (int i = 0; i < 8; i++) r.v[i] = __builtin_subc(a.v[i], (unsigned)F::P[i], br, &br);
+  return br;
 }
 // a >= p ?  (plain integer compare)
 template <class F> AVRF_DI bool ge_p(const fp &a) { fp t; return sub_p<F>(t, a) == 0; }
@@ -75,16 +78,16 @@ template <class F> AVRF_DI fp fp_add(const fp &a, const fp &b) {
   return t;
 }
 template <class F> AVRF_DI fp fp_sub(const fp &a, const fp &b) {
-  fp t; uint32_t br = sub8(t, a, b);
-  uint64_t c = 0;
+  fp t; const uint32_t m = 0u - sub8(t, a, b);           // borrow: add p back
+  unsigned c = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) { c += (uint64_t)t.v[i] + (br ? F::P[i] : 0u); t.v[i] = (uint32_t)c; c >>= 32; }
+  for (int i = 0; i < 8; i++) t.v[i] = __builtin_addc(t.v[i], (unsigned)(F::P[i] & m), c, &c);
   return t;
 }
 template <class F> AVRF_DI fp fp_neg(const fp &a) {
-  fp t; int64_t c = 0; bool z = fp_is_zero(a);
+  fp t; unsigned br = 0; const bool z = fp_is_zero(a);
 #pragma unroll
-  for (int i = 0; i < 8; i++) { c += (int64_t)F::P[i] - (int64_t)a.v[i]; t.v[i] = z ? 0u : (uint32_t)c; c >>= 32; }
+  for (int i = 0; i < 8; i++) { const unsigned d = __builtin_subc((unsigned)F::P[i], a.v[i], br, &br); t.v[i] = z ? 0u : d; }
   return t;
 }
 template <class F> AVRF_DI fp fp_dbl(const fp &a) { return fp_add<F>(a, a); }

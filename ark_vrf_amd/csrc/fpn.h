@@ -37,35 +37,34 @@ template <int N> AVRF_DI bool fn_eq(const fpn<N> &a, const fpn<N> &b) { uint32_t
   return o == 0; }
 
 template <class F> AVRF_DI uint32_t fn_sub_p(fe<F> &r, const fe<F> &a) {
-  int64_t c = 0;
+  unsigned br = 0;                                       // (carry builtins: see fp256.h add8)
 #pragma unroll
-  for (int i = 0; i < F::N; i++) { c += (int64_t)a.v[i] - (int64_t)F::P[i]; r.v[i] = (uint32_t)c; c >>= 32; }
-  return (uint32_t)(c & 1);
+  for (int i = 0; i < F::N; i++) r.v[i] = __builtin_subc(a.v[i], (unsigned)F::P[i], br, &br);
+  return br;
 }
 template <class F> AVRF_DI bool fn_ge_p(const fe<F> &a) { fe<F> t; return fn_sub_p<F>(t, a) == 0; }
 template <class F> AVRF_DI fe<F> fn_add(const fe<F> &a, const fe<F> &b) {
-  fe<F> t, u; uint64_t c = 0;
+  fe<F> t, u; unsigned c = 0;
 #pragma unroll
-  for (int i = 0; i < F::N; i++) { c += (uint64_t)a.v[i] + b.v[i]; t.v[i] = (uint32_t)c; c >>= 32; }
+  for (int i = 0; i < F::N; i++) t.v[i] = __builtin_addc(a.v[i], b.v[i], c, &c);
   uint32_t br = fn_sub_p<F>(u, t);
 #pragma unroll
   for (int i = 0; i < F::N; i++) t.v[i] = br ? t.v[i] : u.v[i];
   return t;
 }
 template <class F> AVRF_DI fe<F> fn_sub(const fe<F> &a, const fe<F> &b) {
-  fe<F> t; int64_t c = 0;
+  fe<F> t; unsigned br = 0;
 #pragma unroll
-  for (int i = 0; i < F::N; i++) { c += (int64_t)a.v[i] - (int64_t)b.v[i]; t.v[i] = (uint32_t)c; c >>= 32; }
-  uint32_t br = (uint32_t)(c & 1);
-  uint64_t d = 0;
+  for (int i = 0; i < F::N; i++) t.v[i] = __builtin_subc(a.v[i], b.v[i], br, &br);
+  const uint32_t m = 0u - br; unsigned c = 0;
 #pragma unroll
-  for (int i = 0; i < F::N; i++) { d += (uint64_t)t.v[i] + (br ? F::P[i] : 0u); t.v[i] = (uint32_t)d; d >>= 32; }
+  for (int i = 0; i < F::N; i++) t.v[i] = __builtin_addc(t.v[i], (unsigned)(F::P[i] & m), c, &c);
   return t;
 }
 template <class F> AVRF_DI fe<F> fn_neg(const fe<F> &a) {
-  fe<F> t; int64_t c = 0; bool z = fn_is_zero(a);
+  fe<F> t; unsigned br = 0; const bool z = fn_is_zero(a);
 #pragma unroll
-  for (int i = 0; i < F::N; i++) { c += (int64_t)F::P[i] - (int64_t)a.v[i]; t.v[i] = z ? 0u : (uint32_t)c; c >>= 32; }
+  for (int i = 0; i < F::N; i++) { const unsigned d = __builtin_subc((unsigned)F::P[i], a.v[i], br, &br); t.v[i] = z ? 0u : d; }
   return t;
 }
 template <class F> AVRF_DI fe<F> fn_dbl(const fe<F> &a) { return fn_add<F>(a, a); }

@@ -580,21 +580,33 @@ MsmPlan msm_plan(size_t n, int scalar_bits) {
 
 static uint32_t tile_len_for(size_t n) { return 8192; }
 
-// lanes one residency round of k_accumulate<CV> holds on the current device (CUs x resident workgroups x 256)
-template <class CV> static size_t accumulate_lanes() {
-  static size_t cache[64] = {0};
+// lanes one residency round of k_accumulate<CV> holds on the current device (CUs x resident workgroups x 256), and the
+// dynamic LDS bytes that hold the kernel to that many workgroups per CU.  The kernel uses no LDS; asking for a slice of the
+// CU's 160 KB is how a launch is kept BELOW what its registers would allow (AVRF_MSM_OCC, or the policy's MAX_WAVES): with
+// several contexts in flight the waves of a register-light k_accumulate otherwise take every slot of a SIMD and the other
+// contexts' latency-bound kernels (hashing, sort, reductions) no longer overlap with it.
+struct AccShape { size_t lanes; unsigned lds; };
+template <class CV> static AccShape accumulate_shape() {
+  static AccShape cache[64] = {};
   int dev = 0; HIP_CHECK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) dev = 0;
-  if (!cache[dev]) {
+  if (!cache[dev].lanes) {
     int cus = 0, blocks = 0;
     HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_accumulate<CV>, 256, 0));
     if (blocks < 1) blocks = 1;
-    if (msm_env().occ && msm_env().occ < blocks) blocks = msm_env().occ;      // a block of 256 lanes = one wave on each of a CU's 4 SIMDs
-    cache[dev] = (size_t)cus * blocks * 256;
+    int cap = CV::MAX_WAVES;                                                  // a block of 256 lanes = one wave on each of a CU's 4 SIMDs
+    if (msm_env().occ) cap = msm_env().occ;
+    unsigned lds = 0;
+    if (cap >= 1 && cap < blocks) {
+      blocks = cap; lds = (unsigned)(160 * 1024 / (cap + 1) + 1024);                                     // cap + 1 slices do not fit
+      if (lds > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    cache[dev] = AccShape{(size_t)cus * blocks * 256, lds};
   }
   return cache[dev];
 }
+template <class CV> static size_t accumulate_lanes() { return accumulate_shape<CV>().lanes; }
 
 template <class T> static void grow(T *&p, size_t &cap, size_t need, size_t elem) {
   if (need <= cap) return;
@@ -705,7 +717,7 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
   if (CV::ZERO_IS_IDENTITY) HIP_CHECK(hipMemsetAsync(ws.buckets, 0, (size_t)nbk * acc_bytes, stream));   // empty buckets
   HIP_CHECK(hipEventRecord(ws.ev0, stream));
-  hipLaunchKernelGGL(k_accumulate<CV>, dim3((unsigned)((lanes_max + 255) / 256)), b256, 0, stream, d_bases, (const uint32_t *)ws.sorted,
+  hipLaunchKernelGGL(k_accumulate<CV>, dim3((unsigned)((lanes_max + 255) / 256)), b256, accumulate_shape<CV>().lds, stream, d_bases, (const uint32_t *)ws.sorted,
                      (const uint32_t *)ws.offsets, (const uint32_t *)ws.win_tot, (const uint32_t *)ws.lane_base, (const uint32_t *)ws.plan_dev, vwin,
                      (uint32_t)p.nb, (uint32_t)n, ws.part);
   HIP_CHECK(hipEventRecord(ws.ev1, stream));

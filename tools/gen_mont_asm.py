@@ -71,13 +71,26 @@ def body(N, sqr=False, limbs=None, ninv=None):
     T0, T1, T2, TMP = f"v{T_BASE}", f"v{T_BASE + 1}", f"v{T_BASE + 2}", f"v{T_BASE + 3}"
     TP = f"v[{T_BASE}:{T_BASE + 1}]"
 
+    # registers of the accumulator block that hold a value: a word nothing has been written to yet reads as the literal 0 and
+    # is never cleared by a v_mov (a column's first product into a fresh 64-bit pair takes the addend 0 and cannot carry, the
+    # first carry into a fresh third word is written as 0 + 0 + vcc): 4-5 instructions fewer per odd column, 1 per even one
+    written = set()
+    src = lambda r: r if r in written else "0"
+
+    def addc(dst, x, y):                                   # dst = x + y + vcc; a literal goes first (VOP2 wants a VGPR second)
+        if y == "0":
+            x, y = y, x
+        L.append(f"v_addc_co_u32 {dst}, vcc, {x}, {y}, vcc")
+        written.add(dst)
+
     def mac(k, x, y):
-        if k % 2 == 0:
-            L.append(f"v_mad_u64_u32 {pair(k)}, vcc, {x}, {y}, {pair(k)}")
-            L.append(f"v_addc_co_u32 {A(k + 2)}, vcc, 0, {A(k + 2)}, vcc")
-        else:
-            L.append(f"v_mad_u64_u32 {TP}, vcc, {x}, {y}, {TP}")
-            L.append(f"v_addc_co_u32 {T2}, vcc, 0, {T2}, vcc")
+        lo, hi, c2, pr = (A(k), A(k + 1), A(k + 2), pair(k)) if k % 2 == 0 else (T0, T1, T2, TP)
+        assert (lo in written) == (hi in written)
+        fresh = lo not in written
+        L.append(f"v_mad_u64_u32 {pr}, vcc, {x}, {y}, {'0' if fresh else pr}")
+        written.update((lo, hi))
+        if not fresh:
+            addc(c2, "0", src(c2))
 
     av = lambda i: f"%{n_out + i}"
     if sqr:
@@ -87,13 +100,9 @@ def body(N, sqr=False, limbs=None, ninv=None):
             L.append(f"v_lshlrev_b32 {LL(j)}, 1, {av(j)}")
             if j >= 2:
                 L.append(f"v_alignbit_b32 {D(j)}, {av(j)}, {av(j - 1)}, 31")
-    for i in range(2):
-        L.append(f"v_mov_b32 {A(i)}, 0")
     for k in range(2 * N - 1):
-        L.append(f"v_mov_b32 {A(k + 2)}, 0")
         if k % 2:
-            for r in (T0, T1, T2):
-                L.append(f"v_mov_b32 {r}, 0")
+            written.difference_update((T0, T1, T2))
         lo, hi = (0, k) if k < N else (k - N + 1, N - 1)
         for i in range(lo, hi + 1):
             j = k - i
@@ -105,16 +114,19 @@ def body(N, sqr=False, limbs=None, ninv=None):
                 mac(k, av(i), LL(j) if j == i + 1 else D(j))
         for i in range(lo, min(hi, k - 1) + 1):
             mac(k, M(i), P(k - i))
-        fold = [f"v_add_co_u32 {A(k)}, vcc, {A(k)}, {T0}",
-                f"v_addc_co_u32 {A(k + 1)}, vcc, {A(k + 1)}, {T1}, vcc",
-                f"v_addc_co_u32 {A(k + 2)}, vcc, {A(k + 2)}, {T2}, vcc"]
+
+        def fold():
+            assert A(k) in written and T0 in written
+            L.append(f"v_add_co_u32 {A(k)}, vcc, {A(k)}, {T0}")
+            addc(A(k + 1), src(A(k + 1)), T1)
+            addc(A(k + 2), src(A(k + 2)), src(T2))
         if k < N and p0_is_one:
             if k % 2:
-                L.extend(fold)                                           # the odd column's sum first: its low word is A(k)
+                fold()                                                   # the odd column's sum first: its low word is A(k)
             L.append(f"v_sub_u32 {M(k)}, 0, {A(k)}")                      # m_k = -lo mod 2^32
             L.append(f"v_cmp_ne_u32 vcc, 0, {A(k)}")                      # lo + m_k = 2^32 [lo != 0]: the word is done, its carry moves up
-            L.append(f"v_addc_co_u32 {A(k + 1)}, vcc, 0, {A(k + 1)}, vcc")
-            L.append(f"v_addc_co_u32 {A(k + 2)}, vcc, 0, {A(k + 2)}, vcc")
+            addc(A(k + 1), "0", src(A(k + 1)))
+            addc(A(k + 2), "0", src(A(k + 2)))
             continue
         if k < N:
             if k % 2 == 0:
@@ -124,7 +136,8 @@ def body(N, sqr=False, limbs=None, ninv=None):
                 L.append(f"v_mul_lo_u32 {M(k)}, {TMP}, s{S0 + N}")
             mac(k, M(k), P(0))
         if k % 2:
-            L.extend(fold)
+            fold()
+    assert all(A(N + i) in written for i in range(N))
     if N == 8:
         for i in range(N):
             L.append(f"v_mov_b32 %{i}, {A(N + i)}")
@@ -220,7 +233,7 @@ def emulate(N, ins, limbs, ninv, a, b):
             reg[o[0]] = prd(o[1])
         elif op == "v_mad_u64_u32":
             assert o[1] == "vcc" and int(o[0][2:o[0].index(":")]) % 2 == 0
-            v = rd(o[2]) * rd(o[3]) + prd(o[4]); vcc = v >> 64; pwr(o[0], v & ((1 << 64) - 1))
+            v = rd(o[2]) * rd(o[3]) + (0 if o[4] == "0" else prd(o[4])); vcc = v >> 64; pwr(o[0], v & ((1 << 64) - 1))
         elif op == "v_addc_co_u32":
             assert o[1] == "vcc" and o[4] == "vcc"
             v = rd(o[2]) + rd(o[3]) + vcc; reg[o[0]] = v & MASK; vcc = v >> 32
