@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONSTS = os.path.join(ROOT, "ark_vrf_amd", "csrc", "consts_gen.h")
 OUT = os.path.join(ROOT, "ark_vrf_amd", "csrc", "mont8_asm_gen.h")
 S0 = 36
+ONES_BY_SUBTRACTION = False      # see mac_ones
 # per limb count: first accumulator register (even), odd-column scratch (even), m registers
 # squaring only: D = the limbs of 2a, L = the limbs a_j << 1 (no carry-in)
 LAYOUT = {8: dict(A0=96, T=114, M0=118, D0=80, L0=87), 12: dict(A0=100, T=126, M0=130, D0=142, L0=154)}
@@ -92,6 +93,20 @@ def body(N, sqr=False, limbs=None, ninv=None):
         if not fresh:
             addc(c2, "0", src(c2))
 
+    def mac_ones(k, m):
+        """column += m * (2^32 - 1) without the multiplier: subtract m at the column's low word (borrow through the two words
+        above), add it one word up.  Five full-rate instructions for a quarter-rate multiply-add and its carry: the kernels are
+        OFF: measured slower (tools/r3_run12.sh, Bandersnatch base field, 112 multiply-adds + 205 other instructions against
+        120 + 173): k_accumulate 0.462 ms against 0.439 ms, k_thin_verify 3.03-3.12 ms against 2.89 ms -- the kernels are bound by
+        the total issue time of the stream, not by the multiplier alone."""
+        lo, hi, c2 = (A(k), A(k + 1), A(k + 2)) if k % 2 == 0 else (T0, T1, T2)
+        assert lo in written and hi in written
+        L.append(f"v_sub_co_u32 {lo}, vcc, {lo}, {m}")
+        L.append(f"v_subbrev_co_u32 {hi}, vcc, 0, {hi}, vcc")
+        L.append(f"v_subbrev_co_u32 {c2}, vcc, 0, {src(c2)}, vcc"); written.add(c2)
+        L.append(f"v_add_co_u32 {hi}, vcc, {hi}, {m}")
+        addc(c2, "0", c2)
+
     av = lambda i: f"%{n_out + i}"
     if sqr:
         D = lambda j: f"v{lay['D0'] + j}"
@@ -113,7 +128,10 @@ def body(N, sqr=False, limbs=None, ninv=None):
             elif i < j:
                 mac(k, av(i), LL(j) if j == i + 1 else D(j))
         for i in range(lo, min(hi, k - 1) + 1):
-            mac(k, M(i), P(k - i))
+            if ONES_BY_SUBTRACTION and limbs is not None and limbs[k - i] == 0xffffffff:
+                mac_ones(k, M(i))
+            else:
+                mac(k, M(i), P(k - i))
 
         def fold():
             assert A(k) in written and T0 in written
@@ -239,6 +257,11 @@ def emulate(N, ins, limbs, ninv, a, b):
             v = rd(o[2]) + rd(o[3]) + vcc; reg[o[0]] = v & MASK; vcc = v >> 32
         elif op == "v_add_co_u32":
             v = rd(o[2]) + rd(o[3]); reg[o[0]] = v & MASK; vcc = v >> 32
+        elif op == "v_sub_co_u32":
+            v = rd(o[2]) - rd(o[3]); reg[o[0]] = v & MASK; vcc = 1 if v < 0 else 0
+        elif op == "v_subbrev_co_u32":                      # dst = src1 - src0 - borrow
+            assert o[1] == "vcc" and o[4] == "vcc"
+            v = rd(o[3]) - rd(o[2]) - vcc; reg[o[0]] = v & MASK; vcc = 1 if v < 0 else 0
         elif op == "v_lshlrev_b32":
             reg[o[0]] = (rd(o[2]) << int(o[1])) & MASK
         elif op == "v_alignbit_b32":
