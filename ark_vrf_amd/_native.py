@@ -161,6 +161,16 @@ class Context:
     def pedersen_batch_run(self):
         return lib().avrf_pedersen_batch_run(self._h)
 
+    # the run of the staged batch in three calls (include/avrf.h): one host thread can keep several contexts in flight
+    def batch_run_begin(self):
+        return lib().avrf_batch_run_begin(self._h)
+
+    def batch_run_hash(self):
+        return lib().avrf_batch_run_hash(self._h)
+
+    def batch_run_end(self):
+        return lib().avrf_batch_run_end(self._h)
+
     def last_terms(self):
         k = lib().avrf_batch_last_terms(self._h, None, None)
         bases, sc = (C.c_uint8 * max(1, 64 * k))(), (C.c_uint8 * max(1, 32 * k))()

@@ -89,6 +89,8 @@ struct avrf_ctx {
   DevBuf d_fixed; bool fixed_ready = false;   // fixed-base tables of G and BLINDING_BASE (provers, scalar_mul_base), built on first use
   PinBuf h_c, h_flags, h_io;
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int run_phase = 0;              // batch_begin / batch_hash / batch_end
+  double run_t0 = 0, run_begin_us = 0, run_msm_us = 0;
 };
 
 // fixed-base tables for the provers: built once per context, on the context's stream
@@ -282,7 +284,7 @@ int avrf_g1_msm(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *s
 // kind: 1 thin (pks + 96-byte proofs), 2 pedersen (256-byte proofs); proofs/pks/sks may be NULL for provers
 static int stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy,
                  const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
-  if (!c) return AVRF_ERR_BAD_ARG;
+  if (!c || c->run_phase) return AVRF_ERR_BAD_ARG;              // (a run in flight owns the staged buffers)
   if (n && (!io_counts || !ad_lens)) return AVRF_ERR_BAD_ARG;
   if (n > 0x0fffffffULL) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
@@ -395,13 +397,16 @@ class WeightHashService {
 };
 }  // namespace
 
-// shared tail of both batch verifiers: weight transcript on the host, terms + MSM on the device
-static int batch_run(avrf_ctx *c, int kind) {
-  if (!c || c->staged_kind != kind) return AVRF_ERR_BAD_ARG;
-  if (c->n == 0) return AVRF_OK;                                       // src/thin.rs:262-264, src/pedersen.rs:343-345
+// shared tail of both batch verifiers in three phases (run_phase): 1 = validation + prepare kernel + copies back enqueued,
+// 2 = weight transcript hashed on the host and terms + MSM enqueued, 0 = idle.  batch_run walks all three; the
+// avrf_batch_run_begin / _hash / _end entry points let one host thread keep several contexts in flight (hash one context's
+// transcript while the others' kernels run) instead of parking a thread per context.
+static int batch_begin(avrf_ctx *c, int kind) {
+  if (!c || c->staged_kind != kind || c->run_phase != 0) return AVRF_ERR_BAD_ARG;
+  if (c->n == 0) { c->run_phase = 1; return AVRF_OK; }                 // src/thin.rs:262-264, src/pedersen.rs:343-345
   if (!c->n_terms) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
-  double t0 = now_us();
+  c->run_t0 = now_us();
   const size_t n = c->n;
   BatchDev b = batch_of(c);
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
@@ -423,6 +428,25 @@ static int batch_run(avrf_ctx *c, int kind) {
     HIP_TRY(hipMemcpyAsync(c->h_msg.as<uint8_t>() + pl, c->d_rec.p, n * recsz, hipMemcpyDeviceToHost, c->stream));
   } else HIP_TRY(hipMemcpyAsync(c->h_c.p, c->d_c.p, n * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
+  c->run_begin_us = now_us() - c->run_t0;
+  c->run_phase = 1;
+  return AVRF_OK;
+}
+
+static int batch_hash(avrf_ctx *c, int kind) {
+  if (!c || c->staged_kind != kind || c->run_phase != 1) return AVRF_ERR_BAD_ARG;
+  if (c->n == 0) { c->run_phase = 2; return AVRF_OK; }
+  c->run_phase = 0;                                                    // an error below leaves the context idle
+  HIP_TRY(hipSetDevice(c->device));
+  const double tw = now_us();
+  const size_t n = c->n;
+  BatchDev b = batch_of(c);
+  const int host_stream = with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; return S::XOF_SHAKE ? 1 : S::TR_SHA256 ? 2 : 0; });
+  const size_t recsz = kind == 1 ? 64 : 96;
+  uint8_t prefix[64]; size_t pl = 0;
+  with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; memcpy(prefix, S::SUITE_ID, S::SUITE_ID_LEN); pl = S::SUITE_ID_LEN; });
+  prefix[pl++] = DS_BATCH_VERIFY;
+  if (!host_stream) b.records = c->d_rec.as<uint8_t>();
   HIP_TRY(hipStreamSynchronize(c->stream));
   double t1 = now_us();
   if (*c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;            // src/thin.rs:266-271, src/pedersen.rs:348-353
@@ -468,17 +492,40 @@ static int batch_run(avrf_ctx *c, int kind) {
   else launch_ped_terms(c->suite, b, seed, 0, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_scalars.as<uint32_t>(),
                         c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
   double t3 = now_us();
+  if (int e = guarded([&] { return msm_te_enqueue(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  c->timing[1] = c->run_begin_us + (t1 - tw); c->timing[2] = t2 - t1; c->timing[3] = t3 - t2;
+  c->run_msm_us = now_us() - t3;
+  c->run_phase = 2;
+  return AVRF_OK;
+}
+
+static int batch_end(avrf_ctx *c, int kind) {
+  if (!c || c->staged_kind != kind || c->run_phase != 2) return AVRF_ERR_BAD_ARG;
+  c->run_phase = 0;
+  if (c->n == 0) return AVRF_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const double t3 = now_us();
   HostExt r;
-  if (int e = guarded([&] { return msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  if (int e = guarded([&] { return msm_te_finish(c->suite, c->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
   double t4 = now_us();
   int st = point_is_identity(c, r) ? AVRF_OK : AVRF_VERIFICATION_FAILURE;   // src/thin.rs:319-322, src/pedersen.rs:420-423
   double t5 = now_us();
-  c->timing[0] = t5 - t0; c->timing[1] = t1 - t0; c->timing[2] = t2 - t1; c->timing[3] = t3 - t2; c->timing[4] = t4 - t3; c->timing[5] = t5 - t4;
+  c->timing[4] = c->run_msm_us + (t4 - t3); c->timing[5] = t5 - t4;
+  c->timing[0] = c->timing[1] + c->timing[2] + c->timing[3] + c->timing[4] + c->timing[5];   // time spent IN the three calls
   return st;
+}
+
+static int batch_run(avrf_ctx *c, int kind) {
+  if (int e = batch_begin(c, kind)) return e;
+  if (int e = batch_hash(c, kind)) return e;
+  return batch_end(c, kind);
 }
 
 int avrf_thin_batch_run(avrf_ctx *c) { return batch_run(c, 1); }
 int avrf_pedersen_batch_run(avrf_ctx *c) { return batch_run(c, 2); }
+int avrf_batch_run_begin(avrf_ctx *c) { return c && c->staged_kind ? batch_begin(c, c->staged_kind) : AVRF_ERR_BAD_ARG; }
+int avrf_batch_run_hash(avrf_ctx *c) { return c && c->staged_kind ? batch_hash(c, c->staged_kind) : AVRF_ERR_BAD_ARG; }
+int avrf_batch_run_end(avrf_ctx *c) { return c && c->staged_kind ? batch_end(c, c->staged_kind) : AVRF_ERR_BAD_ARG; }
 
 int avrf_thin_batch_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
                            const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {

@@ -47,6 +47,8 @@ struct MsmWorkspace {
   double accum_ms_total = 0; uint64_t accum_launches = 0; float accum_ms_last = 0;
   MsmPlan last_plan = {0, 0, 0, 0};
   int wsum_lg = 4;               // scale 2^lg of the third point of a window triple (TE window sums)
+  // an enqueued launch chain whose results have not been collected yet (msm_te_enqueue / msm_te_finish)
+  MsmPlan pending_plan = {0, 0, 0, 0}; int pending_ret = 0; size_t pending_n = 0;
   void ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch, size_t lanes_max);
   void release();
 };
@@ -55,6 +57,10 @@ struct MsmWorkspace {
 // already < r), on `stream`.  Result: extended point on the host.  suite: 0 Bandersnatch, 1 Baby-JubJub.
 int msm_te_device(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n,
                   MsmWorkspace &ws, hipStream_t stream, HostExt *out);
+// the same in two halves: msm_te_enqueue launches the whole kernel chain and the copies back on `stream` and returns without
+// waiting; msm_te_finish waits for the stream and folds the window sums on the host.  One chain in flight per workspace.
+int msm_te_enqueue(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream);
+int msm_te_finish(int suite, MsmWorkspace &ws, hipStream_t stream, HostExt *out);
 
 // G1 MSM over a short-Weierstrass curve (curve: 0 BLS12-381, 1 BN254): d_bases = n Montgomery affine
 // points (2 * Fq words each, (0,0) = infinity), d_scalars = n plain 256-bit scalars (< r).

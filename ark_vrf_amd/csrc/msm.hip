@@ -674,6 +674,15 @@ void MsmWorkspace::release() {
   cap_n = cap_slots = cap_buckets = cap_bits = cap_part = cap_hist = cap_vwin = 0;
 }
 
+// waits for the launch chain msm_device enqueued on `stream` and books its plan / k_accumulate timing
+static void msm_wait(MsmWorkspace &ws, hipStream_t stream) {
+  HIP_CHECK(hipStreamSynchronize(stream));
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipEventElapsedTime(&ws.accum_ms_last, ws.ev0, ws.ev1));
+  ws.pending_plan.lpb = (int)ws.plan_host[0];
+  ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = ws.pending_plan;
+}
+
 // Runs the whole device pipeline for one MSM and leaves the nwin*c bit sums T_p in ws.bits_host
 // (accumulator layout of CV); returns the number of bit sums.
 // `batch` scalar vectors of length n over the SAME n bases (d_scalars = batch x n x 8 words): every vector
@@ -683,7 +692,8 @@ void MsmWorkspace::release() {
 // Throws HipFailure when a HIP call fails.
 template <class CV>
 static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n_in, int scalar_bits, MsmWorkspace &ws, hipStream_t stream,
-                      size_t batch = 1, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0, const uint32_t *d_base_idx = nullptr) {
+                      size_t batch = 1, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0, const uint32_t *d_base_idx = nullptr,
+                      bool defer = false) {
   MsmPlan p = msm_plan(n_in, scalar_bits);
   if (!scalar_stride) scalar_stride = n_in;                            // vector b's scalars start at b * scalar_stride
   const size_t lanes_target = accumulate_lanes<CV>();
@@ -727,13 +737,9 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
                      (const uint32_t *)ws.lane_base, (const uint32_t *)ws.plan_dev, (uint32_t)p.nb, (uint32_t)n, (const uint32_t *)ws.part, ws.buckets,
                      (const uint32_t *)ws.heavy);
   HIP_CHECK(hipMemcpyAsync(ws.plan_host, ws.plan_dev, 8, hipMemcpyDeviceToHost, stream));
-  auto finish = [&]() {
-    HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipEventElapsedTime(&ws.accum_ms_last, ws.ev0, ws.ev1));
-    p.lpb = (int)ws.plan_host[0];
-    ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = p;
-  };
+  // defer: the caller collects the results later (msm_wait): everything up to the copies back is enqueued, nothing is waited for
+  ws.pending_plan = p;
+  auto finish = [&]() { if (!defer) msm_wait(ws, stream); };
   if constexpr (CV::WINDOW_SUMS) if (batch == 1 && msm_env().window_sums) {
     // weighted bucket sum of every window with the four-lanes-per-point kernels (te_quad.h): three points per window come
     // back; the host folds them into its window Horner (scales 1, 2^4, 16 m), so the device does no doublings at all
@@ -791,11 +797,19 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
 }
 
 template <class S>
-static int msm_te_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, HostExt *out) {
+static int msm_te_enqueue_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream) {
+  ws.pending_n = n; ws.pending_ret = 0;
+  if (n) ws.pending_ret = msm_device<TeCurve<S>>((const uint32_t *)d_pre, d_scalars, n, S::Fr::BITS, ws, stream, 1, 0, 0, 0, nullptr, /*defer=*/true);
+  return 0;
+}
+template <class S>
+static int msm_te_finish_impl(MsmWorkspace &ws, hipStream_t stream, HostExt *out) {
   using HT = HostTe<S>;
   *out = HT::identity();
-  if (n == 0) return 0;
-  int nbits = msm_device<TeCurve<S>>((const uint32_t *)d_pre, d_scalars, n, S::Fr::BITS, ws, stream);
+  if (ws.pending_n == 0) return 0;
+  ws.pending_n = 0;
+  msm_wait(ws, stream);
+  const int nbits = ws.pending_ret;
   HostExt acc = HT::identity();
   const uint32_t *bh = ws.bits_host;
   if (nbits < 0) {                                        // window triples: W_w = P1 + 2^4 P2 + 2^lg P3; sum_w 2^(c w) W_w
@@ -816,10 +830,18 @@ static int msm_te_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_
   return 0;
 }
 
+int msm_te_enqueue(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream) {
+  if (suite < 0 || suite >= AVRF_N_SUITES) return -1;
+  return with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return msm_te_enqueue_impl<S>(d_pre, d_scalars, n, ws, stream); });
+}
+int msm_te_finish(int suite, MsmWorkspace &ws, hipStream_t stream, HostExt *out) {
+  if (suite < 0 || suite >= AVRF_N_SUITES) return -1;
+  return with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return msm_te_finish_impl<S>(ws, stream, out); });
+}
 int msm_te_device(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n,
                   MsmWorkspace &ws, hipStream_t stream, HostExt *out) {
-  if (suite < 0 || suite >= AVRF_N_SUITES) return -1;
-  return with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return msm_te_impl<S>(d_pre, d_scalars, n, ws, stream, out); });
+  if (int e = msm_te_enqueue(suite, d_pre, d_scalars, n, ws, stream)) return e;
+  return msm_te_finish(suite, ws, stream, out);
 }
 
 // ---------------------------------------------------------------- G1 (KZG) MSM

@@ -132,6 +132,18 @@ int avrf_thin_batch_stage(avrf_ctx *ctx, size_t n, const uint8_t *pks_xy, const 
                           const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens,
                           const uint8_t *proofs);
 int avrf_thin_batch_run(avrf_ctx *ctx);
+/* The run of a staged batch (Thin or Pedersen) in three non-overlapping calls, for a host thread that keeps several contexts
+ * in flight: BatchVerifier::verify (src/thin.rs:257-325, src/pedersen.rs:341-426) is device work, then the sequential
+ * weight transcript on the host (src/thin.rs:274-279), then device work again.
+ *   avrf_batch_run_begin  enqueues validation + the prepare kernel + the copies back on the context's stream and returns;
+ *   avrf_batch_run_hash   waits for them, returns AVRF_INVALID_DATA as the one-call form would, hashes the weight transcript
+ *                         on the calling thread, enqueues the terms kernel and the MSM, returns without waiting;
+ *   avrf_batch_run_end    waits for the MSM and returns the verdict (AVRF_OK / AVRF_VERIFICATION_FAILURE).
+ * Results are those of avrf_thin_batch_run / avrf_pedersen_batch_run (which are these three in a row).  A context takes no
+ * other call between begin and end; a call out of order returns AVRF_ERR_BAD_ARG; an error ends the sequence. */
+int avrf_batch_run_begin(avrf_ctx *ctx);
+int avrf_batch_run_hash(avrf_ctx *ctx);
+int avrf_batch_run_end(avrf_ctx *ctx);
 
 /* pedersen::BatchVerifier split the same way (src/pedersen.rs:341-426): stage the shard with avrf_pedersen_batch_stage,
  * avrf_pedersen_batch_challenges -> n_shard x 16 bytes, avrf_batch_weight_seed(pedersen = 1) over all items

@@ -56,11 +56,14 @@ def test_host_plan_follows_the_quota():
     """contexts per rank and hashing mode from the CPU quota divided by the ranks (bench.host_plan)"""
     sys.path.insert(0, ROOT)
     import bench
-    streams, mb, cores = bench.host_plan(16, 1, 0, 480)
-    assert (streams, mb, cores) == (20, 0, 16.0)
-    streams, mb, cores = bench.host_plan(16, 8, 0, 480)           # 2 cores per rank: the multi-buffer service, 8 lanes per thread
-    assert mb == 2 and streams == 20 and cores == 2.0
-    assert bench.host_plan(256, 8, 0, 480)[:2] == (24, 0)
-    assert bench.host_plan(16, 1, 0, 20)[0] == 20 and bench.host_plan(64, 1, 0, 5)[0] == 5     # never more contexts than steps
-    assert bench.host_plan(16, 1, 12, 480)[0] == 12                                         # --streams overrides
+    streams, mb, cores, threads = bench.host_plan(16, 1, 0, 480)
+    assert (streams, mb, cores, threads) == (21, 0, 16.0, 7)      # seven host threads keep three contexts each in flight
+    streams, mb, cores, threads = bench.host_plan(16, 8, 0, 480)  # 2 cores per rank: the multi-buffer service, 8 lanes per thread
+    assert mb == 2 and streams == 20 and cores == 2.0 and threads == 20     # ... with one host thread per context
+    assert bench.host_plan(256, 8, 0, 480) == (21, 0, 32.0, 7)
+    assert bench.host_plan(16, 2, 0, 480)[::3] == (21, 7) and bench.host_plan(12, 2, 0, 480)[::3] == (15, 5)
+    assert bench.host_plan(16, 1, 0, 20)[::3] == (21, 7)                                     # (a block of steps may be smaller than the contexts)
+    assert bench.host_plan(16, 1, 12, 480)[::3] == (12, 7)                                   # --streams overrides
+    assert bench.host_plan(16, 1, 20, 480, 20)[::3] == (20, 20)                              # --host-threads: one thread per context
+    assert all(bench.host_plan(q, w, 0, 480)[0] <= 23 for q in (1, 2, 4, 16, 64, 256) for w in (1, 2, 4, 8))   # 24 contexts halve the rate
     assert bench.cpu_quota() >= 1
