@@ -180,7 +180,8 @@ int avrf_points_sum(int suite, size_t k, const uint8_t *points_xy, uint8_t out_x
 size_t avrf_batch_last_terms(avrf_ctx *ctx, uint8_t *bases_xy, uint8_t *scalars);
 
 /* Last-call timing breakdown in microseconds (host wall clock):
- * [0] total, [1] device prepare (hash), [2] host weight transcript, [3] scalars, [4] msm, [5] finish */
+ * [0] total, [1] device prepare (hash), [2] host weight transcript, [3] scalars, [4] msm, [5] finish.
+ * Time spent inside the calls: with avrf_batch_run_begin / _hash / _end the gaps between the three calls are not counted. */
 void avrf_last_timing(avrf_ctx *ctx, double out[8]);
 
 /* Device-side timing of the dominant kernel (MSM bucket accumulation), measured with HIP events
