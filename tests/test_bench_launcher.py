@@ -61,7 +61,8 @@ def test_host_plan_follows_the_quota():
     streams, mb, cores, threads = bench.host_plan(16, 8, 0, 480)  # 2 cores per rank: the multi-buffer service, 8 lanes per thread
     assert mb == 2 and streams == 20 and cores == 2.0 and threads == 20     # ... with one host thread per context
     assert bench.host_plan(256, 8, 0, 480) == (21, 0, 32.0, 7)
-    assert bench.host_plan(16, 2, 0, 480)[::3] == (21, 7) and bench.host_plan(12, 2, 0, 480)[::3] == (15, 5)
+    assert bench.host_plan(16, 2, 0, 480)[::3] == (21, 7) and bench.host_plan(12, 2, 0, 480)[::3] == (18, 6)
+    assert bench.host_plan(16, 4, 0, 480) == (12, 0, 4.0, 4)      # 4 cores per rank: still scalar chains, four pipelined threads
     assert bench.host_plan(16, 1, 0, 20)[::3] == (21, 7)                                     # (a block of steps may be smaller than the contexts)
     assert bench.host_plan(16, 1, 12, 480)[::3] == (12, 7)                                   # --streams overrides
     assert bench.host_plan(16, 1, 20, 480, 20)[::3] == (20, 20)                              # --host-threads: one thread per context
