@@ -17,14 +17,17 @@
 #ifndef AVRF_TE_ACC_MAX_WAVES
 #define AVRF_TE_ACC_MAX_WAVES 2
 #endif
-// 12-limb G1 accumulate: 2 waves per SIMD = 192 VGPRs, no scratch; 3 = 168 VGPRs + 44 spilled registers.  A/B on one box
+// 12-limb G1 accumulate: 2 waves per SIMD = 192 VGPRs (201 with the carry-chain field additions), no scratch; 3 = 168 VGPRs + 44
+// spilled registers.  A/B on one box
 // (tools/r3_run4.sh, ring 1024): 4 contexts 11.49 k proofs/s against 11.05-11.11 k, one context 8.0-9.3 k against 7.4-7.8 k,
 // and the window-table build of a setup 82 ms against 96-118 ms.
 #ifndef AVRF_G1_ACC_WAVES
 #define AVRF_G1_ACC_WAVES 2
 #endif
 // reduction kernels of the 12-limb curve (general additions, two accumulators live): the whole register file, no scratch
-// (at 2 waves per SIMD k_wsum spilled 94 registers and k_wsum_blk 458; same A/B: 11.48-11.63 k proofs/s against 11.19-11.51 k)
+// (at 2 waves per SIMD k_wsum spilled 94 registers and k_wsum_blk 458; same A/B: 11.48-11.63 k proofs/s against 11.19-11.51 k.
+// With the carry-chain field additions the spills are 40 / 71 registers and the A/B is a tie: 12.4-12.9 k against 12.7 k,
+// tools/r3_run13.sh)
 #ifndef AVRF_G1_RED_WAVES
 #define AVRF_G1_RED_WAVES 1
 #endif
