@@ -156,6 +156,9 @@ def body(N, sqr=False, limbs=None, ninv=None):
         if k % 2:
             fold()
     assert all(A(N + i) in written for i in range(N))
+    # (the conditional subtraction of p stays in C++: done here -- the modulus limbs copied to VGPRs, because a carry instruction
+    # already reads vcc over the constant bus, then v_sub / v_subb / v_cndmask -- it measured no faster: k_accumulate 0.445 ms
+    # against 0.441, tools/r3_run12.sh)
     if N == 8:
         for i in range(N):
             L.append(f"v_mov_b32 %{i}, {A(N + i)}")
