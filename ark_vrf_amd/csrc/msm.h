@@ -76,7 +76,8 @@ int msm_g1_device(int curve, const uint32_t *d_bases, const uint32_t *d_scalars,
 void build_g1_table(int curve, const uint32_t *d_bases, size_t n, int c, int nwin, uint32_t *d_table, hipStream_t stream);
 int msm_g1_fixed_device(int curve, const uint32_t *d_table, int table_c, size_t table_stride, const uint32_t *d_scalars, size_t n,
                         size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch,
-                        const uint32_t *d_base_idx = nullptr);
+                        const uint32_t *d_base_idx = nullptr, int scalars_mont = 0);
+// (scalars_mont: the scalar vectors hold Montgomery limbs -- 1 = BLS12-381 Fr, 2 = BN254 Fr -- and the digit kernel converts on load)
 // n compressed G1 points (FQ_BYTES each, ark-serialize) -> canonical x || y little-endian + ok[i] (0 invalid, 1 point, 2 infinity)
 void launch_g1_decompress(int curve, const uint8_t *d_comp, size_t n, uint8_t *d_out_xy, uint8_t *d_ok, hipStream_t stream);
 void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, uint32_t *d_flag, hipStream_t stream);

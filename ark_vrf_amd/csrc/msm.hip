@@ -95,7 +95,7 @@ void launch_scalars_from_mont(int suite, uint32_t *d_scalars, size_t n, uint32_t
 // v = batch * nwin + w everywhere downstream)
 // (With fixed-base window tables the nwin digit rows of one vector are simply consumed as ONE window of
 // n * nwin keys: same layout, different interpretation downstream.)
-__global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ scalars, uint32_t n, uint32_t stride, int c, int nwin, uint16_t *__restrict__ keys) {
+__global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ scalars, uint32_t n, uint32_t stride, int c, int nwin, uint16_t *__restrict__ keys, int mont) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t bat = blockIdx.y;
@@ -104,6 +104,14 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t *__restrict__ sca
   const uint4 *p = reinterpret_cast<const uint4 *>(scalars + 8 * ((size_t)bat * stride + i));
   uint4 a = p[0], b = p[1];
   s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; s[8] = 0;
+  if (mont) {                                                // the vector holds Montgomery limbs (the ring prover's coefficient vectors): 1 = BLS12-381 Fr, 2 = BN254 Fr
+    fp v;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v.v[k] = s[k];
+    v = mont == 1 ? fp_from_mont<FqBandersnatch>(v) : fp_from_mont<FqBabyJubJub>(v);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = v.v[k];
+  }
   const uint32_t nb = 1u << (c - 1), mask = (1u << c) - 1;
   uint32_t carry = 0;
   for (int w = 0; w < nwin; w++) {
@@ -693,7 +701,7 @@ static void msm_wait(MsmWorkspace &ws, hipStream_t stream) {
 template <class CV>
 static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n_in, int scalar_bits, MsmWorkspace &ws, hipStream_t stream,
                       size_t batch = 1, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0, const uint32_t *d_base_idx = nullptr,
-                      bool defer = false) {
+                      bool defer = false, int scalars_mont = 0) {
   MsmPlan p = msm_plan(n_in, scalar_bits);
   if (!scalar_stride) scalar_stride = n_in;                            // vector b's scalars start at b * scalar_stride
   const size_t lanes_target = accumulate_lanes<CV>();
@@ -716,7 +724,7 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   const uint32_t tile_len = tile_len_for(n), ntiles = (uint32_t)((n + tile_len - 1) / tile_len);
   const size_t lds_bytes = (size_t)p.nb * 4;
   hipLaunchKernelGGL(k_digits, dim3((unsigned)((n_in + 255) / 256), (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n_in, (uint32_t)scalar_stride,
-                     p.c, dig_nwin, ws.keys);
+                     p.c, dig_nwin, ws.keys, scalars_mont);
   hipLaunchKernelGGL(k_hist, dim3(ntiles, vwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist);
   hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)((p.nb + 255) / 256), vwin), b256, 0, stream, ws.hist, ntiles, p.c, ws.cnts);
   hipLaunchKernelGGL(k_scan_offs, dim3(vwin), dim3(1024), 0, stream, (const uint32_t *)ws.cnts, (uint32_t)n, p.c, ws.offsets, ws.win_tot);
@@ -961,10 +969,11 @@ void build_g1_table(int curve, const uint32_t *d_bases, size_t n, int c, int nwi
 
 template <class C>
 static int msm_g1_impl(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy,
-                       size_t batch, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0, const uint32_t *d_base_idx = nullptr) {
+                       size_t batch, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0, const uint32_t *d_base_idx = nullptr,
+                       int scalars_mont = 0) {
   using HG = HostG1<C>;
   constexpr size_t OUT = 8 * C::Fq::N;                    // bytes of one affine result
-  int nbits = n ? msm_device<G1Curve<C>>(d_bases, d_scalars, n, C::Fr::BITS, ws, stream, batch, table_c, table_stride, scalar_stride, d_base_idx) : 0;
+  int nbits = n ? msm_device<G1Curve<C>>(d_bases, d_scalars, n, C::Fr::BITS, ws, stream, batch, table_c, table_stride, scalar_stride, d_base_idx, false, scalars_mont) : 0;
   std::vector<typename HG::Pt> res(batch);
   for (size_t b = 0; b < batch; b++) {
     typename HG::Pt acc = HG::identity();
@@ -1136,9 +1145,10 @@ int msm_g1_device(int curve, const uint32_t *d_bases, const uint32_t *d_scalars,
   return -1;
 }
 int msm_g1_fixed_device(int curve, const uint32_t *d_table, int table_c, size_t table_stride, const uint32_t *d_scalars, size_t n,
-                        size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch, const uint32_t *d_base_idx) {
-  if (curve == 0) return msm_g1_impl<G1Bls12381>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride, scalar_stride, d_base_idx);
-  if (curve == 1) return msm_g1_impl<G1Bn254>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride, scalar_stride, d_base_idx);
+                        size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch, const uint32_t *d_base_idx,
+                        int scalars_mont) {
+  if (curve == 0) return msm_g1_impl<G1Bls12381>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride, scalar_stride, d_base_idx, scalars_mont);
+  if (curve == 1) return msm_g1_impl<G1Bn254>(d_table, d_scalars, n, ws, stream, out_xy, batch, table_c, table_stride, scalar_stride, d_base_idx, scalars_mont);
   return -1;
 }
 
