@@ -769,6 +769,8 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
     uint32_t wps = 1;                                      // waves per bucket set when the launch has few sets
     // (a wave per set does the least work per bucket -- 2.5 adds against 4.4 with four waves -- and measured faster as
     // soon as a few hundred sets are in flight; the workgroup form is for the handful of sets of a single proof)
+    // (round 3 re-check with 512-set launches, which fill only half the SIMDs with one wave per set: two waves per set 12.4 k proofs/s,
+    // four 11.9 k against 12.6-12.7 k -- with several contexts in flight the idle SIMDs are not idle, total work decides)
     const uint32_t wps_max = batch <= 64 ? 4 : 1;
     while (wps < wps_max && (uint32_t)p.nb >= 64 * wps * 2) wps *= 2;
     if (wps > 1) {
