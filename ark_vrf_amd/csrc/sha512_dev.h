@@ -113,7 +113,10 @@ AVRF_DI void sha512_init(Sha512 &s) {
   s.fill = 0; s.total = 0;
 }
 
-// OR a byte into block position `pos` (0..127) without dynamic register indexing
+// OR a byte into block position `pos` (0..127) without dynamic register indexing.  (The select chains are two thirds of
+// k_thin_prepare's instruction stream; the alternative -- the block as a dynamically indexed byte array in the lane's private
+// memory, one store per absorbed word -- drops the kernel to 111 VGPRs and measured SLOWER: 141 us against 102 us per 65 536
+// items, tools/r3_run18.sh: the block is re-read, byte-swapped and cleared through scratch at every compression.)
 AVRF_DI void sha512_put(Sha512 &s, uint32_t pos, uint8_t b) {
   uint32_t wi = pos >> 3;
   uint64_t v = (uint64_t)b << (56 - 8 * (pos & 7));
