@@ -237,9 +237,15 @@ k_plan(const uint32_t *__restrict__ win_tot, uint32_t vwin, uint32_t lanes_targe
 __global__ void __launch_bounds__(256)
 k_scatter(const uint16_t *__restrict__ keys, uint32_t n, uint32_t tile_len, int c, const uint32_t *__restrict__ H,
           const uint32_t *__restrict__ offs, uint32_t *__restrict__ sorted, uint32_t remap_n, uint32_t remap_stride,
-          const uint32_t *__restrict__ bidx) {
+          const uint32_t *__restrict__ bidx, uint32_t ntiles, uint32_t vwin) {
   extern __shared__ uint32_t lds[];
-  const uint32_t nb = 1u << (c - 1), tile = blockIdx.x, w = blockIdx.y, ntiles = gridDim.x;
+  // XCD-aware placement: workgroups go round-robin over the 8 XCDs by linear id, and every XCD has its own L2.  All tiles of a
+  // window run on ONE XCD (window w on XCD w mod 8), so the 4-byte scattered stores into that window's region of sorted[]
+  // meet in one L2 and leave it as whole lines (with tiles of a window spread over all XCDs every L2 evicted partial lines:
+  // 142 MB written for 21 MB of indices, rounds 1-2).
+  const uint32_t nb = 1u << (c - 1);
+  const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3, tile = k % ntiles, w = xcd + 8u * (k / ntiles);
+  if (w >= vwin) return;
   const uint32_t *Hin = H + ((size_t)w * ntiles + tile) * nb;
   for (uint32_t b = threadIdx.x; b < nb; b += blockDim.x) lds[b] = offs[(size_t)w * nb + b] + Hin[b];
   __syncthreads();
@@ -730,8 +736,8 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   hipLaunchKernelGGL(k_scan_offs, dim3(vwin), dim3(1024), 0, stream, (const uint32_t *)ws.cnts, (uint32_t)n, p.c, ws.offsets, ws.win_tot);
   hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint32_t *)ws.win_tot, vwin, (uint32_t)lanes_target, (uint32_t)msm_env().per_min,
                      ws.lane_base, ws.plan_dev);
-  hipLaunchKernelGGL(k_scatter, dim3(ntiles, vwin), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist, ws.offsets, ws.sorted,
-                     remap_n, remap_stride, d_base_idx);
+  hipLaunchKernelGGL(k_scatter, dim3(8u * ((vwin + 7u) / 8u) * ntiles), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist, ws.offsets, ws.sorted,
+                     remap_n, remap_stride, d_base_idx, ntiles, vwin);
   if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
   if (CV::ZERO_IS_IDENTITY) HIP_CHECK(hipMemsetAsync(ws.buckets, 0, (size_t)nbk * acc_bytes, stream));   // empty buckets
   HIP_CHECK(hipEventRecord(ws.ev0, stream));
