@@ -592,6 +592,8 @@ MsmPlan msm_plan(size_t n, int scalar_bits) {
   return p;
 }
 
+// (sort tile: 2048 / 4096 / 8192 keys per workgroup measured the same headline, single-context MSM time and ring rate; 4096 moves
+// 65 MB instead of 90 in k_scatter but doubles the histogram table)
 static uint32_t tile_len_for(size_t n) { return 8192; }
 
 // lanes one residency round of k_accumulate<CV> holds on the current device (CUs x resident workgroups x 256), and the
