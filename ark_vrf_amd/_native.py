@@ -281,3 +281,106 @@ class Context:
         if st != OK:
             raise AvrfError(f"avrf_points_compress -> {st}")
         return bytes(out)[: self.point_len * n]
+
+
+class PinnedBatch:
+    """A Batch whose buffers live in page-locked host memory (avrf_host_alloc): staging copies from it are DMA transfers."""
+
+    def __init__(self, n, ios_xy, io_counts, ads, ad_lens, pks_xy=None, proofs=None):
+        self.n = n
+        self._ptrs = []
+        self.ios_xy = self._pin(bytes(ios_xy))
+        self.io_counts = self._pin(bytes(_u32(io_counts)))
+        self.ads = self._pin(bytes(ads))
+        self.ad_lens = self._pin(bytes(_u32(ad_lens)))
+        self.pks_xy = self._pin(bytes(pks_xy)) if pks_xy is not None else None
+        self.proofs = self._pin(bytes(proofs)) if proofs is not None else None
+
+    def _pin(self, data):
+        p = C.c_void_p()
+        st = lib().avrf_host_alloc(C.c_size_t(max(1, len(data))), C.byref(p))
+        if st != OK or not p:
+            raise AvrfError(f"avrf_host_alloc -> {st}")
+        C.memmove(p, data, len(data))
+        self._ptrs.append(p)
+        return p
+
+    def close(self):
+        for p in self._ptrs:
+            lib().avrf_host_free(p)
+        self._ptrs = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pool:
+    """avrf_pool: many BatchVerifier::verify jobs in flight on one device (include/avrf.h).  kind 1 thin, 2 pedersen."""
+
+    def __init__(self, suite=BANDERSNATCH_SHA512_ELL2, device=0, kind=1, slots=8, lanes=4, threads=2, hash_group=1, depth=0):
+        self._h = C.c_void_p()
+        st = lib().avrf_pool_create(int(suite), int(device), int(kind), int(slots), int(lanes), int(depth), int(threads), int(hash_group), C.byref(self._h))
+        if st != OK:
+            raise AvrfError(f"avrf_pool_create -> {st}")
+        self.kind = kind
+        self._keep = {}                                         # ticket -> batch object (its buffers must outlive the run)
+
+    def close(self):
+        if self._h:
+            lib().avrf_pool_destroy(self._h)
+            self._h = C.c_void_p()
+            self._keep = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_validation(self, level):
+        return lib().avrf_pool_set_validation(self._h, int(level))
+
+    def submit(self, b):
+        """b: Batch or PinnedBatch.  Returns the ticket."""
+        t = C.c_uint64(0)
+        st = lib().avrf_pool_submit(self._h, C.c_size_t(b.n), b.pks_xy, b.ios_xy, b.io_counts, b.ads, b.ad_lens, b.proofs, C.byref(t))
+        if st != OK:
+            raise AvrfError(f"avrf_pool_submit -> {st}")
+        self._keep[t.value] = b
+        return t.value
+
+    def wait(self, ticket):
+        s = C.c_int(0)
+        st = lib().avrf_pool_wait(self._h, C.c_uint64(ticket), C.byref(s))
+        if st != OK:
+            raise AvrfError(f"avrf_pool_wait -> {st}")
+        return s.value
+
+    def resubmit(self, ticket, from_host=False):
+        t = C.c_uint64(0)
+        st = lib().avrf_pool_resubmit(self._h, C.c_uint64(ticket), 1 if from_host else 0, C.byref(t))
+        if st != OK:
+            raise AvrfError(f"avrf_pool_resubmit -> {st}")
+        self._keep[t.value] = self._keep.pop(ticket, None)
+        return t.value
+
+    def cycle(self, steps_block, min_seconds=0.0, from_host=False, max_steps=0, expect=0):
+        """-> (runs made, runs with another status than `expect`, seconds from first launch to last verdict)"""
+        done, bad, sec = C.c_uint64(0), C.c_uint64(0), C.c_double(0)
+        st = lib().avrf_pool_cycle(self._h, 1 if from_host else 0, C.c_uint64(steps_block), C.c_double(min_seconds), C.c_uint64(max_steps),
+                                   int(expect), C.byref(done), C.byref(bad), C.byref(sec))
+        if st != OK:
+            raise AvrfError(f"avrf_pool_cycle -> {st}")
+        return done.value, bad.value, sec.value
+
+    def stats(self, reset=False):
+        out = (C.c_double * 16)()
+        st = lib().avrf_pool_stats(self._h, 1 if reset else 0, out, C.c_size_t(16))
+        if st != OK:
+            raise AvrfError(f"avrf_pool_stats -> {st}")
+        k = ["cpu_us_begin", "cpu_us_collect", "cpu_us_hash", "cpu_us_launch", "cpu_us_end", "cpu_us_total", "hash_groups", "hashed", "sleeps",
+             "accumulate_ms_total", "accumulate_launches"]
+        return {k[i]: out[i] for i in range(len(k))}

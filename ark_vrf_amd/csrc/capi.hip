@@ -4,7 +4,7 @@
 // (src/thin.rs:188-326 BatchVerifier; src/pedersen.rs:303-426).  All group/field work is
 // launched on the context's HIP stream; the host only (1) runs the sequential weight
 // transcript (host_sha512.h), (2) finishes the MSM's O(256)-step window Horner (host_te.h).
-#include "../../include/avrf.h"
+#include "capi_internal.h"
 #include "host_sha512.h"
 #include "host_shake128.h"
 #include "host_sha256.h"
@@ -13,90 +13,27 @@
 #include <deque>
 #include <mutex>
 #include <thread>
-#include "host_te.h"
-#include "msm.h"
 #include "proto_dev.h"
 #include "vrf_batch.h"
 #include "suite_dispatch.h"
 #include <chrono>
-#include <new>
-#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include <vector>
 
 using namespace avrf;
 
-#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "avrf: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return AVRF_ERR_NO_DEVICE; } } while (0)
-
-namespace {
-
-struct DevBuf {
-  void *p = nullptr; size_t cap = 0;
-  hipError_t ensure(size_t bytes) {
-    if (bytes <= cap && p) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr; cap = 0;
-    size_t want = bytes + bytes / 8 + 256;
-    hipError_t e = hipMalloc(&p, want);
-    if (e == hipSuccess) cap = want;
-    return e;
-  }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  template <class T> T *as() const { return (T *)p; }
-};
-struct PinBuf {
-  void *p = nullptr; size_t cap = 0;
-  hipError_t ensure(size_t bytes) {
-    if (bytes <= cap && p) return hipSuccess;
-    if (p) (void)hipHostFree(p);
-    p = nullptr; cap = 0;
-    hipError_t e = hipHostMalloc(&p, bytes + 256);
-    if (e == hipSuccess) cap = bytes + 256;
-    return e;
-  }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-  template <class T> T *as() const { return (T *)p; }
-};
-
-template <class F> int guarded(F f) {
-  try { return f(); }
-  catch (const avrf::HipFailure &e) { fprintf(stderr, "avrf: HIP error %s at %s:%d\n", hipGetErrorString(e.err), e.file, e.line); return AVRF_ERR_NO_DEVICE; }
-  catch (const std::bad_alloc &) { return AVRF_ERR_NO_DEVICE; }
-}
-
+namespace avrf {
 double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+}  // namespace avrf
 
-}  // namespace
-
-struct avrf_ctx {
-  int suite = 0, device = 0;
-  hipStream_t stream = nullptr;
-  MsmWorkspace ws;
-  // staged batch
-  int validate = 0;               // avrf_ctx_set_validation: 0 unchecked (typed-point callers), 1 on-curve, 2 + subgroup
-  uint64_t stage_gen = 0, chal_gen = 0;   // challenges of *_batch_challenges belong to staging generation chal_gen
-  int staged_kind = 0;            // 0 none, 1 thin, 2 pedersen
-  size_t n = 0, tot_io = 0, n_terms = 0;
-  DevBuf d_pks, d_ios, d_io_off, d_ads, d_ad_off, d_proofs, d_sks;
-  std::vector<uint8_t> h_resp;    // host copy of the response scalars (s [, sb]) for the weight transcript
-  DevBuf d_rec; PinBuf h_msg;     // counter-mode transcripts: the records written by the prepare kernel, and prefix || records on the host
-  std::vector<uint8_t> h_weights; DevBuf d_weights;   // sponge transcripts: the squeezed weight stream of the staged batch
-  DevBuf d_c, d_z, d_flags, d_scalars, d_pre, d_gpart, d_misc, d_out, d_status;
-  DevBuf d_tabs;                               // per-item window tables of the independent prove / verify kernels
-  DevBuf d_fixed; bool fixed_ready = false;   // fixed-base tables of G and BLINDING_BASE (provers, scalar_mul_base), built on first use
-  PinBuf h_c, h_flags, h_io;
-  double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int run_phase = 0;              // batch_begin / batch_hash / batch_end
-  double run_t0 = 0, run_begin_us = 0, run_msm_us = 0;
-};
+// A run opened by avrf_batch_run_begin owns the context's stream, staged buffers and MSM workspace until avrf_batch_run_end
+// (or an error) closes it: every other entry point that touches them refuses with AVRF_ERR_BAD_ARG meanwhile (include/avrf.h).
+static inline bool ctx_busy(const avrf_ctx *c) { return c->run_phase != 0; }
 
 // fixed-base tables for the provers: built once per context, on the context's stream
 static int ensure_fixed(avrf_ctx *c) {
-  // window tables of the staged items (proto_dev.h te_smul_ws): ITEM_TAB_SLOTS x 128 bytes each, 5 KB per item, kept by the context
-  if (c->n && c->d_tabs.ensure(c->n * (size_t)ITEM_TAB_SLOTS * sizeof(te_ext_raw)) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   if (c->fixed_ready) return AVRF_OK;
   if (c->d_fixed.ensure((size_t)2 * 32 * 256 * sizeof(te_pre_raw)) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   launch_fixed_table(c->suite, c->d_fixed.as<te_pre_raw>(), c->stream);
@@ -110,9 +47,27 @@ static BatchDev batch_of(avrf_ctx *c) {
   b.ads = c->d_ads.as<uint8_t>(); b.ad_off = c->d_ad_off.as<uint32_t>(); b.proofs = c->d_proofs.as<uint8_t>();
   b.sks = c->d_sks.as<uint8_t>(); b.n = (uint32_t)c->n;
   b.fixed = (const te_pre *)c->d_fixed.p;
-  b.tabs = (te_ext *)c->d_tabs.p;                  // per-item window tables (sized by ensure_fixed for the staged batch)
+  b.tabs = (te_ext *)c->d_tabs.p; b.first = 0;     // per-item window tables (sized by per_item_chunks)
   b.weights = nullptr; b.records = nullptr;
   return b;
+}
+
+// The independent per-item kernels (vrf_single.hip) keep ITEM_TAB_SLOTS window-table entries of 128 bytes per item (5 KB) in
+// the context's workspace.  A call of any size walks its items in chunks of at most ITEM_CHUNK (two residency rounds of the
+// chip: 65 536 lanes at one wave per SIMD), launched back to back on the context's stream, so the workspace is bounded by
+// ITEM_CHUNK x 5 KB = 671 MB whatever n is; `launch` receives the BatchDev of one chunk (first .. n).
+static constexpr size_t ITEM_CHUNK = 131072;
+template <class F> static int per_item_chunks(avrf_ctx *c, bool with_pks, F launch) {
+  if (int fs = ensure_fixed(c)) return fs;
+  const size_t chunk = c->n < ITEM_CHUNK ? c->n : ITEM_CHUNK;
+  if (c->d_tabs.ensure(chunk * (size_t)ITEM_TAB_SLOTS * sizeof(te_ext_raw)) != hipSuccess) return AVRF_ERR_NO_DEVICE;
+  BatchDev b = batch_of(c);
+  if (!with_pks) b.pks_xy = nullptr;
+  for (size_t i = 0; i < c->n; i += chunk) {
+    b.first = (uint32_t)i; b.n = (uint32_t)(c->n - i < chunk ? c->n : i + chunk);
+    launch(b);
+  }
+  return AVRF_OK;
 }
 
 // Validate::Yes over every point of the staged batch (pk, I/O pairs, proof points) when the context asks for it;
@@ -137,6 +92,25 @@ static void validate_staged(avrf_ctx *c, int kind, int32_t *d_rec_status) {
   }
 }
 
+namespace avrf {
+int ctx_create(int suite, int device, bool lane_owner, avrf_ctx **out) {
+  if (!out || suite < 0 || suite >= AVRF_N_SUITES) return AVRF_ERR_BAD_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return AVRF_ERR_NO_DEVICE;
+  HIP_TRY(hipSetDevice(device));
+  avrf_ctx *c = new avrf_ctx();
+  c->suite = suite; c->device = device; c->lane_owner = lane_owner;
+  if (lane_owner) {
+    if (hipStreamCreateWithFlags(&c->own.stream, hipStreamNonBlocking) != hipSuccess) { delete c; return AVRF_ERR_NO_DEVICE; }
+    c->stream = c->own.stream;
+  }
+  if (c->d_flags.ensure(64) != hipSuccess || c->h_flags.ensure(64) != hipSuccess) { avrf_ctx_destroy(c); return AVRF_ERR_NO_DEVICE; }
+  *out = c;
+  return AVRF_OK;
+}
+}  // namespace avrf
+
 extern "C" {
 
 int avrf_ctx_set_validation(avrf_ctx *c, int level) {
@@ -149,6 +123,7 @@ int avrf_ctx_set_validation(avrf_ctx *c, int level) {
 hipStream_t avrf_ctx_stream_(avrf_ctx *c) { return c->stream; }
 int avrf_ctx_suite_(avrf_ctx *c) { return c->suite; }
 int avrf_ctx_device_(avrf_ctx *c) { return c->device; }
+int avrf_ctx_busy_(avrf_ctx *c) { return c && ctx_busy(c); }
 
 const char *avrf_version(void) { return "avrf 0.3 (gfx950; tiny/thin/pedersen/ring VRF over Bandersnatch, Baby-JubJub, JubJub; device pairing)"; }
 
@@ -167,30 +142,17 @@ int avrf_device_set_blocking_sync(int device, int on) {
   return e == hipSuccess ? AVRF_OK : AVRF_ERR_NO_DEVICE;
 }
 
-int avrf_ctx_create(int suite, int device, avrf_ctx **out) {
-  if (!out || suite < 0 || suite >= AVRF_N_SUITES) return AVRF_ERR_BAD_ARG;
-  *out = nullptr;
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return AVRF_ERR_NO_DEVICE;
-  HIP_TRY(hipSetDevice(device));
-  avrf_ctx *c = new avrf_ctx();
-  c->suite = suite; c->device = device;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return AVRF_ERR_NO_DEVICE; }
-  if (c->d_flags.ensure(64) != hipSuccess || c->h_flags.ensure(64) != hipSuccess) { avrf_ctx_destroy(c); return AVRF_ERR_NO_DEVICE; }
-  *out = c;
-  return AVRF_OK;
-}
+int avrf_ctx_create(int suite, int device, avrf_ctx **out) { return ctx_create(suite, device, true, out); }
 
 void avrf_ctx_destroy(avrf_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
-  c->ws.release();
+  if (c->lane_owner) (void)hipStreamSynchronize(c->own.stream);
   DevBuf *bufs[] = {&c->d_pks, &c->d_ios, &c->d_io_off, &c->d_ads, &c->d_ad_off, &c->d_proofs, &c->d_sks, &c->d_c, &c->d_z,
-                    &c->d_flags, &c->d_scalars, &c->d_pre, &c->d_gpart, &c->d_misc, &c->d_out, &c->d_status, &c->d_fixed, &c->d_weights, &c->d_rec, &c->d_tabs};
+                    &c->d_flags, &c->d_misc, &c->d_out, &c->d_status, &c->d_fixed, &c->d_weights, &c->d_rec, &c->d_tabs};
   for (DevBuf *b : bufs) b->release();
   c->h_c.release(); c->h_flags.release(); c->h_io.release(); c->h_msg.release();
-  (void)hipStreamDestroy(c->stream);
+  c->own.release();                                                    // stream + workspace (nothing for a pool slot)
   delete c;
 }
 
@@ -208,19 +170,20 @@ static bool scalar_in_range(int suite, const uint8_t *s) {
 
 int avrf_msm_te(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *scalars, uint8_t out_xy[64]) {
   if (!c || !out_xy || (n && (!bases_xy || !scalars))) return AVRF_ERR_BAD_ARG;
+  if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
   for (size_t i = 0; i < n; i++) if (!scalar_in_range(c->suite, scalars + 32 * i)) return AVRF_INVALID_DATA;
   HostExt r;
   if (n) {
-    HIP_TRY(c->d_misc.ensure(n * 64)); HIP_TRY(c->d_scalars.ensure(n * 32)); HIP_TRY(c->d_pre.ensure(n * sizeof(te_pre_raw)));
+    HIP_TRY(c->d_misc.ensure(n * 64)); HIP_TRY(c->L->d_scalars.ensure(n * 32)); HIP_TRY(c->L->d_pre.ensure(n * sizeof(te_pre_raw)));
     HIP_TRY(hipMemcpyAsync(c->d_misc.p, bases_xy, n * 64, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->L->d_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
-    launch_pre_from_affine(c->suite, c->d_misc.as<uint8_t>(), n, c->d_pre.as<te_pre_raw>(), c->d_flags.as<uint32_t>(), 0, c->stream);
+    launch_pre_from_affine(c->suite, c->d_misc.as<uint8_t>(), n, c->L->d_pre.as<te_pre_raw>(), c->d_flags.as<uint32_t>(), 0, c->stream);
     HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
   }
   c->staged_kind = 0;
-  if (int e = guarded([&] { return msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), n, c->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  if (int e = guarded([&] { return msm_te_device(c->suite, c->L->d_pre.as<te_pre_raw>(), c->L->d_scalars.as<uint32_t>(), n, c->L->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
   if (n && *c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;
   return finish_point(c, r, out_xy);
 }
@@ -232,19 +195,20 @@ int avrf_msm_te(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *s
 // multiplication each) and takes the bases as they are.
 int avrf_msm_te_mont(avrf_ctx *c, size_t n, const uint8_t *bases_mont_xy, const uint8_t *scalars_mont, uint8_t out_mont_xy[64]) {
   if (!c || !out_mont_xy || (n && (!bases_mont_xy || !scalars_mont))) return AVRF_ERR_BAD_ARG;
+  if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
   HostExt r;
   if (n) {
-    HIP_TRY(c->d_misc.ensure(n * 64)); HIP_TRY(c->d_scalars.ensure(n * 32)); HIP_TRY(c->d_pre.ensure(n * sizeof(te_pre_raw)));
+    HIP_TRY(c->d_misc.ensure(n * 64)); HIP_TRY(c->L->d_scalars.ensure(n * 32)); HIP_TRY(c->L->d_pre.ensure(n * sizeof(te_pre_raw)));
     HIP_TRY(hipMemcpyAsync(c->d_misc.p, bases_mont_xy, n * 64, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_scalars.p, scalars_mont, n * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->L->d_scalars.p, scalars_mont, n * 32, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
-    launch_pre_from_affine(c->suite, c->d_misc.as<uint8_t>(), n, c->d_pre.as<te_pre_raw>(), c->d_flags.as<uint32_t>(), 0, c->stream, 1);
-    launch_scalars_from_mont(c->suite, c->d_scalars.as<uint32_t>(), n, c->d_flags.as<uint32_t>(), c->stream);
+    launch_pre_from_affine(c->suite, c->d_misc.as<uint8_t>(), n, c->L->d_pre.as<te_pre_raw>(), c->d_flags.as<uint32_t>(), 0, c->stream, 1);
+    launch_scalars_from_mont(c->suite, c->L->d_scalars.as<uint32_t>(), n, c->d_flags.as<uint32_t>(), c->stream);
     HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
   }
   c->staged_kind = 0;
-  if (int e = guarded([&] { return msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), n, c->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  if (int e = guarded([&] { return msm_te_device(c->suite, c->L->d_pre.as<te_pre_raw>(), c->L->d_scalars.as<uint32_t>(), n, c->L->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
   if (n && *c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;
   uint8_t canon[64];
   finish_point(c, r, canon);
@@ -257,6 +221,7 @@ int avrf_msm_te_mont(avrf_ctx *c, size_t n, const uint8_t *bases_mont_xy, const 
 // (48+48 bytes BLS12-381, 32+32 bytes BN254; all-zero = infinity), scalars LE32 < r.
 int avrf_g1_msm(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *scalars, uint8_t *out_xy) {
   if (!c || !out_xy || (n && (!bases_xy || !scalars))) return AVRF_ERR_BAD_ARG;
+  if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
   const int curve = pairing_curve_of(c->suite);
   const size_t fqb = curve == 0 ? 48 : 32;
@@ -267,14 +232,14 @@ int avrf_g1_msm(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *s
   }
   c->staged_kind = 0;
   if (n) {
-    HIP_TRY(c->d_misc.ensure(n * 2 * fqb)); HIP_TRY(c->d_scalars.ensure(n * 32)); HIP_TRY(c->d_pre.ensure(n * 2 * fqb));
+    HIP_TRY(c->d_misc.ensure(n * 2 * fqb)); HIP_TRY(c->L->d_scalars.ensure(n * 32)); HIP_TRY(c->L->d_pre.ensure(n * 2 * fqb));
     HIP_TRY(hipMemcpyAsync(c->d_misc.p, bases_xy, n * 2 * fqb, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->L->d_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
-    launch_g1_bases(curve, c->d_misc.as<uint8_t>(), n, c->d_pre.as<uint32_t>(), c->d_flags.as<uint32_t>(), c->stream);
+    launch_g1_bases(curve, c->d_misc.as<uint8_t>(), n, c->L->d_pre.as<uint32_t>(), c->d_flags.as<uint32_t>(), c->stream);
     HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
   }
-  if (int e = guarded([&] { return msm_g1_device(curve, c->d_pre.as<uint32_t>(), c->d_scalars.as<uint32_t>(), n, c->ws, c->stream, out_xy) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  if (int e = guarded([&] { return msm_g1_device(curve, c->L->d_pre.as<uint32_t>(), c->L->d_scalars.as<uint32_t>(), n, c->L->ws, c->stream, out_xy) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
   if (n && *c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;
   return AVRF_OK;
 }
@@ -282,8 +247,13 @@ int avrf_g1_msm(avrf_ctx *c, size_t n, const uint8_t *bases_xy, const uint8_t *s
 // ---------------------------------------------------------------- staging
 
 // kind: 1 thin (pks + 96-byte proofs), 2 pedersen (256-byte proofs); proofs/pks/sks may be NULL for provers
-static int stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy,
-                 const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
+// wait = false (pool.hip): the copies are left in flight on c->stream -- from buffers of avrf_host_alloc they are DMA transfers
+// that cost no host time; the caller's buffers must stay untouched until the batch's verdict is out
+}  // extern "C"
+namespace avrf {
+static bool suite_host_weights(int suite) { return with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return (bool)S::HOST_WEIGHTS; }); }
+int ctx_stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy,
+              const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, bool wait) {
   if (!c || c->run_phase) return AVRF_ERR_BAD_ARG;              // (a run in flight owns the staged buffers)
   if (n && (!io_counts || !ad_lens)) return AVRF_ERR_BAD_ARG;
   if (n > 0x0fffffffULL) return AVRF_ERR_BAD_ARG;
@@ -310,18 +280,25 @@ static int stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint
   if (proofs) {
     HIP_TRY(c->d_proofs.ensure(n * psz)); HIP_TRY(hipMemcpyAsync(c->d_proofs.p, proofs, n * psz, hipMemcpyHostToDevice, c->stream));
     if (kind == 3) { HIP_TRY(hipStreamSynchronize(c->stream)); c->staged_kind = kind; return AVRF_OK; }   // Tiny: no batch verifier
-    const size_t rsz = kind == 1 ? 32 : 64, roff = kind == 1 ? 64 : 192;
-    c->h_resp.resize(n * rsz);
-    for (size_t j = 0; j < n; j++) memcpy(&c->h_resp[rsz * j], proofs + psz * j + roff, rsz);
+    if (suite_host_weights(c->suite)) {       // a sponge transcript absorbs the responses on the host; counter-mode ones hash the device's records
+      const size_t rsz = kind == 1 ? 32 : 64, roff = kind == 1 ? 64 : 192;
+      c->h_resp.resize(n * rsz);
+      for (size_t j = 0; j < n; j++) memcpy(&c->h_resp[rsz * j], proofs + psz * j + roff, rsz);
+    }
     c->n_terms = kind == 1 ? 2 * n + 2 * c->tot_io + 1 : 5 * n + 2;
     HIP_TRY(c->d_c.ensure(n * 16)); HIP_TRY(c->h_c.ensure(n * 16));
     HIP_TRY(c->d_z.ensure(kind == 1 ? c->tot_io * 16 + 16 : n * 128));
-    HIP_TRY(c->d_scalars.ensure(c->n_terms * 32)); HIP_TRY(c->d_pre.ensure(c->n_terms * sizeof(te_pre_raw)));
-    HIP_TRY(c->d_gpart.ensure(((n + 127) / 128) * 64 + 64));
+    if (c->lane_owner) { HIP_TRY(c->L->d_scalars.ensure(c->n_terms * 32)); HIP_TRY(c->L->d_pre.ensure(c->n_terms * sizeof(te_pre_raw))); HIP_TRY(c->L->d_gpart.ensure(((n + 127) / 128) * 64 + 64)); }
   }
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (wait) HIP_TRY(hipStreamSynchronize(c->stream));
   c->staged_kind = kind;
   return AVRF_OK;
+}
+}  // namespace avrf
+extern "C" {
+static int stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy,
+                 const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
+  return ctx_stage(c, kind, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs, true);
 }
 
 int avrf_thin_batch_stage(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
@@ -400,8 +377,20 @@ class WeightHashService {
 // shared tail of both batch verifiers in three phases (run_phase): 1 = validation + prepare kernel + copies back enqueued,
 // 2 = weight transcript hashed on the host and terms + MSM enqueued, 0 = idle.  batch_run walks all three; the
 // avrf_batch_run_begin / _hash / _end entry points let one host thread keep several contexts in flight (hash one context's
-// transcript while the others' kernels run) instead of parking a thread per context.
-static int batch_begin(avrf_ctx *c, int kind) {
+// transcript while the others' kernels run) instead of parking a thread per context; the pool's workers (pool.hip) call the
+// pieces themselves (batch_collect / batch_seed / batch_launch) and hash several contexts' transcripts together.
+}  // extern "C"
+namespace avrf {
+static int host_stream_kind(int suite) { return with_suite(suite, [&](auto tag_) { using S = typename decltype(tag_)::type; return S::XOF_SHAKE ? 1 : S::TR_SHA256 ? 2 : 0; }); }
+static size_t batch_prefix(int suite, uint8_t prefix[64]) {
+  size_t pl = 0;
+  with_suite(suite, [&](auto tag_) { using S = typename decltype(tag_)::type; memcpy(prefix, S::SUITE_ID, S::SUITE_ID_LEN); pl = S::SUITE_ID_LEN; });
+  prefix[pl++] = DS_BATCH_VERIFY;
+  return pl;
+}
+bool batch_host_weights(const avrf_ctx *c) { return host_stream_kind(c->suite) != 0; }
+
+int batch_begin(avrf_ctx *c, int kind) {
   if (!c || c->staged_kind != kind || c->run_phase != 0) return AVRF_ERR_BAD_ARG;
   if (c->n == 0) { c->run_phase = 1; return AVRF_OK; }                 // src/thin.rs:262-264, src/pedersen.rs:343-345
   if (!c->n_terms) return AVRF_ERR_BAD_ARG;
@@ -411,12 +400,10 @@ static int batch_begin(avrf_ctx *c, int kind) {
   BatchDev b = batch_of(c);
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
   validate_staged(c, kind, nullptr);
-  const int host_stream = with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; return S::XOF_SHAKE ? 1 : S::TR_SHA256 ? 2 : 0; });
+  const int host_stream = host_stream_kind(c->suite);
   // the weight transcript's message, prefix || records: the prepare kernel writes the records, one copy brings them back
   const size_t recsz = kind == 1 ? 64 : 96;
-  uint8_t prefix[64]; size_t pl = 0;
-  with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; memcpy(prefix, S::SUITE_ID, S::SUITE_ID_LEN); pl = S::SUITE_ID_LEN; });
-  prefix[pl++] = DS_BATCH_VERIFY;
+  uint8_t prefix[64]; const size_t pl = batch_prefix(c->suite, prefix);
   if (!host_stream) {
     HIP_TRY(c->d_rec.ensure(n * recsz)); HIP_TRY(c->h_msg.ensure(pl + n * recsz));
     b.records = c->d_rec.as<uint8_t>();
@@ -426,6 +413,7 @@ static int batch_begin(avrf_ctx *c, int kind) {
   if (!host_stream) {
     memcpy(c->h_msg.p, prefix, pl);
     HIP_TRY(hipMemcpyAsync(c->h_msg.as<uint8_t>() + pl, c->d_rec.p, n * recsz, hipMemcpyDeviceToHost, c->stream));
+    c->h_msg_len = pl + n * recsz;
   } else HIP_TRY(hipMemcpyAsync(c->h_c.p, c->d_c.p, n * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipMemcpyAsync(c->h_flags.p, c->d_flags.p, 4, hipMemcpyDeviceToHost, c->stream));
   c->run_begin_us = now_us() - c->run_t0;
@@ -433,36 +421,29 @@ static int batch_begin(avrf_ctx *c, int kind) {
   return AVRF_OK;
 }
 
-static int batch_hash(avrf_ctx *c, int kind) {
+// the prepare kernel and the copies back have completed (the caller waited for c->stream or for an event behind them)
+int batch_collect(avrf_ctx *c, int kind) {
   if (!c || c->staged_kind != kind || c->run_phase != 1) return AVRF_ERR_BAD_ARG;
-  if (c->n == 0) { c->run_phase = 2; return AVRF_OK; }
-  c->run_phase = 0;                                                    // an error below leaves the context idle
-  HIP_TRY(hipSetDevice(c->device));
-  const double tw = now_us();
+  if (c->n && *c->h_flags.as<uint32_t>()) { c->run_phase = 0; return AVRF_INVALID_DATA; }   // src/thin.rs:266-271, src/pedersen.rs:348-353
+  return AVRF_OK;
+}
+
+// weight transcript (src/thin.rs:274-279, src/pedersen.rs:361-367):
+//   new(SUITE_ID); absorb [0x50]; per item absorb LE32(c) || LE32(s) [|| LE32(sb)]
+// counter-mode transcripts: SHA-512 of prefix || records -> digest.  Sponge / SHA-256 transcripts (Shake128Transcript: the
+// weights are the sponge's OUTPUT STREAM, 16 bytes per item, 32 for Pedersen -- sequential, so the host squeezes it and the
+// terms kernel reads it from HBM instead of deriving block j / 4 from a seed; HashTranscript<Sha256> of the test suite takes
+// the same route): the stream goes to c->h_weights and the digest is not used.
+int batch_seed(avrf_ctx *c, int kind, uint8_t digest[64]) {
   const size_t n = c->n;
-  BatchDev b = batch_of(c);
-  const int host_stream = with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; return S::XOF_SHAKE ? 1 : S::TR_SHA256 ? 2 : 0; });
-  const size_t recsz = kind == 1 ? 64 : 96;
-  uint8_t prefix[64]; size_t pl = 0;
-  with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; memcpy(prefix, S::SUITE_ID, S::SUITE_ID_LEN); pl = S::SUITE_ID_LEN; });
-  prefix[pl++] = DS_BATCH_VERIFY;
-  if (!host_stream) b.records = c->d_rec.as<uint8_t>();
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  double t1 = now_us();
-  if (*c->h_flags.as<uint32_t>()) return AVRF_INVALID_DATA;            // src/thin.rs:266-271, src/pedersen.rs:348-353
-  // weight transcript (src/thin.rs:274-279, src/pedersen.rs:361-367):
-  //   new(SUITE_ID); absorb [0x50]; per item absorb LE32(c) || LE32(s) [|| LE32(sb)]
-  Seed64 seed; memset(&seed, 0, sizeof seed);
-  const uint8_t tag = DS_BATCH_VERIFY;
-  const uint8_t *cs = c->h_c.as<uint8_t>();
-  const size_t rsz = kind == 1 ? 32 : 64;
-  uint8_t rec[96];
-  memset(rec, 0, sizeof rec);
+  memset(digest, 0, 64);
+  if (!n) return AVRF_OK;
+  const int host_stream = host_stream_kind(c->suite);
   if (host_stream) {
-    // Shake128Transcript: the weights are the sponge's OUTPUT STREAM (16 bytes per item, 32 for Pedersen) -- sequential, so the
-    // host squeezes it and the terms kernel reads it from HBM instead of deriving block j / 4 from a seed.  (HashTranscript<Sha256>
-    // of the test suite takes the same route: its counter-mode blocks are cheap to produce here.)
-    const size_t wsz = kind == 1 ? 16 : 32;
+    const uint8_t tag = DS_BATCH_VERIFY;
+    const uint8_t *cs = c->h_c.as<uint8_t>();
+    const size_t rsz = kind == 1 ? 32 : 64, wsz = kind == 1 ? 16 : 32;
+    uint8_t rec[96]; memset(rec, 0, sizeof rec);
     c->h_weights.resize(n * wsz);
     auto run = [&](auto &h) {
       with_suite(c->suite, [&](auto tag_) { using S = typename decltype(tag_)::type; h.update(S::SUITE_ID, S::SUITE_ID_LEN); });
@@ -471,48 +452,83 @@ static int batch_hash(avrf_ctx *c, int kind) {
       h.squeeze_copy(c->h_weights.data(), n * wsz);
     };
     if (host_stream == 1) { HostShake128 h; run(h); } else { HostSha256 h; run(h); }
+    return AVRF_OK;
+  }
+#ifdef AVRF_EXPERIMENTS   // timing experiment only (tools/gpu_only_rate.py): wrong weights, wrong verdict; never in the shipped build
+  static const bool skip_hash = getenv("AVRF_EXPERIMENT_SKIP_HASH") != nullptr;
+#else
+  constexpr bool skip_hash = false;
+#endif
+  WeightJob job; job.prefix = nullptr; job.prefix_len = 0; job.c16 = nullptr; job.resp = nullptr; job.n = n; job.rsz = 0;
+  job.msg = c->h_msg.as<uint8_t>(); job.msg_len = skip_hash ? c->h_msg_len - (n - 1) * (kind == 1 ? 64 : 96) : c->h_msg_len;
+  WeightHashService &svc = WeightHashService::get();
+  if (svc.enabled()) svc.run(job); else weight_digest_scalar(job);
+  memcpy(digest, job.digest, 64);
+  return AVRF_OK;
+}
+
+int batch_launch(avrf_ctx *c, int kind, const uint8_t digest[64]) {
+  if (!c || c->staged_kind != kind || c->run_phase != 1) return AVRF_ERR_BAD_ARG;
+  if (c->n == 0) { c->run_phase = 2; return AVRF_OK; }
+  c->run_phase = 0;                                                    // an error below leaves the context idle
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t n = c->n;
+  BatchDev b = batch_of(c);
+  if (!host_stream_kind(c->suite)) b.records = c->d_rec.as<uint8_t>();
+  else {
+    const size_t wsz = kind == 1 ? 16 : 32;
     HIP_TRY(c->d_weights.ensure(n * wsz));
     HIP_TRY(hipMemcpyAsync(c->d_weights.p, c->h_weights.data(), n * wsz, hipMemcpyHostToDevice, c->stream));
     b.weights = c->d_weights.as<uint8_t>();
-  } else {
-#ifdef AVRF_EXPERIMENTS   // timing experiment only (tools/gpu_only_rate.py): wrong weights, wrong verdict; never in the shipped build
-    static const bool skip_hash = getenv("AVRF_EXPERIMENT_SKIP_HASH") != nullptr;
-#else
-    constexpr bool skip_hash = false;
-#endif
-    WeightJob job; job.prefix = prefix; job.prefix_len = pl; job.c16 = cs; job.resp = c->h_resp.data(); job.n = n; job.rsz = rsz;
-    job.msg = c->h_msg.as<uint8_t>(); job.msg_len = skip_hash ? pl + recsz : pl + n * recsz;
-    WeightHashService &svc = WeightHashService::get();
-    if (svc.enabled()) svc.run(job); else weight_digest_scalar(job);
-    for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, job.digest + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
   }
-  double t2 = now_us();
-  if (kind == 1) launch_thin_terms(c->suite, b, seed, 0, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_scalars.as<uint32_t>(),
-                                   c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
-  else launch_ped_terms(c->suite, b, seed, 0, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_scalars.as<uint32_t>(),
-                        c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
-  double t3 = now_us();
-  if (int e = guarded([&] { return msm_te_enqueue(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
-  c->timing[1] = c->run_begin_us + (t1 - tw); c->timing[2] = t2 - t1; c->timing[3] = t3 - t2;
+  Seed64 seed;
+  for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, digest + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
+  HIP_TRY(c->L->d_scalars.ensure(c->n_terms * 32)); HIP_TRY(c->L->d_pre.ensure(c->n_terms * sizeof(te_pre_raw))); HIP_TRY(c->L->d_gpart.ensure(((n + 127) / 128) * 64 + 64));
+  const double t2 = now_us();
+  if (kind == 1) launch_thin_terms(c->suite, b, seed, 0, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->L->d_scalars.as<uint32_t>(),
+                                   c->L->d_pre.as<te_pre_raw>(), c->L->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
+  else launch_ped_terms(c->suite, b, seed, 0, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->L->d_scalars.as<uint32_t>(),
+                        c->L->d_pre.as<te_pre_raw>(), c->L->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
+  const double t3 = now_us();
+  if (int e = guarded([&] { return msm_te_enqueue(c->suite, c->L->d_pre.as<te_pre_raw>(), c->L->d_scalars.as<uint32_t>(), c->n_terms, c->L->ws, c->stream, c->pend) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  c->timing[3] = t3 - t2;
   c->run_msm_us = now_us() - t3;
   c->run_phase = 2;
   return AVRF_OK;
 }
 
-static int batch_end(avrf_ctx *c, int kind) {
+int batch_end(avrf_ctx *c, int kind) {
   if (!c || c->staged_kind != kind || c->run_phase != 2) return AVRF_ERR_BAD_ARG;
   c->run_phase = 0;
   if (c->n == 0) return AVRF_OK;
   HIP_TRY(hipSetDevice(c->device));
   const double t3 = now_us();
   HostExt r;
-  if (int e = guarded([&] { return msm_te_finish(c->suite, c->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  if (int e = guarded([&] { return msm_te_finish(c->suite, c->L->ws, c->stream, &r, c->pend) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
   double t4 = now_us();
   int st = point_is_identity(c, r) ? AVRF_OK : AVRF_VERIFICATION_FAILURE;   // src/thin.rs:319-322, src/pedersen.rs:420-423
   double t5 = now_us();
   c->timing[4] = c->run_msm_us + (t4 - t3); c->timing[5] = t5 - t4;
   c->timing[0] = c->timing[1] + c->timing[2] + c->timing[3] + c->timing[4] + c->timing[5];   // time spent IN the three calls
   return st;
+}
+}  // namespace avrf
+extern "C" {
+
+// the second of the three calls: wait for the prepare kernel, hash on the calling thread, enqueue terms + MSM
+static int batch_hash(avrf_ctx *c, int kind) {
+  if (!c || c->staged_kind != kind || c->run_phase != 1) return AVRF_ERR_BAD_ARG;
+  if (c->n == 0) { c->run_phase = 2; return AVRF_OK; }
+  HIP_TRY(hipSetDevice(c->device));
+  const double tw = now_us();
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { c->run_phase = 0; (void)hipGetLastError(); return AVRF_ERR_NO_DEVICE; }
+  const double t1 = now_us();
+  if (int e = batch_collect(c, kind)) return e;
+  uint8_t digest[64];
+  if (int e = batch_seed(c, kind, digest)) { c->run_phase = 0; return e; }
+  const double t2 = now_us();
+  c->timing[1] = c->run_begin_us + (t1 - tw); c->timing[2] = t2 - t1;
+  return batch_launch(c, kind, digest);
 }
 
 static int batch_run(avrf_ctx *c, int kind) {
@@ -523,9 +539,19 @@ static int batch_run(avrf_ctx *c, int kind) {
 
 int avrf_thin_batch_run(avrf_ctx *c) { return batch_run(c, 1); }
 int avrf_pedersen_batch_run(avrf_ctx *c) { return batch_run(c, 2); }
-int avrf_batch_run_begin(avrf_ctx *c) { return c && c->staged_kind ? batch_begin(c, c->staged_kind) : AVRF_ERR_BAD_ARG; }
-int avrf_batch_run_hash(avrf_ctx *c) { return c && c->staged_kind ? batch_hash(c, c->staged_kind) : AVRF_ERR_BAD_ARG; }
-int avrf_batch_run_end(avrf_ctx *c) { return c && c->staged_kind ? batch_end(c, c->staged_kind) : AVRF_ERR_BAD_ARG; }
+// (defensive: a run can only be open on a staged batch -- every entry point that would un-stage it is refused while
+// run_phase != 0 -- but should the two ever disagree the run is closed rather than leaving the context refusing every call)
+static int run_call(avrf_ctx *c, int (*phase)(avrf_ctx *, int)) {
+  if (!c) return AVRF_ERR_BAD_ARG;
+  if (!c->staged_kind) {
+    if (c->run_phase) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); c->run_phase = 0; c->L->ws.pending_armed = false; }
+    return AVRF_ERR_BAD_ARG;
+  }
+  return phase(c, c->staged_kind);
+}
+int avrf_batch_run_begin(avrf_ctx *c) { return run_call(c, batch_begin); }
+int avrf_batch_run_hash(avrf_ctx *c) { return run_call(c, batch_hash); }
+int avrf_batch_run_end(avrf_ctx *c) { return run_call(c, batch_end); }
 
 int avrf_thin_batch_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
                            const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
@@ -594,6 +620,7 @@ int avrf_sha512_x8(int count, const uint8_t *const *msgs, const size_t *lens, ui
 // prepare (src/thin.rs:209-226) on the staged shard: per-item challenges, 16 bytes each
 int avrf_thin_batch_challenges(avrf_ctx *c, uint8_t *c_out) {
   if (!c || c->staged_kind != 1 || (c->n && !c_out)) return AVRF_ERR_BAD_ARG;
+  if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;
   if (c->n == 0) return AVRF_OK;
   HIP_TRY(hipSetDevice(c->device));
   BatchDev b = batch_of(c);
@@ -613,6 +640,7 @@ int avrf_thin_batch_challenges(avrf_ctx *c, uint8_t *c_out) {
 // so the partial points of all shards add up to the batch MSM of src/thin.rs:319.
 int avrf_thin_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t first_index, uint8_t out_xy[64]) {
   if (!c || c->staged_kind != 1 || !seed64 || !out_xy) return AVRF_ERR_BAD_ARG;
+  if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;
   // a sponge / SHA-256 transcript has no seed to hand to the shards (avrf_batch_weight_seed refuses those suites too)
   if (with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; return (bool)S::HOST_WEIGHTS; })) return AVRF_ERR_BAD_ARG;
   if (c->n && c->chal_gen != c->stage_gen) return AVRF_ERR_BAD_ARG;     // avrf_thin_batch_challenges has not run on this staging (or it failed)
@@ -622,9 +650,9 @@ int avrf_thin_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t firs
   Seed64 seed;
   for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, seed64 + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
   BatchDev b = batch_of(c);
-  launch_thin_terms(c->suite, b, seed, first_index, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->d_scalars.as<uint32_t>(),
-                    c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
-  if (int e = guarded([&] { return msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  launch_thin_terms(c->suite, b, seed, first_index, c->d_c.as<uint32_t>(), c->d_z.as<uint32_t>(), c->L->d_scalars.as<uint32_t>(),
+                    c->L->d_pre.as<te_pre_raw>(), c->L->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
+  if (int e = guarded([&] { return msm_te_device(c->suite, c->L->d_pre.as<te_pre_raw>(), c->L->d_scalars.as<uint32_t>(), c->n_terms, c->L->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
   return finish_point(c, r, out_xy);
 }
 
@@ -632,6 +660,7 @@ int avrf_thin_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t firs
 // of its 5 n_shard + 2 terms under the global weight stream (the shard's shares of the G and BLINDING_BASE terms included).
 int avrf_pedersen_batch_challenges(avrf_ctx *c, uint8_t *c_out) {
   if (!c || c->staged_kind != 2 || (c->n && !c_out)) return AVRF_ERR_BAD_ARG;
+  if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;
   if (c->n == 0) return AVRF_OK;
   HIP_TRY(hipSetDevice(c->device));
   BatchDev b = batch_of(c);
@@ -647,6 +676,7 @@ int avrf_pedersen_batch_challenges(avrf_ctx *c, uint8_t *c_out) {
 }
 int avrf_pedersen_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t first_index, uint8_t out_xy[64]) {
   if (!c || c->staged_kind != 2 || !seed64 || !out_xy) return AVRF_ERR_BAD_ARG;
+  if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;
   // a sponge / SHA-256 transcript has no seed to hand to the shards (avrf_batch_weight_seed refuses those suites too)
   if (with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; return (bool)S::HOST_WEIGHTS; })) return AVRF_ERR_BAD_ARG;
   if (c->n && c->chal_gen != c->stage_gen) return AVRF_ERR_BAD_ARG;
@@ -656,9 +686,9 @@ int avrf_pedersen_batch_partial(avrf_ctx *c, const uint8_t seed64[64], uint64_t 
   Seed64 seed;
   for (int i = 0; i < 8; i++) { uint64_t v; memcpy(&v, seed64 + 8 * i, 8); seed.w[i] = __builtin_bswap64(v); }
   BatchDev b = batch_of(c);
-  launch_ped_terms(c->suite, b, seed, first_index, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->d_scalars.as<uint32_t>(),
-                   c->d_pre.as<te_pre_raw>(), c->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
-  if (int e = guarded([&] { return msm_te_device(c->suite, c->d_pre.as<te_pre_raw>(), c->d_scalars.as<uint32_t>(), c->n_terms, c->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  launch_ped_terms(c->suite, b, seed, first_index, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->L->d_scalars.as<uint32_t>(),
+                   c->L->d_pre.as<te_pre_raw>(), c->L->d_gpart.as<uint32_t>(), (uint32_t)c->n_terms, c->stream);
+  if (int e = guarded([&] { return msm_te_device(c->suite, c->L->d_pre.as<te_pre_raw>(), c->L->d_scalars.as<uint32_t>(), c->n_terms, c->L->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
   return finish_point(c, r, out_xy);
 }
 
@@ -675,13 +705,13 @@ int avrf_points_sum(int suite, size_t k, const uint8_t *points_xy, uint8_t out_x
 }
 
 size_t avrf_batch_last_terms(avrf_ctx *c, uint8_t *bases_xy, uint8_t *scalars) {
-  if (!c || !c->staged_kind || !c->n_terms) return 0;
+  if (!c || !c->staged_kind || !c->n_terms || ctx_busy(c)) return 0;
   if (hipSetDevice(c->device) != hipSuccess) return 0;
   size_t k = c->n_terms;
-  if (scalars) { if (hipMemcpy(scalars, c->d_scalars.p, k * 32, hipMemcpyDeviceToHost) != hipSuccess) return 0; }
+  if (scalars) { if (hipMemcpy(scalars, c->L->d_scalars.p, k * 32, hipMemcpyDeviceToHost) != hipSuccess) return 0; }
   if (bases_xy) {
     std::vector<te_pre_raw> pre(k);
-    if (hipMemcpy(pre.data(), c->d_pre.p, k * sizeof(te_pre_raw), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (hipMemcpy(pre.data(), c->L->d_pre.p, k * sizeof(te_pre_raw), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     for (size_t i = 0; i < k; i++) {
       H256 x, y; memcpy(x.l, pre[i].w, 32); memcpy(y.l, pre[i].w + 8, 32);
       with_suite(c->suite, [&](auto tag) { using S = typename decltype(tag)::type; x = HostField<typename S::Fq>::from_mont(x); y = HostField<typename S::Fq>::from_mont(y); });
@@ -698,10 +728,10 @@ void avrf_last_timing(avrf_ctx *c, double out[8]) {
 
 int avrf_kernel_stats(avrf_ctx *c, int reset, double *accum_ms_total, uint64_t *accum_launches, int32_t plan[4]) {
   if (!c) return AVRF_ERR_BAD_ARG;
-  if (accum_ms_total) *accum_ms_total = c->ws.accum_ms_total;
-  if (accum_launches) *accum_launches = c->ws.accum_launches;
-  if (plan) { plan[0] = c->ws.last_plan.c; plan[1] = c->ws.last_plan.nwin; plan[2] = c->ws.last_plan.nb; plan[3] = c->ws.last_plan.lpb; }
-  if (reset) { c->ws.accum_ms_total = 0; c->ws.accum_launches = 0; }
+  if (accum_ms_total) *accum_ms_total = c->L->ws.accum_ms_total;
+  if (accum_launches) *accum_launches = c->L->ws.accum_launches;
+  if (plan) { plan[0] = c->L->ws.last_plan.c; plan[1] = c->L->ws.last_plan.nwin; plan[2] = c->L->ws.last_plan.nb; plan[3] = c->L->ws.last_plan.lpb; }
+  if (reset) { c->L->ws.accum_ms_total = 0; c->L->ws.accum_launches = 0; }
   return AVRF_OK;
 }
 
@@ -721,12 +751,10 @@ int avrf_thin_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pk
   int st = stage(c, 1, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, nullptr);
   if (st || !n) return st;
   c->staged_kind = 0;
-  if (int fs = ensure_fixed(c)) return fs;
-  BatchDev b = batch_of(c); if (!pks_xy) b.pks_xy = nullptr;
   HIP_TRY(c->d_out.ensure(n * 96));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
   double t0 = now_us();
-  launch_thin_prove(c->suite, b, c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream);
+  if (int e = per_item_chunks(c, pks_xy != nullptr, [&](const BatchDev &b) { launch_thin_prove(c->suite, b, c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream); })) return e;
   HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, n * 96, hipMemcpyDeviceToHost, c->stream));
   int f = read_flags(c);
   c->timing[0] = now_us() - t0;
@@ -739,10 +767,9 @@ int avrf_thin_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t
   if (n && (!pks_xy || !proofs || !status_out)) return AVRF_ERR_BAD_ARG;
   int st = stage(c, 1, n, nullptr, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs);
   if (st || !n) return st;
-  if (int fs = ensure_fixed(c)) return fs;
   HIP_TRY(c->d_status.ensure(n * 4));
   double t0 = now_us();
-  launch_thin_verify(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream);
+  if (int e = per_item_chunks(c, true, [&](const BatchDev &b) { launch_thin_verify(c->suite, b, c->d_status.as<int32_t>(), c->stream); })) return e;
   validate_staged(c, 1, c->d_status.as<int32_t>());                   // Validate::Yes failures overwrite the item's status with InvalidData
   HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
@@ -757,11 +784,9 @@ int avrf_tiny_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pk
   int st = stage(c, 3, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, nullptr);
   if (st || !n) return st;
   c->staged_kind = 0;
-  if (int fs = ensure_fixed(c)) return fs;
-  BatchDev b = batch_of(c); if (!pks_xy) b.pks_xy = nullptr;
   HIP_TRY(c->d_out.ensure(n * 48));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
-  launch_thin_prove(c->suite, b, c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream, true);
+  if (int e = per_item_chunks(c, pks_xy != nullptr, [&](const BatchDev &b) { launch_thin_prove(c->suite, b, c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream, true); })) return e;
   HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, n * 48, hipMemcpyDeviceToHost, c->stream));
   int f = read_flags(c);
   if (f < 0) return AVRF_ERR_NO_DEVICE;
@@ -772,10 +797,9 @@ int avrf_tiny_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t
   if (n && (!pks_xy || !proofs || !status_out)) return AVRF_ERR_BAD_ARG;
   int st = stage(c, 3, n, nullptr, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs);
   if (st || !n) return st;
-  if (int fs = ensure_fixed(c)) return fs;
   HIP_TRY(c->d_status.ensure(n * 4));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
-  launch_tiny_verify(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream);
+  if (int e = per_item_chunks(c, true, [&](const BatchDev &b) { launch_tiny_verify(c->suite, b, c->d_status.as<int32_t>(), c->stream); })) return e;
   validate_staged(c, 3, c->d_status.as<int32_t>());
   HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
@@ -789,12 +813,10 @@ int avrf_pedersen_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t
   int st = stage(c, 2, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, nullptr);
   if (st || !n) return st;
   c->staged_kind = 0;
-  if (int fs = ensure_fixed(c)) return fs;
-  BatchDev b = batch_of(c); if (!pks_xy) b.pks_xy = nullptr;
   HIP_TRY(c->d_out.ensure(n * 256)); HIP_TRY(c->d_misc.ensure(n * 32));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
   double t0 = now_us();
-  launch_ped_prove(c->suite, b, c->d_out.as<uint8_t>(), c->d_misc.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream);
+  if (int e = per_item_chunks(c, pks_xy != nullptr, [&](const BatchDev &b) { launch_ped_prove(c->suite, b, c->d_out.as<uint8_t>(), c->d_misc.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream); })) return e;
   HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, n * 256, hipMemcpyDeviceToHost, c->stream));
   if (blindings_out) HIP_TRY(hipMemcpyAsync(blindings_out, c->d_misc.p, n * 32, hipMemcpyDeviceToHost, c->stream));
   int f = read_flags(c);
@@ -808,10 +830,9 @@ int avrf_pedersen_verify(avrf_ctx *c, size_t n, const uint8_t *ios_xy, const uin
   if (n && (!proofs || !status_out)) return AVRF_ERR_BAD_ARG;
   int st = stage(c, 2, n, nullptr, nullptr, ios_xy, io_counts, ads, ad_lens, proofs);
   if (st || !n) return st;
-  if (int fs = ensure_fixed(c)) return fs;
   HIP_TRY(c->d_status.ensure(n * 4));
   double t0 = now_us();
-  launch_ped_verify(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream);
+  if (int e = per_item_chunks(c, true, [&](const BatchDev &b) { launch_ped_verify(c->suite, b, c->d_status.as<int32_t>(), c->stream); })) return e;
   validate_staged(c, 2, c->d_status.as<int32_t>());
   HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
@@ -821,6 +842,7 @@ int avrf_pedersen_verify(avrf_ctx *c, size_t n, const uint8_t *ios_xy, const uin
 
 static int smul_common(avrf_ctx *c, size_t n, const uint8_t *scalars, const uint8_t *points_xy, uint8_t *out_xy) {
   if (!c || (n && (!scalars || !out_xy))) return AVRF_ERR_BAD_ARG;
+  if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;
   if (!n) return AVRF_OK;
   if (n > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
@@ -847,6 +869,7 @@ size_t avrf_point_len(int suite) { return (suite < 0 || suite >= AVRF_N_SUITES) 
 
 int avrf_points_decompress(avrf_ctx *c, size_t n, const uint8_t *in, uint8_t *out_xy, int validate, int32_t *status_out) {
   if (!c || (n && (!in || !out_xy || !status_out))) return AVRF_ERR_BAD_ARG;
+  if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;
   if (!n) return AVRF_OK;
   if (n > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
@@ -862,6 +885,7 @@ int avrf_points_decompress(avrf_ctx *c, size_t n, const uint8_t *in, uint8_t *ou
 }
 int avrf_hash_to_curve(avrf_ctx *c, size_t n, const uint8_t *data, const uint32_t *data_lens, uint8_t *out_xy, int32_t *status_out) {
   if (!c || (n && (!data_lens || !out_xy || !status_out))) return AVRF_ERR_BAD_ARG;
+  if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;
   if (!n) return AVRF_OK;
   if (n > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
   std::vector<uint32_t> off(n + 1); uint64_t tot = 0;
@@ -881,6 +905,7 @@ int avrf_hash_to_curve(avrf_ctx *c, size_t n, const uint8_t *data, const uint32_
 }
 int avrf_points_compress(avrf_ctx *c, size_t n, const uint8_t *in_xy, uint8_t *out) {
   if (!c || (n && (!in_xy || !out))) return AVRF_ERR_BAD_ARG;
+  if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;
   if (!n) return AVRF_OK;
   if (n > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));

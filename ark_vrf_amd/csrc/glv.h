@@ -114,7 +114,7 @@ template <class S> AVRF_DI void glv_table_ws(te_ext *tab, const te_pre &p, const
     for (int i = 1; i < 4; i++) { cur = te_madd<S>(cur, p); store_ext(tab + 4 * j + i, cur); }
   }
 }
-// k * P with the table in the workspace (ws: ITEM_TAB_SLOTS entries of this item, or nullptr = private memory)
+// k * P with the table in the workspace (ws: the ITEM_TAB_SLOTS entries of this item; never null -- every caller sizes BatchDev::tabs first)
 template <class S> AVRF_DN te_ext te_smul_glv_ws_nf(te_ext *ws, te_pre p, fp k) {
   using Fr = typename S::Fr;
   te_ext q;

@@ -159,4 +159,130 @@ AVRF_MB_TARGET static inline void sha512_weights_x8(WeightJob *const *jobs, int 
     for (int i = 0; i < 8; i++) for (int k = 0; k < 8; k++) jobs[l]->digest[8 * i + k] = (uint8_t)(out[i][l] >> (56 - 8 * k));
 }
 
+
+// ---------------------------------------------------------------- sixteen chains: two groups of eight, interleaved (round 4)
+// One 8-lane compression is a latency chain: e -> Sigma1 / Ch -> three additions -> e of the next round, about 12 cycles per
+// round on the bench host against ~7 of pure port time (28 vector operations).  Two INDEPENDENT groups advanced in the same
+// loop give the out-of-order core a second chain to fill the gaps with; the message words live in memory (2 x 16 registers
+// of schedule + 2 x 8 of state do not fit in 32 zmm), and the 16 x 128 message bytes of a group are transposed with
+// unpack / 128-bit shuffles and byte-swapped with one vpshufb per register instead of 128 scalar load-swap-store triples.
+#define AVRF_MB16_TARGET __attribute__((target("avx512f,avx512bw")))
+
+namespace mb_detail {
+
+// rows[l] = the next 128-byte block of lane l (two loads each) -> W[t] lane l = big-endian word t of lane l
+AVRF_MB16_TARGET static inline void load_transpose_x8(const uint8_t *const rows[8], __m512i W[16]) {
+  const __m512i bswap = _mm512_set_epi8(8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7,
+                                        8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 0, 1, 2, 3, 4, 5, 6, 7);
+  for (int half = 0; half < 2; half++) {
+    __m512i r[8], t[8], u[8];
+    for (int l = 0; l < 8; l++) r[l] = _mm512_shuffle_epi8(_mm512_loadu_si512((const void *)(rows[l] + 64 * half)), bswap);
+    for (int k = 0; k < 4; k++) { t[2 * k] = _mm512_unpacklo_epi64(r[2 * k], r[2 * k + 1]); t[2 * k + 1] = _mm512_unpackhi_epi64(r[2 * k], r[2 * k + 1]); }
+    // t[2k + p]: 128-bit block b = words (2b + p) of lanes 2k, 2k + 1
+    for (int p = 0; p < 2; p++) {
+      u[0 + p] = _mm512_shuffle_i64x2(t[0 + p], t[2 + p], 0x88); u[2 + p] = _mm512_shuffle_i64x2(t[0 + p], t[2 + p], 0xDD);
+      u[4 + p] = _mm512_shuffle_i64x2(t[4 + p], t[6 + p], 0x88); u[6 + p] = _mm512_shuffle_i64x2(t[4 + p], t[6 + p], 0xDD);
+      W[8 * half + 0 + p] = _mm512_shuffle_i64x2(u[0 + p], u[4 + p], 0x88);
+      W[8 * half + 4 + p] = _mm512_shuffle_i64x2(u[0 + p], u[4 + p], 0xDD);
+      W[8 * half + 2 + p] = _mm512_shuffle_i64x2(u[2 + p], u[6 + p], 0x88);
+      W[8 * half + 6 + p] = _mm512_shuffle_i64x2(u[2 + p], u[6 + p], 0xDD);
+    }
+  }
+}
+
+#define AVRF_MB_ROUND(a, b, c, d, e, f, g, h, W, r)                                                                              \
+  do {                                                                                                                         \
+    const int i_ = (r) & 15;                                                                                                   \
+    if ((r) >= 16) {                                                                                                           \
+      const __m512i w15 = W[(i_ + 1) & 15], w2 = W[(i_ + 14) & 15];                                                            \
+      const __m512i s0 = xor3(_mm512_ror_epi64(w15, 1), _mm512_ror_epi64(w15, 8), _mm512_srli_epi64(w15, 7));                  \
+      const __m512i s1 = xor3(_mm512_ror_epi64(w2, 19), _mm512_ror_epi64(w2, 61), _mm512_srli_epi64(w2, 6));                   \
+      W[i_] = _mm512_add_epi64(_mm512_add_epi64(W[i_], s0), _mm512_add_epi64(W[(i_ + 9) & 15], s1));                           \
+    }                                                                                                                          \
+    const __m512i hk = _mm512_add_epi64(h, _mm512_add_epi64(W[i_], _mm512_set1_epi64((long long)K512[r]))); /* off the chain */ \
+    const __m512i dhk = _mm512_add_epi64(d, hk);                                                            /* off the chain */ \
+    const __m512i S1 = xor3(_mm512_ror_epi64(e, 14), _mm512_ror_epi64(e, 18), _mm512_ror_epi64(e, 41));                        \
+    const __m512i sc = _mm512_add_epi64(S1, _mm512_ternarylogic_epi64(e, f, g, 0xCA));                                         \
+    const __m512i S0 = xor3(_mm512_ror_epi64(a, 28), _mm512_ror_epi64(a, 34), _mm512_ror_epi64(a, 39));                        \
+    const __m512i t2 = _mm512_add_epi64(_mm512_add_epi64(S0, _mm512_ternarylogic_epi64(a, b, c, 0xE8)), hk);                   \
+    d = _mm512_add_epi64(dhk, sc);                            /* e of the next round: rotate, xor3, add, add */                \
+    h = _mm512_add_epi64(t2, sc);                             /* a of the next round */                                        \
+  } while (0)
+
+// one compression of two independent groups; state rotates through the argument order instead of being moved
+AVRF_MB16_TARGET static inline void compress_x16(__m512i (&HA)[8], __m512i (&WA)[16], __m512i (&HB)[8], __m512i (&WB)[16]) {
+  __m512i a = HA[0], b = HA[1], c = HA[2], d = HA[3], e = HA[4], f = HA[5], g = HA[6], h = HA[7];
+  __m512i p = HB[0], q = HB[1], s = HB[2], t = HB[3], u = HB[4], v = HB[5], w = HB[6], x = HB[7];
+#pragma unroll
+  for (int r = 0; r < 80; r += 8) {
+    AVRF_MB_ROUND(a, b, c, d, e, f, g, h, WA, r + 0); AVRF_MB_ROUND(p, q, s, t, u, v, w, x, WB, r + 0);
+    AVRF_MB_ROUND(h, a, b, c, d, e, f, g, WA, r + 1); AVRF_MB_ROUND(x, p, q, s, t, u, v, w, WB, r + 1);
+    AVRF_MB_ROUND(g, h, a, b, c, d, e, f, WA, r + 2); AVRF_MB_ROUND(w, x, p, q, s, t, u, v, WB, r + 2);
+    AVRF_MB_ROUND(f, g, h, a, b, c, d, e, WA, r + 3); AVRF_MB_ROUND(v, w, x, p, q, s, t, u, WB, r + 3);
+    AVRF_MB_ROUND(e, f, g, h, a, b, c, d, WA, r + 4); AVRF_MB_ROUND(u, v, w, x, p, q, s, t, WB, r + 4);
+    AVRF_MB_ROUND(d, e, f, g, h, a, b, c, WA, r + 5); AVRF_MB_ROUND(t, u, v, w, x, p, q, s, WB, r + 5);
+    AVRF_MB_ROUND(c, d, e, f, g, h, a, b, WA, r + 6); AVRF_MB_ROUND(s, t, u, v, w, x, p, q, WB, r + 6);
+    AVRF_MB_ROUND(b, c, d, e, f, g, h, a, WA, r + 7); AVRF_MB_ROUND(q, s, t, u, v, w, x, p, WB, r + 7);
+  }
+  HA[0] = _mm512_add_epi64(HA[0], a); HA[1] = _mm512_add_epi64(HA[1], b); HA[2] = _mm512_add_epi64(HA[2], c); HA[3] = _mm512_add_epi64(HA[3], d);
+  HA[4] = _mm512_add_epi64(HA[4], e); HA[5] = _mm512_add_epi64(HA[5], f); HA[6] = _mm512_add_epi64(HA[6], g); HA[7] = _mm512_add_epi64(HA[7], h);
+  HB[0] = _mm512_add_epi64(HB[0], p); HB[1] = _mm512_add_epi64(HB[1], q); HB[2] = _mm512_add_epi64(HB[2], s); HB[3] = _mm512_add_epi64(HB[3], t);
+  HB[4] = _mm512_add_epi64(HB[4], u); HB[5] = _mm512_add_epi64(HB[5], v); HB[6] = _mm512_add_epi64(HB[6], w); HB[7] = _mm512_add_epi64(HB[7], x);
+}
+AVRF_MB16_TARGET static inline void compress_x8r(__m512i (&HA)[8], __m512i (&WA)[16]) {
+  __m512i a = HA[0], b = HA[1], c = HA[2], d = HA[3], e = HA[4], f = HA[5], g = HA[6], h = HA[7];
+#pragma unroll
+  for (int r = 0; r < 80; r += 8) {
+    AVRF_MB_ROUND(a, b, c, d, e, f, g, h, WA, r + 0); AVRF_MB_ROUND(h, a, b, c, d, e, f, g, WA, r + 1);
+    AVRF_MB_ROUND(g, h, a, b, c, d, e, f, WA, r + 2); AVRF_MB_ROUND(f, g, h, a, b, c, d, e, WA, r + 3);
+    AVRF_MB_ROUND(e, f, g, h, a, b, c, d, WA, r + 4); AVRF_MB_ROUND(d, e, f, g, h, a, b, c, WA, r + 5);
+    AVRF_MB_ROUND(c, d, e, f, g, h, a, b, WA, r + 6); AVRF_MB_ROUND(b, c, d, e, f, g, h, a, WA, r + 7);
+  }
+  HA[0] = _mm512_add_epi64(HA[0], a); HA[1] = _mm512_add_epi64(HA[1], b); HA[2] = _mm512_add_epi64(HA[2], c); HA[3] = _mm512_add_epi64(HA[3], d);
+  HA[4] = _mm512_add_epi64(HA[4], e); HA[5] = _mm512_add_epi64(HA[5], f); HA[6] = _mm512_add_epi64(HA[6], g); HA[7] = _mm512_add_epi64(HA[7], h);
+}
+
+}  // namespace mb_detail
+
+inline bool sha512_mb16_available() { return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw"); }
+
+// digests of up to sixteen weight transcripts: lanes 0-7 and 8-15 are two groups advanced in one interleaved round loop
+// (count <= 8: one group through the same transposing loader)
+AVRF_MB16_TARGET static inline void sha512_weights_x16(WeightJob *const *jobs, int count) {
+  using namespace mb_detail;
+  static const uint64_t iv[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                                 0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+  alignas(64) static const uint8_t zero_block[128] = {0};
+  LaneFeed feed[16];
+  for (int l = 0; l < count; l++) feed[l].start(jobs[l]);
+  const int groups = count > 8 ? 2 : 1;
+  __m512i H[2][8];
+  for (int gI = 0; gI < 2; gI++) for (int i = 0; i < 8; i++) H[gI][i] = _mm512_set1_epi64((long long)iv[i]);
+  alignas(64) uint8_t tail[16][128];
+  for (;;) {
+    unsigned active = 0;
+    const uint8_t *rows[16];
+    for (int l = 0; l < 8 * groups; l++) {
+      rows[l] = zero_block;
+      if (l >= count) continue;
+      const uint8_t *p = feed[l].next_direct();
+      if (!p) { if (!feed[l].next(tail[l])) continue; p = tail[l]; }
+      rows[l] = p; active |= 1u << l;
+    }
+    if (!active) break;
+    __m512i W[2][16], Hn[2][8];
+    for (int gI = 0; gI < groups; gI++) { load_transpose_x8(rows + 8 * gI, W[gI]); for (int i = 0; i < 8; i++) Hn[gI][i] = H[gI][i]; }
+    if (groups == 2 && (active >> 8)) compress_x16(Hn[0], W[0], Hn[1], W[1]);
+    else compress_x8r(Hn[0], W[0]);
+    for (int gI = 0; gI < groups; gI++)
+      for (int i = 0; i < 8; i++) H[gI][i] = _mm512_mask_blend_epi64((__mmask8)(active >> (8 * gI)), H[gI][i], Hn[gI][i]);
+  }
+  alignas(64) uint64_t out[8][8];
+  for (int gI = 0; gI < groups; gI++) {
+    for (int i = 0; i < 8; i++) _mm512_store_si512((void *)out[i], H[gI][i]);
+    for (int l = 8 * gI; l < count && l < 8 * gI + 8; l++)
+      for (int i = 0; i < 8; i++) for (int k = 0; k < 8; k++) jobs[l]->digest[8 * i + k] = (uint8_t)(out[i][l - 8 * gI] >> (56 - 8 * k));
+  }
+}
+
 }  // namespace avrf

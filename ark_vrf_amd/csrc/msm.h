@@ -48,8 +48,19 @@ struct MsmWorkspace {
   MsmPlan last_plan = {0, 0, 0, 0};
   int wsum_lg = 4;               // scale 2^lg of the third point of a window triple (TE window sums)
   // an enqueued launch chain whose results have not been collected yet (msm_te_enqueue / msm_te_finish)
-  MsmPlan pending_plan = {0, 0, 0, 0}; int pending_ret = 0; size_t pending_n = 0;
+  MsmPlan pending_plan = {0, 0, 0, 0}; int pending_ret = 0; size_t pending_n = 0; bool pending_armed = false;
   void ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch, size_t lanes_max);
+  void release();
+};
+
+// Results of ONE enqueued twisted-Edwards chain kept outside the workspace, so that several chains can be queued behind each
+// other on one lane (stream + workspace): the device-side workspace is reused in stream order, what comes back to the host
+// (window sums, the plan, the timing events of the dominant kernel) lands here.  pool.hip gives every slot one.
+struct MsmPending {
+  uint32_t *bits_host = nullptr, *plan_host = nullptr; size_t cap_bytes = 0;   // pinned
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  MsmPlan plan = {0, 0, 0, 0}; int ret = 0, wsum_lg = 4; size_t n = 0; bool armed = false;
+  void ensure(size_t bytes);
   void release();
 };
 
@@ -59,8 +70,11 @@ int msm_te_device(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars,
                   MsmWorkspace &ws, hipStream_t stream, HostExt *out);
 // the same in two halves: msm_te_enqueue launches the whole kernel chain and the copies back on `stream` and returns without
 // waiting; msm_te_finish waits for the stream and folds the window sums on the host.  One chain in flight per workspace.
-int msm_te_enqueue(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream);
-int msm_te_finish(int suite, MsmWorkspace &ws, hipStream_t stream, HostExt *out);
+// pend != nullptr: the chain's results go to *pend (see MsmPending); msm_te_finish then does NOT wait for the stream -- the
+// caller has seen an event recorded behind the chain complete.
+int msm_te_enqueue(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, MsmPending *pend = nullptr);
+int msm_te_finish(int suite, MsmWorkspace &ws, hipStream_t stream, HostExt *out, MsmPending *pend = nullptr);
+bool msm_te_pending_supported(int suite);   // external results exist for the window-sum form of the chain only
 
 // G1 MSM over a short-Weierstrass curve (curve: 0 BLS12-381, 1 BN254): d_bases = n Montgomery affine
 // points (2 * Fq words each, (0,0) = infinity), d_scalars = n plain 256-bit scalars (< r).

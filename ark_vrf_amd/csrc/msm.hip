@@ -39,6 +39,8 @@
 #include "host_g1.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <mutex>
 #include <vector>
 
 namespace avrf {
@@ -604,19 +606,35 @@ static uint32_t tile_len_for(size_t n) { return 8192; }
 struct AccShape { size_t lanes; unsigned lds; };
 template <class CV> static AccShape accumulate_shape() {
   static AccShape cache[64] = {};
+  static std::mutex mu;                                                       // contexts call this from their own host threads
   int dev = 0; HIP_CHECK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) dev = 0;
+  std::lock_guard<std::mutex> lk(mu);
   if (!cache[dev].lanes) {
-    int cus = 0, blocks = 0;
+    int cus = 0, blocks = 0, lds_cu = 0, lds_blk = 0;
     HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_accumulate<CV>, 256, 0));
     if (blocks < 1) blocks = 1;
+    // LDS of one CU and the most one workgroup may ask for (160 KB both on gfx950; the slice below is computed from what the
+    // device reports, and the cap is skipped where a slice cannot be expressed)
+    if (hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || lds_cu <= 0) { (void)hipGetLastError(); lds_cu = 0; }
+    if (hipDeviceGetAttribute(&lds_blk, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds_blk <= 0) { (void)hipGetLastError(); lds_blk = 64 * 1024; }
+    {  // the runtime may report the 64 KB of older parts for gfx950, whose CUs have 160 KB (MI355X_MICROARCH.md)
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) == hipSuccess && !strncmp(prop.gcnArchName, "gfx950", 6)) {
+        if (lds_cu < 160 * 1024) lds_cu = 160 * 1024;
+        if (lds_blk < 160 * 1024) lds_blk = 160 * 1024;
+      } else (void)hipGetLastError();
+    }
     int cap = CV::MAX_WAVES;                                                  // a block of 256 lanes = one wave on each of a CU's 4 SIMDs
     if (msm_env().occ) cap = msm_env().occ;
     unsigned lds = 0;
-    if (cap >= 1 && cap < blocks) {
-      blocks = cap; lds = (unsigned)(160 * 1024 / (cap + 1) + 1024);                                     // cap + 1 slices do not fit
-      if (lds > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (cap >= 1 && cap < blocks && lds_cu > 0) {
+      const unsigned slice = (unsigned)(lds_cu / (cap + 1) + 1024);           // cap + 1 slices do not fit, cap slices do
+      if ((size_t)slice * cap <= (size_t)lds_cu && slice <= (unsigned)lds_blk) {
+        blocks = cap; lds = slice;
+        if (lds > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      }
     }
     cache[dev] = AccShape{(size_t)cus * blocks * 256, lds};
   }
@@ -690,6 +708,22 @@ void MsmWorkspace::release() {
   cap_n = cap_slots = cap_buckets = cap_bits = cap_part = cap_hist = cap_vwin = 0;
 }
 
+void MsmPending::ensure(size_t bytes) {
+  if (!plan_host) HIP_CHECK(hipHostMalloc(&plan_host, 64));
+  if (!ev0) { HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); }
+  if (bytes <= cap_bytes) return;
+  if (bits_host) HIP_CHECK(hipHostFree(bits_host));
+  bits_host = nullptr; cap_bytes = 0;
+  HIP_CHECK(hipHostMalloc(&bits_host, bytes));
+  cap_bytes = bytes;
+}
+void MsmPending::release() {
+  if (bits_host) (void)hipHostFree(bits_host);
+  if (plan_host) (void)hipHostFree(plan_host);
+  if (ev0) (void)hipEventDestroy(ev0); if (ev1) (void)hipEventDestroy(ev1);
+  bits_host = plan_host = nullptr; ev0 = ev1 = nullptr; cap_bytes = 0; armed = false;
+}
+
 // waits for the launch chain msm_device enqueued on `stream` and books its plan / k_accumulate timing
 static void msm_wait(MsmWorkspace &ws, hipStream_t stream) {
   HIP_CHECK(hipStreamSynchronize(stream));
@@ -709,7 +743,7 @@ static void msm_wait(MsmWorkspace &ws, hipStream_t stream) {
 template <class CV>
 static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t n_in, int scalar_bits, MsmWorkspace &ws, hipStream_t stream,
                       size_t batch = 1, int table_c = 0, size_t table_stride = 0, size_t scalar_stride = 0, const uint32_t *d_base_idx = nullptr,
-                      bool defer = false, int scalars_mont = 0) {
+                      bool defer = false, int scalars_mont = 0, MsmPending *pend = nullptr) {
   MsmPlan p = msm_plan(n_in, scalar_bits);
   if (!scalar_stride) scalar_stride = n_in;                            // vector b's scalars start at b * scalar_stride
   const size_t lanes_target = accumulate_lanes<CV>();
@@ -741,20 +775,22 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   hipLaunchKernelGGL(k_scatter, dim3(8u * ((vwin + 7u) / 8u) * ntiles), b256, lds_bytes, stream, ws.keys, (uint32_t)n, tile_len, p.c, ws.hist, ws.offsets, ws.sorted,
                      remap_n, remap_stride, d_base_idx, ntiles, vwin);
   if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
+  if (pend) pend->ensure((size_t)vwin * 3 * acc_bytes);
+  hipEvent_t ev0 = pend ? pend->ev0 : ws.ev0, ev1 = pend ? pend->ev1 : ws.ev1;
   if (CV::ZERO_IS_IDENTITY) HIP_CHECK(hipMemsetAsync(ws.buckets, 0, (size_t)nbk * acc_bytes, stream));   // empty buckets
-  HIP_CHECK(hipEventRecord(ws.ev0, stream));
+  HIP_CHECK(hipEventRecord(ev0, stream));
   hipLaunchKernelGGL(k_accumulate<CV>, dim3((unsigned)((lanes_max + 255) / 256)), b256, accumulate_shape<CV>().lds, stream, d_bases, (const uint32_t *)ws.sorted,
                      (const uint32_t *)ws.offsets, (const uint32_t *)ws.win_tot, (const uint32_t *)ws.lane_base, (const uint32_t *)ws.plan_dev, vwin,
                      (uint32_t)p.nb, (uint32_t)n, ws.part);
-  HIP_CHECK(hipEventRecord(ws.ev1, stream));
+  HIP_CHECK(hipEventRecord(ev1, stream));
   hipLaunchKernelGGL(k_bucket_sum<CV>, dim3((nbk + 255) / 256), b256, 0, stream, (const uint32_t *)ws.offsets, (const uint32_t *)ws.cnts,
                      (const uint32_t *)ws.lane_base, ws.plan_dev, nbk, (uint32_t)p.nb, (uint32_t)n, (const uint32_t *)ws.part, ws.buckets, ws.heavy);
   hipLaunchKernelGGL(k_heavy_sum<CV>, dim3(nbk < 1024 ? nbk : 1024), b256, 4 * acc_bytes, stream, (const uint32_t *)ws.offsets, (const uint32_t *)ws.cnts,
                      (const uint32_t *)ws.lane_base, (const uint32_t *)ws.plan_dev, (uint32_t)p.nb, (uint32_t)n, (const uint32_t *)ws.part, ws.buckets,
                      (const uint32_t *)ws.heavy);
-  HIP_CHECK(hipMemcpyAsync(ws.plan_host, ws.plan_dev, 8, hipMemcpyDeviceToHost, stream));
+  HIP_CHECK(hipMemcpyAsync(pend ? pend->plan_host : ws.plan_host, ws.plan_dev, 8, hipMemcpyDeviceToHost, stream));
   // defer: the caller collects the results later (msm_wait): everything up to the copies back is enqueued, nothing is waited for
-  ws.pending_plan = p;
+  if (pend) pend->plan = p; else ws.pending_plan = p;
   auto finish = [&]() { if (!defer) msm_wait(ws, stream); };
   if constexpr (CV::WINDOW_SUMS) if (batch == 1 && msm_env().window_sums) {
     // weighted bucket sum of every window with the four-lanes-per-point kernels (te_quad.h): three points per window come
@@ -764,12 +800,13 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
     const uint32_t nwaves = vwin * wpw;
     hipLaunchKernelGGL(k_wsum_q1<typename CV::suite>, dim3((nwaves + 3) / 4), b256, 0, stream, (const uint32_t *)ws.buckets, nb, m, wpw, nwaves, ws.rc);
     hipLaunchKernelGGL(k_wsum_q2<typename CV::suite>, dim3(vwin), dim3(64), 0, stream, (const uint32_t *)ws.rc, wpw, ws.bits);
-    HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.bits, (size_t)vwin * 3 * acc_bytes, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(pend ? pend->bits_host : ws.bits_host, ws.bits, (size_t)vwin * 3 * acc_bytes, hipMemcpyDeviceToHost, stream));
     finish();
     int lg = 4; while ((1u << lg) < 16 * m) lg++;
-    ws.wsum_lg = lg;
+    if (pend) pend->wsum_lg = lg; else ws.wsum_lg = lg;
     return -(int)vwin;                                       // negative: bits_host holds window triples, not bit sums
   }
+  if (pend) throw HipFailure{hipErrorInvalidValue, __FILE__, __LINE__};   // external results exist for the window-sum form only
   const int h = (p.c - 1) / 2;
   const uint32_t tasks = (1u << h) + ((uint32_t)p.nb >> h);
   const int nbits = (int)vwin * p.c;
@@ -815,23 +852,39 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
 }
 
 template <class S>
-static int msm_te_enqueue_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream) {
-  ws.pending_n = n; ws.pending_ret = 0;
+static int msm_te_enqueue_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, MsmPending *pend) {
+  if (pend) {
+    pend->n = n; pend->ret = 0; pend->armed = true;
+    if (n) pend->ret = msm_device<TeCurve<S>>((const uint32_t *)d_pre, d_scalars, n, S::Fr::BITS, ws, stream, 1, 0, 0, 0, nullptr, /*defer=*/true, 0, pend);
+    return 0;
+  }
+  ws.pending_n = n; ws.pending_ret = 0; ws.pending_armed = true;
   if (n) ws.pending_ret = msm_device<TeCurve<S>>((const uint32_t *)d_pre, d_scalars, n, S::Fr::BITS, ws, stream, 1, 0, 0, 0, nullptr, /*defer=*/true);
   return 0;
 }
 template <class S>
-static int msm_te_finish_impl(MsmWorkspace &ws, hipStream_t stream, HostExt *out) {
+static int msm_te_finish_impl(MsmWorkspace &ws, hipStream_t stream, HostExt *out, MsmPending *pend) {
   using HT = HostTe<S>;
   *out = HT::identity();
-  if (ws.pending_n == 0) return 0;
-  ws.pending_n = 0;
-  msm_wait(ws, stream);
-  const int nbits = ws.pending_ret;
+  int nbits, c, lg; const uint32_t *bh;
+  if (pend) {
+    if (!pend->armed) return -1;
+    pend->armed = false;
+    if (pend->n == 0) return 0;
+    HIP_CHECK(hipEventElapsedTime(&ws.accum_ms_last, pend->ev0, pend->ev1));   // (the caller saw the chain complete)
+    pend->plan.lpb = (int)pend->plan_host[0];
+    ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = pend->plan;
+    nbits = pend->ret; c = pend->plan.c; lg = pend->wsum_lg; bh = pend->bits_host;
+  } else {
+    if (!ws.pending_armed) return -1;                     // nothing was enqueued (or another call consumed the chain): an error, never the identity
+    ws.pending_armed = false;
+    if (ws.pending_n == 0) return 0;
+    ws.pending_n = 0;
+    msm_wait(ws, stream);
+    nbits = ws.pending_ret; c = ws.last_plan.c; lg = ws.wsum_lg; bh = ws.bits_host;
+  }
   HostExt acc = HT::identity();
-  const uint32_t *bh = ws.bits_host;
   if (nbits < 0) {                                        // window triples: W_w = P1 + 2^4 P2 + 2^lg P3; sum_w 2^(c w) W_w
-    const int c = ws.last_plan.c, lg = ws.wsum_lg;
     for (int w = -nbits - 1; w >= 0; w--) {
       for (int k = 0; k < c - lg; k++) acc = HT::dbl(acc);
       acc = HT::add(acc, HT::from_raw32(bh + ((size_t)w * 3 + 2) * 32));
@@ -848,13 +901,17 @@ static int msm_te_finish_impl(MsmWorkspace &ws, hipStream_t stream, HostExt *out
   return 0;
 }
 
-int msm_te_enqueue(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream) {
+int msm_te_enqueue(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, MsmPending *pend) {
   if (suite < 0 || suite >= AVRF_N_SUITES) return -1;
-  return with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return msm_te_enqueue_impl<S>(d_pre, d_scalars, n, ws, stream); });
+  return with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return msm_te_enqueue_impl<S>(d_pre, d_scalars, n, ws, stream, pend); });
 }
-int msm_te_finish(int suite, MsmWorkspace &ws, hipStream_t stream, HostExt *out) {
+int msm_te_finish(int suite, MsmWorkspace &ws, hipStream_t stream, HostExt *out, MsmPending *pend) {
   if (suite < 0 || suite >= AVRF_N_SUITES) return -1;
-  return with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return msm_te_finish_impl<S>(ws, stream, out); });
+  return with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return msm_te_finish_impl<S>(ws, stream, out, pend); });
+}
+bool msm_te_pending_supported(int suite) {
+  if (suite < 0 || suite >= AVRF_N_SUITES || !msm_env().window_sums) return false;
+  return with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return (bool)TeCurve<S>::WINDOW_SUMS; });
 }
 int msm_te_device(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n,
                   MsmWorkspace &ws, hipStream_t stream, HostExt *out) {
@@ -967,14 +1024,14 @@ k_g1_table(const uint32_t *__restrict__ bases, uint32_t n, int c, int nwin, uint
 void build_g1_table(int curve, const uint32_t *d_bases, size_t n, int c, int nwin, uint32_t *d_table, hipStream_t stream) {
   if (!n) return;
   const size_t fqn = curve == 0 ? G1Bls12381::Fq::N : G1Bn254::Fq::N;
+  // scratch from the stream-ordered pool: no device-wide synchronisation (hipFree stalls every other context in flight), and the
+  // build stays asynchronous -- callers synchronise the stream when they need the table
   uint32_t *tmp = nullptr;
-  HIP_CHECK(hipMalloc(&tmp, (size_t)nwin * n * 3 * fqn * 4));
+  HIP_CHECK(hipMallocAsync((void **)&tmp, (size_t)nwin * n * 3 * fqn * 4, stream));
   dim3 g((unsigned)((n + 63) / 64)), b(64);
   if (curve == 0) hipLaunchKernelGGL(k_g1_table<G1Bls12381>, g, b, 0, stream, d_bases, (uint32_t)n, c, nwin, d_table, tmp);
   else hipLaunchKernelGGL(k_g1_table<G1Bn254>, g, b, 0, stream, d_bases, (uint32_t)n, c, nwin, d_table, tmp);
-  hipError_t e = hipStreamSynchronize(stream);
-  (void)hipFree(tmp);
-  HIP_CHECK(e);
+  HIP_CHECK(hipFreeAsync(tmp, stream));
 }
 
 template <class C>

@@ -53,8 +53,10 @@ struct BatchDev {
                             // one contiguous buffer that came back in a single copy; nullptr: not wanted
   const uint8_t *weights;   // batch verifiers, sponge transcripts only: the squeezed weight stream of THIS batch (16 / 32 bytes per
                             // item), produced by the host -- a sponge's output is sequential; nullptr: counter-mode stream from the seed
-  te_ext *tabs;             // per-item kernels: ITEM_TAB_SLOTS window-table entries per item, item j's at tabs + j * ITEM_TAB_SLOTS
-                            // (te_smul_ws below)
+  te_ext *tabs;             // per-item kernels: ITEM_TAB_SLOTS window-table entries per item of THIS LAUNCH, item j's at
+                            // tabs + (j - first) * ITEM_TAB_SLOTS (te_smul_ws below)
+  uint32_t first;           // per-item kernels: a launch covers items first .. n - 1 (the host walks a large call in chunks so
+                            // that the table workspace stays bounded, capi.hip per_item_chunks)
 };
 struct Seed64 { uint64_t w[8]; };  // a SHA-512 digest as big-endian words
 // Suite::Transcript (src/lib.rs:177-250): HashTranscript<Sha512>, or the SHAKE128 sponge for the suites that say so

@@ -464,6 +464,7 @@ struct avrf_ring_vk_builder {
 };
 
 extern "C" hipStream_t avrf_ctx_stream_(avrf_ctx *c);
+extern "C" int avrf_ctx_busy_(avrf_ctx *c);     // a three-call batch run is open on the context (capi.hip): its stream is taken
 extern "C" int avrf_ctx_suite_(avrf_ctx *c);
 extern "C" int avrf_ctx_device_(avrf_ctx *c);
 
@@ -1483,12 +1484,14 @@ extern "C" {
 
 int avrf_ring_setup_load(avrf_ctx *ctx, const uint8_t *srs, size_t srs_len, size_t ring_size, avrf_ring_setup **out) {
   if (!ctx || !srs || !out || ring_size == 0) return AVRF_ERR_BAD_ARG;
+  if (avrf_ctx_busy_(ctx)) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
   if (!ring_suite(avrf_ctx_suite_(ctx))) return AVRF_ERR_BAD_ARG;      // not a RingSuite (Ed25519)
   return guarded([&] { return with_ring(avrf_ctx_suite_(ctx), [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::setup_load(ctx, srs, srs_len, ring_size, out); }); });
 }
 int avrf_ring_srs_generate(avrf_ctx *ctx, const uint8_t *tau, const uint8_t *g1, const uint8_t *g2, size_t n_g1, uint8_t *out, size_t out_cap, size_t *out_len) {
   if (!ctx || !tau || !g1 || !g2 || !ring_suite(avrf_ctx_suite_(ctx))) return AVRF_ERR_BAD_ARG;
+  if (avrf_ctx_busy_(ctx)) return AVRF_ERR_BAD_ARG;
   return guarded([&] { return with_ring(avrf_ctx_suite_(ctx), [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::srs_generate(ctx, tau, g1, g2, n_g1, out, out_cap, out_len); }); });
 }
 size_t avrf_ring_pcs_domain_size(int suite, size_t ring_size) {       /* pcs_domain_size, src/ring.rs:810-817: 3 * piop_domain + 1 */
@@ -1528,6 +1531,7 @@ int avrf_ring_setup_plan(const avrf_ring_setup *su, int32_t out[4]) {
 
 int avrf_ring_index(avrf_ring_setup *su, const uint8_t *pks_xy, size_t n_keys, avrf_ring_key **out, uint8_t *commitment_out) {
   if (!su || !out || (n_keys && !pks_xy)) return AVRF_ERR_BAD_ARG;
+  if (avrf_ctx_busy_(su->ctx)) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
   if (!su->n_srs) return AVRF_SRS_LOOKUP_FAILED;                       // verifier-only setup
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
@@ -1543,6 +1547,7 @@ void avrf_ring_key_free(avrf_ring_key *k) { if (!k) return; if (k->d_fixed4) (vo
 
 int avrf_ring_vk_builder_new(avrf_ring_setup *su, avrf_ring_vk_builder **out) {
   if (!su || !out) return AVRF_ERR_BAD_ARG;
+  if (avrf_ctx_busy_(su->ctx)) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
   if (!su->n_srs) return AVRF_SRS_LOOKUP_FAILED;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
@@ -1552,6 +1557,7 @@ void avrf_ring_vk_builder_free(avrf_ring_vk_builder *b) { delete b; }
 size_t avrf_ring_vk_builder_free_slots(const avrf_ring_vk_builder *b) { return b ? b->setup->keyset - b->curr : 0; }
 int avrf_ring_vk_builder_append(avrf_ring_vk_builder *b, const uint8_t *pks_xy, size_t n) {
   if (!b || (n && !pks_xy)) return AVRF_ERR_BAD_ARG;
+  if (avrf_ctx_busy_(b->setup->ctx)) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(b->setup->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   return guarded([&] { return with_ring(b->setup->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::builder_append(b, pks_xy, n); }); });
 }
@@ -1565,6 +1571,7 @@ int avrf_ring_vk_builder_finalize(const avrf_ring_vk_builder *b, uint8_t *commit
 
 int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const uint8_t *blindings, int blinding_mode, uint8_t *proofs_out) {
   if (!k || (n && (!key_index || !blindings || !proofs_out))) return AVRF_ERR_BAD_ARG;
+  if (avrf_ctx_busy_(k->setup->ctx)) return AVRF_ERR_BAD_ARG;
   if (blinding_mode != 0 && blinding_mode != 1) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(k->setup->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   const size_t plen = k->setup->curve == 0 ? 592 : 480;
@@ -1602,6 +1609,7 @@ static int copy_out(const std::vector<uint8_t> &v, uint8_t *out, size_t cap, siz
 }
 int avrf_ring_verifier_setup_load(avrf_ctx *ctx, const uint8_t *params, size_t params_len, size_t ring_size, avrf_ring_setup **out) {
   if (!ctx || !params || !out || ring_size == 0) return AVRF_ERR_BAD_ARG;
+  if (avrf_ctx_busy_(ctx)) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
   if (!ring_suite(avrf_ctx_suite_(ctx))) return AVRF_ERR_BAD_ARG;
   return guarded([&] { return with_ring(avrf_ctx_suite_(ctx), [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::verifier_setup_load(ctx, params, params_len, ring_size, out); }); });
@@ -1621,6 +1629,7 @@ int avrf_ring_setup_serialize(avrf_ring_setup *su, int compress, uint8_t *out, s
 }
 int avrf_ring_builder_params_serialize(avrf_ring_setup *su, int compress, uint8_t *out, size_t out_cap, size_t *out_len) {
   if (!su) return AVRF_ERR_BAD_ARG;
+  if (avrf_ctx_busy_(su->ctx)) return AVRF_ERR_BAD_ARG;
   if (!su->n_srs) return AVRF_SRS_LOOKUP_FAILED;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   std::vector<uint8_t> v;
@@ -1631,6 +1640,7 @@ int avrf_ring_builder_params_serialize(avrf_ring_setup *su, int compress, uint8_
 int avrf_ring_verify_each(avrf_ring_setup *su, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,
                           const uint8_t *instances_xy, const uint8_t *ring_proofs, int32_t *status_out) {
   if (!su || (n && (!ring_commitments || !n_rings || !instances_xy || !ring_proofs || !status_out))) return AVRF_ERR_BAD_ARG;
+  if (avrf_ctx_busy_(su->ctx)) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   return guarded([&] {
     return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs, status_out); }); });
@@ -1638,6 +1648,7 @@ int avrf_ring_verify_each(avrf_ring_setup *su, size_t n, const uint8_t *ring_com
 
 int avrf_ring_pairing_check(avrf_ring_setup *su, size_t n, const uint8_t *a_xy, const uint8_t *b_xy, int32_t *ok_out) {
   if (!su || (n && (!a_xy || !b_xy || !ok_out))) return AVRF_ERR_BAD_ARG;
+  if (avrf_ctx_busy_(su->ctx)) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   return guarded([&] { return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::pairing_check(su, n, a_xy, b_xy, ok_out); }); });
 }
@@ -1645,6 +1656,7 @@ int avrf_ring_pairing_check(avrf_ring_setup *su, size_t n, const uint8_t *a_xy, 
 int avrf_ring_batch_verify(avrf_ring_setup *su, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,
                            const uint8_t *instances_xy, const uint8_t *ring_proofs) {
   if (!su || (n && (!ring_commitments || !n_rings || !instances_xy || !ring_proofs))) return AVRF_ERR_BAD_ARG;
+  if (avrf_ctx_busy_(su->ctx)) return AVRF_ERR_BAD_ARG;
   if (hipSetDevice(su->device) != hipSuccess) return AVRF_ERR_NO_DEVICE;
   return guarded([&] {
     return with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::verify_batch(su, n, ring_commitments, ring_of_item, n_rings, instances_xy, ring_proofs); }); });

@@ -113,7 +113,7 @@ AVRF_DI te_ext schnorr_lhs(const BatchDev &b, te_ext *ws, const uint8_t *ios, co
   return te_smul_multi_glv<S, false>(ws, pre_from_aff<S>(ia), s, pre_from_aff<S>(ia), fp_zero(), te_pre_neg<S>(pre_from_aff<S>(oa)), c);
 }
 // the item's window-table slots in the context's workspace (proto_dev.h te_smul_ws)
-AVRF_DI te_ext *item_ws(const BatchDev &b, uint32_t j) { return b.tabs + (size_t)j * ITEM_TAB_SLOTS; }
+AVRF_DI te_ext *item_ws(const BatchDev &b, uint32_t j) { return b.tabs + (size_t)(j - b.first) * ITEM_TAB_SLOTS; }
 
 // ---------------------------------------------------------------- Thin VRF
 
@@ -123,7 +123,7 @@ template <class S, bool TINY>
 __global__ void __launch_bounds__(128, AVRF_ITEM_WAVES)
 k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict__ flags) {
   using Fr = typename S::Fr;
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t j = b.first + blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= b.n) return;
   uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
   const uint8_t *ios = b.ios_xy + 128 * (size_t)io0;
@@ -179,7 +179,7 @@ template <class S>
 __global__ void __launch_bounds__(128, AVRF_ITEM_WAVES)
 k_tiny_verify(BatchDev b, int32_t *__restrict__ status) {
   using Fr = typename S::Fr;
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t j = b.first + blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= b.n) return;
   uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
   const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pk_xy = b.pks_xy + 64 * (size_t)j, *pr = b.proofs + 48 * (size_t)j;
@@ -200,7 +200,7 @@ template <class S>
 __global__ void __launch_bounds__(128, AVRF_ITEM_WAVES)
 k_thin_verify(BatchDev b, int32_t *__restrict__ status) {
   using Fr = typename S::Fr; using Fq = typename S::Fq;
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t j = b.first + blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= b.n) return;
   uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
   const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pk_xy = b.pks_xy + 64 * (size_t)j, *pr = b.proofs + 96 * (size_t)j;
@@ -224,7 +224,7 @@ template <class S>
 __global__ void __launch_bounds__(128, AVRF_ITEM_WAVES)
 k_ped_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ blindings_out, uint32_t *__restrict__ flags) {
   using Fr = typename S::Fr;
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t j = b.first + blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= b.n) return;
   uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
   const uint8_t *ios = b.ios_xy + 128 * (size_t)io0;
@@ -274,7 +274,7 @@ template <class S>
 __global__ void __launch_bounds__(128, AVRF_ITEM_WAVES)
 k_ped_verify(BatchDev b, int32_t *__restrict__ status) {
   using Fr = typename S::Fr; using Fq = typename S::Fq;
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t j = b.first + blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= b.n) return;
   uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
   const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pr = b.proofs + 256 * (size_t)j;
@@ -567,21 +567,21 @@ template <class S> void SingleOps<S>::smul(const uint8_t *d_scalars, const uint8
   hipLaunchKernelGGL(k_smul<S>, dim3((n + 127) / 128), dim3(128), 0, st, d_scalars, d_points_xy, n, d_out, d_flags, (const te_pre *)d_fixed);
 }
 template <class S> void SingleOps<S>::thin_prove(const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny) {
-  const dim3 g((b.n + 127) / 128), bl(128);
+  const dim3 g((b.n - b.first + 127) / 128), bl(128);
   if (tiny) hipLaunchKernelGGL((k_thin_prove<S, true>), g, bl, 0, st, b, d_proofs_out, d_flags);
   else hipLaunchKernelGGL((k_thin_prove<S, false>), g, bl, 0, st, b, d_proofs_out, d_flags);
 }
 template <class S> void SingleOps<S>::tiny_verify(const BatchDev &b, int32_t *d_status, hipStream_t st) {
-  hipLaunchKernelGGL(k_tiny_verify<S>, dim3((b.n + 127) / 128), dim3(128), 0, st, b, d_status);
+  hipLaunchKernelGGL(k_tiny_verify<S>, dim3((b.n - b.first + 127) / 128), dim3(128), 0, st, b, d_status);
 }
 template <class S> void SingleOps<S>::thin_verify(const BatchDev &b, int32_t *d_status, hipStream_t st) {
-  hipLaunchKernelGGL(k_thin_verify<S>, dim3((b.n + 127) / 128), dim3(128), 0, st, b, d_status);
+  hipLaunchKernelGGL(k_thin_verify<S>, dim3((b.n - b.first + 127) / 128), dim3(128), 0, st, b, d_status);
 }
 template <class S> void SingleOps<S>::ped_prove(const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st) {
-  hipLaunchKernelGGL(k_ped_prove<S>, dim3((b.n + 127) / 128), dim3(128), 0, st, b, d_proofs_out, d_blind, d_flags);
+  hipLaunchKernelGGL(k_ped_prove<S>, dim3((b.n - b.first + 127) / 128), dim3(128), 0, st, b, d_proofs_out, d_blind, d_flags);
 }
 template <class S> void SingleOps<S>::ped_verify(const BatchDev &b, int32_t *d_status, hipStream_t st) {
-  hipLaunchKernelGGL(k_ped_verify<S>, dim3((b.n + 127) / 128), dim3(128), 0, st, b, d_status);
+  hipLaunchKernelGGL(k_ped_verify<S>, dim3((b.n - b.first + 127) / 128), dim3(128), 0, st, b, d_status);
 }
 template <class S> void SingleOps<S>::hash_to_curve(const uint8_t *d_data, const uint32_t *d_off, uint32_t n, uint8_t *d_out, int32_t *d_status, hipStream_t st) {
   hipLaunchKernelGGL(k_hash_to_curve<S>, dim3((n + 127) / 128), dim3(128), 0, st, d_data, d_off, n, d_out, d_status);

@@ -139,11 +139,64 @@ int avrf_thin_batch_run(avrf_ctx *ctx);
  *   avrf_batch_run_hash   waits for them, returns AVRF_INVALID_DATA as the one-call form would, hashes the weight transcript
  *                         on the calling thread, enqueues the terms kernel and the MSM, returns without waiting;
  *   avrf_batch_run_end    waits for the MSM and returns the verdict (AVRF_OK / AVRF_VERIFICATION_FAILURE).
- * Results are those of avrf_thin_batch_run / avrf_pedersen_batch_run (which are these three in a row).  A context takes no
- * other call between begin and end; a call out of order returns AVRF_ERR_BAD_ARG; an error ends the sequence. */
+ * Results are those of avrf_thin_batch_run / avrf_pedersen_batch_run (which are these three in a row).  Between begin and
+ * end the run owns the context: EVERY other entry point that takes the context (staging, MSMs, challenges / partials, scalar
+ * multiplications, the point codecs, the per-item provers / verifiers, the avrf_ring_* calls of setups created from it)
+ * returns AVRF_ERR_BAD_ARG and leaves the run undisturbed; _begin / _hash / _end out of order return AVRF_ERR_BAD_ARG too;
+ * an error status from _hash or _end ends the run (the context is idle again). */
 int avrf_batch_run_begin(avrf_ctx *ctx);
 int avrf_batch_run_hash(avrf_ctx *ctx);
 int avrf_batch_run_end(avrf_ctx *ctx);
+
+/* ---- Ownership of host buffers; page-locked memory (SURVEY.md 8b "Ownership").
+ * Every entry point copies what it needs out of the caller's buffers before it returns, EXCEPT avrf_pool_submit (below), whose
+ * copies are left in flight.  From ordinary (pageable) memory a copy to the device goes through the runtime's bounce buffers
+ * at ~10 GB/s of a host core; from page-locked memory it is a DMA transfer that costs no host time and overlaps kernels.
+ * avrf_host_alloc returns page-locked memory for the batch buffers (pks / ios / ads / proofs / counts); avrf_host_register
+ * pins memory the caller already owns (page-aligned ranges are cheapest; unregister before freeing it). */
+int avrf_host_alloc(size_t bytes, void **out);
+void avrf_host_free(void *p);
+int avrf_host_register(void *p, size_t bytes);
+int avrf_host_unregister(void *p);
+
+/* ---- avrf_pool: many BatchVerifier::verify jobs in flight on one device (thin::BatchVerifier src/thin.rs:188-326 when
+ * kind = 1, pedersen::BatchVerifier src/pedersen.rs:303-426 when kind = 2) -- the form a service that verifies batch after
+ * batch wants, and the one bench.py measures.  The reference's verify() is one call on one thread; here a batch is device
+ * work, 3.5 ms of a host core for the sequential weight transcript (src/thin.rs:274-279), then 0.6 ms of device work, so
+ * throughput comes from overlapping many batches, and host time per batch is what bounds a node with several GPUs.
+ *   n_slots    batches that can be staged at once (inputs + transcript records, ~30 MB each at 65 536 items);
+ *   n_lanes    streams + MSM workspaces (~150 MB each) the MSM chains run on; waiting batches hold no lane;
+ *   lane_depth chains queued behind each other on one lane (0 = 3): a host thread that has just hashed a group of transcripts
+ *              enqueues ALL their chains at once and goes back to hashing while the device works through them (few streams,
+ *              deep queues: more than ~20 streams in flight slow the device down);
+ *   n_threads  native host threads; each owns a share of the slots and lanes and is driven by completion events;
+ *   hash_group transcripts a thread hashes TOGETHER: 1 = one scalar SHA-512 chain at a time (lowest latency; right when the
+ *              process has >= ~4 cores per GPU), 8 / 16 = the AVX-512 multi-buffer code (3.5-5 x the hashes per core-second at
+ *              the price of latency; right for 1-3 cores per GPU; falls back to 1 without AVX-512).
+ * avrf_pool_submit hands over one batch (arguments as avrf_thin_batch_stage; pks_xy NULL for kind 2) and returns a ticket
+ * at once; THE BUFFERS MUST STAY UNTOUCHED UNTIL avrf_pool_wait HAS RETURNED FOR THAT TICKET (the copies are asynchronous).
+ * It blocks while every slot is in flight and returns AVRF_ERR_BAD_ARG when every slot holds an uncollected verdict.
+ * avrf_pool_wait blocks until the verdict of `ticket` is out: *status = AVRF_OK / AVRF_VERIFICATION_FAILURE /
+ * AVRF_INVALID_DATA exactly as avrf_thin_batch_verify would return for that batch.  avrf_pool_resubmit runs the batch of a
+ * collected ticket again (from_host = 0: the copy resident in HBM; 1: staged again from the same host buffers).
+ * avrf_pool_cycle is the measurement loop: every slot that holds a collected batch is run again and again by the workers
+ * themselves until the region consists of whole blocks of `steps_block` runs and has lasted `min_seconds` (0: one block;
+ * max_steps bounds it), no foreign-function call per step; returns the runs made, how many returned something else than
+ * `expect_status`, and the time from the first launch to the last verdict.
+ * avrf_pool_stats: out[0..4] host-thread CPU microseconds spent in staging + prepare launches / collecting / hashing /
+ * terms + MSM launches / folding, out[6] hash groups, out[7] transcripts hashed, out[8] times a thread slept, out[9] / out[10]
+ * total milliseconds / launches of the dominant kernel (k_accumulate, HIP events on the lanes' streams); n_out >= 11. */
+typedef struct avrf_pool avrf_pool;
+int avrf_pool_create(int suite, int device, int kind, int n_slots, int n_lanes, int lane_depth, int n_threads, int hash_group, avrf_pool **out);
+void avrf_pool_destroy(avrf_pool *pool);
+int avrf_pool_set_validation(avrf_pool *pool, int level);
+int avrf_pool_submit(avrf_pool *pool, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
+                     const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, uint64_t *ticket);
+int avrf_pool_wait(avrf_pool *pool, uint64_t ticket, int *status);
+int avrf_pool_resubmit(avrf_pool *pool, uint64_t ticket, int from_host, uint64_t *new_ticket);
+int avrf_pool_cycle(avrf_pool *pool, int from_host, uint64_t steps_block, double min_seconds, uint64_t max_steps, int expect_status,
+                    uint64_t *steps_done, uint64_t *mismatches, double *seconds);
+int avrf_pool_stats(avrf_pool *pool, int reset, double *out, size_t n_out);
 
 /* pedersen::BatchVerifier split the same way (src/pedersen.rs:341-426): stage the shard with avrf_pedersen_batch_stage,
  * avrf_pedersen_batch_challenges -> n_shard x 16 bytes, avrf_batch_weight_seed(pedersen = 1) over all items

@@ -38,7 +38,7 @@ def test_launcher_starts_n_ranks_and_prints_one_line():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_counted"] == 2 and out["master_addr"] == "127.0.0.1" and out["local_rank"] == "0"
-    assert out["contexts_per_rank"] >= 1
+    assert out["slots_per_rank"] >= 1 and out["host_threads_per_rank"] >= 1
 
 
 def test_under_a_launcher_the_process_is_a_rank():
@@ -53,18 +53,27 @@ def test_under_a_launcher_the_process_is_a_rank():
 
 
 def test_host_plan_follows_the_quota():
-    """contexts per rank and hashing mode from the CPU quota divided by the ranks (bench.host_plan)"""
+    """slots, lanes, native host threads and the hash group of a rank's pool from the CPU quota divided by the ranks (bench.host_plan)"""
     sys.path.insert(0, ROOT)
     import bench
-    streams, mb, cores, threads = bench.host_plan(16, 1, 0, 480)
-    assert (streams, mb, cores, threads) == (21, 0, 16.0, 7)      # seven host threads keep three contexts each in flight
-    streams, mb, cores, threads = bench.host_plan(16, 8, 0, 480)  # 2 cores per rank: the multi-buffer service, 8 lanes per thread
-    assert mb == 2 and streams == 20 and cores == 2.0 and threads == 20     # ... with one host thread per context
-    assert bench.host_plan(256, 8, 0, 480) == (21, 0, 32.0, 7)
-    assert bench.host_plan(16, 2, 0, 480)[::3] == (21, 7) and bench.host_plan(12, 2, 0, 480)[::3] == (18, 6)
-    assert bench.host_plan(16, 4, 0, 480) == (12, 0, 4.0, 4)      # 4 cores per rank: still scalar chains, four pipelined threads
-    assert bench.host_plan(16, 1, 0, 20)[::3] == (21, 7)                                     # (a block of steps may be smaller than the contexts)
-    assert bench.host_plan(16, 1, 12, 480)[::3] == (12, 7)                                   # --streams overrides
-    assert bench.host_plan(16, 1, 20, 480, 20)[::3] == (20, 20)                              # --host-threads: one thread per context
-    assert all(bench.host_plan(q, w, 0, 480)[0] <= 23 for q in (1, 2, 4, 16, 64, 256) for w in (1, 2, 4, 8))   # 24 contexts halve the rate
+    p = bench.host_plan(16, 1)
+    assert (p["slots"], p["lanes"], p["threads"], p["group"], p["cores"]) == (28, 14, 7, 1, 16.0)   # seven threads, four slots and two lanes each, scalar chains
+    p = bench.host_plan(16, 8)                                    # 2 cores per rank: eight transcripts hashed together, three groups per thread
+    assert (p["threads"], p["group"], p["cores"]) == (2, 8, 2.0) and p["slots"] == 48 and p["lanes"] == 12
+    assert bench.host_plan(256, 8)["threads"] == 7 and bench.host_plan(256, 8)["group"] == 1
+    assert bench.host_plan(16, 2)["threads"] == 7 and bench.host_plan(12, 2)["threads"] == 4 and bench.host_plan(12, 2)["slots"] == 96
+    p = bench.host_plan(16, 4)                                    # 4 cores per rank: multi-buffer hashing on four threads
+    assert (p["slots"], p["threads"], p["group"], p["lanes"]) == (96, 4, 8, 12)
+    p = bench.host_plan(16, 1, slots_arg=12)                      # --slots overrides
+    assert (p["slots"], p["threads"], p["lanes"]) == (12, 7, 12)
+    p = bench.host_plan(16, 1, slots_arg=20, threads_arg=20)
+    assert (p["slots"], p["threads"]) == (20, 20)
+    p = bench.host_plan(2, 1, group_arg=16)
+    assert (p["group"], p["slots"], p["threads"]) == (16, 96, 2)
+    for q in (1, 2, 4, 16, 64, 256):
+        for w in (1, 2, 4, 8):
+            p = bench.host_plan(q, w)
+            assert 1 <= p["threads"] <= p["lanes"] <= p["slots"] and p["lanes"] + p["threads"] <= 21     # lanes + ingest streams
+    cp = bench.pick_cpus(2)
+    assert len(cp) == min(2, len(os.sched_getaffinity(0))) and len(set(cp)) == len(cp)
     assert bench.cpu_quota() >= 1

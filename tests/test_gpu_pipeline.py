@@ -114,3 +114,41 @@ def test_interleaved_contexts_on_one_thread(nat):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_no_other_call_while_a_run_is_open(nat):
+    """avrf_thin_batch_partial between _hash and _end ran its own MSM on the context's workspace, consumed the pending
+    chain, and _end then folded NOTHING into the identity = AVRF_OK for a tampered batch.  Every entry point that touches the
+    context is refused while a run is open, the run itself is not disturbed, and a finish without an enqueued chain is an error."""
+    import ctypes as C
+    L = nat.lib()
+    c = nat.Context(0)
+    try:
+        n = 500
+        b = orc.gen_batch(0, 0, n)
+        pr = bytearray(b["proofs"]); pr[96 * 17 + 64] ^= 1; b["proofs"] = bytes(pr)       # tampered: the verdict must be 1
+        assert orc.thin_batch_verify_xy(0, b) == 1
+        assert c.thin_batch_stage(nat_batch(b)) == 0
+        chal = (C.c_uint8 * (16 * n))()
+        assert L.avrf_thin_batch_challenges(c._h, chal) == 0                              # (legal before the run: the old hole)
+        seed, out = (C.c_uint8 * 64)(), (C.c_uint8 * 64)()
+        one_xy, one_sc = (C.c_uint8 * 64)(*IDENTITY_XY), (C.c_uint8 * 32)()
+        st4 = (C.c_int32 * 4)()
+        for phase in ("begin", "hash"):
+            assert getattr(c, "batch_run_" + phase)() == 0
+            assert L.avrf_thin_batch_partial(c._h, seed, C.c_uint64(0), out) == BAD_ARG
+            assert L.avrf_thin_batch_challenges(c._h, chal) == BAD_ARG
+            assert L.avrf_msm_te(c._h, C.c_size_t(1), one_xy, one_sc, out) == BAD_ARG
+            assert L.avrf_msm_te_mont(c._h, C.c_size_t(1), one_xy, one_sc, out) == BAD_ARG
+            assert L.avrf_scalar_mul(c._h, C.c_size_t(1), one_sc, one_xy, out) == BAD_ARG
+            assert L.avrf_scalar_mul_base(c._h, C.c_size_t(1), one_sc, out) == BAD_ARG
+            assert L.avrf_points_compress(c._h, C.c_size_t(1), one_xy, out) == BAD_ARG
+            assert L.avrf_points_decompress(c._h, C.c_size_t(1), one_sc, out, 0, st4) == BAD_ARG
+            assert c.thin_batch_stage(nat_batch(b)) == BAD_ARG
+        assert c.batch_run_end() == 1                                                      # the run was not disturbed: still REJECTED
+        assert c.batch_run_end() == BAD_ARG                                                # and it is closed
+        # the context is usable again
+        assert c.thin_batch_run() == 1
+        assert L.avrf_thin_batch_partial(c._h, seed, C.c_uint64(0), out) == 0              # legal again once the run is closed
+    finally:
+        c.close()

@@ -1,0 +1,124 @@
+"""avrf_pool (include/avrf.h, csrc/pool.hip): many BatchVerifier::verify jobs in flight, native host threads, grouped weight
+hashing, page-locked ingest.  Verdicts must be those of thin::BatchVerifier::verify (src/thin.rs:257-325) /
+pedersen::BatchVerifier::verify (src/pedersen.rs:341-426), i.e. of the oracle and of the one-call entry points."""
+import pytest
+
+import oracle as orc
+from helpers import IDENTITY_XY, nat_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from ark_vrf_amd import _native as nat
+    return nat
+
+
+def variants(suite, kind, n, seed):
+    """a valid batch, one with a tampered response, one with a tampered proof point, (thin) one with an identity public key"""
+    b = orc.gen_batch(suite, kind, n, start=100000 * seed)
+    if kind == 1:
+        b["pks_xy"] = b""
+    psz = len(b["proofs"]) // n
+    out = [b]
+    pr = bytearray(b["proofs"]); pr[psz * (n // 2) + psz - 32] ^= 1
+    out.append(dict(b, proofs=bytes(pr)))
+    pr = bytearray(b["proofs"]); j = n - 1; pr[psz * j: psz * j + 64] = b["proofs"][psz * 0: psz * 0 + 64]     # another item's nonce point
+    out.append(dict(b, proofs=bytes(pr)))
+    if kind == 0:
+        pk = bytearray(b["pks_xy"]); pk[64 * 3: 64 * 4] = bytes(64) if suite == 7 else IDENTITY_XY   # (short Weierstrass: the identity is all-zero)
+        out.append(dict(b, pks_xy=bytes(pk)))
+    return out
+
+
+@pytest.mark.parametrize("suite,kind,group", [(0, 0, 1), (0, 0, 8), (0, 0, 16), (0, 1, 8), (1, 0, 16), (5, 0, 8), (5, 1, 1), (7, 0, 8)])
+def test_pool_verdicts_match_oracle_and_one_call(nat, suite, kind, group):
+    want_fn = orc.thin_batch_verify_xy if kind == 0 else orc.pedersen_batch_verify_xy
+    bs = []
+    for i, n in enumerate((300, 257, 64)):
+        bs += variants(suite, kind, n, i)
+    want = [want_fn(suite, b) for b in bs]
+    assert 0 in want and 1 in want and (kind == 1 or 2 in want)
+    c = nat.Context(suite)
+    one_call = []
+    for b in bs:
+        stage = c.thin_batch_stage if kind == 0 else c.pedersen_batch_stage
+        run = c.thin_batch_run if kind == 0 else c.pedersen_batch_run
+        assert stage(nat_batch(b)) == 0
+        one_call.append(run())
+    c.close()
+    assert one_call == want
+    pool = nat.Pool(suite, kind=kind + 1, slots=5, lanes=2, threads=2, hash_group=group, depth=(1 if group == 1 else 0))
+    try:
+        nbs = [nat_batch(b) for b in bs]
+        got = {}
+        tickets = []
+        for k, nb in enumerate(nbs):                                   # more batches than slots: submit blocks only while all are in flight
+            if len(tickets) == 5:
+                t0, k0 = tickets.pop(0)
+                got[k0] = pool.wait(t0)
+            tickets.append((pool.submit(nb), k))
+        for t0, k0 in tickets:
+            got[k0] = pool.wait(t0)
+        assert [got[k] for k in range(len(bs))] == want
+    finally:
+        pool.close()
+
+
+def test_pool_resubmit_cycle_and_pinned_ingest(nat):
+    suite, n = 0, 1000
+    good = orc.gen_batch(suite, 0, n)
+    pr = bytearray(good["proofs"]); pr[96 * 11 + 64] ^= 1
+    bad = dict(good, proofs=bytes(pr))
+    assert orc.thin_batch_verify_xy(suite, good) == 0 and orc.thin_batch_verify_xy(suite, bad) == 1
+    pool = nat.Pool(suite, kind=1, slots=6, lanes=3, threads=2, hash_group=8)
+    try:
+        def pinned(b):
+            return nat.PinnedBatch(b["n"], b["ios_xy"], b["io_counts"], b["ads"], b["ad_lens"], pks_xy=b["pks_xy"], proofs=b["proofs"])
+        # the same batches from pageable and from page-locked buffers: same verdicts
+        batches = [nat_batch(good), pinned(good), nat_batch(bad), pinned(bad), pinned(good), nat_batch(good)]
+        tk = [pool.submit(b) for b in batches]
+        assert [pool.wait(t) for t in tk] == [0, 0, 1, 1, 0, 0]
+        # run the resident copies again, and stage them again from the host buffers
+        tk2 = [pool.resubmit(t, from_host=(i % 2 == 1)) for i, t in enumerate(tk)]
+        assert [pool.wait(t) for t in tk2] == [0, 0, 1, 1, 0, 0]
+        with pytest.raises(nat.AvrfError):
+            pool.wait(tk[0])                                           # a collected ticket is gone
+        # cycle mode refuses mixed expectations: slots 2 and 3 hold the tampered batch
+        done, mism, sec = pool.cycle(steps_block=6, min_seconds=0.0, expect=0)
+        assert done == 6 and mism == 2 and sec > 0
+        # make all six good (the resident tampered copies are overwritten), then whole blocks only
+        tk3 = [pool.submit(b) for b in (batches[0], batches[1], batches[4], batches[5], batches[0], batches[1])]
+        assert [pool.wait(t) for t in tk3] == [0] * 6
+        for from_host in (False, True):
+            done, mism, sec = pool.cycle(steps_block=7, min_seconds=0.05, from_host=from_host, expect=0)
+            assert mism == 0 and done >= 7 and done % 7 == 0
+        done, mism, sec = pool.cycle(steps_block=5, min_seconds=10.0, max_steps=20, expect=0)
+        assert (done, mism) == (20, 0)
+        st = pool.stats()
+        assert st["hashed"] >= 6 and st["accumulate_launches"] >= 6 and st["cpu_us_hash"] > 0
+    finally:
+        pool.close()
+
+
+def test_pool_empty_and_error_paths(nat):
+    pool = nat.Pool(0, kind=1, slots=2, lanes=1, threads=1, hash_group=1)
+    try:
+        e = orc.gen_batch(0, 0, 0)
+        assert pool.wait(pool.submit(nat_batch(e))) == 0               # src/thin.rs:262-264
+        b = orc.gen_batch(0, 0, 40)
+        t1, t2 = pool.submit(nat_batch(b)), pool.submit(nat_batch(b))
+        import ctypes as C
+        tk = C.c_uint64(0); nb = nat_batch(b)
+        for _ in range(50):                                            # both slots hold uncollected verdicts: a third submit is refused
+            import time; time.sleep(0.02)
+        assert nat.lib().avrf_pool_submit(pool._h, C.c_size_t(nb.n), nb.pks_xy, nb.ios_xy, nb.io_counts, nb.ads, nb.ad_lens, nb.proofs, C.byref(tk)) == -2
+        assert pool.wait(t2) == 0 and pool.wait(t1) == 0
+        with pytest.raises(nat.AvrfError):
+            pool.wait(12345)
+        pool.set_validation(1)
+        off = bytearray(b["ios_xy"]); off[5] ^= 0x40                   # an I/O point off the curve
+        assert pool.wait(pool.submit(nat_batch(dict(b, ios_xy=bytes(off))))) == 2
+    finally:
+        pool.close()
