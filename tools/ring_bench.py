@@ -14,6 +14,8 @@ from ark_vrf_amd.ring import RingSetup  # noqa: E402
 ring = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 nproofs = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 suite = int(sys.argv[4]) if len(sys.argv) > 4 else 0                # 0 Bandersnatch/BLS12-381, 1 Baby-JubJub/BN254
+if os.environ.get("AVRF_BLOCKING") == "1":                          # waiting host threads sleep in the driver (what bench.py's ranks do)
+    assert nat.set_blocking_sync(0, True) == 0
 ctx = nat.Context(suite)
 srs = open(os.path.join(ROOT, "tests", "golden", ["bls12-381-srs-2-11-uncompressed-zcash.bin", "bn254-testing-2-9-uncompressed.bin"][suite]), "rb").read()
 fq = 48 if suite == 0 else 32
