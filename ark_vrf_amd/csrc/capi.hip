@@ -300,6 +300,11 @@ static int stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint
                  const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
   return ctx_stage(c, kind, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs, true);
 }
+// the per-item entry points wait for the stream before they return: their staging copies need no wait of their own
+static int stage_nowait(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy,
+                        const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
+  return ctx_stage(c, kind, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs, false);
+}
 
 int avrf_thin_batch_stage(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
                           const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
@@ -745,15 +750,37 @@ static int read_flags(avrf_ctx *c) {
   return (int)*c->h_flags.as<uint32_t>();
 }
 
+// few items with one I/O pair each: the kernels that spread an item over 32 lanes (vrf_single.hip "few items")
+static bool wave_shape(const avrf_ctx *c, size_t n, const uint32_t *io_counts) {
+  if (!n || n > (size_t)AVRF_WAVE_ITEMS_MAX || c->tot_io != n) return false;
+  static const bool off = getenv("AVRF_NO_WAVE_ITEMS") != nullptr;     // (A/B hook)
+  if (off) return false;
+  for (size_t j = 0; j < n; j++) if (io_counts[j] != 1) return false;
+  return true;
+}
+
 int avrf_thin_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
                     const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out) {
   if (n && (!sks || !proofs_out)) return AVRF_ERR_BAD_ARG;
-  int st = stage(c, 1, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, nullptr);
+  int st = stage_nowait(c, 1, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, nullptr);
   if (st || !n) return st;
   c->staged_kind = 0;
   HIP_TRY(c->d_out.ensure(n * 96));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
   double t0 = now_us();
+  if (pks_xy && wave_shape(c, n, io_counts)) {
+    HIP_TRY(c->d_status.ensure(n * 4)); HIP_TRY(c->h_c.ensure(n * 4));
+    if (launch_thin_prove_wave(c->suite, batch_of(c), c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->d_status.as<int32_t>(), c->stream)) {
+      HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, n * 96, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(c->h_c.p, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+      int f = read_flags(c);
+      if (f < 0) return AVRF_ERR_NO_DEVICE;
+      bool fallback = false;
+      for (size_t j = 0; j < n; j++) fallback |= c->h_c.as<int32_t>()[j] == AVRF_WAVE_FALLBACK;
+      if (!fallback) { c->timing[0] = now_us() - t0; return f ? AVRF_INVALID_DATA : AVRF_OK; }
+      HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));          // a degenerate point somewhere: the lane-per-item kernel takes the call
+    }
+  }
   if (int e = per_item_chunks(c, pks_xy != nullptr, [&](const BatchDev &b) { launch_thin_prove(c->suite, b, c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream); })) return e;
   HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, n * 96, hipMemcpyDeviceToHost, c->stream));
   int f = read_flags(c);
@@ -765,10 +792,18 @@ int avrf_thin_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pk
 int avrf_thin_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
                      const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, int32_t *status_out) {
   if (n && (!pks_xy || !proofs || !status_out)) return AVRF_ERR_BAD_ARG;
-  int st = stage(c, 1, n, nullptr, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs);
+  int st = stage_nowait(c, 1, n, nullptr, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs);
   if (st || !n) return st;
   HIP_TRY(c->d_status.ensure(n * 4));
   double t0 = now_us();
+  if (wave_shape(c, n, io_counts) && launch_thin_verify_wave(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream)) {
+    validate_staged(c, 1, c->d_status.as<int32_t>());
+    HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
+    bool fallback = false;
+    for (size_t j = 0; j < n; j++) fallback |= status_out[j] == AVRF_WAVE_FALLBACK;
+    if (!fallback) { c->timing[0] = now_us() - t0; return AVRF_OK; }     // (else a degenerate point somewhere: the lane-per-item kernel takes the call)
+  }
   if (int e = per_item_chunks(c, true, [&](const BatchDev &b) { launch_thin_verify(c->suite, b, c->d_status.as<int32_t>(), c->stream); })) return e;
   validate_staged(c, 1, c->d_status.as<int32_t>());                   // Validate::Yes failures overwrite the item's status with InvalidData
   HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));

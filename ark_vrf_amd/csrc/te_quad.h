@@ -47,6 +47,54 @@ template <class S> __device__ __noinline__ static fp q_add(fp a, fp b, uint32_t 
   return fp_mul<Fq>(qperm<0, 1, 0, 3>(U), qperm<3, 2, 1, 2>(U));
 }
 
+// coordinate j of 2 P given coordinate j of P (dbl-2008-hwcd): two rounds instead of the addition's three --
+//   round 1   lane 0: X^2, lane 1: Y^2, lane 2: (X + Y)^2, lane 3: Z^2        (T is not an input of a doubling)
+//   linear    lane 0: E = (X+Y)^2 - A - B; lane 1: H = aA - B; lane 2: G = aA + B; lane 3: F = G - 2 Z^2
+//   round 2   lane 0: E F; lane 1: G H; lane 2: E H; lane 3: F G
+template <class S> __device__ __noinline__ static fp q_dbl(fp a, uint32_t j) {
+  using Fq = typename S::Fq;
+  const fp sa = fp_add<Fq>(a, qperm<1, 0, 3, 2>(a));
+  const fp m1 = fp_sqr<Fq>(fp_sel(j == 2, qperm<0, 1, 0, 3>(sa), a));
+  const fp A = qperm<0, 0, 0, 0>(m1), B = qperm<1, 1, 1, 1>(m1), Sq = qperm<2, 2, 2, 2>(m1), ZZ = qperm<3, 3, 3, 3>(m1);
+  const fp aA = mul_a<S>(A);
+  const fp X = fp_sel(j == 0, Sq, fp_sel(j == 1, aA, fp_add<Fq>(aA, B)));
+  const fp Y = fp_sel(j == 0, fp_add<Fq>(A, B), fp_sel(j == 1, B, fp_sel(j == 2, fp_zero(), fp_add<Fq>(ZZ, ZZ))));
+  const fp U = fp_sub<Fq>(X, Y);                                   // lane 0 E, 1 H, 2 G, 3 F
+  return fp_mul<Fq>(qperm<0, 1, 0, 3>(U), qperm<3, 2, 1, 2>(U));
+}
+
+// coordinate j of k P from coordinate j of P: fixed 3-bit windows over a per-lane table {0, P, .., 7 P} (registers; the entry is
+// picked with a select chain, so the quads of a wave may hold different scalars), NBITS <= 253 bits of the plain integer k.
+// The window digits are read from the top of a left-aligned copy of k that moves up three bits per step.
+template <class S, int NBITS> __device__ static fp q_smul(const fp &base, const fp &k, uint32_t j) {
+  constexpr int NW = (NBITS + 2) / 3, W = (3 * NW + 31) / 32, SH = 32 * W - 3 * NW;     // 128 bits: 43 windows in 5 words; 253: 85 in 8
+  static_assert(W <= 8 && SH < 32, "scalar window layout");
+  fp tab[8];
+  tab[0] = q_identity<S>(j); tab[1] = base; tab[2] = q_dbl<S>(base, j);
+#pragma unroll 1
+  for (int i = 3; i < 8; i++) tab[i] = q_add<S>(tab[i - 1], base, j);
+  uint32_t kk[W];
+#pragma unroll
+  for (int i = W - 1; i >= 0; i--) {
+    const uint32_t hi = i < 8 ? k.v[i] : 0u, lo = i >= 1 ? k.v[i - 1] : 0u;
+    kk[i] = SH ? (hi << SH) | (lo >> (32 - SH)) : hi;
+  }
+  fp acc = q_identity<S>(j);
+#pragma unroll 1
+  for (int w = 0; w < NW; w++) {
+    const uint32_t d = kk[W - 1] >> 29;
+#pragma unroll
+    for (int i = W - 1; i >= 1; i--) kk[i] = (kk[i] << 3) | (kk[i - 1] >> 29);
+    kk[0] <<= 3;
+    if (w) { acc = q_dbl<S>(acc, j); acc = q_dbl<S>(acc, j); acc = q_dbl<S>(acc, j); }
+    fp e = tab[0];
+#pragma unroll
+    for (uint32_t i = 1; i < 8; i++) e = fp_sel(d == i, tab[i], e);
+    acc = q_add<S>(acc, e, j);
+  }
+  return acc;
+}
+
 AVRF_DI fp fp_shfl_down(const fp &a, int delta) {
   fp r;
 #pragma unroll

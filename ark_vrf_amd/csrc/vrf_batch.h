@@ -32,6 +32,12 @@ void launch_smul(int suite, const uint8_t *d_scalars, const uint8_t *d_points_xy
 void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny = false);
 void launch_tiny_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);   // proofs: n x 48 (c16 || s32)
 void launch_thin_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
+// few items, ONE I/O pair each, twisted-Edwards suites: an item spread over 32 lanes (vrf_single.hip "few items"); false = the
+// suite has no such kernel (nothing was launched).  d_status[j] = AVRF_WAVE_FALLBACK for an item with a degenerate point: the
+// caller re-runs the call on the lane-per-item kernel.
+enum { AVRF_WAVE_ITEMS_MAX = 2048, AVRF_WAVE_FALLBACK = -99 };
+bool launch_thin_verify_wave(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
+bool launch_thin_prove_wave(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st);
 void launch_ped_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st);
 void launch_ped_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
 
@@ -62,6 +68,8 @@ template <class S> struct SingleOps {
   static void thin_prove(const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny);
   static void tiny_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
   static void thin_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
+  static bool thin_verify_wave(const BatchDev &b, int32_t *d_status, hipStream_t st);
+  static bool thin_prove_wave(const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st);
   static void ped_prove(const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st);
   static void ped_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
   static void hash_to_curve(const uint8_t *d_data, const uint32_t *d_off, uint32_t n, uint8_t *d_out, int32_t *d_status, hipStream_t st);

@@ -12,6 +12,7 @@
 #include "vrf_batch.h"
 #include "proto_dev.h"
 #include "glv.h"
+#include "te_quad.h"
 #include "suite_dispatch.h"
 
 // Built once per suite (-DAVRF_TU_SUITE=<id>: the kernels of that suite and the explicit instantiation of SingleOps<S>) and
@@ -216,6 +217,126 @@ k_thin_verify(BatchDev b, int32_t *__restrict__ status) {
   te_ext lhs = schnorr_lhs<S>(b, item_ws(b, j), ios, pk_xy, m, t, s, c);
   te_pre rp = te_make_pre<S>(fp_to_mont<Fq>(rx), fp_to_mont<Fq>(ry));
   status[j] = ext_eq_aff<S>(lhs, rp) ? 0 : 1;
+}
+
+// ---------------------------------------------------------------- Thin VRF, few items: one item spread over half a wave
+//
+// The lane-per-item kernels above walk ~3 000 DEPENDENT field multiplications per item (128 doublings + up to 192 additions on
+// one chain): 2.1-2.4 ms however few items there are, eleven times the reference's 188 us for one verification
+// (benches/SUMMARY.md:53-54).  For calls of up to AVRF_WAVE_ITEMS_MAX items an item takes 32 lanes instead: eight quads, each quad one
+// scalar multiplication with the four coordinates of a point on its four lanes (te_quad.h: a doubling is two rounds of
+// multiplications, an addition three).  The equation's terms -- s G, (s z) I, -c pk, -(c z) O for the verifier (thin.rs:158-161,
+// one pair), k G, (k z) I for the prover (thin.rs:115-119) -- are split with the endomorphism where the curve has one
+// (k P = k1 P + k2 psi(P), 127-bit halves, glv.h), one half per quad, so every quad runs the SAME 43 windows of three doublings
+// and one addition; suites without the endomorphism run 85 windows on four quads.  The eight partial results are summed with three
+// butterfly steps.  Transcript, challenge and scalar preparation are computed redundantly by the 32 lanes of the item (same
+// instruction stream, no divergence).  Results are the same group elements, hence the same verdicts and proof bytes.
+// One pair per item and a twisted-Edwards suite only; everything else stays on the lane-per-item kernels.
+template <class S> struct WaveTerm { fp coord; fp k; bool ok; };
+// coordinate jc of this quad's base point and the quad's scalar: term (p affine Montgomery, scalar k plain, negated?) split over the
+// quads 2 t (k1, P) and 2 t + 1 (k2, psi(P)) when the suite has the endomorphism; else quad 2 t takes (k, P), quad 2 t + 1 idles
+template <class S> AVRF_DI WaveTerm<S> wave_term(const fp &px, const fp &py, const fp &k, bool neg, uint32_t half, uint32_t jc) {
+  using Fq = typename S::Fq;
+  WaveTerm<S> r; r.ok = true;
+  te_ext e; e.x = px; e.y = py; e.t = fp_mul<Fq>(px, py); e.z = fp_one<Fq>();
+  fp ks = k; bool ng = neg;
+  if constexpr (S::HAS_GLV) {
+    te_pre p; p.x = px; p.y = py; p.k = fp_zero();
+    te_ext q;
+    r.ok = te_endo<S>(p, q);                                        // (x y = 0 or y^2 = b: the caller sends the item to the lane-per-item kernel)
+    const glv_scalars g = glv_decompose<S>(k);
+    ks = half ? g.k2 : g.k1; ng = neg != (half ? g.n2 : g.n1);
+    if (half) e = q;
+  } else if (half) { e = te_identity<S>(); ks = fp_zero(); }
+  fp c = jc == 0 ? e.x : jc == 1 ? e.y : jc == 2 ? e.t : e.z;
+  if (ng && (jc == 0 || jc == 2)) c = fp_neg<Fq>(c);               // -(X, Y, T, Z) = (-X, Y, -T, Z)
+  r.coord = c; r.k = ks;
+  return r;
+}
+// sum of the eight quads' points of a 32-lane item group, in every quad
+template <class S> AVRF_DI fp wave_group_sum(fp v, uint32_t jc) {
+#pragma unroll 1
+  for (int off = 16; off >= 4; off >>= 1) v = q_add<S>(v, fp_shfl_xor(v, off), jc);
+  return v;
+}
+
+template <class S>
+__global__ void __launch_bounds__(64)
+k_thin_verify_wave(BatchDev b, int32_t *__restrict__ status) {
+  using Fr = typename S::Fr; using Fq = typename S::Fq;
+  constexpr int NBITS = S::HAS_GLV ? 128 : Fr::BITS;
+  const uint32_t lane = threadIdx.x & 63, gl = lane & 31, q = gl >> 2, jc = gl & 3, tq = q >> 1, half = q & 1;
+  uint32_t j = b.first + 2 * blockIdx.x + (lane >> 5);
+  const bool live = j < b.n;
+  if (!live) j = b.n - 1;                                                       // (all lanes stay in step: the cross-lane moves need them)
+  const uint32_t io0 = b.io_off[j], ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pk_xy = b.pks_xy + 64 * (size_t)j, *pr = b.proofs + 96 * (size_t)j;
+  suite_tr<S> t; uint32_t f = 0;
+  tr_base<S>(t, DS_THIN, true, pk_xy, ios, 1, b.ads + ad0, adl, &f);
+  const fp rx = fp_load_le(pr), ry = fp_load_le(pr + 32), s = fp_load_le(pr + 64);
+  if (point_flags<S>(rx, ry) & FLAG_RANGE) f |= FLAG_RANGE;
+  if (ge_p<Fr>(s)) f |= FLAG_SCALAR;                                            // InvalidData, thin.rs:140-149 (reported below)
+  suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_xy<S>(tc, rx, ry);
+  const fp c = challenge_finish(tc);                                            // plain, 128 bits
+  auto dseed = delin_seed(t);
+  const fp z = xof128(dseed, 0);
+  // this quad's term of  s G + (s z) I - c pk - (c z) O  (thin.rs:158-161 expanded for one pair, as schnorr_lhs does)
+  const uint8_t *src = tq == 1 ? ios : tq == 2 ? pk_xy : ios + 64;
+  const te_pre g = g_pre<S>();
+  const fp px = tq == 0 ? g.x : fp_to_mont<Fq>(fp_load_le(src)), py = tq == 0 ? g.y : fp_to_mont<Fq>(fp_load_le(src + 32));
+  const fp sm = fp_to_mont<Fr>(tq < 2 ? s : c);
+  const fp k = (tq & 1) ? fp_mul<Fr>(sm, z) : (tq < 2 ? s : c);                 // s, s z, c, c z as plain integers mod r
+  const WaveTerm<S> w = wave_term<S>(px, py, k, tq >= 2, half, jc);
+  fp v = q_smul<S, NBITS>(w.coord, w.k, jc);
+  v = wave_group_sum<S>(v, jc);
+  const fp X = qperm<0, 0, 0, 0>(v), Y = qperm<1, 1, 1, 1>(v), Z = qperm<3, 3, 3, 3>(v);
+  const bool eq = fp_eq(X, fp_mul<Fq>(fp_to_mont<Fq>(rx), Z)) && fp_eq(Y, fp_mul<Fq>(fp_to_mont<Fq>(ry), Z));   // == R  (ext_eq_aff)
+  // a degenerate base point in ANY quad of the item: no verdict from here
+  uint32_t bad = w.ok ? 0u : 1u;
+  for (int off = 16; off >= 1; off >>= 1) bad |= __shfl_xor(bad, off);
+  if (live && gl == 0) status[j] = f ? 2 : bad ? (int32_t)AVRF_WAVE_FALLBACK : eq ? 0 : 1;
+}
+
+// thin::Prover::prove (thin.rs:111-135) for one pair, the same layout: R = k G + (k z) I on four quads (the other four idle)
+template <class S>
+__global__ void __launch_bounds__(64)
+k_thin_prove_wave(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict__ flags, int32_t *__restrict__ status) {
+  using Fr = typename S::Fr; using Fq = typename S::Fq;
+  constexpr int NBITS = S::HAS_GLV ? 128 : Fr::BITS;
+  const uint32_t lane = threadIdx.x & 63, gl = lane & 31, q = gl >> 2, jc = gl & 3, tq = q >> 1, half = q & 1;
+  uint32_t j = b.first + 2 * blockIdx.x + (lane >> 5);
+  const bool live = j < b.n;
+  if (!live) j = b.n - 1;
+  const uint32_t io0 = b.io_off[j], ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0;
+  const fp sk = fp_load_le(b.sks + 32 * (size_t)j);
+  uint32_t f = ge_p<Fr>(sk) ? FLAG_SCALAR : 0;
+  const fp pkx = fp_load_le(b.pks_xy + 64 * (size_t)j), pky = fp_load_le(b.pks_xy + 64 * (size_t)j + 32);
+  suite_tr<S> t; uint32_t pf = 0;
+  tr_base<S>(t, DS_THIN, true, pkx, pky, ios, 1, b.ads + ad0, adl, &pf);          // thin.rs:112
+  f |= pf & FLAG_RANGE;
+  const fp k = nonce<S>(sk, t);                                                  // thin.rs:115 (Montgomery)
+  auto dseed = delin_seed(t);
+  const fp kz = fp_mul<Fr>(k, xof128(dseed, 0));                                 // Montgomery k times plain z: plain k z mod r
+  const te_pre g = g_pre<S>();
+  const fp px = tq == 0 ? g.x : fp_to_mont<Fq>(fp_load_le(ios)), py = tq == 0 ? g.y : fp_to_mont<Fq>(fp_load_le(ios + 32));
+  const fp ks = tq == 0 ? fp_from_mont<Fr>(k) : tq == 1 ? kz : fp_zero();
+  const WaveTerm<S> w = wave_term<S>(px, py, ks, false, half, jc);
+  fp v = q_smul<S, NBITS>(w.coord, w.k, jc);
+  v = wave_group_sum<S>(v, jc);
+  const fp zi = fp_inv<Fq>(qperm<3, 3, 3, 3>(v));
+  te_aff r; r.x = fp_mul<Fq>(qperm<0, 0, 0, 0>(v), zi); r.y = fp_mul<Fq>(qperm<1, 1, 1, 1>(v), zi);      // thin.rs:119
+  suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);    // thin.rs:122
+  const fp c = fp_to_mont<Fr>(challenge_finish(tc));
+  const fp s = fp_add<Fr>(k, fp_mul<Fr>(c, fp_to_mont<Fr>(sk)));                 // thin.rs:125
+  uint32_t bad = (w.ok || tq >= 2) ? 0u : 1u;
+  for (int off = 16; off >= 1; off >>= 1) bad |= __shfl_xor(bad, off);
+  if (live && gl == 0) {
+    status[j] = bad ? (int32_t)AVRF_WAVE_FALLBACK : 0;
+    store_xy<S>(proofs_out + 96 * (size_t)j, r);
+    fp_store_le(proofs_out + 96 * (size_t)j + 64, fp_from_mont<Fr>(s));
+    if (f) atomicOr(flags, f);
+  }
 }
 
 // ---------------------------------------------------------------- Pedersen VRF
@@ -577,6 +698,14 @@ template <class S> void SingleOps<S>::tiny_verify(const BatchDev &b, int32_t *d_
 template <class S> void SingleOps<S>::thin_verify(const BatchDev &b, int32_t *d_status, hipStream_t st) {
   hipLaunchKernelGGL(k_thin_verify<S>, dim3((b.n - b.first + 127) / 128), dim3(128), 0, st, b, d_status);
 }
+template <class S> bool SingleOps<S>::thin_verify_wave(const BatchDev &b, int32_t *d_status, hipStream_t st) {
+  if constexpr (S::SW_NATIVE) return false;
+  else { hipLaunchKernelGGL(k_thin_verify_wave<S>, dim3((b.n - b.first + 1) / 2), dim3(64), 0, st, b, d_status); return true; }
+}
+template <class S> bool SingleOps<S>::thin_prove_wave(const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st) {
+  if constexpr (S::SW_NATIVE) return false;
+  else { hipLaunchKernelGGL(k_thin_prove_wave<S>, dim3((b.n - b.first + 1) / 2), dim3(64), 0, st, b, d_proofs_out, d_flags, d_status); return true; }
+}
 template <class S> void SingleOps<S>::ped_prove(const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st) {
   hipLaunchKernelGGL(k_ped_prove<S>, dim3((b.n - b.first + 127) / 128), dim3(128), 0, st, b, d_proofs_out, d_blind, d_flags);
 }
@@ -622,6 +751,14 @@ void launch_tiny_verify(int suite, const BatchDev &b, int32_t *d_status, hipStre
 void launch_thin_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st) {
   if (!b.n) return;
   AVRF_SINGLE(suite, thin_verify(b, d_status, st));
+}
+bool launch_thin_verify_wave(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st) {
+  if (!b.n) return false;
+  return with_suite(suite, [&](auto tag_) { using S_ = typename decltype(tag_)::type; return SingleOps<S_>::thin_verify_wave(b, d_status, st); });
+}
+bool launch_thin_prove_wave(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st) {
+  if (!b.n) return false;
+  return with_suite(suite, [&](auto tag_) { using S_ = typename decltype(tag_)::type; return SingleOps<S_>::thin_prove_wave(b, d_proofs_out, d_flags, d_status, st); });
 }
 void launch_ped_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st) {
   if (!b.n) return;

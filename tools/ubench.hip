@@ -45,6 +45,81 @@ template <int OP> __global__ void k_op(uint32_t *out, int iters, uint32_t seed) 
   out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32) ^ (uint32_t)dr;
 }
 
+// The multiply-add the Montgomery multipliers are made of, issued by hand so that the compiler can neither fold nor reorder it
+// (k_op<0> above is NOT such a stream: its eight chains compile to three v_mad_u64_u32 per iteration -- see the disassembly count
+// in profiles/r4_ubench.txt -- which is why its "rate" contradicted the mixed-addition kernels in round 3).  Sixteen independent
+// 64-bit accumulators, distinct multiplicand registers, one multiplier operand in an SGPR (SG = 1, as the modulus limbs are) or
+// in a VGPR; CARRY = 1 follows every multiply-add with the v_addc_co_u32 of the product-scanning form.
+template <int SG, int CARRY> __global__ void k_mad_asm(uint32_t *out, int iters, uint32_t seed) {
+  uint64_t a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 9, a5 = a0 * 11, a6 = a0 * 13, a7 = a0 * 15;
+  uint64_t a8 = a0 * 17, a9 = a0 * 19, a10 = a0 * 21, a11 = a0 * 23, a12 = a0 * 25, a13 = a0 * 27, a14 = a0 * 29, a15 = a0 * 31;
+  uint32_t x0 = seed * 3 + blockIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, c = 0;
+  const uint32_t ys = seed | 1; uint32_t yv = ys + (threadIdx.x & 1);
+#define MAD_(acc, x) do { if (SG) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(ys) : "vcc"); \
+                          else asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(yv) : "vcc"); \
+                          if (CARRY) asm volatile("v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(c) : : "vcc"); } while (0)
+  for (int i = 0; i < iters; i++) {
+    MAD_(a0, x0); MAD_(a1, x1); MAD_(a2, x2); MAD_(a3, x3); MAD_(a4, x0); MAD_(a5, x1); MAD_(a6, x2); MAD_(a7, x3);
+    MAD_(a8, x0); MAD_(a9, x1); MAD_(a10, x2); MAD_(a11, x3); MAD_(a12, x0); MAD_(a13, x1); MAD_(a14, x2); MAD_(a15, x3);
+  }
+#undef MAD_
+  uint64_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ a8 ^ a9 ^ a10 ^ a11 ^ a12 ^ a13 ^ a14 ^ a15;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32) ^ c;
+}
+
+// Where does the multiply-add + carry PAIR lose time?  MODE 0: every pair's carry goes into its OWN third word (no chain through
+// one register); MODE 1: carries leave through SGPR pairs and are consumed four multiply-adds later (software-pipelined carries);
+// MODE 2: the real column shape -- a dependent chain mad -> mad on ONE accumulator with its carries into one third word, four
+// such columns interleaved instruction by instruction; MODE 3: the same four columns one after the other (what the generated
+// multiplier does today).
+template <int MODE> __global__ void k_mad_pairs(uint32_t *out, int iters, uint32_t seed) {
+  uint64_t a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 9, a5 = a0 * 11, a6 = a0 * 13, a7 = a0 * 15;
+  uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+  uint32_t x0 = seed * 3 + blockIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3;
+  const uint32_t ys = seed | 1;
+#define PV_(acc, c, x) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(c) : "v"(x), "s"(ys) : "vcc")
+  for (int i = 0; i < iters; i++) {
+    if (MODE == 0) {
+      PV_(a0, c0, x0); PV_(a1, c1, x1); PV_(a2, c2, x2); PV_(a3, c3, x3); PV_(a4, c4, x0); PV_(a5, c5, x1); PV_(a6, c6, x2); PV_(a7, c7, x3);
+      PV_(a0, c0, x1); PV_(a1, c1, x2); PV_(a2, c2, x3); PV_(a3, c3, x0); PV_(a4, c4, x1); PV_(a5, c5, x2); PV_(a6, c6, x3); PV_(a7, c7, x0);
+    } else if (MODE == 1) {
+      asm volatile("v_mad_u64_u32 %0, s[20:21], %8, %12, %0\n\tv_mad_u64_u32 %1, s[22:23], %9, %12, %1\n\t"
+                   "v_mad_u64_u32 %2, s[24:25], %10, %12, %2\n\tv_mad_u64_u32 %3, s[26:27], %11, %12, %3\n\t"
+                   "v_addc_co_u32 %4, s[20:21], 0, %4, s[20:21]\n\tv_addc_co_u32 %5, s[22:23], 0, %5, s[22:23]\n\t"
+                   "v_addc_co_u32 %6, s[24:25], 0, %6, s[24:25]\n\tv_addc_co_u32 %7, s[26:27], 0, %7, s[26:27]"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "s"(ys)
+                   : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+      asm volatile("v_mad_u64_u32 %0, s[20:21], %8, %12, %0\n\tv_mad_u64_u32 %1, s[22:23], %9, %12, %1\n\t"
+                   "v_mad_u64_u32 %2, s[24:25], %10, %12, %2\n\tv_mad_u64_u32 %3, s[26:27], %11, %12, %3\n\t"
+                   "v_addc_co_u32 %4, s[20:21], 0, %4, s[20:21]\n\tv_addc_co_u32 %5, s[22:23], 0, %5, s[22:23]\n\t"
+                   "v_addc_co_u32 %6, s[24:25], 0, %6, s[24:25]\n\tv_addc_co_u32 %7, s[26:27], 0, %7, s[26:27]"
+                   : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(x1), "v"(x2), "v"(x3), "v"(x0), "s"(ys)
+                   : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+      asm volatile("v_mad_u64_u32 %0, s[20:21], %8, %12, %0\n\tv_mad_u64_u32 %1, s[22:23], %9, %12, %1\n\t"
+                   "v_mad_u64_u32 %2, s[24:25], %10, %12, %2\n\tv_mad_u64_u32 %3, s[26:27], %11, %12, %3\n\t"
+                   "v_addc_co_u32 %4, s[20:21], 0, %4, s[20:21]\n\tv_addc_co_u32 %5, s[22:23], 0, %5, s[22:23]\n\t"
+                   "v_addc_co_u32 %6, s[24:25], 0, %6, s[24:25]\n\tv_addc_co_u32 %7, s[26:27], 0, %7, s[26:27]"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(x2), "v"(x3), "v"(x0), "v"(x1), "s"(ys)
+                   : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+      asm volatile("v_mad_u64_u32 %0, s[20:21], %8, %12, %0\n\tv_mad_u64_u32 %1, s[22:23], %9, %12, %1\n\t"
+                   "v_mad_u64_u32 %2, s[24:25], %10, %12, %2\n\tv_mad_u64_u32 %3, s[26:27], %11, %12, %3\n\t"
+                   "v_addc_co_u32 %4, s[20:21], 0, %4, s[20:21]\n\tv_addc_co_u32 %5, s[22:23], 0, %5, s[22:23]\n\t"
+                   "v_addc_co_u32 %6, s[24:25], 0, %6, s[24:25]\n\tv_addc_co_u32 %7, s[26:27], 0, %7, s[26:27]"
+                   : "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(c4), "+v"(c5), "+v"(c6), "+v"(c7) : "v"(x3), "v"(x0), "v"(x1), "v"(x2), "s"(ys)
+                   : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+    } else if (MODE == 2) {      // four dependent columns, interleaved
+      PV_(a0, c0, x0); PV_(a1, c1, x1); PV_(a2, c2, x2); PV_(a3, c3, x3); PV_(a0, c0, x1); PV_(a1, c1, x2); PV_(a2, c2, x3); PV_(a3, c3, x0);
+      PV_(a0, c0, x2); PV_(a1, c1, x3); PV_(a2, c2, x0); PV_(a3, c3, x1); PV_(a0, c0, x3); PV_(a1, c1, x0); PV_(a2, c2, x1); PV_(a3, c3, x2);
+    } else {                      // the same four columns one after the other
+      PV_(a0, c0, x0); PV_(a0, c0, x1); PV_(a0, c0, x2); PV_(a0, c0, x3); PV_(a1, c1, x1); PV_(a1, c1, x2); PV_(a1, c1, x3); PV_(a1, c1, x0);
+      PV_(a2, c2, x2); PV_(a2, c2, x3); PV_(a2, c2, x0); PV_(a2, c2, x1); PV_(a3, c3, x3); PV_(a3, c3, x0); PV_(a3, c3, x1); PV_(a3, c3, x2);
+    }
+  }
+#undef PV_
+  uint64_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)r ^ (uint32_t)(r >> 32) ^ c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7;
+}
+
 template <class F> __global__ void k_fmul(uint32_t *out, int iters, uint32_t seed) {
   fp a, b;
   for (int i = 0; i < 8; i++) { a.v[i] = seed * (i + 1) + threadIdx.x; b.v[i] = seed * (i + 7) + blockIdx.x; }
@@ -149,6 +224,23 @@ int main() {
       double ops = (double)blocks * threads * iters * 8;
       printf("  %-22s %8.2f Gop/s  (%.2f lane-ops/clk/CU @2.4GHz)\n", names[op], ops / t * 1e-9, ops / t / 2.4e9 / 256);
     }
+    {
+      const double mops = (double)blocks * threads * iters * 16;
+      double tm = time_kernel([&] { hipLaunchKernelGGL((k_mad_asm<1, 0>), dim3(blocks), dim3(threads), 0, 0, out, iters, 12345u); });
+      printf("  %-22s %8.2f Gop/s  (asm stream, 16 independent accumulators, SGPR multiplier)\n", "mad_u64_u32 asm/s", mops / tm * 1e-9);
+      tm = time_kernel([&] { hipLaunchKernelGGL((k_mad_asm<0, 0>), dim3(blocks), dim3(threads), 0, 0, out, iters, 12345u); });
+      printf("  %-22s %8.2f Gop/s  (asm stream, VGPR multiplier)\n", "mad_u64_u32 asm/v", mops / tm * 1e-9);
+      tm = time_kernel([&] { hipLaunchKernelGGL((k_mad_asm<1, 1>), dim3(blocks), dim3(threads), 0, 0, out, iters, 12345u); });
+      printf("  %-22s %8.2f Gop/s  (each followed by v_addc_co_u32: the product-scanning pair)\n", "mad+addc asm pairs", mops / tm * 1e-9);
+      tm = time_kernel([&] { hipLaunchKernelGGL(k_mad_pairs<0>, dim3(blocks), dim3(threads), 0, 0, out, iters, 12345u); });
+      printf("  %-22s %8.2f Gop/s  (pairs, 8 independent accumulators AND third words, carries through vcc)\n", "pairs independent", mops / tm * 1e-9);
+      tm = time_kernel([&] { hipLaunchKernelGGL(k_mad_pairs<1>, dim3(blocks), dim3(threads), 0, 0, out, iters, 12345u); });
+      printf("  %-22s %8.2f Gop/s  (pairs, carries through SGPR pairs, consumed 4 multiply-adds later)\n", "pairs sgpr-carry d4", mops / tm * 1e-9);
+      tm = time_kernel([&] { hipLaunchKernelGGL(k_mad_pairs<2>, dim3(blocks), dim3(threads), 0, 0, out, iters, 12345u); });
+      printf("  %-22s %8.2f Gop/s  (4 dependent columns interleaved)\n", "pairs 4 cols interl.", mops / tm * 1e-9);
+      tm = time_kernel([&] { hipLaunchKernelGGL(k_mad_pairs<3>, dim3(blocks), dim3(threads), 0, 0, out, iters, 12345u); });
+      printf("  %-22s %8.2f Gop/s  (4 dependent columns one after the other: today's multiplier)\n", "pairs 4 cols serial", mops / tm * 1e-9);
+    }
     int fit = 512;
     double t = time_kernel([&] { hipLaunchKernelGGL(k_fmul<FqBandersnatch>, dim3(blocks), dim3(threads), 0, 0, out, fit, 777u); });
     printf("  %-22s %8.2f Gmul/s\n", "fp_mul<FqBandersnatch>", (double)blocks * threads * fit * 2 / t * 1e-9);
@@ -165,6 +257,8 @@ int main() {
     if (wpc <= 8) {
       t = time_kernel([&] { hipLaunchKernelGGL(k_g1madd<G1Bls12381>, dim3(blocks), dim3(threads), 0, 0, out, 64, 777u); });
       printf("  %-22s %8.3f Gadd/s\n", "g1_madd<Bls12381>", (double)blocks * threads * 64 / t * 1e-9);
+      t = time_kernel([&] { hipLaunchKernelGGL(k_g1madd<G1Bn254>, dim3(blocks), dim3(threads), 0, 0, out, 64, 777u); });
+      printf("  %-22s %8.3f Gadd/s\n", "g1_madd<Bn254>", (double)blocks * threads * 64 / t * 1e-9);
     }
     t = time_kernel([&] { hipLaunchKernelGGL(k_fadd<FqBandersnatch>, dim3(blocks), dim3(threads), 0, 0, out, fit * 4, 777u); });
     printf("  %-22s %8.2f Gop/s\n", "fp_add/sub", (double)blocks * threads * fit * 4 * 2 / t * 1e-9);
