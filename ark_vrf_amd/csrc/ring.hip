@@ -12,6 +12,7 @@
 // host pool, two G1 MSMs on the device, one 2-pairing check on the host (host_pairing.h).
 #include "../../include/avrf.h"
 #include "te.h"
+#include "te_quad.h"
 #include "host_g1.h"
 #include "host_pairing.h"
 #include "host_te.h"
@@ -356,62 +357,88 @@ k_ring_witness_acc(const te_pre *__restrict__ points, const uint32_t *__restrict
                    uint32_t L, uint32_t N, uint32_t cap, fp seedx, fp seedy, const uint32_t *__restrict__ zk, uint32_t *__restrict__ scratch,
                    uint32_t *__restrict__ pos, uint32_t *__restrict__ cnt, uint32_t *__restrict__ vals, uint32_t *__restrict__ sc, uint32_t *__restrict__ bi,
                    uint32_t *__restrict__ out) {
+  // FOUR lanes per proof (te_quad.h: lane jc of the quad holds coordinate jc of the accumulator): a mixed addition is two rounds
+  // of multiplications instead of eight sequential ones, the backward pass two rounds per row instead of four multiplications.
   using F = typename S::Fq;
   constexpr uint32_t MP = 264;
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
+  const uint32_t lane = threadIdx.x & 63, jc = lane & 3;
+  uint32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const bool live = p < n;
+  if (!live) p = n - 1;                                                        // (whole quads stay in step for the cross-lane moves; they write nothing)
   uint32_t *ppos = pos + (size_t)p * 256;
-  uint32_t m = 0;
   const uint32_t ki = kidx[p];
-  ppos[m++] = ki;
-  for (uint32_t i = 0; i < L; i++) if ((blind[32 * (size_t)p + (i >> 3)] >> (i & 7)) & 1) ppos[m++] = keyset + i;
-  for (uint32_t j = m; j < 256; j++) ppos[j] = 0xffffffffu;
-  cnt[p] = m;
-  // pass 1: the chain; entry i of the lane's scratch = x | y | z of acc_i | prefix product z_0 .. z_{i-1}
+  // the row list (every lane of the quad derives it; lane 0 writes it)
+  uint32_t m = 1;
+  for (uint32_t i = 0; i < L; i++) if ((blind[32 * (size_t)p + (i >> 3)] >> (i & 7)) & 1) m++;
+  if (live && jc == 0) {
+    uint32_t w = 0; ppos[w++] = ki;
+    for (uint32_t i = 0; i < L; i++) if ((blind[32 * (size_t)p + (i >> 3)] >> (i & 7)) & 1) ppos[w++] = keyset + i;
+    for (uint32_t j = w; j < 256; j++) ppos[j] = 0xffffffffu;
+    cnt[p] = m;
+  }
+  // pass 1: the chain.  Scratch entry i of the proof: x | y | z of acc_i | prefix product z_0 .. z_{i-1}; lane jc stores word block jc
+  // (lane 2 carries T, which is not kept: it stores the prefix product instead)
   uint32_t *sp = scratch + (size_t)p * 257 * 32;
-  te_ext acc; acc.x = seedx; acc.y = seedy; acc.t = fp_mul<F>(seedx, seedy); acc.z = fp_one<F>();
-  fp run = fp_one<F>();
+  fp acc = jc == 0 ? seedx : jc == 1 ? seedy : jc == 2 ? fp_mul<F>(seedx, seedy) : fp_one<F>();
+  fp run = fp_one<F>();                                                        // (meaningful on lane 3, mirrored to lane 2 for the store)
+  uint32_t next_row = ki, bit = 0;
 #pragma unroll 1
   for (uint32_t j = 0; j <= m; j++) {
-    uint32_t *e = sp + (size_t)j * 32;
-    store_fp(e, acc.x); store_fp(e + 8, acc.y); store_fp(e + 16, acc.z); store_fp(e + 24, run);
-    run = fp_mul<F>(run, acc.z);
-    if (j < m) acc = te_madd<S>(acc, points[ppos[j]]);
+    const fp z = qperm<3, 3, 3, 3>(acc);
+    if (live) store_fp(sp + (size_t)j * 32 + 8 * (jc == 2 ? 3 : jc == 3 ? 2 : jc), jc == 2 ? run : acc);   // x, y, [z at block 2 from lane 3], run at block 3 from lane 2
+    run = fp_mul<F>(run, z);
+    if (j < m) {
+      const te_pre q = points[next_row];
+      acc = q_madd<S>(acc, q.x, q.y, q.k, jc);
+      while (bit < L && !((blind[32 * (size_t)p + (bit >> 3)] >> (bit & 7)) & 1)) bit++;     // the next set bit of the blinding
+      next_row = keyset + bit; bit++;
+    }
   }
   fp inv = fp_inv<F>(run);
-  // pass 2 (backwards): affine coordinates, Montgomery form
+  // pass 2 (backwards): affine coordinates (Montgomery form) and, one row behind, the sparse scalars of the two accumulator columns
   uint32_t *v = vals + (size_t)p * 257 * 16;
+  uint32_t *b = bi + (size_t)p * 4 * MP; uint32_t *qv = sc + (size_t)p * 4 * MP * 8;
+  fp prev = fp_zero(), res = fp_zero();                                        // lane 0 / 1: x / y of row i + 1; of the last row (the result)
 #pragma unroll 1
   for (uint32_t i = m + 1; i-- > 0;) {
     const uint32_t *e = sp + (size_t)i * 32;
-    const fp z = load_fp(e + 16), zi = fp_mul<F>(inv, load_fp(e + 24));
-    inv = fp_mul<F>(inv, z);
-    store_fp(v + (size_t)i * 16, fp_mul<F>(load_fp(e), zi)); store_fp(v + (size_t)i * 16 + 8, fp_mul<F>(load_fp(e + 8), zi));
+    // round 1: lane 3: zi = inv * pre_i; lane 2: inv * z_i (the next inv); lanes 0, 1: from_mont of the previous row's difference
+    const fp z = load_fp(e + 16), pre = load_fp(e + 24), xy = load_fp(e + 8 * (jc & 1));
+    fp one_plain = fp_zero(); one_plain.v[0] = 1;
+    const fp a1 = jc >= 2 ? inv : fp_zero(), b1 = jc == 3 ? pre : z;
+    const fp r1 = fp_mul<F>(a1, b1);
+    const fp zi = qperm<3, 3, 3, 3>(r1);
+    inv = qperm<2, 2, 2, 2>(r1);
+    // round 2: lanes 0, 1: x_i zi, y_i zi
+    const fp aff = fp_mul<F>(xy, zi);
+    if (live && jc < 2) store_fp(v + (size_t)i * 16 + 8 * jc, aff);
+    if (i < m) {                                                               // scalar of row i: from_mont(v_i - v_{i+1}), base N + pos_i + 1
+      const fp d = fp_from_mont<F>(fp_sub<F>(aff, prev));
+      if (live && jc < 2) store_fp(qv + (size_t)((2 + jc) * MP + i) * 8, d);
+    }
+    if (i == m) res = aff;
+    prev = aff;
   }
-  const fp resx = load_fp(v + (size_t)m * 16), resy = load_fp(v + (size_t)m * 16 + 8);
+  // the rest is cheap and done by lane 0 of the quad (result coordinates from the registers of lanes 0 and 1, not through memory)
+  const fp resx = qperm<0, 0, 0, 0>(res), resy = qperm<1, 1, 1, 1>(res);
+  if (!live || jc != 0) return;
   // instance = result - seed  (-(x, y) = (-x, y))
   te_ext r; r.x = resx; r.y = resy; r.t = fp_mul<F>(resx, resy); r.z = fp_one<F>();
   const te_aff inst = te_to_aff<S>(te_madd<S>(r, te_make_pre<S>(fp_neg<F>(seedx), seedy)));
   uint32_t *o = out + (size_t)p * 32;
   store_fp(o, resx); store_fp(o + 8, resy); store_fp(o + 16, inst.x); store_fp(o + 24, inst.y);
   // sparse vectors: bits | ip | ax | ay   (the host zeroed both arrays: unused entries are scalar 0 at base 0)
-  uint32_t *b = bi + (size_t)p * 4 * MP; uint32_t *q = sc + (size_t)p * 4 * MP * 8;
   fp one_plain = fp_zero(); one_plain.v[0] = 1;
   const fp minus1 = fp_from_mont<F>(fp_neg<F>(fp_one<F>()));
-  for (uint32_t j = 0; j < m; j++) { b[j] = ppos[j]; store_fp(q + (size_t)j * 8, one_plain); }
-  b[MP] = N + cap; store_fp(q + (size_t)MP * 8, one_plain);
-  b[MP + 1] = N + ki + 1; store_fp(q + (size_t)(MP + 1) * 8, minus1);
-  for (uint32_t j = 0; j < m; j++) {
-    b[2 * MP + j] = b[3 * MP + j] = N + ppos[j] + 1;
-    const uint32_t *v0 = v + (size_t)j * 16, *v1 = v + (size_t)(j + 1) * 16;
-    store_fp(q + (size_t)(2 * MP + j) * 8, fp_from_mont<F>(fp_sub<F>(load_fp(v0), load_fp(v1))));
-    store_fp(q + (size_t)(3 * MP + j) * 8, fp_from_mont<F>(fp_sub<F>(load_fp(v0 + 8), load_fp(v1 + 8))));
-  }
+  for (uint32_t j = 0; j < m; j++) { b[j] = ppos[j]; store_fp(qv + (size_t)j * 8, one_plain); }
+  b[MP] = N + cap; store_fp(qv + (size_t)MP * 8, one_plain);
+  b[MP + 1] = N + ki + 1; store_fp(qv + (size_t)(MP + 1) * 8, minus1);
+  for (uint32_t j = 0; j < m; j++) b[2 * MP + j] = b[3 * MP + j] = N + ppos[j] + 1;
   b[2 * MP + m] = b[3 * MP + m] = N + cap;
-  store_fp(q + (size_t)(2 * MP + m) * 8, fp_from_mont<F>(resx)); store_fp(q + (size_t)(3 * MP + m) * 8, fp_from_mont<F>(resy));
+  store_fp(qv + (size_t)(2 * MP + m) * 8, fp_from_mont<F>(resx)); store_fp(qv + (size_t)(3 * MP + m) * 8, fp_from_mont<F>(resy));
   if (zk) for (uint32_t col = 0; col < 4; col++) for (uint32_t j = 0; j < 3; j++) {     // + zk_j * L_{cap+j}(tau) G
     b[col * MP + m + 1 + j] = cap + j;
-    store_fp(q + (size_t)(col * MP + m + 1 + j) * 8, fp_from_mont<F>(load_fp(zk + (((size_t)p * 4 + col) * 3 + j) * 8)));
+    store_fp(qv + (size_t)(col * MP + m + 1 + j) * 8, fp_from_mont<F>(load_fp(zk + (((size_t)p * 4 + col) * 3 + j) * 8)));
   }
 }
 template <class S>
@@ -1050,7 +1077,7 @@ template <class S, class G> struct Ring {
       HIP_CHECK(hipMemsetAsync(d_sc, 0, b_sc, su->stream));
       HIP_CHECK(hipMemsetAsync(d_bi, 0, b_bi, su->stream));
       fp sx, sy; { const H256 ax = Fr::from32(S::ACC_X), ay = Fr::from32(S::ACC_Y); memcpy(sx.v, ax.l, 32); memcpy(sy.v, ay.l, 32); }
-      hipLaunchKernelGGL(k_ring_witness_acc<S>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, su->stream, (const te_pre *)k->d_points_pre, (const uint32_t *)d_ki,
+      hipLaunchKernelGGL(k_ring_witness_acc<S>, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, su->stream, (const te_pre *)k->d_points_pre, (const uint32_t *)d_ki,
                          (const uint8_t *)d_bl, (uint32_t)n, (uint32_t)su->keyset, (uint32_t)su->L, (uint32_t)N, (uint32_t)cap, sx, sy,
                          hiding ? (const uint32_t *)d_zk : nullptr, d_e4, d_pos, d_cnt, d_val, d_sc, d_bi, d_out);
       HIP_CHECK(hipMemcpyAsync(wout.data(), d_out, b_out, hipMemcpyDeviceToHost, su->stream));

@@ -63,6 +63,25 @@ template <class S> __device__ __noinline__ static fp q_dbl(fp a, uint32_t j) {
   return fp_mul<Fq>(qperm<0, 1, 0, 3>(U), qperm<3, 2, 1, 2>(U));
 }
 
+// coordinate j of P1 + Q for an AFFINE Q given as te_pre {x2, y2, k2 = d x2 y2} (every lane sees all three): Z2 = 1 leaves the
+// fourth lane of the addition's first round free for (X1 + Y1)(x2 + y2), and k2 makes C = T1 k2 a product of that round too, so
+// a mixed addition is TWO rounds:
+//   round 1   lane 0: X1 x2 = A; lane 1: Y1 y2 = B; lane 2: T1 k2 = C; lane 3: (X1 + Y1)(x2 + y2) = E'
+//   linear    lane 0: E = E' - A - B; lane 1: H = B - aA; lane 2: G = Z1 + C; lane 3: F = Z1 - C
+//   round 2   lane 0: E F; lane 1: G H; lane 2: E H; lane 3: F G
+template <class S> __device__ __noinline__ static fp q_madd(fp a, fp x2, fp y2, fp k2, uint32_t j) {
+  using Fq = typename S::Fq;
+  const fp sa = fp_add<Fq>(a, qperm<1, 0, 3, 2>(a));               // lanes 0, 1: X1 + Y1
+  const fp opa = fp_sel(j == 3, qperm<0, 1, 2, 0>(sa), a);
+  const fp opb = fp_sel(j == 0, x2, fp_sel(j == 1, y2, fp_sel(j == 2, k2, fp_add<Fq>(x2, y2))));
+  const fp m1 = fp_mul<Fq>(opa, opb);
+  const fp A = qperm<0, 0, 0, 0>(m1), B = qperm<1, 1, 1, 1>(m1), C = qperm<2, 2, 2, 2>(m1), Ep = qperm<3, 3, 3, 3>(m1), Z1 = qperm<3, 3, 3, 3>(a);
+  const fp X = fp_sel(j == 0, Ep, fp_sel(j == 1, B, Z1));
+  const fp Y = fp_sel(j == 0, fp_add<Fq>(A, B), fp_sel(j == 1, mul_a<S>(A), fp_sel(j == 2, fp_neg<Fq>(C), C)));
+  const fp U = fp_sub<Fq>(X, Y);                                   // lane 0 E, 1 H, 2 G, 3 F
+  return fp_mul<Fq>(qperm<0, 1, 0, 3>(U), qperm<3, 2, 1, 2>(U));
+}
+
 // coordinate j of k P from coordinate j of P: fixed 3-bit windows over a per-lane table {0, P, .., 7 P} (registers; the entry is
 // picked with a select chain, so the quads of a wave may hold different scalars), NBITS <= 253 bits of the plain integer k.
 // The window digits are read from the top of a left-aligned copy of k that moves up three bits per step.
