@@ -845,12 +845,27 @@ int avrf_tiny_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t
 int avrf_pedersen_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
                         const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out, uint8_t *blindings_out) {
   if (n && (!sks || !proofs_out)) return AVRF_ERR_BAD_ARG;
-  int st = stage(c, 2, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, nullptr);
+  int st = stage_nowait(c, 2, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, nullptr);
   if (st || !n) return st;
   c->staged_kind = 0;
   HIP_TRY(c->d_out.ensure(n * 256)); HIP_TRY(c->d_misc.ensure(n * 32));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
   double t0 = now_us();
+  if (pks_xy && wave_shape(c, n, io_counts)) {                         // few items: 32 lanes per item (vrf_single.hip)
+    if (int fs = ensure_fixed(c)) return fs;
+    HIP_TRY(c->d_status.ensure(n * 4)); HIP_TRY(c->h_c.ensure(n * 4));
+    if (launch_ped_prove_wave(c->suite, batch_of(c), c->d_out.as<uint8_t>(), c->d_misc.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->d_status.as<int32_t>(), c->stream)) {
+      HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, n * 256, hipMemcpyDeviceToHost, c->stream));
+      if (blindings_out) HIP_TRY(hipMemcpyAsync(blindings_out, c->d_misc.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(c->h_c.p, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+      int f = read_flags(c);
+      if (f < 0) return AVRF_ERR_NO_DEVICE;
+      bool fallback = false;
+      for (size_t j = 0; j < n; j++) fallback |= c->h_c.as<int32_t>()[j] == AVRF_WAVE_FALLBACK;
+      if (!fallback) { c->timing[0] = now_us() - t0; return f ? AVRF_INVALID_DATA : AVRF_OK; }
+      HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+    }
+  }
   if (int e = per_item_chunks(c, pks_xy != nullptr, [&](const BatchDev &b) { launch_ped_prove(c->suite, b, c->d_out.as<uint8_t>(), c->d_misc.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream); })) return e;
   HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, n * 256, hipMemcpyDeviceToHost, c->stream));
   if (blindings_out) HIP_TRY(hipMemcpyAsync(blindings_out, c->d_misc.p, n * 32, hipMemcpyDeviceToHost, c->stream));
@@ -863,10 +878,18 @@ int avrf_pedersen_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t
 int avrf_pedersen_verify(avrf_ctx *c, size_t n, const uint8_t *ios_xy, const uint32_t *io_counts,
                          const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, int32_t *status_out) {
   if (n && (!proofs || !status_out)) return AVRF_ERR_BAD_ARG;
-  int st = stage(c, 2, n, nullptr, nullptr, ios_xy, io_counts, ads, ad_lens, proofs);
+  int st = stage_nowait(c, 2, n, nullptr, nullptr, ios_xy, io_counts, ads, ad_lens, proofs);
   if (st || !n) return st;
   HIP_TRY(c->d_status.ensure(n * 4));
   double t0 = now_us();
+  if (wave_shape(c, n, io_counts) && launch_ped_verify_wave(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream)) {
+    validate_staged(c, 2, c->d_status.as<int32_t>());
+    HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
+    bool fallback = false;
+    for (size_t j = 0; j < n; j++) fallback |= status_out[j] == AVRF_WAVE_FALLBACK;
+    if (!fallback) { c->timing[0] = now_us() - t0; return AVRF_OK; }
+  }
   if (int e = per_item_chunks(c, true, [&](const BatchDev &b) { launch_ped_verify(c->suite, b, c->d_status.as<int32_t>(), c->stream); })) return e;
   validate_staged(c, 2, c->d_status.as<int32_t>());
   HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));

@@ -38,6 +38,8 @@ void launch_thin_verify(int suite, const BatchDev &b, int32_t *d_status, hipStre
 enum { AVRF_WAVE_ITEMS_MAX = 2048, AVRF_WAVE_FALLBACK = -99 };
 bool launch_thin_verify_wave(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
 bool launch_thin_prove_wave(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st);
+bool launch_ped_verify_wave(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);     // one item per wave (two equations)
+bool launch_ped_prove_wave(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, int32_t *d_status, hipStream_t st);
 void launch_ped_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st);
 void launch_ped_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
 
@@ -70,6 +72,8 @@ template <class S> struct SingleOps {
   static void thin_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
   static bool thin_verify_wave(const BatchDev &b, int32_t *d_status, hipStream_t st);
   static bool thin_prove_wave(const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st);
+  static bool ped_verify_wave(const BatchDev &b, int32_t *d_status, hipStream_t st);
+  static bool ped_prove_wave(const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, int32_t *d_status, hipStream_t st);
   static void ped_prove(const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st);
   static void ped_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
   static void hash_to_curve(const uint8_t *d_data, const uint32_t *d_off, uint32_t n, uint8_t *d_out, int32_t *d_status, hipStream_t st);

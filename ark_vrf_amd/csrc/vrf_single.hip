@@ -439,6 +439,128 @@ k_ped_verify(BatchDev b, int32_t *__restrict__ status) {
 }
 
 
+// ---------------------------------------------------------------- Pedersen VRF, few items (see "Thin VRF, few items" above)
+//
+// pedersen::Verifier::verify (pedersen.rs:188-249), one pair: ONE item per wave.  Lanes 0-31 evaluate s I - c O (== Ok, :229-232),
+// lanes 32-63 s G + sb B - c Yb (== R, :238-245): five terms, each split into its two endomorphism halves, one half per quad.
+template <class S>
+__global__ void __launch_bounds__(64)
+k_ped_verify_wave(BatchDev b, int32_t *__restrict__ status) {
+  using Fr = typename S::Fr; using Fq = typename S::Fq;
+  constexpr int NBITS = S::HAS_GLV ? 128 : Fr::BITS;
+  const uint32_t lane = threadIdx.x & 63, h = lane >> 5, gl = lane & 31, q = gl >> 2, jc = gl & 3, tq = q >> 1, half = q & 1;
+  const uint32_t j = b.first + blockIdx.x;
+  const uint32_t io0 = b.io_off[j], ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pr = b.proofs + 256 * (size_t)j;
+  suite_tr<S> t; uint32_t f = 0;
+  tr_base<S>(t, DS_PEDERSEN, false, nullptr, ios, 1, b.ads + ad0, adl, &f);
+  const fp ybx = fp_load_le(pr), yby = fp_load_le(pr + 32), rx = fp_load_le(pr + 64), ry = fp_load_le(pr + 96);
+  const fp okx = fp_load_le(pr + 128), oky = fp_load_le(pr + 160), s = fp_load_le(pr + 192), sb = fp_load_le(pr + 224);
+  f |= point_flags<S>(ybx, yby);                                               // Yb == 0 rejected, pedersen.rs:204-206
+  f |= (point_flags<S>(rx, ry) | point_flags<S>(okx, oky)) & FLAG_RANGE;
+  if (ge_p<Fr>(s) || ge_p<Fr>(sb)) f |= FLAG_SCALAR;                           // (reported below: all lanes stay in step)
+  if constexpr (S::SW_CODEC) {                                                 // three 33-byte SW forms, one inversion
+    const fp xs[3] = {ybx, rx, okx}, ys[3] = {yby, ry, oky};
+    sw_enc enc[3]; sw_encode_te_many<S, 3>(xs, ys, enc);
+    absorb_sw_enc(t, enc[0]); tr_byte(t, DS_CHALLENGE); absorb_sw_enc(t, enc[1]); absorb_sw_enc(t, enc[2]);
+  } else {
+    absorb_point_xy<S>(t, ybx, yby);                                           // :219
+    tr_byte(t, DS_CHALLENGE); absorb_point_xy<S>(t, rx, ry); absorb_point_xy<S>(t, okx, oky);
+  }
+  const fp c = challenge_finish(t);                                            // :222
+  // this quad's term: lower half  (I, s), (-O, c);  upper half  (G, s), (B, sb), (-Yb, c);  the other quads carry a zero scalar
+  const bool from_mem = h == 0 ? tq < 2 : tq == 2;
+  const uint8_t *src = h == 0 ? (tq == 1 ? ios + 64 : ios) : pr;
+  const te_pre cst = tq == 1 ? b_pre<S>() : g_pre<S>();
+  const fp px = from_mem ? fp_to_mont<Fq>(fp_load_le(src)) : cst.x, py = from_mem ? fp_to_mont<Fq>(fp_load_le(src + 32)) : cst.y;
+  const bool used = h == 0 ? tq < 2 : tq < 3, neg = h == 0 ? tq == 1 : tq == 2;
+  const fp k = !used ? fp_zero() : (neg ? c : (h == 1 && tq == 1) ? sb : s);
+  const WaveTerm<S> w = wave_term<S>(px, py, k, neg, half, jc);
+  fp v = q_smul<S, NBITS>(w.coord, w.k, jc);
+  v = wave_group_sum<S>(v, jc);
+  const fp X = qperm<0, 0, 0, 0>(v), Y = qperm<1, 1, 1, 1>(v), Z = qperm<3, 3, 3, 3>(v);
+  const fp tx = h == 0 ? okx : rx, ty = h == 0 ? oky : ry;
+  uint32_t eq = (fp_eq(X, fp_mul<Fq>(fp_to_mont<Fq>(tx), Z)) && fp_eq(Y, fp_mul<Fq>(fp_to_mont<Fq>(ty), Z))) ? 1u : 0u;
+  eq &= __shfl_xor(eq, 32);                                                    // both equations
+  uint32_t bad = (w.ok || !used) ? 0u : 1u;
+  for (int off = 32; off >= 1; off >>= 1) bad |= __shfl_xor(bad, off);
+  if (lane == 0) status[j] = f ? 2 : bad ? (int32_t)AVRF_WAVE_FALLBACK : eq ? 0 : 1;
+}
+
+// k P from the context's fixed-base table (proto_dev.h te_smul_fixed) in the quad form: 32 mixed additions of two rounds each
+template <class S> AVRF_DI fp q_smul_fixed(const te_pre *tab, int base, const fp &k, uint32_t jc) {
+  using Fq = typename S::Fq;
+  const te_pre *t = tab + (size_t)base * 32 * 256;
+  fp acc = q_identity<S>(jc);
+#pragma unroll 1
+  for (int w = 0; w < 32; w++) {
+    const uint32_t d = (k.v[w >> 2] >> (8 * (w & 3))) & 255u;
+    te_pre e; e.x = fp_zero(); e.y = fp_one<Fq>(); e.k = fp_zero();           // digit 0: the identity (an addition of it is harmless)
+    if (d) e = load_pre(t + w * 256 + d);
+    acc = q_madd<S>(acc, e.x, e.y, e.k, jc);
+  }
+  return acc;
+}
+
+// pedersen::Prover::prove (pedersen.rs:136-186), one pair: an item on 32 lanes.  The two fixed-base results (Yb, then R after the
+// nonces) are computed by EVERY quad of the item alike (same table entries, two-round mixed additions: no divergence, 32 + 64 of
+// them); Ok = k I runs as the two endomorphism halves on quads 0 and 1.
+template <class S>
+__global__ void __launch_bounds__(64)
+k_ped_prove_wave(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ blindings_out, uint32_t *__restrict__ flags, int32_t *__restrict__ status) {
+  using Fr = typename S::Fr; using Fq = typename S::Fq;
+  constexpr int NBITS = S::HAS_GLV ? 128 : Fr::BITS;
+  const uint32_t lane = threadIdx.x & 63, gl = lane & 31, q = gl >> 2, jc = gl & 3, tq = q >> 1, half = q & 1;
+  uint32_t j = b.first + 2 * blockIdx.x + (lane >> 5);
+  const bool live = j < b.n;
+  if (!live) j = b.n - 1;
+  const uint32_t io0 = b.io_off[j], ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0;
+  const fp sk = fp_load_le(b.sks + 32 * (size_t)j);
+  uint32_t f = ge_p<Fr>(sk) ? FLAG_SCALAR : 0, pf = 0;
+  suite_tr<S> t;
+  tr_base<S>(t, DS_PEDERSEN, false, nullptr, ios, 1, b.ads + ad0, adl, &pf);   // pedersen.rs:142
+  f |= pf & FLAG_RANGE;
+  suite_tr<S> tb = t; tr_byte(tb, DS_PEDERSEN_BLINDING);
+  const fp bl = nonce<S>(sk, tb);                                               // pedersen.rs:51-54,145
+  const fp bl_plain = fp_from_mont<Fr>(bl);
+  const te_pre pkp = pre_from_xy<S>(b.pks_xy + 64 * (size_t)j);
+  fp yq = q_smul_fixed<S>(b.fixed, FIXED_B, bl_plain, jc);                      // :148-149
+  yq = q_madd<S>(yq, pkp.x, pkp.y, pkp.k, jc);
+  te_aff yb;
+  { const fp zi = fp_inv<Fq>(qperm<3, 3, 3, 3>(yq)); yb.x = fp_mul<Fq>(qperm<0, 0, 0, 0>(yq), zi); yb.y = fp_mul<Fq>(qperm<1, 1, 1, 1>(yq), zi); }
+  absorb_point_mont<S>(t, yb);                                                  // :152
+  const fp k = nonce<S>(sk, t), kb = nonce<S>(bl_plain, t);                     // :155-156
+  const fp k_plain = fp_from_mont<Fr>(k);
+  fp rq = q_smul_fixed<S>(b.fixed, FIXED_G, k_plain, jc);                       // :159-161
+  { const fp kbq = q_smul_fixed<S>(b.fixed, FIXED_B, fp_from_mont<Fr>(kb), jc); rq = q_add<S>(rq, kbq, jc); }
+  const fp ix = fp_to_mont<Fq>(fp_load_le(ios)), iy = fp_to_mont<Fq>(fp_load_le(ios + 32));
+  const WaveTerm<S> w = wave_term<S>(ix, iy, tq == 0 ? k_plain : fp_zero(), false, half, jc);
+  fp oq = q_smul<S, NBITS>(w.coord, w.k, jc);                                   // :164
+  oq = wave_group_sum<S>(oq, jc);
+  te_aff ra, oka;                                                               // :166-167, one inversion for both
+  {
+    const fp rz = qperm<3, 3, 3, 3>(rq), oz = qperm<3, 3, 3, 3>(oq);
+    const fp inv = fp_inv<Fq>(fp_mul<Fq>(rz, oz)), ri = fp_mul<Fq>(inv, oz), oi = fp_mul<Fq>(inv, rz);
+    ra.x = fp_mul<Fq>(qperm<0, 0, 0, 0>(rq), ri); ra.y = fp_mul<Fq>(qperm<1, 1, 1, 1>(rq), ri);
+    oka.x = fp_mul<Fq>(qperm<0, 0, 0, 0>(oq), oi); oka.y = fp_mul<Fq>(qperm<1, 1, 1, 1>(oq), oi);
+  }
+  suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, ra); absorb_point_mont<S>(tc, oka);
+  const fp c = fp_to_mont<Fr>(challenge_finish(tc));                            // :170
+  const fp s = fp_add<Fr>(k, fp_mul<Fr>(c, fp_to_mont<Fr>(sk)));                // :173
+  const fp sbv = fp_add<Fr>(kb, fp_mul<Fr>(c, bl));                             // :175
+  uint32_t bad = (w.ok || tq != 0) ? 0u : 1u;
+  for (int off = 16; off >= 1; off >>= 1) bad |= __shfl_xor(bad, off);
+  if (live && gl == 0) {
+    status[j] = bad ? (int32_t)AVRF_WAVE_FALLBACK : 0;
+    uint8_t *o = proofs_out + 256 * (size_t)j;
+    store_xy<S>(o, yb); store_xy<S>(o + 64, ra); store_xy<S>(o + 128, oka);
+    fp_store_le(o + 192, fp_from_mont<Fr>(s)); fp_store_le(o + 224, fp_from_mont<Fr>(sbv));
+    if (blindings_out) fp_store_le(blindings_out + 32 * (size_t)j, bl_plain);
+    if (f) atomicOr(flags, f);
+  }
+}
+
 // ---------------------------------------------------------------- point codecs
 
 // CanonicalDeserialize for TE affine points, compressed form: y = LE32 with the
@@ -706,6 +828,14 @@ template <class S> bool SingleOps<S>::thin_prove_wave(const BatchDev &b, uint8_t
   if constexpr (S::SW_NATIVE) return false;
   else { hipLaunchKernelGGL(k_thin_prove_wave<S>, dim3((b.n - b.first + 1) / 2), dim3(64), 0, st, b, d_proofs_out, d_flags, d_status); return true; }
 }
+template <class S> bool SingleOps<S>::ped_verify_wave(const BatchDev &b, int32_t *d_status, hipStream_t st) {
+  if constexpr (S::SW_NATIVE) return false;
+  else { hipLaunchKernelGGL(k_ped_verify_wave<S>, dim3(b.n - b.first), dim3(64), 0, st, b, d_status); return true; }
+}
+template <class S> bool SingleOps<S>::ped_prove_wave(const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, int32_t *d_status, hipStream_t st) {
+  if constexpr (S::SW_NATIVE) return false;
+  else { hipLaunchKernelGGL(k_ped_prove_wave<S>, dim3((b.n - b.first + 1) / 2), dim3(64), 0, st, b, d_proofs_out, d_blind, d_flags, d_status); return true; }
+}
 template <class S> void SingleOps<S>::ped_prove(const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st) {
   hipLaunchKernelGGL(k_ped_prove<S>, dim3((b.n - b.first + 127) / 128), dim3(128), 0, st, b, d_proofs_out, d_blind, d_flags);
 }
@@ -759,6 +889,14 @@ bool launch_thin_verify_wave(int suite, const BatchDev &b, int32_t *d_status, hi
 bool launch_thin_prove_wave(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st) {
   if (!b.n) return false;
   return with_suite(suite, [&](auto tag_) { using S_ = typename decltype(tag_)::type; return SingleOps<S_>::thin_prove_wave(b, d_proofs_out, d_flags, d_status, st); });
+}
+bool launch_ped_verify_wave(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st) {
+  if (!b.n) return false;
+  return with_suite(suite, [&](auto tag_) { using S_ = typename decltype(tag_)::type; return SingleOps<S_>::ped_verify_wave(b, d_status, st); });
+}
+bool launch_ped_prove_wave(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, int32_t *d_status, hipStream_t st) {
+  if (!b.n) return false;
+  return with_suite(suite, [&](auto tag_) { using S_ = typename decltype(tag_)::type; return SingleOps<S_>::ped_prove_wave(b, d_proofs_out, d_blind, d_flags, d_status, st); });
 }
 void launch_ped_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st) {
   if (!b.n) return;

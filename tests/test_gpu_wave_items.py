@@ -85,3 +85,25 @@ def test_single_item_latency(nat):
 def _t(fn):
     import time
     t0 = time.perf_counter(); fn(); return time.perf_counter() - t0
+
+
+@pytest.mark.parametrize("suite", TE_SUITES + [7])
+@pytest.mark.parametrize("n", [1, 2, 5, 33])
+def test_pedersen_small_n_matches_oracle(nat, suite, n):
+    """pedersen::Prover::prove / Verifier::verify (src/pedersen.rs:136-249) on the few-items kernels: proofs and blindings byte for
+    byte, verdicts per item"""
+    b = orc.gen_batch(suite, 1, n, start=11 * n)
+    c = nat.Context(suite)
+    try:
+        proofs, blind = c.pedersen_prove(nat_batch(b, with_sks=True, with_proofs=False))
+        assert proofs == b["proofs"]
+        vb = dict(b, pks_xy=b"")
+        assert c.pedersen_verify(nat_batch(vb)) == [0] * n
+        for off, want_st in ((192, 1), (224, 1), (70, 1), (130, 1)):       # s, sb, R.x, Ok.x of the last item
+            pr = bytearray(b["proofs"]); pr[256 * (n - 1) + off] ^= 1
+            got = c.pedersen_verify(nat_batch(dict(vb, proofs=bytes(pr))))
+            assert got[: n - 1] == [0] * (n - 1) and got[n - 1] in (want_st, 2), (off, got)      # (a flipped coordinate may leave the field: InvalidData)
+        pr = bytearray(b["proofs"]); pr[0:64] = bytes(64) if suite == 7 else IDENTITY_XY          # Yb = identity: InvalidData (pedersen.rs:204-206)
+        assert c.pedersen_verify(nat_batch(dict(vb, proofs=bytes(pr))))[0] == 2
+    finally:
+        c.close()

@@ -20,3 +20,10 @@ for n in (1, 2, 16, 64, 512, 2048):
             t0 = time.perf_counter(); fn(); t = min(t, time.perf_counter() - t0)
         return t
     print(f"suite {suite} n={n}: thin verify {best(lambda: c.thin_verify(vb)) * 1e3:.3f} ms, thin prove {best(lambda: c.thin_prove(pb)) * 1e3:.3f} ms", flush=True)
+
+for n in (1, 64):
+    b = orc.gen_batch(suite, 1, n)
+    pb = nat_batch(b, with_sks=True, with_proofs=False); vb = nat_batch(dict(b, pks_xy=b""))
+    for _ in range(3):
+        assert c.pedersen_prove(pb)[0] == b["proofs"] and c.pedersen_verify(vb) == [0] * n
+    print(f"suite {suite} n={n}: pedersen verify {best(lambda: c.pedersen_verify(vb)) * 1e3:.3f} ms, pedersen prove {best(lambda: c.pedersen_prove(pb)) * 1e3:.3f} ms", flush=True)
