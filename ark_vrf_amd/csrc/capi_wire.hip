@@ -36,8 +36,16 @@ int decompress_all(avrf_ctx *ctx, const Gather &g, int validate, std::vector<uin
 size_t sum_counts(const uint32_t *c, size_t n) { size_t t = 0; for (size_t i = 0; i < n; i++) t += c[i]; return t; }
 
 // shared by the thin / tiny / pedersen wire verifiers: kind 1 thin (64-byte proofs, 1 point), 3 tiny (48, 0 points), 2 pedersen (160, 3)
+// pp0_xy / pp0_st (optional): xy and decode status of every item's FIRST proof point (the Pedersen key commitment Yb, which
+// ring::Verifier also needs as the ring proof's instance) -- so that a caller does not decompress it a second time
+constexpr size_t SMALL_BATCH = 64;   // a "batch" of up to this many items takes the per-item verifiers (one wave per item: 0.6 ms) instead
+                                     // of the Pippenger chain (14 launches + the weight transcript: 1.5 ms for one item); same verdict
 int verify_wire(avrf_ctx *ctx, int kind, bool batch, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
-                const uint32_t *ad_lens, const uint8_t *proofs, int validate, int32_t *status_out) {
+                const uint32_t *ad_lens, const uint8_t *proofs, int validate, int32_t *status_out,
+                std::vector<uint8_t> *pp0_xy = nullptr, std::vector<int32_t> *pp0_st = nullptr) {
+  std::vector<int32_t> small_status;
+  const bool small = batch && n <= SMALL_BATCH && kind != 3;
+  if (small) { small_status.assign(n ? n : 1, 0); status_out = small_status.data(); batch = false; }
   if (!ctx || (n && (!io_counts || !ad_lens || !proofs)) || (n && kind != 2 && !pks) || (!batch && n && !status_out)) return AVRF_ERR_BAD_ARG;
   if (!n) return AVRF_OK;
   const size_t tot = sum_counts(io_counts, n);
@@ -49,9 +57,12 @@ int verify_wire(avrf_ctx *ctx, int kind, bool batch, size_t n, const uint8_t *pk
   g.add(ios, 2 * tot, L);
   for (size_t p = 0; p < ppts; p++) g.add(proofs + L * p, n, plen);
   std::vector<uint8_t> xy; std::vector<int32_t> pst;
-  int rc = decompress_all(ctx, g, validate, xy, batch ? nullptr : &pst);
+  int rc = decompress_all(ctx, g, validate, xy, (batch && !pp0_st) ? nullptr : &pst);
   if (rc != AVRF_OK) return rc;
   const uint8_t *x_pks = xy.data(), *x_ios = xy.data() + (kind != 2 ? n * 64 : 0), *x_pp = x_ios + 2 * tot * 64;
+  if (pp0_xy && ppts) pp0_xy->assign(x_pp, x_pp + n * 64);
+  if (pp0_st && ppts) pp0_st->assign(pst.begin() + ((kind != 2 ? n : 0) + 2 * tot), pst.begin() + ((kind != 2 ? n : 0) + 2 * tot + n));
+  if (batch && pp0_st) for (size_t i = 0; i < pst.size(); i++) if (pst[i]) return AVRF_INVALID_DATA;
   std::vector<uint8_t> px(n * xlen);
   for (size_t j = 0; j < n; j++) {
     for (size_t p = 0; p < ppts; p++) memcpy(&px[j * xlen + 64 * p], x_pp + (p * n + j) * 64, 64);
@@ -71,6 +82,11 @@ int verify_wire(avrf_ctx *ctx, int kind, bool batch, size_t n, const uint8_t *pk
   for (size_t j = 0; j < n; j++) { for (size_t k = 0; k < 2 * (size_t)io_counts[j]; k++) if (pst[at + io_at + k]) status_out[j] = AVRF_INVALID_DATA; io_at += 2 * io_counts[j]; }
   at += 2 * tot;
   for (size_t p = 0; p < ppts; p++) for (size_t j = 0; j < n; j++) if (pst[at + p * n + j]) status_out[j] = AVRF_INVALID_DATA;
+  if (small) {                                                         // BatchVerifier's verdict: InvalidData before VerificationFailure
+    int worst = AVRF_OK;
+    for (size_t j = 0; j < n; j++) { if (status_out[j] == AVRF_INVALID_DATA) return AVRF_INVALID_DATA; if (status_out[j]) worst = AVRF_VERIFICATION_FAILURE; }
+    return worst;
+  }
   return AVRF_OK;
 }
 
@@ -139,19 +155,16 @@ int avrf_ring_vrf_verify(avrf_ctx *ctx, avrf_ring_setup *setup, size_t n, const 
   if (tot && !ios) return AVRF_ERR_BAD_ARG;
   std::vector<uint8_t> ped(n * pedlen), rp(n * rlen);
   for (size_t j = 0; j < n; j++) { memcpy(&ped[j * pedlen], proofs + j * plen, pedlen); memcpy(&rp[j * rlen], proofs + j * plen + pedlen, rlen); }
-  // Yb of every Pedersen proof as xy (the ring verifier's instance)
-  Gather g(L); g.add(ped.data(), n, pedlen);
+  // the Pedersen half first: it decompresses (and validates) every point of the Pedersen proofs ONCE, including Yb, the ring
+  // verifier's instance
   std::vector<uint8_t> yb; std::vector<int32_t> yst;
-  int rc = decompress_all(ctx, g, validate, yb, &yst);
-  if (rc != AVRF_OK) return rc;
   if (!each) {
-    for (size_t j = 0; j < n; j++) if (yst[j]) return AVRF_INVALID_DATA;
-    rc = avrf_pedersen_batch_verify_wire(ctx, n, ios, io_counts, ads, ad_lens, ped.data(), validate);
+    int rc = verify_wire(ctx, 2, true, n, nullptr, ios, io_counts, ads, ad_lens, ped.data(), validate, nullptr, &yb, &yst);
     if (rc != AVRF_OK) return rc;
     return avrf_ring_batch_verify(setup, n, ring_commitments, n_rings, ring_of_item, yb.data(), rp.data());
   }
   std::vector<int32_t> s1(n), s2(n);
-  rc = avrf_pedersen_verify_wire(ctx, n, ios, io_counts, ads, ad_lens, ped.data(), validate, s1.data());
+  int rc = verify_wire(ctx, 2, false, n, nullptr, ios, io_counts, ads, ad_lens, ped.data(), validate, s1.data(), &yb, &yst);
   if (rc != AVRF_OK) return rc;
   rc = avrf_ring_verify_each(setup, n, ring_commitments, n_rings, ring_of_item, yb.data(), rp.data(), s2.data());
   if (rc != AVRF_OK) return rc;

@@ -698,12 +698,10 @@ k_hash_to_curve(const uint8_t *__restrict__ data, const uint32_t *__restrict__ o
   else { for (int i = 0; i < 64; i++) out_xy[64 * (size_t)j + i] = 0; status[j] = 2; }
 }
 
-template <class S>
-__global__ void __launch_bounds__(128)
-k_decompress(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ out_xy, int validate, int32_t *__restrict__ status) {
-  using Fq = typename S::Fq; using Fr = typename S::Fr;
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+// decode point j of `in`: Montgomery (xm, ym), canonical (x, y) for the output, status 0 / 2; *check = the subgroup test is still due
+template <class S> AVRF_DI int32_t decode_point(const uint8_t *__restrict__ in, uint32_t j, int validate, fp &xm, fp &ym, fp &x, fp &y, bool &check) {
+  using Fq = typename S::Fq;
+  check = false;
   if constexpr (S::SW_CODEC) {
     // SWAffine::deserialize_compressed (33 bytes; unused flag bits and the infinity flag are rejected: the point at infinity has
     // no twisted-Edwards image, sw_to_te -> None, and the reference's verifiers refuse the identity anyway)
@@ -712,27 +710,23 @@ k_decompress(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ o
     for (int i = 0; i < 8; i++) xs.v[i] = (uint32_t)src[4 * i] | ((uint32_t)src[4 * i + 1] << 8) | ((uint32_t)src[4 * i + 2] << 16) | ((uint32_t)src[4 * i + 3] << 24);
     const uint8_t flag = src[32];
     const fp idy = S::SW_NATIVE ? fp_zero() : fp_one<Fq>();      // y of the identity in the xy flavour
-    int32_t st = 0; fp xm = fp_zero(), ym = idy;
+    int32_t st = 0; xm = fp_zero(); ym = idy;
     if ((flag & 0x7f) || ge_p<Fq>(xs) || !sw_decode_te<S>(xs, (flag & 0x80) != 0, xm, ym)) { st = 2; xm = fp_zero(); ym = idy; }
-    else if (validate) {
-      te_ext rp = te_smul<S>(te_make_pre<S>(xm, ym), fp_const<Fr>(Fr::P), Fr::BITS);   // r * P == 0
-      if (!te_is_identity<S>(rp)) st = 2;
-    }
-    fp_store_le(out_xy + 64 * (size_t)j, fp_from_mont<Fq>(xm)); fp_store_le(out_xy + 64 * (size_t)j + 32, fp_from_mont<Fq>(ym));
-    status[j] = st;
-    return;
+    else check = validate != 0;
+    x = fp_from_mont<Fq>(xm); y = fp_from_mont<Fq>(ym);
+    return st;
   }
-  fp y = fp_load_le(in + 32 * (size_t)j);
+  y = fp_load_le(in + 32 * (size_t)j);
   bool neg = (y.v[7] >> 31) != 0; y.v[7] &= 0x7fffffffu;
   int32_t st = 0;
-  fp x = fp_zero();
+  x = fp_zero(); xm = fp_zero(); ym = fp_zero();
   if (ge_p<Fq>(y)) st = 2;
   else {
-    fp ym = fp_to_mont<Fq>(y), y2 = fp_sqr<Fq>(ym), one = fp_one<Fq>();
+    ym = fp_to_mont<Fq>(y);
+    fp y2 = fp_sqr<Fq>(ym), one = fp_one<Fq>();
     fp num = fp_sub<Fq>(one, y2);
     fp a_const = mul_a<S>(one);   // the curve coefficient a (1, -5 or -1)
     fp den = fp_sub<Fq>(a_const, fp_mul<Fq>(fp_const<Fq>(S::D), y2));
-    fp xm;
     if (fp_is_zero(den) || !fp_sqrt_nf<Fq>(fp_mul<Fq>(num, fp_inv<Fq>(den)), &xm)) st = 2;
     else {
       if (fp_is_negative_mont<Fq>(xm) != neg) xm = fp_neg<Fq>(xm);
@@ -741,15 +735,45 @@ k_decompress(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ o
       if (!st && validate) {
         fp onep = fp_zero(); onep.v[0] = 1;
         if (fp_is_zero(x) && fp_eq(y, onep)) st = 2;                       // identity
-        else {
-          te_ext rp = te_smul<S>(te_make_pre<S>(xm, ym), fp_const<Fr>(Fr::P), Fr::BITS);   // r * P == 0
-          if (!te_is_identity<S>(rp)) st = 2;
-        }
+        else check = true;
       }
     }
   }
+  return st;
+}
+template <class S>
+__global__ void __launch_bounds__(128)
+k_decompress(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ out_xy, int validate, int32_t *__restrict__ status) {
+  using Fr = typename S::Fr;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  fp xm, ym, x, y; bool check;
+  int32_t st = decode_point<S>(in, j, validate, xm, ym, x, y, check);
+  if (check) {
+    te_ext rp = te_smul<S>(te_make_pre<S>(xm, ym), fp_const<Fr>(Fr::P), Fr::BITS);   // r * P == 0
+    if (!te_is_identity<S>(rp)) st = 2;
+  }
   fp_store_le(out_xy + 64 * (size_t)j, x); fp_store_le(out_xy + 64 * (size_t)j + 32, y);
   status[j] = st;
+}
+// few points with the subgroup test: FOUR lanes per point -- the decoding is computed alike by the four lanes, r P runs as one
+// quad scalar multiplication (te_quad.h: 85 windows of three doublings and an addition, 0.6 ms instead of 1.7 ms on one lane)
+template <class S>
+__global__ void __launch_bounds__(64)
+k_decompress_wave(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ out_xy, int32_t *__restrict__ status) {
+  using Fr = typename S::Fr; using Fq = typename S::Fq;
+  const uint32_t jc = threadIdx.x & 3;
+  uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const bool live = j < n;
+  if (!live) j = n - 1;
+  fp xm, ym, x, y; bool check;
+  int32_t st = decode_point<S>(in, j, 1, xm, ym, x, y, check);
+  if (!check) { xm = fp_zero(); ym = fp_one<Fq>(); }                           // (all quads run the multiplication; an undecodable point runs it on the identity)
+  const fp coord = jc == 0 ? xm : jc == 1 ? ym : jc == 2 ? fp_mul<Fq>(xm, ym) : fp_one<Fq>();
+  const fp v = q_smul<S, Fr::BITS>(coord, fp_const<Fr>(Fr::P), jc);            // r * P == 0  <=>  X = 0 and Y = Z
+  const fp X = qperm<0, 0, 0, 0>(v), Y = qperm<1, 1, 1, 1>(v), Z = qperm<3, 3, 3, 3>(v);
+  if (check && !(fp_is_zero(X) && fp_eq(Y, Z))) st = 2;
+  if (live && jc == 0) { fp_store_le(out_xy + 64 * (size_t)j, x); fp_store_le(out_xy + 64 * (size_t)j + 32, y); status[j] = st; }
 }
 // Validate::Yes for points that cross the ABI as canonical x || y (the reference's typed points have passed
 // CanonicalDeserialize / the checked constructors, src/lib.rs:410-433,471-494): point p of record j sits at
@@ -846,6 +870,10 @@ template <class S> void SingleOps<S>::hash_to_curve(const uint8_t *d_data, const
   hipLaunchKernelGGL(k_hash_to_curve<S>, dim3((n + 127) / 128), dim3(128), 0, st, d_data, d_off, n, d_out, d_status);
 }
 template <class S> void SingleOps<S>::decompress(const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st) {
+  if constexpr (!S::SW_NATIVE) if (validate && n <= 4096) {           // few points: four lanes per point for the subgroup test
+    hipLaunchKernelGGL(k_decompress_wave<S>, dim3((4 * n + 63) / 64), dim3(64), 0, st, d_in, n, d_out, d_status);
+    return;
+  }
   hipLaunchKernelGGL(k_decompress<S>, dim3((n + 127) / 128), dim3(128), 0, st, d_in, n, d_out, validate, d_status);
 }
 template <class S> void SingleOps<S>::validate_xy(const uint8_t *d_base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *d_flags,

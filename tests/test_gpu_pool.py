@@ -122,3 +122,53 @@ def test_pool_empty_and_error_paths(nat):
         assert pool.wait(pool.submit(nat_batch(dict(b, ios_xy=bytes(off))))) == 2
     finally:
         pool.close()
+
+
+def test_pool_concurrent_submitters_and_destroy_in_flight(nat):
+    """several caller threads share one pool (submit / wait are thread-safe); a pool destroyed with work in flight shuts down cleanly"""
+    import threading
+    good = orc.gen_batch(0, 0, 400)
+    pr = bytearray(good["proofs"]); pr[96 * 7 + 64] ^= 1
+    bad = dict(good, proofs=bytes(pr))
+    pool = nat.Pool(0, kind=1, slots=6, lanes=2, threads=2, hash_group=8)
+    errs = []
+
+    def caller(k):
+        try:
+            for i in range(6):
+                b = bad if (k + i) % 3 == 0 else good
+                want = 1 if (k + i) % 3 == 0 else 0
+                got = pool.wait(pool.submit(nat_batch(b)))
+                if got != want:
+                    errs.append((k, i, got, want))
+        except Exception as e:                                         # noqa: BLE001
+            errs.append((k, repr(e)))
+    th = [threading.Thread(target=caller, args=(k,)) for k in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert not errs, errs
+    # destroy with batches in flight: nothing to collect, no crash, a new pool works afterwards
+    keep = [nat_batch(good) for _ in range(6)]
+    for b in keep:
+        pool.submit(b)
+    pool.close()
+    pool2 = nat.Pool(0, kind=1, slots=2, lanes=1, threads=1, hash_group=1)
+    try:
+        assert pool2.wait(pool2.submit(nat_batch(bad))) == 1
+    finally:
+        pool2.close()
+
+
+def test_pool_full_size_batch(nat):
+    """BASELINE configs[1] size through the pool: 65 536 items, a tampered copy next to the good one"""
+    n = 65536
+    good = orc.gen_batch(0, 0, n)
+    pr = bytearray(good["proofs"]); pr[96 * 40000 + 70] ^= 2
+    pool = nat.Pool(0, kind=1, slots=4, lanes=2, threads=2, hash_group=8)
+    try:
+        pg = nat.PinnedBatch(n, good["ios_xy"], good["io_counts"], good["ads"], good["ad_lens"], pks_xy=good["pks_xy"], proofs=good["proofs"])
+        tk = [pool.submit(pg), pool.submit(nat_batch(dict(good, proofs=bytes(pr)))), pool.submit(pg), pool.submit(pg)]
+        assert [pool.wait(t) for t in tk] == [0, 1, 0, 0]
+        done, mism, _ = pool.cycle(steps_block=8, min_seconds=0.0, expect=0)
+        assert done == 8 and mism == 1                                  # eight runs over the four resident batches; the tampered slot is not reissued after its mismatch
+    finally:
+        pool.close()
