@@ -821,6 +821,19 @@ int avrf_tiny_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pk
   c->staged_kind = 0;
   HIP_TRY(c->d_out.ensure(n * 48));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  if (pks_xy && wave_shape(c, n, io_counts)) {                         // few items: 32 lanes per item (vrf_single.hip)
+    HIP_TRY(c->d_status.ensure(n * 4)); HIP_TRY(c->h_c.ensure(n * 4));
+    if (launch_thin_prove_wave(c->suite, batch_of(c), c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->d_status.as<int32_t>(), c->stream, true)) {
+      HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, n * 48, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipMemcpyAsync(c->h_c.p, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+      int f = read_flags(c);
+      if (f < 0) return AVRF_ERR_NO_DEVICE;
+      bool fallback = false;
+      for (size_t j = 0; j < n; j++) fallback |= c->h_c.as<int32_t>()[j] == AVRF_WAVE_FALLBACK;
+      if (!fallback) return f ? AVRF_INVALID_DATA : AVRF_OK;
+      HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+    }
+  }
   if (int e = per_item_chunks(c, pks_xy != nullptr, [&](const BatchDev &b) { launch_thin_prove(c->suite, b, c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream, true); })) return e;
   HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, n * 48, hipMemcpyDeviceToHost, c->stream));
   int f = read_flags(c);
@@ -834,6 +847,14 @@ int avrf_tiny_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t
   if (st || !n) return st;
   HIP_TRY(c->d_status.ensure(n * 4));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  if (wave_shape(c, n, io_counts) && launch_tiny_verify_wave(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream)) {
+    validate_staged(c, 3, c->d_status.as<int32_t>());
+    HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
+    bool fallback = false;
+    for (size_t j = 0; j < n; j++) fallback |= status_out[j] == AVRF_WAVE_FALLBACK;
+    if (!fallback) { c->staged_kind = 0; return AVRF_OK; }
+  }
   if (int e = per_item_chunks(c, true, [&](const BatchDev &b) { launch_tiny_verify(c->suite, b, c->d_status.as<int32_t>(), c->stream); })) return e;
   validate_staged(c, 3, c->d_status.as<int32_t>());
   HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));

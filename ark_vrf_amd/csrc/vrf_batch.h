@@ -37,7 +37,8 @@ void launch_thin_verify(int suite, const BatchDev &b, int32_t *d_status, hipStre
 // caller re-runs the call on the lane-per-item kernel.
 enum { AVRF_WAVE_ITEMS_MAX = 2048, AVRF_WAVE_FALLBACK = -99 };
 bool launch_thin_verify_wave(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
-bool launch_thin_prove_wave(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st);
+bool launch_thin_prove_wave(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st, bool tiny = false);
+bool launch_tiny_verify_wave(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
 bool launch_ped_verify_wave(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);     // one item per wave (two equations)
 bool launch_ped_prove_wave(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, int32_t *d_status, hipStream_t st);
 void launch_ped_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st);
@@ -71,7 +72,8 @@ template <class S> struct SingleOps {
   static void tiny_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
   static void thin_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
   static bool thin_verify_wave(const BatchDev &b, int32_t *d_status, hipStream_t st);
-  static bool thin_prove_wave(const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st);
+  static bool thin_prove_wave(const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st, bool tiny);
+  static bool tiny_verify_wave(const BatchDev &b, int32_t *d_status, hipStream_t st);
   static bool ped_verify_wave(const BatchDev &b, int32_t *d_status, hipStream_t st);
   static bool ped_prove_wave(const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, int32_t *d_status, hipStream_t st);
   static void ped_prove(const BatchDev &b, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st);

@@ -298,7 +298,7 @@ k_thin_verify_wave(BatchDev b, int32_t *__restrict__ status) {
 }
 
 // thin::Prover::prove (thin.rs:111-135) for one pair, the same layout: R = k G + (k z) I on four quads (the other four idle)
-template <class S>
+template <class S, bool TINY>
 __global__ void __launch_bounds__(64)
 k_thin_prove_wave(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict__ flags, int32_t *__restrict__ status) {
   using Fr = typename S::Fr; using Fq = typename S::Fq;
@@ -313,7 +313,7 @@ k_thin_prove_wave(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__rest
   uint32_t f = ge_p<Fr>(sk) ? FLAG_SCALAR : 0;
   const fp pkx = fp_load_le(b.pks_xy + 64 * (size_t)j), pky = fp_load_le(b.pks_xy + 64 * (size_t)j + 32);
   suite_tr<S> t; uint32_t pf = 0;
-  tr_base<S>(t, DS_THIN, true, pkx, pky, ios, 1, b.ads + ad0, adl, &pf);          // thin.rs:112
+  tr_base<S>(t, TINY ? DS_TINY : DS_THIN, true, pkx, pky, ios, 1, b.ads + ad0, adl, &pf);   // thin.rs:112, tiny.rs:164
   f |= pf & FLAG_RANGE;
   const fp k = nonce<S>(sk, t);                                                  // thin.rs:115 (Montgomery)
   auto dseed = delin_seed(t);
@@ -333,10 +333,55 @@ k_thin_prove_wave(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__rest
   for (int off = 16; off >= 1; off >>= 1) bad |= __shfl_xor(bad, off);
   if (live && gl == 0) {
     status[j] = bad ? (int32_t)AVRF_WAVE_FALLBACK : 0;
-    store_xy<S>(proofs_out + 96 * (size_t)j, r);
-    fp_store_le(proofs_out + 96 * (size_t)j + 64, fp_from_mont<Fr>(s));
+    if (TINY) {                                                                   // LE16(c) || LE32(s), tiny.rs:60-78
+      const fp cp = fp_from_mont<Fr>(c);
+      uint8_t *o = proofs_out + 48 * (size_t)j;
+      for (int i = 0; i < 4; i++) for (int bb = 0; bb < 4; bb++) o[4 * i + bb] = (uint8_t)(cp.v[i] >> (8 * bb));
+      fp_store_le(o + 16, fp_from_mont<Fr>(s));
+    } else {
+      store_xy<S>(proofs_out + 96 * (size_t)j, r);
+      fp_store_le(proofs_out + 96 * (size_t)j + 64, fp_from_mont<Fr>(s));
+    }
     if (f) atomicOr(flags, f);
   }
+}
+
+// tiny::Verifier::verify (tiny.rs:178-214), one pair: R = s G + (s z) I - c pk - (c z) O on the eight quads, normalised (one
+// inversion), the challenge recomputed over it and compared with the proof's
+template <class S>
+__global__ void __launch_bounds__(64)
+k_tiny_verify_wave(BatchDev b, int32_t *__restrict__ status) {
+  using Fr = typename S::Fr; using Fq = typename S::Fq;
+  constexpr int NBITS = S::HAS_GLV ? 128 : Fr::BITS;
+  const uint32_t lane = threadIdx.x & 63, gl = lane & 31, q = gl >> 2, jc = gl & 3, tq = q >> 1, half = q & 1;
+  uint32_t j = b.first + 2 * blockIdx.x + (lane >> 5);
+  const bool live = j < b.n;
+  if (!live) j = b.n - 1;
+  const uint32_t io0 = b.io_off[j], ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0, *pk_xy = b.pks_xy + 64 * (size_t)j, *pr = b.proofs + 48 * (size_t)j;
+  suite_tr<S> t; uint32_t f = 0;
+  tr_base<S>(t, DS_TINY, true, pk_xy, ios, 1, b.ads + ad0, adl, &f);
+  fp c = fp_zero();
+  for (int i = 0; i < 4; i++) c.v[i] = (uint32_t)pr[4 * i] | ((uint32_t)pr[4 * i + 1] << 8) | ((uint32_t)pr[4 * i + 2] << 16) | ((uint32_t)pr[4 * i + 3] << 24);
+  const fp s = fp_load_le(pr + 16);
+  if (ge_p<Fr>(s)) f |= FLAG_SCALAR;                                            // InvalidData, tiny.rs:186-198 (reported below)
+  auto dseed = delin_seed(t);
+  const fp z = xof128(dseed, 0);
+  const uint8_t *src = tq == 1 ? ios : tq == 2 ? pk_xy : ios + 64;
+  const te_pre g = g_pre<S>();
+  const fp px = tq == 0 ? g.x : fp_to_mont<Fq>(fp_load_le(src)), py = tq == 0 ? g.y : fp_to_mont<Fq>(fp_load_le(src + 32));
+  const fp sm = fp_to_mont<Fr>(tq < 2 ? s : c);
+  const fp k = (tq & 1) ? fp_mul<Fr>(sm, z) : (tq < 2 ? s : c);
+  const WaveTerm<S> w = wave_term<S>(px, py, k, tq >= 2, half, jc);
+  fp v = q_smul<S, NBITS>(w.coord, w.k, jc);
+  v = wave_group_sum<S>(v, jc);
+  const fp zi = fp_inv<Fq>(qperm<3, 3, 3, 3>(v));
+  te_aff r; r.x = fp_mul<Fq>(qperm<0, 0, 0, 0>(v), zi); r.y = fp_mul<Fq>(qperm<1, 1, 1, 1>(v), zi);      // tiny.rs:207
+  suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);
+  const fp c_exp = challenge_finish(tc);                                        // plain, 128 bits
+  uint32_t bad = w.ok ? 0u : 1u;
+  for (int off = 16; off >= 1; off >>= 1) bad |= __shfl_xor(bad, off);
+  if (live && gl == 0) status[j] = f ? 2 : bad ? (int32_t)AVRF_WAVE_FALLBACK : fp_eq(c_exp, c) ? 0 : 1;
 }
 
 // ---------------------------------------------------------------- Pedersen VRF
@@ -848,9 +893,17 @@ template <class S> bool SingleOps<S>::thin_verify_wave(const BatchDev &b, int32_
   if constexpr (S::SW_NATIVE) return false;
   else { hipLaunchKernelGGL(k_thin_verify_wave<S>, dim3((b.n - b.first + 1) / 2), dim3(64), 0, st, b, d_status); return true; }
 }
-template <class S> bool SingleOps<S>::thin_prove_wave(const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st) {
+template <class S> bool SingleOps<S>::thin_prove_wave(const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st, bool tiny) {
   if constexpr (S::SW_NATIVE) return false;
-  else { hipLaunchKernelGGL(k_thin_prove_wave<S>, dim3((b.n - b.first + 1) / 2), dim3(64), 0, st, b, d_proofs_out, d_flags, d_status); return true; }
+  else {
+    if (tiny) hipLaunchKernelGGL((k_thin_prove_wave<S, true>), dim3((b.n - b.first + 1) / 2), dim3(64), 0, st, b, d_proofs_out, d_flags, d_status);
+    else hipLaunchKernelGGL((k_thin_prove_wave<S, false>), dim3((b.n - b.first + 1) / 2), dim3(64), 0, st, b, d_proofs_out, d_flags, d_status);
+    return true;
+  }
+}
+template <class S> bool SingleOps<S>::tiny_verify_wave(const BatchDev &b, int32_t *d_status, hipStream_t st) {
+  if constexpr (S::SW_NATIVE) return false;
+  else { hipLaunchKernelGGL(k_tiny_verify_wave<S>, dim3((b.n - b.first + 1) / 2), dim3(64), 0, st, b, d_status); return true; }
 }
 template <class S> bool SingleOps<S>::ped_verify_wave(const BatchDev &b, int32_t *d_status, hipStream_t st) {
   if constexpr (S::SW_NATIVE) return false;
@@ -914,9 +967,13 @@ bool launch_thin_verify_wave(int suite, const BatchDev &b, int32_t *d_status, hi
   if (!b.n) return false;
   return with_suite(suite, [&](auto tag_) { using S_ = typename decltype(tag_)::type; return SingleOps<S_>::thin_verify_wave(b, d_status, st); });
 }
-bool launch_thin_prove_wave(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st) {
+bool launch_thin_prove_wave(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, int32_t *d_status, hipStream_t st, bool tiny) {
   if (!b.n) return false;
-  return with_suite(suite, [&](auto tag_) { using S_ = typename decltype(tag_)::type; return SingleOps<S_>::thin_prove_wave(b, d_proofs_out, d_flags, d_status, st); });
+  return with_suite(suite, [&](auto tag_) { using S_ = typename decltype(tag_)::type; return SingleOps<S_>::thin_prove_wave(b, d_proofs_out, d_flags, d_status, st, tiny); });
+}
+bool launch_tiny_verify_wave(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st) {
+  if (!b.n) return false;
+  return with_suite(suite, [&](auto tag_) { using S_ = typename decltype(tag_)::type; return SingleOps<S_>::tiny_verify_wave(b, d_status, st); });
 }
 bool launch_ped_verify_wave(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st) {
   if (!b.n) return false;
