@@ -9,10 +9,11 @@
 //   k_smul           Secret::from_scalar / Secret::output  src/lib.rs:331-334,391-393
 // The merged I/O pair follows vrf_transcript_from_iter / merge_ios (src/utils/common.rs:181-202,
 // 389-419); any summation order gives the same group element.
+#include "te_quad.h"     // BEFORE proto_dev.h routes fp_mul to its out-of-line form: the quad operations of the few-items kernels are
+                         // latency chains and inline their two or three multiplier blocks (and use the dedicated squaring)
 #include "vrf_batch.h"
 #include "proto_dev.h"
 #include "glv.h"
-#include "te_quad.h"
 #include "suite_dispatch.h"
 
 // Built once per suite (-DAVRF_TU_SUITE=<id>: the kernels of that suite and the explicit instantiation of SingleOps<S>) and
