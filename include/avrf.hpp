@@ -156,6 +156,33 @@ class BatchVerifier {
  private:
   const Suite &su_; size_t n_ = 0;
   std::vector<uint8_t> pks_, proofs_; detail::Packed packed_;
+  friend class VerifierPool;
+};
+
+// Many thin::BatchVerifier::verify calls in flight on one device (avrf_pool, include/avrf.h): submit() hands a filled
+// BatchVerifier over and returns a ticket at once, wait() blocks for that batch's verdict.  The BatchVerifier (its buffers)
+// must stay alive and unchanged until wait() has returned for its ticket.
+class VerifierPool {
+ public:
+  VerifierPool(int suite, int device, int slots = 8, int lanes = 4, int threads = 2, int hash_group = 8) {
+    if (avrf_pool_create(suite, device, 1, slots, lanes, 0, threads, hash_group, &p_) != AVRF_OK) throw std::runtime_error("avrf: pool create");
+  }
+  ~VerifierPool() { avrf_pool_destroy(p_); }
+  VerifierPool(const VerifierPool &) = delete;
+  VerifierPool &operator=(const VerifierPool &) = delete;
+  uint64_t submit(const BatchVerifier &b) {
+    uint64_t t = 0;
+    if (avrf_pool_submit(p_, b.n_, b.pks_.data(), b.packed_.ios.data(), b.packed_.io_counts.data(), b.packed_.ads.data(), b.packed_.ad_lens.data(),
+                         b.proofs_.data(), &t) != AVRF_OK) throw std::runtime_error("avrf: pool submit");
+    return t;
+  }
+  Status wait(uint64_t ticket) {
+    int st = 0;
+    if (avrf_pool_wait(p_, ticket, &st) != AVRF_OK) throw std::runtime_error("avrf: pool wait");
+    return st;
+  }
+ private:
+  avrf_pool *p_ = nullptr;
 };
 
 }  // namespace thin

@@ -45,6 +45,13 @@ int main(int argc, char **argv) {
   thin::Proof bad = tp; bad.s[0] ^= 1;
   tb.push(pub, {io}, ad, bad);
   printf("thin_batch_bad=%d\n", tb.verify());
+  {  // the same two batches through the pool (native host threads, batches in flight together)
+    thin::BatchVerifier good(su);
+    for (int i = 0; i < 3; i++) good.push(pub, {io}, ad, tp);
+    thin::VerifierPool pool(atoi(argv[1]), 0, 4, 2, 2, 8);
+    const uint64_t t1 = pool.submit(good), t2 = pool.submit(tb), t3 = pool.submit(good);
+    printf("thin_pool=%d%d%d\n", pool.wait(t1), pool.wait(t2), pool.wait(t3));
+  }
 
   auto pp = pedersen::prove(su, secret, {io}, ad);
   put("ped_pk_com", pp.first.pk_com); put("ped_r", pp.first.r); put("ped_ok", pp.first.ok);

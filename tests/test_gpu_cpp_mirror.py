@@ -41,6 +41,7 @@ def test_mirror_reproduces_vectors(exe, golden_dir, suite):
         assert kv["ped_s"] == p["proof_s"] and kv["ped_sb"] == p["proof_sb"] and kv["ped_blinding"] == p["blinding"]
         assert [kv[k] for k in ("thin_verify", "thin_verify_bad_ad", "thin_batch_empty", "thin_batch", "thin_batch_bad")] == ["0", "1", "0", "0", "1"]
         assert [kv[k] for k in ("ped_verify", "ped_batch", "ped_batch_bad")] == ["0", "0", "1"]
+        assert kv["thin_pool"] == "010"                                   # good / tampered / good through thin::VerifierPool
 
 
 @pytest.mark.parametrize("suite", [0, 1, 2])
