@@ -30,9 +30,19 @@ def test_interleaved_suites_repeat(golden_dir):
         first = c.thin_prove(Batch.from_items(ios, ads, sks=sks, pks_xy=pks))
         assert [orc.point_compress(s, first[96 * j: 96 * j + 64]).hex() + first[96 * j + 64: 96 * j + 96].hex() for j in range(7)] == \
             [v["proof_r"] + v["proof_s"] for v in vs]
-        work[s] = (c, sks, pks, ios, ads, first)
+        # items with TWO I/O pairs take the lane-per-item kernels (one-pair calls of this size take the 32-lanes-per-item ones since
+        # round 4): both families stay under the interleaving
+        ios2 = []
+        for j in range(7):
+            inp2 = ios[(j + 1) % 7][0][0]                                             # another item's input point, this item's key
+            out2 = xy(s, orc.vrf_output(s, sks[j], orc.point_compress(s, inp2)))
+            ios2.append([ios[j][0], (inp2, out2)])
+        first2 = c.thin_prove(Batch.from_items(ios2, ads, sks=sks, pks_xy=pks))
+        work[s] = (c, sks, pks, ios, ads, first, ios2, first2)
     for rnd in range(25):
-        for s, (c, sks, pks, ios, ads, first) in work.items():
+        for s, (c, sks, pks, ios, ads, first, ios2, first2) in work.items():
+            assert c.thin_prove(Batch.from_items(ios2, ads, sks=sks, pks_xy=pks)) == first2, (rnd, s, "two pairs")
+            assert c.thin_verify(Batch.from_items(ios2, ads, pks_xy=pks, proofs=[first2[96 * j: 96 * j + 96] for j in range(7)])) == [0] * 7, (rnd, s, "two pairs")
             assert c.thin_prove(Batch.from_items(ios, ads, sks=sks, pks_xy=pks)) == first, (rnd, s, "given")
             assert c.thin_prove(Batch.from_items(ios, ads, sks=sks)) == first, (rnd, s, "derived")
             tp = [first[96 * j: 96 * j + 96] for j in range(7)]
