@@ -572,16 +572,23 @@ k_wsum_blk(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t *__restri
 
 // tuning knobs from the environment, read once per process
 struct MsmEnv {
-  int c = 0, per_min = 8, wsum_wps = 0, occ = 0; bool window_sums = true;
+  int c = 0, per_min = 8, wsum_wps = 0, occ = 0, tile = 0; bool window_sums = true;
   MsmEnv() {
     if (const char *e = getenv("AVRF_MSM_C")) { int v = atoi(e); if (v >= 3 && v <= 15) c = v; }
     if (const char *e = getenv("AVRF_MSM_OCC")) { int v = atoi(e); if (v >= 1 && v <= 8) occ = v; }   // resident k_accumulate waves per SIMD to fill
+    if (const char *e = getenv("AVRF_MSM_TILE")) { int v = atoi(e); if (v >= 1024 && v <= (1 << 22)) tile = v; }       // keys per sort workgroup of a batched launch
     if (const char *e = getenv("AVRF_MSM_PER_MIN")) { int v = atoi(e); if (v >= 1 && v <= 4096) per_min = v; }
     if (const char *e = getenv("AVRF_TE_WSUM_WPS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) wsum_wps = v; }
     if (const char *e = getenv("AVRF_TE_WINDOW_SUMS")) window_sums = atoi(e) != 0;
   }
 };
 static const MsmEnv &msm_env() { static const MsmEnv e; return e; }
+// sort tile: keys per workgroup of k_hist / k_scatter.  2048 / 4096 / 8192 measured the same headline, single-context MSM time and ring
+// rate (4096 moves 65 MB instead of 90 in k_scatter but doubles the histogram table); for the batched launches of the ring prover
+// (>= 64 bucket sets: parallelism comes from the vectors) AVRF_MSM_TILE = 32 768 / 131 072 / one tile per vector were no faster on
+// BLS12-381 and 5 % slower on BN254 (round 4: k_scatter moves 11 x its algorithmic bytes there, but it runs beside the other
+// contexts' multiplier-bound k_accumulate, so its memory time is not on the critical path).
+static uint32_t tile_len_for(size_t n, size_t vwin) { return vwin >= 64 && msm_env().tile ? (uint32_t)msm_env().tile : 8192u; }
 
 MsmPlan msm_plan(size_t n, int scalar_bits) {
   MsmPlan p;
@@ -594,9 +601,6 @@ MsmPlan msm_plan(size_t n, int scalar_bits) {
   return p;
 }
 
-// (sort tile: 2048 / 4096 / 8192 keys per workgroup measured the same headline, single-context MSM time and ring rate; 4096 moves
-// 65 MB instead of 90 in k_scatter but doubles the histogram table)
-static uint32_t tile_len_for(size_t n) { return 8192; }
 
 // lanes one residency round of k_accumulate<CV> holds on the current device (CUs x resident workgroups x 256), and the
 // dynamic LDS bytes that hold the kernel to that many workgroups per CU.  The kernel uses no LDS; asking for a slice of the
@@ -654,7 +658,7 @@ void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t b
   const size_t vwin = (size_t)p.nwin * batch;           // virtual windows
   const size_t nbk = vwin * p.nb, nbits = vwin * p.c;
   const size_t need_n = vwin * n;
-  const size_t ntiles = (n + tile_len_for(n) - 1) / tile_len_for(n);
+  const size_t ntiles = (n + tile_len_for(n, vwin) - 1) / tile_len_for(n, vwin);
   if (need_n > cap_n) {
     if (keys) HIP_CHECK(hipFree(keys));
     if (sorted) HIP_CHECK(hipFree(sorted));
@@ -763,7 +767,7 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   if ((size_t)vwin * n >= 0xffff0000ull) throw HipFailure{hipErrorInvalidValue, __FILE__, __LINE__};   // 32-bit entry offsets
   ws.ensure(n, p, acc_bytes, batch, lanes_max);
   const uint32_t nbk = vwin * p.nb;
-  const uint32_t tile_len = tile_len_for(n), ntiles = (uint32_t)((n + tile_len - 1) / tile_len);
+  const uint32_t tile_len = tile_len_for(n, vwin), ntiles = (uint32_t)((n + tile_len - 1) / tile_len);
   const size_t lds_bytes = (size_t)p.nb * 4;
   hipLaunchKernelGGL(k_digits, dim3((unsigned)((n_in + 255) / 256), (unsigned)batch), b256, 0, stream, d_scalars, (uint32_t)n_in, (uint32_t)scalar_stride,
                      p.c, dig_nwin, ws.keys, scalars_mont);

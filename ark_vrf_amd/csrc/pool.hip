@@ -13,7 +13,8 @@
 //     chains, folds finished ones (host_te.h) -- all from completion events, sleeping in the driver only when idle;
 //   * inputs are read where the caller put them: from buffers of avrf_host_alloc the staging copies are DMA transfers that
 //     overlap the other batches' kernels and cost no host time (include/avrf.h "Ownership").
-// Verdicts are those of avrf_thin_batch_run / avrf_pedersen_batch_run: the workers call the same phases (capi_internal.h).
+// Verdicts are those of avrf_thin_batch_run / avrf_pedersen_batch_run: the workers call the same phases (capi_internal.h), each
+// under `guarded` -- a failed HIP call or allocation inside a worker becomes the batch's status, never an exception off the thread.
 #include "capi_internal.h"
 #include "suite_dispatch.h"
 #include "host_sha512.h"
@@ -115,10 +116,10 @@ struct Run {
     c->L = &c->own;
     int st = AVRF_OK;
     if (S.from_host) {
-      st = ctx_stage(c, P->kind, S.n, nullptr, S.pks, S.ios, S.io_counts, S.ads, S.ad_lens, S.proofs, /*wait=*/false);
+      st = guarded([&] { return ctx_stage(c, P->kind, S.n, nullptr, S.pks, S.ios, S.io_counts, S.ads, S.ad_lens, S.proofs, /*wait=*/false); });
       S.has_batch = st == AVRF_OK;
     }
-    if (st == AVRF_OK) st = batch_begin(c, P->kind);
+    if (st == AVRF_OK) st = guarded([&] { return batch_begin(c, P->kind); });
     if (st == AVRF_OK && hipEventRecord(S.ev, c->stream) != hipSuccess) { (void)hipGetLastError(); st = AVRF_ERR_NO_DEVICE; }
     W.cpu_us[0] += thread_cpu_us() - t0;
     if (st != AVRF_OK) { done(S, st); return; }
@@ -131,7 +132,7 @@ struct Run {
     for (size_t i = 0; i < count; i++) {
       Slot &S = P->slots[ready[i]];
       if (batch_host_weights(S.c) || S.c->n == 0) {                    // sponge transcripts squeeze their own stream; empty batches have no transcript
-        int st = batch_seed(S.c, P->kind, S.digest);
+        int st = guarded([&] { return batch_seed(S.c, P->kind, S.digest); });
         if (st != AVRF_OK) { done(S, st); continue; }
         S.state = S_HASHED;
         continue;
@@ -157,7 +158,7 @@ struct Run {
     const double t0 = thread_cpu_us();
     S.lane = pick_lane(); S.lane->queued++;
     S.c->L = S.lane; S.c->stream = S.lane->stream;
-    int st = batch_launch(S.c, P->kind, S.digest);
+    int st = guarded([&] { return batch_launch(S.c, P->kind, S.digest); });
     if (st == AVRF_OK && hipEventRecord(S.ev, S.lane->stream) != hipSuccess) { (void)hipGetLastError(); st = AVRF_ERR_NO_DEVICE; }
     W.cpu_us[3] += thread_cpu_us() - t0;
     if (st != AVRF_OK) { if (S.c->run_phase == 2) { (void)hipStreamSynchronize(S.lane->stream); S.lane->ws.pending_armed = false; S.pend.armed = false; } done(S, st); return; }
@@ -166,7 +167,7 @@ struct Run {
 
   void finish(Slot &S) {
     const double t0 = thread_cpu_us();
-    const int st = batch_end(S.c, P->kind);
+    const int st = guarded([&] { return batch_end(S.c, P->kind); });
     W.cpu_us[4] += thread_cpu_us() - t0;
     done(S, st);
   }
@@ -202,7 +203,7 @@ struct Run {
         if (S.state != S_BEGUN) continue;
         if (hipEventQuery(S.ev) == hipSuccess) {
           const double t0 = thread_cpu_us();
-          const int st = batch_collect(S.c, P->kind);
+          const int st = guarded([&] { return batch_collect(S.c, P->kind); });
           W.cpu_us[1] += thread_cpu_us() - t0;
           if (st != AVRF_OK) done(S, st); else { S.state = S_READY; ready.push_back(si); }
           progress = true;
