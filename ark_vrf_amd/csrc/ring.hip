@@ -1319,9 +1319,43 @@ template <class S, class G> struct Ring {
     su->ptab.build(su->curve, su->g2_raw.data(), 2, su->stream);
     su->ptab_ready = true;
   }
+  // the Miller-loop lines of the setup's two fixed G2 arguments, tabulated once for the host pairing (host_pairing.h G2Lines)
+  using HP = HostPairing<G>;
+  static const typename HP::G2Lines *host_lines(avrf_ring_setup *su) {
+    static std::mutex lines_mu;
+    std::lock_guard<std::mutex> lk(lines_mu);
+    if (!su->host_lines) {
+      typename HP::G2 q[2];
+      const size_t g2len = su->g2_raw.size() / 2;
+      HP::g2_decode(su->g2_raw.data(), &q[0]); HP::g2_decode(su->g2_raw.data() + g2len, &q[1]);
+      auto *t = new typename HP::G2Lines[2];
+      t[0] = HP::g2_lines(q[0]); t[1] = HP::g2_lines(q[1]);
+      su->host_lines = t;
+      su->host_lines_free = [](void *p) { delete[] static_cast<typename HP::G2Lines *>(p); };
+    }
+    return static_cast<const typename HP::G2Lines *>(su->host_lines);
+  }
+  // Few independent checks: ONE wave of the device pairing kernel needs 11.7 ms whatever it carries, a host core 1.0 ms per check
+  // (line tables), so up to two checks per pool thread (at most 16) are finished on the host pool from the device's G1 sums.
+  static bool few_checks(size_t n) { size_t t = HostPool::get().size(); if (t > 8) t = 8; return n <= 2 * t; }
+  // pts: n x {A, B} Montgomery affine points as launch_g1_bases / launch_g1_lincomb write them ((0, 0) = infinity)
+  static void host_pair_checks(avrf_ring_setup *su, const uint32_t *pts, size_t n, int32_t *ok) {
+    const typename HP::G2Lines *lines = host_lines(su);
+    constexpr size_t FW = FQB / 4;
+    parallel_for(n, [&](size_t it) {
+      QEl px[2], py[2]; bool pinf[2];
+      for (int i = 0; i < 2; i++) {
+        const uint32_t *w = pts + (2 * it + i) * 2 * FW;
+        memset(&px[i], 0, sizeof(QEl)); memset(&py[i], 0, sizeof(QEl));
+        memcpy(px[i].l, w, FQB); memcpy(py[i].l, w + FW, FQB);
+        bool z = true; for (size_t k = 0; k < 2 * FW; k++) z = z && w[k] == 0;
+        pinf[i] = z;
+      }
+      ok[it] = HP::product_is_one_lines(px, py, pinf, lines, 2) ? 1 : 0;
+    });
+  }
   static int pairing_check(avrf_ring_setup *su, size_t n, const uint8_t *a_xy, const uint8_t *b_xy, int32_t *ok_out) {
     if (!n) return AVRF_OK;
-    ensure_pairing(su);
     const size_t e1 = 2 * FQB;
     std::vector<uint8_t> le(2 * n * e1);
     for (size_t i = 0; i < n; i++) { memcpy(&le[(2 * i) * e1], a_xy + i * e1, e1); memcpy(&le[(2 * i + 1) * e1], b_xy + i * e1, e1); }
@@ -1331,8 +1365,18 @@ template <class S, class G> struct Ring {
     HIP_CHECK(hipMemcpyAsync(d_le, le.data(), 2 * n * e1, hipMemcpyHostToDevice, su->stream));
     HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream));
     launch_g1_bases(su->curve, d_le, 2 * n, d_pts, d_flag, su->stream);
-    launch_pairing_check(su->ptab, d_pts, n, d_ok, su->stream);
     uint32_t flag = 0;
+    if (few_checks(n)) {
+      std::vector<uint32_t> pts(2 * n * e1 / 4);
+      HIP_CHECK(hipMemcpyAsync(pts.data(), d_pts, 2 * n * e1, hipMemcpyDeviceToHost, su->stream));
+      HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, su->stream));
+      HIP_CHECK(hipStreamSynchronize(su->stream)); HIP_CHECK(hipGetLastError());
+      if (flag) return AVRF_INVALID_DATA;
+      host_pair_checks(su, pts.data(), n, ok_out);
+      return AVRF_OK;
+    }
+    ensure_pairing(su);
+    launch_pairing_check(su->ptab, d_pts, n, d_ok, su->stream);
     HIP_CHECK(hipMemcpyAsync(ok_out, d_ok, n * 4, hipMemcpyDeviceToHost, su->stream));
     HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, su->stream));
     HIP_CHECK(hipStreamSynchronize(su->stream)); HIP_CHECK(hipGetLastError());
@@ -1488,7 +1532,10 @@ template <class S, class G> struct Ring {
     });
     if (status != AVRF_OK) return status;
     lap("decode + transcripts (host)");
-    if (each_status) {
+    // ONE independent verification is a batch of one: its two 11- / 2-term sums go through the MSM engine and the pairing
+    // check runs on the host (2.4 ms; the per-item device form below is paced by lone 381-bit double-and-add chains: 5 ms)
+    if (each_status && n == 1 && item_st[0]) { each_status[0] = item_st[0]; return AVRF_OK; }
+    if (each_status && n > 1) {
       // 13 (base, scalar) pairs per item: its 10 terms of the first argument, the g1 term, its 2 terms of the second
       const size_t e1 = 2 * FQB, TPI = 13;
       std::vector<uint8_t> bb(n * TPI * e1); std::vector<H256> ss(n * TPI);
@@ -1499,7 +1546,8 @@ template <class S, class G> struct Ring {
         memcpy(&bb[(it * TPI + 11) * e1], &b2[(2 * it) * e1], 2 * e1);
         ss[it * TPI + 11] = s2[2 * it]; ss[it * TPI + 12] = s2[2 * it + 1];
       }
-      ensure_pairing(su);
+      const bool host_pair = few_checks(n);
+      if (!host_pair) ensure_pairing(su);
       const size_t nb = n * TPI;
       const size_t pb = (nb * e1 + 255) / 256 * 256, sb = (nb * 32 + 255) / 256 * 256, ob = (n * 2 * e1 + 255) / 256 * 256, kb = (n * 4 + 255) / 256 * 256;
       uint8_t *base = (uint8_t *)dev_scratch(su, 1, 2 * pb + sb + ob + 2 * kb + 256);
@@ -1513,14 +1561,19 @@ template <class S, class G> struct Ring {
       launch_g1_bases(su->curve, d_xy, nb, d_b, d_flag, su->stream);
       if (!host_subgroup) launch_g1_subgroup_check(su->curve, d_b, nb, d_flag, su->stream, d_rec, (uint32_t)TPI);
       launch_g1_lincomb(su->curve, d_b, d_s, n, (uint32_t)TPI, 11, d_pts, su->stream, su->curve == 0);
-      launch_pairing_check(su->ptab, d_pts, n, d_ok, su->stream);
       std::vector<int32_t> okv(n), rec(n); uint32_t range_flag = 0;
-      HIP_CHECK(hipMemcpyAsync(okv.data(), d_ok, n * 4, hipMemcpyDeviceToHost, su->stream));
+      std::vector<uint32_t> pts(host_pair ? n * 2 * e1 / 4 : 0);
+      if (host_pair) HIP_CHECK(hipMemcpyAsync(pts.data(), d_pts, n * 2 * e1, hipMemcpyDeviceToHost, su->stream));
+      else {
+        launch_pairing_check(su->ptab, d_pts, n, d_ok, su->stream);
+        HIP_CHECK(hipMemcpyAsync(okv.data(), d_ok, n * 4, hipMemcpyDeviceToHost, su->stream));
+      }
       HIP_CHECK(hipMemcpyAsync(rec.data(), d_rec, n * 4, hipMemcpyDeviceToHost, su->stream));
       HIP_CHECK(hipMemcpyAsync(&range_flag, d_flag, 4, hipMemcpyDeviceToHost, su->stream));
       HIP_CHECK(hipStreamSynchronize(su->stream)); HIP_CHECK(hipGetLastError());
-      lap("per-item G1 sums + pairing checks (device)");
+      lap(host_pair ? "per-item G1 sums (device)" : "per-item G1 sums + pairing checks (device)");
       if (range_flag & 1) return AVRF_INVALID_DATA;      // a base with a coordinate >= p (launch_g1_bases): no item to pin it on
+      if (host_pair) { host_pair_checks(su, pts.data(), n, okv.data()); lap("pairing checks (host pool)"); }
       for (size_t it = 0; it < n; it++)
         each_status[it] = item_st[it] ? item_st[it] : rec[it] ? AVRF_INVALID_DATA : okv[it] ? AVRF_OK : AVRF_VERIFICATION_FAILURE;
       return AVRF_OK;
@@ -1532,27 +1585,16 @@ template <class S, class G> struct Ring {
     // subgroup-checked on the device before they are used (ark-serialize Validate::Yes; BLS12-381 G1 has a large cofactor)
     bool bad = false;
     G1Aff acc1 = g1_msm(su, b1, s1, !host_subgroup, &bad);
-    if (bad) return AVRF_INVALID_DATA;
+    if (bad) { if (each_status) { each_status[0] = AVRF_INVALID_DATA; return AVRF_OK; } return AVRF_INVALID_DATA; }
     G1Aff acc2 = g1_msm(su, b2, s2);
     lap("two G1 MSMs (device)");
-    using HP = HostPairing<G>;
-    // the two G2 arguments are the setup's: their Miller-loop lines are tabulated once (host_pairing.h G2Lines)
-    static std::mutex lines_mu;
-    if (std::lock_guard<std::mutex> lk(lines_mu); !su->host_lines) {
-      typename HP::G2 q[2];
-      const size_t g2len = su->g2_raw.size() / 2;
-      HP::g2_decode(su->g2_raw.data(), &q[0]); HP::g2_decode(su->g2_raw.data() + g2len, &q[1]);
-      auto *t = new typename HP::G2Lines[2];
-      t[0] = HP::g2_lines(q[0]); t[1] = HP::g2_lines(q[1]);
-      su->host_lines = t;
-      su->host_lines_free = [](void *p) { delete[] static_cast<typename HP::G2Lines *>(p); };
-    }
-    const typename HP::G2Lines *lines = static_cast<const typename HP::G2Lines *>(su->host_lines);
+    const typename HP::G2Lines *lines = host_lines(su);
     QEl px[2], py[2]; bool pinf[2] = {acc1.inf, acc2.inf};
     const G1Aff *accs[2] = {&acc1, &acc2};
     for (int i = 0; i < 2; i++) { QEl x, y; memset(&x, 0, sizeof x); memset(&y, 0, sizeof y); memcpy(x.l, accs[i]->xy, FQB); memcpy(y.l, accs[i]->xy + FQB, FQB); px[i] = FqN::to_mont(x); py[i] = FqN::to_mont(y); }
     const bool ok = HP::product_is_one_lines(px, py, pinf, lines, 2);
     lap("2-pairing check (host)");
+    if (each_status) { each_status[0] = ok ? AVRF_OK : AVRF_VERIFICATION_FAILURE; return AVRF_OK; }
     return ok ? AVRF_OK : AVRF_VERIFICATION_FAILURE;
   }
 };

@@ -373,8 +373,10 @@ int avrf_ring_batch_verify(avrf_ring_setup *setup, size_t n, const uint8_t *ring
 /* n x ring::Verifier::verify (src/ring.rs:228-247, the ring half): the same inputs as avrf_ring_batch_verify, but every proof is
  * checked on its own and gets its own status (status_out[i] = AVRF_OK / AVRF_VERIFICATION_FAILURE / AVRF_INVALID_DATA), so a
  * bad proof is identified instead of failing the batch: per proof two small G1 linear combinations and one 2-pairing check,
- * all on the device (Miller loops + final exponentiations of all proofs in one kernel, pairing.hip).  A ring commitment that
- * does not decode fails the call (AVRF_INVALID_DATA). */
+ * all on the device (Miller loops + final exponentiations of all proofs in one kernel, pairing.hip).  Few proofs are latency
+ * cases -- one wave of the pairing kernel needs 11.7 ms whatever it carries -- so up to 16 checks are finished on the host pool
+ * from the device's G1 sums (tabulated G2 lines, 1.0 ms per check and core), and n = 1 runs as a batch of one (2.4 ms; the
+ * reference: 3.24 ms).  Same statuses either way.  A ring commitment that does not decode fails the call (AVRF_INVALID_DATA). */
 int avrf_ring_verify_each(avrf_ring_setup *setup, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,
                           const uint8_t *instances_xy, const uint8_t *ring_proofs, int32_t *status_out);
 
@@ -383,7 +385,8 @@ int avrf_ring_verify_each(avrf_ring_setup *setup, size_t n, const uint8_t *ring_
  * the two `powers_in_g2` of the setup's SRS.  a_xy / b_xy: n G1 points each, canonical little-endian x || y (48+48 bytes
  * BLS12-381, 32+32 BN254; all-zero = infinity), assumed on the curve (they are outputs of the verifier's own MSMs).  Miller
  * loops and final exponentiations run as one kernel, an Fp12 element spread over 16 lanes (pairing.hip); the line tables of
- * the two G2 arguments are built on the device at first use.  AVRF_INVALID_DATA for a coordinate >= p. */
+ * the two G2 arguments are built on the device at first use (up to 16 checks: on the host pool, see avrf_ring_verify_each).
+ * AVRF_INVALID_DATA for a coordinate >= p. */
 int avrf_ring_pairing_check(avrf_ring_setup *setup, size_t n, const uint8_t *a_xy, const uint8_t *b_xy, int32_t *ok_out);
 
 /* Input::new(data) = Suite::data_to_point (src/lib.rs:440-444 via src/utils/hash_to_curve.rs:34-100) for n messages:

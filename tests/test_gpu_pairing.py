@@ -56,7 +56,8 @@ def test_srs_relations(env, suite):
 
 @pytest.mark.parametrize("suite", [0, 1])
 def test_matches_oracle_pairing(env, suite):
-    """Random G1 arguments (multiples of g1 and of tau g1): the device verdict equals oracle/pairing_py.pairing_product_is_one."""
+    """Random G1 arguments (multiples of g1 and of tau g1): the verdict of both forms of avrf_ring_pairing_check (<= 16 checks: host pool
+    with the tabulated G2 lines; more: device Miller loops) equals oracle/pairing_py.pairing_product_is_one."""
     from ark_vrf_amd.ring import pairing_check
     ctx, setup, srs = env[suite]
     s = R.SUITES[suite]
@@ -75,7 +76,8 @@ def test_matches_oracle_pairing(env, suite):
             A.append(a); B.append(b)
             want.append(1 if PP.pairing_product_is_one([(a, q0), (b, q1)]) else 0)
         assert want == [1, 0, 1, 0]
-        assert pairing_check(setup, [le_xy(s, P) for P in A], [le_xy(s, P) for P in B]) == want
+        assert pairing_check(setup, [le_xy(s, P) for P in A], [le_xy(s, P) for P in B]) == want          # few checks: finished on the host pool
+        assert pairing_check(setup, [le_xy(s, P) for P in A] * 8, [le_xy(s, P) for P in B] * 8) == want * 8  # 32 checks: the device pairing kernel
     finally:
         PP.use_curve("bls12_381")
 

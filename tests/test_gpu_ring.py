@@ -144,7 +144,8 @@ def test_ring_verify_reference_vectors(env, suite):
 @pytest.mark.parametrize("suite", [0, 1])
 def test_ring_verify_each(env, suite):
     """n x ring::Verifier::verify (src/ring.rs:228-247) with per-proof statuses: G1 sums and the 2-pairing checks of all proofs
-    on the device (avrf_ring_verify_each).  The reference's vectors verify; exactly the perturbed proofs are reported."""
+    on the device for many proofs, on the host pool for <= 16, one lone verification as a batch of one (avrf_ring_verify_each).  The
+    reference's vectors verify; exactly the perturbed proofs are reported."""
     from ark_vrf_amd.ring import ring_batch_verify, ring_verify_each
     ctx, setup, vs, srs = env[suite]
     coms = [bytes.fromhex(v["ring_pks_com"]) for v in vs]
@@ -158,6 +159,9 @@ def test_ring_verify_each(env, suite):
     b2 = bytearray(bad[2]); b2[4 * fq + 5] ^= 1; bad[2] = bytes(b2)                       # an evaluation
     b5 = bytearray(bad[5]); b5[4 * fq + 7 * 32 + fq + 31] = 0xff; bad[5] = bytes(b5)      # a scalar >= r: InvalidData
     assert ring_verify_each(setup, coms, list(range(7)), insts, bad) == [0, 0, 1, 0, 0, 2, 0]
+    # one verification per call (the batch-of-one form: MSM engine + host pairing) reports the same statuses
+    assert [ring_verify_each(setup, [coms[i]], None, [insts[i]], [bad[i]])[0] for i in range(7)] == [0, 0, 1, 0, 0, 2, 0]
+    assert ring_verify_each(setup, coms, [4], [insts[3]], [proofs[3]]) == [1]             # against the wrong ring
     assert ring_batch_verify(setup, coms, list(range(7)), insts, bad) == 2                # the batch verifier only sees "something is wrong"
     assert ring_verify_each(setup, coms, [0, 1, 2, 4, 3, 5, 6], insts, proofs) == [0, 0, 0, 1, 1, 0, 0]      # two proofs against the wrong ring
     assert ring_verify_each(setup, coms, list(range(7)), insts[1:] + insts[:1], proofs) == [1] * 7
@@ -168,6 +172,7 @@ def test_ring_verify_each(env, suite):
         off = R.g1_encode(s, (x, y), True)
         bad = list(proofs); bad[4] = off + bad[4][48:]
         assert ring_verify_each(setup, coms, list(range(7)), insts, bad) == [0, 0, 0, 0, 2, 0, 0]
+        assert ring_verify_each(setup, [coms[4]], None, [insts[4]], [bad[4]]) == [2]
 
 
 @pytest.mark.parametrize("suite", [0, 1])
