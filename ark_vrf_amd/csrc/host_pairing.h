@@ -236,6 +236,30 @@ template <class C> struct HostPairing {
     return f12_is_one(final_exp(f));
   }
 
+  // the same with one Miller loop per pair, each on its own thread of `pf` (pf(n, fn) runs fn(0..n-1)): a pair then pays its own
+  // squarings of f, but for the verifier's two pairs the loop takes 63 squarings + 69 line products on the critical path
+  // instead of 63 + 138 (a lone verification is a latency case: 1.04 -> 0.85 ms for the check)
+  template <class ParFor>
+  static bool product_is_one_lines_par(const El *px, const El *py, const bool *pinf, const G2Lines *tabs, int n, ParFor pf) {
+    std::vector<F12> fs(n);
+    pf((size_t)n, [&](size_t i) {
+      F12 f = f12_one();
+      if (!(pinf[i] || tabs[i].inf)) {
+        size_t pos = 0;
+        for (int bit = C::ATE_LOOP_BITS - 2; bit >= 0; bit--) {
+          f = f12_sqr(f);
+          const int steps = 1 + (int)((C::ATE_LOOP[bit >> 6] >> (bit & 63)) & 1);
+          for (int st = 0; st < steps && pos < tabs[i].live_steps; st++, pos++)
+            f = f12_mul_line(f, tabs[i].c[pos], f2_neg(f2_scale(tabs[i].lam[pos], px[i])), py[i]);
+        }
+      }
+      fs[i] = f;
+    });
+    F12 f = fs[0];
+    for (int i = 1; i < n; i++) f = f12_mul(f, fs[i]);
+    return f12_is_one(final_exp(f));
+  }
+
   // prod_i e(P_i, Q_i) == 1 ?   P_i affine G1 (Montgomery x, y; inf flag), Q_i affine G2 on the twist
   static bool product_is_one(const El *px, const El *py, const bool *pinf, const G2 *q, int n) {
     std::vector<F2> rx(n), ry(n);

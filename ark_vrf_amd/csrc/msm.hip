@@ -33,6 +33,7 @@
 // Layout in HBM: points AoS (te_pre x|y|k 96 B; G1 affine x|y 64 / 96 B), gathered whole by one lane with dwordx4
 // loads; keys/sorted SoA per window (coalesced); buckets AoS (te_ext 128 B; XYZZ 128 / 192 B).
 #include "msm.h"
+#include "host_pool.h"
 #include "curves.h"
 #include "suite_dispatch.h"
 #include "te_quad.h"
@@ -1046,7 +1047,8 @@ static int msm_g1_impl(const uint32_t *d_bases, const uint32_t *d_scalars, size_
   constexpr size_t OUT = 8 * C::Fq::N;                    // bytes of one affine result
   int nbits = n ? msm_device<G1Curve<C>>(d_bases, d_scalars, n, C::Fr::BITS, ws, stream, batch, table_c, table_stride, scalar_stride, d_base_idx, false, scalars_mont) : 0;
   std::vector<typename HG::Pt> res(batch);
-  for (size_t b = 0; b < batch; b++) {
+  // (a few vectors without the device Horner: their bit-sum Horners -- nbits doublings and additions each -- run side by side)
+  auto fold = [&](size_t b) {
     typename HG::Pt acc = HG::identity();
     if (batch >= 8 || table_c) acc = HG::from_raw32(ws.bits_host + b * 4 * C::Fq::N);      // Horner already done on the device
     else if (n) {
@@ -1057,7 +1059,9 @@ static int msm_g1_impl(const uint32_t *d_bases, const uint32_t *d_scalars, size_
       }
     }
     res[b] = acc;
-  }
+  };
+  if (batch >= 2 && batch < 8 && !table_c) parallel_for(batch, fold);
+  else for (size_t b = 0; b < batch; b++) fold(b);
   HG::to_affine_bytes_batch(res.data(), batch, out_xy);
   (void)OUT;
   return 0;
