@@ -231,6 +231,34 @@ template <class F> AVRF_DN fp fp_inv_nf(fp a) {
   }
   return r;
 }
+// a^-1 of a Montgomery-form a (0 -> 0, as a^(p-2) gives) by the binary extended Euclidean algorithm on the plain integers:
+// ~1.4 * 255 halvings and ~0.7 * 255 subtractions of 8-limb values (~20 k carry instructions) instead of the 255 squarings and
+// ~130 products of the fixed power (~110 k instructions, two thirds of them multiply-adds).  For the LATENCY kernels only
+// (vrf_single.hip "few items"): there the lanes of an item hold the same value, so the data-dependent loops do not diverge (two
+// items in a wave: at most both paths).  The lane-per-item kernels keep the fixed-length power -- 64 different trip counts per
+// wave would serialise.  Invariants: x1 a = u, x2 a = v (mod p).
+template <class F> AVRF_DN fp fp_inv_few(fp a) {
+  if (fp_is_zero(a)) return a;
+  const fp P = fp_const<F>(F::P);
+  fp u = a, v = P, x1 = fp_zero(), x2 = fp_zero();
+  x1.v[0] = 1;
+  auto is_one = [](const fp &x) { uint32_t o = x.v[0] ^ 1u; for (int i = 1; i < 8; i++) o |= x.v[i]; return o == 0; };
+  auto shr1 = [](fp &x, uint32_t top) { for (int i = 0; i < 7; i++) x.v[i] = (x.v[i] >> 1) | (x.v[i + 1] << 31); x.v[7] = (x.v[7] >> 1) | (top << 31); };
+  auto halve_mod = [&](fp &x) { uint32_t c = 0; if (x.v[0] & 1u) c = add8(x, x, P); shr1(x, c); };
+#pragma unroll 1
+  while (!is_one(u) && !is_one(v)) {
+#pragma unroll 1
+    while (!(u.v[0] & 1u)) { shr1(u, 0); halve_mod(x1); }
+#pragma unroll 1
+    while (!(v.v[0] & 1u)) { shr1(v, 0); halve_mod(x2); }
+    fp t;
+    if (sub8(t, u, v) == 0) { u = t; x1 = fp_sub<F>(x1, x2); }
+    else { sub8(v, v, u); x2 = fp_sub<F>(x2, x1); }
+  }
+  const fp r = is_one(u) ? x1 : x2;                       // (a' R)^-1 for a = a' R; times R^3 / R gives a'^-1 R
+  const fp r2 = fp_const<F>(F::R2);
+  return fp_mul_nf<F>(r, fp_mul_nf<F>(r2, r2));
+}
 template <class F> AVRF_DN fp fp_pow_nf(fp a, int which) {   // which: 0 -> T_MINUS1_HALF
   fp r = fp_one<F>();
   bool started = false;

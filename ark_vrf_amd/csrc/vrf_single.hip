@@ -325,7 +325,7 @@ k_thin_prove_wave(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__rest
   const WaveTerm<S> w = wave_term<S>(px, py, ks, false, half, jc);
   fp v = q_smul<S, NBITS>(w.coord, w.k, jc);
   v = wave_group_sum<S>(v, jc);
-  const fp zi = fp_inv<Fq>(qperm<3, 3, 3, 3>(v));
+  const fp zi = fp_inv_few<Fq>(qperm<3, 3, 3, 3>(v));
   te_aff r; r.x = fp_mul<Fq>(qperm<0, 0, 0, 0>(v), zi); r.y = fp_mul<Fq>(qperm<1, 1, 1, 1>(v), zi);      // thin.rs:119
   suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);    // thin.rs:122
   const fp c = fp_to_mont<Fr>(challenge_finish(tc));
@@ -376,7 +376,7 @@ k_tiny_verify_wave(BatchDev b, int32_t *__restrict__ status) {
   const WaveTerm<S> w = wave_term<S>(px, py, k, tq >= 2, half, jc);
   fp v = q_smul<S, NBITS>(w.coord, w.k, jc);
   v = wave_group_sum<S>(v, jc);
-  const fp zi = fp_inv<Fq>(qperm<3, 3, 3, 3>(v));
+  const fp zi = fp_inv_few<Fq>(qperm<3, 3, 3, 3>(v));
   te_aff r; r.x = fp_mul<Fq>(qperm<0, 0, 0, 0>(v), zi); r.y = fp_mul<Fq>(qperm<1, 1, 1, 1>(v), zi);      // tiny.rs:207
   suite_tr<S> tc = t; tr_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);
   const fp c_exp = challenge_finish(tc);                                        // plain, 128 bits
@@ -548,9 +548,10 @@ template <class S> AVRF_DI fp q_smul_fixed(const te_pre *tab, int base, const fp
   return acc;
 }
 
-// pedersen::Prover::prove (pedersen.rs:136-186), one pair: an item on 32 lanes.  The two fixed-base results (Yb, then R after the
-// nonces) are computed by EVERY quad of the item alike (same table entries, two-round mixed additions: no divergence, 32 + 64 of
-// them); Ok = k I runs as the two endomorphism halves on quads 0 and 1.
+// pedersen::Prover::prove (pedersen.rs:136-186), one pair: an item on 32 lanes.  Yb = pk + bl B, which the nonces wait for, is
+// computed by EVERY quad of the item alike from the context's fixed-base table (32 two-round mixed additions, no divergence);
+// R = k G + kb B and Ok = k I then share one doubling chain, a term's endomorphism half per quad.  The two normalisations use the
+// binary-Euclid inversion (fp256.h fp_inv_few).
 template <class S>
 __global__ void __launch_bounds__(64)
 k_ped_prove_wave(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ blindings_out, uint32_t *__restrict__ flags, int32_t *__restrict__ status) {
@@ -574,20 +575,30 @@ k_ped_prove_wave(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restri
   fp yq = q_smul_fixed<S>(b.fixed, FIXED_B, bl_plain, jc);                      // :148-149
   yq = q_madd<S>(yq, pkp.x, pkp.y, pkp.k, jc);
   te_aff yb;
-  { const fp zi = fp_inv<Fq>(qperm<3, 3, 3, 3>(yq)); yb.x = fp_mul<Fq>(qperm<0, 0, 0, 0>(yq), zi); yb.y = fp_mul<Fq>(qperm<1, 1, 1, 1>(yq), zi); }
+  { const fp zi = fp_inv_few<Fq>(qperm<3, 3, 3, 3>(yq)); yb.x = fp_mul<Fq>(qperm<0, 0, 0, 0>(yq), zi); yb.y = fp_mul<Fq>(qperm<1, 1, 1, 1>(yq), zi); }
   absorb_point_mont<S>(t, yb);                                                  // :152
   const fp k = nonce<S>(sk, t), kb = nonce<S>(bl_plain, t);                     // :155-156
   const fp k_plain = fp_from_mont<Fr>(k);
-  fp rq = q_smul_fixed<S>(b.fixed, FIXED_G, k_plain, jc);                       // :159-161
-  { const fp kbq = q_smul_fixed<S>(b.fixed, FIXED_B, fp_from_mont<Fr>(kb), jc); rq = q_add<S>(rq, kbq, jc); }
-  const fp ix = fp_to_mont<Fq>(fp_load_le(ios)), iy = fp_to_mont<Fq>(fp_load_le(ios + 32));
-  const WaveTerm<S> w = wave_term<S>(ix, iy, tq == 0 ? k_plain : fp_zero(), false, half, jc);
-  fp oq = q_smul<S, NBITS>(w.coord, w.k, jc);                                   // :164
-  oq = wave_group_sum<S>(oq, jc);
+  // R = k G + kb B (:159-161) and Ok = k I (:164) on ONE doubling chain: term pair 0 = (I, k), 1 = (G, k), 2 = (B, kb), each as its
+  // two endomorphism halves; pair 3 carries a zero scalar.  Two butterfly steps then leave Ok in quads 0-1 and R in quads 2-5
+  // (quads 0-1 and 6-7 only meet pair 3's identity in the second step).
+  const te_pre cst = tq == 2 ? b_pre<S>() : g_pre<S>();
+  const fp px = tq == 0 ? fp_to_mont<Fq>(fp_load_le(ios)) : cst.x, py = tq == 0 ? fp_to_mont<Fq>(fp_load_le(ios + 32)) : cst.y;
+  const fp kt = tq == 2 ? fp_from_mont<Fr>(kb) : tq == 3 ? fp_zero() : k_plain;
+  const WaveTerm<S> w = wave_term<S>(px, py, kt, false, half, jc);
+  fp sq = q_smul<S, NBITS>(w.coord, w.k, jc);
+  sq = q_add<S>(sq, fp_shfl_xor(sq, 4), jc);
+  sq = q_add<S>(sq, fp_shfl_xor(sq, 24), jc);
+  fp oq, rq;                                                                    // every lane of the item: its coordinate of Ok and of R
+  {
+    const int base_lane = (int)(lane & 32u) + (int)jc;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { oq.v[i] = __shfl(sq.v[i], base_lane); rq.v[i] = __shfl(sq.v[i], base_lane + 8); }
+  }
   te_aff ra, oka;                                                               // :166-167, one inversion for both
   {
     const fp rz = qperm<3, 3, 3, 3>(rq), oz = qperm<3, 3, 3, 3>(oq);
-    const fp inv = fp_inv<Fq>(fp_mul<Fq>(rz, oz)), ri = fp_mul<Fq>(inv, oz), oi = fp_mul<Fq>(inv, rz);
+    const fp inv = fp_inv_few<Fq>(fp_mul<Fq>(rz, oz)), ri = fp_mul<Fq>(inv, oz), oi = fp_mul<Fq>(inv, rz);
     ra.x = fp_mul<Fq>(qperm<0, 0, 0, 0>(rq), ri); ra.y = fp_mul<Fq>(qperm<1, 1, 1, 1>(rq), ri);
     oka.x = fp_mul<Fq>(qperm<0, 0, 0, 0>(oq), oi); oka.y = fp_mul<Fq>(qperm<1, 1, 1, 1>(oq), oi);
   }
