@@ -120,8 +120,48 @@ template <class F> AVRF_DI fe<F> fn_sqr(const fe<F> &a) {
 template <class F> AVRF_DI fe<F> fn_to_mont(const fe<F> &a) { return fn_mul<F>(a, fn_const<F>(F::R2)); }
 template <class F> AVRF_DI fe<F> fn_from_mont(const fe<F> &a) { fe<F> one = fn_zero<F::N>(); one.v[0] = 1; return fn_mul<F>(a, one); }
 
-// a^(p-2) (field inversion), square-and-multiply over the constant exponent
-template <class F> AVRF_DI fe<F> fn_inv(const fe<F> &a) {
+// a^-1 (0 -> 0): branch-free binary GCD, one fused halving step per iteration -- the N-limb form of fp256.h's fp_inv_nf (see the
+// comment there; invariants x1 a = u, x2 a = v mod p, v odd).  ~1.4 x BITS iterations of ~15 N carry / select instructions: for
+// the 381-bit field ~95 k instructions against ~570 twelve-limb Montgomery products (~330 k instructions, most of them
+// multiply-adds) for the fixed power below -- the inversion was 1.4 ms of a lone wave in k_g1_lincomb and in the pairing kernel.
+template <class F> __device__ __noinline__ static fe<F> fn_inv(fe<F> a) {
+  constexpr int N = F::N;
+  fe<F> u = a, v = fn_const<F>(F::P), x1 = fn_zero<N>(), x2 = fn_zero<N>();
+  x1.v[0] = 1;
+#pragma unroll 1
+  while (!fn_is_zero(u)) {
+    const bool odd = (u.v[0] & 1u) != 0;
+    fe<F> d1, d2; unsigned b1 = 0, b2 = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) { d1.v[i] = __builtin_subc(u.v[i], v.v[i], b1, &b1); d2.v[i] = __builtin_subc(v.v[i], u.v[i], b2, &b2); }
+    const bool lt = b1 != 0, sw = odd && lt;
+    fe<F> xa, xb;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const uint32_t un = odd ? (lt ? d2.v[i] : d1.v[i]) : u.v[i];
+      v.v[i] = sw ? u.v[i] : v.v[i];
+      u.v[i] = un;
+      xa.v[i] = sw ? x2.v[i] : x1.v[i];
+      xb.v[i] = odd ? (sw ? x1.v[i] : x2.v[i]) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) u.v[i] = (u.v[i] >> 1) | (u.v[i + 1] << 31);
+    u.v[N - 1] >>= 1;
+#pragma unroll
+    for (int i = 0; i < N; i++) x2.v[i] = sw ? x1.v[i] : x2.v[i];
+    fe<F> t = fn_sub<F>(xa, xb);
+    const uint32_t m = 0u - (t.v[0] & 1u); unsigned c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) t.v[i] = __builtin_addc(t.v[i], (unsigned)(F::P[i] & m), c, &c);
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) x1.v[i] = (t.v[i] >> 1) | (t.v[i + 1] << 31);
+    x1.v[N - 1] = (t.v[N - 1] >> 1) | ((uint32_t)c << 31);
+  }
+  const fe<F> r2 = fn_const<F>(F::R2);                      // x2 = (a' R)^-1 for a = a' R; times R^3 / R gives a'^-1 R
+  return fn_mul<F>(x2, fn_mul<F>(r2, r2));
+}
+// a^(p-2), square-and-multiply over the constant exponent (the cross-check of fn_inv)
+template <class F> AVRF_DI fe<F> fn_inv_fermat(const fe<F> &a) {
   fe<F> r = fn_one<F>();
   bool started = false;
   for (int i = 32 * F::N - 1; i >= 0; i--) {
