@@ -394,7 +394,7 @@ k_ring_witness_acc(const te_pre *__restrict__ points, const uint32_t *__restrict
       next_row = keyset + bit; bit++;
     }
   }
-  fp inv = fp_inv<F>(run);
+  fp inv = fp_inv_nf<F>(run);                                                   // (binary GCD, fp256.h: the fixed power was ~30 % of this kernel)
   // pass 2 (backwards): affine coordinates (Montgomery form) and, one row behind, the sparse scalars of the two accumulator columns
   uint32_t *v = vals + (size_t)p * 257 * 16;
   uint32_t *b = bi + (size_t)p * 4 * MP; uint32_t *qv = sc + (size_t)p * 4 * MP * 8;
