@@ -820,6 +820,41 @@ __global__ void __launch_bounds__(64)
 k_decompress_wave(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ out_xy, int32_t *__restrict__ status) {
   using Fr = typename S::Fr; using Fq = typename S::Fq;
   const uint32_t jc = threadIdx.x & 3;
+  if constexpr (S::HAS_GLV) {
+    // With the endomorphism the test is  a2 P + b2 psi(P) == 0  for the lattice vector (a2, b2), a2 + b2 lambda = 0 mod r, both
+    // below 2^127: two quads per point run 43 windows instead of one quad running 85.  WHICH basis vector matters: on a point
+    // S + T (S of order r, T in the 2-torsion: (0, -1) and the two points at infinity of this model) the sum is a2 T + b2 psi(T),
+    // and (a2, b2) = (3, 0) mod 4 leaves T itself, while (a1, b1) = (0, 1) mod 4 would ACCEPT the coset of (0, -1)
+    // (checked over all cosets by tests/test_gpu_wire.py::test_torsion_points; a point at infinity has Z = 0 != Y).
+    const uint32_t h = (threadIdx.x >> 2) & 1u;
+    uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const bool live = j < n;
+    if (!live) j = n - 1;
+    fp xm, ym, x, y; bool check;
+    int32_t st = decode_point<S>(in, j, 1, xm, ym, x, y, check);
+    if (!check) { xm = fp_zero(); ym = fp_one<Fq>(); }
+    te_pre p; p.x = xm; p.y = ym; p.k = fp_zero();
+    te_ext e; e.x = xm; e.y = ym; e.t = fp_mul<Fq>(xm, ym); e.z = fp_one<Fq>();
+    te_ext q;
+    const bool endo_ok = te_endo<S>(p, q);                                      // false: x y = 0 (order <= 2) or y^2 = b
+    if (__any(check && !endo_ok)) {                                             // (rare, uniform: the whole wave takes the plain r P test)
+      const fp coord = jc == 0 ? e.x : jc == 1 ? e.y : jc == 2 ? e.t : e.z;
+      const fp v = q_smul<S, Fr::BITS>(coord, fp_const<Fr>(Fr::P), jc);
+      const fp X = qperm<0, 0, 0, 0>(v), Y = qperm<1, 1, 1, 1>(v), Z = qperm<3, 3, 3, 3>(v);
+      if (check && !(fp_is_zero(X) && fp_eq(Y, Z))) st = 2;
+    } else {
+      if (h) e = q;
+      fp k = fp_zero();
+#pragma unroll
+      for (int i = 0; i < 4; i++) k.v[i] = h ? S::GLV_B2[i] : S::GLV_A2[i];
+      const fp coord = jc == 0 ? e.x : jc == 1 ? e.y : jc == 2 ? e.t : e.z;
+      fp v = q_smul<S, 128>(coord, k, jc);
+      v = q_add<S>(v, fp_shfl_xor(v, 4), jc);
+      const fp X = qperm<0, 0, 0, 0>(v), Y = qperm<1, 1, 1, 1>(v), Z = qperm<3, 3, 3, 3>(v);
+      if (check && !(fp_is_zero(X) && fp_eq(Y, Z))) st = 2;
+    }
+    if (live && jc == 0 && h == 0) { fp_store_le(out_xy + 64 * (size_t)j, x); fp_store_le(out_xy + 64 * (size_t)j + 32, y); status[j] = st; }
+  } else {
   uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   const bool live = j < n;
   if (!live) j = n - 1;
@@ -831,6 +866,7 @@ k_decompress_wave(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restric
   const fp X = qperm<0, 0, 0, 0>(v), Y = qperm<1, 1, 1, 1>(v), Z = qperm<3, 3, 3, 3>(v);
   if (check && !(fp_is_zero(X) && fp_eq(Y, Z))) st = 2;
   if (live && jc == 0) { fp_store_le(out_xy + 64 * (size_t)j, x); fp_store_le(out_xy + 64 * (size_t)j + 32, y); status[j] = st; }
+  }
 }
 // Validate::Yes for points that cross the ABI as canonical x || y (the reference's typed points have passed
 // CanonicalDeserialize / the checked constructors, src/lib.rs:410-433,471-494): point p of record j sits at
@@ -936,7 +972,7 @@ template <class S> void SingleOps<S>::hash_to_curve(const uint8_t *d_data, const
 }
 template <class S> void SingleOps<S>::decompress(const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st) {
   if constexpr (!S::SW_NATIVE) if (validate && n <= 4096) {           // few points: four lanes per point for the subgroup test
-    hipLaunchKernelGGL(k_decompress_wave<S>, dim3((4 * n + 63) / 64), dim3(64), 0, st, d_in, n, d_out, d_status);
+    hipLaunchKernelGGL(k_decompress_wave<S>, dim3(((S::HAS_GLV ? 8 : 4) * n + 63) / 64), dim3(64), 0, st, d_in, n, d_out, d_status);   // (two quads per point with the endomorphism)
     return;
   }
   hipLaunchKernelGGL(k_decompress<S>, dim3((n + 127) / 128), dim3(128), 0, st, d_in, n, d_out, validate, d_status);

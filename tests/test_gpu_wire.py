@@ -114,6 +114,53 @@ def test_torsion_points(ctxs, golden_dir, suite):
     assert _call("avrf_thin_verify_wire", c, 7, pks, ios_t, one, ads, tp, 1, True) == (0, [0, 0, 2, 0, 0, 0, 0])
 
 
+def test_subgroup_check_all_cosets(ctxs):
+    """Validate::Yes on random AFFINE Bandersnatch points: a curve point is S + T with S of order r and T one of the four 2-torsion
+    points of this model -- the identity, (0, -1), and two points at infinity (a = -5 is not a square) -- so only a quarter of
+    the curve's affine points pass.  The few-points kernel tests  a2 P + b2 psi(P) == 0  with the endomorphism (two 127-bit halves
+    instead of r P); the lane-per-item kernels compute r P.  Both must agree with plain affine arithmetic on every coset (the OTHER
+    basis vector of the lattice would accept the coset of (0, -1): vrf_single.hip k_decompress_wave)."""
+    import random
+    c = ctxs[0]
+    q = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    r = 0x1cfb69d4ca675f520cce760202687600ff8f87007419047174fd06b52876e7e1
+    d = 0x6389c12633c267cbc66e3bf86be3b6d8cb66677177e54f92b369f2f5188d58e7
+    a = q - 5
+
+    def add(p1, p2):                                                    # affine law; ValueError = the sum is a point at infinity
+        x1, y1 = p1; x2, y2 = p2
+        t = d * x1 * x2 * y1 * y2 % q
+        return ((x1 * y2 + y1 * x2) * pow(1 + t, -1, q) % q, (y1 * y2 - a * x1 * x2) * pow(1 - t, -1, q) % q)
+
+    def coset(p):                                                       # r P: (0, 1) in the subgroup, (0, -1), or at infinity
+        acc = (0, 1)
+        try:
+            for bit in bin(r)[2:]:
+                acc = add(acc, acc)
+                if bit == "1":
+                    acc = add(acc, p)
+        except ValueError:
+            return "inf"
+        return {(0, 1): "sub", (0, q - 1): "neg"}[acc]
+    rng = random.Random(11)
+    comp, kinds = [], []
+    while len(comp) < 40:
+        y = rng.randrange(q)
+        st, pxy = orc.point_decompress(0, y.to_bytes(32, "little"))
+        if st != 0:
+            continue
+        x = int.from_bytes(pxy[:32], "little")
+        assert (a * x * x + y * y - 1 - d * x * x * y * y) % q == 0
+        comp.append(y.to_bytes(32, "little")); kinds.append(coset((x, y)))
+    assert {"sub", "neg", "inf"} <= set(kinds)                          # all three kinds occur among 40 random points
+    want = [0 if k == "sub" else 2 for k in kinds]
+    xy_out, st = c.points_decompress(b"".join(comp), validate=True)     # the few-points kernel (<= 4096 points)
+    assert st == want
+    xy_all, st_all = c.points_decompress(b"".join(comp) * 110, validate=True)   # 4400 points: the lane-per-item kernel
+    assert st_all == want * 110 and xy_all[: 64 * 40] == xy_out
+    assert c.points_decompress(b"".join(comp), validate=False)[1] == [0] * 40
+
+
 @pytest.mark.parametrize("suite", [0, 1])
 def test_ring_vrf_one_call(ctxs, golden_dir, suite):
     """ring::Prover::prove / ring::Verifier::verify / ring::BatchVerifier as single calls on the reference's ring vectors:
