@@ -10,6 +10,7 @@
 //   ring-VRF proof  pedersen proof || ring proof            src/ring.rs:160-166        (752 / 640 bytes)
 #include "../../include/avrf.h"
 #include <string.h>
+#include <thread>
 #include <vector>
 
 extern "C" int avrf_ctx_suite_(avrf_ctx *c);
@@ -40,54 +41,81 @@ size_t sum_counts(const uint32_t *c, size_t n) { size_t t = 0; for (size_t i = 0
 // ring::Verifier also needs as the ring proof's instance) -- so that a caller does not decompress it a second time
 constexpr size_t SMALL_BATCH = 64;   // a "batch" of up to this many items takes the per-item verifiers (one wave per item: 0.6 ms) instead
                                      // of the Pippenger chain (14 launches + the weight transcript: 1.5 ms for one item); same verdict
-int verify_wire(avrf_ctx *ctx, int kind, bool batch, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
-                const uint32_t *ad_lens, const uint8_t *proofs, int validate, int32_t *status_out,
-                std::vector<uint8_t> *pp0_xy = nullptr, std::vector<int32_t> *pp0_st = nullptr) {
-  std::vector<int32_t> small_status;
-  const bool small = batch && n <= SMALL_BATCH && kind != 3;
-  if (small) { small_status.assign(n ? n : 1, 0); status_out = small_status.data(); batch = false; }
-  if (!ctx || (n && (!io_counts || !ad_lens || !proofs)) || (n && kind != 2 && !pks) || (!batch && n && !status_out)) return AVRF_ERR_BAD_ARG;
+// The two phases of a wire verification, separate so that a caller can run the verification proper beside other work (the ring
+// half of avrf_ring_vrf_verify): wire_prepare decompresses (and validates) every point and lays the proofs out in the x || y form;
+// wire_finish runs the verifier and folds the points' decode statuses into the items' statuses.
+struct WirePrep {
+  int kind = 0; bool batch = false, small = false; size_t n = 0, tot = 0, ppts = 0;
+  const uint32_t *io_counts = nullptr, *ad_lens = nullptr; const uint8_t *ads = nullptr;
+  std::vector<uint8_t> xy, px; std::vector<int32_t> pst, small_status;
+  const uint8_t *x_pks = nullptr, *x_ios = nullptr;
+};
+int wire_prepare(avrf_ctx *ctx, int kind, bool batch, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                 const uint32_t *ad_lens, const uint8_t *proofs, int validate, bool have_status_out, WirePrep &w,
+                 std::vector<uint8_t> *pp0_xy = nullptr, std::vector<int32_t> *pp0_st = nullptr) {
+  w.small = batch && n <= SMALL_BATCH && kind != 3;
+  if (w.small) { w.small_status.assign(n ? n : 1, 0); batch = false; have_status_out = true; }
+  if (!ctx || (n && (!io_counts || !ad_lens || !proofs)) || (n && kind != 2 && !pks) || (!batch && n && !have_status_out)) return AVRF_ERR_BAD_ARG;
+  w.kind = kind; w.batch = batch; w.n = n; w.io_counts = io_counts; w.ad_lens = ad_lens; w.ads = ads;
   if (!n) return AVRF_OK;
   const size_t tot = sum_counts(io_counts, n);
   if (tot && !ios) return AVRF_ERR_BAD_ARG;
+  w.tot = tot;
   const size_t L = avrf_point_len(avrf_ctx_suite_(ctx));
   const size_t ppts = kind == 1 ? 1 : kind == 3 ? 0 : 3, plen = ppts * L + (kind == 1 ? 32 : kind == 3 ? 48 : 64), xlen = kind == 1 ? 96 : kind == 3 ? 48 : 256;
+  w.ppts = ppts;
   Gather g(L);
   if (kind != 2) g.add(pks, n, L);
   g.add(ios, 2 * tot, L);
   for (size_t p = 0; p < ppts; p++) g.add(proofs + L * p, n, plen);
-  std::vector<uint8_t> xy; std::vector<int32_t> pst;
-  int rc = decompress_all(ctx, g, validate, xy, (batch && !pp0_st) ? nullptr : &pst);
+  int rc = decompress_all(ctx, g, validate, w.xy, (batch && !pp0_st) ? nullptr : &w.pst);
   if (rc != AVRF_OK) return rc;
-  const uint8_t *x_pks = xy.data(), *x_ios = xy.data() + (kind != 2 ? n * 64 : 0), *x_pp = x_ios + 2 * tot * 64;
+  w.x_pks = w.xy.data(); w.x_ios = w.xy.data() + (kind != 2 ? n * 64 : 0);
+  const uint8_t *x_pp = w.x_ios + 2 * tot * 64;
   if (pp0_xy && ppts) pp0_xy->assign(x_pp, x_pp + n * 64);
-  if (pp0_st && ppts) pp0_st->assign(pst.begin() + ((kind != 2 ? n : 0) + 2 * tot), pst.begin() + ((kind != 2 ? n : 0) + 2 * tot + n));
-  if (batch && pp0_st) for (size_t i = 0; i < pst.size(); i++) if (pst[i]) return AVRF_INVALID_DATA;
-  std::vector<uint8_t> px(n * xlen);
+  if (pp0_st && ppts) pp0_st->assign(w.pst.begin() + ((kind != 2 ? n : 0) + 2 * tot), w.pst.begin() + ((kind != 2 ? n : 0) + 2 * tot + n));
+  if (batch && pp0_st) for (size_t i = 0; i < w.pst.size(); i++) if (w.pst[i]) return AVRF_INVALID_DATA;
+  w.px.resize(n * xlen);
   for (size_t j = 0; j < n; j++) {
-    for (size_t p = 0; p < ppts; p++) memcpy(&px[j * xlen + 64 * p], x_pp + (p * n + j) * 64, 64);
-    memcpy(&px[j * xlen + 64 * ppts], proofs + j * plen + L * ppts, plen - L * ppts);
+    for (size_t p = 0; p < ppts; p++) memcpy(&w.px[j * xlen + 64 * p], x_pp + (p * n + j) * 64, 64);
+    memcpy(&w.px[j * xlen + 64 * ppts], proofs + j * plen + L * ppts, plen - L * ppts);
   }
-  if (batch) {
-    if (kind == 1) return avrf_thin_batch_verify(ctx, n, x_pks, x_ios, io_counts, ads, ad_lens, px.data());
-    return avrf_pedersen_batch_verify(ctx, n, x_ios, io_counts, ads, ad_lens, px.data());
+  return AVRF_OK;
+}
+int wire_finish(avrf_ctx *ctx, WirePrep &w, int32_t *status_out) {
+  const size_t n = w.n, tot = w.tot, ppts = w.ppts; const int kind = w.kind;
+  if (!n) return AVRF_OK;
+  if (w.small) status_out = w.small_status.data();
+  if (w.batch) {
+    if (kind == 1) return avrf_thin_batch_verify(ctx, n, w.x_pks, w.x_ios, w.io_counts, w.ads, w.ad_lens, w.px.data());
+    return avrf_pedersen_batch_verify(ctx, n, w.x_ios, w.io_counts, w.ads, w.ad_lens, w.px.data());
   }
-  if (kind == 1) rc = avrf_thin_verify(ctx, n, x_pks, x_ios, io_counts, ads, ad_lens, px.data(), status_out);
-  else if (kind == 3) rc = avrf_tiny_verify(ctx, n, x_pks, x_ios, io_counts, ads, ad_lens, px.data(), status_out);
-  else rc = avrf_pedersen_verify(ctx, n, x_ios, io_counts, ads, ad_lens, px.data(), status_out);
+  int rc;
+  if (kind == 1) rc = avrf_thin_verify(ctx, n, w.x_pks, w.x_ios, w.io_counts, w.ads, w.ad_lens, w.px.data(), status_out);
+  else if (kind == 3) rc = avrf_tiny_verify(ctx, n, w.x_pks, w.x_ios, w.io_counts, w.ads, w.ad_lens, w.px.data(), status_out);
+  else rc = avrf_pedersen_verify(ctx, n, w.x_ios, w.io_counts, w.ads, w.ad_lens, w.px.data(), status_out);
   if (rc != AVRF_OK) return rc;
   // a point that does not decode (or fails validation) makes ITS item InvalidData
+  const std::vector<int32_t> &pst = w.pst;
   size_t at = 0, io_at = 0;
   if (kind != 2) { for (size_t j = 0; j < n; j++) if (pst[j]) status_out[j] = AVRF_INVALID_DATA; at = n; }
-  for (size_t j = 0; j < n; j++) { for (size_t k = 0; k < 2 * (size_t)io_counts[j]; k++) if (pst[at + io_at + k]) status_out[j] = AVRF_INVALID_DATA; io_at += 2 * io_counts[j]; }
+  for (size_t j = 0; j < n; j++) { for (size_t k = 0; k < 2 * (size_t)w.io_counts[j]; k++) if (pst[at + io_at + k]) status_out[j] = AVRF_INVALID_DATA; io_at += 2 * w.io_counts[j]; }
   at += 2 * tot;
   for (size_t p = 0; p < ppts; p++) for (size_t j = 0; j < n; j++) if (pst[at + p * n + j]) status_out[j] = AVRF_INVALID_DATA;
-  if (small) {                                                         // BatchVerifier's verdict: InvalidData before VerificationFailure
+  if (w.small) {                                                       // BatchVerifier's verdict: InvalidData before VerificationFailure
     int worst = AVRF_OK;
     for (size_t j = 0; j < n; j++) { if (status_out[j] == AVRF_INVALID_DATA) return AVRF_INVALID_DATA; if (status_out[j]) worst = AVRF_VERIFICATION_FAILURE; }
     return worst;
   }
   return AVRF_OK;
+}
+int verify_wire(avrf_ctx *ctx, int kind, bool batch, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                const uint32_t *ad_lens, const uint8_t *proofs, int validate, int32_t *status_out,
+                std::vector<uint8_t> *pp0_xy = nullptr, std::vector<int32_t> *pp0_st = nullptr) {
+  WirePrep w;
+  int rc = wire_prepare(ctx, kind, batch, n, pks, ios, io_counts, ads, ad_lens, proofs, validate, status_out != nullptr, w, pp0_xy, pp0_st);
+  if (rc != AVRF_OK || !n) return rc;
+  return wire_finish(ctx, w, status_out);
 }
 
 }  // namespace
@@ -157,16 +185,21 @@ int avrf_ring_vrf_verify(avrf_ctx *ctx, avrf_ring_setup *setup, size_t n, const 
   for (size_t j = 0; j < n; j++) { memcpy(&ped[j * pedlen], proofs + j * plen, pedlen); memcpy(&rp[j * rlen], proofs + j * plen + pedlen, rlen); }
   // the Pedersen half first: it decompresses (and validates) every point of the Pedersen proofs ONCE, including Yb, the ring
   // verifier's instance
+  // (the two halves only share Yb: once the points are decompressed, the Pedersen verifier runs on a thread of its own -- the
+  // context's stream and buffers -- beside the ring half on the setup's stream and the host pool)
   std::vector<uint8_t> yb; std::vector<int32_t> yst;
-  if (!each) {
-    int rc = verify_wire(ctx, 2, true, n, nullptr, ios, io_counts, ads, ad_lens, ped.data(), validate, nullptr, &yb, &yst);
-    if (rc != AVRF_OK) return rc;
-    return avrf_ring_batch_verify(setup, n, ring_commitments, n_rings, ring_of_item, yb.data(), rp.data());
-  }
   std::vector<int32_t> s1(n), s2(n);
-  int rc = verify_wire(ctx, 2, false, n, nullptr, ios, io_counts, ads, ad_lens, ped.data(), validate, s1.data(), &yb, &yst);
+  WirePrep w;
+  int rc = wire_prepare(ctx, 2, !each, n, nullptr, ios, io_counts, ads, ad_lens, ped.data(), validate, each != 0, w, &yb, &yst);
   if (rc != AVRF_OK) return rc;
-  rc = avrf_ring_verify_each(setup, n, ring_commitments, n_rings, ring_of_item, yb.data(), rp.data(), s2.data());
+  int rc_ped = AVRF_OK;
+  std::thread ped_half; bool threaded = true;
+  try { ped_half = std::thread([&] { rc_ped = wire_finish(ctx, w, s1.data()); }); } catch (...) { threaded = false; }
+  if (!each) rc = avrf_ring_batch_verify(setup, n, ring_commitments, n_rings, ring_of_item, yb.data(), rp.data());
+  else rc = avrf_ring_verify_each(setup, n, ring_commitments, n_rings, ring_of_item, yb.data(), rp.data(), s2.data());
+  if (threaded) ped_half.join(); else rc_ped = wire_finish(ctx, w, s1.data());
+  if (rc_ped != AVRF_OK) return rc_ped;
+  if (!each) return rc;
   if (rc != AVRF_OK) return rc;
   for (size_t j = 0; j < n; j++) status_out[j] = (yst[j] || s1[j] == AVRF_INVALID_DATA || s2[j] == AVRF_INVALID_DATA) ? AVRF_INVALID_DATA : (s1[j] || s2[j]) ? AVRF_VERIFICATION_FAILURE : AVRF_OK;
   return AVRF_OK;
