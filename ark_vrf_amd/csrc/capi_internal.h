@@ -83,6 +83,7 @@ struct avrf_ctx {
   avrf::PinBuf h_c, h_flags, h_io;
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int run_phase = 0;              // batch_begin / batch_hash / batch_end
+  bool unit_weights = false;      // batch_launch: every item's weight is 1 (avrf_thin_verify runs ONE item as its own equation through the MSM path)
   double run_t0 = 0, run_begin_us = 0, run_msm_us = 0;
 };
 

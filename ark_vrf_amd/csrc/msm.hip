@@ -573,7 +573,7 @@ k_wsum_blk(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t *__restri
 
 // tuning knobs from the environment, read once per process
 struct MsmEnv {
-  int c = 0, per_min = 8, wsum_wps = 0, occ = 0, tile = 0; bool window_sums = true;
+  int c = 0, per_min = 8, wsum_wps = 0, occ = 0, tile = 0; bool window_sums = true, tiny = true;
   MsmEnv() {
     if (const char *e = getenv("AVRF_MSM_C")) { int v = atoi(e); if (v >= 3 && v <= 15) c = v; }
     if (const char *e = getenv("AVRF_MSM_OCC")) { int v = atoi(e); if (v >= 1 && v <= 8) occ = v; }   // resident k_accumulate waves per SIMD to fill
@@ -581,6 +581,7 @@ struct MsmEnv {
     if (const char *e = getenv("AVRF_MSM_PER_MIN")) { int v = atoi(e); if (v >= 1 && v <= 4096) per_min = v; }
     if (const char *e = getenv("AVRF_TE_WSUM_WPS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) wsum_wps = v; }
     if (const char *e = getenv("AVRF_TE_WINDOW_SUMS")) window_sums = atoi(e) != 0;
+    if (const char *e = getenv("AVRF_MSM_TINY")) tiny = atoi(e) != 0;                    // (A/B hook: 0 sends <= 64-term MSMs through the general chain)
   }
 };
 static const MsmEnv &msm_env() { static const MsmEnv e; return e; }
@@ -856,8 +857,48 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   return p.nwin * p.c;
 }
 
+// Tiny MSMs (<= 64 terms: a BatchVerifier of a dozen items, ONE independent verification run as a batch of one): the Pippenger
+// chain above is twelve launches of latency there (0.28 ms for five terms) and almost no work.  One launch instead: wave p sums
+// the bases whose scalar has bit p set -- lane = term, a butterfly of ceil(log2 n) additions -- which are exactly the bit sums
+// T_p the general path hands to the host's Horner (msm_te_finish: sum_p 2^p T_p; the sequential doublings run ~10 x faster on
+// a host core than on a lone wave).
+constexpr size_t MSM_TINY_TERMS = 64;
+template <class S>
+__global__ void __launch_bounds__(64)
+k_msm_tiny_bits(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ scalars, uint32_t n, uint32_t *__restrict__ out) {
+  using CV = TeCurve<S>;
+  const uint32_t p = blockIdx.x, t = threadIdx.x;
+  typename CV::acc_t acc = CV::identity();
+  if (t < n && ((scalars[8 * (size_t)t + (p >> 5)] >> (p & 31)) & 1u)) acc = CV::from_base(CV::load_base(bases + (size_t)t * CV::BASE_WORDS), false);
+  uint32_t span = 1; while (span < n) span <<= 1;
+#pragma unroll 1
+  for (uint32_t off = span >> 1; off >= 1; off >>= 1) acc = cv_add<CV>(acc, CV::shfl_down(acc, (int)off));
+  if (t == 0) CV::store_acc(out + (size_t)p * CV::ACC_WORDS, acc);
+}
+template <class S>
+static int msm_te_tiny_enqueue(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, MsmPending *pend) {
+  using CV = TeCurve<S>;
+  MsmPlan p; p.c = 1; p.nwin = S::Fr::BITS; p.nb = 1; p.lpb = 0;
+  const size_t acc_bytes = (size_t)CV::ACC_WORDS * 4, nbits = (size_t)p.nwin;
+  ws.ensure(n, p, acc_bytes, 1, 256);
+  if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
+  if (pend) { pend->ensure(nbits * acc_bytes); pend->plan_host[0] = 0; }
+  hipEvent_t ev0 = pend ? pend->ev0 : ws.ev0, ev1 = pend ? pend->ev1 : ws.ev1;
+  HIP_CHECK(hipEventRecord(ev0, stream));
+  hipLaunchKernelGGL(k_msm_tiny_bits<S>, dim3((unsigned)nbits), dim3(64), 0, stream, (const uint32_t *)d_pre, d_scalars, (uint32_t)n, ws.bits);
+  HIP_CHECK(hipEventRecord(ev1, stream));
+  HIP_CHECK(hipMemcpyAsync(pend ? pend->bits_host : ws.bits_host, ws.bits, nbits * acc_bytes, hipMemcpyDeviceToHost, stream));
+  if (pend) pend->plan = p; else ws.pending_plan = p;
+  return (int)nbits;
+}
+
 template <class S>
 static int msm_te_enqueue_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, MsmPending *pend) {
+  if (n && n <= MSM_TINY_TERMS && msm_env().tiny) {
+    if (pend) { pend->n = n; pend->armed = true; pend->ret = msm_te_tiny_enqueue<S>(d_pre, d_scalars, n, ws, stream, pend); }
+    else { ws.pending_n = n; ws.pending_armed = true; ws.pending_ret = msm_te_tiny_enqueue<S>(d_pre, d_scalars, n, ws, stream, nullptr); }
+    return 0;
+  }
   if (pend) {
     pend->n = n; pend->ret = 0; pend->armed = true;
     if (n) pend->ret = msm_device<TeCurve<S>>((const uint32_t *)d_pre, d_scalars, n, S::Fr::BITS, ws, stream, 1, 0, 0, 0, nullptr, /*defer=*/true, 0, pend);

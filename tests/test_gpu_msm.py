@@ -17,7 +17,7 @@ def ctxs():
 
 
 @pytest.mark.parametrize("suite", [0, 1])
-@pytest.mark.parametrize("n", [0, 1, 2, 3, 29, 64, 257, 1000, 4097])
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 29, 64, 65, 257, 1000, 4097])
 def test_msm_random(ctxs, suite, n):
     rng = random.Random(1000 * suite + n)
     pts = rand_points_xy(rng, suite, min(n, 300))
