@@ -765,6 +765,30 @@ static bool wave_shape(const avrf_ctx *c, size_t n, const uint32_t *io_counts) {
   return true;
 }
 
+// ONE thin / tiny proof through the MSM engine (vrf_single.hip k_thin_prove_begin / _end): the terms of R = k G + sum (k z_i) I_i,
+// the single-launch MSM of <= 64 terms with the host's Horner, R back as canonical x || y, challenge and response.  0.71 -> ~0.3 ms
+// for one proof; same bytes (any evaluation of R gives the same group element).  The nonce never leaves device memory.
+static bool one_as_msm() { static const bool on = getenv("AVRF_NO_ONE_AS_MSM") == nullptr; return on; }   // (A/B hook)
+static int prove_one_as_msm(avrf_ctx *c, bool have_pk, bool tiny, uint8_t *proofs_out) {
+  const size_t nt = 1 + c->tot_io, plen = tiny ? 48 : 96, sb = thin_prove_state_bytes(c->suite);
+  if (!have_pk) { if (int fs = ensure_fixed(c)) return fs; }
+  HIP_TRY(c->L->d_scalars.ensure(nt * 32)); HIP_TRY(c->L->d_pre.ensure(nt * sizeof(te_pre_raw))); HIP_TRY(c->d_misc.ensure(sb + 64)); HIP_TRY(c->d_out.ensure(plen));
+  BatchDev b = batch_of(c);
+  if (!have_pk) b.pks_xy = nullptr;
+  uint8_t *d_state = c->d_misc.as<uint8_t>();
+  launch_thin_prove_begin(c->suite, b, c->L->d_scalars.as<uint32_t>(), c->L->d_pre.as<te_pre_raw>(), d_state, c->stream, tiny);
+  HostExt r;
+  if (int e = guarded([&] { return msm_te_device(c->suite, c->L->d_pre.as<te_pre_raw>(), c->L->d_scalars.as<uint32_t>(), nt, c->L->ws, c->stream, &r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  uint8_t *rxy = c->h_c.as<uint8_t>();                                  // (pinned; the challenges are not in use by a prover)
+  finish_point(c, r, rxy);
+  HIP_TRY(hipMemcpyAsync(d_state + sb, rxy, 64, hipMemcpyHostToDevice, c->stream));
+  launch_thin_prove_end(c->suite, b, d_state, d_state + sb, c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream, tiny);
+  HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, plen, hipMemcpyDeviceToHost, c->stream));
+  const int f = read_flags(c);
+  if (f < 0) return AVRF_ERR_NO_DEVICE;
+  return f ? AVRF_INVALID_DATA : AVRF_OK;
+}
+
 int avrf_thin_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
                     const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out) {
   if (n && (!sks || !proofs_out)) return AVRF_ERR_BAD_ARG;
@@ -774,6 +798,12 @@ int avrf_thin_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pk
   HIP_TRY(c->d_out.ensure(n * 96));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
   double t0 = now_us();
+  if (n == 1 && c->tot_io < 64 && one_as_msm()) {
+    HIP_TRY(c->h_c.ensure(64));
+    const int st1 = prove_one_as_msm(c, pks_xy != nullptr, false, proofs_out);
+    c->timing[0] = now_us() - t0;
+    return st1;
+  }
   if (pks_xy && wave_shape(c, n, io_counts)) {
     HIP_TRY(c->d_status.ensure(n * 4)); HIP_TRY(c->h_c.ensure(n * 4));
     if (launch_thin_prove_wave(c->suite, batch_of(c), c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->d_status.as<int32_t>(), c->stream)) {
@@ -807,8 +837,7 @@ int avrf_thin_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t
   // (msm.hip k_msm_tiny_bits): the doubling chain runs on the host's Horner instead of a lone wave -- 0.54 -> 0.28 ms.  Same
   // statuses as the per-item kernels: the flags of the prepare kernel and of the validation are InvalidData, a non-zero sum is
   // VerificationFailure.  Everything is enqueued back to back; the one wait is in batch_end.
-  static const bool one_as_msm = getenv("AVRF_NO_ONE_AS_MSM") == nullptr;   // (A/B hook)
-  if (n == 1 && one_as_msm && c->n_terms && c->n_terms <= 64) {
+  if (n == 1 && one_as_msm() && c->n_terms && c->n_terms <= 64) {
     uint8_t zero[64] = {0};
     c->unit_weights = true;
     int st = batch_begin(c, 1);
@@ -848,6 +877,7 @@ int avrf_tiny_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pk
   c->staged_kind = 0;
   HIP_TRY(c->d_out.ensure(n * 48));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  if (n == 1 && c->tot_io < 64 && one_as_msm()) { HIP_TRY(c->h_c.ensure(64)); return prove_one_as_msm(c, pks_xy != nullptr, true, proofs_out); }
   if (pks_xy && wave_shape(c, n, io_counts)) {                         // few items: 32 lanes per item (vrf_single.hip)
     HIP_TRY(c->d_status.ensure(n * 4)); HIP_TRY(c->h_c.ensure(n * 4));
     if (launch_thin_prove_wave(c->suite, batch_of(c), c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->d_status.as<int32_t>(), c->stream, true)) {

@@ -30,6 +30,11 @@ void launch_fixed_table(int suite, te_pre_raw *d_tab, hipStream_t st);
 void launch_smul(int suite, const uint8_t *d_scalars, const uint8_t *d_points_xy, uint32_t n, uint8_t *d_out, uint32_t *d_flags,
                  const te_pre_raw *d_fixed, hipStream_t st);
 void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny = false);
+// one proof split around the MSM engine (vrf_single.hip k_thin_prove_begin / _end): terms of R = k G + sum (k z_i) I_i, then the
+// challenge and the response from the normalised R; d_state holds the nonce and the transcript between the two
+size_t thin_prove_state_bytes(int suite);
+void launch_thin_prove_begin(int suite, const BatchDev &b, uint32_t *d_scalars, struct te_pre_raw *d_pre, uint8_t *d_state, hipStream_t st, bool tiny);
+void launch_thin_prove_end(int suite, const BatchDev &b, const uint8_t *d_state, const uint8_t *d_rxy, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny);
 void launch_tiny_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);   // proofs: n x 48 (c16 || s32)
 void launch_thin_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
 // few items, ONE I/O pair each, twisted-Edwards suites: an item spread over 32 lanes (vrf_single.hip "few items"); false = the
@@ -69,6 +74,9 @@ template <class S> struct SingleOps {
   static void smul(const uint8_t *d_scalars, const uint8_t *d_points_xy, uint32_t n, uint8_t *d_out, uint32_t *d_flags,
                    const te_pre_raw *d_fixed, hipStream_t st);
   static void thin_prove(const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny);
+  static size_t prove_state_bytes();
+  static void thin_prove_begin(const BatchDev &b, uint32_t *d_scalars, te_pre_raw *d_pre, uint8_t *d_state, hipStream_t st, bool tiny);
+  static void thin_prove_end(const BatchDev &b, const uint8_t *d_state, const uint8_t *d_rxy, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny);
   static void tiny_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
   static void thin_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
   static bool thin_verify_wave(const BatchDev &b, int32_t *d_status, hipStream_t st);

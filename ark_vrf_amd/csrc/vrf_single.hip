@@ -176,6 +176,64 @@ k_thin_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint32_t *__restrict_
   if (f) atomicOr(flags, f);
 }
 
+// ONE proof (thin / tiny), split around the MSM engine: the prover's only group work is R = k I_m = k G + sum_i (k z_i) I_i
+// (thin.rs:115-119), an MSM of 1 + m terms whose doubling chain the host folds ~10 x faster than a lone wave walks it (msm.hip
+// k_msm_tiny_bits).  k_thin_prove_begin: transcript, nonce, the terms; the nonce and the transcript stay in device memory.
+// k_thin_prove_end: challenge over the normalised R (it comes back as canonical x || y), response, proof bytes.  One lane each.
+template <class S> struct ProveState { suite_tr<S> t; fp k; uint32_t f; };
+template <class S, bool TINY>
+__global__ void __launch_bounds__(64)
+k_thin_prove_begin(BatchDev b, uint32_t *__restrict__ scalars, te_pre *__restrict__ pre, uint8_t *__restrict__ state) {
+  using Fr = typename S::Fr;
+  if (threadIdx.x) return;
+  const uint32_t j = b.first;
+  const uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0;
+  const fp sk = fp_load_le(b.sks + 32 * (size_t)j);
+  uint32_t f = ge_p<Fr>(sk) ? FLAG_SCALAR : 0;
+  fp pkx, pky;
+  if (b.pks_xy) { pkx = fp_load_le(b.pks_xy + 64 * (size_t)j); pky = fp_load_le(b.pks_xy + 64 * (size_t)j + 32); }
+  else { using Fq = typename S::Fq; te_aff pk = te_to_aff<S>(te_smul_fixed<S>(b.fixed, FIXED_G, sk)); pkx = fp_from_mont<Fq>(pk.x); pky = fp_from_mont<Fq>(pk.y); }
+  ProveState<S> *st = reinterpret_cast<ProveState<S> *>(state);
+  suite_tr<S> t; uint32_t pf = 0;
+  tr_base<S>(t, TINY ? DS_TINY : DS_THIN, true, pkx, pky, ios, m, b.ads + ad0, adl, &pf);
+  f |= pf & FLAG_RANGE;
+  const fp k = nonce<S>(sk, t);                                                 // thin.rs:115 (Montgomery)
+  store_fp(scalars, fp_from_mont<Fr>(k));
+  store_pre(pre, g_pre<S>());
+  if (m) {
+    auto dseed = delin_seed(t);
+    for (uint32_t i = 0; i < m; i++) {
+      store_fp(scalars + 8 * (size_t)(1 + i), fp_mul<Fr>(k, xof128(dseed, i)));  // Montgomery k times plain z_i: plain k z_i mod r
+      store_pre(pre + 1 + i, pre_from_xy<S>(ios + 128 * (size_t)i));
+    }
+  }
+  st->t = t; st->k = k; st->f = f;
+}
+template <class S, bool TINY>
+__global__ void __launch_bounds__(64)
+k_thin_prove_end(BatchDev b, const uint8_t *__restrict__ state, const uint8_t *__restrict__ r_xy, uint8_t *__restrict__ proofs_out, uint32_t *__restrict__ flags) {
+  using Fr = typename S::Fr; using Fq = typename S::Fq;
+  if (threadIdx.x) return;
+  const uint32_t j = b.first;
+  const ProveState<S> *st = reinterpret_cast<const ProveState<S> *>(state);
+  const fp sk = fp_load_le(b.sks + 32 * (size_t)j), k = st->k;
+  te_aff r; r.x = fp_to_mont<Fq>(fp_load_le(r_xy)); r.y = fp_to_mont<Fq>(fp_load_le(r_xy + 32));   // thin.rs:119
+  suite_tr<S> tc = st->t; tr_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, r);                 // thin.rs:122
+  const fp c = fp_to_mont<Fr>(challenge_finish(tc));
+  const fp s = fp_add<Fr>(k, fp_mul<Fr>(c, fp_to_mont<Fr>(sk)));                                  // thin.rs:125
+  if (TINY) {
+    const fp cp = fp_from_mont<Fr>(c);
+    uint8_t *o = proofs_out + 48 * (size_t)j;
+    for (int i = 0; i < 4; i++) for (int bb = 0; bb < 4; bb++) o[4 * i + bb] = (uint8_t)(cp.v[i] >> (8 * bb));
+    fp_store_le(o + 16, fp_from_mont<Fr>(s));
+  } else {
+    store_xy<S>(proofs_out + 96 * (size_t)j, r);
+    fp_store_le(proofs_out + 96 * (size_t)j + 64, fp_from_mont<Fr>(s));
+  }
+  if (st->f) atomicOr(flags, st->f);
+}
+
 // tiny::Verifier::verify (src/tiny.rs:178-214): R = s I_m - c O_m, recompute the challenge, compare with c
 template <class S>
 __global__ void __launch_bounds__(128, AVRF_ITEM_WAVES)
@@ -931,6 +989,15 @@ template <class S> void SingleOps<S>::thin_prove(const BatchDev &b, uint8_t *d_p
   if (tiny) hipLaunchKernelGGL((k_thin_prove<S, true>), g, bl, 0, st, b, d_proofs_out, d_flags);
   else hipLaunchKernelGGL((k_thin_prove<S, false>), g, bl, 0, st, b, d_proofs_out, d_flags);
 }
+template <class S> size_t SingleOps<S>::prove_state_bytes() { return (sizeof(ProveState<S>) + 63) / 64 * 64; }
+template <class S> void SingleOps<S>::thin_prove_begin(const BatchDev &b, uint32_t *d_scalars, te_pre_raw *d_pre, uint8_t *d_state, hipStream_t st, bool tiny) {
+  if (tiny) hipLaunchKernelGGL((k_thin_prove_begin<S, true>), dim3(1), dim3(64), 0, st, b, d_scalars, (te_pre *)d_pre, d_state);
+  else hipLaunchKernelGGL((k_thin_prove_begin<S, false>), dim3(1), dim3(64), 0, st, b, d_scalars, (te_pre *)d_pre, d_state);
+}
+template <class S> void SingleOps<S>::thin_prove_end(const BatchDev &b, const uint8_t *d_state, const uint8_t *d_rxy, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny) {
+  if (tiny) hipLaunchKernelGGL((k_thin_prove_end<S, true>), dim3(1), dim3(64), 0, st, b, d_state, d_rxy, d_proofs_out, d_flags);
+  else hipLaunchKernelGGL((k_thin_prove_end<S, false>), dim3(1), dim3(64), 0, st, b, d_state, d_rxy, d_proofs_out, d_flags);
+}
 template <class S> void SingleOps<S>::tiny_verify(const BatchDev &b, int32_t *d_status, hipStream_t st) {
   hipLaunchKernelGGL(k_tiny_verify<S>, dim3((b.n - b.first + 127) / 128), dim3(128), 0, st, b, d_status);
 }
@@ -998,6 +1065,15 @@ void launch_smul(int suite, const uint8_t *d_scalars, const uint8_t *d_points_xy
                  const struct te_pre_raw *d_fixed, hipStream_t st) {
   if (!n) return;
   AVRF_SINGLE(suite, smul(d_scalars, d_points_xy, n, d_out, d_flags, d_fixed, st));
+}
+size_t thin_prove_state_bytes(int suite) {
+  return with_suite(suite, [&](auto tag_) { using S_ = typename decltype(tag_)::type; return SingleOps<S_>::prove_state_bytes(); });
+}
+void launch_thin_prove_begin(int suite, const BatchDev &b, uint32_t *d_scalars, struct te_pre_raw *d_pre, uint8_t *d_state, hipStream_t st, bool tiny) {
+  AVRF_SINGLE(suite, thin_prove_begin(b, d_scalars, d_pre, d_state, st, tiny));
+}
+void launch_thin_prove_end(int suite, const BatchDev &b, const uint8_t *d_state, const uint8_t *d_rxy, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny) {
+  AVRF_SINGLE(suite, thin_prove_end(b, d_state, d_rxy, d_proofs_out, d_flags, st, tiny));
 }
 void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny) {
   if (!b.n) return;

@@ -77,6 +77,16 @@ def test_multi_io(ctxs, suite):
     assert bad == [0, 0, 0, 1, 1, 0, 0, 0, 0]
     ios[6][15] = (ios[6][15][0], ios[6][14][1]); ios[7][16] = (ios[7][0][0], ios[7][16][1])   # last pair of the 16- and 17-pair items
     assert c.thin_verify(Batch.from_items(ios, ads, pks_xy=pkl, proofs=pl)) == [0, 0, 0, 1, 1, 0, 1, 1, 0]
+    # ONE item per call takes the MSM engine (capi.hip prove_one_as_msm / the unit-weight equation of avrf_thin_verify): the
+    # same bytes and verdicts for every pair count, with and without a given public key; 33 pairs = 67 terms: beyond the
+    # single-launch MSM of <= 64 terms, the call falls back to the general paths
+    ios_ok = [[(xy(suite, i), xy(suite, o)) for i, o in io] for io in ios_c]
+    for j in range(len(sks)):
+        one = lambda **kw: Batch.from_items([ios_ok[j]], [ads[j]], **kw)
+        assert c.thin_prove(one(sks=[sks[j]])) == pl[j] and c.thin_prove(one(sks=[sks[j]], pks_xy=[pkl[j]])) == pl[j]
+        assert c.thin_verify(one(pks_xy=[pkl[j]], proofs=[pl[j]])) == [0]
+        assert c.thin_verify(Batch.from_items([ios[j]], [ads[j]], pks_xy=[pkl[j]], proofs=[pl[j]])) == [[0, 0, 0, 1, 1, 0, 1, 1, 0][j]]
+        assert c.thin_verify(one(pks_xy=[pkl[(j + 1) % len(sks)]], proofs=[pl[j]])) == [1]
 
 
 def test_points_without_endomorphism_image_take_the_plain_path(ctxs):
