@@ -960,6 +960,31 @@ int avrf_pedersen_verify(avrf_ctx *c, size_t n, const uint8_t *ios_xy, const uin
   if (st || !n) return st;
   HIP_TRY(c->d_status.ensure(n * 4));
   double t0 = now_us();
+  // ONE item: its two equations (src/pedersen.rs:229-245) as two scalar vectors over the item's seven bases -- the terms kernel run with
+  // the weights (t, u) = (1, 0) and (0, 1) -- through the single-launch MSM with the host's two Horners side by side (see
+  // avrf_thin_verify): both sums must be the identity, exactly the reference's two checks.  0.52 -> ~0.33 ms.
+  if (n == 1 && one_as_msm() && c->n_terms && c->n_terms <= 64) {
+    int st = batch_begin(c, 2);                                        // validation + prepare kernel (challenge, merged pair) + flags copy
+    c->run_phase = 0;
+    if (st != AVRF_OK) return st;
+    const size_t nt = c->n_terms;
+    HIP_TRY(c->L->d_scalars.ensure(2 * nt * 32)); HIP_TRY(c->L->d_pre.ensure(nt * sizeof(te_pre_raw))); HIP_TRY(c->L->d_gpart.ensure(2 * 64 + 64));
+    c->h_weights.assign(64, 0); c->h_weights[0] = 1; c->h_weights[32 + 16] = 1;                   // (t, u) = (1, 0) | (0, 1)
+    HIP_TRY(c->d_weights.ensure(64));
+    HIP_TRY(hipMemcpyAsync(c->d_weights.p, c->h_weights.data(), 64, hipMemcpyHostToDevice, c->stream));
+    BatchDev b = batch_of(c);
+    Seed64 seed; for (int i = 0; i < 8; i++) seed.w[i] = 0;
+    for (int v = 0; v < 2; v++) {
+      b.weights = c->d_weights.as<uint8_t>() + 32 * v;
+      launch_ped_terms(c->suite, b, seed, 0, c->d_c.as<uint32_t>(), c->d_z.as<uint8_t>(), c->L->d_scalars.as<uint32_t>() + (size_t)v * nt * 8,
+                       c->L->d_pre.as<te_pre_raw>(), c->L->d_gpart.as<uint32_t>(), (uint32_t)nt, c->stream);
+    }
+    HostExt r[2];
+    if (int e = guarded([&] { return msm_te_small_vectors(c->suite, c->L->d_pre.as<te_pre_raw>(), c->L->d_scalars.as<uint32_t>(), nt, 2, c->L->ws, c->stream, r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+    status_out[0] = *c->h_flags.as<uint32_t>() ? AVRF_INVALID_DATA : (point_is_identity(c, r[0]) && point_is_identity(c, r[1])) ? AVRF_OK : AVRF_VERIFICATION_FAILURE;
+    c->timing[0] = now_us() - t0;
+    return AVRF_OK;
+  }
   if (wave_shape(c, n, io_counts) && launch_ped_verify_wave(c->suite, batch_of(c), c->d_status.as<int32_t>(), c->stream)) {
     validate_staged(c, 2, c->d_status.as<int32_t>());
     HIP_TRY(hipMemcpyAsync(status_out, c->d_status.p, n * 4, hipMemcpyDeviceToHost, c->stream));

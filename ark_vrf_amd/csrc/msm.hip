@@ -739,6 +739,24 @@ static void msm_wait(MsmWorkspace &ws, hipStream_t stream) {
   ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = ws.pending_plan;
 }
 
+// Tiny MSMs (<= 64 terms: a BatchVerifier of a dozen items, ONE independent verification run as its own equation, the verifier's
+// two G1 sums of one ring proof): the Pippenger chain below is twelve launches of latency there (0.28 ms for five terms) and
+// almost no work.  One launch instead: wave (p, v) sums the bases whose scalar of vector v has bit p set -- lane = term, a
+// butterfly of ceil(log2 n) additions -- which are exactly the bit sums T_p the general path hands to the host's Horner
+// (sum_p 2^p T_p; the sequential doublings run ~10 x faster on a host core than on a lone wave).
+constexpr size_t MSM_TINY_TERMS = 64, MSM_TINY_VECTORS = 7;
+template <class CV>
+__global__ void __launch_bounds__(64)
+k_msm_tiny_bits(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ scalars, uint32_t n, uint32_t stride, uint32_t *__restrict__ out) {
+  const uint32_t p = blockIdx.x, v = blockIdx.y, t = threadIdx.x;
+  typename CV::acc_t acc = CV::identity();
+  if (t < n && ((scalars[8 * ((size_t)v * stride + t) + (p >> 5)] >> (p & 31)) & 1u)) acc = CV::from_base(CV::load_base(bases + (size_t)t * CV::BASE_WORDS), false);
+  uint32_t span = 1; while (span < n) span <<= 1;
+#pragma unroll 1
+  for (uint32_t off = span >> 1; off >= 1; off >>= 1) acc = cv_add<CV>(acc, CV::shfl_down(acc, (int)off));
+  if (t == 0) CV::store_acc(out + ((size_t)v * gridDim.x + p) * CV::ACC_WORDS, acc);
+}
+
 // Runs the whole device pipeline for one MSM and leaves the nwin*c bit sums T_p in ws.bits_host
 // (accumulator layout of CV); returns the number of bit sums.
 // `batch` scalar vectors of length n over the SAME n bases (d_scalars = batch x n x 8 words): every vector
@@ -752,6 +770,21 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
                       bool defer = false, int scalars_mont = 0, MsmPending *pend = nullptr) {
   MsmPlan p = msm_plan(n_in, scalar_bits);
   if (!scalar_stride) scalar_stride = n_in;                            // vector b's scalars start at b * scalar_stride
+  if (n_in <= MSM_TINY_TERMS && batch <= MSM_TINY_VECTORS && !table_c && !d_base_idx && !scalars_mont && msm_env().tiny) {
+    p.c = 1; p.nwin = scalar_bits; p.nb = 1; p.lpb = 0;
+    const size_t acc_b = (size_t)CV::ACC_WORDS * 4, nbits = (size_t)scalar_bits;
+    ws.ensure(n_in, p, acc_b, batch, 256);
+    if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
+    if (pend) { pend->ensure(batch * nbits * acc_b); pend->plan_host[0] = 0; }
+    hipEvent_t e0 = pend ? pend->ev0 : ws.ev0, e1 = pend ? pend->ev1 : ws.ev1;
+    HIP_CHECK(hipEventRecord(e0, stream));
+    hipLaunchKernelGGL(k_msm_tiny_bits<CV>, dim3((unsigned)nbits, (unsigned)batch), dim3(64), 0, stream, d_bases, d_scalars, (uint32_t)n_in, (uint32_t)scalar_stride, ws.bits);
+    HIP_CHECK(hipEventRecord(e1, stream));
+    HIP_CHECK(hipMemcpyAsync(pend ? pend->bits_host : ws.bits_host, ws.bits, batch * nbits * acc_b, hipMemcpyDeviceToHost, stream));
+    if (pend) pend->plan = p; else ws.pending_plan = p;
+    if (!defer) msm_wait(ws, stream);
+    return (int)nbits;
+  }
   const size_t lanes_target = accumulate_lanes<CV>();
   size_t n = n_in;
   uint32_t remap_n = 0, remap_stride = 0;
@@ -857,48 +890,8 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   return p.nwin * p.c;
 }
 
-// Tiny MSMs (<= 64 terms: a BatchVerifier of a dozen items, ONE independent verification run as a batch of one): the Pippenger
-// chain above is twelve launches of latency there (0.28 ms for five terms) and almost no work.  One launch instead: wave p sums
-// the bases whose scalar has bit p set -- lane = term, a butterfly of ceil(log2 n) additions -- which are exactly the bit sums
-// T_p the general path hands to the host's Horner (msm_te_finish: sum_p 2^p T_p; the sequential doublings run ~10 x faster on
-// a host core than on a lone wave).
-constexpr size_t MSM_TINY_TERMS = 64;
-template <class S>
-__global__ void __launch_bounds__(64)
-k_msm_tiny_bits(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ scalars, uint32_t n, uint32_t *__restrict__ out) {
-  using CV = TeCurve<S>;
-  const uint32_t p = blockIdx.x, t = threadIdx.x;
-  typename CV::acc_t acc = CV::identity();
-  if (t < n && ((scalars[8 * (size_t)t + (p >> 5)] >> (p & 31)) & 1u)) acc = CV::from_base(CV::load_base(bases + (size_t)t * CV::BASE_WORDS), false);
-  uint32_t span = 1; while (span < n) span <<= 1;
-#pragma unroll 1
-  for (uint32_t off = span >> 1; off >= 1; off >>= 1) acc = cv_add<CV>(acc, CV::shfl_down(acc, (int)off));
-  if (t == 0) CV::store_acc(out + (size_t)p * CV::ACC_WORDS, acc);
-}
-template <class S>
-static int msm_te_tiny_enqueue(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, MsmPending *pend) {
-  using CV = TeCurve<S>;
-  MsmPlan p; p.c = 1; p.nwin = S::Fr::BITS; p.nb = 1; p.lpb = 0;
-  const size_t acc_bytes = (size_t)CV::ACC_WORDS * 4, nbits = (size_t)p.nwin;
-  ws.ensure(n, p, acc_bytes, 1, 256);
-  if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
-  if (pend) { pend->ensure(nbits * acc_bytes); pend->plan_host[0] = 0; }
-  hipEvent_t ev0 = pend ? pend->ev0 : ws.ev0, ev1 = pend ? pend->ev1 : ws.ev1;
-  HIP_CHECK(hipEventRecord(ev0, stream));
-  hipLaunchKernelGGL(k_msm_tiny_bits<S>, dim3((unsigned)nbits), dim3(64), 0, stream, (const uint32_t *)d_pre, d_scalars, (uint32_t)n, ws.bits);
-  HIP_CHECK(hipEventRecord(ev1, stream));
-  HIP_CHECK(hipMemcpyAsync(pend ? pend->bits_host : ws.bits_host, ws.bits, nbits * acc_bytes, hipMemcpyDeviceToHost, stream));
-  if (pend) pend->plan = p; else ws.pending_plan = p;
-  return (int)nbits;
-}
-
 template <class S>
 static int msm_te_enqueue_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, MsmPending *pend) {
-  if (n && n <= MSM_TINY_TERMS && msm_env().tiny) {
-    if (pend) { pend->n = n; pend->armed = true; pend->ret = msm_te_tiny_enqueue<S>(d_pre, d_scalars, n, ws, stream, pend); }
-    else { ws.pending_n = n; ws.pending_armed = true; ws.pending_ret = msm_te_tiny_enqueue<S>(d_pre, d_scalars, n, ws, stream, nullptr); }
-    return 0;
-  }
   if (pend) {
     pend->n = n; pend->ret = 0; pend->armed = true;
     if (n) pend->ret = msm_device<TeCurve<S>>((const uint32_t *)d_pre, d_scalars, n, S::Fr::BITS, ws, stream, 1, 0, 0, 0, nullptr, /*defer=*/true, 0, pend);
@@ -954,6 +947,25 @@ int msm_te_enqueue(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars
 int msm_te_finish(int suite, MsmWorkspace &ws, hipStream_t stream, HostExt *out, MsmPending *pend) {
   if (suite < 0 || suite >= AVRF_N_SUITES) return -1;
   return with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return msm_te_finish_impl<S>(ws, stream, out, pend); });
+}
+template <class S>
+static int msm_te_small_vectors_impl(const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, size_t nv, MsmWorkspace &ws, hipStream_t stream, HostExt *out) {
+  using HT = HostTe<S>;
+  if (!n || n > MSM_TINY_TERMS || !nv || nv > MSM_TINY_VECTORS || !msm_env().tiny) return -1;
+  const int nbits = msm_device<TeCurve<S>>((const uint32_t *)d_pre, d_scalars, n, S::Fr::BITS, ws, stream, nv, 0, 0, n);
+  ws.pending_armed = false;
+  const uint32_t *bh = ws.bits_host;
+  parallel_for(nv, [&](size_t v) {                          // the vectors' Horners side by side (sum_p 2^p T_p)
+    HostExt acc = HT::identity();
+    for (int i = nbits - 1; i >= 0; i--) { acc = HT::dbl(acc); acc = HT::add(acc, HT::from_raw32(bh + ((size_t)v * nbits + i) * 32)); }
+    out[v] = acc;
+  });
+  return 0;
+}
+int msm_te_small_vectors(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, size_t n_vectors, MsmWorkspace &ws, hipStream_t stream,
+                         HostExt *out) {
+  if (suite < 0 || suite >= AVRF_N_SUITES) return -1;
+  return with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return msm_te_small_vectors_impl<S>(d_pre, d_scalars, n, n_vectors, ws, stream, out); });
 }
 bool msm_te_pending_supported(int suite) {
   if (suite < 0 || suite >= AVRF_N_SUITES || !msm_env().window_sums) return false;

@@ -55,6 +55,16 @@ def test_reference_vectors_prove_verify_batch(ctxs, golden_dir, suite):
     assert stt == [0, 1, 1, 1, 0, 1, 0]
     assert c.pedersen_batch_verify(ios, ads, [bytes(bad[1])] + pl[1:]) == 1   # item 0 carries item 1's (tampered) proof
     assert c.pedersen_batch_verify(ios, ads, pl[:2] + [bytes(bad[2])] + pl[3:]) == 1
+    # ONE item per call: its two equations as two scalar vectors through the single-launch MSM (capi.hip avrf_pedersen_verify) --
+    # each equation must fail on its own: s and Ok only enter the first, sb and R only the second, the challenge both
+    ads_t = ads[:5] + [b"zz"] + ads[6:]
+    for j in range(len(vs)):
+        assert c.pedersen_verify(Batch.from_items([ios[j]], [ads[j]], proofs=[pl[j]])) == [0]
+        assert c.pedersen_verify(Batch.from_items([ios[j]], [ads_t[j]], proofs=[bytes(bad[j])])) == [[0, 1, 1, 1, 0, 1, 0][j]]
+    one_bad = bytearray(pl[0]); one_bad[64:128] = pl[1][64:128]            # R of another proof: second equation only
+    assert c.pedersen_verify(Batch.from_items([ios[0]], [ads[0]], proofs=[bytes(one_bad)])) == [1]
+    one_bad = bytearray(pl[0]); one_bad[192:224] = b"\xff" * 32             # s >= r
+    assert c.pedersen_verify(Batch.from_items([ios[0]], [ads[0]], proofs=[bytes(one_bad)])) == [2]
     # identity key commitment / identity io -> InvalidData (src/pedersen.rs:204-213,348-353)
     idp = IDENTITY_XY + pl[0][64:]
     assert c.pedersen_verify(Batch.from_items(ios[:1], ads[:1], proofs=[idp])) == [2]
