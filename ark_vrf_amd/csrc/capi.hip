@@ -789,6 +789,35 @@ static int prove_one_as_msm(avrf_ctx *c, bool have_pk, bool tiny, uint8_t *proof
   return f ? AVRF_INVALID_DATA : AVRF_OK;
 }
 
+// ONE Pedersen proof the same way (vrf_single.hip k_ped_prove_begin / _mid / _end): Yb = pk + bl B as a two-term MSM, then R = k G + kb B
+// and Ok = k I_m as two scalar vectors over {G, B, I_0, ..} in one launch; every doubling chain is the host's.  1.03 -> ~0.5 ms.
+static int prove_ped_one_as_msm(avrf_ctx *c, bool have_pk, uint8_t *proofs_out, uint8_t *blindings_out) {
+  const size_t m = c->tot_io, nt = 2 + m, sb = ped_prove_state_bytes(c->suite), wb = (m * 32 + 63) / 64 * 64 + 64;
+  HIP_TRY(c->L->d_scalars.ensure(2 * nt * 32)); HIP_TRY(c->L->d_pre.ensure(nt * sizeof(te_pre_raw)));
+  HIP_TRY(c->d_misc.ensure(sb + wb + 192 + 32)); HIP_TRY(c->d_out.ensure(256)); HIP_TRY(c->h_c.ensure(192));
+  BatchDev b = batch_of(c);
+  if (!have_pk) b.pks_xy = nullptr;
+  uint8_t *d_state = c->d_misc.as<uint8_t>(), *d_pts = d_state + sb + wb, *d_blind = d_pts + 192;
+  uint32_t *d_wts = reinterpret_cast<uint32_t *>(d_state + sb);
+  uint32_t *d_sc = c->L->d_scalars.as<uint32_t>(); te_pre_raw *d_pre = c->L->d_pre.as<te_pre_raw>();
+  launch_ped_prove_begin(c->suite, b, d_sc, d_pre, d_state, d_wts, c->stream);
+  HostExt r[2];
+  if (int e = guarded([&] { return msm_te_device(c->suite, d_pre, d_sc, 2, c->L->ws, c->stream, &r[0]) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  uint8_t *pts = c->h_c.as<uint8_t>();                                  // pinned: Yb | R | Ok
+  finish_point(c, r[0], pts);
+  HIP_TRY(hipMemcpyAsync(d_pts, pts, 64, hipMemcpyHostToDevice, c->stream));
+  launch_ped_prove_mid(c->suite, b, d_sc, d_pre, d_state, d_wts, d_pts, c->stream);
+  if (int e = guarded([&] { return msm_te_small_vectors(c->suite, d_pre, d_sc, nt, 2, c->L->ws, c->stream, r) ? (int)AVRF_ERR_BAD_ARG : 0; })) return e;
+  finish_point(c, r[0], pts + 64); finish_point(c, r[1], pts + 128);
+  HIP_TRY(hipMemcpyAsync(d_pts + 64, pts + 64, 128, hipMemcpyHostToDevice, c->stream));
+  launch_ped_prove_end(c->suite, b, d_state, d_pts, c->d_out.as<uint8_t>(), blindings_out ? d_blind : nullptr, c->d_flags.as<uint32_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(proofs_out, c->d_out.p, 256, hipMemcpyDeviceToHost, c->stream));
+  if (blindings_out) HIP_TRY(hipMemcpyAsync(blindings_out, d_blind, 32, hipMemcpyDeviceToHost, c->stream));
+  const int f = read_flags(c);
+  if (f < 0) return AVRF_ERR_NO_DEVICE;
+  return f ? AVRF_INVALID_DATA : AVRF_OK;
+}
+
 int avrf_thin_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
                     const uint8_t *ads, const uint32_t *ad_lens, uint8_t *proofs_out) {
   if (n && (!sks || !proofs_out)) return AVRF_ERR_BAD_ARG;
@@ -929,6 +958,12 @@ int avrf_pedersen_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t
   HIP_TRY(c->d_out.ensure(n * 256)); HIP_TRY(c->d_misc.ensure(n * 32));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
   double t0 = now_us();
+  if (n == 1 && c->tot_io <= 60 && one_as_msm()) {
+    if (!pks_xy) { if (int fs = ensure_fixed(c)) return fs; }
+    const int st1 = prove_ped_one_as_msm(c, pks_xy != nullptr, proofs_out, blindings_out);
+    c->timing[0] = now_us() - t0;
+    return st1;
+  }
   if (pks_xy && wave_shape(c, n, io_counts)) {                         // few items: 32 lanes per item (vrf_single.hip)
     if (int fs = ensure_fixed(c)) return fs;
     HIP_TRY(c->d_status.ensure(n * 4)); HIP_TRY(c->h_c.ensure(n * 4));

@@ -35,6 +35,11 @@ void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint
 size_t thin_prove_state_bytes(int suite);
 void launch_thin_prove_begin(int suite, const BatchDev &b, uint32_t *d_scalars, struct te_pre_raw *d_pre, uint8_t *d_state, hipStream_t st, bool tiny);
 void launch_thin_prove_end(int suite, const BatchDev &b, const uint8_t *d_state, const uint8_t *d_rxy, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny);
+// one Pedersen proof the same way (k_ped_prove_begin / _mid / _end): Yb, then R and Ok as two scalar vectors over {G, B, I_0 ..}
+size_t ped_prove_state_bytes(int suite);
+void launch_ped_prove_begin(int suite, const BatchDev &b, uint32_t *d_scalars, struct te_pre_raw *d_pre, uint8_t *d_state, uint32_t *d_wts, hipStream_t st);
+void launch_ped_prove_mid(int suite, const BatchDev &b, uint32_t *d_scalars, struct te_pre_raw *d_pre, uint8_t *d_state, const uint32_t *d_wts, const uint8_t *d_yb, hipStream_t st);
+void launch_ped_prove_end(int suite, const BatchDev &b, const uint8_t *d_state, const uint8_t *d_pts, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st);
 void launch_tiny_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);   // proofs: n x 48 (c16 || s32)
 void launch_thin_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
 // few items, ONE I/O pair each, twisted-Edwards suites: an item spread over 32 lanes (vrf_single.hip "few items"); false = the
@@ -77,6 +82,10 @@ template <class S> struct SingleOps {
   static size_t prove_state_bytes();
   static void thin_prove_begin(const BatchDev &b, uint32_t *d_scalars, te_pre_raw *d_pre, uint8_t *d_state, hipStream_t st, bool tiny);
   static void thin_prove_end(const BatchDev &b, const uint8_t *d_state, const uint8_t *d_rxy, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny);
+  static size_t ped_state_bytes();
+  static void ped_prove_begin(const BatchDev &b, uint32_t *d_scalars, te_pre_raw *d_pre, uint8_t *d_state, uint32_t *d_wts, hipStream_t st);
+  static void ped_prove_mid(const BatchDev &b, uint32_t *d_scalars, te_pre_raw *d_pre, uint8_t *d_state, const uint32_t *d_wts, const uint8_t *d_yb, hipStream_t st);
+  static void ped_prove_end(const BatchDev &b, const uint8_t *d_state, const uint8_t *d_pts, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st);
   static void tiny_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
   static void thin_verify(const BatchDev &b, int32_t *d_status, hipStream_t st);
   static bool thin_verify_wave(const BatchDev &b, int32_t *d_status, hipStream_t st);

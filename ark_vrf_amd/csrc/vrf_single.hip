@@ -495,6 +495,90 @@ k_ped_prove(BatchDev b, uint8_t *__restrict__ proofs_out, uint8_t *__restrict__ 
   if (f) atomicOr(flags, f);
 }
 
+// ONE Pedersen proof split around the MSM engine like k_thin_prove_begin / _end: its three commitments are MSMs whose doubling chains
+// the host folds -- Yb = pk + bl B (pedersen.rs:148-149: two terms), then, once Yb is absorbed and the nonces exist, R = k G + kb B and
+// Ok = k I_m (:159-164) as two scalar vectors over the bases {G, B, I_0 ..}.  Three one-lane kernels; blinding, nonces and transcript stay
+// in device memory (PedState), the item's delinearisation weights (1, z_0, z_1, ..: common.rs:186-199) beside it.
+template <class S> struct PedState { suite_tr<S> t; fp bl, k, kb; uint32_t f; };
+template <class S>
+__global__ void __launch_bounds__(64)
+k_ped_prove_begin(BatchDev b, uint32_t *__restrict__ scalars, te_pre *__restrict__ pre, uint8_t *__restrict__ state, uint32_t *__restrict__ wts) {
+  using Fr = typename S::Fr;
+  if (threadIdx.x) return;
+  const uint32_t j = b.first;
+  const uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, ad0 = b.ad_off[j], adl = b.ad_off[j + 1] - ad0;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0;
+  const fp sk = fp_load_le(b.sks + 32 * (size_t)j);
+  uint32_t f = ge_p<Fr>(sk) ? FLAG_SCALAR : 0, pf = 0;
+  PedState<S> *st = reinterpret_cast<PedState<S> *>(state);
+  suite_tr<S> t;
+  tr_base<S>(t, DS_PEDERSEN, false, nullptr, ios, m, b.ads + ad0, adl, &pf);   // pedersen.rs:142
+  f |= pf & FLAG_RANGE;
+  if (m > 1) {                                                                  // weights of the merged input: 1, z_0, z_1, ..
+    auto dseed = delin_seed(t);
+    for (uint32_t i = 1; i < m; i++) store_fp(wts + 8 * (size_t)i, xof128(dseed, i - 1));
+  }
+  suite_tr<S> tb = t; tr_byte(tb, DS_PEDERSEN_BLINDING);
+  const fp bl = nonce<S>(sk, tb);                                               // pedersen.rs:51-54,145
+  // Yb = pk + bl B (:148-149): (pk, 1), (B, bl) -- or (G, sk), (B, bl) when the caller gave no public key
+  fp one = fp_zero(); one.v[0] = 1;
+  if (b.pks_xy) { store_pre(pre, pre_from_xy<S>(b.pks_xy + 64 * (size_t)j)); store_fp(scalars, one); }
+  else { store_pre(pre, g_pre<S>()); store_fp(scalars, sk); }
+  store_pre(pre + 1, b_pre<S>()); store_fp(scalars + 8, fp_from_mont<Fr>(bl));
+  st->t = t; st->bl = bl; st->f = f;
+}
+template <class S>
+__global__ void __launch_bounds__(64)
+k_ped_prove_mid(BatchDev b, uint32_t *__restrict__ scalars, te_pre *__restrict__ pre, uint8_t *__restrict__ state, const uint32_t *__restrict__ wts,
+                const uint8_t *__restrict__ yb_xy) {
+  using Fr = typename S::Fr; using Fq = typename S::Fq;
+  if (threadIdx.x) return;
+  const uint32_t j = b.first;
+  const uint32_t io0 = b.io_off[j], m = b.io_off[j + 1] - io0, nt = 2 + m;
+  const uint8_t *ios = b.ios_xy + 128 * (size_t)io0;
+  PedState<S> *st = reinterpret_cast<PedState<S> *>(state);
+  const fp sk = fp_load_le(b.sks + 32 * (size_t)j);
+  suite_tr<S> t = st->t;
+  te_aff yb; yb.x = fp_to_mont<Fq>(fp_load_le(yb_xy)); yb.y = fp_to_mont<Fq>(fp_load_le(yb_xy + 32));
+  absorb_point_mont<S>(t, yb);                                                  // :152
+  const fp bl_plain = fp_from_mont<Fr>(st->bl);
+  const fp k = nonce<S>(sk, t), kb = nonce<S>(bl_plain, t);                     // :155-156
+  // vector 0: R = k G + kb B; vector 1: Ok = k I_m = sum_i (k w_i) I_i
+  const fp zero = fp_zero();
+  store_pre(pre, g_pre<S>()); store_pre(pre + 1, b_pre<S>());
+  store_fp(scalars, fp_from_mont<Fr>(k)); store_fp(scalars + 8, fp_from_mont<Fr>(kb));
+  store_fp(scalars + 8 * (size_t)nt, zero); store_fp(scalars + 8 * (size_t)(nt + 1), zero);
+  for (uint32_t i = 0; i < m; i++) {
+    store_pre(pre + 2 + i, pre_from_xy<S>(ios + 128 * (size_t)i));
+    store_fp(scalars + 8 * (size_t)(2 + i), zero);
+    store_fp(scalars + 8 * (size_t)(nt + 2 + i), i == 0 ? fp_from_mont<Fr>(k) : fp_mul<Fr>(k, load_fp(wts + 8 * (size_t)i)));   // Montgomery k times plain w_i: plain
+  }
+  st->t = t; st->k = k; st->kb = kb;
+}
+template <class S>
+__global__ void __launch_bounds__(64)
+k_ped_prove_end(BatchDev b, const uint8_t *__restrict__ state, const uint8_t *__restrict__ pts_xy, uint8_t *__restrict__ proofs_out,
+                uint8_t *__restrict__ blindings_out, uint32_t *__restrict__ flags) {
+  using Fr = typename S::Fr; using Fq = typename S::Fq;
+  if (threadIdx.x) return;
+  const uint32_t j = b.first;
+  const PedState<S> *st = reinterpret_cast<const PedState<S> *>(state);
+  const fp sk = fp_load_le(b.sks + 32 * (size_t)j);
+  te_aff yb, ra, oka;                                                           // pts_xy: Yb | R | Ok, canonical x || y
+  yb.x = fp_to_mont<Fq>(fp_load_le(pts_xy)); yb.y = fp_to_mont<Fq>(fp_load_le(pts_xy + 32));
+  ra.x = fp_to_mont<Fq>(fp_load_le(pts_xy + 64)); ra.y = fp_to_mont<Fq>(fp_load_le(pts_xy + 96));
+  oka.x = fp_to_mont<Fq>(fp_load_le(pts_xy + 128)); oka.y = fp_to_mont<Fq>(fp_load_le(pts_xy + 160));
+  suite_tr<S> tc = st->t; tr_byte(tc, DS_CHALLENGE); absorb_point_mont<S>(tc, ra); absorb_point_mont<S>(tc, oka);
+  const fp c = fp_to_mont<Fr>(challenge_finish(tc));                            // :170
+  const fp s = fp_add<Fr>(st->k, fp_mul<Fr>(c, fp_to_mont<Fr>(sk)));            // :173
+  const fp sb = fp_add<Fr>(st->kb, fp_mul<Fr>(c, st->bl));                      // :175
+  uint8_t *o = proofs_out + 256 * (size_t)j;
+  store_xy<S>(o, yb); store_xy<S>(o + 64, ra); store_xy<S>(o + 128, oka);
+  fp_store_le(o + 192, fp_from_mont<Fr>(s)); fp_store_le(o + 224, fp_from_mont<Fr>(sb));
+  if (blindings_out) fp_store_le(blindings_out + 32 * (size_t)j, fp_from_mont<Fr>(st->bl));
+  if (st->f) atomicOr(flags, st->f);
+}
+
 template <class S>
 __global__ void __launch_bounds__(128, AVRF_ITEM_WAVES)
 k_ped_verify(BatchDev b, int32_t *__restrict__ status) {
@@ -998,6 +1082,16 @@ template <class S> void SingleOps<S>::thin_prove_end(const BatchDev &b, const ui
   if (tiny) hipLaunchKernelGGL((k_thin_prove_end<S, true>), dim3(1), dim3(64), 0, st, b, d_state, d_rxy, d_proofs_out, d_flags);
   else hipLaunchKernelGGL((k_thin_prove_end<S, false>), dim3(1), dim3(64), 0, st, b, d_state, d_rxy, d_proofs_out, d_flags);
 }
+template <class S> size_t SingleOps<S>::ped_state_bytes() { return (sizeof(PedState<S>) + 63) / 64 * 64; }
+template <class S> void SingleOps<S>::ped_prove_begin(const BatchDev &b, uint32_t *d_scalars, te_pre_raw *d_pre, uint8_t *d_state, uint32_t *d_wts, hipStream_t st) {
+  hipLaunchKernelGGL(k_ped_prove_begin<S>, dim3(1), dim3(64), 0, st, b, d_scalars, (te_pre *)d_pre, d_state, d_wts);
+}
+template <class S> void SingleOps<S>::ped_prove_mid(const BatchDev &b, uint32_t *d_scalars, te_pre_raw *d_pre, uint8_t *d_state, const uint32_t *d_wts, const uint8_t *d_yb, hipStream_t st) {
+  hipLaunchKernelGGL(k_ped_prove_mid<S>, dim3(1), dim3(64), 0, st, b, d_scalars, (te_pre *)d_pre, d_state, d_wts, d_yb);
+}
+template <class S> void SingleOps<S>::ped_prove_end(const BatchDev &b, const uint8_t *d_state, const uint8_t *d_pts, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st) {
+  hipLaunchKernelGGL(k_ped_prove_end<S>, dim3(1), dim3(64), 0, st, b, d_state, d_pts, d_proofs_out, d_blind, d_flags);
+}
 template <class S> void SingleOps<S>::tiny_verify(const BatchDev &b, int32_t *d_status, hipStream_t st) {
   hipLaunchKernelGGL(k_tiny_verify<S>, dim3((b.n - b.first + 127) / 128), dim3(128), 0, st, b, d_status);
 }
@@ -1074,6 +1168,18 @@ void launch_thin_prove_begin(int suite, const BatchDev &b, uint32_t *d_scalars, 
 }
 void launch_thin_prove_end(int suite, const BatchDev &b, const uint8_t *d_state, const uint8_t *d_rxy, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny) {
   AVRF_SINGLE(suite, thin_prove_end(b, d_state, d_rxy, d_proofs_out, d_flags, st, tiny));
+}
+size_t ped_prove_state_bytes(int suite) {
+  return with_suite(suite, [&](auto tag_) { using S_ = typename decltype(tag_)::type; return SingleOps<S_>::ped_state_bytes(); });
+}
+void launch_ped_prove_begin(int suite, const BatchDev &b, uint32_t *d_scalars, struct te_pre_raw *d_pre, uint8_t *d_state, uint32_t *d_wts, hipStream_t st) {
+  AVRF_SINGLE(suite, ped_prove_begin(b, d_scalars, d_pre, d_state, d_wts, st));
+}
+void launch_ped_prove_mid(int suite, const BatchDev &b, uint32_t *d_scalars, struct te_pre_raw *d_pre, uint8_t *d_state, const uint32_t *d_wts, const uint8_t *d_yb, hipStream_t st) {
+  AVRF_SINGLE(suite, ped_prove_mid(b, d_scalars, d_pre, d_state, d_wts, d_yb, st));
+}
+void launch_ped_prove_end(int suite, const BatchDev &b, const uint8_t *d_state, const uint8_t *d_pts, uint8_t *d_proofs_out, uint8_t *d_blind, uint32_t *d_flags, hipStream_t st) {
+  AVRF_SINGLE(suite, ped_prove_end(b, d_state, d_pts, d_proofs_out, d_blind, d_flags, st));
 }
 void launch_thin_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint32_t *d_flags, hipStream_t st, bool tiny) {
   if (!b.n) return;

@@ -93,6 +93,15 @@ def test_multi_io(ctxs, suite):
     for j, (p, b) in enumerate(want):
         assert proof_comp(suite, pl[j], 1) == p and blind[32 * j: 32 * j + 32] == b
     assert c.pedersen_verify(Batch.from_items(ios, ads, proofs=pl)) == [0] * len(sks)
+    # ONE item per call: prover and verifier through the MSM engine (capi.hip prove_ped_one_as_msm / avrf_pedersen_verify), every
+    # pair count, with and without a given public key -- same bytes, same blinding, same verdicts
+    for j in range(len(sks)):
+        pk_j = xy(suite, orc.from_seed(suite, bytes([j + 9]) + bytes(31))[1])
+        p1, b1 = c.pedersen_prove(Batch.from_items([ios[j]], [ads[j]], sks=[sks[j]]))
+        p2, b2 = c.pedersen_prove(Batch.from_items([ios[j]], [ads[j]], sks=[sks[j]], pks_xy=[pk_j]))
+        assert p1 == pl[j] and p2 == pl[j] and b1 == blind[32 * j: 32 * j + 32] and b2 == b1
+        assert c.pedersen_verify(Batch.from_items([ios[j]], [ads[j]], proofs=[pl[j]])) == [0]
+        assert c.pedersen_verify(Batch.from_items([ios[j]], [ads[j] + b"x"], proofs=[pl[j]])) == [1]
     assert c.pedersen_batch_verify(ios, ads, pl) == 0
     st, bases, sc = orc.pedersen_batch_terms(suite, ios_c, ads, [w[0] for w in want])
     gb, gs = c.last_terms()
