@@ -376,7 +376,7 @@ int avrf_ring_batch_verify(avrf_ring_setup *setup, size_t n, const uint8_t *ring
  * bad proof is identified instead of failing the batch: per proof two small G1 linear combinations and one 2-pairing check,
  * all on the device (Miller loops + final exponentiations of all proofs in one kernel, pairing.hip).  Few proofs are latency
  * cases -- one wave of the pairing kernel needs 11.7 ms whatever it carries -- so up to 16 checks are finished on the host pool
- * from the device's G1 sums (tabulated G2 lines, 1.0 ms per check and core), and n = 1 runs as a batch of one (1.9 ms; the
+ * from the device's G1 sums (tabulated G2 lines, 1.0 ms per check and core), and n = 1 runs as a batch of one (1.7 ms; the
  * reference: 3.24 ms).  Same statuses either way.  A ring commitment that does not decode fails the call (AVRF_INVALID_DATA). */
 int avrf_ring_verify_each(avrf_ring_setup *setup, size_t n, const uint8_t *ring_commitments, size_t n_rings, const uint32_t *ring_of_item,
                           const uint8_t *instances_xy, const uint8_t *ring_proofs, int32_t *status_out);
