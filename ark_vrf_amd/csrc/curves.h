@@ -43,7 +43,9 @@ template <class S> struct TeCurve {
   static constexpr bool PREFETCH = true;
   static constexpr bool ZERO_IS_IDENTITY = S::SW_NATIVE;   // twisted Edwards: (0, 1, 0, 1); XYZZ: ZZ = 0
   static constexpr bool FIXED_TABLE = false;          // no fixed-base window-table mode (bases change per batch)
-  static constexpr int MIN_WAVES = AVRF_TE_ACC_WAVES; // waves per SIMD asked of the register allocator in k_accumulate
+  // waves per SIMD asked of the register allocator in k_accumulate (the XYZZ mixed addition over the GENERIC multiplier -- secp256r1, whose
+  // modulus fills its top bit -- needs more than 256 registers: one wave, the whole file, instead of 60 spilled registers)
+  static constexpr int MIN_WAVES = (S::SW_NATIVE && S::Fq::FULL) ? 1 : AVRF_TE_ACC_WAVES;
   static constexpr int MAX_WAVES = AVRF_TE_ACC_MAX_WAVES;   // resident k_accumulate waves per SIMD at most (0 = what the registers allow), msm.hip accumulate_shape
   static constexpr int RED_WAVES = 1;                 // reduction kernels (general additions, several points live): latency-bound, full register file
   static constexpr bool INLINE_REDUCE_OPS = true;
