@@ -292,8 +292,9 @@ template <class F> AVRF_DN fp fp_inv_few(fp a) {
   auto is_one = [](const fp &x) { uint32_t o = x.v[0] ^ 1u; for (int i = 1; i < 8; i++) o |= x.v[i]; return o == 0; };
   auto shr1 = [](fp &x, uint32_t top) { for (int i = 0; i < 7; i++) x.v[i] = (x.v[i] >> 1) | (x.v[i + 1] << 31); x.v[7] = (x.v[7] >> 1) | (top << 31); };
   auto halve_mod = [&](fp &x) { uint32_t c = 0; if (x.v[0] & 1u) c = add8(x, x, P); shr1(x, c); };
+  // (u = 0 cannot happen for a canonical non-zero a -- gcd(a, p) = 1 -- but a loop on the device must end whatever it is fed)
 #pragma unroll 1
-  while (!is_one(u) && !is_one(v)) {
+  while (!is_one(u) && !is_one(v) && !fp_is_zero(u)) {
 #pragma unroll 1
     while (!(u.v[0] & 1u)) { shr1(u, 0); halve_mod(x1); }
 #pragma unroll 1
