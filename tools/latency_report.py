@@ -11,9 +11,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import oracle as orc  # noqa: E402  (test-side generator of synthetic batches; nothing of it is timed)
-from helpers import nat_batch, xy  # noqa: E402
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (make_batch / derive_scalars: synthetic items built on the GPU itself, as the bench line's are)
 from ark_vrf_amd import _native as nat  # noqa: E402
 from ark_vrf_amd.ring import RingSetup, ring_batch_verify, ring_verify_each  # noqa: E402
 
@@ -27,21 +26,29 @@ def best(fn, reps=30):
 
 c = nat.Context(0)
 L = nat.lib()
+
+
+def items(n):
+    """n synthetic one-pair items (bench.make_batch): thin verifier / prover batches and the Pedersen ones over the same keys"""
+    vb, raw = bench.make_batch(c, nat, n, start=0)
+    sks = bench.derive_scalars(b"avrf-bench-sk", 0, n, bench.R_BANDERSNATCH)
+    pb = nat.Batch(n, raw["ios_xy"], raw["io_counts"], raw["ads"], raw["ad_lens"], pks_xy=raw["pks_xy"], sks=sks)
+    ped, _ = c.pedersen_prove(pb)
+    pvb = nat.Batch(n, raw["ios_xy"], raw["io_counts"], raw["ads"], raw["ad_lens"], proofs=ped)
+    return vb, pb, pvb, raw
+
+
 for n in (1, 8, 64):
-    b = orc.gen_batch(0, 0, n); vb, pb = nat_batch(b), nat_batch(b, with_sks=True, with_proofs=False)
-    assert c.thin_verify(vb) == [0] * n and c.thin_prove(pb) == b["proofs"]
+    vb, pb, pvb, raw = items(n)
+    assert c.thin_verify(vb) == [0] * n and c.thin_prove(pb) == raw["proofs"]
     print(f"thin      n={n:<5} verify {best(lambda: c.thin_verify(vb)):.3f} ms   prove {best(lambda: c.thin_prove(pb)):.3f} ms", flush=True)
-for n in (1, 8, 64):
-    b = orc.gen_batch(0, 1, n); pb = nat_batch(b, with_sks=True, with_proofs=False); vb = nat_batch(dict(b, pks_xy=b""))
-    assert c.pedersen_prove(pb)[0] == b["proofs"] and c.pedersen_verify(vb) == [0] * n
-    print(f"pedersen  n={n:<5} verify {best(lambda: c.pedersen_verify(vb)):.3f} ms   prove {best(lambda: c.pedersen_prove(pb)):.3f} ms", flush=True)
+    assert c.pedersen_verify(pvb) == [0] * n
+    print(f"pedersen  n={n:<5} verify {best(lambda: c.pedersen_verify(pvb)):.3f} ms   prove {best(lambda: c.pedersen_prove(pb)):.3f} ms", flush=True)
 for n in (1, 8, 64, 1024):
-    b = orc.gen_batch(0, 0, n); vb = nat_batch(b)
+    vb, pb, pvb, raw = items(n)
     f = lambda: L.avrf_thin_batch_verify(c._h, C.c_size_t(vb.n), vb.pks_xy, vb.ios_xy, vb.io_counts, vb.ads, vb.ad_lens, vb.proofs)
-    assert f() == 0
-    b2 = orc.gen_batch(0, 1, n); vb2 = nat_batch(dict(b2, pks_xy=b""))
-    g = lambda: L.avrf_pedersen_batch_verify(c._h, C.c_size_t(vb2.n), vb2.ios_xy, vb2.io_counts, vb2.ads, vb2.ad_lens, vb2.proofs)
-    assert g() == 0
+    g = lambda: L.avrf_pedersen_batch_verify(c._h, C.c_size_t(pvb.n), pvb.ios_xy, pvb.io_counts, pvb.ads, pvb.ad_lens, pvb.proofs)
+    assert f() == 0 and g() == 0
     print(f"batch     n={n:<5} thin BatchVerifier {best(f, 20):.3f} ms   pedersen BatchVerifier {best(g, 20):.3f} ms", flush=True)
 
 gdir = os.path.join(ROOT, "tests", "golden")
@@ -50,8 +57,9 @@ srs = open(os.path.join(gdir, "bls12-381-srs-2-11-uncompressed-zcash.bin"), "rb"
 setup = RingSetup(c, srs, 8)
 v = vs[0]
 raw = bytes.fromhex(v["ring_pks"])
-key = setup.index([xy(0, raw[32 * i: 32 * i + 32]) for i in range(len(raw) // 32)])
-inst = xy(0, bytes.fromhex(v["proof_pk_com"])); rp = bytes.fromhex(v["ring_proof"])
+xy = lambda comp: c.points_decompress(comp)[0]
+key = setup.index([xy(raw[32 * i: 32 * i + 32]) for i in range(len(raw) // 32)])
+inst = xy(bytes.fromhex(v["proof_pk_com"])); rp = bytes.fromhex(v["ring_proof"])
 assert ring_batch_verify(setup, [key.commitment], None, [inst], [rp]) == 0 and ring_verify_each(setup, [key.commitment], None, [inst], [rp]) == [0]
 print(f"ring      n=1     avrf_ring_batch_verify {best(lambda: ring_batch_verify(setup, [key.commitment], None, [inst], [rp])):.3f} ms   "
       f"avrf_ring_verify_each {best(lambda: ring_verify_each(setup, [key.commitment], None, [inst], [rp])):.3f} ms", flush=True)
