@@ -827,7 +827,7 @@ int avrf_thin_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pk
   HIP_TRY(c->d_out.ensure(n * 96));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
   double t0 = now_us();
-  if (n == 1 && c->tot_io < 64 && one_as_msm()) {
+  if (n == 1 && c->tot_io < 1000 && one_as_msm()) {
     HIP_TRY(c->h_c.ensure(64));
     const int st1 = prove_one_as_msm(c, pks_xy != nullptr, false, proofs_out);
     c->timing[0] = now_us() - t0;
@@ -866,7 +866,7 @@ int avrf_thin_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t
   // (msm.hip k_msm_tiny_bits): the doubling chain runs on the host's Horner instead of a lone wave -- 0.54 -> 0.28 ms.  Same
   // statuses as the per-item kernels: the flags of the prepare kernel and of the validation are InvalidData, a non-zero sum is
   // VerificationFailure.  Everything is enqueued back to back; the one wait is in batch_end.
-  if (n == 1 && one_as_msm() && c->n_terms && c->n_terms <= 64) {
+  if (n == 1 && one_as_msm() && c->n_terms && c->n_terms <= 2048) {
     uint8_t zero[64] = {0};
     c->unit_weights = true;
     int st = batch_begin(c, 1);
@@ -906,7 +906,7 @@ int avrf_tiny_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t *pk
   c->staged_kind = 0;
   HIP_TRY(c->d_out.ensure(n * 48));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
-  if (n == 1 && c->tot_io < 64 && one_as_msm()) { HIP_TRY(c->h_c.ensure(64)); return prove_one_as_msm(c, pks_xy != nullptr, true, proofs_out); }
+  if (n == 1 && c->tot_io < 1000 && one_as_msm()) { HIP_TRY(c->h_c.ensure(64)); return prove_one_as_msm(c, pks_xy != nullptr, true, proofs_out); }
   if (pks_xy && wave_shape(c, n, io_counts)) {                         // few items: 32 lanes per item (vrf_single.hip)
     HIP_TRY(c->d_status.ensure(n * 4)); HIP_TRY(c->h_c.ensure(n * 4));
     if (launch_thin_prove_wave(c->suite, batch_of(c), c->d_out.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->d_status.as<int32_t>(), c->stream, true)) {
@@ -958,7 +958,7 @@ int avrf_pedersen_prove(avrf_ctx *c, size_t n, const uint8_t *sks, const uint8_t
   HIP_TRY(c->d_out.ensure(n * 256)); HIP_TRY(c->d_misc.ensure(n * 32));
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
   double t0 = now_us();
-  if (n == 1 && c->tot_io <= 60 && one_as_msm()) {
+  if (n == 1 && c->tot_io <= 1000 && one_as_msm()) {
     if (!pks_xy) { if (int fs = ensure_fixed(c)) return fs; }
     const int st1 = prove_ped_one_as_msm(c, pks_xy != nullptr, proofs_out, blindings_out);
     c->timing[0] = now_us() - t0;
@@ -998,7 +998,7 @@ int avrf_pedersen_verify(avrf_ctx *c, size_t n, const uint8_t *ios_xy, const uin
   // ONE item: its two equations (src/pedersen.rs:229-245) as two scalar vectors over the item's seven bases -- the terms kernel run with
   // the weights (t, u) = (1, 0) and (0, 1) -- through the single-launch MSM with the host's two Horners side by side (see
   // avrf_thin_verify): both sums must be the identity, exactly the reference's two checks.  0.52 -> ~0.33 ms.
-  if (n == 1 && one_as_msm() && c->n_terms && c->n_terms <= 64) {
+  if (n == 1 && one_as_msm() && c->n_terms && c->n_terms <= 2048) {
     int st = batch_begin(c, 2);                                        // validation + prepare kernel (challenge, merged pair) + flags copy
     c->run_phase = 0;
     if (st != AVRF_OK) return st;

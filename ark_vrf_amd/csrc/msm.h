@@ -74,7 +74,7 @@ int msm_te_device(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars,
 // caller has seen an event recorded behind the chain complete.
 int msm_te_enqueue(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, MsmWorkspace &ws, hipStream_t stream, MsmPending *pend = nullptr);
 int msm_te_finish(int suite, MsmWorkspace &ws, hipStream_t stream, HostExt *out, MsmPending *pend = nullptr);
-// two or more scalar vectors over the SAME n <= 64 bases (vector v's scalars start at element v * n) through the single-launch
+// two or more scalar vectors over the SAME n <= 2048 bases (vector v's scalars start at element v * n) through the single-launch
 // form: out[v] = sum_t s_{v,t} P_t.  Synchronises the stream.  Returns -1 when the shape is not the single-launch one.
 int msm_te_small_vectors(int suite, const te_pre_raw *d_pre, const uint32_t *d_scalars, size_t n, size_t n_vectors, MsmWorkspace &ws, hipStream_t stream,
                          HostExt *out);

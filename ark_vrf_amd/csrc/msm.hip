@@ -739,21 +739,42 @@ static void msm_wait(MsmWorkspace &ws, hipStream_t stream) {
   ws.accum_ms_total += ws.accum_ms_last; ws.accum_launches++; ws.last_plan = ws.pending_plan;
 }
 
-// Tiny MSMs (<= 64 terms: a BatchVerifier of a dozen items, ONE independent verification run as its own equation, the verifier's
-// two G1 sums of one ring proof): the Pippenger chain below is twelve launches of latency there (0.28 ms for five terms) and
+// Small MSMs (a BatchVerifier of up to a few hundred items, ONE independent verification run as its own equation, the verifier's
+// two G1 sums of a few ring proofs): the Pippenger chain below is twelve launches of latency there (0.28 ms for five terms) and
 // almost no work.  One launch instead: wave (p, v) sums the bases whose scalar of vector v has bit p set -- lane = term, a
 // butterfly of ceil(log2 n) additions -- which are exactly the bit sums T_p the general path hands to the host's Horner
 // (sum_p 2^p T_p; the sequential doublings run ~10 x faster on a host core than on a lone wave).
-constexpr size_t MSM_TINY_TERMS = 64, MSM_TINY_VECTORS = 7;
+// (Up to 2 048 terms with workgroups of up to four waves -- one per SIMD, the whole register file each: a thread takes the terms
+// t, t + T, .., the waves' sums meet in LDS --
+// the reference's own batch-size sweep, 1 .. 256 items per BatchVerifier, benches/SUMMARY.md:43-61, lives entirely in this range.
+// Above it the bit sums cost too much work -- n * bits / 2 additions against n * windows -- and the Pippenger chain takes over.)
+constexpr size_t MSM_TINY_TERMS = 2048, MSM_TINY_VECTORS = 7;
 template <class CV>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_msm_tiny_bits(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ scalars, uint32_t n, uint32_t stride, uint32_t *__restrict__ out) {
-  const uint32_t p = blockIdx.x, v = blockIdx.y, t = threadIdx.x;
+  extern __shared__ uint32_t lds[];                                            // one accumulator per wave
+  const uint32_t p = blockIdx.x, v = blockIdx.y, t = threadIdx.x, T = blockDim.x, lane = t & 63, wv = t >> 6, nw = T >> 6;
   typename CV::acc_t acc = CV::identity();
-  if (t < n && ((scalars[8 * ((size_t)v * stride + t) + (p >> 5)] >> (p & 31)) & 1u)) acc = CV::from_base(CV::load_base(bases + (size_t)t * CV::BASE_WORDS), false);
-  uint32_t span = 1; while (span < n) span <<= 1;
+  bool first = true;
+#pragma unroll 1
+  for (uint32_t k = t; k < n; k += T) {
+    if (!((scalars[8 * ((size_t)v * stride + k) + (p >> 5)] >> (p & 31)) & 1u)) continue;
+    const typename CV::base_t q = CV::load_base(bases + (size_t)k * CV::BASE_WORDS);
+    acc = first ? CV::from_base(q, false) : CV::madd(acc, q, false);
+    first = false;
+  }
+  uint32_t span = 1; while (span < n && span < 64) span <<= 1;
 #pragma unroll 1
   for (uint32_t off = span >> 1; off >= 1; off >>= 1) acc = cv_add<CV>(acc, CV::shfl_down(acc, (int)off));
+  if (nw > 1) {
+    if (lane == 0) CV::store_acc(lds + wv * CV::ACC_WORDS, acc);
+    __syncthreads();
+    if (wv == 0) {
+      acc = lane < nw ? CV::load_acc(lds + lane * CV::ACC_WORDS) : CV::identity();
+#pragma unroll 1
+      for (uint32_t off = nw >> 1; off >= 1; off >>= 1) acc = cv_add<CV>(acc, CV::shfl_down(acc, (int)off));
+    }
+  }
   if (t == 0) CV::store_acc(out + ((size_t)v * gridDim.x + p) * CV::ACC_WORDS, acc);
 }
 
@@ -778,7 +799,9 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
     if (pend) { pend->ensure(batch * nbits * acc_b); pend->plan_host[0] = 0; }
     hipEvent_t e0 = pend ? pend->ev0 : ws.ev0, e1 = pend ? pend->ev1 : ws.ev1;
     HIP_CHECK(hipEventRecord(e0, stream));
-    hipLaunchKernelGGL(k_msm_tiny_bits<CV>, dim3((unsigned)nbits, (unsigned)batch), dim3(64), 0, stream, d_bases, d_scalars, (uint32_t)n_in, (uint32_t)scalar_stride, ws.bits);
+    unsigned threads = 64; while (threads < n_in && threads < 256) threads <<= 1;           // a power of two of waves: the LDS butterfly halves it
+    hipLaunchKernelGGL(k_msm_tiny_bits<CV>, dim3((unsigned)nbits, (unsigned)batch), dim3(threads), (threads / 64) * acc_b, stream, d_bases, d_scalars, (uint32_t)n_in,
+                       (uint32_t)scalar_stride, ws.bits);
     HIP_CHECK(hipEventRecord(e1, stream));
     HIP_CHECK(hipMemcpyAsync(pend ? pend->bits_host : ws.bits_host, ws.bits, batch * nbits * acc_b, hipMemcpyDeviceToHost, stream));
     if (pend) pend->plan = p; else ws.pending_plan = p;

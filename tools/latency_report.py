@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Single-call latencies through the C ABI on one GPU (DESIGN.md section 5 "One item"; references: benches/SUMMARY.md:53-88):
    python tools/latency_report.py
-Thin / Pedersen verify and prove with n = 1, 8, 64; BatchVerifier calls of 1, 8, 64, 1024 items; one ring verification
+Thin / Pedersen verify and prove with n = 1, 8, 64; the reference's own batch-size sweep (benches/thin.rs:41 BATCH_SIZES = 1 .. 256;
+its published table: benches/SUMMARY.md:43-47,57-61,81-88) for the Thin, Pedersen and ring-VRF BatchVerifiers; one ring verification
 (avrf_ring_batch_verify / avrf_ring_verify_each, n = 1); one complete ring-VRF verification from wire bytes (avrf_ring_vrf_verify,
 with and without Validate::Yes); decompression of five points.  Best of 20-50 calls each."""
 import ctypes as C
@@ -44,12 +45,53 @@ for n in (1, 8, 64):
     print(f"thin      n={n:<5} verify {best(lambda: c.thin_verify(vb)):.3f} ms   prove {best(lambda: c.thin_prove(pb)):.3f} ms", flush=True)
     assert c.pedersen_verify(pvb) == [0] * n
     print(f"pedersen  n={n:<5} verify {best(lambda: c.pedersen_verify(pvb)):.3f} ms   prove {best(lambda: c.pedersen_prove(pb)):.3f} ms", flush=True)
-for n in (1, 8, 64, 1024):
+# ---- the reference's batch-size sweep: BatchVerifier::verify (prepare included) for 1 .. 256 items; ring-VRF on a ring of 1023 keys
+REF = {"thin": [0.5035, 0.5746, 0.7301, 1.68, 2.00, 3.40, 5.81, 7.77, 14.3],             # benches/SUMMARY.md:61 (batch_verify) + :60 (batch_prepare)
+       "pedersen": [0.5294, 0.6061, 0.7747, 1.72, 2.09, 3.52, 6.04, 8.53, 15.6],        # :47 + :46
+       "ring": [3.35, 3.91, 5.26, 7.76, 11.09, 18.94, 28.46, 49.66, 84.04]}             # :88 (batch_verify; + :86 batch_prepare_par)
+PREP = {"thin": [0.00187, 0.00374, 0.00747, 0.0142, 0.0287, 0.0583, 0.1169, 0.2341, 0.4978],
+        "pedersen": [0.00121, 0.00241, 0.00487, 0.00929, 0.0197, 0.0367, 0.0735, 0.1582, 0.3087],
+        "ring": [0.0424, 0.0801, 0.1172, 0.1834, 0.2419, 0.2557, 0.2109, 0.4516, 0.8404]}
+SIZES = [1, 2, 4, 8, 16, 32, 64, 128, 256]
+RING = 1023
+from ark_vrf_amd.ring import srs_generate  # noqa: E402
+srs_b = open(os.path.join(ROOT, "tests", "golden", "bls12-381-srs-2-11-uncompressed-zcash.bin"), "rb").read()
+have = int.from_bytes(srs_b[:8], "little")
+if have < 3 * (1 << (RING + 4 + 253 - 1).bit_length()) + 1:
+    srs_b = srs_generate(c, 0, 0x1234567890abcdef1234567890abcdef, srs_b[8: 8 + 96], srs_b[8 + have * 96 + 8: 8 + have * 96 + 8 + 192], RING)
+rsetup = RingSetup(c, srs_b, RING)
+rsks = bench.derive_scalars(b"avrf-ring-sk", 0, RING, bench.R_BANDERSNATCH)
+rpks = c.scalar_mul_base(rsks)
+rkey = rsetup.index([rpks[64 * i: 64 * i + 64] for i in range(RING)])
+nmax = SIZES[-1]
+idx = [(7 * j + 3) % RING for j in range(nmax)]
+inputs = c.scalar_mul_base(bench.derive_scalars(b"avrf-ring-input", 0, nmax, bench.R_BANDERSNATCH))
+psk = b"".join(rsks[32 * k: 32 * k + 32] for k in idx); ppk = b"".join(rpks[64 * k: 64 * k + 64] for k in idx)
+outs = c.scalar_mul(psk, inputs)
+rios = b"".join(inputs[64 * j: 64 * j + 64] + outs[64 * j: 64 * j + 64] for j in range(nmax))
+rads = [b"ad-%d" % j for j in range(nmax)]
+ped_all, blind = c.pedersen_prove(nat.Batch(nmax, rios, [1] * nmax, b"".join(rads), [len(x) for x in rads], pks_xy=ppk, sks=psk))
+rproofs = rkey.prove(idx, [blind[32 * j: 32 * j + 32] for j in range(nmax)])
+rows = {"thin": [], "pedersen": [], "ring": []}
+for n in SIZES:
     vb, pb, pvb, raw = items(n)
     f = lambda: L.avrf_thin_batch_verify(c._h, C.c_size_t(vb.n), vb.pks_xy, vb.ios_xy, vb.io_counts, vb.ads, vb.ad_lens, vb.proofs)
     g = lambda: L.avrf_pedersen_batch_verify(c._h, C.c_size_t(pvb.n), pvb.ios_xy, pvb.io_counts, pvb.ads, pvb.ad_lens, pvb.proofs)
+    rvb = nat.Batch(n, rios[: 128 * n], [1] * n, b"".join(rads[:n]), [len(x) for x in rads[:n]], proofs=ped_all[: 256 * n])
+    insts = [ped_all[256 * j: 256 * j + 64] for j in range(n)]
+
+    def h():                                                # ring::BatchVerifier::verify: the Pedersen batch and the ring batch (src/ring.rs:713-735)
+        assert L.avrf_pedersen_batch_verify(c._h, C.c_size_t(rvb.n), rvb.ios_xy, rvb.io_counts, rvb.ads, rvb.ad_lens, rvb.proofs) == 0
+        assert ring_batch_verify(rsetup, [rkey.commitment], None, insts, rproofs[:n]) == 0
     assert f() == 0 and g() == 0
-    print(f"batch     n={n:<5} thin BatchVerifier {best(f, 20):.3f} ms   pedersen BatchVerifier {best(g, 20):.3f} ms", flush=True)
+    h()
+    rows["thin"].append(best(f, 15)); rows["pedersen"].append(best(g, 15)); rows["ring"].append(best(h, 8))
+print("batch-size sweep, ms per BatchVerifier::verify call (prepare included); reference = benches/SUMMARY.md batch_prepare + batch_verify, one CPU thread")
+print("           " + "".join(f"n={n:<8}" for n in SIZES))
+for k in ("thin", "pedersen", "ring"):
+    print(f"{k:<9}  " + "".join(f"{v:<10.3f}" for v in rows[k]) + " this engine")
+    print(f"{'':<9}  " + "".join(f"{a + b:<10.3f}" for a, b in zip(REF[k], PREP[k])) + " reference")
+    print(f"{'':<9}  " + "".join(f"{(a + b) / v:<10.1f}" for a, b, v in zip(REF[k], PREP[k], rows[k])) + " x")
 
 gdir = os.path.join(ROOT, "tests", "golden")
 vs = json.load(open(os.path.join(gdir, "bandersnatch_sha-512_ell2_ring.json")))
