@@ -766,7 +766,7 @@ static bool wave_shape(const avrf_ctx *c, size_t n, const uint32_t *io_counts) {
 }
 
 // ONE thin / tiny proof through the MSM engine (vrf_single.hip k_thin_prove_begin / _end): the terms of R = k G + sum (k z_i) I_i,
-// the single-launch MSM of <= 64 terms with the host's Horner, R back as canonical x || y, challenge and response.  0.71 -> ~0.3 ms
+// the single-launch MSM with the host's Horner, R back as canonical x || y, challenge and response.  0.71 -> ~0.3 ms
 // for one proof; same bytes (any evaluation of R gives the same group element).  The nonce never leaves device memory.
 static bool one_as_msm() { static const bool on = getenv("AVRF_NO_ONE_AS_MSM") == nullptr; return on; }   // (A/B hook)
 static int prove_one_as_msm(avrf_ctx *c, bool have_pk, bool tiny, uint8_t *proofs_out) {
@@ -862,7 +862,7 @@ int avrf_thin_verify(avrf_ctx *c, size_t n, const uint8_t *pks_xy, const uint8_t
   HIP_TRY(c->d_status.ensure(n * 4));
   double t0 = now_us();
   // ONE item: its equation  R + c z0 pk + sum_i c z_i O_i - s z0 G - sum_i s z_i I_i == 0  (src/thin.rs:158-161 expanded, the
-  // BatchVerifier's sum with the weight w = 1) through the prepare / terms kernels and the single-launch MSM of <= 64 terms
+  // BatchVerifier's sum with the weight w = 1) through the prepare / terms kernels and the single-launch MSM
   // (msm.hip k_msm_tiny_bits): the doubling chain runs on the host's Horner instead of a lone wave -- 0.54 -> 0.28 ms.  Same
   // statuses as the per-item kernels: the flags of the prepare kernel and of the validation are InvalidData, a non-zero sum is
   // VerificationFailure.  Everything is enqueued back to back; the one wait is in batch_end.

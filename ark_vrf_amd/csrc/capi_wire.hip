@@ -39,7 +39,7 @@ size_t sum_counts(const uint32_t *c, size_t n) { size_t t = 0; for (size_t i = 0
 // shared by the thin / tiny / pedersen wire verifiers: kind 1 thin (64-byte proofs, 1 point), 3 tiny (48, 0 points), 2 pedersen (160, 3)
 // pp0_xy / pp0_st (optional): xy and decode status of every item's FIRST proof point (the Pedersen key commitment Yb, which
 // ring::Verifier also needs as the ring proof's instance) -- so that a caller does not decompress it a second time
-// (Until the single-launch MSM of <= 64 terms -- msm.hip k_msm_tiny_bits -- a "batch" of <= 64 items went through the per-item
+// (Until the single-launch MSM -- msm.hip k_msm_tiny_bits -- a "batch" of <= 64 items went through the per-item
 // verifiers here, 0.6 ms against 1.5 ms for the Pippenger chain on one item; the batch verifier now takes 0.30 ms for one item,
 // 0.32 for eight, 0.46 for 64, against 0.52-0.55 ms per per-item call, so a batch is a batch whatever its size: SMALL_BATCH = 0.)
 constexpr size_t SMALL_BATCH = 0;

@@ -581,7 +581,7 @@ struct MsmEnv {
     if (const char *e = getenv("AVRF_MSM_PER_MIN")) { int v = atoi(e); if (v >= 1 && v <= 4096) per_min = v; }
     if (const char *e = getenv("AVRF_TE_WSUM_WPS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) wsum_wps = v; }
     if (const char *e = getenv("AVRF_TE_WINDOW_SUMS")) window_sums = atoi(e) != 0;
-    if (const char *e = getenv("AVRF_MSM_TINY")) tiny = atoi(e) != 0;                    // (A/B hook: 0 sends <= 64-term MSMs through the general chain)
+    if (const char *e = getenv("AVRF_MSM_TINY")) tiny = atoi(e) != 0;                    // (A/B hook: 0 sends small MSMs through the general chain too)
   }
 };
 static const MsmEnv &msm_env() { static const MsmEnv e; return e; }

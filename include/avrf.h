@@ -245,7 +245,7 @@ int avrf_kernel_stats(avrf_ctx *ctx, int reset, double *accum_ms_total, uint64_t
 /* ---- Independent items (the per-item Prover / Verifier traits).  Two device forms behind every entry point below, same
  * results: calls of up to 2 048 items with ONE I/O pair each (and a given public key, for the provers) on the twisted-Edwards
  * suites spread an item over 32 lanes -- latency of a call 0.5-1.1 ms whatever n (Thin 0.54 / 0.72 ms, Pedersen 0.52 / 1.03 ms);
- * ONE item per call goes through the MSM engine instead (its equations / its commitments as MSMs of <= 64 terms in one launch,
+ * ONE item per call goes through the MSM engine instead (its equations / its commitments as small MSMs in one launch,
  * the doubling chains folded on the host): Thin 0.28 ms verifying, 0.36 ms proving; Pedersen 0.35 / 0.69 ms; up to 30 pairs; everything else runs one lane per item (2-3.4 ms per call up to 65 536 items: 19-25 M items/s). */
 
 /* thin::Prover::prove for a batch of independent (sk, ios, ad)  (src/thin.rs:111-129).
