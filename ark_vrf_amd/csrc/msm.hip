@@ -748,7 +748,7 @@ static void msm_wait(MsmWorkspace &ws, hipStream_t stream) {
 // t, t + T, .., the waves' sums meet in LDS --
 // the reference's own batch-size sweep, 1 .. 256 items per BatchVerifier, benches/SUMMARY.md:43-61, lives entirely in this range.
 // Above it the bit sums cost too much work -- n * bits / 2 additions against n * windows -- and the Pippenger chain takes over.)
-constexpr size_t MSM_TINY_TERMS = 2048, MSM_TINY_VECTORS = 7;
+constexpr size_t MSM_TINY_TERMS = 2048, MSM_TINY_VECTORS = 32;
 template <class CV>
 __global__ void __launch_bounds__(256)
 k_msm_tiny_bits(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ scalars, uint32_t n, uint32_t stride, uint32_t *__restrict__ out) {
@@ -791,7 +791,8 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
                       bool defer = false, int scalars_mont = 0, MsmPending *pend = nullptr) {
   MsmPlan p = msm_plan(n_in, scalar_bits);
   if (!scalar_stride) scalar_stride = n_in;                            // vector b's scalars start at b * scalar_stride
-  if (n_in <= MSM_TINY_TERMS && batch <= MSM_TINY_VECTORS && !table_c && !d_base_idx && !scalars_mont && msm_env().tiny) {
+  // (the G1 callers take eight or more vectors back as finished points -- device Horner below -- so they keep that form)
+  if (n_in <= MSM_TINY_TERMS && batch <= (CV::FIXED_TABLE ? (size_t)7 : MSM_TINY_VECTORS) && !table_c && !d_base_idx && !scalars_mont && msm_env().tiny) {
     p.c = 1; p.nwin = scalar_bits; p.nb = 1; p.lpb = 0;
     const size_t acc_b = (size_t)CV::ACC_WORDS * 4, nbits = (size_t)scalar_bits;
     ws.ensure(n_in, p, acc_b, batch, 256);

@@ -45,6 +45,12 @@ for n in (1, 8, 64):
     print(f"thin      n={n:<5} verify {best(lambda: c.thin_verify(vb)):.3f} ms   prove {best(lambda: c.thin_prove(pb)):.3f} ms", flush=True)
     assert c.pedersen_verify(pvb) == [0] * n
     print(f"pedersen  n={n:<5} verify {best(lambda: c.pedersen_verify(pvb)):.3f} ms   prove {best(lambda: c.pedersen_prove(pb)):.3f} ms", flush=True)
+for n in (1, 8, 32):
+    ks = bench.derive_scalars(b"k", 0, n, bench.R_BANDERSNATCH); pts = c.scalar_mul_base(ks)
+    ss = bench.derive_scalars(b"s", 0, n, bench.R_BANDERSNATCH)
+    c.scalar_mul(ss, pts)
+    print(f"common    n={n:<5} avrf_scalar_mul (Secret::output, vrf_output) {best(lambda: c.scalar_mul(ss, pts)):.3f} ms   "
+          f"avrf_scalar_mul_base (public key) {best(lambda: c.scalar_mul_base(ks)):.3f} ms", flush=True)
 # ---- the reference's batch-size sweep: BatchVerifier::verify (prepare included) for 1 .. 256 items; ring-VRF on a ring of 1023 keys
 REF = {"thin": [0.5035, 0.5746, 0.7301, 1.68, 2.00, 3.40, 5.81, 7.77, 14.3],             # benches/SUMMARY.md:61 (batch_verify) + :60 (batch_prepare)
        "pedersen": [0.5294, 0.6061, 0.7747, 1.72, 2.09, 3.52, 6.04, 8.53, 15.6],        # :47 + :46
