@@ -1,0 +1,402 @@
+#!/usr/bin/env python3
+"""Model of ark_vrf_amd/csrc/fpu.h / fpu_te.h / fpu_g1.h (unsaturated signed limbs) in exact integer arithmetic.
+
+  python tools/fpu_model.py            # all checks
+
+What it proves, for every field / curve of consts_gen.h the kernels instantiate:
+  1. fu_mul / fu_sqr: on random and extreme limb vectors inside the documented magnitude bounds, no column accumulator leaves
+     the signed 64-bit range, the result is a b 2^(-W L) mod p with limbs 0..L-2 in [0, 2^W) and |value| < |a b| / 2^(W L) + p;
+     the worst case column sum is also bounded analytically.
+  2. teu_madd (twisted Edwards, a in {1, -1, -5}): chains of mixed additions with random signs agree with the affine group law;
+     at every product the limb magnitudes are within (2^30, 2^29 + 4); the value bounds |X| < 1.5p, |Y| < 1.7p, |T| < 2.4p,
+     |Z| < 1.3p are inductive (interval arithmetic over the formulas, worst case) and fu_to_packed returns the canonical value.
+  3. g1u_madd (XYZZ, a = 0): the same for the short-Weierstrass mixed addition (value bounds printed), incl. the closing
+     conversion by two constant multiplications.
+"""
+import os
+import random
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONSTS = os.path.join(ROOT, "ark_vrf_amd", "csrc", "consts_gen.h")
+I64 = 1 << 63
+
+
+def parse():
+    txt = open(CONSTS).read()
+    out = {}
+    for m in re.finditer(r"struct (\w+) \{(.*?)\n\};", txt, re.S):
+        name, body = m.group(1), m.group(2)
+        d = {}
+        for a in re.finditer(r"uint32_t (\w+)\[(\d+)\] = \{([^}]*)\}", body):
+            d[a.group(1)] = sum(int(x.strip().rstrip("u"), 16) << (32 * i) for i, x in enumerate(a.group(3).split(",")))
+            d[a.group(1) + "_n"] = int(a.group(2))
+        for a in re.finditer(r"(?:int|uint32_t|bool) (\w+) = (\w+)u?;", body):
+            v = a.group(2)
+            d[a.group(1)] = {"true": 1, "false": 0}.get(v, None) if v in ("true", "false") else int(v.rstrip("u"), 0)
+        u = re.search(r"using Fq = (\w+);", body)
+        if u:
+            d["Fq"] = u.group(1)
+        out[name] = d
+    return out
+
+
+class Field:
+    def __init__(self, name, d):
+        self.name, self.p, self.N = name, d["P"], d["P_n"]
+        self.W, self.L = (29, 9) if self.N == 8 else (28, 14)
+        self.SH = self.W * self.L - 32 * self.N
+        self.MASK = (1 << self.W) - 1
+        self.ninv = d["NINV"] & self.MASK
+        assert (self.p * self.ninv + 1) % (1 << self.W) == 0
+        self.R = 1 << (32 * self.N)            # saturated form
+        self.Ru = 1 << (self.W * self.L)       # unsaturated form
+        self.pl = self.slice_pos(self.p)
+        self.max_col = 0
+
+    def slice_pos(self, v):
+        """limbs of a non-negative value (top limb takes the rest)"""
+        return [(v >> (self.W * i)) & self.MASK for i in range(self.L - 1)] + [v >> (self.W * (self.L - 1))]
+
+    def slice(self, words_value, S):
+        v = words_value << S
+        assert v < 1 << (self.W * self.L)
+        return self.slice_pos(v)
+
+    def val(self, limbs):
+        return sum(l << (self.W * i) for i, l in enumerate(limbs))
+
+    def acc_ok(self, acc):
+        assert -I64 <= acc < I64, "int64 overflow in a column"
+        self.max_col = max(self.max_col, abs(acc))
+
+    def mul(self, a, b, sqr=False):
+        L, W = self.L, self.W
+        for x in a + b:
+            assert -(1 << 31) <= x < (1 << 31)
+        acc, m, r = 0, [0] * L, [0] * L
+        for k in range(2 * L - 1):
+            lo, hi = (0, k) if k < L else (k - L + 1, L - 1)
+            for i in range(lo, hi + 1):
+                acc += a[i] * b[k - i]; self.acc_ok(acc)
+            for i in range(lo, min(hi, k - 1) + 1):
+                acc += m[i] * self.pl[k - i]; self.acc_ok(acc)
+            if k < L:
+                m[k] = ((acc & 0xffffffff) * self.ninv) & self.MASK
+                acc += m[k] * self.pl[0]; self.acc_ok(acc)
+                assert acc & self.MASK == 0
+            else:
+                r[k - L] = acc & self.MASK
+            acc >>= W
+        assert -(1 << 31) <= acc < (1 << 31)
+        r[L - 1] = acc
+        va, vb, vr = self.val(a), self.val(b), self.val(r)
+        assert (vr * self.Ru - va * vb) % self.p == 0
+        assert abs(vr) < abs(va * vb) // self.Ru + self.p + 1
+        return r
+
+    def carry(self, a):
+        L, W = self.L, self.W
+        r = [a[0] & self.MASK] + [(a[i] & self.MASK) + (a[i - 1] >> W) for i in range(1, L - 1)] + [a[L - 1] + (a[L - 2] >> W)]
+        assert self.val(r) == self.val(a)
+        return r
+
+    def to_packed(self, a):
+        v = self.val(a)
+        assert abs(v) < 3 * self.p, "fu_to_packed wants |value| < 3p"
+        L, W = self.L, self.W
+        p3 = self.slice_pos(3 * self.p)
+        u, c = [0] * L, 0
+        for i in range(L - 1):
+            t = a[i] + p3[i] + c
+            assert -(1 << 31) <= t < (1 << 31)
+            u[i] = t & self.MASK; c = t >> W
+        u[L - 1] = a[L - 1] + p3[L - 1] + c
+        assert 0 <= u[L - 1] < 1 << 32
+        x = self.val(u)
+        assert x == v + 3 * self.p and x < 1 << (32 * (self.N + 1))
+        for K in (4, 2, 1):
+            if x >= K * self.p:
+                x -= K * self.p
+        assert x == v % self.p
+        return x
+
+
+def rand_limbs(f, rng, bound, top_bound):
+    pick = lambda b: rng.choice([b, -b, b - 1, 0, rng.randrange(-b, b + 1)])
+    return [pick(bound) for _ in range(f.L - 1)] + [pick(top_bound)]
+
+
+def check_mul(f, rng, rounds=300):
+    f.max_col = 0
+    A, B = 1 << 30, (1 << 29) + 4
+    # analytic worst case: L products |a_i b_j| + L products m_i p_j + the carry from below
+    worst = f.L * A * B + f.L * f.MASK * f.MASK + (1 << 36)
+    assert worst < I64, (f.name, worst / I64)
+    for r in range(rounds):
+        if r < 8:                                            # every limb at its extreme, all sign patterns of the two operands
+            a = [A if (r & 1) else -A] * f.L; b = [B if (r & 2) else -B] * f.L
+            a[-1] = b[-1] = (1 << 28) * (1 if r & 4 else -1)
+        else:
+            a, b = rand_limbs(f, rng, A, 1 << 28), rand_limbs(f, rng, B, 1 << 28)
+        f.mul(a, b)
+    for r in range(rounds // 3):
+        a = rand_limbs(f, rng, B, 1 << 28)
+        f.mul(a, a, sqr=True)
+    print(f"  {f.name}: {f.L} x {f.W}-bit limbs, SH = {f.SH}; fu_mul ok on {rounds} operand pairs, largest column |acc| = 2^{f.max_col.bit_length() - 1}."
+          f"{(f.max_col >> (f.max_col.bit_length() - 8)) & 0x7f:02x}.. (analytic worst case {worst / I64:.3f} of 2^63)")
+
+
+# ---------------------------------------------------------------------------------------------- twisted Edwards
+
+def te_bounds(p_bits_frac, a_kind, SH, WL):
+    """interval arithmetic over teu_madd in units of p: returns the output bounds for input bounds (x, y, t, z)"""
+    ratio = 2.0 ** (WL - p_bits_frac)                      # R' / p
+    kb = 2.0 ** SH / ratio                                 # |A| < kb |X| + 1 for a base coordinate < p sliced with the shift
+    x, y, t, z = 1.5, 1.7, 2.4, 1.3
+    A, B, C = kb * x + 1, kb * y + 1, kb * t + 1
+    E = 2 * kb * (x + y) + 1 + A + B
+    FG = z + C
+    H = {0: B + A, 2: B + A, 1: B + 5 * A}[a_kind]
+    return (E * FG / ratio + 1, FG * H / ratio + 1, E * H / ratio + 1, FG * FG / ratio + 1), (E, FG, H)
+
+
+class TE:
+    def __init__(self, name, d, f):
+        self.name, self.f, self.a_kind = name, f, d["A_KIND"]
+        p = f.p
+        rinv = pow(f.R, -1, p)
+        self.a = {0: 1, 1: p - 5, 2: p - 1}[self.a_kind]
+        self.d = d["D"] * rinv % p
+        self.G = (d["G_X"] * rinv % p, d["G_Y"] * rinv % p)
+        x, y = self.G
+        assert (self.a * x * x + y * y - 1 - self.d * x * x * y * y) % p == 0
+
+    def add(self, P, Q):
+        p = self.f.p
+        (x1, y1), (x2, y2) = P, Q
+        k = self.d * x1 * x2 * y1 * y2 % p
+        return ((x1 * y2 + y1 * x2) * pow(1 + k, -1, p) % p, (y1 * y2 - self.a * x1 * x2) * pow(1 - k, -1, p) % p)
+
+    def neg(self, P):
+        return ((-P[0]) % self.f.p, P[1])
+
+    def pre(self, P):
+        """saturated Montgomery words of (x, y, d x y) as integers"""
+        f = self.f
+        return (P[0] * f.R % f.p, P[1] * f.R % f.p, self.d * P[0] * P[1] % f.p * f.R % f.p)
+
+    def limb_check(self, a, A, b, B):
+        assert max(abs(v) for v in a) <= A and max(abs(v) for v in b) <= B, (self.name, "limb bound")
+
+    def madd(self, acc, q, neg):
+        f, L = self.f, self.f.L
+        X, Y, T, Z, s = acc
+        e = -1 if neg else 0
+        flip = s ^ e
+        cneg = lambda v, m: [(l ^ m) - m for l in v]
+        X1, T1 = cneg(X, flip), cneg(T, flip)
+        qx, qy, qk = q
+        xy = qx + qy
+        assert xy < 1 << 256
+        n29, n30 = (1 << 29) + 4, 1 << 30
+        sx, sy, sk, sxy = (f.slice(v, f.SH) for v in (qx, qy, qk, xy))
+        self.limb_check(X1, n29, sx, n29); A = f.mul(X1, sx)
+        self.limb_check(Y, n29, sy, n29); B = f.mul(Y, sy)
+        self.limb_check(T1, n29, sk, n29); C = f.mul(T1, sk)
+        XY = [a + b for a, b in zip(X1, Y)]
+        self.limb_check(XY, n30, sxy, n29); E = f.mul(XY, sxy)
+        E = [e_ - a - b for e_, a, b in zip(E, A, B)]
+        F = [z - c for z, c in zip(Z, C)]; G = [z + c for z, c in zip(Z, C)]
+        if self.a_kind == 1:
+            H = f.carry([b + 5 * a for a, b in zip(A, B)])
+        elif self.a_kind == 2:
+            H = f.carry([b + a for a, b in zip(A, B)])
+        else:
+            H = [b - a for a, b in zip(A, B)]
+        self.limb_check(E, n30, F, n29); X3 = f.mul(E, F)
+        self.limb_check(G, n30, H, n29); Y3 = f.mul(G, H)
+        self.limb_check(E, n30, H, n29); T3 = f.mul(E, H)
+        self.limb_check(G, n30, F, n29); Z3 = f.mul(G, F)
+        for v, b in ((X3, 1.5), (Y3, 1.7), (T3, 2.4), (Z3, 1.3)):
+            assert abs(f.val(v)) < b * f.p, (self.name, "value bound", abs(f.val(v)) / f.p, b)
+        return (X3, Y3, T3, Z3, e)
+
+    def from_pre(self, q, neg):
+        f = self.f
+        x, y = f.slice(q[0], 0), f.slice(q[1], 0)
+        return (x, y, f.mul(x, f.slice(q[1], f.SH)), f.slice(f.R % f.p, 0), -1 if neg else 0)
+
+    def to_affine(self, acc):
+        f = self.f
+        X, Y, T, Z, s = acc
+        cneg = lambda v, m: [(l ^ m) - m for l in v]
+        x, y, t, z = f.to_packed(cneg(X, s)), f.to_packed(Y), f.to_packed(cneg(T, s)), f.to_packed(Z)
+        assert (x * y - t * z) % f.p == 0
+        zi = pow(z, -1, f.p)
+        return (x * zi % f.p, y * zi % f.p)
+
+
+def check_te(te, rng, chains=6, length=40):
+    f = te.f
+    (ox, oy, ot, oz), (E, FG, H) = te_bounds(_log2(f.p), te.a_kind, f.SH, f.W * f.L)
+    assert ox < 1.5 and oy < 1.7 and ot < 2.4 and oz < 1.3, (te.name, ox, oy, ot, oz)
+    assert max(E, FG, H) * f.p < 1 << (f.W * (f.L - 1) + 28)       # top limbs stay below 2^28
+    pts = [te.G]
+    for _ in range(12):
+        pts.append(te.add(pts[-1], te.G))
+    for c in range(chains):
+        neg0 = bool(rng.getrandbits(1))
+        P = rng.choice(pts)
+        acc = te.from_pre(te.pre(P), neg0)
+        ref = te.neg(P) if neg0 else P
+        if c == 0:
+            acc = (f.slice(0, 0), f.slice(f.R % f.p, 0), f.slice(0, 0), f.slice(f.R % f.p, 0), 0); ref = (0, 1)
+        for _ in range(length):
+            Q, neg = rng.choice(pts), bool(rng.getrandbits(1))
+            acc = te.madd(acc, te.pre(Q), neg)
+            ref = te.add(ref, te.neg(Q) if neg else Q)
+        assert te.to_affine(acc) == ref, te.name
+    print(f"  {te.name}: a kind {te.a_kind}; {chains} chains of {length} mixed additions == affine law; inductive bounds "
+          f"|X|,|Y|,|T|,|Z| < 1.5p, 1.7p, 2.4p, 1.3p (worst case out: {ox:.2f} {oy:.2f} {ot:.2f} {oz:.2f})")
+
+
+def _log2(v):
+    import math
+    return math.log2(v)
+
+
+# ---------------------------------------------------------------------------------------------- short Weierstrass, XYZZ
+
+class G1:
+    """y^2 = x^3 + b; accumulator (X, Y, ZZ, ZZZ) in the UNSATURATED Montgomery domain (values times 2^(W L)); see fpu_g1.h"""
+    BX, BY, BZZ, BZZZ = 4.6, 2.6, 1.5, 1.5                  # inductive value bounds in units of p (checked below)
+
+    def __init__(self, name, d, f):
+        self.name, self.f = name, f
+        self.b = d["B"] * pow(f.R, -1, f.p) % f.p
+
+    def on_curve(self, P):
+        return (P[1] * P[1] - P[0] ** 3 - self.b) % self.f.p == 0
+
+    def add(self, P, Q):
+        p = self.f.p
+        if P is None: return Q
+        if Q is None: return P
+        (x1, y1), (x2, y2) = P, Q
+        if x1 == x2:
+            if (y1 + y2) % p == 0: return None
+            l = 3 * x1 * x1 * pow(2 * y1, -1, p) % p
+        else:
+            l = (y2 - y1) * pow(x2 - x1, -1, p) % p
+        x3 = (l * l - x1 - x2) % p
+        return (x3, (l * (x1 - x3) - y1) % p)
+
+    def rand_point(self, rng):
+        p = self.f.p
+        while True:
+            x = rng.randrange(p); r = (x ** 3 + self.b) % p
+            if pow(r, (p - 1) // 2, p) == 1:
+                if p % 4 == 3:
+                    y = pow(r, (p + 1) // 4, p)
+                    if y * y % p == r: return (x, y)
+
+    def madd(self, acc, q, neg):
+        """acc + (neg ? -q : q), q = saturated Montgomery words (x R, y R); the generic path only (no exceptional cases)"""
+        f, L = self.f, self.f.L
+        X, Y, ZZ, ZZZ = acc
+        qx, qy = q
+        if neg: qy = (f.p - qy) % f.p
+        n28, n29 = (1 << f.W) + 4, 1 << (f.W + 1)
+        lim = lambda a, A, b, B: (max(abs(v) for v in a) <= A and max(abs(v) for v in b) <= B) or (_ for _ in ()).throw(AssertionError((self.name, "limb bound")))
+        sx, sy = f.slice(qx, f.SH), f.slice(qy, f.SH)
+        lim(ZZ, n28, sx, n28); U2 = f.mul(ZZ, sx)
+        lim(ZZZ, n28, sy, n28); S2 = f.mul(ZZZ, sy)
+        P = [a - b for a, b in zip(U2, X)]; R = [a - b for a, b in zip(S2, Y)]          # limbs (-2^W, 2^W)
+        lim(P, n28, P, n28); PP = f.mul(P, P, sqr=True)
+        PPP = f.mul(P, PP); Q = f.mul(X, PP)
+        ZZ3 = f.mul(ZZ, PP); ZZZ3 = f.mul(ZZZ, PPP); T = f.mul(Y, PPP)
+        RR = f.mul(R, R, sqr=True)
+        X3 = [r - a - 2 * b for r, a, b in zip(RR, PPP, Q)]                              # limbs (-3 2^W, 2^W)
+        QX = f.carry([a - b for a, b in zip(Q, X3)])                                     # (-2^W, 4 2^W) -> carry pass
+        lim(R, n28, QX, n28); Y3 = f.mul(R, QX)
+        Y3 = [a - b for a, b in zip(Y3, T)]
+        X3 = f.carry(X3); Y3 = f.carry(Y3)
+        for v, b in ((X3, self.BX), (Y3, self.BY), (ZZ3, self.BZZ), (ZZZ3, self.BZZZ)):
+            assert abs(f.val(v)) < b * f.p, (self.name, "value bound", abs(f.val(v)) / f.p, b)
+        return (X3, Y3, ZZ3, ZZZ3)
+
+    def from_affine(self, q, neg):
+        f = self.f
+        qx, qy = q
+        if neg: qy = (f.p - qy) % f.p
+        one = f.slice(f.Ru % f.p, 0)
+        return (f.slice(qx * (1 << f.SH) % f.p, 0), f.slice(qy * (1 << f.SH) % f.p, 0), one, one)   # model only: the kernel multiplies by a constant
+
+    def to_affine(self, acc):
+        f = self.f
+        X, Y, ZZ, ZZZ = (f.val(v) * pow(f.Ru, -1, f.p) % f.p for v in acc)
+        assert (ZZ ** 3 - ZZZ ** 2) % f.p == 0
+        return (X * pow(ZZ, -1, f.p) % f.p, Y * pow(ZZZ, -1, f.p) % f.p)
+
+
+def g1_bounds(f):
+    """interval arithmetic over g1u_madd in units of p"""
+    ratio = f.Ru / f.p
+    kb = 2.0 ** f.SH / ratio
+    x, y, zz, zzz = G1.BX, G1.BY, G1.BZZ, G1.BZZZ
+    U2, S2 = kb * zz + 1, kb * zzz + 1
+    P, R = U2 + x, S2 + y
+    PP = P * P / ratio + 1
+    PPP = P * PP / ratio + 1; Q = x * PP / ratio + 1
+    ZZ3 = zz * PP / ratio + 1; ZZZ3 = zzz * PPP / ratio + 1; T = y * PPP / ratio + 1
+    RR = R * R / ratio + 1
+    X3 = RR + PPP + 2 * Q
+    Y3 = R * (Q + X3) / ratio + 1 + T
+    return X3, Y3, ZZ3, ZZZ3
+
+
+def check_g1(g, rng, chains=3, length=25):
+    f = g.f
+    b = g1_bounds(f)
+    assert b[0] < g.BX and b[1] < g.BY and b[2] < g.BZZ and b[3] < g.BZZZ, (g.name, b)
+    pts = [g.rand_point(rng) for _ in range(6)]
+    for c in range(chains):
+        P, neg0 = rng.choice(pts), bool(rng.getrandbits(1))
+        acc = g.from_affine((P[0] * f.R % f.p, P[1] * f.R % f.p), neg0)
+        ref = (P[0], (-P[1]) % f.p) if neg0 else P
+        for _ in range(length):
+            Q, neg = rng.choice(pts), bool(rng.getrandbits(1))
+            Qs = (Q[0], (-Q[1]) % f.p) if neg else Q
+            if ref is None or Qs[0] == ref[0]:
+                continue                                    # exceptional cases take the saturated path in the kernel
+            acc = g.madd(acc, (Q[0] * f.R % f.p, Q[1] * f.R % f.p), neg)
+            ref = g.add(ref, Qs)
+        assert g.to_affine(acc) == ref, g.name
+    print(f"  {g.name}: {chains} chains of {length} XYZZ mixed additions == affine law; inductive bounds |X|,|Y|,|ZZ|,|ZZZ| < "
+          f"{g.BX}p, {g.BY}p, {g.BZZ}p, {g.BZZZ}p (worst case out: {b[0]:.2f} {b[1]:.2f} {b[2]:.2f} {b[3]:.2f})")
+
+
+def main():
+    C = parse()
+    rng = random.Random(5)
+    fields = {}
+    print("fu_mul / fu_sqr:")
+    for name, d in C.items():
+        if "P" in d and name.startswith("Fq") and not d.get("FULL"):
+            fields[name] = Field(name, d)
+            check_mul(fields[name], rng)
+    print("teu_madd:")
+    for name, d in C.items():
+        if name.startswith("Suite") and not d.get("SW_NATIVE") and d.get("Fq") in fields and "D" in d:
+            check_te(TE(name, d, fields[d["Fq"]]), rng)
+    print("g1u_madd:")
+    for name, d in C.items():
+        if name.startswith("G1") and d.get("Fq") in fields:
+            check_g1(G1(name, d, fields[d["Fq"]]), rng)
+    print("all checks passed")
+
+
+if __name__ == "__main__":
+    main()
