@@ -5,8 +5,10 @@
 // A policy provides: base_t (precomputed affine base as stored in HBM), acc_t (accumulator),
 // identity / madd(acc, base, negate) / add(acc, acc), raw load/store, and a lane shuffle.
 #pragma once
+#include <type_traits>
 #include "fpn.h"
 #include "te.h"
+#include "fpu_te.h"
 
 #ifndef AVRF_TE_ACC_WAVES
 #define AVRF_TE_ACC_WAVES 2
@@ -34,8 +36,37 @@
 
 namespace avrf {
 
+// what k_accumulate keeps in registers between the bucket boundaries of a lane's share: the policy's own accumulator, or -- the
+// twisted-Edwards suites with an asm-free path -- the unsaturated-limb form of fpu_te.h (teu_madd 18.3 G/s against te_madd
+// 12.7 G/s at two waves per SIMD, profiles/r5_ubench_fpu_gate.txt).  Bases are read and partial sums are written in the
+// policy's HBM formats either way.
+template <class CV> struct AccumSame {
+  using acc_t = typename CV::acc_t; using base_t = typename CV::base_t;
+  static AVRF_DI acc_t identity() { return CV::identity(); }
+  static AVRF_DI acc_t madd(const acc_t &a, const base_t &q, bool neg) { return CV::madd(a, q, neg); }
+  static AVRF_DI acc_t from_base(const base_t &q, bool neg) { return CV::from_base(q, neg); }
+  // a lane's partial sums in HBM (the array k_bucket_sum / k_heavy_sum read): words per slot, store, load as the policy's accumulator
+  static constexpr int PART_WORDS = CV::ACC_WORDS;
+  static AVRF_DI void store_part(uint32_t *p, const acc_t &a) { CV::store_acc(p, a); }
+  static AVRF_DI typename CV::acc_t load_part(const uint32_t *p) { return CV::load_acc(p); }
+};
+template <class S> struct AccumTeU {
+  using acc_t = te_acc_u<S>; using base_t = te_pre;
+  static AVRF_DI acc_t identity() { return teu_identity<S>(); }
+  static AVRF_DI acc_t madd(const acc_t &a, const base_t &q, bool neg) { return teu_madd<S>(a, q, neg); }
+  static AVRF_DI acc_t from_base(const base_t &q, bool neg) { return teu_from_pre<S>(q, neg); }
+  static constexpr int PART_WORDS = TEU_PART_WORDS;           // raw limbs + sign: fpu_te.h teu_store_part
+  static AVRF_DI void store_part(uint32_t *p, const acc_t &a) { teu_store_part<S>(p, a); }
+  static AVRF_DI te_ext load_part(const uint32_t *p) { return teu_load_part<S>(p); }
+};
+
 template <class S> struct TeCurve {
   using base_t = te_pre; using acc_t = te_ext; using suite = S;
+#ifndef AVRF_NO_UNSAT
+  using accum = typename std::conditional<!S::SW_NATIVE, AccumTeU<S>, AccumSame<TeCurve<S>>>::type;
+#else
+  using accum = AccumSame<TeCurve<S>>;
+#endif
   static constexpr int BASE_WORDS = 24, ACC_WORDS = 32;
   // (S::SW_NATIVE, secp256r1: the policy's types hold XYZZ coordinates, te.h; the twisted-Edwards-only reduction kernels
   // -- te_quad.h, window triples -- are switched off and the generic row / column + bit-sum reduction of the G1 MSMs runs)
@@ -91,6 +122,7 @@ template <class C> struct G1Curve {
   using el = fpn<N>;
   struct base_t { el x, y; };
   struct acc_t { el x, y, zz, zzz; };
+  using accum = AccumSame<G1Curve<C>>;
   static constexpr int BASE_WORDS = 2 * N, ACC_WORDS = 4 * N;
   static constexpr bool QUAD = false;
   static constexpr bool PREFETCH = (N <= 8);

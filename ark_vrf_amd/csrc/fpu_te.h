@@ -77,4 +77,42 @@ template <class S> AVRF_DI te_ext teu_to_ext(const te_acc_u<S> &p) {
   return r;
 }
 
+// A partial sum as a lane of k_accumulate leaves it at a bucket boundary: the 4 x 9 limbs and the sign, forty words, ten 16-byte
+// stores under the lane mask -- NOT the canonical te_ext.  The boundary falls at a different iteration in every lane, so
+// whatever runs there runs for the whole wave once per iteration with ANY boundary in it (64 % of the iterations at C2's
+// 40-entry shares of 64-entry buckets); the four conditional-subtraction chains of fu_to_packed (~450 instructions) belong to
+// the readers (k_bucket_sum, k_heavy_sum: one lane or one quad per partial, uniform control flow).
+constexpr int TEU_PART_WORDS = 40;
+template <class S> AVRF_DI void teu_store_part(uint32_t *p, const te_acc_u<S> &a) {
+  uint4 *d = reinterpret_cast<uint4 *>(p);
+  const int32_t *x = a.x.v, *y = a.y.v, *t = a.t.v, *z = a.z.v;
+  d[0] = make_uint4(x[0], x[1], x[2], x[3]); d[1] = make_uint4(x[4], x[5], x[6], x[7]);
+  d[2] = make_uint4(x[8], y[0], y[1], y[2]); d[3] = make_uint4(y[3], y[4], y[5], y[6]);
+  d[4] = make_uint4(y[7], y[8], t[0], t[1]); d[5] = make_uint4(t[2], t[3], t[4], t[5]);
+  d[6] = make_uint4(t[6], t[7], t[8], z[0]); d[7] = make_uint4(z[1], z[2], z[3], z[4]);
+  d[8] = make_uint4(z[5], z[6], z[7], z[8]); d[9] = make_uint4(a.neg, 0u, 0u, 0u);
+}
+// coordinate j (0 x, 1 y, 2 t, 3 z) of a stored partial as canonical saturated words
+template <class S> AVRF_DI fp teu_load_part_coord(const uint32_t *p, int j) {
+  using Fq = typename S::Fq;
+  constexpr int L = UL<Fq>::L;
+  fu<L> v;
+#pragma unroll
+  for (int i = 0; i < L; i++) v.v[i] = (int32_t)p[j * L + i];
+  const int32_t s = (j & 1) ? 0 : (int32_t)p[4 * L];
+  fp r; fu_to_packed<Fq>(r.v, fu_cneg<L>(v, s));
+  return r;
+}
+template <class S> AVRF_DI te_ext teu_load_part(const uint32_t *p) {
+  const uint4 *d = reinterpret_cast<const uint4 *>(p);
+  uint32_t w[40];
+#pragma unroll
+  for (int i = 0; i < 10; i++) { const uint4 q = d[i]; w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w; }
+  te_acc_u<S> a;
+#pragma unroll
+  for (int i = 0; i < 9; i++) { a.x.v[i] = (int32_t)w[i]; a.y.v[i] = (int32_t)w[9 + i]; a.t.v[i] = (int32_t)w[18 + i]; a.z.v[i] = (int32_t)w[27 + i]; }
+  a.neg = w[36];
+  return teu_to_ext<S>(a);
+}
+
 }  // namespace avrf

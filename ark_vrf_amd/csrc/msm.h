@@ -49,7 +49,7 @@ struct MsmWorkspace {
   int wsum_lg = 4;               // scale 2^lg of the third point of a window triple (TE window sums)
   // an enqueued launch chain whose results have not been collected yet (msm_te_enqueue / msm_te_finish)
   MsmPlan pending_plan = {0, 0, 0, 0}; int pending_ret = 0; size_t pending_n = 0; bool pending_armed = false;
-  void ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch, size_t lanes_max);
+  void ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch, size_t lanes_max, size_t part_bytes = 0);   // part_bytes: one slot of `part` (0: acc_bytes)
   void release();
 };
 

@@ -211,6 +211,10 @@ k_plan(const uint32_t *__restrict__ win_tot, uint32_t vwin, uint32_t lanes_targe
   __syncthreads();
   for (uint32_t off = 512; off >= 1; off >>= 1) { if (t < off) red[t] += red[t + off]; __syncthreads(); }
   const uint64_t total = red[0];
+  // every window rounds its last lane up, so the launch uses up to total / per + vwin lanes: shares are sized for
+  // lanes_target - vwin, or those few extra lanes land in a workgroup that is NOT resident in the first round -- it starts when
+  // the first workgroup retires and the kernel ends a whole share later (round 5: waves lived 280 us of a 355 us launch)
+  if (lanes_target > 8 * vwin) lanes_target -= vwin;
   uint64_t per64 = (total + lanes_target - 1) / lanes_target;
   if (per64 < per_min) per64 = per_min;
   const uint32_t per = (uint32_t)per64;
@@ -290,7 +294,8 @@ __global__ void __launch_bounds__(256, CV::MIN_WAVES)
 k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ sorted,
              const uint32_t *__restrict__ offs, const uint32_t *__restrict__ win_tot, const uint32_t *__restrict__ lane_base,
              const uint32_t *__restrict__ plan, uint32_t vwin, uint32_t nb, uint32_t n, uint32_t *__restrict__ part) {
-  using acc_t = typename CV::acc_t; using base_t = typename CV::base_t;
+  using AC = typename CV::accum;                              // the register form of the accumulator (curves.h)
+  using acc_t = typename AC::acc_t; using base_t = typename CV::base_t;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t per = plan[0];
   if (t >= plan[1]) return;
@@ -308,37 +313,44 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
   const size_t slot0 = (size_t)t + (size_t)v * nb;
   acc_t acc;
   if (CV::PREFETCH) {
-    // software-pipelined gather: the next base is in flight while the current addition runs
+    // software-pipelined gather, two stages: the index of entry i + 2 and the base of entry i + 1 are in flight while the
+    // addition of entry i runs (with the index only one ahead every iteration waited out the index load before it could even
+    // issue the gather that depends on it: wait_any 21 % of the wave cycles, profiles/r5a_pmc_thin.json)
     uint32_t idx = sorted[e0];
+    uint32_t idx1 = e0 + 1 < e1 ? sorted[e0 + 1] : 0u;
     base_t q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS);
     {                                                          // first entry of every lane: no addition, just the base
       const uint32_t cidx = idx; const base_t cur = q;
-      if (e0 + 1 < e1) { idx = sorted[e0 + 1]; q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS); }
-      acc = CV::from_base(cur, (cidx & 0x80000000u) != 0);
+      idx = idx1;
+      if (e0 + 1 < e1) q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS);
+      if (e0 + 2 < e1) idx1 = sorted[e0 + 2];
+      acc = AC::from_base(cur, (cidx & 0x80000000u) != 0);
     }
     for (uint32_t i = e0 + 1; i < e1; i++) {
       const uint32_t cidx = idx; const base_t cur = q;
-      if (i + 1 < e1) { idx = sorted[i + 1]; q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS); }
+      idx = idx1;
+      if (i + 1 < e1) q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS);
+      if (i + 2 < e1) idx1 = sorted[i + 2];
       if (i >= nxt) {                                          // bucket boundary inside the lane's range
-        CV::store_acc(part + (slot0 + b) * CV::ACC_WORDS, acc);
-        acc = CV::identity();
+        AC::store_part(part + (slot0 + b) * AC::PART_WORDS, acc);
+        acc = AC::identity();
         do { b++; nxt = (b + 1 < nb) ? ow[b + 1] : 0xffffffffu; } while (i >= nxt);
       }
-      acc = CV::madd(acc, cur, (cidx & 0x80000000u) != 0);
+      acc = AC::madd(acc, cur, (cidx & 0x80000000u) != 0);
     }
   } else {                                                     // 381-bit points: registers are the scarcer resource
-    acc = CV::identity();
+    acc = AC::identity();
     for (uint32_t i = e0; i < e1; i++) {
       if (i >= nxt) {
-        CV::store_acc(part + (slot0 + b) * CV::ACC_WORDS, acc);
-        acc = CV::identity();
+        AC::store_part(part + (slot0 + b) * AC::PART_WORDS, acc);
+        acc = AC::identity();
         do { b++; nxt = (b + 1 < nb) ? ow[b + 1] : 0xffffffffu; } while (i >= nxt);
       }
       const uint32_t idx = sorted[i];
-      acc = CV::madd(acc, CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS), (idx & 0x80000000u) != 0);
+      acc = AC::madd(acc, CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS), (idx & 0x80000000u) != 0);
     }
   }
-  CV::store_acc(part + (slot0 + b) * CV::ACC_WORDS, acc);
+  AC::store_part(part + (slot0 + b) * AC::PART_WORDS, acc);
 }
 
 template <class CV> AVRF_DI typename CV::acc_t wave_sum(typename CV::acc_t acc);
@@ -362,9 +374,10 @@ k_bucket_sum(const uint32_t *__restrict__ offs, const uint32_t *__restrict__ cnt
   const uint32_t lf = rel / per, ll = (rel + cnt - 1) / per, np = ll - lf + 1;
   if (np > HEAVY_PARTIALS) { heavy[atomicAdd(&plan[2], 1u)] = slot; return; }
   const size_t p0 = (size_t)lane_base[v] + lf + slot;
-  acc_t acc = CV::load_acc(part + p0 * CV::ACC_WORDS);
+  using AC = typename CV::accum;
+  acc_t acc = AC::load_part(part + p0 * AC::PART_WORDS);
 #pragma unroll 1
-  for (uint32_t k = 1; k < np; k++) acc = cv_add<CV>(acc, CV::load_acc(part + (p0 + k) * CV::ACC_WORDS));
+  for (uint32_t k = 1; k < np; k++) acc = cv_add<CV>(acc, AC::load_part(part + (p0 + k) * AC::PART_WORDS));
   CV::store_acc(buckets + (size_t)slot * CV::ACC_WORDS, acc);
 }
 
@@ -384,7 +397,7 @@ k_heavy_sum(const uint32_t *__restrict__ offs, const uint32_t *__restrict__ cnts
     if constexpr (CV::QUAD) { q_heavy_sum<typename CV::suite>(part, p0, np, buckets + (size_t)slot * CV::ACC_WORDS, lds); continue; }
     acc_t a = CV::identity();
 #pragma unroll 1
-    for (uint32_t k = t; k < np; k += 256) a = cv_add<CV>(a, CV::load_acc(part + (p0 + k) * CV::ACC_WORDS));
+    for (uint32_t k = t; k < np; k += 256) a = cv_add<CV>(a, CV::accum::load_part(part + (p0 + k) * CV::accum::PART_WORDS));
     a = wave_sum<CV>(a);                                                        // valid in lane 0
     if (lane == 0) CV::store_acc(lds + wv * CV::ACC_WORDS, a);
     __syncthreads();
@@ -656,7 +669,7 @@ template <class T> static void grow(T *&p, size_t &cap, size_t need, size_t elem
   cap = need;
 }
 
-void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch, size_t lanes_max) {
+void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t batch, size_t lanes_max, size_t part_bytes) {
   const size_t vwin = (size_t)p.nwin * batch;           // virtual windows
   const size_t nbk = vwin * p.nb, nbits = vwin * p.c;
   const size_t need_n = vwin * n;
@@ -693,7 +706,7 @@ void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t b
     HIP_CHECK(hipMalloc(&rc, nbk * acc_bytes));               // >= nwin * (NR + NC)
     cap_buckets = nbk * acc_bytes;
   }
-  grow(part, cap_part, (lanes_max + nbk + 64) * acc_bytes, 1);
+  grow(part, cap_part, (lanes_max + nbk + 64) * (part_bytes ? part_bytes : acc_bytes), 1);
   if (nbits * acc_bytes > cap_bits) {
     if (bits) HIP_CHECK(hipFree(bits));
     if (bits_host) HIP_CHECK(hipHostFree(bits_host));
@@ -824,7 +837,7 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
   const uint32_t vwin = (uint32_t)(p.nwin * batch);
   const size_t lanes_max = lanes_target + vwin + 256;                   // sum_v ceil(tot_v / per) <= total / per + vwin
   if ((size_t)vwin * n >= 0xffff0000ull) throw HipFailure{hipErrorInvalidValue, __FILE__, __LINE__};   // 32-bit entry offsets
-  ws.ensure(n, p, acc_bytes, batch, lanes_max);
+  ws.ensure(n, p, acc_bytes, batch, lanes_max, (size_t)CV::accum::PART_WORDS * 4);
   const uint32_t nbk = vwin * p.nb;
   const uint32_t tile_len = tile_len_for(n, vwin), ntiles = (uint32_t)((n + tile_len - 1) / tile_len);
   const size_t lds_bytes = (size_t)p.nb * 4;

@@ -13,6 +13,7 @@
 // point addition costs ~1/3 of the instructions of the one-lane form.
 #pragma once
 #include "te.h"
+#include "curves.h"
 
 namespace avrf {
 
@@ -213,7 +214,12 @@ template <class S> AVRF_DI void q_heavy_sum(const uint32_t *__restrict__ part, s
   const uint32_t t = threadIdx.x, lane = t & 63, q = lane >> 2, j = lane & 3, gq = t >> 2, wv = t >> 6;
   fp a = q_identity<S>(j);
 #pragma unroll 1
-  for (uint32_t k = gq; k < np; k += 64) a = q_add<S>(a, load_fp(part + (p0 + k) * 32 + j * 8), j);
+  for (uint32_t k = gq; k < np; k += 64) {
+    fp c;                                                              // coordinate j of partial k (curves.h: the k_accumulate policy's format)
+    if constexpr (TeCurve<S>::accum::PART_WORDS == 32) c = load_fp(part + (p0 + k) * 32 + j * 8);
+    else c = teu_load_part_coord<S>(part + (p0 + k) * TEU_PART_WORDS, (int)j);
+    a = q_add<S>(a, c, j);
+  }
   a = q_wave_sum<S>(a, q, j);
   if (q == 0) store_fp(lds + wv * 32 + j * 8, a);
   __syncthreads();
