@@ -9,6 +9,7 @@
 #include "fpn.h"
 #include "te.h"
 #include "fpu_te.h"
+#include "fpu_g1.h"
 
 #ifndef AVRF_TE_ACC_WAVES
 #define AVRF_TE_ACC_WAVES 2
@@ -58,6 +59,27 @@ template <class S> struct AccumTeU {
   static constexpr int PART_WORDS = TEU_PART_WORDS;           // raw limbs + sign: fpu_te.h teu_store_part
   static AVRF_DI void store_part(uint32_t *p, const acc_t &a) { teu_store_part<S>(p, a); }
   static AVRF_DI te_ext load_part(const uint32_t *p) { return teu_load_part<S>(p); }
+};
+
+template <class C> struct G1Curve;
+// XYZZ on unsaturated limbs (fpu_g1.h); the doubling of the P = Q case runs in the saturated form and is converted
+template <class C> struct AccumG1U {
+  using CV = G1Curve<C>; using Fq = typename C::Fq;
+  using acc_t = g1_acc_u<C>; using base_t = typename CV::base_t;
+  static AVRF_DI acc_t identity() { return g1u_identity<C>(); }
+  static AVRF_DI acc_t madd(const acc_t &a, const base_t &q, bool neg) {
+    return g1u_madd<C>(a, q.x.v, q.y.v, neg, [&]() {
+      base_t t = q; if (neg) t.y = fn_neg<Fq>(t.y);
+      const typename CV::acc_t r = CV::dbl_affine(t);
+      return g1u_from_xyzz<C>(r.x.v, r.y.v, r.zz.v, r.zzz.v);
+    });
+  }
+  static AVRF_DI acc_t from_base(const base_t &q, bool neg) { return g1u_from_affine<C>(q.x.v, q.y.v, neg); }
+  static constexpr int PART_WORDS = G1UPart<C>::WORDS;
+  static AVRF_DI void store_part(uint32_t *p, const acc_t &a) { g1u_store_part<C>(p, a); }
+  static AVRF_DI typename CV::acc_t load_part(const uint32_t *p) {
+    typename CV::acc_t r; g1u_load_part<C>(p, r.x.v, r.y.v, r.zz.v, r.zzz.v); return r;
+  }
 };
 
 template <class S> struct TeCurve {
@@ -122,11 +144,19 @@ template <class C> struct G1Curve {
   using el = fpn<N>;
   struct base_t { el x, y; };
   struct acc_t { el x, y, zz, zzz; };
+#ifndef AVRF_NO_UNSAT_G1
+  using accum = AccumG1U<C>;
+#else
   using accum = AccumSame<G1Curve<C>>;
+#endif
   static constexpr int BASE_WORDS = 2 * N, ACC_WORDS = 4 * N;
   static constexpr bool QUAD = false;
   static constexpr bool PREFETCH = (N <= 8);
+#ifndef AVRF_NO_UNSAT_G1
+  static constexpr int MIN_WAVES = AVRF_G1_ACC_WAVES;              // k_accumulate on unsaturated limbs: 256 registers (14 x 28), 166 (9 x 29; at three waves it spilled 57)
+#else
   static constexpr int MIN_WAVES = N > 8 ? AVRF_G1_ACC_WAVES : 3;   // k_accumulate holds one accumulator + one base
+#endif
   static constexpr int MAX_WAVES = 0;
   static constexpr int RED_WAVES = N > 8 ? AVRF_G1_RED_WAVES : 2;   // the general addition (two accumulators live) needs the 256-register budget
   static constexpr bool INLINE_REDUCE_OPS = true;     // k_wsum*: additions inlined (the asm multiplier keeps the code small)

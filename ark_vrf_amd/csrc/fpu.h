@@ -48,8 +48,21 @@ template <class F> struct UL {
     }
     return r;
   }
+  // limbs of value(c) * 2^k mod p (c < p): k modular doublings
+  static constexpr ulimbs<L> shl_mod(const uint32_t (&c)[N], int k) {
+    uint32_t w[N] = {};
+    for (int j = 0; j < N; j++) w[j] = c[j];
+    for (int s = 0; s < k; s++) {
+      uint32_t cy = 0;
+      for (int j = 0; j < N; j++) { const uint32_t t = (w[j] << 1) | cy; cy = w[j] >> 31; w[j] = t; }   // < 2p < 2^(32 N): the top bit of p is clear
+      uint32_t d[N] = {}; uint64_t br = 0;
+      for (int j = 0; j < N; j++) { const uint64_t t = (uint64_t)w[j] - F::P[j] - br; d[j] = (uint32_t)t; br = (t >> 32) & 1; }
+      if (!br) for (int j = 0; j < N; j++) w[j] = d[j];
+    }
+    return slice_const(w, 1);
+  }
   static constexpr ulimbs<L> P1 = slice_const(F::P, 1);           // p
-  static constexpr ulimbs<L> P3 = slice_const(F::P, 3);           // 3 p: makes a lazily reduced value positive (fu_to_packed)
+  template <int KB> static constexpr ulimbs<L> PK = slice_const(F::P, 1u << KB);   // 2^KB p: makes a lazily reduced value positive (fu_to_packed)
   static constexpr ulimbs<L> ONE = slice_const(F::ONE, 1);        // R mod p: the saturated form's Montgomery one
 };
 
@@ -165,16 +178,16 @@ template <class F> AVRF_DI fuF<F> fu_sqr(const fuF<F> &a) {
   return r;
 }
 
-// the canonical value (< p) of a lazily reduced element with |value| < 3 p, as N saturated words: add 3 p, one exact carry
-// pass, repack, subtract 4p / 2p / p where it fits.  Off the hot path: once per partial sum a lane writes.
-template <class F> AVRF_DI void fu_to_packed(uint32_t (&w)[UL<F>::N], const fuF<F> &a) {
+// the canonical value (< p) of a lazily reduced element with |value| < 2^KB p, as N saturated words: add 2^KB p, one exact
+// carry pass, repack, subtract 2^KB p .. 2p, p where it fits.  Off the hot path: once per partial sum, in its reader.
+template <class F, int KB = 2> AVRF_DI void fu_to_packed(uint32_t (&w)[UL<F>::N], const fuF<F> &a) {
   using U = UL<F>;
   constexpr int L = U::L, W = U::W, N = U::N;
   uint32_t u[L];
   int32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < L - 1; i++) { const int32_t t = a.v[i] + (int32_t)U::P3.v[i] + c; u[i] = (uint32_t)t & U::MASK; c = t >> W; }
-  u[L - 1] = (uint32_t)(a.v[L - 1] + (int32_t)U::P3.v[L - 1] + c);          // >= 0: the value is in (0, 6p)
+  for (int i = 0; i < L - 1; i++) { const int32_t t = a.v[i] + (int32_t)U::template PK<KB>.v[i] + c; u[i] = (uint32_t)t & U::MASK; c = t >> W; }
+  u[L - 1] = (uint32_t)(a.v[L - 1] + (int32_t)U::template PK<KB>.v[L - 1] + c);   // >= 0: the value is in (0, 2^(KB+1) p)
   uint32_t x[N + 1];
 #pragma unroll
   for (int j = 0; j <= N; j++) {                                             // word j = bits [32 j, 32 j + 32)
@@ -188,7 +201,7 @@ template <class F> AVRF_DI void fu_to_packed(uint32_t (&w)[UL<F>::N], const fuF<
     x[j] = v;
   }
 #pragma unroll
-  for (int K = 4; K >= 1; K >>= 1) {
+  for (int K = 1 << KB; K >= 1; K >>= 1) {
     uint32_t kp[N + 1]; uint64_t cy = 0;
 #pragma unroll
     for (int j = 0; j < N; j++) { cy += (uint64_t)F::P[j] * (uint32_t)K; kp[j] = (uint32_t)cy; cy >>= 32; }

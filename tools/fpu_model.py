@@ -102,23 +102,25 @@ class Field:
         assert self.val(r) == self.val(a)
         return r
 
-    def to_packed(self, a):
+    def to_packed(self, a, KB=2):
         v = self.val(a)
-        assert abs(v) < 3 * self.p, "fu_to_packed wants |value| < 3p"
+        assert abs(v) < (1 << KB) * self.p, "fu_to_packed<KB> wants |value| < 2^KB p"
         L, W = self.L, self.W
-        p3 = self.slice_pos(3 * self.p)
+        pk = self.slice_pos((1 << KB) * self.p)
         u, c = [0] * L, 0
         for i in range(L - 1):
-            t = a[i] + p3[i] + c
+            t = a[i] + pk[i] + c
             assert -(1 << 31) <= t < (1 << 31)
             u[i] = t & self.MASK; c = t >> W
-        u[L - 1] = a[L - 1] + p3[L - 1] + c
+        u[L - 1] = a[L - 1] + pk[L - 1] + c
         assert 0 <= u[L - 1] < 1 << 32
         x = self.val(u)
-        assert x == v + 3 * self.p and x < 1 << (32 * (self.N + 1))
-        for K in (4, 2, 1):
+        assert x == v + (1 << KB) * self.p and x < 1 << (32 * (self.N + 1))
+        K = 1 << KB
+        while K:
             if x >= K * self.p:
                 x -= K * self.p
+            K >>= 1
         assert x == v % self.p
         return x
 
@@ -270,15 +272,20 @@ def _log2(v):
 # ---------------------------------------------------------------------------------------------- short Weierstrass, XYZZ
 
 class G1:
-    """y^2 = x^3 + b; accumulator (X, Y, ZZ, ZZZ) in the UNSATURATED Montgomery domain (values times 2^(W L)); see fpu_g1.h"""
-    BX, BY, BZZ, BZZZ = 4.6, 2.6, 1.5, 1.5                  # inductive value bounds in units of p (checked below)
+    """y^2 = x^3 + b, XYZZ.  fpu_g1.h: the accumulator holds (2^a R X, 2^b R Y, 2^g R ZZ, 2^d R ZZZ) (R = the saturated form's
+    Montgomery radix) with 3a - 2b = SH, g = 2m, d = 3m; a base coordinate is sliced as x R 2^sx / y R 2^sy, sx = a + SH - g,
+    sy = b + SH - d: every product then lands on the same weighted-projective class (see the header for the algebra)."""
+    INV = (4.6, 2.6, 1.5, 1.5)                               # inductive value bounds |X|, |Y|, |ZZ|, |ZZZ| in units of p
 
     def __init__(self, name, d, f):
         self.name, self.f = name, f
         self.b = d["B"] * pow(f.R, -1, f.p) % f.p
-
-    def on_curve(self, P):
-        return (P[1] * P[1] - P[0] ** 3 - self.b) % self.f.p == 0
+        SH = f.SH
+        self.a, self.bb = next((a, (3 * a - SH) // 2) for a in range(0, 9) if 3 * a >= SH and (3 * a - SH) % 2 == 0)
+        self.m = max((self.a + 1) // 2, (self.bb + 2) // 3)
+        self.g, self.d = 2 * self.m, 3 * self.m
+        self.sx, self.sy = self.a + SH - self.g, self.bb + SH - self.d
+        assert 0 <= self.sx <= SH and 0 <= self.sy <= SH, (name, self.sx, self.sy)
 
     def add(self, P, Q):
         p = self.f.p
@@ -295,58 +302,87 @@ class G1:
 
     def rand_point(self, rng):
         p = self.f.p
+        assert p % 4 == 3
         while True:
             x = rng.randrange(p); r = (x ** 3 + self.b) % p
-            if pow(r, (p - 1) // 2, p) == 1:
-                if p % 4 == 3:
-                    y = pow(r, (p + 1) // 4, p)
-                    if y * y % p == r: return (x, y)
+            y = pow(r, (p + 1) // 4, p)
+            if y * y % p == r: return (x, y)
 
-    def madd(self, acc, q, neg):
-        """acc + (neg ? -q : q), q = saturated Montgomery words (x R, y R); the generic path only (no exceptional cases)"""
+    def lim(self, a, A, b, B):
+        assert max(abs(v) for v in a) <= A and max(abs(v) for v in b) <= B, (self.name, "limb bound")
+
+    def zero_mod_p(self, v, operand_value):
+        """the kernel's test on a product's output: limbs all zero, or equal to p's -- valid because |operand|^2 / R' < p"""
+        f = self.f
+        assert operand_value * operand_value < f.Ru * f.p * 9 // 10, (self.name, "zero test out of range")
+        is0 = all(l == 0 for l in v) or all(l == pl for l, pl in zip(v, f.pl))
+        assert is0 == (f.val(v) % f.p == 0)
+        return is0
+
+    def madd(self, acc, q, neg, track=None):
+        """acc + (neg ? -q : q), q = saturated Montgomery words (x R, y R); returns None for the exceptional cases (the caller
+        of the model skips them; the kernel takes the saturated path)"""
         f, L = self.f, self.f.L
         X, Y, ZZ, ZZZ = acc
         qx, qy = q
-        if neg: qy = (f.p - qy) % f.p
-        n28, n29 = (1 << f.W) + 4, 1 << (f.W + 1)
-        lim = lambda a, A, b, B: (max(abs(v) for v in a) <= A and max(abs(v) for v in b) <= B) or (_ for _ in ()).throw(AssertionError((self.name, "limb bound")))
-        sx, sy = f.slice(qx, f.SH), f.slice(qy, f.SH)
-        lim(ZZ, n28, sx, n28); U2 = f.mul(ZZ, sx)
-        lim(ZZZ, n28, sy, n28); S2 = f.mul(ZZZ, sy)
-        P = [a - b for a, b in zip(U2, X)]; R = [a - b for a, b in zip(S2, Y)]          # limbs (-2^W, 2^W)
-        lim(P, n28, P, n28); PP = f.mul(P, P, sqr=True)
-        PPP = f.mul(P, PP); Q = f.mul(X, PP)
-        ZZ3 = f.mul(ZZ, PP); ZZZ3 = f.mul(ZZZ, PPP); T = f.mul(Y, PPP)
+        nrm, dbl = (1 << f.W) + 4, (1 << (f.W + 1)) + 8
+        sx, sy = f.slice(qx, self.sx), f.slice(qy, self.sy)
+        if neg: sy = [-v for v in sy]
+        self.lim(ZZ, nrm, sx, nrm); U2 = f.mul(ZZ, sx)
+        self.lim(ZZZ, nrm, sy, nrm); S2 = f.mul(ZZZ, sy)
+        P = [u - x for u, x in zip(U2, X)]; R = [s - y for s, y in zip(S2, Y)]
+        self.lim(P, dbl, R, dbl)
+        PP = f.mul(P, P, sqr=True)
+        if self.zero_mod_p(PP, abs(f.val(P))):
+            return None
+        self.lim(P, dbl, PP, nrm); PPP = f.mul(P, PP)
+        self.lim(X, nrm, PP, nrm); Q = f.mul(X, PP)
+        ZZ3 = f.mul(ZZ, PP); ZZZ3 = f.mul(ZZZ, PPP)
+        self.lim(Y, nrm, PPP, nrm); T = f.mul(Y, PPP)
         RR = f.mul(R, R, sqr=True)
-        X3 = [r - a - 2 * b for r, a, b in zip(RR, PPP, Q)]                              # limbs (-3 2^W, 2^W)
-        QX = f.carry([a - b for a, b in zip(Q, X3)])                                     # (-2^W, 4 2^W) -> carry pass
-        lim(R, n28, QX, n28); Y3 = f.mul(R, QX)
+        self.zero_mod_p(RR, abs(f.val(R)))
+        X3 = [r - a - 2 * b for r, a, b in zip(RR, PPP, Q)]
+        QX = f.carry([a - b for a, b in zip(Q, X3)])
+        self.lim(R, dbl, QX, nrm); Y3 = f.mul(R, QX)
         Y3 = [a - b for a, b in zip(Y3, T)]
-        X3 = f.carry(X3); Y3 = f.carry(Y3)
-        for v, b in ((X3, self.BX), (Y3, self.BY), (ZZ3, self.BZZ), (ZZZ3, self.BZZZ)):
-            assert abs(f.val(v)) < b * f.p, (self.name, "value bound", abs(f.val(v)) / f.p, b)
+        X3 = f.carry(X3)
+        self.lim(X3, nrm, Y3, nrm)
+        if track is not None:
+            track.append(tuple(abs(f.val(v)) / f.p for v in (X3, Y3, ZZ3, ZZZ3)))
         return (X3, Y3, ZZ3, ZZZ3)
 
     def from_affine(self, q, neg):
         f = self.f
-        qx, qy = q
-        if neg: qy = (f.p - qy) % f.p
-        one = f.slice(f.Ru % f.p, 0)
-        return (f.slice(qx * (1 << f.SH) % f.p, 0), f.slice(qy * (1 << f.SH) % f.p, 0), one, one)   # model only: the kernel multiplies by a constant
+        y = f.slice(q[1], self.bb)
+        return (f.slice(q[0], self.a), [-v for v in y] if neg else y, f.slice((f.R << self.g) % f.p, 0), f.slice((f.R << self.d) % f.p, 0))
+
+    def from_xyzz(self, X, Y, ZZ, ZZZ):
+        """a canonical saturated XYZZ point (the doubling branch computes one) in the accumulator's scaling: constant multiplications"""
+        f = self.f
+        cm = lambda v, k: f.mul(f.slice(v, 0), f.slice((f.Ru << k) % f.p, 0))
+        return (cm(X, self.a), cm(Y, self.bb), cm(ZZ, self.g), cm(ZZZ, self.d))
+
+    def to_saturated(self, acc):
+        """what the readers of a partial sum do: the canonical saturated XYZZ point (mu = 2^m): X 2^(2m - a), Y 2^(3m - b) by constant multiplications"""
+        f = self.f
+        X, Y, ZZ, ZZZ = acc
+        cm = lambda v, k: f.mul(v, f.slice((f.Ru << k) % f.p, 0)) if k else v
+        out = [f.to_packed(cm(X, 2 * self.m - self.a), 4 if 2 * self.m == self.a else 2), f.to_packed(cm(Y, 3 * self.m - self.bb)), f.to_packed(ZZ), f.to_packed(ZZZ)]
+        Rinv = pow(f.R, -1, f.p)
+        return [v * Rinv % f.p for v in out]
 
     def to_affine(self, acc):
         f = self.f
-        X, Y, ZZ, ZZZ = (f.val(v) * pow(f.Ru, -1, f.p) % f.p for v in acc)
+        X, Y, ZZ, ZZZ = self.to_saturated(acc)
         assert (ZZ ** 3 - ZZZ ** 2) % f.p == 0
         return (X * pow(ZZ, -1, f.p) % f.p, Y * pow(ZZZ, -1, f.p) % f.p)
 
 
-def g1_bounds(f):
-    """interval arithmetic over g1u_madd in units of p"""
+def g1_bounds(g, x, y, zz, zzz):
+    """interval arithmetic over g1u_madd in units of p: output bounds, and the operands of the two zero tests"""
+    f = g.f
     ratio = f.Ru / f.p
-    kb = 2.0 ** f.SH / ratio
-    x, y, zz, zzz = G1.BX, G1.BY, G1.BZZ, G1.BZZZ
-    U2, S2 = kb * zz + 1, kb * zzz + 1
+    U2, S2 = zz * 2.0 ** g.sx / ratio + 1, zzz * 2.0 ** g.sy / ratio + 1
     P, R = U2 + x, S2 + y
     PP = P * P / ratio + 1
     PPP = P * PP / ratio + 1; Q = x * PP / ratio + 1
@@ -354,28 +390,46 @@ def g1_bounds(f):
     RR = R * R / ratio + 1
     X3 = RR + PPP + 2 * Q
     Y3 = R * (Q + X3) / ratio + 1 + T
+    assert P * P < 0.9 * ratio and R * R < 0.9 * ratio, (g.name, "zero test", P, R, ratio)
+    assert max(P, R, X3, Y3) * f.p < 1 << (f.W * (f.L - 1) + f.W - 1)
     return X3, Y3, ZZ3, ZZZ3
 
 
-def check_g1(g, rng, chains=3, length=25):
+def check_g1(g, rng, chains=4, length=25):
     f = g.f
-    b = g1_bounds(f)
-    assert b[0] < g.BX and b[1] < g.BY and b[2] < g.BZZ and b[3] < g.BZZZ, (g.name, b)
+    b = g1_bounds(g, *g.INV)
+    assert all(o < i for o, i in zip(b, g.INV)), (g.name, b)
+    # entry state outside the invariant: a sliced affine point (a converted doubling result is reduced); it must fall into it
+    for st in ((2.0 ** g.a, 2.0 ** g.bb, 1.0, 1.0),):
+        steps = 0
+        while not all(o < i for o, i in zip(st, g.INV)):
+            st = tuple(max(o, 0.0) for o in g1_bounds(g, *[max(s, i) if k < 0 else s for k, (s, i) in enumerate(zip(st, g.INV))]))
+            steps += 1
+            assert steps < 6, (g.name, "entry state does not contract", st)
     pts = [g.rand_point(rng) for _ in range(6)]
+    sat = lambda P: (P[0] * f.R % f.p, P[1] * f.R % f.p)
+    worst = [0.0] * 4
     for c in range(chains):
         P, neg0 = rng.choice(pts), bool(rng.getrandbits(1))
-        acc = g.from_affine((P[0] * f.R % f.p, P[1] * f.R % f.p), neg0)
+        acc = g.from_affine(sat(P), neg0)
         ref = (P[0], (-P[1]) % f.p) if neg0 else P
+        if c == 1:                                           # start from a doubled point handed over in saturated XYZZ form (X, Y, 1, 1)
+            ref = g.add(P, P); acc = g.from_xyzz(ref[0] * f.R % f.p, ref[1] * f.R % f.p, f.R % f.p, f.R % f.p)
         for _ in range(length):
             Q, neg = rng.choice(pts), bool(rng.getrandbits(1))
             Qs = (Q[0], (-Q[1]) % f.p) if neg else Q
-            if ref is None or Qs[0] == ref[0]:
-                continue                                    # exceptional cases take the saturated path in the kernel
-            acc = g.madd(acc, (Q[0] * f.R % f.p, Q[1] * f.R % f.p), neg)
-            ref = g.add(ref, Qs)
+            tr = []
+            nxt = g.madd(acc, sat(Q), neg, tr)
+            if nxt is None:
+                assert ref is not None and Qs[0] == ref[0]  # exactly the exceptional inputs
+                continue
+            assert ref is not None and Qs[0] != ref[0]
+            acc, ref = nxt, g.add(ref, Qs)
+            worst = [max(w, t) for w, t in zip(worst, tr[0])]
         assert g.to_affine(acc) == ref, g.name
-    print(f"  {g.name}: {chains} chains of {length} XYZZ mixed additions == affine law; inductive bounds |X|,|Y|,|ZZ|,|ZZZ| < "
-          f"{g.BX}p, {g.BY}p, {g.BZZ}p, {g.BZZZ}p (worst case out: {b[0]:.2f} {b[1]:.2f} {b[2]:.2f} {b[3]:.2f})")
+    print(f"  {g.name}: a, b, g, d = {g.a}, {g.bb}, {g.g}, {g.d}; base shifts {g.sx}, {g.sy}; {chains} chains of {length} XYZZ mixed additions == affine law "
+          f"(P = +-Q detected exactly by the limb test); invariant |X|,|Y|,|ZZ|,|ZZZ| < {g.INV} p (interval worst case out: "
+          f"{b[0]:.2f} {b[1]:.2f} {b[2]:.2f} {b[3]:.2f}; seen {worst[0]:.2f} {worst[1]:.2f} {worst[2]:.2f} {worst[3]:.2f})")
 
 
 def main():

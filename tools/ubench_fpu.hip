@@ -7,9 +7,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "../ark_vrf_amd/csrc/fpu_te.h"
-#ifdef WITH_G1
-#include "../ark_vrf_amd/csrc/fpu_g1.h"
-#endif
 #include "../ark_vrf_amd/csrc/curves.h"
 
 using namespace avrf;
@@ -95,26 +92,27 @@ template <class S> __global__ void k_same_point(const te_ext *a, const te_ext *b
   if (!ok) atomicAdd(bad, 1u);
 }
 
-#ifdef WITH_G1
-// G1: mode 0 saturated G1Curve::madd, mode 1 g1u_madd
+// G1: mode 0 the saturated G1Curve::madd, mode 1 the k_accumulate policy (AccumG1U: g1u_madd, raw partial out, reader's conversion back)
 template <class C, int MODE> __global__ void __launch_bounds__(256, 2) k_g1madd(uint32_t *out, const uint32_t *bases, int nbases, int iters, uint32_t seed, int store) {
-  using CV = G1Curve<C>; constexpr int N = C::Fq::N;
+  using CV = G1Curve<C>; using AC = AccumG1U<C>; constexpr int N = C::Fq::N;
   const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
   typename CV::acc_t res;
   if (MODE == 0) {
     typename CV::acc_t p = CV::identity();
     for (int i = 0; i < iters; i++) {
       const uint32_t h = lane * 2654435761u + i * 40503u + seed;
-      p = CV::madd(p, CV::load_base(bases + (size_t)(h % nbases) * 2 * N), (h >> 13) & 1);
+      p = CV::madd(p, CV::load_base(bases + (size_t)((h >> 3) % nbases) * 2 * N), (h >> 13) & 1);
     }
     res = p;
   } else {
-    g1_acc_u<C> p = g1u_identity<C>();
+    typename AC::acc_t p = AC::identity();
     for (int i = 0; i < iters; i++) {
       const uint32_t h = lane * 2654435761u + i * 40503u + seed;
-      p = g1u_madd<C>(p, CV::load_base(bases + (size_t)(h % nbases) * 2 * N), (h >> 13) & 1);
+      p = AC::madd(p, CV::load_base(bases + (size_t)((h >> 3) % nbases) * 2 * N), (h >> 13) & 1);
     }
-    res = g1u_to_acc<C>(p);
+    alignas(16) uint32_t tmp[AC::PART_WORDS];                  // through the partial-sum format, as k_accumulate -> k_bucket_sum
+    AC::store_part(tmp, p);
+    res = AC::load_part(tmp);
   }
   if (store) CV::store_acc(out + (size_t)lane * 4 * N, res);
   else {
@@ -123,19 +121,19 @@ template <class C, int MODE> __global__ void __launch_bounds__(256, 2) k_g1madd(
     out[lane] = r + seed;
   }
 }
-// table of nbases points: i G for a generator-like starting point (x, y) given in Montgomery words
+// table of nbases points: entry i = i G (entry 0 = infinity, entry 4 = entry 3: the exceptional cases), from an affine generator in PLAIN words
 template <class C> __global__ void k_g1_table(uint32_t *bases, int nbases, const uint32_t *g) {
   using CV = G1Curve<C>; using Fq = typename C::Fq; constexpr int N = Fq::N;
-  if (threadIdx.x || blockIdx.x) return;
-  typename CV::base_t q = CV::load_base(g);
-  typename CV::acc_t p = CV::from_affine(q);
-  for (int i = 0; i < nbases; i++) {
-    // to affine: x = X / ZZ, y = Y / ZZZ
-    fe<Fq> izz = fn_inv<Fq>(p.zz), izzz = fn_inv<Fq>(p.zzz);
-    fe<Fq> x = fn_mul<Fq>(p.x, izz), y = fn_mul<Fq>(p.y, izzz);
-    fn_store<N>(bases + (size_t)i * 2 * N, x); fn_store<N>(bases + (size_t)i * 2 * N + N, y);
-    p = CV::madd(p, q, false);
-  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nbases) return;
+  typename CV::base_t q;
+  q.x = fn_to_mont<Fq>(fn_load<N>(g)); q.y = fn_to_mont<Fq>(fn_load<N>(g + N));
+  const int k = i == 4 ? 3 : i;
+  typename CV::acc_t p = CV::identity();
+  for (int bit = 15; bit >= 0; bit--) { p = CV::dbl(p); if ((k >> bit) & 1) p = CV::madd(p, q, false); }
+  fe<Fq> x = fn_zero<N>(), y = fn_zero<N>();
+  if (k) { const fe<Fq> izz = fn_inv<Fq>(p.zz), izzz = fn_inv<Fq>(p.zzz); x = fn_mul<Fq>(p.x, izz); y = fn_mul<Fq>(p.y, izzz); }
+  fn_store<N>(bases + (size_t)i * 2 * N, x); fn_store<N>(bases + (size_t)i * 2 * N + N, y);
 }
 template <class C> __global__ void k_same_g1(const uint32_t *a, const uint32_t *b, uint32_t n, uint32_t *bad) {
   using CV = G1Curve<C>; using Fq = typename C::Fq;
@@ -151,8 +149,6 @@ template <class C> __global__ void k_same_g1(const uint32_t *a, const uint32_t *
   }
   if (!ok) atomicAdd(bad, 1u);
 }
-
-#endif
 
 template <class K> double time_kernel(K launch, int reps = 3) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -176,30 +172,37 @@ template <class S> void check_te(const char *name, uint32_t *d0, uint32_t *d1, u
     printf("teu_madd vs te_madd <%s>, %d additions per lane, %d lanes: %u mismatches\n", name, iters, n, bad);
   }
 }
-#ifdef WITH_G1
-template <class C> void check_g1(const char *name, uint32_t *d0, uint32_t *d1, uint32_t *dbad, uint32_t *dbases, int nbases) {
+template <class C> void check_g1(const char *name, uint32_t *d0, uint32_t *d1, uint32_t *dbad, uint32_t *dbases, int nbases, const uint32_t *g_plain, uint32_t *dg) {
+  constexpr int N = C::Fq::N;
+  CK(hipMemcpy(dg, g_plain, 2 * N * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_g1_table<C>, dim3((nbases + 63) / 64), dim3(64), 0, 0, dbases, nbases, (const uint32_t *)dg);
   const int blocks = 16, threads = 256, n = blocks * threads;
-  for (int iters : {1, 2, 7, 30}) {
+  for (int iters : {1, 2, 3, 7, 30}) {
     CK(hipMemset(dbad, 0, 4));
-    hipLaunchKernelGGL((k_g1madd<C, 0>), dim3(blocks), dim3(threads), 0, 0, d0, dbases, nbases, iters, 99u, 1);
-    hipLaunchKernelGGL((k_g1madd<C, 1>), dim3(blocks), dim3(threads), 0, 0, d1, dbases, nbases, iters, 99u, 1);
-    hipLaunchKernelGGL(k_same_g1<C>, dim3(blocks), dim3(threads), 0, 0, d0, d1, (uint32_t)n, dbad);
+    hipLaunchKernelGGL((k_g1madd<C, 0>), dim3(blocks), dim3(threads), 0, 0, d0, (const uint32_t *)dbases, nbases, iters, 99u, 1);
+    hipLaunchKernelGGL((k_g1madd<C, 1>), dim3(blocks), dim3(threads), 0, 0, d1, (const uint32_t *)dbases, nbases, iters, 99u, 1);
+    hipLaunchKernelGGL(k_same_g1<C>, dim3(blocks), dim3(threads), 0, 0, (const uint32_t *)d0, (const uint32_t *)d1, (uint32_t)n, dbad);
     uint32_t bad; CK(hipMemcpy(&bad, dbad, 4, hipMemcpyDeviceToHost));
-    printf("g1u_madd vs G1Curve::madd <%s>, %d additions per lane over %d bases (repeats: doublings, cancellations), %d lanes: %u mismatches\n", name, iters, nbases, n, bad);
+    printf("g1u_madd vs G1Curve::madd <%s>, %d additions per lane over %d bases (infinity, repeats -> doublings, cancellations), %d lanes: %u mismatches\n", name, iters, nbases, n, bad);
   }
 }
-
-#endif
 
 int main(int argc, char **argv) {
   const bool quick = argc > 1;
   uint32_t *out, *d0, *d1, *dbad, *dbases, *dg;
   CK(hipMalloc(&out, 256 * 32 * 256 * 4 * 4)); CK(hipMalloc(&d0, 64 * 256 * 192)); CK(hipMalloc(&d1, 64 * 256 * 192)); CK(hipMalloc(&dbad, 4));
-  CK(hipMalloc(&dbases, 64 * 96)); CK(hipMalloc(&dg, 96));
+  CK(hipMalloc(&dbases, 8192 * 96)); CK(hipMalloc(&dg, 96));
+  uint32_t *dg381, *dg254; CK(hipMalloc(&dg381, 96)); CK(hipMalloc(&dg254, 96));
   check_te<SuiteBandersnatch>("Bandersnatch a=-5", d0, d1, dbad);
   check_te<SuiteBabyJubJub>("BabyJubJub a=1", d0, d1, dbad);
   check_te<SuiteJubJub>("JubJub a=-1", d0, d1, dbad);
   check_te<SuiteEd25519>("Ed25519 a=-1", d0, d1, dbad);
+  static const uint32_t g381[24] = {0xdb22c6bbu, 0xfb3af00au, 0xf97a1aefu, 0x6c55e83fu, 0x171bac58u, 0xa14e3a3fu, 0x9774b905u, 0xc3688c4fu, 0x4fa9ac0fu, 0x2695638cu, 0x3197d794u, 0x17f1d3a7u,
+                                    0x46c5e7e1u, 0x0caa2329u, 0xa2888ae4u, 0xd03cc744u, 0x2c04b3edu, 0x00db18cbu, 0xd5d00af6u, 0xfcf5e095u, 0x741d8ae4u, 0xa09e30edu, 0xe3aaa0f1u, 0x08b3f481u};
+  static const uint32_t g254[16] = {1, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0};
+  CK(hipMemcpy(dg381, g381, 96, hipMemcpyHostToDevice)); CK(hipMemcpy(dg254, g254, 64, hipMemcpyHostToDevice));
+  check_g1<G1Bls12381>("BLS12-381", d0, d1, dbad, dbases, 6, g381, dg);
+  check_g1<G1Bn254>("BN254", d0, d1, dbad, dbases, 6, g254, dg);
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s, CUs %d\n", prop.name, prop.multiProcessorCount);
   for (int wpc = 4; wpc <= 32; wpc *= 2) {
@@ -219,6 +222,19 @@ int main(int argc, char **argv) {
     RATE("fu_mul<FqBls12381> 14x28", (k_fumul<FqBls12381>), 2, "Gmul/s");
     RATE("fu_sqr<FqBls12381> 14x28", (k_fusqr<FqBls12381>), 2, "Gsqr/s");
 #undef RATE
+    if (wpc <= 8) {
+      const int it = 48, nb = 8192;
+      hipLaunchKernelGGL(k_g1_table<G1Bls12381>, dim3(nb / 64), dim3(64), 0, 0, dbases, nb, (const uint32_t *)dg381);
+      t = time_kernel([&] { hipLaunchKernelGGL((k_g1madd<G1Bls12381, 0>), dim3(blocks), dim3(threads), 0, 0, out, (const uint32_t *)dbases, nb, it, 777u, 0); });
+      printf("  %-34s %8.3f Gadd/s\n", "g1 madd<Bls12381> (saturated)", (double)blocks * threads * it / t * 1e-9);
+      t = time_kernel([&] { hipLaunchKernelGGL((k_g1madd<G1Bls12381, 1>), dim3(blocks), dim3(threads), 0, 0, out, (const uint32_t *)dbases, nb, it, 777u, 0); });
+      printf("  %-34s %8.3f Gadd/s\n", "g1u_madd<Bls12381> 14x28", (double)blocks * threads * it / t * 1e-9);
+      hipLaunchKernelGGL(k_g1_table<G1Bn254>, dim3(nb / 64), dim3(64), 0, 0, dbases, nb, (const uint32_t *)dg254);
+      t = time_kernel([&] { hipLaunchKernelGGL((k_g1madd<G1Bn254, 0>), dim3(blocks), dim3(threads), 0, 0, out, (const uint32_t *)dbases, nb, it, 777u, 0); });
+      printf("  %-34s %8.3f Gadd/s\n", "g1 madd<Bn254> (saturated)", (double)blocks * threads * it / t * 1e-9);
+      t = time_kernel([&] { hipLaunchKernelGGL((k_g1madd<G1Bn254, 1>), dim3(blocks), dim3(threads), 0, 0, out, (const uint32_t *)dbases, nb, it, 777u, 0); });
+      printf("  %-34s %8.3f Gadd/s\n", "g1u_madd<Bn254> 9x29", (double)blocks * threads * it / t * 1e-9);
+    }
     if (wpc <= 16) {
       const int it = 128;
       t = time_kernel([&] { hipLaunchKernelGGL((k_madd<SuiteBandersnatch, 0>), dim3(blocks), dim3(threads), 0, 0, out, it, 777u, 0); });
