@@ -115,6 +115,12 @@ template <class S> struct TeCurve {
   static AVRF_DI acc_t add(const acc_t &a, const acc_t &b) { return te_add<S>(a, b); }
   static AVRF_DI acc_t dbl(const acc_t &a) { return te_dbl<S>(a); }
   static AVRF_DI base_t load_base(const uint32_t *p) { return load_pre(reinterpret_cast<const te_pre *>(p)); }
+  static AVRF_DI base_t base_from_words(const uint32_t (&w)[BASE_WORDS]) {
+    base_t r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { r.x.v[i] = w[i]; r.y.v[i] = w[8 + i]; r.k.v[i] = w[16 + i]; }
+    return r;
+  }
   static AVRF_DI acc_t load_acc(const uint32_t *p) { return load_ext(reinterpret_cast<const te_ext *>(p)); }
   static AVRF_DI void store_acc(uint32_t *p, const acc_t &a) { store_ext(reinterpret_cast<te_ext *>(p), a); }
   static AVRF_DI acc_t shfl_down(const acc_t &p, int delta) {
@@ -232,6 +238,12 @@ template <class C> struct G1Curve {
     return r;
   }
   static AVRF_DI base_t load_base(const uint32_t *p) { base_t r; r.x = fn_load<N>(p); r.y = fn_load<N>(p + N); return r; }
+  static AVRF_DI base_t base_from_words(const uint32_t (&w)[BASE_WORDS]) {
+    base_t r;
+#pragma unroll
+    for (int i = 0; i < N; i++) { r.x.v[i] = w[i]; r.y.v[i] = w[N + i]; }
+    return r;
+  }
   static AVRF_DI acc_t load_acc(const uint32_t *p) {
     acc_t r; r.x = fn_load<N>(p); r.y = fn_load<N>(p + N); r.zz = fn_load<N>(p + 2 * N); r.zzz = fn_load<N>(p + 3 * N); return r;
   }

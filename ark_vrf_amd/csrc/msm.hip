@@ -312,6 +312,59 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
   uint32_t nxt = (b + 1 < nb) ? ow[b + 1] : 0xffffffffu;      // first entry of the next bucket
   const size_t slot0 = (size_t)t + (size_t)v * nb;
   acc_t acc;
+#ifndef AVRF_NO_LDS_PREFETCH
+  {
+    // Gather pipeline through LDS: the base of entry k + 1 travels HBM -> LDS by DMA (global_load_lds_dwordx4: lane l's 16-byte
+    // chunk c lands at chunk c's row + 16 l of the wave's buffer) while the addition of entry k runs, and costs NO registers until
+    // it is read back at the top of its own iteration (the register form of this prefetch held 24 VGPRs across the whole
+    // addition: 198 for the twisted-Edwards kernel; the 381-bit kernel had no room for it and waited out every gather).
+    // Two buffers per wave; the index of entry k + 2 is in flight as well.
+    extern __shared__ uint32_t acc_lds[];
+    constexpr int BW = CV::BASE_WORDS, CH = BW / 4;
+    uint32_t *wbuf = acc_lds + (threadIdx.x >> 6) * (2 * BW * 64);
+    const uint32_t lane = threadIdx.x & 63;
+    auto issue = [&](uint32_t ix, uint32_t slot) {
+      const uint32_t *src = bases + (size_t)(ix & 0x7fffffffu) * BW;
+#pragma unroll
+      for (int c = 0; c < CH; c++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * c),
+                                         (__attribute__((address_space(3))) void *)(wbuf + slot * (BW * 64) + c * 256), 16, 0, 0);
+    };
+    auto fetch = [&](uint32_t slot) {
+      uint32_t w[BW];
+#pragma unroll
+      for (int c = 0; c < CH; c++) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(wbuf + slot * (BW * 64) + c * 256 + lane * 4);
+        w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
+      }
+      return CV::base_from_words(w);
+    };
+    const uint32_t cnt = e1 - e0;
+    if constexpr (!CV::PREFETCH) acc = AC::identity();
+    uint32_t idx = sorted[e0];
+    uint32_t idx1 = cnt > 1 ? sorted[e0 + 1] : 0u;
+    issue(idx, 0);
+    for (uint32_t k = 0; k < cnt; k++) {                        // k is the same in every lane of the wave (shares start together)
+      const uint32_t i = e0 + k, cidx = idx;
+      // the DMA of this buffer was issued one iteration ago: the compiler's own wait insertion does not carry an LDS-DMA across
+      // the loop's back edge (it put the ds_reads BEFORE its vmcnt(0)), so the wait is explicit -- and a compiler barrier
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const base_t cur = fetch(k & 1);
+      idx = idx1;
+      if (k + 1 < cnt) issue(idx, (k + 1) & 1);
+      if (k + 2 < cnt) idx1 = sorted[i + 2];
+      if constexpr (CV::PREFETCH) {                             // first entry of every lane: no addition, just the base
+        if (k == 0) { acc = AC::from_base(cur, (cidx & 0x80000000u) != 0); continue; }
+      }                                                          // (the 381-bit policy's madd takes the identity as it comes: one code path, fewer registers)
+      if (i >= nxt) {                                          // bucket boundary inside the lane's range
+        AC::store_part(part + (slot0 + b) * AC::PART_WORDS, acc);
+        acc = AC::identity();
+        do { b++; nxt = (b + 1 < nb) ? ow[b + 1] : 0xffffffffu; } while (i >= nxt);
+      }
+      acc = AC::madd(acc, cur, (cidx & 0x80000000u) != 0);
+    }
+  }
+#else
   if (CV::PREFETCH) {
     // software-pipelined gather, two stages: the index of entry i + 2 and the base of entry i + 1 are in flight while the
     // addition of entry i runs (with the index only one ahead every iteration waited out the index load before it could even
@@ -350,6 +403,7 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
       acc = AC::madd(acc, CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS), (idx & 0x80000000u) != 0);
     }
   }
+#endif
   AC::store_part(part + (slot0 + b) * AC::PART_WORDS, acc);
 }
 
@@ -655,6 +709,16 @@ template <class CV> static AccShape accumulate_shape() {
         if (lds > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       }
     }
+#ifndef AVRF_NO_LDS_PREFETCH
+    {   // the gather pipeline's two buffers per wave (k_accumulate): at least that much dynamic LDS; resident workgroups follow
+      const unsigned need = 4u * 2u * CV::BASE_WORDS * 64u * 4u;
+      if (lds < need) lds = need;
+      if (lds > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      int blk2 = 0;
+      HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blk2, k_accumulate<CV>, 256, lds));
+      if (blk2 >= 1 && blk2 < blocks) blocks = blk2;
+    }
+#endif
     cache[dev] = AccShape{(size_t)cus * blocks * 256, lds};
   }
   return cache[dev];
