@@ -158,14 +158,19 @@ def test_pool_concurrent_submitters_and_destroy_in_flight(nat):
         pool2.close()
 
 
-def test_pool_full_size_batch(nat):
-    """BASELINE configs[1] size through the pool: 65 536 items, a tampered copy next to the good one"""
+@pytest.mark.parametrize("kind", [0, 1])
+def test_pool_full_size_batch(nat, kind):
+    """BASELINE configs[1] / configs[2] size through the pool: 65 536 items (262 145 Thin terms / 327 682 Pedersen terms), a
+    tampered copy next to the good one"""
     n = 65536
-    good = orc.gen_batch(0, 0, n)
-    pr = bytearray(good["proofs"]); pr[96 * 40000 + 70] ^= 2
-    pool = nat.Pool(0, kind=1, slots=4, lanes=2, threads=2, hash_group=8)
+    good = orc.gen_batch(0, kind, n, threads=16)
+    if kind == 1:
+        good["pks_xy"] = b""
+    psz = len(good["proofs"]) // n
+    pr = bytearray(good["proofs"]); pr[psz * 40000 + psz - 26] ^= 2     # inside the last response scalar of item 40 000
+    pool = nat.Pool(0, kind=kind + 1, slots=4, lanes=2, threads=2, hash_group=8)
     try:
-        pg = nat.PinnedBatch(n, good["ios_xy"], good["io_counts"], good["ads"], good["ad_lens"], pks_xy=good["pks_xy"], proofs=good["proofs"])
+        pg = nat.PinnedBatch(n, good["ios_xy"], good["io_counts"], good["ads"], good["ad_lens"], pks_xy=good["pks_xy"] or None, proofs=good["proofs"])
         tk = [pool.submit(pg), pool.submit(nat_batch(dict(good, proofs=bytes(pr)))), pool.submit(pg), pool.submit(pg)]
         assert [pool.wait(t) for t in tk] == [0, 1, 0, 0]
         done, mism, _ = pool.cycle(steps_block=8, min_seconds=0.0, expect=0)

@@ -544,3 +544,44 @@ def test_chunked_two_lane_proving(env, monkeypatch):
     monkeypatch.delenv("AVRF_RING_LANES")
     assert key.prove(idx, bl) == whole
     assert [key.prove([i], [b])[0] for i, b in zip(idx[:3], bl[:3])] == whole[:3]
+
+
+def test_c4_shape_1030_proofs_in_one_call(env, golden_dir):
+    """BASELINE configs[3] as it is BENCHMARKED: ring 1024 (N = 2048), many proofs in ONE avrf_ring_prove call -- default
+    chunking (lockstep chunks of 512 proofs on two lanes, a 6-proof remainder), mixed key indices with repeats, per-proof
+    blindings (src/ring.rs:211-226).  Eleven sampled proofs (first / last of every chunk and of the remainder, some inside)
+    equal the pure-Python oracle's byte for byte (tests/golden/ring_c4_oracle.json, made by gen_ring_c4_oracle.py); all 1 030
+    verify as one batch, and a swapped pair of instances is rejected."""
+    import hashlib
+    import oracle as orc
+    from ark_vrf_amd.ring import RingSetup, ring_batch_verify
+    ctx, _, _, srs_bytes = env[0]
+    s = R.SUITES[0]
+    fx = json.load(open(os.path.join(golden_dir, "ring_c4_oracle.json")))
+    ring, n = fx["ring_size"], fx["n_proofs"]
+    assert (ring, n) == (1024, 1030)
+
+    def key_index(j):
+        return (0, 1, 777, 1023)[j] if j < 4 else (777 if j % 97 == 0 else (j * 389 + 7) % ring)
+    setup = RingSetup(ctx, srs_bytes, ring)
+    ks = b"".join((int.from_bytes(hashlib.sha512(b"k%d" % i).digest(), "little") % (s.r >> 3) + 1).to_bytes(32, "little") for i in range(ring))
+    pks_xy = ctx.scalar_mul_base(ks)
+    pkl = [pks_xy[64 * i: 64 * i + 64] for i in range(ring)]
+    key = setup.index(pkl)
+    assert key.commitment.hex() == fx["commitment"]
+    idx = [key_index(j) for j in range(n)]
+    assert all(fx["key_index"][str(j)] == idx[j] for j in map(int, fx["proofs"]))
+    bl = [(int.from_bytes(hashlib.sha512(b"c4-blinding%d" % j).digest(), "little") % (s.r >> 3)).to_bytes(32, "little") for j in range(n)]
+    proofs = key.prove(idx, bl)                                            # ONE call, default chunk size and lanes
+    assert len(proofs) == n
+    for j, hx in fx["proofs"].items():
+        assert proofs[int(j)].hex() == hx, f"proof {j} (key {idx[int(j)]}) differs from the oracle's"
+    # instances pk + b B (pedersen::Proof::key_commitment, src/pedersen.rs:64-70): one 2-term msm_unchecked each
+    st, bb = orc.point_decompress(0, orc.suite_point(0, 1))
+    assert st == 0 and (int.from_bytes(bb[:32], "little"), int.from_bytes(bb[32:], "little")) == s.blinding_base
+    one = (1).to_bytes(32, "little")
+    inst = [ctx.msm(pkl[idx[j]] + bb, one + bl[j]) for j in range(n)]
+    assert ring_batch_verify(setup, [key.commitment], None, inst, proofs) == 0
+    inst[5], inst[6] = inst[6], inst[5]
+    assert ring_batch_verify(setup, [key.commitment], None, inst, proofs) == 1
+    key.close(); setup.close()

@@ -6,17 +6,22 @@ cd "$(dirname "$0")" || exit 1
 T=$(mktemp -d)
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -enable-ipra=0 -I../ark_vrf_amd/csrc --save-temps=obj -o $T/ubench ubench.hip 2> $T/build.log || { cat $T/build.log; exit 1; }
 $T/ubench
+# the unsaturated-limb forms the bucket-accumulation kernels run on (round 5), same flags, same box
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -mllvm -enable-ipra=0 -I../ark_vrf_amd/csrc --save-temps=obj -o $T/ubench_fpu ubench_fpu.hip 2> $T/build_fpu.log || { cat $T/build_fpu.log; exit 1; }
+echo "=== tools/ubench_fpu.hip"
+$T/ubench_fpu
+cat $T/ubench_fpu-hip-amdgcn-amd-amdhsa-gfx950.s >> $T/ubench-hip-amdgcn-amd-amdhsa-gfx950.s
 python3 - $T/ubench-hip-amdgcn-amd-amdhsa-gfx950.s <<'PY'
 import re, sys
 s = open(sys.argv[1]).read()
-print("--- disassembly of this binary: v_mad_u64_u32 per loop iteration / per mixed addition")
+print("--- disassembly of these binaries: v_mad_u64_u32 + v_mad_i64_i32 per loop iteration / per mixed addition (k_madd / k_g1madd <.., 1> = the unsaturated forms; k_fumul / k_fmul_sat loops hold TWO multiplications)")
 for f in re.split(r'\n(?=_Z[\w]+:)', s):
     name = f.split(':', 1)[0]
-    if not any(k in name for k in ("k_opILi0", "k_mad_asm", "k_madd", "k_g1madd")):
+    if not any(k in name for k in ("k_opILi0", "k_mad_asm", "k_madd", "k_g1madd", "k_fumul", "k_fmul_sat")):
         continue
     lines = [l.strip() for l in f.split('\n')]
     isn = lambda l: re.match(r'^(v_|s_|ds_|global_|buffer_|flat_)', l) is not None
-    mads = [i for i, l in enumerate(lines) if l.startswith("v_mad_u64_u32")]
+    mads = [i for i, l in enumerate(lines) if l.startswith("v_mad_u64_u32") or l.startswith("v_mad_i64_i32")]
     labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r'^(\.LBB\d+_\d+):', l)] if m}
     best = None
     for i, l in enumerate(lines):
