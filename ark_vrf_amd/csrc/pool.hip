@@ -19,6 +19,8 @@
 #include "suite_dispatch.h"
 #include "host_sha512.h"
 #include "host_sha512_mb.h"
+#include "host_numa.h"
+#include <pthread.h>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -69,6 +71,7 @@ double thread_cpu_us() {
 struct avrf_pool {
   int suite = 0, device = 0, kind = 1, group = 1, depth = 1;
   std::vector<Slot> slots; std::vector<Lane> lanes; std::vector<Worker> workers;
+  int numa_node = -1; bool numa_bound = false;          // where the workers run (host_numa.h)
   std::mutex m; std::condition_variable cv_work, cv_done;
   bool stop = false;
   uint64_t next_ticket = 1;
@@ -264,7 +267,19 @@ int avrf_pool_create(int suite, int device, int kind, int n_slots, int n_lanes, 
     ok = ok && hipStreamCreateWithFlags(&W.ingest, hipStreamNonBlocking) == hipSuccess;
   }
   if (!ok) { (void)hipGetLastError(); avrf_pool_destroy(P); return AVRF_ERR_NO_DEVICE; }
-  for (int w = 0; w < n_threads; w++) P->workers[w].th = std::thread([P, w] { Run(P, P->workers[w]).loop(); });
+  // the workers hash transcripts and stage page-locked buffers for THIS device: on a multi-socket host they run on the CPUs of
+  // the device's NUMA node (host_numa.h; the part of it inside the caller's affinity mask -- a caller that bound itself keeps its choice)
+  cpu_set_t node_set; bool bind = false;
+  if (numa_binding_enabled()) {
+    char bdf[32] = {0}; std::vector<int> cpus;
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) == hipSuccess) { P->numa_node = numa_cpus_of_pci(bdf, sysfs_root(), cpus); bind = P->numa_node >= 0 && numa_mask(cpus, node_set); }
+    else (void)hipGetLastError();
+  }
+  P->numa_bound = bind;
+  for (int w = 0; w < n_threads; w++) {
+    P->workers[w].th = std::thread([P, w] { Run(P, P->workers[w]).loop(); });
+    if (bind) (void)pthread_setaffinity_np(P->workers[w].th.native_handle(), sizeof node_set, &node_set);
+  }
   *out = P;
   return AVRF_OK;
 }
@@ -394,13 +409,38 @@ int avrf_pool_stats(avrf_pool *P, int reset, double *out, size_t n_out) {
 
 // Page-locked host memory for the buffers a caller hands to avrf_pool_submit / the *_stage entry points: copies from it are
 // DMA transfers (no staging through the runtime's bounce buffers, no host time), see include/avrf.h "Ownership".
+// (The pages are allocated -- and pinned -- by the calling thread: under the default local policy they come from the node that
+// thread runs on, so for the duration of the call the thread is moved next to the CURRENT device (hipGetDevice), as the pool's
+// workers are; a caller already bound to one node, e.g. a rank of bench.py, is left where it is.)
 int avrf_host_alloc(size_t bytes, void **out) {
   if (!out) return AVRF_ERR_BAD_ARG;
   *out = nullptr;
   if (!bytes) return AVRF_OK;
-  if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return AVRF_ERR_NO_DEVICE; }
+  cpu_set_t saved, node_set; bool moved = false;
+  if (numa_binding_enabled() && sched_getaffinity(0, sizeof saved, &saved) == 0) {
+    int dev = 0; char bdf[32] = {0}; std::vector<int> cpus;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, dev) == hipSuccess &&
+        numa_cpus_of_pci(bdf, sysfs_root(), cpus) >= 0 && numa_mask(cpus, node_set))
+      moved = sched_setaffinity(0, sizeof node_set, &node_set) == 0;
+    else (void)hipGetLastError();
+  }
+  const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (moved) (void)sched_setaffinity(0, sizeof saved, &saved);
+  if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return AVRF_ERR_NO_DEVICE; }
   return AVRF_OK;
 }
+// test hook and diagnostic: NUMA node (-1: unknown) and CPUs of a PCI device under a sysfs root ("" or NULL = "/"); returns the
+// number of CPUs written to cpus_out (at most cap)
+int avrf_numa_cpus_of_pci(const char *pci_bdf, const char *sysfs_root_dir, int32_t *cpus_out, size_t cap, int32_t *node_out) {
+  std::vector<int> cpus;
+  const int node = numa_cpus_of_pci(pci_bdf, sysfs_root_dir, cpus);
+  if (node_out) *node_out = node;
+  size_t k = 0;
+  for (; k < cpus.size() && k < cap && cpus_out; k++) cpus_out[k] = cpus[k];
+  return (int)k;
+}
+// NUMA node the pool's workers were bound to (-1: not bound / unknown)
+int avrf_pool_numa_node(avrf_pool *P) { return P && P->numa_bound ? P->numa_node : -1; }
 void avrf_host_free(void *p) { if (p) (void)hipHostFree(p); }
 int avrf_host_register(void *p, size_t bytes) {
   if (!p || !bytes) return AVRF_ERR_BAD_ARG;

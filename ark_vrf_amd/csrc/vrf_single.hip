@@ -949,8 +949,11 @@ k_decompress(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ o
   fp xm, ym, x, y; bool check;
   int32_t st = decode_point<S>(in, j, validate, xm, ym, x, y, check);
   if (check) {
-    te_ext rp = te_smul<S>(te_make_pre<S>(xm, ym), fp_const<Fr>(Fr::P), Fr::BITS);   // r * P == 0
-    if (!te_is_identity<S>(rp)) st = 2;
+    if constexpr (S::HAS_2DESCENT) { if (!te_in_subgroup_2descent<S>(ym)) st = 2; }      // two Jacobi symbols (glv.h)
+    else {
+      te_ext rp = te_smul<S>(te_make_pre<S>(xm, ym), fp_const<Fr>(Fr::P), Fr::BITS);   // r * P == 0
+      if (!te_is_identity<S>(rp)) st = 2;
+    }
   }
   fp_store_le(out_xy + 64 * (size_t)j, x); fp_store_le(out_xy + 64 * (size_t)j + 32, y);
   status[j] = st;
@@ -1034,8 +1037,11 @@ k_validate_xy(const uint8_t *__restrict__ base, uint32_t stride, uint32_t ppr, u
     fp xm = fp_to_mont<Fq>(x), ym = fp_to_mont<Fq>(y);
     bad = !te_on_curve<S>(xm, ym);
     if (!bad && level >= 2) {
-      te_ext rp = te_smul<S>(te_make_pre<S>(xm, ym), fp_const<Fr>(Fr::P), Fr::BITS);
-      bad = !te_is_identity<S>(rp);
+      if constexpr (S::HAS_2DESCENT) bad = !te_in_subgroup_2descent<S>(ym);
+      else {
+        te_ext rp = te_smul<S>(te_make_pre<S>(xm, ym), fp_const<Fr>(Fr::P), Fr::BITS);
+        bad = !te_is_identity<S>(rp);
+      }
     }
   }
   if (bad) { atomicOr(flags, (uint32_t)FLAG_CURVE); if (rec_status) rec_status[j] = 2; }
@@ -1132,7 +1138,8 @@ template <class S> void SingleOps<S>::hash_to_curve(const uint8_t *d_data, const
   hipLaunchKernelGGL(k_hash_to_curve<S>, dim3((n + 127) / 128), dim3(128), 0, st, d_data, d_off, n, d_out, d_status);
 }
 template <class S> void SingleOps<S>::decompress(const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st) {
-  if constexpr (!S::SW_NATIVE) if (validate && n <= 4096) {           // few points: four lanes per point for the subgroup test
+  // few points: four lanes per point for the subgroup test r P (where the test is two Jacobi symbols the lane-per-point kernel is the fast one at every n)
+  if constexpr (!S::SW_NATIVE && !S::HAS_2DESCENT) if (validate && n <= 4096) {
     hipLaunchKernelGGL(k_decompress_wave<S>, dim3(((S::HAS_GLV ? 8 : 4) * n + 63) / 64), dim3(64), 0, st, d_in, n, d_out, d_status);   // (two quads per point with the endomorphism)
     return;
   }

@@ -155,6 +155,12 @@ int avrf_batch_run_end(avrf_ctx *ctx);
  * avrf_host_alloc returns page-locked memory for the batch buffers (pks / ios / ads / proofs / counts); avrf_host_register
  * pins memory the caller already owns (page-aligned ranges are cheapest; unregister before freeing it). */
 int avrf_host_alloc(size_t bytes, void **out);
+/* NUMA placement (a two-socket host with several GPUs): the pool's worker threads run on the CPUs of their
+ * device's NUMA node, and avrf_host_alloc allocates its pages from the node of the CURRENT device (hipGetDevice) -- both inside
+ * the caller's affinity mask, both read from sysfs (/sys/bus/pci/devices/<bdf>/numa_node), both off with AVRF_POOL_NUMA=0.
+ * avrf_numa_cpus_of_pci is the lookup itself (node_out: -1 = unknown; returns the CPUs written to cpus_out);
+ * avrf_pool_numa_node the node a pool's workers were bound to (-1: not bound). */
+int avrf_numa_cpus_of_pci(const char *pci_bdf, const char *sysfs_root_dir, int32_t *cpus_out, size_t cap, int32_t *node_out);
 void avrf_host_free(void *p);
 int avrf_host_register(void *p, size_t bytes);
 int avrf_host_unregister(void *p);
@@ -197,6 +203,7 @@ int avrf_pool_resubmit(avrf_pool *pool, uint64_t ticket, int from_host, uint64_t
 int avrf_pool_cycle(avrf_pool *pool, int from_host, uint64_t steps_block, double min_seconds, uint64_t max_steps, int expect_status,
                     uint64_t *steps_done, uint64_t *mismatches, double *seconds);
 int avrf_pool_stats(avrf_pool *pool, int reset, double *out, size_t n_out);
+int avrf_pool_numa_node(avrf_pool *pool);
 
 /* pedersen::BatchVerifier split the same way (src/pedersen.rs:341-426): stage the shard with avrf_pedersen_batch_stage,
  * avrf_pedersen_batch_challenges -> n_shard x 16 bytes, avrf_batch_weight_seed(pedersen = 1) over all items

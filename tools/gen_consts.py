@@ -118,8 +118,98 @@ def suite(name, sid, sid_str, fq, fr, q, r, a_kind, d, pts, cof, ell2=None, glv=
             s.append(f"  static constexpr uint32_t {nm}[{n}] = {{{lw(v, n)}}};")
         s.append(f"  static constexpr uint32_t ENDO_B[8] = {{{limbs(mont(glv['eb'], q))}}};  /* psi(x, y) = (c (1 - y^2) / (x y), b (y^2 + b) / (y^2 - b)) */")
         s.append(f"  static constexpr uint32_t ENDO_C[8] = {{{limbs(mont(glv['ec'], q))}}};")
+    # Subgroup membership by 2-descent (vrf_single.hip te_in_subgroup): when E(Fq) = Z2 x Z2 x Zr (cofactor 4, full rational
+    # 2-torsion) the prime-order subgroup is exactly 2 E(Fq), and on the Montgomery model B v^2 = u (u - alpha)(u - beta),
+    # u = (1 + y) / (1 - y), a point is a double iff B u, B (u - alpha), B (u - beta) are squares -- two Legendre symbols in y
+    # alone: chi(1 - y^2) = chi((c0 + c1 y)(1 - y)) = chi(B), c0 = 1 - alpha, c1 = 1 + alpha -- instead of the 253-bit r P.
+    td = two_descent(q, r, a_kind, d, pts["G"]) if cof == 4 else None
+    s.append(f"  static constexpr bool HAS_2DESCENT = {'true' if td else 'false'};")
+    if td:
+        s.append(f"  static constexpr uint32_t TD_C0[8] = {{{limbs(mont(td['c0'], q))}}};  /* 1 - alpha */")
+        s.append(f"  static constexpr uint32_t TD_C1[8] = {{{limbs(mont(td['c1'], q))}}};  /* 1 + alpha */")
+        s.append(f"  static constexpr int TD_WANT = {td['want']};  /* chi(B), B = 4 / (a - d) */")
     s.append("};")
     return "\n".join(s)
+
+
+def legendre(x, q):
+    x %= q
+    return 0 if x == 0 else (1 if pow(x, (q - 1) // 2, q) == 1 else -1)
+
+
+def sqrt_mod(x, q):
+    """Tonelli-Shanks; None for a non-residue"""
+    x %= q
+    if x == 0:
+        return 0
+    if legendre(x, q) != 1:
+        return None
+    s, t = 0, q - 1
+    while t % 2 == 0:
+        t //= 2; s += 1
+    z = 2
+    while legendre(z, q) != -1:
+        z += 1
+    c, R, tt, m = pow(z, t, q), pow(x, (t + 1) // 2, q), pow(x, t, q), s
+    while tt != 1:
+        i, t2 = 0, tt
+        while t2 != 1:
+            t2 = t2 * t2 % q; i += 1
+        b = pow(c, 1 << (m - i - 1), q)
+        R, c = R * b % q, b * b % q
+        tt, m = tt * c % q, i
+    return R
+
+
+def two_descent(q, r, a_kind, d, g):
+    """constants of the 2-descent subgroup test, or None when the 2-torsion is not fully rational; checked against r P on
+    points of every coset (k G, k G + (0, -1), and random curve points, which fall into all four)"""
+    import random
+    a = {0: 1, 1: q - 5, 2: q - 1}[a_kind]
+    A, B = 2 * (a + d) * pow(a - d, -1, q) % q, 4 * pow(a - d, -1, q) % q
+    sd = sqrt_mod(A * A - 4, q)
+    if sd is None:
+        return None
+    alpha = (-A + sd) * pow(2, -1, q) % q
+    assert (alpha * alpha + A * alpha + 1) % q == 0
+    c0, c1, want = (1 - alpha) % q, (1 + alpha) % q, legendre(B, q)
+
+    def add(p1, p2):
+        x1, y1 = p1; x2, y2 = p2
+        t = d * x1 * x2 * y1 * y2 % q
+        return ((x1 * y2 + y1 * x2) * pow(1 + t, -1, q) % q, (y1 * y2 - a * x1 * x2) * pow(1 - t, -1, q) % q)
+
+    def in_subgroup(p):
+        acc = (0, 1)
+        try:
+            for bit in bin(r)[2:]:
+                acc = add(acc, acc)
+                if bit == "1":
+                    acc = add(acc, p)
+        except ValueError:                     # the sum left the affine chart: a point at infinity (2-torsion), not the identity
+            return False
+        return acc == (0, 1)
+
+    def test(p):
+        y = p[1]
+        return legendre(1 - y * y, q) == want and legendre((c0 + c1 * y) * (1 - y), q) == want
+    rng = random.Random(7)
+    pts, seen = [], set()
+    for _ in range(6):
+        P = te_affine_mul(q, a, d, g, rng.randrange(1, r))
+        pts += [P, ((-P[0]) % q, (-P[1]) % q)]             # P and P + (0, -1)
+    while len(pts) < 60:
+        y = rng.randrange(q)
+        x = sqrt_mod((1 - y * y) * pow(a - d * y * y, -1, q), q)
+        if x is not None:
+            pts.append((x, y))
+    for P in pts:
+        ok = in_subgroup(P)
+        seen.add(ok)
+        assert test(P) == ok, "2-descent criterion disagrees with r P"
+    assert seen == {True, False}
+    assert not test((0, q - 1))                # the 2-torsion point (0, -1): u = 0
+    return {"c0": c0, "c1": c1, "want": want}
 
 
 def suite_sw_native(name, sid, sid_str, fq, fr, q, a, b, pts, sha256=True):
@@ -158,6 +248,7 @@ def suite_sw_native(name, sid, sid_str, fq, fr, q, a, b, pts, sha256=True):
     s.append(f"  static constexpr uint32_t SW_A[8] = {{{limbs(mont(a % q, q))}}};")
     s.append(f"  static constexpr uint32_t SW_B[8] = {{{limbs(mont(b, q))}}};")
     s.append("  static constexpr bool HAS_GLV = false;")
+    s.append("  static constexpr bool HAS_2DESCENT = false;")
     s.append("};")
     return "\n".join(s)
 
