@@ -256,6 +256,26 @@ class Context:
             raise AvrfError(f"avrf_scalar_mul -> {st}")
         return bytes(out)[: 64 * n]
 
+    def output_hash(self, points_xy, n_bytes=32):
+        """Output::hash::<N> of output points given as x || y -> list of N-byte strings"""
+        n = len(points_xy) // 64
+        out = (C.c_uint8 * max(1, n_bytes * n))()
+        st = lib().avrf_output_hash(self._h, C.c_size_t(n), _u8(points_xy), C.c_size_t(n_bytes), out)
+        if st != OK:
+            raise AvrfError(f"avrf_output_hash -> {st}")
+        b = bytes(out)
+        return [b[n_bytes * i: n_bytes * (i + 1)] for i in range(n)]
+
+    def secret_from_seed(self, seeds, with_public=True):
+        """Secret::from_seed for 32-byte seeds -> (secret scalars n x 32, public keys n x 64 or None)"""
+        n = len(seeds) // 32
+        sks = (C.c_uint8 * max(1, 32 * n))()
+        pks = (C.c_uint8 * max(1, 64 * n))() if with_public else None
+        st = lib().avrf_secret_from_seed(self._h, C.c_size_t(n), _u8(seeds), sks, pks)
+        if st != OK:
+            raise AvrfError(f"avrf_secret_from_seed -> {st}")
+        return bytes(sks)[: 32 * n], (bytes(pks)[: 64 * n] if with_public else None)
+
     def hash_to_curve(self, messages):
         """Input::new for a list of byte strings -> (xy bytes n x 64, statuses)."""
         n = len(messages)

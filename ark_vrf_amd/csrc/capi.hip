@@ -1119,6 +1119,39 @@ int avrf_hash_to_curve(avrf_ctx *c, size_t n, const uint8_t *data, const uint32_
   HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
   return AVRF_OK;
 }
+// Output::hash::<N> of n output points (x || y in, N = hash_len <= 64 bytes each out)
+int avrf_output_hash(avrf_ctx *c, size_t n, const uint8_t *points_xy, size_t hash_len, uint8_t *out) {
+  if (!c || hash_len < 1 || hash_len > 64 || (n && (!points_xy || !out))) return AVRF_ERR_BAD_ARG;
+  if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;
+  if (!n) return AVRF_OK;
+  if (n > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  c->staged_kind = 0;
+  HIP_TRY(c->d_misc.ensure(n * 64)); HIP_TRY(c->d_out.ensure(n * 64));
+  HIP_TRY(hipMemcpyAsync(c->d_misc.p, points_xy, n * 64, hipMemcpyHostToDevice, c->stream));
+  launch_output_hash(c->suite, c->d_misc.as<uint8_t>(), (uint32_t)n, (uint32_t)hash_len, c->d_out.as<uint8_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(out, c->d_out.p, n * hash_len, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
+  return AVRF_OK;
+}
+// Secret::from_seed for n 32-byte seeds: the secret scalars (LE32, canonical) and, when pks_xy_out is given, the public keys
+int avrf_secret_from_seed(avrf_ctx *c, size_t n, const uint8_t *seeds, uint8_t *sks_out, uint8_t *pks_xy_out) {
+  if (!c || (n && (!seeds || !sks_out))) return AVRF_ERR_BAD_ARG;
+  if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;
+  if (!n) return AVRF_OK;
+  if (n > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  c->staged_kind = 0;
+  HIP_TRY(c->d_misc.ensure(n * 32)); HIP_TRY(c->d_sks.ensure(n * 32));
+  HIP_TRY(hipMemcpyAsync(c->d_misc.p, seeds, n * 32, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
+  launch_secret_from_seed(c->suite, c->d_misc.as<uint8_t>(), (uint32_t)n, c->d_sks.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream);
+  HIP_TRY(hipMemcpyAsync(sks_out, c->d_sks.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+  int f = read_flags(c);
+  if (f < 0) return AVRF_ERR_NO_DEVICE;
+  if (f) return AVRF_INVALID_DATA;
+  return pks_xy_out ? smul_common(c, n, sks_out, nullptr, pks_xy_out) : AVRF_OK;
+}
 int avrf_points_compress(avrf_ctx *c, size_t n, const uint8_t *in_xy, uint8_t *out) {
   if (!c || (n && (!in_xy || !out))) return AVRF_ERR_BAD_ARG;
   if (ctx_busy(c)) return AVRF_ERR_BAD_ARG;

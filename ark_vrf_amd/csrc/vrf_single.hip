@@ -1047,6 +1047,47 @@ k_validate_xy(const uint8_t *__restrict__ base, uint32_t stride, uint32_t ppr, u
   if (bad) { atomicOr(flags, (uint32_t)FLAG_CURVE); if (rec_status) rec_status[j] = 2; }
 }
 
+// Output::hash::<N> = Suite::point_to_hash (src/lib.rs:605-609, src/utils/common.rs:290-305, mul_by_cofactor = false):
+// Transcript::new(SUITE_ID) || 0x20 || serialize_compressed(point), first `len` squeezed bytes (len <= 64).
+template <class S>
+__global__ void __launch_bounds__(128)
+k_output_hash(const uint8_t *__restrict__ in_xy, uint32_t n, uint32_t len, uint8_t *__restrict__ out) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const fp x = fp_load_le(in_xy + 64 * (size_t)j), y = fp_load_le(in_xy + 64 * (size_t)j + 32);
+  suite_tr<S> h; tr_init(h);
+  for (int i = 0; i < S::SUITE_ID_LEN; i++) tr_byte(h, S::SUITE_ID[i]);
+  tr_byte(h, DS_POINT_TO_HASH);
+  absorb_point_xy<S>(h, x, y);
+  fp lo, hi; squeeze64(h, lo, hi);
+  uint8_t *o = out + (size_t)len * j;
+  for (uint32_t i = 0; i < len; i++) { const fp &w = i < 32 ? lo : hi; o[i] = (uint8_t)(w.v[(i & 31) >> 2] >> (8 * (i & 3))); }
+}
+// Secret::from_seed (src/lib.rs:346-369): sk0 = seed mod r; scalar = nonce(sk0, Transcript(SUITE_ID || seed [|| cnt])) for the first
+// cnt in 0..255 that gives a non-zero scalar (cnt is absorbed only when > 0).  Writes the canonical scalar; the public key is the
+// caller's avrf_scalar_mul_base (Secret::from_scalar).
+template <class S>
+__global__ void __launch_bounds__(128)
+k_secret_from_seed(const uint8_t *__restrict__ seeds, uint32_t n, uint8_t *__restrict__ sk_out, uint32_t *__restrict__ flags) {
+  using Fr = typename S::Fr;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const uint8_t *sd = seeds + 32 * (size_t)j;
+  const fp raw = fp_load_le(sd);
+  const fp sk0 = fp_from_mont<Fr>(fp_from_wide_mont<Fr>(raw, fp_zero()));      // from_le_bytes_mod_order(seed), canonical
+  fp k = fp_zero(); bool ok = false;
+  for (int cnt = 0; cnt < 256 && !ok; cnt++) {
+    suite_tr<S> t; tr_init(t);
+    for (int i = 0; i < S::SUITE_ID_LEN; i++) tr_byte(t, S::SUITE_ID[i]);
+    absorb_fp_le(t, raw);
+    if (cnt > 0) tr_byte(t, (uint8_t)cnt);
+    k = nonce<S>(sk0, t);
+    ok = !fp_is_zero(k);
+  }
+  if (!ok) atomicOr(flags, 1u);                                                 // (unreachable under standard assumptions, lib.rs:361-366)
+  fp_store_le(sk_out + 32 * (size_t)j, fp_from_mont<Fr>(k));
+}
+
 template <class S>
 __global__ void __launch_bounds__(256)
 k_compress(const uint8_t *__restrict__ in_xy, uint32_t n, uint8_t *__restrict__ out) {
@@ -1153,6 +1194,12 @@ template <class S> void SingleOps<S>::validate_xy(const uint8_t *d_base, uint32_
 template <class S> void SingleOps<S>::compress(const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st) {
   hipLaunchKernelGGL(k_compress<S>, dim3((n + 255) / 256), dim3(256), 0, st, d_in, n, d_out);
 }
+template <class S> void SingleOps<S>::output_hash(const uint8_t *d_in, uint32_t n, uint32_t len, uint8_t *d_out, hipStream_t st) {
+  hipLaunchKernelGGL(k_output_hash<S>, dim3((n + 127) / 128), dim3(128), 0, st, d_in, n, len, d_out);
+}
+template <class S> void SingleOps<S>::secret_from_seed(const uint8_t *d_seeds, uint32_t n, uint8_t *d_sk, uint32_t *d_flags, hipStream_t st) {
+  hipLaunchKernelGGL(k_secret_from_seed<S>, dim3((n + 127) / 128), dim3(128), 0, st, d_seeds, n, d_sk, d_flags);
+}
 template struct SingleOps<suite_by_id<AVRF_TU_SUITE>::type>;
 
 }  // namespace avrf
@@ -1244,6 +1291,14 @@ void launch_validate_xy(int suite, const uint8_t *d_base, uint32_t stride, uint3
 void launch_compress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st) {
   if (!n) return;
   AVRF_SINGLE(suite, compress(d_in, n, d_out, st));
+}
+void launch_output_hash(int suite, const uint8_t *d_in, uint32_t n, uint32_t len, uint8_t *d_out, hipStream_t st) {
+  if (!n) return;
+  AVRF_SINGLE(suite, output_hash(d_in, n, len, d_out, st));
+}
+void launch_secret_from_seed(int suite, const uint8_t *d_seeds, uint32_t n, uint8_t *d_sk, uint32_t *d_flags, hipStream_t st) {
+  if (!n) return;
+  AVRF_SINGLE(suite, secret_from_seed(d_seeds, n, d_sk, d_flags, st));
 }
 
 }  // namespace avrf

@@ -411,6 +411,11 @@ int avrf_hash_to_curve(avrf_ctx *ctx, size_t n, const uint8_t *data, const uint3
  * validate != 0 additionally requires prime-order-subgroup membership and non-identity. */
 size_t avrf_point_len(int suite);
 int avrf_points_decompress(avrf_ctx *ctx, size_t n, const uint8_t *in, uint8_t *out_xy, int validate, int32_t *status_out);
+/* Output::hash::<N> (src/lib.rs:605-609 -> Suite::point_to_hash, src/utils/common.rs:290-305): the VRF output bytes `beta` of n
+ * output points, hash_len = N <= 64 bytes each.  Secret::from_seed (src/lib.rs:346-369) for n 32-byte seeds: the secret scalars
+ * (LE32) and, when pks_xy_out is not NULL, their public keys (Secret::from_scalar). */
+int avrf_output_hash(avrf_ctx *ctx, size_t n, const uint8_t *points_xy, size_t hash_len, uint8_t *out);
+int avrf_secret_from_seed(avrf_ctx *ctx, size_t n, const uint8_t *seeds, uint8_t *sks_out, uint8_t *pks_xy_out);
 int avrf_points_compress(avrf_ctx *ctx, size_t n, const uint8_t *in_xy, uint8_t *out);
 
 /* Secret::from_scalar / Secret::output: sk*G and sk*I for a batch (src/lib.rs:331-334,391-393). */
