@@ -700,7 +700,17 @@ template <class S, class G> struct Ring {
     HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag));
     if (flag) { HIP_CHECK(hipFree(su->d_srs)); delete su; return AVRF_INVALID_DATA; }
     {  // fixed-base window table: T[w][i] = 2^(c w) * tau^i G, all windows of a commit then share one bucket set
-      su->table_c = 12;
+      // window width from the size of the commitments (3N + 1 coefficients): wider windows save bucket additions (k_accumulate:
+      // one per table row and coefficient), narrower ones save bucket REDUCTION (k_bucket_sum + k_wsum: 2^(c-1) buckets per set).
+      // Which wins depends on what else runs: ONE context alone prefers narrow windows (ring 1024, N = 2048, BLS12-381:
+      // c = 12 / 11 / 10 / 9 -> 11.1 / 11.4 / 11.6 / 10.8 k proofs/s -- its latency-bound reductions sit on the critical path),
+      // FOUR contexts sharing the chip, as bench.py and a loaded server run it, hide each other's reductions and pay for
+      // additions only: c = 11 / 12 / 13 -> 13.8 / 14.4 / 13.8 k; BN254 ring 4096 (N = 8192): c = 12 / 13 -> 7.39 / 7.56 k
+      // (tools/ring4_bench.py, tools/scratch/r5_ringsweep*.sh).  The loaded regime decides: c = log2(3N + 1) rounded down
+      // (381-bit curve), one less on the 254-bit curve whose additions are cheaper relative to its reductions.
+      { int lg = 0; while (((size_t)2 << lg) <= pcs) lg++;                    // floor(log2(3N + 1)) = log2(N) + 1
+        su->table_c = G::Fq::N > 8 ? lg : lg - 1;
+        if (su->table_c < 8) su->table_c = 8; if (su->table_c > 13) su->table_c = 13; }
       if (const char *e = getenv("AVRF_RING_TABLE_C")) { int v = atoi(e); if (v >= 4 && v <= 14) su->table_c = v; }
       {
         su->table_nwin = (G::Fr::BITS + 1 + su->table_c - 1) / su->table_c;
