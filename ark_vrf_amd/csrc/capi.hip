@@ -294,8 +294,75 @@ int ctx_stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint8_t
   c->staged_kind = kind;
   return AVRF_OK;
 }
+// The wire flavour of the batch verifiers' staging (src/thin.rs:78-94, src/pedersen.rs:106-134 deserialise, then
+// `push`): the caller's `serialize_compressed` bytes go to the device as they are, every point is decompressed (validate: + not the
+// identity, + prime-order subgroup, src/lib.rs:410-433) STRAIGHT INTO the context's staged x || y buffers, the proofs' scalars are
+// copied beside their points -- no decompressed byte crosses PCIe or a host core.  A point that fails makes the batch InvalidData
+// here, before any equation (as the reference's deserialisation would).  kind 1 thin (pk, R || s), 2 pedersen (Yb, R, Ok || s || sb).
+int ctx_stage_wire(avrf_ctx *c, int kind, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                   const uint32_t *ad_lens, const uint8_t *proofs, int validate) {
+  if (!c || c->run_phase || (kind != 1 && kind != 2)) return AVRF_ERR_BAD_ARG;
+  if (n && (!io_counts || !ad_lens || !proofs || (kind == 1 && !pks))) return AVRF_ERR_BAD_ARG;
+  if (n > 0x0fffffffULL) return AVRF_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  c->staged_kind = 0; c->n = n; c->tot_io = 0; c->n_terms = 0; c->stage_gen++;
+  if (n == 0) { c->staged_kind = kind; return AVRF_OK; }
+  HIP_TRY(c->h_io.ensure((n + 1) * 8));
+  uint32_t *io_off = c->h_io.as<uint32_t>(), *ad_off = io_off + (n + 1);
+  uint64_t a = 0, b = 0;
+  for (size_t j = 0; j < n; j++) { io_off[j] = (uint32_t)a; ad_off[j] = (uint32_t)b; a += io_counts[j]; b += ad_lens[j]; }
+  if (a > 0x1fffffffULL || b > 0x7fffffffULL) return AVRF_ERR_BAD_ARG;
+  if ((a && !ios) || (b && !ads)) return AVRF_ERR_BAD_ARG;
+  io_off[n] = (uint32_t)a; ad_off[n] = (uint32_t)b;
+  c->tot_io = (size_t)a;
+  const size_t L = (size_t)point_len_of(c->suite), ppts = kind == 1 ? 1 : 3, tail = kind == 1 ? 32 : 64, plen = ppts * L + tail, psz = kind == 1 ? 96 : 256;
+  const size_t w_pks = kind == 1 ? n * L : 0, w_ios = 2 * (size_t)a * L, w_pr = n * plen;
+  HIP_TRY(c->d_io_off.ensure((n + 1) * 4)); HIP_TRY(c->d_ad_off.ensure((n + 1) * 4));
+  HIP_TRY(c->d_ios.ensure(a * 128 + 16)); HIP_TRY(c->d_ads.ensure(b + 16)); HIP_TRY(c->d_proofs.ensure(n * psz));
+  if (kind == 1) HIP_TRY(c->d_pks.ensure(n * 64));
+  HIP_TRY(c->d_misc.ensure(w_pks + w_ios + w_pr + 64)); HIP_TRY(c->d_status.ensure(64));
+  uint8_t *dw = c->d_misc.as<uint8_t>();
+  HIP_TRY(hipMemcpyAsync(c->d_io_off.p, io_off, (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_ad_off.p, ad_off, (n + 1) * 4, hipMemcpyHostToDevice, c->stream));
+  if (b) HIP_TRY(hipMemcpyAsync(c->d_ads.p, ads, b, hipMemcpyHostToDevice, c->stream));
+  if (w_pks) HIP_TRY(hipMemcpyAsync(dw, pks, w_pks, hipMemcpyHostToDevice, c->stream));
+  if (w_ios) HIP_TRY(hipMemcpyAsync(dw + w_pks, ios, w_ios, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(dw + w_pks + w_ios, proofs, w_pr, hipMemcpyHostToDevice, c->stream));
+  uint32_t *d_flag = c->d_status.as<uint32_t>(), *h_flag = c->h_flags.as<uint32_t>() + 2;
+  HIP_TRY(hipMemsetAsync(d_flag, 0, 4, c->stream));
+  if (kind == 1) launch_decompress_strided(c->suite, dw, (uint32_t)L, (uint32_t)n, c->d_pks.as<uint8_t>(), 64, validate, d_flag, c->stream);
+  launch_decompress_strided(c->suite, dw + w_pks, (uint32_t)L, (uint32_t)(2 * a), c->d_ios.as<uint8_t>(), 64, validate, d_flag, c->stream);
+  const uint8_t *dpr = dw + w_pks + w_ios;
+  for (size_t p = 0; p < ppts; p++)
+    launch_decompress_strided(c->suite, dpr + L * p, (uint32_t)plen, (uint32_t)n, c->d_proofs.as<uint8_t>() + 64 * p, (uint32_t)psz, validate, d_flag, c->stream);
+  HIP_TRY(hipMemcpy2DAsync(c->d_proofs.as<uint8_t>() + 64 * ppts, psz, dpr + L * ppts, plen, tail, n, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+  if (suite_host_weights(c->suite)) {
+    const size_t rsz = kind == 1 ? 32 : 64, roff = ppts * L;
+    c->h_resp.resize(n * rsz);
+    for (size_t j = 0; j < n; j++) memcpy(&c->h_resp[rsz * j], proofs + plen * j + roff, rsz);
+  }
+  c->n_terms = kind == 1 ? 2 * n + 2 * c->tot_io + 1 : 5 * n + 2;
+  HIP_TRY(c->d_c.ensure(n * 16)); HIP_TRY(c->h_c.ensure(n * 16));
+  HIP_TRY(c->d_z.ensure(kind == 1 ? c->tot_io * 16 + 16 : n * 128));
+  if (c->lane_owner) { HIP_TRY(c->L->d_scalars.ensure(c->n_terms * 32)); HIP_TRY(c->L->d_pre.ensure(c->n_terms * sizeof(te_pre_raw))); HIP_TRY(c->L->d_gpart.ensure(((n + 127) / 128) * 64 + 64)); }
+  HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
+  if (*h_flag) return AVRF_INVALID_DATA;
+  c->staged_kind = kind;
+  return AVRF_OK;
+}
 }  // namespace avrf
 extern "C" {
+int avrf_thin_batch_stage_wire(avrf_ctx *c, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                               const uint32_t *ad_lens, const uint8_t *proofs, int validate) {
+  if (!c || ctx_busy(c)) return AVRF_ERR_BAD_ARG;
+  return avrf::ctx_stage_wire(c, 1, n, pks, ios, io_counts, ads, ad_lens, proofs, validate);
+}
+int avrf_pedersen_batch_stage_wire(avrf_ctx *c, size_t n, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                                   const uint32_t *ad_lens, const uint8_t *proofs, int validate) {
+  if (!c || ctx_busy(c)) return AVRF_ERR_BAD_ARG;
+  return avrf::ctx_stage_wire(c, 2, n, nullptr, ios, io_counts, ads, ad_lens, proofs, validate);
+}
 static int stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy,
                  const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
   return ctx_stage(c, kind, n, sks, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs, true);

@@ -114,6 +114,13 @@ int wire_finish(avrf_ctx *ctx, WirePrep &w, int32_t *status_out) {
 int verify_wire(avrf_ctx *ctx, int kind, bool batch, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
                 const uint32_t *ad_lens, const uint8_t *proofs, int validate, int32_t *status_out,
                 std::vector<uint8_t> *pp0_xy = nullptr, std::vector<int32_t> *pp0_st = nullptr) {
+  if (batch && !pp0_xy && !pp0_st && (kind == 1 || kind == 2)) {
+    // BatchVerifier from wire bytes: decompression on the device straight into the staged buffers (capi.hip ctx_stage_wire), then the run
+    int rc = kind == 1 ? avrf_thin_batch_stage_wire(ctx, n, pks, ios, io_counts, ads, ad_lens, proofs, validate)
+                       : avrf_pedersen_batch_stage_wire(ctx, n, ios, io_counts, ads, ad_lens, proofs, validate);
+    if (rc != AVRF_OK) return rc;
+    return kind == 1 ? avrf_thin_batch_run(ctx) : avrf_pedersen_batch_run(ctx);
+  }
   WirePrep w;
   int rc = wire_prepare(ctx, kind, batch, n, pks, ios, io_counts, ads, ad_lens, proofs, validate, status_out != nullptr, w, pp0_xy, pp0_st);
   if (rc != AVRF_OK || !n) return rc;

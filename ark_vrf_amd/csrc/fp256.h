@@ -351,6 +351,45 @@ template <class F> AVRF_DN fp fp_pow_nf(fp a, int which) {   // which: 0 -> T_MI
   }
   return r;
 }
+// sqrt(u / v) without an inversion and without a data-dependent loop (the lanes of a wave decompress 64 different points: the
+// classic Tonelli-Shanks loop below runs every lane for the LONGEST of their discrete-log walks -- up to 32 x 32 squarings on a field
+// with 2-adicity 32 -- and the quotient cost a ~45 k-instruction inversion first).  With p - 1 = 2^s t, a = u v, w = a^((t-1)/2):
+//   a w^2 = a^t = g^e (g = ROOT, order 2^s),     1 / sqrt(a) = w g^(-e/2),     sqrt(u / v) = u / sqrt(u v) = u w g^(-e/2);
+// e is read in 4-bit windows from the low end: the window's value is the j with c^(2^(s - 4i - w)) = h^j (16 compares), then
+// c <- c g^(-j 16^i) (tables SQRT_H / SQRT_G / SQRT_GH of consts_gen.h, tools/gen_consts.py).  112 squarings + 16 products for
+// s = 32 after the one fixed exponentiation; the same instruction stream in every lane.  Returns false when u / v is not a square
+// (e odd), and checks x^2 v = u.  u = 0 gives x = 0; v = 0 is the caller's case.
+template <class F> AVRF_DN bool fp_sqrt_ratio_nf(fp u, fp v, fp *out) {
+  constexpr int S = F::TWO_ADICITY;
+  const fp a = fp_mul_nf<F>(u, v);
+  const fp w = fp_pow_nf<F>(a, 0);                                   // a^((t-1)/2)
+  fp c = fp_mul_nf<F>(a, fp_mul_nf<F>(w, w));                        // a^t, in the group of 2^s-th roots of unity
+  fp r = fp_mul_nf<F>(u, w);
+  bool odd = false;
+#pragma unroll 1
+  for (int i = 0; i < F::SQRT_STEPS; i++) {
+    const int wd = S - 4 * i < 4 ? S - 4 * i : 4;                    // bits of this window
+    fp d = c;
+#pragma unroll 1
+    for (int k = 0; k < S - 4 * i - wd; k++) d = fp_mul_nf<F>(d, d);
+    uint32_t j = 0;
+#pragma unroll 1
+    for (uint32_t cand = 1; cand < (1u << wd); cand++) {
+      uint32_t o = 0;
+#pragma unroll
+      for (int l = 0; l < 8; l++) o |= d.v[l] ^ F::SQRT_H[(cand << ((S < 4 ? S : 4) - wd)) & 15][l];   // SQRT_H holds the 2^min(4, s)-th roots
+      j = o == 0 ? cand : j;
+    }
+    if (i == 0 && (j & 1u)) odd = true;
+    fp gs, gh;
+#pragma unroll
+    for (int l = 0; l < 8; l++) { gs.v[l] = F::SQRT_G[i][j][l]; gh.v[l] = F::SQRT_GH[i][j][l]; }
+    c = fp_mul_nf<F>(c, gs);
+    r = fp_mul_nf<F>(r, gh);
+  }
+  *out = r;
+  return !odd && fp_eq(fp_mul_nf<F>(fp_mul_nf<F>(r, r), v), u);
+}
 // Tonelli-Shanks, out-of-line (see fp_sqrt)
 template <class F> AVRF_DN bool fp_sqrt_nf(fp a, fp *out) {
   if (fp_is_zero(a)) { *out = a; return true; }

@@ -55,6 +55,7 @@ void launch_ped_prove(int suite, const BatchDev &b, uint8_t *d_proofs_out, uint8
 void launch_ped_verify(int suite, const BatchDev &b, int32_t *d_status, hipStream_t st);
 
 void launch_hash_to_curve(int suite, const uint8_t *d_data, const uint32_t *d_off, uint32_t n, uint8_t *d_out, int32_t *d_status, hipStream_t st);
+void launch_decompress_strided(int suite, const uint8_t *d_in, uint32_t in_stride, uint32_t n, uint8_t *d_out, uint32_t out_stride, int validate, uint32_t *d_flags, hipStream_t st);
 void launch_output_hash(int suite, const uint8_t *d_in_xy, uint32_t n, uint32_t len, uint8_t *d_out, hipStream_t st);     // Output::hash, src/lib.rs:605-609
 void launch_secret_from_seed(int suite, const uint8_t *d_seeds, uint32_t n, uint8_t *d_sk, uint32_t *d_flags, hipStream_t st);   // Secret::from_seed, src/lib.rs:346-369
 void launch_decompress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, int validate, int32_t *d_status, hipStream_t st);
@@ -102,6 +103,7 @@ template <class S> struct SingleOps {
   static void validate_xy(const uint8_t *d_base, uint32_t stride, uint32_t ppr, uint32_t nrec, int level, uint32_t *d_flags,
                           int32_t *d_rec_status, hipStream_t st, const uint32_t *d_item_off, uint32_t n_items);
   static void compress(const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st);
+  static void decompress_strided(const uint8_t *d_in, uint32_t in_stride, uint32_t n, uint8_t *d_out, uint32_t out_stride, int validate, uint32_t *d_flags, hipStream_t st);
   static void output_hash(const uint8_t *d_in, uint32_t n, uint32_t len, uint8_t *d_out, hipStream_t st);
   static void secret_from_seed(const uint8_t *d_seeds, uint32_t n, uint8_t *d_sk, uint32_t *d_flags, hipStream_t st);
 };

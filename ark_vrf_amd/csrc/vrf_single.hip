@@ -898,13 +898,16 @@ k_hash_to_curve(const uint8_t *__restrict__ data, const uint32_t *__restrict__ o
 }
 
 // decode point j of `in`: Montgomery (xm, ym), canonical (x, y) for the output, status 0 / 2; *check = the subgroup test is still due
+template <class S> AVRF_DI int32_t decode_point_at(const uint8_t *__restrict__ src, int validate, fp &xm, fp &ym, fp &x, fp &y, bool &check);
 template <class S> AVRF_DI int32_t decode_point(const uint8_t *__restrict__ in, uint32_t j, int validate, fp &xm, fp &ym, fp &x, fp &y, bool &check) {
+  return decode_point_at<S>(in + (size_t)S::POINT_LEN * j, validate, xm, ym, x, y, check);
+}
+template <class S> AVRF_DI int32_t decode_point_at(const uint8_t *__restrict__ src, int validate, fp &xm, fp &ym, fp &x, fp &y, bool &check) {
   using Fq = typename S::Fq;
   check = false;
   if constexpr (S::SW_CODEC) {
     // SWAffine::deserialize_compressed (33 bytes; unused flag bits and the infinity flag are rejected: the point at infinity has
     // no twisted-Edwards image, sw_to_te -> None, and the reference's verifiers refuse the identity anyway)
-    const uint8_t *src = in + 33 * (size_t)j;
     fp xs;
     for (int i = 0; i < 8; i++) xs.v[i] = (uint32_t)src[4 * i] | ((uint32_t)src[4 * i + 1] << 8) | ((uint32_t)src[4 * i + 2] << 16) | ((uint32_t)src[4 * i + 3] << 24);
     const uint8_t flag = src[32];
@@ -915,7 +918,7 @@ template <class S> AVRF_DI int32_t decode_point(const uint8_t *__restrict__ in, 
     x = fp_from_mont<Fq>(xm); y = fp_from_mont<Fq>(ym);
     return st;
   }
-  y = fp_load_le(in + 32 * (size_t)j);
+  y = fp_load_le(src);
   bool neg = (y.v[7] >> 31) != 0; y.v[7] &= 0x7fffffffu;
   int32_t st = 0;
   x = fp_zero(); xm = fp_zero(); ym = fp_zero();
@@ -926,7 +929,7 @@ template <class S> AVRF_DI int32_t decode_point(const uint8_t *__restrict__ in, 
     fp num = fp_sub<Fq>(one, y2);
     fp a_const = mul_a<S>(one);   // the curve coefficient a (1, -5 or -1)
     fp den = fp_sub<Fq>(a_const, fp_mul<Fq>(fp_const<Fq>(S::D), y2));
-    if (fp_is_zero(den) || !fp_sqrt_nf<Fq>(fp_mul<Fq>(num, fp_inv<Fq>(den)), &xm)) st = 2;
+    if (fp_is_zero(den) || !fp_sqrt_ratio_nf<Fq>(num, den, &xm)) st = 2;      // x^2 = (1 - y^2) / (a - d y^2): no inversion, no data-dependent loop
     else {
       if (fp_is_negative_mont<Fq>(xm) != neg) xm = fp_neg<Fq>(xm);
       if (fp_is_zero(xm) && neg) st = 2;
@@ -957,6 +960,29 @@ k_decompress(const uint8_t *__restrict__ in, uint32_t n, uint8_t *__restrict__ o
   }
   fp_store_le(out_xy + 64 * (size_t)j, x); fp_store_le(out_xy + 64 * (size_t)j + 32, y);
   status[j] = st;
+}
+// The same decoding for points that sit INSIDE wire records (a proof's R at the head of `R || s`) and go INTO staged records (the
+// x || y proof layout): point j is read at in + j * in_stride and written at out + j * out_stride; a point that does not decode --
+// or, with validate, is the identity or outside the prime-order subgroup -- raises FLAG_CURVE in *flags (InvalidData for the batch).
+// This is what lets the wire flavour of the batch verifiers stage straight into a context's device buffers (capi.hip ctx_stage_wire).
+template <class S>
+__global__ void __launch_bounds__(128)
+k_decompress_strided(const uint8_t *__restrict__ in, uint32_t in_stride, uint32_t n, uint8_t *__restrict__ out_xy, uint32_t out_stride, int validate,
+                     uint32_t *__restrict__ flags) {
+  using Fr = typename S::Fr;
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  fp xm, ym, x, y; bool check;
+  int32_t st = decode_point_at<S>(in + (size_t)in_stride * j, validate, xm, ym, x, y, check);
+  if (check) {
+    if constexpr (S::HAS_2DESCENT) { if (!te_in_subgroup_2descent<S>(ym)) st = 2; }
+    else {
+      te_ext rp = te_smul<S>(te_make_pre<S>(xm, ym), fp_const<Fr>(Fr::P), Fr::BITS);
+      if (!te_is_identity<S>(rp)) st = 2;
+    }
+  }
+  fp_store_le(out_xy + (size_t)out_stride * j, x); fp_store_le(out_xy + (size_t)out_stride * j + 32, y);
+  if (st) atomicOr(flags, (uint32_t)FLAG_CURVE);
 }
 // few points with the subgroup test: FOUR lanes per point -- the decoding is computed alike by the four lanes, r P runs as one
 // quad scalar multiplication (te_quad.h: 85 windows of three doublings and an addition, 0.6 ms instead of 1.7 ms on one lane)
@@ -1191,6 +1217,9 @@ template <class S> void SingleOps<S>::validate_xy(const uint8_t *d_base, uint32_
   const uint32_t tot = nrec * ppr;
   hipLaunchKernelGGL(k_validate_xy<S>, dim3((tot + 127) / 128), dim3(128), 0, st, d_base, stride, ppr, nrec, level, d_flags, d_rec_status, d_item_off, n_items);
 }
+template <class S> void SingleOps<S>::decompress_strided(const uint8_t *d_in, uint32_t in_stride, uint32_t n, uint8_t *d_out, uint32_t out_stride, int validate, uint32_t *d_flags, hipStream_t st) {
+  hipLaunchKernelGGL(k_decompress_strided<S>, dim3((n + 127) / 128), dim3(128), 0, st, d_in, in_stride, n, d_out, out_stride, validate, d_flags);
+}
 template <class S> void SingleOps<S>::compress(const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st) {
   hipLaunchKernelGGL(k_compress<S>, dim3((n + 255) / 256), dim3(256), 0, st, d_in, n, d_out);
 }
@@ -1287,6 +1316,10 @@ void launch_validate_xy(int suite, const uint8_t *d_base, uint32_t stride, uint3
                         int32_t *d_rec_status, hipStream_t st, const uint32_t *d_item_off, uint32_t n_items) {
   if (!nrec || !ppr || level <= 0) return;
   AVRF_SINGLE(suite, validate_xy(d_base, stride, ppr, nrec, level, d_flags, d_rec_status, st, d_item_off, n_items));
+}
+void launch_decompress_strided(int suite, const uint8_t *d_in, uint32_t in_stride, uint32_t n, uint8_t *d_out, uint32_t out_stride, int validate, uint32_t *d_flags, hipStream_t st) {
+  if (!n) return;
+  AVRF_SINGLE(suite, decompress_strided(d_in, in_stride, n, d_out, out_stride, validate, d_flags, st));
 }
 void launch_compress(int suite, const uint8_t *d_in, uint32_t n, uint8_t *d_out, hipStream_t st) {
   if (!n) return;

@@ -432,6 +432,14 @@ int avrf_scalar_mul(avrf_ctx *ctx, size_t n, const uint8_t *scalars, const uint8
  * A point that fails gives AVRF_INVALID_DATA (for its item in the per-item calls) before any equation is evaluated.
  * These calls decompress on the device (avrf_points_decompress) and then run the xy entry points above: the xy flavour is
  * the fast path for callers that hold deserialised points, as the reference's own benches do (benches/thin.rs:46-90). */
+/* Staging from wire bytes for the three-call run (avrf_*_batch_stage_wire, then avrf_thin_batch_run / avrf_pedersen_batch_run or
+ * avrf_batch_run_begin / _hash / _end): every point is decompressed (and validated) on the device straight into the context's
+ * staged buffers; AVRF_INVALID_DATA when a point does not decode / fails validation (nothing is staged then).  The *_batch_verify_wire
+ * entry points below are exactly stage_wire + run. */
+int avrf_thin_batch_stage_wire(avrf_ctx *ctx, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                               const uint32_t *ad_lens, const uint8_t *proofs, int validate);
+int avrf_pedersen_batch_stage_wire(avrf_ctx *ctx, size_t n, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                                   const uint32_t *ad_lens, const uint8_t *proofs, int validate);
 int avrf_thin_batch_verify_wire(avrf_ctx *ctx, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
                                 const uint32_t *ad_lens, const uint8_t *proofs, int validate);
 int avrf_thin_verify_wire(avrf_ctx *ctx, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,

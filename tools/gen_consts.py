@@ -40,6 +40,28 @@ def field(name, p):
     s.append(f"  static constexpr uint32_t T_MINUS1_HALF[8] = {{{limbs((t - 1) // 2)}}};")
     s.append(f"  static constexpr uint32_t ROOT[8] = {{{limbs(pow(g, t, p) * R % p)}}};  /* g^t, Montgomery */")
     s.append(f"  static constexpr uint32_t PM2[8] = {{{limbs(p - 2)}}};  /* p-2 (inversion exponent) */")
+    if name.startswith("Fq"):
+        # Branch-free square roots (fp256.h fp_sqrt_ratio_nf): with p - 1 = 2^s t and g = ROOT of order 2^s, a^t = g^e for every
+        # a != 0; e is read off in windows of 4 bits from the low end (Pohlig-Hellman in the 2-group): the window's value j is
+        # found by comparing c^(2^(s - 4i - w)) with the 2^w-th roots of unity SQRT_H, then stripped by SQRT_G[i][j] = g^(-j 16^i);
+        # SQRT_GH[i][j] = g^(-j 16^i / 2) accumulates g^(-e/2) (e odd <=> a is a non-residue: window 0 shows it).
+        steps = (tw + 3) // 4
+        gg = pow(g, t, p)
+        ginv = pow(gg, -1, p)
+        h = pow(gg, 1 << max(0, tw - 4), p) if tw >= 4 else gg            # order 2^min(4, s)
+        hw = min(4, tw)
+        s.append(f"  static constexpr int SQRT_STEPS = {steps};")
+        s.append(f"  static constexpr uint32_t SQRT_H[16][8] = {{" + ", ".join("{" + limbs(pow(h, j, p) * R % p if j < (1 << hw) else 0) + "}" for j in range(16)) + "};  /* h^j, h = g^(2^(s-4)) */")
+        rows_g, rows_gh = [], []
+        for i in range(steps):
+            rg, rgh = [], []
+            for j in range(16):
+                e = j << (4 * i)
+                rg.append("{" + limbs(pow(ginv, e, p) * R % p) + "}")
+                rgh.append("{" + limbs((pow(ginv, e // 2, p) if e % 2 == 0 else 0) * R % p) + "}")
+            rows_g.append("{" + ", ".join(rg) + "}"); rows_gh.append("{" + ", ".join(rgh) + "}")
+        s.append(f"  static constexpr uint32_t SQRT_G[{steps}][16][8] = {{" + ",\n    ".join(rows_g) + "};")
+        s.append(f"  static constexpr uint32_t SQRT_GH[{steps}][16][8] = {{" + ",\n    ".join(rows_gh) + "};")
     s.append("};")
     return "\n".join(s)
 

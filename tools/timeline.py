@@ -35,11 +35,13 @@ rows.sort()
 t0, t1 = rows[0][0], max(r[1] for r in rows)
 # the busiest window of W ms (default 600): the timed region of the bench, not its warm-up / latency / end-to-end phases
 W = (float(sys.argv[2]) if len(sys.argv) > 2 else 600.0) * 1e6
-starts = [a for a, b, n in rows if n == "k_accumulate"]
-best, j = (0, t0), 0
-for i, a in enumerate(starts):
-    while starts[j] < a - W: j += 1
-    if i - j + 1 > best[0]: best = (i - j + 1, starts[j])
+acc_iv = sorted((a, b) for a, b, n in rows if n == "k_accumulate")
+best, j, run = (0, t0), 0, 0                                  # the window in which k_accumulate accumulates the most running time
+for i, (a, b) in enumerate(acc_iv):
+    run += b - a
+    while acc_iv[j][0] < a - W:
+        run -= acc_iv[j][1] - acc_iv[j][0]; j += 1
+    if run > best[0]: best = (run, acc_iv[j][0])
 lo, hi = best[1], best[1] + W
 rows = [(max(a, lo), min(b, hi), n) for a, b, n in rows if b > lo and a < hi]
 wall = hi - lo

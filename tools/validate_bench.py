@@ -47,6 +47,22 @@ for v in (0, 1):
     for _ in range(reps):
         assert L.avrf_thin_batch_verify_wire(*args, v) == 0
     out[f"thin_batch_verify_wire_validate{v}_per_sec"] = reps * n / (time.perf_counter() - t)
+# the same entry point from several caller threads, one context each (the sequential weight transcript of a batch, 3.5 ms of one
+# host core, is what a single caller waits for; independent callers overlap theirs)
+from concurrent.futures import ThreadPoolExecutor
+for nthreads in (4, 8, 12):
+    ctxs = [nat.Context(0) for _ in range(nthreads)]
+    argl = [(cx._h,) + args[1:] for cx in ctxs]
+    for v in (0, 1):
+        def work(i, v=v):
+            for _ in range(4):
+                assert L.avrf_thin_batch_verify_wire(*argl[i], v) == 0
+        with ThreadPoolExecutor(nthreads) as ex:
+            list(ex.map(work, range(nthreads)))                       # warm-up
+            t = time.perf_counter(); list(ex.map(work, range(nthreads))); dt = time.perf_counter() - t
+        out[f"thin_batch_verify_wire_validate{v}_{nthreads}_callers_per_sec"] = nthreads * 4 * n / dt
+    for cx in ctxs:
+        cx.close()
 cp, st = None, None
 t = time.perf_counter(); xy, st = ctx.points_decompress(pks_c + ios_c, validate=True); dt = time.perf_counter() - t
 out["points_decompress_validate1_points_per_sec"] = 3 * n / dt
