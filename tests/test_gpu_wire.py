@@ -245,3 +245,51 @@ def test_empty_and_bad_arguments(ctxs, golden_dir):
     assert L.avrf_ring_vrf_verify(c._h, setup._h, C.c_size_t(0), None, C.c_size_t(0), None, None, None, None, None, None, 1, 1, None) == 0
     assert L.avrf_ctx_set_validation(c._h, 7) == nat.ERR_BAD_ARG
     setup.close()
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_batch_stage_wire_full_size(ctxs, kind):
+    """BASELINE configs[1] / [2] from `serialize_compressed` bytes: avrf_*_batch_stage_wire decompresses (and validates) all
+    4 x 65 536 / 5 x 65 536 points on the device straight into the staged buffers; the staged batch then IS the x || y batch -- same
+    terms, same verdicts (one-call run and the three-call run), a tampered scalar fails, a point that does not decode / a torsion
+    point under Validate::Yes is InvalidData and leaves nothing staged."""
+    from ark_vrf_amd import _native as nat
+    from helpers import compressed_items, nat_batch
+    c = ctxs[0]
+    n = 65536
+    b = orc.gen_batch(0, kind, n, threads=16)
+    if kind == 1:
+        b["pks_xy"] = b""
+    pks, ios, ads, proofs = compressed_items(0, b, kind)
+    L = nat.lib()
+    io_b = nat._u8(b"".join(i + o for it in ios for i, o in it)); cnt = nat._u32([1] * n); ad_b = nat._u8(b"".join(ads)); adl = nat._u32([len(a) for a in ads])
+
+    def stage(pks_l, proofs_l, validate, io_buf=io_b):
+        if kind == 0:
+            return L.avrf_thin_batch_stage_wire(c._h, C.c_size_t(n), nat._u8(b"".join(pks_l)), io_buf, cnt, ad_b, adl, nat._u8(b"".join(proofs_l)), validate)
+        return L.avrf_pedersen_batch_stage_wire(c._h, C.c_size_t(n), io_buf, cnt, ad_b, adl, nat._u8(b"".join(proofs_l)), validate)
+    run = c.thin_batch_run if kind == 0 else c.pedersen_batch_run
+    # the xy batch's terms, then the wire-staged batch's terms: identical
+    assert (c.thin_batch_stage if kind == 0 else c.pedersen_batch_stage)(nat_batch(b)) == 0 and run() == 0
+    want_terms = c.last_terms()
+    for validate in (0, 1):
+        assert stage(pks, proofs, validate) == 0 and run() == 0
+        assert c.last_terms() == want_terms
+    assert stage(pks, proofs, 1) == 0
+    assert c.batch_run_begin() == 0 and c.batch_run_hash() == 0 and c.batch_run_end() == 0       # the three-call run on a wire-staged batch
+    # tampered response scalar of item 40 000
+    j = 40000
+    p2 = list(proofs); p2[j] = proofs[j][:-20] + bytes([proofs[j][-20] ^ 1]) + proofs[j][-19:]
+    assert stage(pks, p2, 1) == 0 and run() == 1
+    # a y with no x on the curve in the LAST proof; a torsion point (x, y) -> (-x, -y) as an output point
+    bad_y = next(k.to_bytes(32, "little") for k in range(2, 300) if orc.point_decompress(0, k.to_bytes(32, "little"))[0] != 0)
+    p3 = list(proofs); p3[n - 1] = bad_y + proofs[n - 1][32:]
+    assert stage(pks, p3, 0) == 2
+    assert run() == -2                                                                            # nothing staged: BAD_ARG
+    q = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    st, oxy = orc.point_decompress(0, ios[123][0][1])
+    tors = orc.point_compress(0, ((q - int.from_bytes(oxy[:32], "little")) % q).to_bytes(32, "little") + ((q - int.from_bytes(oxy[32:], "little")) % q).to_bytes(32, "little"))
+    ios_t = list(ios); ios_t[123] = [(ios[123][0][0], tors)]
+    io_t = nat._u8(b"".join(i + o for it in ios_t for i, o in it))
+    assert stage(pks, proofs, 1, io_t) == 2                                                        # Validate::Yes: InvalidData before any equation
+    assert stage(pks, proofs, 0, io_t) == 0 and run() in (0, 1)                                    # Validate::No: it decodes; the verdict is the equation's
