@@ -71,6 +71,12 @@ struct Secret {                          // src/lib.rs:258
     if (avrf_scalar_mul_base(s.ctx(), 1, sk.data(), r.public_key.point.data()) != AVRF_OK) throw std::invalid_argument("avrf: bad scalar");
     return r;
   }
+  // Secret::from_seed (src/lib.rs:346-369): the scalar is derived from the seed by the suite's transcript, on the device
+  static Secret from_seed(const Suite &s, const std::array<uint8_t, 32> &seed) {
+    Secret r;
+    if (avrf_secret_from_seed(s.ctx(), 1, seed.data(), r.scalar.data(), r.public_key.point.data()) != AVRF_OK) throw std::invalid_argument("avrf: from_seed");
+    return r;
+  }
   // Secret::output / vrf_io (src/lib.rs:391-401)
   VrfIo vrf_io(const Suite &s, const Point &input) const {
     VrfIo io; io.input = input;
@@ -78,6 +84,13 @@ struct Secret {                          // src/lib.rs:258
     return io;
   }
 };
+
+// Output::hash::<32> (src/lib.rs:605-609): the VRF output bytes of an output point
+inline std::array<uint8_t, 32> output_hash(const Suite &s, const Point &output) {
+  std::array<uint8_t, 32> h{};
+  if (avrf_output_hash(s.ctx(), 1, output.data(), 32, h.data()) != AVRF_OK) throw std::invalid_argument("avrf: output hash");
+  return h;
+}
 
 namespace detail {
 // flattens {ios per item, ad per item} into the C-ABI layout

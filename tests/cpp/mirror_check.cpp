@@ -27,6 +27,12 @@ int main(int argc, char **argv) {
   Public pub = secret.public_key;
   VrfIo io = secret.vrf_io(su, in);
   put("pk", pub.point); put("output", io.output);
+  put("beta", output_hash(su, io.output));                               // Output::hash::<32>, src/lib.rs:605-609
+  if (argc > 5) {                                                        // Secret::from_seed, src/lib.rs:346-369
+    std::array<uint8_t, 32> seed{}; auto sb = unhex(argv[5]); std::copy(sb.begin(), sb.end(), seed.begin());
+    Secret fs = Secret::from_seed(su, seed);
+    put("seed_sk", fs.scalar); put("seed_pk", fs.public_key.point);
+  }
 
   tiny::Proof yp = tiny::prove(su, secret, {io}, ad);                    // src/tiny.rs tests: prove_verify
   put("tiny_c", yp.c); put("tiny_s", yp.s);

@@ -28,12 +28,14 @@ def test_mirror_reproduces_vectors(exe, golden_dir, suite):
     vt = json.load(open(os.path.join(golden_dir, NAMES[suite] + "_thin.json")))
     vp = json.load(open(os.path.join(golden_dir, NAMES[suite] + "_pedersen.json")))
     vy = json.load(open(os.path.join(golden_dir, NAMES[suite] + "_tiny.json")))
-    for t, p, y in list(zip(vt, vp, vy))[:3]:
-        res = subprocess.run([exe, str(suite), t["sk"], xy(suite, bytes.fromhex(t["h"])).hex(), t["ad"] or ""],
+    for i, (t, p, y) in enumerate(list(zip(vt, vp, vy))[:3]):
+        seed = bytes([[1, 2, 3, 4, 5, 5, 6][i]]) + bytes(31)              # src/testing.rs: the vectors' secrets come from these seeds
+        res = subprocess.run([exe, str(suite), t["sk"], xy(suite, bytes.fromhex(t["h"])).hex(), t["ad"] or "", seed.hex()],
                              capture_output=True, text=True, check=True).stdout
         kv = dict(line.split("=", 1) for line in res.strip().splitlines())
         comp = lambda k: orc.point_compress(suite, bytes.fromhex(kv[k])).hex()
         assert comp("pk") == t["pk"] and comp("output") == t["gamma"]
+        assert kv["beta"] == t["beta"] and kv["seed_sk"] == t["sk"] and comp("seed_pk") == t["pk"]   # Output::hash, Secret::from_seed
         assert kv["tiny_c"] == y["proof_c"] and kv["tiny_s"] == y["proof_s"]
         assert [kv[k] for k in ("tiny_verify", "tiny_verify_bad_ad", "tiny_verify_bad_c")] == ["0", "1", "1"]
         assert comp("thin_r") == t["proof_r"] and kv["thin_s"] == t["proof_s"]
