@@ -372,6 +372,15 @@ class Pool:
         self._keep[t.value] = b
         return t.value
 
+    def submit_wire(self, b, validate=1):
+        """b: a Batch / PinnedBatch whose pks_xy / ios_xy / proofs fields hold the WIRE bytes (compressed points)"""
+        t = C.c_uint64(0)
+        st = lib().avrf_pool_submit_wire(self._h, C.c_size_t(b.n), b.pks_xy, b.ios_xy, b.io_counts, b.ads, b.ad_lens, b.proofs, int(validate), C.byref(t))
+        if st != OK:
+            raise AvrfError(f"avrf_pool_submit_wire -> {st}")
+        self._keep[t.value] = b
+        return t.value
+
     def wait(self, ticket):
         s = C.c_int(0)
         st = lib().avrf_pool_wait(self._h, C.c_uint64(ticket), C.byref(s))

@@ -258,7 +258,7 @@ int ctx_stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint8_t
   if (n && (!io_counts || !ad_lens)) return AVRF_ERR_BAD_ARG;
   if (n > 0x0fffffffULL) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
-  c->staged_kind = 0; c->n = n; c->tot_io = 0; c->n_terms = 0; c->stage_gen++;
+  c->staged_kind = 0; c->n = n; c->tot_io = 0; c->n_terms = 0; c->stage_gen++; c->wire_pending = false;
   if (n == 0) { c->staged_kind = kind; return AVRF_OK; }
   HIP_TRY(c->h_io.ensure((n + 1) * 8));
   uint32_t *io_off = c->h_io.as<uint32_t>(), *ad_off = io_off + (n + 1);
@@ -299,13 +299,14 @@ int ctx_stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint8_t
 // identity, + prime-order subgroup, src/lib.rs:410-433) STRAIGHT INTO the context's staged x || y buffers, the proofs' scalars are
 // copied beside their points -- no decompressed byte crosses PCIe or a host core.  A point that fails makes the batch InvalidData
 // here, before any equation (as the reference's deserialisation would).  kind 1 thin (pk, R || s), 2 pedersen (Yb, R, Ok || s || sb).
+// wait = false (pool.hip): nothing is waited for -- the flag is read by batch_collect once the stream's work has completed
 int ctx_stage_wire(avrf_ctx *c, int kind, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
-                   const uint32_t *ad_lens, const uint8_t *proofs, int validate) {
+                   const uint32_t *ad_lens, const uint8_t *proofs, int validate, bool wait) {
   if (!c || c->run_phase || (kind != 1 && kind != 2)) return AVRF_ERR_BAD_ARG;
   if (n && (!io_counts || !ad_lens || !proofs || (kind == 1 && !pks))) return AVRF_ERR_BAD_ARG;
   if (n > 0x0fffffffULL) return AVRF_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
-  c->staged_kind = 0; c->n = n; c->tot_io = 0; c->n_terms = 0; c->stage_gen++;
+  c->staged_kind = 0; c->n = n; c->tot_io = 0; c->n_terms = 0; c->stage_gen++; c->wire_pending = false;
   if (n == 0) { c->staged_kind = kind; return AVRF_OK; }
   HIP_TRY(c->h_io.ensure((n + 1) * 8));
   uint32_t *io_off = c->h_io.as<uint32_t>(), *ad_off = io_off + (n + 1);
@@ -346,6 +347,7 @@ int ctx_stage_wire(avrf_ctx *c, int kind, size_t n, const uint8_t *pks, const ui
   HIP_TRY(c->d_c.ensure(n * 16)); HIP_TRY(c->h_c.ensure(n * 16));
   HIP_TRY(c->d_z.ensure(kind == 1 ? c->tot_io * 16 + 16 : n * 128));
   if (c->lane_owner) { HIP_TRY(c->L->d_scalars.ensure(c->n_terms * 32)); HIP_TRY(c->L->d_pre.ensure(c->n_terms * sizeof(te_pre_raw))); HIP_TRY(c->L->d_gpart.ensure(((n + 127) / 128) * 64 + 64)); }
+  if (!wait) { c->wire_pending = true; c->staged_kind = kind; return AVRF_OK; }
   HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipGetLastError());
   if (*h_flag) return AVRF_INVALID_DATA;
   c->staged_kind = kind;
@@ -356,12 +358,12 @@ extern "C" {
 int avrf_thin_batch_stage_wire(avrf_ctx *c, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
                                const uint32_t *ad_lens, const uint8_t *proofs, int validate) {
   if (!c || ctx_busy(c)) return AVRF_ERR_BAD_ARG;
-  return avrf::ctx_stage_wire(c, 1, n, pks, ios, io_counts, ads, ad_lens, proofs, validate);
+  return avrf::ctx_stage_wire(c, 1, n, pks, ios, io_counts, ads, ad_lens, proofs, validate, true);
 }
 int avrf_pedersen_batch_stage_wire(avrf_ctx *c, size_t n, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
                                    const uint32_t *ad_lens, const uint8_t *proofs, int validate) {
   if (!c || ctx_busy(c)) return AVRF_ERR_BAD_ARG;
-  return avrf::ctx_stage_wire(c, 2, n, nullptr, ios, io_counts, ads, ad_lens, proofs, validate);
+  return avrf::ctx_stage_wire(c, 2, n, nullptr, ios, io_counts, ads, ad_lens, proofs, validate, true);
 }
 static int stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy,
                  const uint32_t *io_counts, const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs) {
@@ -497,6 +499,10 @@ int batch_begin(avrf_ctx *c, int kind) {
 int batch_collect(avrf_ctx *c, int kind) {
   if (!c || c->staged_kind != kind || c->run_phase != 1) return AVRF_ERR_BAD_ARG;
   if (c->n && *c->h_flags.as<uint32_t>()) { c->run_phase = 0; return AVRF_INVALID_DATA; }   // src/thin.rs:266-271, src/pedersen.rs:348-353
+  if (c->wire_pending) {                                               // staged from wire bytes without waiting (ctx_stage_wire): a point that failed to decode / validate
+    c->wire_pending = false;
+    if (c->n && c->h_flags.as<uint32_t>()[2]) { c->run_phase = 0; c->staged_kind = 0; return AVRF_INVALID_DATA; }
+  }
   return AVRF_OK;
 }
 

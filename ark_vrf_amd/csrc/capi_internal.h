@@ -69,6 +69,7 @@ struct avrf_ctx {
   bool lane_owner = true;         // false: a pool slot -- no stream or workspace of its own (L and stream are set by the pool)
   // staged batch
   int validate = 0;               // avrf_ctx_set_validation: 0 unchecked (typed-point callers), 1 on-curve, 2 + subgroup
+  bool wire_pending = false;              // staged from wire bytes without waiting: batch_collect reads the decode flag (h_flags[2])
   uint64_t stage_gen = 0, chal_gen = 0;   // challenges of *_batch_challenges belong to staging generation chal_gen
   int staged_kind = 0;            // 0 none, 1 thin, 2 pedersen
   size_t n = 0, tot_io = 0, n_terms = 0;
@@ -92,6 +93,8 @@ namespace avrf {
 int ctx_create(int suite, int device, bool lane_owner, avrf_ctx **out);
 int ctx_stage(avrf_ctx *c, int kind, size_t n, const uint8_t *sks, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
               const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, bool wait);
+int ctx_stage_wire(avrf_ctx *c, int kind, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                   const uint32_t *ad_lens, const uint8_t *proofs, int validate, bool wait);   // serialize_compressed bytes in, decompressed on the device
 int batch_begin(avrf_ctx *c, int kind);                               // validation + prepare kernel + copies back enqueued on c->stream
 int batch_collect(avrf_ctx *c, int kind);                             // (c->stream's work has completed) AVRF_INVALID_DATA for a refused item
 bool batch_host_weights(const avrf_ctx *c);                           // sponge / SHA-256 transcript: batch_seed squeezes the weight stream itself

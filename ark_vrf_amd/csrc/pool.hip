@@ -38,6 +38,7 @@ struct Slot {
   avrf_ctx *c = nullptr;          // a lane-less context: staged buffers, challenges, records, pinned transcript
   std::atomic<int> state{S_FREE};
   bool has_batch = false;         // the buffers hold a staged batch (it can be run again without its host sources)
+  bool wire = false; int validate = 0;   // the host sources are serialize_compressed bytes (avrf_pool_submit_wire): decompressed on the device while staging
   bool from_host = false;         // stage from the host sources before the run
   uint64_t ticket = 0;
   int status = 0;
@@ -119,7 +120,8 @@ struct Run {
     c->L = &c->own;
     int st = AVRF_OK;
     if (S.from_host) {
-      st = guarded([&] { return ctx_stage(c, P->kind, S.n, nullptr, S.pks, S.ios, S.io_counts, S.ads, S.ad_lens, S.proofs, /*wait=*/false); });
+      if (S.wire) st = guarded([&] { return ctx_stage_wire(c, P->kind, S.n, S.pks, S.ios, S.io_counts, S.ads, S.ad_lens, S.proofs, S.validate, /*wait=*/false); });
+      else st = guarded([&] { return ctx_stage(c, P->kind, S.n, nullptr, S.pks, S.ios, S.io_counts, S.ads, S.ad_lens, S.proofs, /*wait=*/false); });
       S.has_batch = st == AVRF_OK;
     }
     if (st == AVRF_OK) st = guarded([&] { return batch_begin(c, P->kind); });
@@ -304,8 +306,21 @@ int avrf_pool_set_validation(avrf_pool *P, int level) {
   return AVRF_OK;
 }
 
+static int pool_submit(avrf_pool *P, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts, const uint8_t *ads,
+                       const uint32_t *ad_lens, const uint8_t *proofs, uint64_t *ticket, bool wire, int validate);
 int avrf_pool_submit(avrf_pool *P, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts, const uint8_t *ads,
                      const uint32_t *ad_lens, const uint8_t *proofs, uint64_t *ticket) {
+  return pool_submit(P, n, pks_xy, ios_xy, io_counts, ads, ad_lens, proofs, ticket, false, 0);
+}
+// the same job from the reference's wire bytes (`serialize_compressed` points, proofs as CanonicalSerialize writes them): the
+// points are decompressed -- validate != 0: and checked for non-identity and prime-order-subgroup membership -- on the device
+// while the batch is staged; a point that fails makes the batch's verdict AVRF_INVALID_DATA
+int avrf_pool_submit_wire(avrf_pool *P, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts, const uint8_t *ads,
+                          const uint32_t *ad_lens, const uint8_t *proofs, int validate, uint64_t *ticket) {
+  return pool_submit(P, n, pks, ios, io_counts, ads, ad_lens, proofs, ticket, true, validate);
+}
+static int pool_submit(avrf_pool *P, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts, const uint8_t *ads,
+                       const uint32_t *ad_lens, const uint8_t *proofs, uint64_t *ticket, bool wire, int validate) {
   if (!P || !ticket || (n && (!proofs || !io_counts || !ad_lens)) || (n && P->kind == 1 && !pks_xy)) return AVRF_ERR_BAD_ARG;
   std::unique_lock<std::mutex> lk(P->m);
   if (P->cycling) return AVRF_ERR_BAD_ARG;
@@ -320,7 +335,7 @@ int avrf_pool_submit(avrf_pool *P, size_t n, const uint8_t *pks_xy, const uint8_
     if (best >= 0) {
       Slot &S = P->slots[best];
       S.n = n; S.pks = pks_xy; S.ios = ios_xy; S.io_counts = io_counts; S.ads = ads; S.ad_lens = ad_lens; S.proofs = proofs;
-      S.from_host = true; S.ticket = P->next_ticket++; S.status = 0;
+      S.from_host = true; S.wire = wire; S.validate = validate; S.ticket = P->next_ticket++; S.status = 0;
       S.state = S_SUBMITTED;
       *ticket = S.ticket;
       P->cv_work.notify_all();

@@ -198,6 +198,12 @@ void avrf_pool_destroy(avrf_pool *pool);
 int avrf_pool_set_validation(avrf_pool *pool, int level);
 int avrf_pool_submit(avrf_pool *pool, size_t n, const uint8_t *pks_xy, const uint8_t *ios_xy, const uint32_t *io_counts,
                      const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, uint64_t *ticket);
+/* avrf_pool_submit_wire: the same job from wire bytes (`serialize_compressed` points; thin proofs R || s, pedersen proofs
+ * Yb || R || Ok || s || sb as CanonicalSerialize writes them): decompression, and with validate != 0 the non-identity and
+ * prime-order-subgroup checks of Validate::Yes (src/lib.rs:410-433), run on the device while the batch is staged; a point that
+ * fails makes the verdict AVRF_INVALID_DATA.  Resubmission and the cycle mode work on such slots as on any other. */
+int avrf_pool_submit_wire(avrf_pool *pool, size_t n, const uint8_t *pks, const uint8_t *ios, const uint32_t *io_counts,
+                          const uint8_t *ads, const uint32_t *ad_lens, const uint8_t *proofs, int validate, uint64_t *ticket);
 int avrf_pool_wait(avrf_pool *pool, uint64_t ticket, int *status);
 int avrf_pool_resubmit(avrf_pool *pool, uint64_t ticket, int from_host, uint64_t *new_ticket);
 int avrf_pool_cycle(avrf_pool *pool, int from_host, uint64_t steps_block, double min_seconds, uint64_t max_steps, int expect_status,

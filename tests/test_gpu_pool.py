@@ -177,3 +177,59 @@ def test_pool_full_size_batch(nat, kind):
         assert done == 8 and mism == 1                                  # eight runs over the four resident batches; the tampered slot is not reissued after its mismatch
     finally:
         pool.close()
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_pool_wire_ingest(nat, kind):
+    """avrf_pool_submit_wire: batches handed over as the reference's `serialize_compressed` bytes, decompressed and -- validate = 1 --
+    checked as Validate::Yes does (src/lib.rs:410-433) on the device while they are staged.  Verdicts: valid 0, tampered scalar 1,
+    a point that does not decode 2, a torsion point 2 under validate = 1 (and the equation's verdict under validate = 0);
+    resubmission from the same host bytes; pinned and pageable sources; 65 536 items next to small batches."""
+    import hashlib
+    from helpers import compressed_items
+    suite = 0
+    q = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+    def wire(b, n, pinned=False, pks=None, ios=None, proofs=None):
+        p0, i0, ads, pr0 = compressed_items(suite, b, kind)
+        pks = p0 if pks is None else pks; ios = i0 if ios is None else ios; proofs = pr0 if proofs is None else proofs
+        cls = nat.PinnedBatch if pinned else nat.Batch
+        return cls(n, b"".join(i + o for it in ios for i, o in it), [1] * n, b"".join(ads), [len(a) for a in ads],
+                   pks_xy=(b"".join(pks) if kind == 0 else None), proofs=b"".join(proofs)), (pks, ios, ads, proofs)
+    n = 300
+    b = orc.gen_batch(suite, kind, n, start=7000)
+    if kind == 1:
+        b["pks_xy"] = b""
+    good, (pks, ios, ads, proofs) = wire(b, n)
+    j = n // 2
+    tam = list(proofs); tam[j] = proofs[j][:-9] + bytes([proofs[j][-9] ^ 1]) + proofs[j][-8:]
+    bad_y = next(k.to_bytes(32, "little") for k in range(2, 300) if orc.point_decompress(suite, k.to_bytes(32, "little"))[0] != 0)
+    und = list(proofs); und[n - 1] = bad_y + proofs[n - 1][32:]
+    st, oxy = orc.point_decompress(suite, ios[5][0][1])
+    tors = orc.point_compress(suite, ((q - int.from_bytes(oxy[:32], "little")) % q).to_bytes(32, "little") + ((q - int.from_bytes(oxy[32:], "little")) % q).to_bytes(32, "little"))
+    ios_t = list(ios); ios_t[5] = [(ios[5][0][0], tors)]
+    pool = nat.Pool(suite, kind=kind + 1, slots=6, lanes=2, threads=2, hash_group=8)
+    try:
+        batches = [good, wire(b, n, pinned=True)[0], wire(b, n, proofs=tam)[0], wire(b, n, proofs=und)[0], wire(b, n, ios=ios_t)[0]]
+        tk = [pool.submit_wire(x, validate=1) for x in batches]
+        assert [pool.wait(t) for t in tk] == [0, 0, 1, 2, 2]
+        tk = [pool.submit_wire(x, validate=0) for x in batches]
+        got = [pool.wait(t) for t in tk]
+        assert got[:4] == [0, 0, 1, 2] and got[4] in (0, 1)
+        t2 = [pool.resubmit(t, from_host=True) for t in tk[:3]]                      # staged again from the same wire bytes
+        assert [pool.wait(t) for t in t2] == [0, 0, 1]
+        # a wire batch and an x || y batch side by side in one pool
+        from helpers import nat_batch
+        ta, tb = pool.submit_wire(good), pool.submit(nat_batch(b))
+        assert (pool.wait(ta), pool.wait(tb)) == (0, 0)
+        # full size
+        N = 65536
+        big = orc.gen_batch(suite, kind, N, threads=16)
+        if kind == 1:
+            big["pks_xy"] = b""
+        gw, (_, _, _, bp) = wire(big, N, pinned=True)
+        bt = list(bp); bt[40000] = bp[40000][:-9] + bytes([bp[40000][-9] ^ 1]) + bp[40000][-8:]
+        tk = [pool.submit_wire(gw), pool.submit_wire(wire(big, N, proofs=bt)[0]), pool.submit_wire(gw, validate=0)]
+        assert [pool.wait(t) for t in tk] == [0, 1, 0]
+    finally:
+        pool.close()

@@ -38,6 +38,18 @@ comp = lambda xy_all: b"".join(orc.point_compress(0, xy_all[64 * i: 64 * i + 64]
 pks_c = comp(b["pks_xy"]); ios_c = comp(b["ios_xy"])
 pr = b["proofs"]
 proofs_c = b"".join(orc.point_compress(0, pr[96 * j: 96 * j + 64]) + pr[96 * j + 64: 96 * j + 96] for j in range(n))
+# (a') the pool fed with the COMPRESSED bytes (avrf_pool_submit_wire): every step staged again from page-locked wire buffers
+for v in (0, 1):
+    pool = nat.Pool(0, kind=1, slots=48, lanes=10, threads=6, hash_group=8)
+    try:
+        pw = nat.PinnedBatch(n, ios_c, b["io_counts"], b["ads"], b["ad_lens"], pks_xy=pks_c, proofs=proofs_c)
+        tk = [pool.submit_wire(pw, validate=v) for _ in range(48)]
+        assert all(pool.wait(t) == 0 for t in tk)
+        done, mism, sec = pool.cycle(steps_block=96, min_seconds=1.5, from_host=True, expect=0)
+        assert mism == 0
+        out[f"pool_wire_validate{v}_from_pinned_host_per_sec"] = done * n / sec
+    finally:
+        pool.close()
 ctx = nat.Context(0)
 L = nat.lib()
 args = (ctx._h, C.c_size_t(n), nat._u8(pks_c), nat._u8(ios_c), nat._u32(b["io_counts"]), nat._u8(b["ads"]), nat._u32(b["ad_lens"]), nat._u8(proofs_c))
