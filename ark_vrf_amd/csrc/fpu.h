@@ -120,6 +120,17 @@ template <class F> AVRF_DI fuF<F> fu_carry(const fuF<F> &a) {
   return r;
 }
 
+// the same pass for sums of NON-NEGATIVE limbs that need all 32 bits (B + 5 A < 6 * 2^29): unsigned arithmetic and logical shifts
+// for limbs 0 .. L-2 (a signed int32 would overflow -- undefined behaviour, however the hardware wraps); the top limb stays signed
+template <class F> AVRF_DI fuF<F> fu_carry_u(const uint32_t (&a)[UL<F>::L - 1], int32_t top) {
+  using U = UL<F>;
+  fuF<F> r;
+  r.v[0] = (int32_t)(a[0] & U::MASK);
+#pragma unroll
+  for (int i = 1; i < U::L - 1; i++) r.v[i] = (int32_t)((a[i] & U::MASK) + (a[i - 1] >> U::W));
+  r.v[U::L - 1] = top + (int32_t)(a[U::L - 2] >> U::W);
+  return r;
+}
 // a * b / 2^(W L) mod p for limbs with L |a_i| |b_j| + L 2^(2W) < 2^63 (e.g. |a_i| <= 2^30, |b_j| <= 2^29 + 2^4), product scanning with the
 // reduction interleaved: column k gets its k + 1 (or fewer) limb products and the products m_i p_(k-i) of the reduction so far, m_k
 // is chosen to clear the column's low W bits, and the rest of the accumulator moves down by W bits into column k + 1.

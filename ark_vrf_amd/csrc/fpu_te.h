@@ -56,10 +56,11 @@ template <class S> AVRF_DI te_acc_u<S> teu_madd(const te_acc_u<S> &p, const te_p
   E = fu_sub<L>(fu_sub<L>(E, A), B);
   const fu<L> F = fu_sub<L>(p.z, C), G = fu_add<L>(p.z, C);
   fu<L> H;                                                                   // B - a A
-  if (S::A_KIND == 1) {                                                      // a = -5: B + 5 A, limbs < 6 * 2^29
+  if (S::A_KIND == 1) {                                                      // a = -5: B + 5 A, limbs < 6 * 2^29 (unsigned: more than an int32 holds)
+    uint32_t h[L - 1];
 #pragma unroll
-    for (int i = 0; i < L; i++) H.v[i] = B.v[i] + 5 * A.v[i];
-    H = fu_carry<Fq>(H);
+    for (int i = 0; i < L - 1; i++) h[i] = (uint32_t)B.v[i] + 5u * (uint32_t)A.v[i];
+    H = fu_carry_u<Fq>(h, B.v[L - 1] + 5 * A.v[L - 1]);
   } else if (S::A_KIND == 2) H = fu_carry<Fq>(fu_add<L>(B, A));              // a = -1
   else H = fu_sub<L>(B, A);                                                  // a = 1
   te_acc_u<S> r;

@@ -212,7 +212,7 @@ class TE:
         E = [e_ - a - b for e_, a, b in zip(E, A, B)]
         F = [z - c for z, c in zip(Z, C)]; G = [z + c for z, c in zip(Z, C)]
         if self.a_kind == 1:
-            H = f.carry([b + 5 * a for a, b in zip(A, B)])
+            H = TEChain(self).hsum(A, B)
         elif self.a_kind == 2:
             H = f.carry([b + a for a, b in zip(A, B)])
         else:
@@ -238,6 +238,37 @@ class TE:
         assert (x * y - t * z) % f.p == 0
         zi = pow(z, -1, f.p)
         return (x * zi % f.p, y * zi % f.p)
+
+
+def i32(v):
+    assert -(1 << 31) <= v < (1 << 31), "int32 overflow in a limb expression"
+    return v
+
+
+def u32(v):
+    assert 0 <= v < (1 << 32), "uint32 overflow in a limb expression"
+    return v
+
+
+class TEChain:
+    """the sum B - a A of fpu_te.h teu_madd with the C types' ranges asserted (a = -5: unsigned limbs, fu_carry_u)"""
+
+    def __init__(self, te):
+        self.te, self.f = te, te.f
+
+    def carry_u(self, h, top):
+        f = self.f
+        return [h[0] & f.MASK] + [(h[i] & f.MASK) + (h[i - 1] >> f.W) for i in range(1, f.L - 1)] + [top + (h[f.L - 2] >> f.W)]
+
+    def hsum(self, A, B):
+        f, k = self.f, self.te.a_kind
+        if k == 1:
+            r = self.carry_u([u32(b + 5 * a) for a, b in zip(A[:-1], B[:-1])], i32(B[-1] + 5 * A[-1]))
+            assert f.val(r) == f.val(B) + 5 * f.val(A)
+            return r
+        if k == 2:
+            return f.carry([i32(a + b) for a, b in zip(A, B)])
+        return [i32(b - a) for a, b in zip(A, B)]
 
 
 def check_te(te, rng, chains=6, length=40):
