@@ -4,7 +4,8 @@
 #                          GPU box gets a snapshot without .git); refuses a dirty tree unless DIRTY=1
 #   make profiles R=r5     on a GPU box (gpurun -- 'make profiles R=r5'): every committed profile summary of the round,
 #                          regenerated from the current build and stamped with build/HEAD_STAMP (tools/refresh_profiles.sh)
-#   make check-model       the exact-integer model of the unsaturated-limb arithmetic (tools/fpu_model.py)
+#   make check-model       the exact-integer model of the unsaturated-limb arithmetic (tools/fpu_model.py) and the emulator run of
+#                          the generated asm multipliers (tools/gen_fpu_asm.py --check)
 R ?= r5
 lib:
 	$(MAKE) -C ark_vrf_amd/csrc -j8
@@ -17,4 +18,5 @@ profiles:
 	bash tools/refresh_profiles.sh $(R) $(WHAT)
 check-model:
 	python3 tools/fpu_model.py
+	python3 tools/gen_fpu_asm.py --check
 .PHONY: lib stamp profiles check-model

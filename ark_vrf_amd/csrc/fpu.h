@@ -67,6 +67,9 @@ template <class F> struct UL {
 };
 
 template <class F> using fuF = fu<UL<F>::L>;
+}  // namespace avrf
+#include "fpu_asm_gen.h"     // fu_mul_asm / fu_sqr_asm: the products below as single asm blocks for the 8-word fields (tools/gen_fpu_asm.py)
+namespace avrf {
 
 // limbs of value(w) * 2^S (S = 0, or UL::SH for a base coordinate that is going to be multiplied): one v_alignbit_b32 (or shift) + one v_and_b32 each
 template <class F, int S> AVRF_DI fuF<F> fu_slice(const uint32_t (&w)[UL<F>::N]) {
@@ -136,6 +139,9 @@ template <class F> AVRF_DI fuF<F> fu_carry_u(const uint32_t (&a)[UL<F>::L - 1], 
 // is chosen to clear the column's low W bits, and the rest of the accumulator moves down by W bits into column k + 1.
 // Result: limbs 0 .. L-2 in [0, 2^W), limb L-1 signed; |value| < |a b| / 2^(W L) + p.
 template <class F> AVRF_DI fuF<F> fu_mul(const fuF<F> &a, const fuF<F> &b) {
+#if !defined(AVRF_NO_FPU_ASM) && defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (FuAsm<F>::value) return fu_mul_asm(F{}, a, b);
+#endif
   using U = UL<F>;
   constexpr int L = U::L, W = U::W;
   int64_t acc = 0;
@@ -165,6 +171,9 @@ template <class F> AVRF_DI fuF<F> fu_mul(const fuF<F> &a, const fuF<F> &b) {
 }
 // a * a / 2^(W L): L (L + 1) / 2 limb products (the cross products against the doubled limbs); |a_i| <= 2^29 + 2^4
 template <class F> AVRF_DI fuF<F> fu_sqr(const fuF<F> &a) {
+#if !defined(AVRF_NO_FPU_ASM) && !defined(AVRF_NO_FPU_ASM_SQR) && defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (FuAsm<F>::value) return fu_sqr_asm(F{}, a);
+#endif
   using U = UL<F>;
   constexpr int L = U::L, W = U::W;
   int64_t acc = 0;

@@ -30,3 +30,14 @@ def test_layout_constants_match_the_headers():
     assert (g254.a, g254.bb, g254.g, g254.d, g254.sx, g254.sy) == (3, 2, 4, 6, 4, 1)
     hdr = open(os.path.join(ROOT, "ark_vrf_amd", "csrc", "fpu_g1.h")).read()
     assert "a = SH == 8 ? 4 : 3, b = 2, m = 2" in hdr
+
+
+def test_asm_multiplier_streams_match_the_model_and_the_header_is_current():
+    """tools/gen_fpu_asm.py --check: the instruction streams of fu_mul_asm / fu_sqr_asm (csrc/fpu_asm_gen.h), run in its emulator,
+    return the limbs of the model's fu_mul on random and extreme operands, honour the asm statement's register contract, and the
+    committed header is what the generator writes from the current consts_gen.h"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_fpu_asm.py"), "--check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for name in ("FqBandersnatch", "FqBabyJubJub", "FqEd25519", "FqBls12381"):
+        assert name in r.stdout
+    assert "limb for limb" in r.stdout and "is current" in r.stdout

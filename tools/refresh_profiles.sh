@@ -2,10 +2,12 @@
 # Regenerates the committed profile summaries of a round from the CURRENT build, on a GPU box:
 #   make stamp                                         (build container: writes build/HEAD_STAMP = the commit being measured)
 #   gpurun -- 'bash tools/refresh_profiles.sh r5 [what ...]'      (or: gpurun -- 'make profiles R=r5')
-#   what: ubench single default benchline ring ring_bn254 peritem latency validate pmc_thin pmc_ring pmc_ring_bn254 (default: all)
+#   what: ubench pmc_thin pmc_ring pmc_ring_bn254 single default benchline ring ring_bn254 peritem latency validate (default: all, in
+#   this order: bench.py reads its roofs and HBM traffic from profiles/<round>_ubench.txt / _pmc_*.json, so those are produced first and
+#   copied into profiles/ of the box's snapshot before the bench line is taken)
 # Outputs land in gpurun_out/<round>_profiles/, every one stamped with the commit (json: key "head"; txt / log: first line;
 # csv: listed with its sha256 in <round>_STAMP.txt); copy them into profiles/ and commit.
-R=${1:-r5}; shift; WHAT=${*:-ubench single default benchline ring ring_bn254 peritem latency validate pmc_thin pmc_ring pmc_ring_bn254}
+R=${1:-r5}; shift; WHAT=${*:-ubench pmc_thin pmc_ring pmc_ring_bn254 single default benchline ring ring_bn254 peritem latency validate}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/${R}_profiles; mkdir -p $OUT
 HEAD=$(cat $ROOT/build/HEAD_STAMP 2>/dev/null | head -1); HEAD=${HEAD:-unknown}
@@ -31,7 +33,7 @@ PY
 }
 stamp_txt() { sed -i "1i # head $HEAD -- $2" "$1"; }
 for w in $WHAT; do case $w in
-  ubench) bash $ROOT/tools/ubench_report.sh > $OUT/${R}_ubench.txt 2>&1; stamp_txt $OUT/${R}_ubench.txt "bash tools/ubench_report.sh"; tail -30 $OUT/${R}_ubench.txt;;
+  ubench) bash $ROOT/tools/ubench_report.sh > $OUT/${R}_ubench.txt 2>&1; stamp_txt $OUT/${R}_ubench.txt "bash tools/ubench_report.sh"; cp $OUT/${R}_ubench.txt $ROOT/profiles/; tail -30 $OUT/${R}_ubench.txt;;
   single) stats single_context $SINGLE;;
   default) stats bench_default python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-ring --no-projection --no-cpu-baseline;;
   benchline) python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${R}_bench_default.json 2> $OUT/${R}_bench_default.err; stamp_json $OUT/${R}_bench_default.json "python bench.py --gpus 1 --steps 20 --warmup 5";;
@@ -40,9 +42,9 @@ for w in $WHAT; do case $w in
   peritem) stats per_item python3 $ROOT/tools/ped_bench.py 65536;;
   latency) python3 $ROOT/tools/latency_report.py > $OUT/${R}_latency_report.txt 2>&1; stamp_txt $OUT/${R}_latency_report.txt "python tools/latency_report.py";;
   validate) python3 $ROOT/tools/validate_bench.py > $OUT/${R}_validate_bench.json 2> $OUT/${R}_validate_bench.err; stamp_json $OUT/${R}_validate_bench.json "python tools/validate_bench.py";;
-  pmc_thin) python3 $ROOT/tools/pmc.py $OUT/${R}_pmc_thin.json "${PASSES[@]}" -- $SINGLE; stamp_json $OUT/${R}_pmc_thin.json "tools/pmc.py <passes> -- $SINGLE";;
-  pmc_ring) python3 $ROOT/tools/pmc.py $OUT/${R}_pmc_ring.json "${PASSES[@]}" -- python3 $ROOT/tools/ring_bench.py 1024 512 1; stamp_json $OUT/${R}_pmc_ring.json "tools/pmc.py <passes> -- python3 tools/ring_bench.py 1024 512 1";;
-  pmc_ring_bn254) python3 $ROOT/tools/pmc.py $OUT/${R}_pmc_ring_bn254.json "${PASSES[@]}" -- python3 $ROOT/tools/ring_bench.py 4096 512 1 1; stamp_json $OUT/${R}_pmc_ring_bn254.json "tools/pmc.py <passes> -- python3 tools/ring_bench.py 4096 512 1 1";;
+  pmc_thin) python3 $ROOT/tools/pmc.py $OUT/${R}_pmc_thin.json "${PASSES[@]}" -- $SINGLE; stamp_json $OUT/${R}_pmc_thin.json "tools/pmc.py <passes> -- $SINGLE"; cp $OUT/${R}_pmc_thin.json $ROOT/profiles/;;
+  pmc_ring) python3 $ROOT/tools/pmc.py $OUT/${R}_pmc_ring.json "${PASSES[@]}" -- python3 $ROOT/tools/ring_bench.py 1024 512 1; stamp_json $OUT/${R}_pmc_ring.json "tools/pmc.py <passes> -- python3 tools/ring_bench.py 1024 512 1"; cp $OUT/${R}_pmc_ring.json $ROOT/profiles/;;
+  pmc_ring_bn254) python3 $ROOT/tools/pmc.py $OUT/${R}_pmc_ring_bn254.json "${PASSES[@]}" -- python3 $ROOT/tools/ring_bench.py 4096 512 1 1; stamp_json $OUT/${R}_pmc_ring_bn254.json "tools/pmc.py <passes> -- python3 tools/ring_bench.py 4096 512 1 1"; cp $OUT/${R}_pmc_ring_bn254.json $ROOT/profiles/;;
 esac; done
 { echo "head $HEAD"; echo "date $(date -u +%Y-%m-%dT%H:%M:%SZ)"; echo "what $WHAT"; ( cd $OUT && sha256sum ${R}_* | grep -v STAMP ); } > $OUT/${R}_STAMP.txt
 cat $OUT/${R}_STAMP.txt | head -5

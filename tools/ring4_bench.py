@@ -15,6 +15,8 @@ ring = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 n_ctx = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+if os.environ.get("AVRF_RING4_CPUS"):         # the per-rank CPU share of an 8-rank node (bench.py projected_child)
+    os.sched_setaffinity(0, bench.pick_cpus(int(os.environ["AVRF_RING4_CPUS"])))
 import torch  # noqa: E402
 torch.cuda.set_device(0)                     # (torch's runtime first, as bench.py's ranks do; then the library's device flags)
 assert nat.set_blocking_sync(0, True) == 0
