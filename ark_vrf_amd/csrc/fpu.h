@@ -134,6 +134,14 @@ template <class F> AVRF_DI fuF<F> fu_carry_u(const uint32_t (&a)[UL<F>::L - 1], 
   r.v[U::L - 1] = top + (int32_t)(a[U::L - 2] >> U::W);
   return r;
 }
+// 5 a for a with limbs 0 .. L-2 in [0, 2^W + 4) (a product's output, or carried), carried to limbs in [0, 2^W + 4)
+template <class F> AVRF_DI fuF<F> fu_times5(const fuF<F> &a) {
+  constexpr int L = UL<F>::L;
+  uint32_t t[L - 1];
+#pragma unroll
+  for (int i = 0; i < L - 1; i++) t[i] = 5u * (uint32_t)a.v[i];
+  return fu_carry_u<F>(t, 5 * a.v[L - 1]);
+}
 // a * b / 2^(W L) mod p for limbs with L |a_i| |b_j| + L 2^(2W) < 2^63 (e.g. |a_i| <= 2^30, |b_j| <= 2^29 + 2^4), product scanning with the
 // reduction interleaved: column k gets its k + 1 (or fewer) limb products and the products m_i p_(k-i) of the reduction so far, m_k
 // is chosen to clear the column's low W bits, and the rest of the accumulator moves down by W bits into column k + 1.

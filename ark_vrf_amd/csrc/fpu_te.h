@@ -78,6 +78,95 @@ template <class S> AVRF_DI te_ext teu_to_ext(const te_acc_u<S> &p) {
   return r;
 }
 
+// ---- the doubling chains of the per-item kernels (proto_dev.h te_smul_*, glv.h): the running point of a scalar multiplication in
+// unsaturated limbs, the window-table entries read from memory in their saturated form and sliced as they arrive
+// (dbl-2008-hwcd / add-2008-hwcd as te.h).  Montgomery domains as above: products by a table coordinate are exact (the entry is
+// sliced with the shift), products of two running values come out times 2^-SH -- uniformly in all four coordinates of a result.
+// Bounds (tools/fpu_model.py, "per-item doubling chains"): |X|, |Y|, |T|, |Z| < 1.6p, 1.8p, 2.5p, 1.9p are closed under both
+// operations; operands of every product are within (2^30, 2^29 + 4) after the carry passes below.  The products are the asm blocks
+// of fpu_asm_gen.h (206 / 178 vector instructions against the saturated multiplier's ~250, which also squares by multiplying).
+template <class S> struct teu4 { fuF<typename S::Fq> x, y, t, z; };
+
+template <class S> AVRF_DI teu4<S> teu4_identity() {
+  using Fq = typename S::Fq;
+  teu4<S> r; r.x = fu_zero<UL<Fq>::L>(); r.t = r.x; r.y = fu_const<Fq>(UL<Fq>::ONE); r.z = r.y; return r;
+}
+template <class S> AVRF_DI teu4<S> teu4_from_ext(const te_ext &e) {
+  using Fq = typename S::Fq;
+  teu4<S> r; r.x = fu_slice<Fq, 0>(e.x.v); r.y = fu_slice<Fq, 0>(e.y.v); r.t = fu_slice<Fq, 0>(e.t.v); r.z = fu_slice<Fq, 0>(e.z.v); return r;
+}
+template <class S> AVRF_DI te_ext teu4_to_ext(const teu4<S> &p) {
+  using Fq = typename S::Fq;
+  te_ext r; fu_to_packed<Fq>(r.x.v, p.x); fu_to_packed<Fq>(r.y.v, p.y); fu_to_packed<Fq>(r.t.v, p.t); fu_to_packed<Fq>(r.z.v, p.z); return r;
+}
+// B - a A for the closing products: carried to limbs in [0, 2^W + 4) where the sum can exceed 2^30
+template <class S, int L> AVRF_DI fu<L> teu_h(const fu<L> &A, const fu<L> &B) {
+  using Fq = typename S::Fq;
+  if (S::A_KIND == 1) {
+    uint32_t h[L - 1];
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) h[i] = (uint32_t)B.v[i] + 5u * (uint32_t)A.v[i];
+    return fu_carry_u<Fq>(h, B.v[L - 1] + 5 * A.v[L - 1]);
+  }
+  if (S::A_KIND == 2) return fu_carry<Fq>(fu_add<L>(B, A));
+  return fu_sub<L>(B, A);
+}
+// 2 P (4M + 4S)
+template <class S> AVRF_DI teu4<S> teu4_dbl(const teu4<S> &p) {
+  using Fq = typename S::Fq;
+  constexpr int L = UL<Fq>::L;
+  const fu<L> A = fu_sqr<Fq>(p.x), B = fu_sqr<Fq>(p.y), Zs = fu_sqr<Fq>(p.z);
+  const fu<L> Sq = fu_sqr<Fq>(fu_carry<Fq>(fu_add<L>(p.x, p.y)));
+  const fu<L> E = fu_sub<L>(fu_sub<L>(Sq, A), B);                  // limbs in (-2^30, 2^29)
+  // G = D + B, H = D - B, F = G - C with D = a A, C = 2 Zs.  a = -5: 5 A is formed and carried in unsigned arithmetic first (its
+  // limbs need 32 bits); then |G_i| <= 2^29 + 4, |H_i| <= 2^30 + 4, |F_i| <= 3 * 2^29 + 4 all fit an int32 and H, F take a carry pass.
+  fu<L> G, H, F;
+  if (S::A_KIND == 1) {
+    const fu<L> A5 = fu_times5<Fq>(A);
+#pragma unroll
+    for (int i = 0; i < L; i++) { G.v[i] = B.v[i] - A5.v[i]; H.v[i] = -A5.v[i] - B.v[i]; F.v[i] = G.v[i] - 2 * Zs.v[i]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      const int32_t D = S::A_KIND == 2 ? -A.v[i] : A.v[i];
+      G.v[i] = D + B.v[i]; H.v[i] = D - B.v[i]; F.v[i] = G.v[i] - 2 * Zs.v[i];
+    }
+  }
+  H = fu_carry<Fq>(H); F = fu_carry<Fq>(F);
+  teu4<S> r;
+  r.x = fu_mul<Fq>(E, F); r.y = fu_mul<Fq>(G, H); r.t = fu_mul<Fq>(E, H); r.z = fu_mul<Fq>(F, G);
+  return r;
+}
+// P + e, e an extended point in saturated canonical words (a window-table entry): 9M + 1 by d
+template <class S> AVRF_DI teu4<S> teu4_add_sat(const teu4<S> &p, const te_ext &e) {
+  using Fq = typename S::Fq;
+  constexpr int L = UL<Fq>::L, SH = UL<Fq>::SH;
+  fp xy; add8(xy, e.x, e.y);
+  const fu<L> A = fu_mul<Fq>(p.x, fu_slice<Fq, SH>(e.x.v)), B = fu_mul<Fq>(p.y, fu_slice<Fq, SH>(e.y.v));
+  const fu<L> C = fu_mul<Fq>(fu_mul<Fq>(p.t, fu_slice<Fq, SH>(e.t.v)), fu_slice<Fq, SH>(S::D));
+  const fu<L> D = fu_mul<Fq>(p.z, fu_slice<Fq, SH>(e.z.v));
+  fu<L> E = fu_mul<Fq>(fu_add<L>(p.x, p.y), fu_slice<Fq, SH>(xy.v));
+  E = fu_sub<L>(fu_sub<L>(E, A), B);
+  const fu<L> F = fu_sub<L>(D, C), G = fu_add<L>(D, C), H = teu_h<S, L>(A, B);
+  teu4<S> r;
+  r.x = fu_mul<Fq>(E, F); r.y = fu_mul<Fq>(G, H); r.t = fu_mul<Fq>(E, H); r.z = fu_mul<Fq>(F, G);
+  return r;
+}
+// P + q, q affine with k = d x y (a fixed-base table entry): 8M
+template <class S> AVRF_DI teu4<S> teu4_madd_pre(const teu4<S> &p, const te_pre &q) {
+  using Fq = typename S::Fq;
+  constexpr int L = UL<Fq>::L, SH = UL<Fq>::SH;
+  fp xy; add8(xy, q.x, q.y);
+  const fu<L> A = fu_mul<Fq>(p.x, fu_slice<Fq, SH>(q.x.v)), B = fu_mul<Fq>(p.y, fu_slice<Fq, SH>(q.y.v));
+  const fu<L> C = fu_mul<Fq>(p.t, fu_slice<Fq, SH>(q.k.v));
+  fu<L> E = fu_mul<Fq>(fu_add<L>(p.x, p.y), fu_slice<Fq, SH>(xy.v));
+  E = fu_sub<L>(fu_sub<L>(E, A), B);
+  const fu<L> F = fu_sub<L>(p.z, C), G = fu_add<L>(p.z, C), H = teu_h<S, L>(A, B);
+  teu4<S> r;
+  r.x = fu_mul<Fq>(E, F); r.y = fu_mul<Fq>(G, H); r.t = fu_mul<Fq>(E, H); r.z = fu_mul<Fq>(F, G);
+  return r;
+}
+
 // A partial sum as a lane of k_accumulate leaves it at a bucket boundary: the 4 x 9 limbs and the sign, forty words, ten 16-byte
 // stores under the lane mask -- NOT the canonical te_ext.  The boundary falls at a different iteration in every lane, so
 // whatever runs there runs for the whole wave once per iteration with ANY boundary in it (64 % of the iterations at C2's

@@ -141,14 +141,15 @@ template <class S> AVRF_DN te_ext te_smul_glv_ws_nf(te_ext *ws, te_pre p, fp k) 
   if (g.n1) p = te_pre_neg<S>(p);
   if (g.n2) q = te_ext_neg<S>(q);
   glv_table_ws<S>(ws, p, q);
-  te_ext acc = te_identity<S>();
+  using CH = Chain<S>;
+  typename CH::acc_t acc = CH::identity();
   for (int w = 63; w >= 0; w--) {
     const uint32_t d = 4 * digit2(g.k2, w) + digit2(g.k1, w);
     te_ext e; if (d) e = load_ext(ws + d);
-    acc = te_dbl<S>(te_dbl<S>(acc));
-    if (d) acc = te_add<S>(acc, e);
+    acc = CH::template dbln<2>(acc);
+    if (d) acc = CH::add(acc, e);
   }
-  return acc;
+  return CH::finish(acc);
 }
 template <class S, bool HAVE_Q> AVRF_DN te_ext te_smul_multi_glv_ws_nf(te_ext *ws, te_pre p, fp a, te_pre q, fp b, te_pre r, fp c) {
   using Fr = typename S::Fr;
@@ -172,19 +173,21 @@ template <class S, bool HAVE_Q> AVRF_DN te_ext te_smul_multi_glv_ws_nf(te_ext *w
     glv_table_ws<S>(tq, q, qe);
   }
   { te_ext cur = te_from_pre<S>(r); store_ext(tr + 1, cur); cur = te_madd<S>(cur, r); store_ext(tr + 2, cur); cur = te_madd<S>(cur, r); store_ext(tr + 3, cur); }
-  te_ext acc = te_identity<S>();
+  using CH = Chain<S>;
+  typename CH::acc_t acc = CH::identity();
   for (int w = 63; w >= 0; w--) {
     const uint32_t d = 4 * digit2(ga.k2, w) + digit2(ga.k1, w), e = HAVE_Q ? 4 * digit2(gb.k2, w) + digit2(gb.k1, w) : 0u, f = digit2(c, w);
-    te_ext e1, e2, e3;                                              // the window's entries: loads issued ahead of the doublings
-    if (d) e1 = load_ext(tp + d);
-    if (HAVE_Q) if (e) e2 = load_ext(tq + e);
-    if (f) e3 = load_ext(tr + f);
-    acc = te_dbl<S>(te_dbl<S>(acc));
-    if (d) acc = te_add<S>(acc, e1);
-    if (HAVE_Q) if (e) acc = te_add<S>(acc, e2);
-    if (f) acc = te_add<S>(acc, e3);
+    acc = CH::template dbln<2>(acc);
+    // one inlined addition per chain function: the window's (up to) three entries go through a loop of one body
+#pragma unroll 1
+    for (int which = 0; which < 3; which++) {
+      const uint32_t dg = which == 0 ? d : which == 1 ? e : f;
+      if (!dg) continue;
+      const te_ext en = load_ext((which == 0 ? tp : which == 1 ? tq : tr) + dg);
+      acc = CH::add(acc, en);
+    }
   }
-  return acc;
+  return CH::finish(acc);
 }
 
 // k * P, k a plain integer < r.  Suites without the endomorphism: the 4-bit window form.
@@ -197,13 +200,14 @@ template <class S> AVRF_DN te_ext te_smul_glv_nf(te_pre p, fp k) {
   if (g.n2) q = te_ext_neg<S>(q);
   te_ext tab[16];
   glv_table<S>(tab, p, q);
-  te_ext acc = te_identity<S>();
+  using CH = Chain<S>;
+  typename CH::acc_t acc = CH::identity();
   for (int w = 63; w >= 0; w--) {
-    acc = te_dbl<S>(te_dbl<S>(acc));
+    acc = CH::template dbln<2>(acc);
     const uint32_t d = 4 * digit2(g.k2, w) + digit2(g.k1, w);
-    if (d) acc = te_add<S>(acc, tab[d]);
+    if (d) acc = CH::add(acc, tab[d]);
   }
-  return acc;
+  return CH::finish(acc);
 }
 template <class S> AVRF_DI te_ext te_smul_glv(const te_pre &p, const fp &k) {
   if constexpr (S::HAS_GLV) return te_smul_glv_nf<S>(p, k);
@@ -238,19 +242,19 @@ template <class S, bool HAVE_Q> AVRF_DN te_ext te_smul_multi_glv_nf(te_pre p, fp
     glv_table<S>(tq, q, qe);
   }
   tr[0] = te_identity<S>(); tr[1] = te_from_pre<S>(r); tr[2] = te_madd<S>(tr[1], r); tr[3] = te_madd<S>(tr[2], r);
-  te_ext acc = te_identity<S>();
+  using CH = Chain<S>;
+  typename CH::acc_t acc = CH::identity();
   for (int w = 63; w >= 0; w--) {
-    acc = te_dbl<S>(te_dbl<S>(acc));
-    const uint32_t d = 4 * digit2(ga.k2, w) + digit2(ga.k1, w);
-    if (d) acc = te_add<S>(acc, tp[d]);
-    if (HAVE_Q) {
-      const uint32_t e = 4 * digit2(gb.k2, w) + digit2(gb.k1, w);
-      if (e) acc = te_add<S>(acc, tq[e]);
+    acc = CH::template dbln<2>(acc);
+    const uint32_t d = 4 * digit2(ga.k2, w) + digit2(ga.k1, w), e = HAVE_Q ? 4 * digit2(gb.k2, w) + digit2(gb.k1, w) : 0u, f = digit2(c, w);
+#pragma unroll 1
+    for (int which = 0; which < 3; which++) {
+      const uint32_t dg = which == 0 ? d : which == 1 ? e : f;
+      if (!dg) continue;
+      acc = CH::add(acc, which == 0 ? tp[dg] : which == 1 ? tq[dg] : tr[dg]);
     }
-    const uint32_t f = digit2(c, w);
-    if (f) acc = te_add<S>(acc, tr[f]);
   }
-  return acc;
+  return CH::finish(acc);
 }
 template <class S, bool HAVE_Q> AVRF_DI te_ext te_smul_multi_glv(te_ext *ws, const te_pre &p, const fp &a, const te_pre &q, const fp &b, const te_pre &r, const fp &c);
 template <class S, bool HAVE_Q> AVRF_DI te_ext te_smul_multi_glv(const te_pre &p, const fp &a, const te_pre &q, const fp &b, const te_pre &r, const fp &c) {

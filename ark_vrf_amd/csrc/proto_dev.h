@@ -28,6 +28,7 @@
 #define te_to_aff te_to_aff_nf
 #define te_make_pre te_make_pre_nf
 #include "sw_map.h"      // (after the routing above: its maps use the out-of-line field operations too)
+#include "fpu_te.h"      // unsaturated-limb running point of the scalar-multiplication chains
 
 namespace avrf {
 
@@ -189,6 +190,30 @@ template <class S> AVRF_DI te_pre pre_from_xy(const uint8_t *xy) {
   using Fq = typename S::Fq;
   return te_make_pre<S>(fp_to_mont<Fq>(fp_load_le(xy)), fp_to_mont<Fq>(fp_load_le(xy + 32)));
 }
+// The running point of a scalar multiplication: on the twisted-Edwards suites whose field has the asm multiplier it lives in
+// unsaturated limbs (fpu_te.h teu4: doubling 4M + 4S and the additions as asm blocks with limb-wise sums between them; the
+// window-table entries stay saturated in memory and are sliced as they arrive), elsewhere (secp256r1: XYZZ coordinates behind the
+// same types, a field that fills its top bit) in the saturated form.  The doublings of a window run as a loop of ONE inlined
+// doubling: a chain function holds one doubling and one addition, ~30 KB of code.
+template <class S> struct Chain {
+#ifndef AVRF_NO_UNSAT_CHAINS
+  static constexpr bool U = !S::SW_NATIVE && FuAsm<typename S::Fq>::value;
+#else
+  static constexpr bool U = false;
+#endif
+  struct sat_t { te_ext p; };
+  using acc_t = std::conditional_t<U, teu4<S>, te_ext>;
+  static AVRF_DI acc_t identity() { if constexpr (U) return teu4_identity<S>(); else return te_identity<S>(); }
+  static AVRF_DI acc_t dbl(const acc_t &a) { if constexpr (U) return teu4_dbl<S>(a); else return te_dbl<S>(a); }
+  template <int N> static AVRF_DI acc_t dbln(acc_t a) {
+#pragma unroll 1
+    for (int t = 0; t < N; t++) a = dbl(a);
+    return a;
+  }
+  static AVRF_DI acc_t add(const acc_t &a, const te_ext &e) { if constexpr (U) return teu4_add_sat<S>(a, e); else return te_add<S>(a, e); }
+  static AVRF_DI acc_t madd(const acc_t &a, const te_pre &q) { if constexpr (U) return teu4_madd_pre<S>(a, q); else return te_madd<S>(a, q); }
+  static AVRF_DI te_ext finish(const acc_t &a) { if constexpr (U) return teu4_to_ext<S>(a); else return a; }
+};
 // k * P, k a plain integer of `nbits` bits: fixed 4-bit windows over a 16-entry per-lane table (private memory).
 // (Binary double-and-add diverges on every bit, so a wave pays doubling + addition for all 253 of them; the window
 // form pays 4 doublings + 1 addition per nibble.)
@@ -196,13 +221,14 @@ template <class S> AVRF_DN te_ext te_smul(te_pre p, fp k, int nbits) {
   te_ext tab[16];
   tab[0] = te_identity<S>(); tab[1] = te_from_pre<S>(p);
   for (int i = 2; i < 16; i++) tab[i] = te_madd<S>(tab[i - 1], p);
-  te_ext acc = te_identity<S>();
+  using CH = Chain<S>;
+  typename CH::acc_t acc = CH::identity();
   for (int w = (nbits + 3) / 4 - 1; w >= 0; w--) {
-    acc = te_dbl<S>(te_dbl<S>(te_dbl<S>(te_dbl<S>(acc))));
+    acc = CH::template dbln<4>(acc);
     uint32_t d = (k.v[w >> 3] >> (4 * (w & 7))) & 15u;
-    if (d) acc = te_add<S>(acc, tab[d]);
+    if (d) acc = CH::add(acc, tab[d]);
   }
-  return acc;
+  return CH::finish(acc);
 }
 // ---- the same with the window table in the CONTEXT'S WORKSPACE instead of private memory.
 // A per-lane array indexed by a runtime digit cannot live in registers; the compiler puts it in scratch, whose layout
@@ -216,14 +242,15 @@ template <class S> AVRF_DN te_ext te_smul_ws(te_ext *tab, te_pre p, fp k, int nb
   te_ext cur = te_from_pre<S>(p);
   store_ext(tab + 1, cur);
   for (int i = 2; i < 16; i++) { cur = te_madd<S>(cur, p); store_ext(tab + i, cur); }
-  te_ext acc = te_identity<S>();
+  using CH = Chain<S>;
+  typename CH::acc_t acc = CH::identity();
   for (int w = (nbits + 3) / 4 - 1; w >= 0; w--) {
     const uint32_t d = (k.v[w >> 3] >> (4 * (w & 7))) & 15u;
     te_ext e; if (d) e = load_ext(tab + d);                      // issued ahead of the doublings
-    acc = te_dbl<S>(te_dbl<S>(te_dbl<S>(te_dbl<S>(acc))));
-    if (d) acc = te_add<S>(acc, e);
+    acc = CH::template dbln<4>(acc);
+    if (d) acc = CH::add(acc, e);
   }
-  return acc;
+  return CH::finish(acc);
 }
 // a*P + b*Q, joint 2-bit windows, table i*P + j*Q (i, j < 4) in the workspace
 template <class S> AVRF_DN te_ext te_smul2_ws(te_ext *tab, te_pre p, fp a, te_pre q, fp b, int nbits) {
@@ -234,26 +261,28 @@ template <class S> AVRF_DN te_ext te_smul2_ws(te_ext *tab, te_pre p, fp a, te_pr
     if (j) store_ext(tab + 4 * j, cur);
     for (int i = 1; i < 4; i++) { cur = te_madd<S>(cur, p); store_ext(tab + 4 * j + i, cur); }
   }
-  te_ext acc = te_identity<S>();
+  using CH = Chain<S>;
+  typename CH::acc_t acc = CH::identity();
   for (int w = (nbits + 1) / 2 - 1; w >= 0; w--) {
     const uint32_t da = (a.v[w >> 4] >> (2 * (w & 15))) & 3u, db = (b.v[w >> 4] >> (2 * (w & 15))) & 3u;
     te_ext e; if (da | db) e = load_ext(tab + 4 * db + da);
-    acc = te_dbl<S>(te_dbl<S>(acc));
-    if (da | db) acc = te_add<S>(acc, e);
+    acc = CH::template dbln<2>(acc);
+    if (da | db) acc = CH::add(acc, e);
   }
-  return acc;
+  return CH::finish(acc);
 }
 // Fixed-base table (one per context, built by k_fixed_table): tab[(base * 32 + w) * 256 + d] = d * 2^(8w) * P,
 // base 0 = the suite generator G, 1 = BLINDING_BASE; d = 0 unused.  k * P is then at most 32 mixed additions.
 enum { FIXED_G = 0, FIXED_B = 1, FIXED_TABLE_POINTS = 2 * 32 * 256 };
 template <class S> AVRF_DN te_ext te_smul_fixed(const te_pre *tab, int base, fp k) {
-  te_ext acc = te_identity<S>();
+  using CH = Chain<S>;
+  typename CH::acc_t acc = CH::identity();
   const te_pre *t = tab + (size_t)base * 32 * 256;
   for (int w = 0; w < 32; w++) {
     uint32_t d = (k.v[w >> 2] >> (8 * (w & 3))) & 255u;
-    if (d) acc = te_madd<S>(acc, load_pre(t + w * 256 + d));
+    if (d) acc = CH::madd(acc, load_pre(t + w * 256 + d));
   }
-  return acc;
+  return CH::finish(acc);
 }
 // a*P + b*Q (Shamir's trick), a/b plain integers of nbits bits: joint 2-bit windows, table i*P + j*Q (i, j < 4)
 template <class S> AVRF_DN te_ext te_smul2(te_pre p, fp a, te_pre q, fp b, int nbits) {
@@ -261,13 +290,14 @@ template <class S> AVRF_DN te_ext te_smul2(te_pre p, fp a, te_pre q, fp b, int n
   tab[0] = te_identity<S>();
   for (int i = 1; i < 4; i++) tab[i] = te_madd<S>(tab[i - 1], p);              // i*P
   for (int j = 1; j < 4; j++) for (int i = 0; i < 4; i++) tab[4 * j + i] = te_madd<S>(tab[4 * (j - 1) + i], q);
-  te_ext acc = te_identity<S>();
+  using CH = Chain<S>;
+  typename CH::acc_t acc = CH::identity();
   for (int w = (nbits + 1) / 2 - 1; w >= 0; w--) {
-    acc = te_dbl<S>(te_dbl<S>(acc));
+    acc = CH::template dbln<2>(acc);
     uint32_t da = (a.v[w >> 4] >> (2 * (w & 15))) & 3u, db = (b.v[w >> 4] >> (2 * (w & 15))) & 3u;
-    if (da | db) acc = te_add<S>(acc, tab[4 * db + da]);
+    if (da | db) acc = CH::add(acc, tab[4 * db + da]);
   }
-  return acc;
+  return CH::finish(acc);
 }
 template <class S> AVRF_DI void store_xy(uint8_t *out, const te_aff &a) {
   using Fq = typename S::Fq;

@@ -14,6 +14,7 @@
 #include "vrf_batch.h"
 #include "proto_dev.h"
 #include "glv.h"
+#include "fpu_sqrt.h"
 #include "suite_dispatch.h"
 
 // Built once per suite (-DAVRF_TU_SUITE=<id>: the kernels of that suite and the explicit instantiation of SingleOps<S>) and
@@ -929,7 +930,15 @@ template <class S> AVRF_DI int32_t decode_point_at(const uint8_t *__restrict__ s
     fp num = fp_sub<Fq>(one, y2);
     fp a_const = mul_a<S>(one);   // the curve coefficient a (1, -5 or -1)
     fp den = fp_sub<Fq>(a_const, fp_mul<Fq>(fp_const<Fq>(S::D), y2));
-    if (fp_is_zero(den) || !fp_sqrt_ratio_nf<Fq>(num, den, &xm)) st = 2;      // x^2 = (1 - y^2) / (a - d y^2): no inversion, no data-dependent loop
+    bool sq = false;                                                       // x^2 = (1 - y^2) / (a - d y^2): no inversion, no data-dependent loop
+    if (!fp_is_zero(den)) {
+#ifndef AVRF_NO_FPU_SQRT
+      if constexpr (FuAsm<Fq>::value) sq = fu_sqrt_ratio_nf<Fq>(num, den, &xm);   // the same on unsaturated limbs (fpu_sqrt.h)
+      else
+#endif
+        sq = fp_sqrt_ratio_nf<Fq>(num, den, &xm);
+    }
+    if (!sq) st = 2;
     else {
       if (fp_is_negative_mont<Fq>(xm) != neg) xm = fp_neg<Fq>(xm);
       if (fp_is_zero(xm) && neg) st = 2;

@@ -251,10 +251,15 @@ def u32(v):
 
 
 class TEChain:
-    """the sum B - a A of fpu_te.h teu_madd with the C types' ranges asserted (a = -5: unsigned limbs, fu_carry_u)"""
+    """teu4_dbl / teu4_add_sat / teu4_madd_pre of fpu_te.h: the running point of the per-item kernels' scalar multiplications (and
+    the sum B - a A of teu_madd), with the C types' ranges asserted (a = -5: unsigned limbs, fu_carry_u)"""
+    INV = (1.6, 1.8, 2.5, 1.9)
 
     def __init__(self, te):
         self.te, self.f = te, te.f
+
+    def lim(self, a, A, b, B):
+        assert max(abs(v) for v in a) <= A and max(abs(v) for v in b) <= B, (self.te.name, "limb bound (chain)")
 
     def carry_u(self, h, top):
         f = self.f
@@ -269,6 +274,105 @@ class TEChain:
         if k == 2:
             return f.carry([i32(a + b) for a, b in zip(A, B)])
         return [i32(b - a) for a, b in zip(A, B)]
+
+    def check_out(self, r):
+        f = self.f
+        for v, b in zip(r, self.INV):
+            assert abs(f.val(v)) < b * f.p, (self.te.name, "chain value bound", abs(f.val(v)) / f.p, b)
+        return r
+
+    def dbl(self, P):
+        f, k = self.f, self.te.a_kind
+        X, Y, T, Z = P
+        n29, n30 = (1 << f.W) + 4, 1 << (f.W + 1)
+        self.lim(X, n29, Y, n29); self.lim(Z, n29, Z, n29)
+        A, B, Zs = f.mul(X, X, sqr=True), f.mul(Y, Y, sqr=True), f.mul(Z, Z, sqr=True)
+        s = f.carry([i32(a + b) for a, b in zip(X, Y)])
+        Sq = f.mul(s, s, sqr=True)
+        E = [i32(q - a - b) for q, a, b in zip(Sq, A, B)]
+        if k == 1:
+            A5 = self.carry_u([u32(5 * a) for a in A[:-1]], i32(5 * A[-1]))
+            assert f.val(A5) == 5 * f.val(A)
+            G = [i32(b - a) for a, b in zip(A5, B)]; H = [i32(-a - b) for a, b in zip(A5, B)]
+        else:
+            D = [(-a if k == 2 else a) for a in A]
+            G = [i32(d + b) for d, b in zip(D, B)]; H = [i32(d - b) for d, b in zip(D, B)]
+        F = [i32(g - 2 * z) for g, z in zip(G, Zs)]
+        H, F = f.carry(H), f.carry(F)
+        self.lim(E, n30, F, n29); self.lim(G, n30, H, n29)
+        return self.check_out((f.mul(E, F), f.mul(G, H), f.mul(E, H), f.mul(F, G)))
+
+    def add_sat(self, P, e):
+        """e = (x, y, t, z) saturated canonical Montgomery values"""
+        f, te = self.f, self.te
+        X, Y, T, Z = P
+        n29, n30 = (1 << f.W) + 4, 1 << (f.W + 1)
+        ex, ey, et, ez = e
+        sl = lambda v: f.slice(v, f.SH)
+        A, B = f.mul(X, sl(ex)), f.mul(Y, sl(ey))
+        C = f.mul(f.mul(T, sl(et)), sl(te.d * f.R % f.p))
+        D = f.mul(Z, sl(ez))
+        XY = [i32(a + b) for a, b in zip(X, Y)]
+        self.lim(XY, n30, sl(ex + ey), n29)
+        E = f.mul(XY, sl(ex + ey))
+        E = [i32(q - a - b) for q, a, b in zip(E, A, B)]
+        F = [i32(d - c) for d, c in zip(D, C)]; G = [i32(d + c) for d, c in zip(D, C)]
+        H = self.hsum(A, B)
+        self.lim(E, n30, F, n29); self.lim(G, n30, H, n29)
+        return self.check_out((f.mul(E, F), f.mul(G, H), f.mul(E, H), f.mul(F, G)))
+
+    def from_ext(self, e):
+        return tuple(self.f.slice(v, 0) for v in e)
+
+    def to_affine(self, P):
+        f = self.f
+        x, y, t, z = (f.to_packed(v) for v in P)
+        assert (x * y - t * z) % f.p == 0
+        zi = pow(z, -1, f.p)
+        return (x * zi % f.p, y * zi % f.p)
+
+
+def chain_bounds(te):
+    """interval arithmetic: INV is closed under teu4_dbl and teu4_add_sat (units of p)"""
+    f = te.f
+    ratio = f.Ru / f.p
+    kb = 2.0 ** f.SH / ratio
+    x, y, t, z = TEChain.INV
+    am = {0: 1, 1: 5, 2: 1}[te.a_kind]
+    sq = lambda v: v * v / ratio + 1
+    A, B, Zs, Sq = sq(x), sq(y), sq(z), (x + y) ** 2 / ratio + 1
+    E = Sq + A + B; G = am * A + B; H = G; F = G + 2 * Zs
+    d = (E * F / ratio + 1, G * H / ratio + 1, E * H / ratio + 1, F * G / ratio + 1)
+    A, B = kb * x + 1, kb * y + 1
+    C = kb * (kb * t + 1) + 1; D = kb * z + 1
+    E = 2 * kb * (x + y) + 1 + A + B; FG = D + C; H = B + am * A
+    a = (E * FG / ratio + 1, FG * H / ratio + 1, E * H / ratio + 1, FG * FG / ratio + 1)
+    for out in (d, a):
+        assert all(o < i for o, i in zip(out, TEChain.INV)), (te.name, "chain invariant not closed", out)
+    return d, a
+
+
+def check_te_chain(te, rng, n_scalars=4):
+    ch = TEChain(te)
+    f = te.f
+    d, a = chain_bounds(te)
+    sat = lambda P: (P[0] * f.R % f.p, P[1] * f.R % f.p, P[0] * P[1] % f.p * f.R % f.p, f.R % f.p)
+    pts = [te.G]
+    for _ in range(5):
+        pts.append(te.add(pts[-1], te.G))
+    tab = [None] + pts                                               # tab[d] = d G
+    for _ in range(n_scalars):
+        k = rng.getrandbits(48) | (1 << 47)
+        acc = ch.from_ext(sat((0, 1)))
+        ref = (0, 1)
+        for w in reversed(range(0, 48, 2)):                           # 2-bit windows: two doublings, one table addition
+            acc = ch.dbl(ch.dbl(acc)); r2 = te.add(ref, ref); ref = te.add(r2, r2)
+            dgt = (k >> w) & 3
+            if dgt:
+                acc = ch.add_sat(acc, sat(tab[dgt])); ref = te.add(ref, tab[dgt])
+        assert ch.to_affine(acc) == ref, te.name
+    print(f"  {te.name}: doubling chains (teu4_dbl / teu4_add_sat) == affine law; invariant |X|,|Y|,|T|,|Z| < {TEChain.INV} p closed "
+          f"(worst case out: dbl {d[0]:.2f} {d[1]:.2f} {d[2]:.2f} {d[3]:.2f}, add {a[0]:.2f} {a[1]:.2f} {a[2]:.2f} {a[3]:.2f})")
 
 
 def check_te(te, rng, chains=6, length=40):
@@ -476,6 +580,10 @@ def main():
     for name, d in C.items():
         if name.startswith("Suite") and not d.get("SW_NATIVE") and d.get("Fq") in fields and "D" in d:
             check_te(TE(name, d, fields[d["Fq"]]), rng)
+    print("per-item doubling chains:")
+    for name, d in C.items():
+        if name.startswith("Suite") and not d.get("SW_NATIVE") and d.get("Fq") in fields and "D" in d:
+            check_te_chain(TE(name, d, fields[d["Fq"]]), rng)
     print("g1u_madd:")
     for name, d in C.items():
         if name.startswith("G1") and d.get("Fq") in fields:
