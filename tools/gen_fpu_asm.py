@@ -34,9 +34,9 @@ ACC, S0 = 30, 36                 # accumulator pair v[30:31]; modulus limbs from
 M0, D0 = 32, 46                  # 14-limb form: m_k in v[32..45], the doubled limbs of a squaring in v[46..59]
 ACCP = f"v[{ACC}:{ACC + 1}]"
 LO = f"v{ACC}"
-# fields left to the compiler's form: BN254's base field is only used by the G1 bucket accumulation, whose kernel spills with the
-# block's early-clobber outputs (8 VGPRs, tools/kernel_regs.py) and measured no faster (gpurun_out/r5/ab_fuasm.txt)
-SKIP = {"FqBn254"}
+# fields left to the compiler's form (none: BN254's base field, used by the G1 bucket accumulation alone, gains 2.6 % on the ring
+# 4096 prover -- gpurun_out/r5/ab_bn254asm.txt)
+SKIP = set()
 
 
 class Form:
