@@ -31,6 +31,7 @@ import fpu_model  # noqa: E402
 
 OUT = os.path.join(ROOT, "ark_vrf_amd", "csrc", "fpu_asm_gen.h")
 ACC, S0 = 30, 36                 # accumulator pair v[30:31]; modulus limbs from s36
+SM = 52                          # s[52:53] = 2^W - 1 as a 64-bit constant (fields with p = 1 mod 2^W)
 M0, D0 = 32, 46                  # 14-limb form: m_k in v[32..45], the doubled limbs of a squaring in v[46..59]
 ACCP = f"v[{ACC}:{ACC + 1}]"
 LO = f"v{ACC}"
@@ -82,6 +83,9 @@ def body(f, sqr=False):
             ins.append(f"s_mov_b32 {P(j)}, 0x{f.pl[j]:x}")
     if not p0_one:
         ins.append(f"s_mov_b32 s{S0 + L}, 0x{f.ninv:x}")
+    else:
+        ins.append(f"s_mov_b32 s{SM}, 0x{MASK:x}")
+        ins.append(f"s_mov_b32 s{SM + 1}, 0")
     if sqr:
         for j in range(1, L):
             ins.append(f"v_lshlrev_b32 {fm.D(j)}, 1, {fm.A(j)}")
@@ -105,10 +109,10 @@ def body(f, sqr=False):
         for i in range(lo, min(hi, k - 1) + 1):
             mad("v_mad_u64_u32", fm.M(i), P(k - i))
         if k < L:
-            if p0_one:                       # p = 1 mod 2^W: m_k = -lo mod 2^W, and m_k p_0 = m_k
-                ins.append(f"v_sub_u32 {fm.M(k)}, 0, {LO}")
-                ins.append(f"v_and_b32 {fm.M(k)}, 0x{MASK:x}, {fm.M(k)}")
-                ins.append(f"v_mad_u64_u32 {ACCP}, vcc, {fm.M(k)}, 1, {ACCP}")
+            if p0_one:                       # p = 1 mod 2^W: m_k = -lo mod 2^W; acc + m_k p_0 = acc + m_k has its low W bits clear,
+                ins.append(f"v_sub_u32 {fm.M(k)}, 0, {LO}")      # so (acc + m_k) >> W = (acc + 2^W - 1) >> W: a 64-bit add of a
+                ins.append(f"v_and_b32 {fm.M(k)}, 0x{MASK:x}, {fm.M(k)}")   # constant, no multiplier slot
+                ins.append(f"v_lshl_add_u64 {ACCP}, {ACCP}, 0, s[{SM}:{SM + 1}]")
             else:
                 ins.append(f"v_mul_lo_u32 {fm.M(k)}, {LO}, s{S0 + L}")
                 ins.append(f"v_and_b32 {fm.M(k)}, 0x{MASK:x}, {fm.M(k)}")
@@ -123,7 +127,7 @@ def body(f, sqr=False):
 def clobbers(f, sqr=False):
     L = f.L
     p0_one = f.pl[0] == 1 and f.ninv == f.MASK
-    s = [f"s{S0 + j}" for j in range(L + 1) if not (p0_one and j in (0, L))]
+    s = [f"s{S0 + j}" for j in range(L + 1) if not (p0_one and j in (0, L))] + ([f"s{SM}", f"s{SM + 1}"] if p0_one else [])
     return Form(f, sqr).fixed_vgprs() + s + ["vcc"]
 
 
@@ -169,6 +173,9 @@ def emulate(ins, f, a, b, sqr=False):
         elif op == "v_mad_u64_u32":
             add = 0 if o[4] == "0" else prd(o[4])
             pwr(o[0], (rd(o[2]) * rd(o[3]) + add) & M64)
+        elif op == "v_lshl_add_u64":
+            sp = o[3]; lo_s = int(sp[2:sp.index(":")])
+            pwr(o[0], ((prd(o[1]) << rd(o[2])) + (reg[f"s{lo_s}"] | (reg[f"s{lo_s + 1}"] << 32))) & M64)
         elif op == "v_sub_u32":
             reg[o[0]] = (rd(o[1]) - rd(o[2])) & M32
         elif op == "v_mul_lo_u32":
@@ -197,6 +204,8 @@ def check_contract(ins, f, sqr, label):
         dst, srcs = o[0], (o[2:] if has_vcc else o[1:])
         for x in srcs:
             regs = [f"v{ACC}", f"v{ACC + 1}"] if x == "PAIR" else ([x] if re.fullmatch(r"[vs]\d+", x) else [])
+            if re.fullmatch(r"s\[\d+:\d+\]", x):
+                regs = [f"s{int(x[2:x.index(':')])}", f"s{int(x[2:x.index(':')]) + 1}"]
             for r in regs:
                 assert r in seen, (label, "reads a register the stream has not written", r, line)
             if x.startswith("%"):
