@@ -35,6 +35,10 @@
 #define AVRF_G1_RED_WAVES 1
 #endif
 
+#ifndef AVRF_G1_RED_INLINE
+#define AVRF_G1_RED_INLINE 1     // the reductions' general additions inlined at each call site (0: one out-of-line copy per kernel)
+#endif
+
 namespace avrf {
 
 // what k_accumulate keeps in registers between the bucket boundaries of a lane's share: the policy's own accumulator, or -- the
@@ -123,6 +127,9 @@ template <class S> struct TeCurve {
   }
   static AVRF_DI acc_t load_acc(const uint32_t *p) { return load_ext(reinterpret_cast<const te_ext *>(p)); }
   static AVRF_DI void store_acc(uint32_t *p, const acc_t &a) { store_ext(reinterpret_cast<te_ext *>(p), a); }
+  using red = TeCurve<S>;                             // the policy of the fixed-base reduction kernels (G1 only has another one)
+  static constexpr int OUT_WORDS = ACC_WORDS;
+  static AVRF_DI void store_out(uint32_t *p, const acc_t &a) { store_acc(p, a); }
   static AVRF_DI acc_t shfl_down(const acc_t &p, int delta) {
     acc_t r;
 #pragma unroll
@@ -144,6 +151,7 @@ template <class S> struct TeCurve {
 };
 
 // XYZZ: x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; identity <=> ZZ = 0.  Affine bases: (0, 0) = infinity.
+template <class C> struct G1RedCurve;
 template <class C> struct G1Curve {
   using Fq = typename C::Fq;
   static constexpr int N = Fq::N;
@@ -250,6 +258,14 @@ template <class C> struct G1Curve {
   static AVRF_DI void store_acc(uint32_t *p, const acc_t &a) {
     fn_store<N>(p, a.x); fn_store<N>(p + N, a.y); fn_store<N>(p + 2 * N, a.zz); fn_store<N>(p + 3 * N, a.zzz);
   }
+  // the reduction kernels of a fixed-base MSM (bucket sums, weighted sums): general additions on the asm multipliers
+#if !defined(AVRF_NO_UNSAT_G1) && !defined(AVRF_NO_UNSAT_G1_RED)
+  using red = G1RedCurve<C>;
+#else
+  using red = G1Curve<C>;
+#endif
+  static constexpr int OUT_WORDS = ACC_WORDS;
+  static AVRF_DI void store_out(uint32_t *p, const acc_t &a) { store_acc(p, a); }
   static AVRF_DI acc_t shfl_down(const acc_t &a, int delta) {
     acc_t r; r.x = fn_shfl_down<N>(a.x, delta); r.y = fn_shfl_down<N>(a.y, delta);
     r.zz = fn_shfl_down<N>(a.zz, delta); r.zzz = fn_shfl_down<N>(a.zzz, delta); return r;
@@ -263,6 +279,35 @@ template <class C> struct G1Curve {
     }
     return r;
   }
+};
+
+// G1 in the reduction kernels of the fixed-base MSMs (k_bucket_sum, k_heavy_sum, k_wsum, k_wsum_blk): the same interface as
+// G1Curve over g1_red (fpu_g1.h: XYZZ in the Montgomery domain of the unsaturated limbs, general addition = 14 asm blocks).
+// Buckets and LDS hold the raw limbs (the partial sums' layout, G1UPart words per point); what leaves for the host (store_out)
+// is the canonical saturated XYZZ the callers have always read.
+template <class C> struct G1RedCurve {
+  using Fq = typename C::Fq; using SAT = G1Curve<C>;
+  static constexpr int N = Fq::N;
+  using acc_t = g1_red<C>;
+  static constexpr int ACC_WORDS = G1UPart<C>::WORDS, OUT_WORDS = SAT::ACC_WORDS;
+  static constexpr bool QUAD = false, ZERO_IS_IDENTITY = true, INLINE_REDUCE_OPS = AVRF_G1_RED_INLINE != 0;
+  static constexpr int RED_WAVES = SAT::RED_WAVES;
+  struct accum {                                      // the partial sums k_accumulate<G1Curve<C>> left
+    static constexpr int PART_WORDS = SAT::accum::PART_WORDS;
+    static AVRF_DI acc_t load_part(const uint32_t *p) {
+      const typename SAT::acc_t t = SAT::accum::load_part(p);
+      return g1r_from_sat<C>(t.x.v, t.y.v, t.zz.v, t.zzz.v);
+    }
+  };
+  static AVRF_DI acc_t identity() { return g1r_identity<C>(); }
+  static AVRF_DI acc_t add(const acc_t &a, const acc_t &b) { return g1r_add<C>(a, b); }
+  static AVRF_DI acc_t dbl(const acc_t &a) { return g1r_dbl<C>(a); }
+  static AVRF_DI acc_t load_acc(const uint32_t *p) { return g1r_load<C>(p); }
+  static AVRF_DI void store_acc(uint32_t *p, const acc_t &a) { g1r_store<C>(p, a); }
+  static AVRF_DI void store_out(uint32_t *p, const acc_t &a) {
+    typename SAT::acc_t t; g1r_to_sat<C>(a, t.x.v, t.y.v, t.zz.v, t.zzz.v); SAT::store_acc(p, t);
+  }
+  static AVRF_DI acc_t shfl_down(const acc_t &a, int delta) { return g1r_shfl_down<C>(a, delta); }
 };
 
 }  // namespace avrf

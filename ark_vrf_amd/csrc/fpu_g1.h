@@ -114,6 +114,101 @@ template <class C, class DBL> AVRF_DI g1_acc_u<C> g1u_madd(const g1_acc_u<C> &p,
   return r;
 }
 
+// ---- the general addition of the fixed-base reduction kernels (k_bucket_sum, k_heavy_sum, k_wsum, k_wsum_blk over G1RedCurve,
+// curves.h): XYZZ in the Montgomery domain R' = 2^(W L) itself -- every coordinate is value * R', lazily reduced, so fu_mul is
+// a plain Montgomery product and the formulas are add-2008-s / dbl-2008-s-1 as written, with no scaling to track.  A saturated
+// coordinate v R enters as the limbs of (v R) * 2^SH = v R' (fu_slice with the shift: an integer below 2^SH p) and leaves through
+// fu_mul(x R', R) = x R and fu_to_packed.  The additions are 12 + 2 asm blocks of 461 / 383 instructions (14 x 28) against
+// ~650 of the saturated 12-word multiplier.  tools/fpu_model.py "g1r_add / g1r_dbl" proves: limbs within the multipliers'
+// operand ranges, |values| < 128 p everywhere (the doubling of a freshly loaded point is the widest), the exceptional-case test
+// below exact for every pair of loaded / computed operands.
+template <class C> struct g1_red {
+  fuF<typename C::Fq> x, y, zz, zzz;
+  uint32_t inf;                                 // != 0: the identity (coordinates meaningless)
+};
+// limbs of a SQUARE's Montgomery output == 0 mod p: all zero, p's or 2 p's (exact while operand^2 / R' < 2 p: two freshly loaded
+// coordinates differ by up to ~1.06 sqrt(R' p))
+template <class F> AVRF_DI bool fu_is_zero_mod_p2(const fuF<F> &v) {
+  using U = UL<F>;
+  uint32_t z = 0, zp = 0, z2 = 0;
+#pragma unroll
+  for (int i = 0; i < U::L; i++) { z |= (uint32_t)v.v[i]; zp |= (uint32_t)v.v[i] ^ U::P1.v[i]; z2 |= (uint32_t)v.v[i] ^ U::template PK<1>.v[i]; }
+  return z == 0 || zp == 0 || z2 == 0;
+}
+template <class F> AVRF_DI bool fu_maybe_zero_mod_p2(const fuF<F> &v) {
+  const uint32_t l = (uint32_t)v.v[0];
+  return l == 0 || l == UL<F>::P1.v[0] || l == UL<F>::template PK<1>.v[0];
+}
+template <class C> AVRF_DI g1_red<C> g1r_identity() {
+  constexpr int L = UL<typename C::Fq>::L;
+  g1_red<C> r; r.x = fu_zero<L>(); r.y = r.x; r.zz = r.x; r.zzz = r.x; r.inf = 1u; return r;
+}
+// canonical saturated XYZZ words (zz = 0: the identity)
+template <class C> AVRF_DI g1_red<C> g1r_from_sat(const uint32_t (&X)[C::Fq::N], const uint32_t (&Y)[C::Fq::N], const uint32_t (&ZZ)[C::Fq::N], const uint32_t (&ZZZ)[C::Fq::N]) {
+  using Fq = typename C::Fq; constexpr int SH = UL<Fq>::SH;
+  g1_red<C> r;
+  r.x = fu_slice<Fq, SH>(X); r.y = fu_slice<Fq, SH>(Y); r.zz = fu_slice<Fq, SH>(ZZ); r.zzz = fu_slice<Fq, SH>(ZZZ);
+  r.inf = words_zero(ZZ) ? 1u : 0u;
+  return r;
+}
+template <class C> AVRF_DI void g1r_to_sat(const g1_red<C> &a, uint32_t (&X)[C::Fq::N], uint32_t (&Y)[C::Fq::N], uint32_t (&ZZ)[C::Fq::N], uint32_t (&ZZZ)[C::Fq::N]) {
+  using Fq = typename C::Fq; constexpr int N = Fq::N;
+  const fuF<Fq> one = fu_const<Fq>(UL<Fq>::ONE);                    // R mod p: fu_mul(x R', R) = x R
+  fu_to_packed<Fq, 2>(X, fu_mul<Fq>(a.x, one)); fu_to_packed<Fq, 2>(Y, fu_mul<Fq>(a.y, one));
+  fu_to_packed<Fq, 2>(ZZ, fu_mul<Fq>(a.zz, one)); fu_to_packed<Fq, 2>(ZZZ, fu_mul<Fq>(a.zzz, one));
+  if (a.inf) {
+#pragma unroll
+    for (int i = 0; i < N; i++) { X[i] = Fq::ONE[i]; Y[i] = Fq::ONE[i]; ZZ[i] = 0; ZZZ[i] = 0; }
+  }
+}
+// 2 a (dbl-2008-s-1, a = 0): 6M + 3S
+template <class C> AVRF_DI g1_red<C> g1r_dbl(const g1_red<C> &a) {
+  using Fq = typename C::Fq; constexpr int L = UL<Fq>::L;
+  if (a.inf) return a;
+  fu<L> V = fu_sqr<Fq>(a.y), U, M = fu_sqr<Fq>(a.x);
+#pragma unroll
+  for (int i = 0; i < L; i++) { V.v[i] *= 4; U.v[i] = 2 * a.y.v[i]; M.v[i] *= 3; }
+  V = fu_carry<Fq>(V); M = fu_carry<Fq>(M);
+  const fu<L> W = fu_mul<Fq>(U, V), S = fu_mul<Fq>(a.x, V), MM = fu_sqr<Fq>(M);
+  fu<L> X3;
+#pragma unroll
+  for (int i = 0; i < L; i++) X3.v[i] = MM.v[i] - 2 * S.v[i];
+  const fu<L> SX = fu_carry<Fq>(fu_sub<L>(S, X3));
+  g1_red<C> r;
+  r.y = fu_sub<L>(fu_mul<Fq>(M, SX), fu_mul<Fq>(W, a.y));
+  r.x = fu_carry<Fq>(X3);
+  r.zz = fu_mul<Fq>(V, a.zz); r.zzz = fu_mul<Fq>(W, a.zzz);
+  r.inf = 0;
+  return r;
+}
+// a + b (add-2008-s): 12M + 2S; the exceptional cases leave early
+template <class C> AVRF_DI g1_red<C> g1r_add(const g1_red<C> &a, const g1_red<C> &b) {
+  using Fq = typename C::Fq; constexpr int L = UL<Fq>::L;
+  if (a.inf) return b;
+  if (b.inf) return a;
+  const fu<L> U1 = fu_mul<Fq>(a.x, b.zz), S1 = fu_mul<Fq>(a.y, b.zzz);
+  const fu<L> P = fu_sub<L>(fu_mul<Fq>(b.x, a.zz), U1), R = fu_sub<L>(fu_mul<Fq>(b.y, a.zzz), S1);
+  const fu<L> PP = fu_sqr<Fq>(P);
+  if (__builtin_expect(__any(fu_maybe_zero_mod_p2<Fq>(PP)), 0)) {
+    if (fu_is_zero_mod_p2<Fq>(PP)) {                                      // b = +-a
+      if (fu_is_zero_mod_p2<Fq>(fu_sqr<Fq>(R))) return g1r_dbl<C>(a);
+      return g1r_identity<C>();
+    }
+  }
+  g1_red<C> r;
+  const fu<L> PPP = fu_mul<Fq>(P, PP), Q = fu_mul<Fq>(U1, PP);
+  r.zz = fu_mul<Fq>(fu_mul<Fq>(a.zz, b.zz), PP); r.zzz = fu_mul<Fq>(fu_mul<Fq>(a.zzz, b.zzz), PPP);
+  const fu<L> T = fu_mul<Fq>(S1, PPP), RR = fu_sqr<Fq>(R);
+  fu<L> X3;
+#pragma unroll
+  for (int i = 0; i < L; i++) X3.v[i] = RR.v[i] - PPP.v[i] - 2 * Q.v[i];
+  const fu<L> QX = fu_carry<Fq>(fu_sub<L>(Q, X3));
+  r.y = fu_sub<L>(fu_mul<Fq>(R, QX), T);
+  r.x = fu_carry<Fq>(X3);
+  r.inf = 0;
+  return r;
+}
+
 // A partial sum as k_accumulate leaves it (raw limbs + the identity flag; see fpu_te.h teu_store_part for why the conversion
 // belongs to the reader): 4 L limbs, the flag, padding to a multiple of four words.
 template <class C> struct G1UPart { static constexpr int L = UL<typename C::Fq>::L, WORDS = (4 * L + 1 + 3) / 4 * 4; };
@@ -148,6 +243,37 @@ template <class C> AVRF_DI void g1u_load_part(const uint32_t *p, uint32_t (&X)[C
 #pragma unroll
     for (int i = 0; i < N; i++) { ZZ[i] = 0; ZZZ[i] = 0; }
   }
+}
+
+// A reduction point in memory (buckets, LDS): the raw limbs and the flag in the partial sums' layout; all-zero words (a bucket
+// nothing was written to) read as the identity
+template <class C> AVRF_DI void g1r_store(uint32_t *p, const g1_red<C> &a) {
+  g1_acc_u<C> t; t.x = a.x; t.y = a.y; t.zz = a.zz; t.zzz = a.zzz; t.inf = a.inf;
+  g1u_store_part<C>(p, t);
+}
+template <class C> AVRF_DI g1_red<C> g1r_load(const uint32_t *p) {
+  constexpr int L = G1UPart<C>::L, WORDS = G1UPart<C>::WORDS;
+  uint32_t w[WORDS];
+  const uint4 *s = reinterpret_cast<const uint4 *>(p);
+#pragma unroll
+  for (int i = 0; i < WORDS / 4; i++) { const uint4 q = s[i]; w[4 * i] = q.x; w[4 * i + 1] = q.y; w[4 * i + 2] = q.z; w[4 * i + 3] = q.w; }
+  g1_red<C> r;
+  uint32_t zzor = 0;
+#pragma unroll
+  for (int i = 0; i < L; i++) { r.x.v[i] = (int32_t)w[i]; r.y.v[i] = (int32_t)w[L + i]; r.zz.v[i] = (int32_t)w[2 * L + i]; r.zzz.v[i] = (int32_t)w[3 * L + i]; zzor |= w[2 * L + i]; }
+  r.inf = (w[4 * L] != 0 || zzor == 0) ? 1u : 0u;
+  return r;
+}
+template <class C> AVRF_DI g1_red<C> g1r_shfl_down(const g1_red<C> &a, int delta) {
+  constexpr int L = G1UPart<C>::L;
+  g1_red<C> r;
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    r.x.v[i] = __shfl_down(a.x.v[i], delta); r.y.v[i] = __shfl_down(a.y.v[i], delta);
+    r.zz.v[i] = __shfl_down(a.zz.v[i], delta); r.zzz.v[i] = __shfl_down(a.zzz.v[i], delta);
+  }
+  r.inf = __shfl_down(a.inf, delta);
+  return r;
 }
 
 }  // namespace avrf

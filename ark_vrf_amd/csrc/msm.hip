@@ -407,6 +407,7 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
   AC::store_part(part + (slot0 + b) * AC::PART_WORDS, acc);
 }
 
+template <class T> struct type_tag { using type = T; };
 template <class CV> AVRF_DI typename CV::acc_t wave_sum(typename CV::acc_t acc);
 
 // Bucket `slot` = v * nb + b holds entries [offs, offs + cnt): they were accumulated by lanes lf..ll of window v, whose partials
@@ -582,7 +583,7 @@ k_wsum(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t nsets, uint32
     acc_t o = CV::shfl_down(V, off);
     if (g + off < lps) V = cv_add<CV>(V, o);
   }
-  if (live && g == 0) CV::store_acc(out + (size_t)set * CV::ACC_WORDS, V);
+  if (live && g == 0) CV::store_out(out + (size_t)set * CV::OUT_WORDS, V);
 }
 
 // Same weighted sum with a whole workgroup (wps waves) per bucket set, for launches with few sets: lane t of the
@@ -632,7 +633,7 @@ k_wsum_blk(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t *__restri
     }
 #pragma unroll 1
     for (uint32_t k = 64 * m; k > 1; k >>= 1) q = cv_dbl<CV>(q);
-    CV::store_acc(out + (size_t)set * CV::ACC_WORDS, cv_add<CV>(r, q));
+    CV::store_out(out + (size_t)set * CV::OUT_WORDS, cv_add<CV>(r, q));
   }
 }
 
@@ -897,7 +898,10 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
     n = n_in * (size_t)dig_nwin;                                        // one window of n_in * dig_nwin keys per vector
     remap_n = (uint32_t)n_in; remap_stride = (uint32_t)table_stride;
   }
-  const size_t acc_bytes = (size_t)CV::ACC_WORDS * 4;
+  // fixed-base mode: the reduction kernels run over CV::red (G1: general additions on the unsaturated limbs, buckets in raw limbs)
+  using RV = typename CV::red;
+  const bool red = CV::FIXED_TABLE && table_c != 0;
+  const size_t acc_bytes = (size_t)(red ? (int)RV::ACC_WORDS : (int)CV::ACC_WORDS) * 4;
   const uint32_t vwin = (uint32_t)(p.nwin * batch);
   const size_t lanes_max = lanes_target + vwin + 256;                   // sum_v ceil(tot_v / per) <= total / per + vwin
   if ((size_t)vwin * n >= 0xffff0000ull) throw HipFailure{hipErrorInvalidValue, __FILE__, __LINE__};   // 32-bit entry offsets
@@ -923,11 +927,15 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
                      (const uint32_t *)ws.offsets, (const uint32_t *)ws.win_tot, (const uint32_t *)ws.lane_base, (const uint32_t *)ws.plan_dev, vwin,
                      (uint32_t)p.nb, (uint32_t)n, ws.part);
   HIP_CHECK(hipEventRecord(ev1, stream));
-  hipLaunchKernelGGL(k_bucket_sum<CV>, dim3((nbk + 255) / 256), b256, 0, stream, (const uint32_t *)ws.offsets, (const uint32_t *)ws.cnts,
-                     (const uint32_t *)ws.lane_base, ws.plan_dev, nbk, (uint32_t)p.nb, (uint32_t)n, (const uint32_t *)ws.part, ws.buckets, ws.heavy);
-  hipLaunchKernelGGL(k_heavy_sum<CV>, dim3(nbk < 1024 ? nbk : 1024), b256, 4 * acc_bytes, stream, (const uint32_t *)ws.offsets, (const uint32_t *)ws.cnts,
-                     (const uint32_t *)ws.lane_base, (const uint32_t *)ws.plan_dev, (uint32_t)p.nb, (uint32_t)n, (const uint32_t *)ws.part, ws.buckets,
-                     (const uint32_t *)ws.heavy);
+  auto bucket_sums = [&](auto tag) {
+    using BV = typename decltype(tag)::type;
+    hipLaunchKernelGGL(k_bucket_sum<BV>, dim3((nbk + 255) / 256), b256, 0, stream, (const uint32_t *)ws.offsets, (const uint32_t *)ws.cnts,
+                       (const uint32_t *)ws.lane_base, ws.plan_dev, nbk, (uint32_t)p.nb, (uint32_t)n, (const uint32_t *)ws.part, ws.buckets, ws.heavy);
+    hipLaunchKernelGGL(k_heavy_sum<BV>, dim3(nbk < 1024 ? nbk : 1024), b256, 4 * acc_bytes, stream, (const uint32_t *)ws.offsets, (const uint32_t *)ws.cnts,
+                       (const uint32_t *)ws.lane_base, (const uint32_t *)ws.plan_dev, (uint32_t)p.nb, (uint32_t)n, (const uint32_t *)ws.part, ws.buckets,
+                       (const uint32_t *)ws.heavy);
+  };
+  if (red) bucket_sums(type_tag<RV>{}); else bucket_sums(type_tag<CV>{});
   HIP_CHECK(hipMemcpyAsync(pend ? pend->plan_host : ws.plan_host, ws.plan_dev, 8, hipMemcpyDeviceToHost, stream));
   // defer: the caller collects the results later (msm_wait): everything up to the copies back is enqueued, nothing is waited for
   if (pend) pend->plan = p; else ws.pending_plan = p;
@@ -959,16 +967,16 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
     const uint32_t wps_max = batch <= 64 ? 4 : 1;
     while (wps < wps_max && (uint32_t)p.nb >= 64 * wps * 2) wps *= 2;
     if (wps > 1) {
-      hipLaunchKernelGGL(k_wsum_blk<CV>, dim3((unsigned)batch), dim3(64 * wps), (size_t)wps * 2 * acc_bytes, stream, (const uint32_t *)ws.buckets,
+      hipLaunchKernelGGL(k_wsum_blk<RV>, dim3((unsigned)batch), dim3(64 * wps), (size_t)wps * 2 * acc_bytes, stream, (const uint32_t *)ws.buckets,
                          (uint32_t)p.nb, ws.rc);
     } else {
       uint32_t lps_log = 6;                                // lanes per bucket set: enough waves to cover the chip, <= nb
       while (lps_log > 2 && (batch << (lps_log - 1)) >= 2048 * 64) lps_log--;
       while ((1u << lps_log) > (uint32_t)p.nb) lps_log--;
-      hipLaunchKernelGGL(k_wsum<CV>, dim3((unsigned)(((batch << lps_log) + 255) / 256)), b256, 0, stream, (const uint32_t *)ws.buckets, (uint32_t)p.nb,
+      hipLaunchKernelGGL(k_wsum<RV>, dim3((unsigned)(((batch << lps_log) + 255) / 256)), b256, 0, stream, (const uint32_t *)ws.buckets, (uint32_t)p.nb,
                          (uint32_t)batch, lps_log, ws.rc);
     }
-    HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.rc, batch * acc_bytes, hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.rc, batch * (size_t)RV::OUT_WORDS * 4, hipMemcpyDeviceToHost, stream));
     finish();
     return p.c;
   }

@@ -567,6 +567,117 @@ def check_g1(g, rng, chains=4, length=25):
           f"{b[0]:.2f} {b[1]:.2f} {b[2]:.2f} {b[3]:.2f}; seen {worst[0]:.2f} {worst[1]:.2f} {worst[2]:.2f} {worst[3]:.2f})")
 
 
+class G1Red:
+    """g1r_add / g1r_dbl of fpu_g1.h: the general XYZZ addition and doubling of the fixed-base reduction kernels (k_bucket_sum,
+    k_heavy_sum, k_wsum*) in the Montgomery domain R' = 2^(W L) -- every coordinate is value * R' lazily reduced, nothing scaled.
+    A point is (X, Y, ZZ, ZZZ) limb lists or None (the identity flag)."""
+    VB = 128.0                                               # results stay below VB * p in magnitude (the doubling of a freshly loaded
+                                                             # point: V = 4 Y^2 / R' < 4 * 2^(2 SH) p / (R' / p)); a loaded (sliced)
+                                                             # coordinate is value * R * 2^SH as an integer: below 2^SH p
+
+    def __init__(self, g):
+        self.g, self.f = g, g.f
+
+    def chk(self, P, vb=None):
+        f = self.f
+        n = (1 << f.W) + 16
+        for c in P:
+            assert max(abs(v) for v in c) <= n and abs(f.val(c)) < (vb or self.VB) * f.p, (self.g.name, "reduction coordinate out of range")
+        return P
+
+    def from_sat(self, X, Y, ZZ, ZZZ, extreme=False):
+        """extreme: the representative of the same residues with the largest value a load can produce (just below 2^SH p)"""
+        f = self.f
+        if extreme:
+            top = ((1 << f.SH) - 1) * f.p
+            return self.chk(tuple(f.slice_pos(((v << f.SH) % f.p) + top) for v in (X, Y, ZZ, ZZZ)), vb=float(1 << f.SH))
+        return self.chk(tuple(f.slice(v, f.SH) for v in (X, Y, ZZ, ZZZ)), vb=float(1 << f.SH))
+
+    def zero(self, v, operand):
+        """fu_is_zero_mod_p2: a square's output is 0 mod p iff its limbs are 0, p's or 2p's -- valid while operand^2 / R' < 2 p
+        (two loaded coordinates can differ by up to 2 * 2^(2 SH) p^2 / R' + 2p)"""
+        f = self.f
+        ov = abs(f.val(operand))
+        assert ov * ov < f.Ru * f.p * 19 // 10, (self.g.name, "zero test out of range", ov / f.p)
+        self.worst_zero = max(getattr(self, "worst_zero", 0.0), ov * ov / (f.Ru * f.p))
+        p2 = f.slice_pos(2 * f.p)
+        is0 = all(l == 0 for l in v) or all(l == pl for l, pl in zip(v, f.pl)) or all(l == pl for l, pl in zip(v, p2))
+        assert is0 == (f.val(v) % f.p == 0)
+        return is0
+
+    def dbl(self, A):
+        f = self.f
+        X, Y, ZZ, ZZZ = A
+        YY = f.mul(Y, Y, sqr=True)
+        V = f.carry([i32(4 * v) for v in YY])
+        U = [i32(2 * v) for v in Y]
+        Wv = f.mul(U, V)
+        S = f.mul(X, V)
+        M = f.carry([i32(3 * v) for v in f.mul(X, X, sqr=True)])
+        X3 = [i32(m - 2 * s) for m, s in zip(f.mul(M, M, sqr=True), S)]
+        SX = f.carry([i32(s - x) for s, x in zip(S, X3)])
+        Y3 = [i32(a - b) for a, b in zip(f.mul(M, SX), f.mul(Wv, Y))]
+        return self.chk((f.carry(X3), Y3, f.mul(V, ZZ), f.mul(Wv, ZZZ)))
+
+    def add(self, A, B):
+        f = self.f
+        if A is None: return B
+        if B is None: return A
+        X1, Y1, ZZ1, ZZZ1 = A
+        X2, Y2, ZZ2, ZZZ2 = B
+        U1, U2 = f.mul(X1, ZZ2), f.mul(X2, ZZ1)
+        S1, S2 = f.mul(Y1, ZZZ2), f.mul(Y2, ZZZ1)
+        P = [i32(a - b) for a, b in zip(U2, U1)]; R = [i32(a - b) for a, b in zip(S2, S1)]
+        PP = f.mul(P, P, sqr=True)
+        if self.zero(PP, P):
+            return self.dbl(A) if self.zero(f.mul(R, R, sqr=True), R) else None
+        PPP, Q = f.mul(P, PP), f.mul(U1, PP)
+        ZZ3 = f.mul(f.mul(ZZ1, ZZ2), PP); ZZZ3 = f.mul(f.mul(ZZZ1, ZZZ2), PPP)
+        T = f.mul(S1, PPP); RR = f.mul(R, R, sqr=True)
+        X3 = [i32(r - a - 2 * b) for r, a, b in zip(RR, PPP, Q)]
+        QX = f.carry([i32(a - b) for a, b in zip(Q, X3)])
+        Y3 = [i32(a - b) for a, b in zip(f.mul(R, QX), T)]
+        return self.chk((f.carry(X3), Y3, ZZ3, ZZZ3))
+
+    def to_affine(self, A):
+        if A is None: return None
+        f = self.f
+        X, Y, ZZ, ZZZ = (f.val(c) % f.p for c in A)            # the common factor R' cancels in X / ZZ and Y / ZZZ
+        if ZZ == 0: return None
+        assert (ZZ ** 3 - ZZZ ** 2 * f.Ru) % f.p == 0          # (zz R')^3 = (zzz R')^2 R'  <=>  zz^3 = zzz^2
+        return (X * pow(ZZ, -1, f.p) % f.p, Y * pow(ZZZ, -1, f.p) % f.p)
+
+
+def check_g1_red(g, rng, rounds=60):
+    r, f = G1Red(g), g.f
+    pts = [g.rand_point(rng) for _ in range(5)]
+    sat = lambda P, ex=False: r.from_sat(P[0] * f.R % f.p, P[1] * f.R % f.p, f.R % f.p, f.R % f.p, extreme=ex)
+    pool = [(sat(P), P) for P in pts] + [(sat(P, True), P) for P in pts] + [(None, None)]
+    for (A, a) in list(pool[:-1]):                                                # loaded x loaded, every pair incl. the extreme representatives
+        for (B, b) in list(pool[:-1]):
+            assert r.to_affine(r.add(A, B)) == g.add(a, b), (g.name, "loaded x loaded")
+        assert r.to_affine(r.dbl(A)) == g.add(a, a)
+    cases = {"add": 0, "dbl": 0, "inverse": 0, "identity": 0}
+    for i in range(rounds):
+        (A, a), (B, b) = rng.choice(pool), rng.choice(pool)
+        if i % 7 == 3: (B, b) = (A, a)                                            # P + P through the addition's own test
+        if i % 7 == 5 and a is not None:                                          # P + (-P)
+            B = (A[0], [-v for v in A[1]], A[2], A[3]); b = (a[0], (-a[1]) % f.p)
+        Cc, c = r.add(A, B), g.add(a, b)
+        assert r.to_affine(Cc) == c, (g.name, "general addition")
+        cases["identity" if A is None or B is None else "inverse" if c is None else "dbl" if a == b else "add"] += 1
+        if A is not None:
+            D = r.dbl(A); assert r.to_affine(D) == g.add(a, a); pool.append((D, g.add(a, a)))
+        if Cc is not None:
+            pool.append((Cc, c))
+        pool = pool[-24:] + [(None, None)]
+    assert all(v > 0 for v in cases.values()), cases
+    # the widest difference two LOADED points can produce: U <= (2^SH p)^2 / R' + p, |P| <= 2 U
+    u = (1 << (2 * f.SH)) * f.p / f.Ru + 1
+    assert (2 * u) ** 2 * f.p / f.Ru < 1.9, (g.name, "loaded operands leave the range of the zero test", (2 * u) ** 2 * f.p / f.Ru)
+    print(f"  {g.name}: general XYZZ additions / doublings in the R' domain == affine law ({cases}); limbs within 2^W + 16, |values| < {G1Red.VB} p, incl. every pair of freshly loaded points at their largest representatives (zero test worst case {r.worst_zero:.2f} < 1.9)")
+
+
 def main():
     C = parse()
     rng = random.Random(5)
@@ -588,6 +699,10 @@ def main():
     for name, d in C.items():
         if name.startswith("G1") and d.get("Fq") in fields:
             check_g1(G1(name, d, fields[d["Fq"]]), rng)
+    print("g1r_add / g1r_dbl (fixed-base reductions):")
+    for name, d in C.items():
+        if name.startswith("G1") and d.get("Fq") in fields:
+            check_g1_red(G1(name, d, fields[d["Fq"]]), rng)
     print("all checks passed")
 
 
