@@ -642,6 +642,7 @@ k_wsum_blk(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t *__restri
 // tuning knobs from the environment, read once per process
 struct MsmEnv {
   int c = 0, per_min = 8, wsum_wps = 0, occ = 0, tile = 0; bool window_sums = true, tiny = true;
+  size_t wsum_blk_max = 64;          // fixed-base launches of at most this many bucket sets take the workgroup-per-set weighted sum
   MsmEnv() {
     if (const char *e = getenv("AVRF_MSM_C")) { int v = atoi(e); if (v >= 3 && v <= 15) c = v; }
     if (const char *e = getenv("AVRF_MSM_OCC")) { int v = atoi(e); if (v >= 1 && v <= 8) occ = v; }   // resident k_accumulate waves per SIMD to fill
@@ -649,6 +650,7 @@ struct MsmEnv {
     if (const char *e = getenv("AVRF_MSM_PER_MIN")) { int v = atoi(e); if (v >= 1 && v <= 4096) per_min = v; }
     if (const char *e = getenv("AVRF_TE_WSUM_WPS")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) wsum_wps = v; }
     if (const char *e = getenv("AVRF_TE_WINDOW_SUMS")) window_sums = atoi(e) != 0;
+    if (const char *e = getenv("AVRF_G1_WSUM_BLK_MAX")) { int v = atoi(e); if (v >= 0 && v <= 65536) wsum_blk_max = (size_t)v; }
     if (const char *e = getenv("AVRF_MSM_TINY")) tiny = atoi(e) != 0;                    // (A/B hook: 0 sends small MSMs through the general chain too)
   }
 };
@@ -964,7 +966,7 @@ static int msm_device(const uint32_t *d_bases, const uint32_t *d_scalars, size_t
     // soon as a few hundred sets are in flight; the workgroup form is for the handful of sets of a single proof)
     // (round 3 re-check with 512-set launches, which fill only half the SIMDs with one wave per set: two waves per set 12.4 k proofs/s,
     // four 11.9 k against 12.6-12.7 k -- with several contexts in flight the idle SIMDs are not idle, total work decides)
-    const uint32_t wps_max = batch <= 64 ? 4 : 1;
+    const uint32_t wps_max = batch <= msm_env().wsum_blk_max ? 4 : 1;
     while (wps < wps_max && (uint32_t)p.nb >= 64 * wps * 2) wps *= 2;
     if (wps > 1) {
       hipLaunchKernelGGL(k_wsum_blk<RV>, dim3((unsigned)batch), dim3(64 * wps), (size_t)wps * 2 * acc_bytes, stream, (const uint32_t *)ws.buckets,

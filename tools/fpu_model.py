@@ -567,6 +567,72 @@ def check_g1(g, rng, chains=4, length=25):
           f"{b[0]:.2f} {b[1]:.2f} {b[2]:.2f} {b[3]:.2f}; seen {worst[0]:.2f} {worst[1]:.2f} {worst[2]:.2f} {worst[3]:.2f})")
 
 
+def check_sqrt_chain(f, d, rng, n=6):
+    """fu_sqrt_ratio_nf of fpu_sqrt.h: u, v enter as (value R) * 2^SH (below 2^SH p), every later operand is a product's output or
+    a slice, results leave through a product with R mod p and fu_to_packed<2>.  Runs the routine on random squares and
+    non-squares with the model's multiplier (columns in 63 bits, limbs in range) and checks x^2 v = u."""
+    p, L = f.p, f.L
+    S = d["TWO_ADICITY"]
+    t = (p - 1) >> S
+    e = (t - 1) // 2
+    g = d["ROOT"] * pow(f.R, -1, p) % p                         # a generator of the 2^S-th roots of unity (Montgomery form in the header)
+    sl = lambda v: f.slice(v, f.SH)
+    to_r = f.slice_pos(f.R % p)
+    big = 0.0
+
+    def val(x):                                                 # residue of a lazily reduced element in the R' domain
+        return f.val(x) * pow(f.Ru, -1, p) % p
+
+    def mul(x, y, sqr=False):
+        nonlocal big
+        big = max(big, abs(f.val(x)) / p, abs(f.val(y)) / p)
+        return f.mul(x, y, sqr=sqr)
+
+    def packed(x):
+        y = mul(x, to_r)
+        assert abs(f.val(y)) < 4 * p
+        return f.to_packed(y) * pow(f.R, -1, p) % p
+
+    for it in range(n):
+        x0 = rng.randrange(1, p); v0 = rng.randrange(1, p)
+        u0 = x0 * x0 * v0 % p if it % 3 else rng.randrange(1, p)
+        uu, vv = sl(u0 * f.R % p), sl(v0 * f.R % p)
+        a = mul(uu, vv)
+        tab = [None, a]
+        for k in range(2, 16):
+            tab.append(mul(tab[-1], a))
+        digits = [(e >> (4 * i)) & 15 for i in range(64)]
+        top = max(i for i in range(64) if digits[i])
+        w = tab[digits[top]]
+        for i in range(top - 1, -1, -1):
+            for _ in range(4):
+                w = mul(w, w, sqr=True)
+            if digits[i]:
+                w = mul(w, tab[digits[i]])
+        assert val(w) == pow(u0 * v0 % p, e, p)
+        c = mul(a, mul(w, w, sqr=True)); r = mul(uu, w)
+        odd = False
+        steps = (S + 3) // 4
+        for i in range(steps):
+            wd = min(4, S - 4 * i)
+            dd = c
+            for _ in range(S - 4 * i - wd):
+                dd = mul(dd, dd, sqr=True)
+            dc = packed(dd)
+            h = pow(g, 1 << (S - wd), p)                           # generator of the 2^wd-th roots
+            j = next(j for j in range(1 << wd) if pow(h, j, p) == dc)
+            if i == 0 and j & 1:
+                odd = True
+            gs = pow(g, -(j << (4 * i)), p); gh = pow(g, -((j << (4 * i)) >> 1), p) if not (i == 0 and j & 1) else 1
+            c = mul(c, sl(gs * f.R % p)); r = mul(r, sl(gh * f.R % p))
+        x = packed(r)
+        is_sq = pow(u0 * pow(v0, -1, p) % p, (p - 1) // 2, p) == 1
+        assert odd == (not is_sq)
+        if is_sq:
+            assert x * x % p * v0 % p == u0
+    print(f"  {f.name}: sqrt(u / v) on unsaturated limbs (4-bit-window power, {S}-bit discrete log) on {n} random inputs; largest operand {big:.1f} p (the inputs sliced with the shift)")
+
+
 class G1Red:
     """g1r_add / g1r_dbl of fpu_g1.h: the general XYZZ addition and doubling of the fixed-base reduction kernels (k_bucket_sum,
     k_heavy_sum, k_wsum*) in the Montgomery domain R' = 2^(W L) -- every coordinate is value * R' lazily reduced, nothing scaled.
@@ -699,6 +765,10 @@ def main():
     for name, d in C.items():
         if name.startswith("G1") and d.get("Fq") in fields:
             check_g1(G1(name, d, fields[d["Fq"]]), rng)
+    print("fu_sqrt_ratio_nf (point decompression):")
+    for name in ("FqBandersnatch", "FqBabyJubJub", "FqEd25519"):
+        if name in fields and "ROOT" in C[name]:
+            check_sqrt_chain(fields[name], C[name], rng)
     print("g1r_add / g1r_dbl (fixed-base reductions):")
     for name, d in C.items():
         if name.startswith("G1") and d.get("Fq") in fields:
