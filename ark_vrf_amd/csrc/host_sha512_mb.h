@@ -8,6 +8,11 @@
 // batch without them, 0.8-0.89 ms with).  This file is the attempt to remove that; it hashes 3.6x more per core-second but
 // did NOT pay in the closed loop of 16 contexts (capi.hip, WeightHashService: opt-in, with the numbers).
 //
+// The routines are compiled by g++ (host_hash.cpp -> host_hash.o, csrc/Makefile), not by hipcc's clang: on the bench host (EPYC 9575F)
+// g++'s code hashes a batch in 0.82 ms of one core with eight lanes and 0.61 ms with two interleaved groups of eight, clang's in
+// 1.01 / 1.14 ms (it spills the second group's message schedule); tools/hostbench/run.sh.  Units compiled by hipcc see the
+// declarations only.
+//
 // Message of a lane: prefix (suite id || 0x50) followed by n records  c(16) || 0(16) || resp(rsz)   (rsz = 32 Thin, 64 Pedersen).
 #pragma once
 #include <immintrin.h>
@@ -25,6 +30,14 @@ struct WeightJob {
   uint8_t digest[64];
 };
 
+inline bool sha512_mb_available() { return __builtin_cpu_supports("avx512f"); }
+inline bool sha512_mb16_available() { return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw"); }
+// digests of up to eight / sixteen weight transcripts (lanes may differ in length: a finished lane keeps its state); sixteen = two
+// groups of eight advanced in one interleaved round loop (count <= 8: one group through the same transposing loader)
+void sha512_weights_x8(WeightJob *const *jobs, int count);
+void sha512_weights_x16(WeightJob *const *jobs, int count);
+
+#ifdef AVRF_SHA_MB_IMPL
 namespace mb_detail {
 
 static const uint64_t K512[80] = {
@@ -124,10 +137,9 @@ AVRF_MB_TARGET static inline void compress_x8(__m512i (&H)[8], __m512i (&W)[16])
 
 }  // namespace mb_detail
 
-inline bool sha512_mb_available() { return __builtin_cpu_supports("avx512f"); }
 
 // digests of up to eight weight transcripts (lanes may differ in length: a finished lane keeps its state)
-AVRF_MB_TARGET static inline void sha512_weights_x8(WeightJob *const *jobs, int count) {
+AVRF_MB_TARGET static inline void sha512_weights_x8_impl(WeightJob *const *jobs, int count) {
   using namespace mb_detail;
   static const uint64_t iv[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
                                  0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
@@ -244,11 +256,10 @@ AVRF_MB16_TARGET static inline void compress_x8r(__m512i (&HA)[8], __m512i (&WA)
 
 }  // namespace mb_detail
 
-inline bool sha512_mb16_available() { return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw"); }
 
 // digests of up to sixteen weight transcripts: lanes 0-7 and 8-15 are two groups advanced in one interleaved round loop
 // (count <= 8: one group through the same transposing loader)
-AVRF_MB16_TARGET static inline void sha512_weights_x16(WeightJob *const *jobs, int count) {
+AVRF_MB16_TARGET static inline void sha512_weights_x16_impl(WeightJob *const *jobs, int count) {
   using namespace mb_detail;
   static const uint64_t iv[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
                                  0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
@@ -284,5 +295,7 @@ AVRF_MB16_TARGET static inline void sha512_weights_x16(WeightJob *const *jobs, i
       for (int i = 0; i < 8; i++) for (int k = 0; k < 8; k++) jobs[l]->digest[8 * i + k] = (uint8_t)(out[i][l - 8 * gI] >> (56 - 8 * k));
   }
 }
+
+#endif  // AVRF_SHA_MB_IMPL
 
 }  // namespace avrf

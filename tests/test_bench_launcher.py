@@ -58,8 +58,8 @@ def test_host_plan_follows_the_quota():
     import bench
     p = bench.host_plan(16, 1)
     assert (p["slots"], p["lanes"], p["threads"], p["group"], p["cores"]) == (240, 10, 10, 8, 16.0)   # ten threads, three groups of eight transcripts each
-    p = bench.host_plan(16, 8)                                    # 2 cores per rank: eight transcripts hashed together, three groups per thread
-    assert (p["threads"], p["group"], p["cores"]) == (2, 8, 2.0) and p["slots"] == 48 and p["lanes"] == 12
+    p = bench.host_plan(16, 8)                                    # 2 cores per rank: sixteen transcripts hashed together (two interleaved groups), three groups per thread
+    assert (p["threads"], p["group"], p["cores"]) == (2, 16, 2.0) and p["slots"] == 96 and p["lanes"] == 12
     assert bench.host_plan(256, 8)["threads"] == 10 and bench.host_plan(256, 8)["group"] == 8
     assert bench.host_plan(16, 2)["threads"] == 6 and bench.host_plan(8, 2)["threads"] == 4 and bench.host_plan(8, 2)["slots"] == 96
     p = bench.host_plan(16, 4)                                    # 4 cores per rank: multi-buffer hashing on four threads
