@@ -701,6 +701,22 @@ int avrf_sha512_x8(int count, const uint8_t *const *msgs, const size_t *lens, ui
   return AVRF_OK;
 }
 
+// the same for up to sixteen messages through the form the pool uses (host_sha512_mb.h sha512_weights_x16: more than eight lanes
+// run as two groups of eight in one interleaved round loop)
+int avrf_sha512_x16(int count, const uint8_t *const *msgs, const size_t *lens, uint8_t *digests_out) {
+  if (count < 1 || count > 16 || !msgs || !lens || !digests_out) return AVRF_ERR_BAD_ARG;
+  if (!sha512_mb16_available()) return AVRF_ERR_NO_DEVICE;
+  static const uint8_t empty = 0;
+  WeightJob jobs[16]; WeightJob *pj[16];
+  for (int i = 0; i < count; i++) {
+    if (lens[i] && !msgs[i]) return AVRF_ERR_BAD_ARG;
+    jobs[i].msg = lens[i] ? msgs[i] : &empty; jobs[i].msg_len = lens[i]; pj[i] = &jobs[i];
+  }
+  sha512_weights_x16(pj, count);
+  for (int i = 0; i < count; i++) memcpy(digests_out + 64 * i, jobs[i].digest, 64);
+  return AVRF_OK;
+}
+
 // prepare (src/thin.rs:209-226) on the staged shard: per-item challenges, 16 bytes each
 int avrf_thin_batch_challenges(avrf_ctx *c, uint8_t *c_out) {
   if (!c || c->staged_kind != 1 || (c->n && !c_out)) return AVRF_ERR_BAD_ARG;

@@ -235,6 +235,8 @@ int avrf_batch_weight_seeds_x8(int suite, int pedersen, int count, const size_t 
 /* SHA-512 of `count` <= 8 contiguous messages through that multi-buffer code (the form avrf_*_batch_run hands to the service:
  * prefix || records in one buffer); digests_out: count x 64 bytes. */
 int avrf_sha512_x8(int count, const uint8_t *const *msgs, const size_t *lens, uint8_t *digests_out);
+/* the same for `count` <= 16 messages through the pool's form (two interleaved groups of eight above eight messages) */
+int avrf_sha512_x16(int count, const uint8_t *const *msgs, const size_t *lens, uint8_t *digests_out);
 /* (AVRF_ERR_BAD_ARG unless avrf_thin_batch_challenges succeeded on the CURRENT staging: re-staging or any other call that
  * stages -- avrf_thin_verify, a prover -- invalidates the challenges) */
 int avrf_thin_batch_partial(avrf_ctx *ctx, const uint8_t seed[64], uint64_t first_index, uint8_t out_xy[64]);

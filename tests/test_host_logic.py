@@ -125,6 +125,32 @@ def test_multibuffer_weight_hash_matches_scalar():
             assert [bytes(out2)[64 * i: 64 * i + 64] for i in range(k)] == [hashlib.sha512(m).digest() for m in msgs] == want
 
 
+def test_multibuffer_hash_sixteen_lanes_matches_hashlib():
+    """host_sha512_mb.h sha512_weights_x16 (what the pool calls; compiled by g++, host_hash.cpp): one group through the transposing
+    loader up to eight messages, two interleaved groups above, lanes of unequal length, empty messages, lengths around the
+    block and padding boundaries -- against hashlib."""
+    import ctypes as C
+    import hashlib
+    import random
+    from ark_vrf_amd import _native as nat
+    L = nat.lib()
+    rng = random.Random(16)
+    edge = [0, 1, 111, 112, 113, 127, 128, 129, 239, 240, 255, 256, 1000, 4096 + 27, 64 * 700 + 28, 3]
+    for k in (1, 7, 8, 9, 12, 16):
+        for lens in ([edge[(i + k) % 16] for i in range(k)], [rng.randrange(0, 5000) for _ in range(k)], [2048 * 64 + 28] * k):
+            msgs = [bytes(rng.getrandbits(8) for _ in range(n)) for n in lens]
+            mbuf = [C.create_string_buffer(m or b"\0", max(1, len(m))) for m in msgs]
+            mp = (C.c_void_p * k)(*[C.cast(b, C.c_void_p) for b in mbuf])
+            ls = (C.c_size_t * k)(*lens)
+            out = (C.c_uint8 * (64 * k))()
+            rc = L.avrf_sha512_x16(k, mp, ls, out)
+            if rc == nat.ERR_NO_DEVICE:
+                import pytest
+                pytest.skip("host CPU without AVX-512BW")
+            assert rc == 0
+            assert [bytes(out)[64 * i: 64 * i + 64] for i in range(k)] == [hashlib.sha512(m).digest() for m in msgs], (k, lens)
+
+
 def test_host_sha512_long_message_path(tmp_path):
     """host_sha512.h: inputs of >= 4096 bytes in one update take the four-blocks-per-step path (message schedule of the next
     four blocks on the vector pipes, AVX-512VL; the scalar rounds read K + W from a buffer).  The digest must not depend on how
