@@ -32,7 +32,7 @@ import fpu_model  # noqa: E402
 OUT = os.path.join(ROOT, "ark_vrf_amd", "csrc", "fpu_asm_gen.h")
 ACC, S0 = 30, 36                 # accumulator pair v[30:31]; modulus limbs from s36
 SM = 52                          # s[52:53] = 2^W - 1 as a 64-bit constant (fields with p = 1 mod 2^W)
-M0, D0 = 32, 46                  # 14-limb form: m_k in v[32..45], the doubled limbs of a squaring in v[46..59]
+M0 = 32                          # 14-limb form: m_k in v[32..45]
 ACCP = f"v[{ACC}:{ACC + 1}]"
 LO = f"v{ACC}"
 # fields left to the compiler's form (none: BN254's base field, used by the G1 bucket accumulation alone, gains 2.6 % on the ring
@@ -44,7 +44,8 @@ class Form:
     """operand numbering of one statement.  9 limbs ("sep"): %0..%8 = r (early-clobber outputs; m_k lives in r_k's register: m_k is
     last read in column k + 8, r_k is written in column k + 9), then a, then b (squaring: r, the doubled limbs as further outputs,
     a).  14 limbs ("tied"): 14 + 14 + 14 operands would pass the 30-operand limit, so a is read-write and returns r (a_j is last
-    read in column j + 13, r_j is written in column j + 14), b follows, m_k and the doubled limbs sit in fixed clobbered VGPRs."""
+    read in column j + 13, r_j is written in column j + 14), b follows (squaring: the doubled limbs as scratch outputs), m_k
+    sits in fixed clobbered VGPRs."""
     def __init__(self, f, sqr):
         self.L, self.W, self.sqr, self.tied = f.L, f.W, sqr, f.L > 9
         L = self.L
@@ -52,8 +53,8 @@ class Form:
             self.R = self.A = lambda i: f"%{i}"
             self.B = lambda i: f"%{L + i}"
             self.M = lambda i: f"v{M0 + i}"
-            self.D = lambda i: f"v{D0 + i}"
-            self.n_written = L
+            self.D = lambda i: f"%{L + i}"                  # squaring: the doubled limbs are scratch outputs the compiler places
+            self.n_written = 2 * L if sqr else L
         else:
             self.R = self.M = lambda i: f"%{i}"
             if sqr:
@@ -68,7 +69,7 @@ class Form:
     def fixed_vgprs(self):
         v = [ACC, ACC + 1]
         if self.tied:
-            v += [M0 + i for i in range(self.L)] + ([D0 + i for i in range(1, self.L)] if self.sqr else [])
+            v += [M0 + i for i in range(self.L)]
         return [f"v{x}" for x in v]
 
 
@@ -234,6 +235,8 @@ def emit(name, f, ins_mul, ins_sqr):
     head = f"\ntemplate <> struct FuAsm<{name}> {{ static constexpr bool value = true; }};\n"
     if L > 9:
         rw = ", ".join(f'"+&v"(a.v[{i}])' for i in range(L))
+        douts14 = ", ".join(f'"=&v"(d{i})' for i in range(L))
+        dd14 = ", ".join(f"d{i}" for i in range(L))
         inb = ", ".join(f'"v"(b.v[{i}])' for i in range(L))
         return head + f"""AVRF_DI fu<{L}> fu_mul_asm({name}, fu<{L}> a, const fu<{L}> &b) {{   // {nv(ins_mul)} vector instructions; a's registers return the product
   asm(
@@ -244,11 +247,13 @@ def emit(name, f, ins_mul, ins_sqr):
   return a;
 }}
 AVRF_DI fu<{L}> fu_sqr_asm({name}, fu<{L}> a) {{   // {nv(ins_sqr)} vector instructions
+  int32_t {dd14};
   asm(
 {txt(ins_sqr)}
-      : {rw}
+      : {rw}, {douts14}
       :
       : {cs});
+  (void)d0;
   return a;
 }}
 """
