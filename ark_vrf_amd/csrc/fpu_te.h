@@ -193,6 +193,16 @@ template <class S> AVRF_DI fp teu_load_part_coord(const uint32_t *p, int j) {
   fp r; fu_to_packed<Fq>(r.v, fu_cneg<L>(v, s));
   return r;
 }
+// the same coordinate as its raw limbs with the point's sign applied (the unsaturated quad addition of te_quad.h reads it as it is)
+template <class S> AVRF_DI fuF<typename S::Fq> teu_load_part_coord_raw(const uint32_t *p, int j) {
+  using Fq = typename S::Fq;
+  constexpr int L = UL<Fq>::L;
+  fu<L> v;
+#pragma unroll
+  for (int i = 0; i < L; i++) v.v[i] = (int32_t)p[j * L + i];
+  const int32_t s = (j & 1) ? 0 : (int32_t)p[4 * L];
+  return fu_cneg<L>(v, s);
+}
 template <class S> AVRF_DI te_ext teu_load_part(const uint32_t *p) {
   const uint4 *d = reinterpret_cast<const uint4 *>(p);
   uint32_t w[40];

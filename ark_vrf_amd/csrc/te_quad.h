@@ -128,35 +128,123 @@ AVRF_DI fp fp_shfl_xor(const fp &a, int mask) {
   return r;
 }
 
+// ---- the same addition on the unsaturated limbs of fpu.h (the MSM's reduction tails: k_wsum_q1 / _q2, q_heavy_sum).  Lane j holds
+// coordinate j as 9 signed limbs in the tables' Montgomery domain; the three rounds are the asm blocks of fpu_asm_gen.h
+// (206 instructions against ~250 of the saturated multiplier) and the sums between them are limb-wise with three carry passes
+// instead of six modular additions: ~860 instructions per lane against ~1 100.  A product of two running values comes out times
+// 2^-SH, d is sliced with the shift, so every coordinate of a result carries the same factor: the same point (fpu_te.h).  Bounds:
+// tools/fpu_model.py TEChain.add_gen (operands normalised to limbs <= 2^W + 4, closing operands carried, B + 5A unsigned).
+template <int P0, int P1, int P2, int P3, int L> AVRF_DI fu<L> fu_qperm(const fu<L> &a) {
+  fu<L> r;
+#pragma unroll
+  for (int i = 0; i < L; i++) r.v[i] = __builtin_amdgcn_mov_dpp(a.v[i], P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xf, 0xf, true);
+  return r;
+}
+template <int L> AVRF_DI fu<L> fu_sel(bool c, const fu<L> &a, const fu<L> &b) {
+  fu<L> r;
+#pragma unroll
+  for (int i = 0; i < L; i++) r.v[i] = c ? a.v[i] : b.v[i];
+  return r;
+}
+template <class S> __device__ __noinline__ static fuF<typename S::Fq> qu_add(fuF<typename S::Fq> a, fuF<typename S::Fq> b, uint32_t j) {
+  using Fq = typename S::Fq;
+  constexpr int L = UL<Fq>::L, SH = UL<Fq>::SH;
+  const fu<L> m1 = fu_mul<Fq>(a, b);                                // X1 X2, Y1 Y2, T1 T2, Z1 Z2
+  const fu<L> sa = fu_add<L>(a, fu_qperm<1, 0, 3, 2>(a)), sb = fu_carry<Fq>(fu_add<L>(b, fu_qperm<1, 0, 3, 2>(b)));
+  const bool l2 = j == 2;
+  const fu<L> m2 = fu_mul<Fq>(fu_sel<L>(l2, m1, sa), fu_sel<L>(l2, fu_slice<Fq, SH>(S::D), sb));   // lanes 0, 1: (X1 + Y1)(X2 + Y2); lane 2: d T1 T2
+  const fu<L> A = fu_qperm<0, 0, 0, 0>(m1), B = fu_qperm<1, 1, 1, 1>(m1), D = fu_qperm<3, 3, 3, 3>(m1);
+  const fu<L> C = fu_qperm<2, 2, 2, 2>(m2), Ep = fu_qperm<0, 0, 0, 0>(m2);
+  // lane 0: E = E' - A - B; lane 1: H = B - a A; lane 2: G = D + C; lane 3: F = D - C -- carried to limbs in [0, 2^W + 4)
+  fu<L> X, Y;
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    X.v[i] = j == 0 ? Ep.v[i] : (j == 1 ? B.v[i] : D.v[i]);
+    const int32_t y1 = S::A_KIND == 0 ? A.v[i] : -A.v[i];           // a = 1: B - A; a = -1 (and the first A of a = -5): B + A
+    Y.v[i] = j == 0 ? A.v[i] + B.v[i] : (j == 1 ? y1 : (l2 ? -C.v[i] : C.v[i]));
+  }
+  fu<L> U = fu_carry<Fq>(fu_sub<L>(X, Y));
+  if (S::A_KIND == 1) {                                              // a = -5: B + 5 A needs 32 unsigned bits (fpu_te.h teu_h)
+    uint32_t h[L - 1];
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) h[i] = (uint32_t)B.v[i] + 5u * (uint32_t)A.v[i];
+    U = fu_sel<L>(j == 1, fu_carry_u<Fq>(h, B.v[L - 1] + 5 * A.v[L - 1]), U);
+  }
+  return fu_mul<Fq>(fu_qperm<0, 1, 0, 3>(U), fu_qperm<3, 2, 1, 2>(U));   // E F, H G, E H, F G
+}
+
+// what the reduction kernels below are written over: one coordinate of a point per lane, saturated (fp) or unsaturated (fu<9>)
+template <class S> struct QuadSat {
+  using el = fp;
+  static AVRF_DI el identity(uint32_t j) { return q_identity<S>(j); }
+  static AVRF_DI el add(const el &a, const el &b, uint32_t j) { return q_add<S>(a, b, j); }
+  static AVRF_DI el sel(bool c, const el &a, const el &b) { return fp_sel(c, a, b); }
+  static AVRF_DI el shfl_down(const el &a, int d) { return fp_shfl_down(a, d); }
+  static AVRF_DI el shfl_xor(const el &a, int m) { return fp_shfl_xor(a, m); }
+  static AVRF_DI el load(const uint32_t *p) { return load_fp(p); }                 // 8 canonical words
+  static AVRF_DI void store(uint32_t *p, const el &v) { store_fp(p, v); }
+  static AVRF_DI el load_part(const uint32_t *part, size_t k, int j) {             // coordinate j of partial sum k (the k_accumulate policy's format)
+    if constexpr (TeCurve<S>::accum::PART_WORDS == 32) return load_fp(part + k * 32 + j * 8);
+    else return teu_load_part_coord<S>(part + k * TEU_PART_WORDS, j);
+  }
+};
+template <class S> struct QuadUns {
+  using Fq = typename S::Fq;
+  static constexpr int L = UL<Fq>::L;
+  using el = fu<L>;
+  static AVRF_DI el identity(uint32_t j) { return (j & 1) ? fu_const<Fq>(UL<Fq>::ONE) : fu_zero<L>(); }
+  static AVRF_DI el add(const el &a, const el &b, uint32_t j) { return qu_add<S>(a, b, j); }
+  static AVRF_DI el sel(bool c, const el &a, const el &b) { return fu_sel<L>(c, a, b); }
+  static AVRF_DI el shfl_down(const el &a, int d) { el r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.v[i] = __shfl_down(a.v[i], d);
+    return r; }
+  static AVRF_DI el shfl_xor(const el &a, int m) { el r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.v[i] = __shfl_xor(a.v[i], m);
+    return r; }
+  static AVRF_DI el load(const uint32_t *p) { const fp v = load_fp(p); return fu_slice<Fq, 0>(v.v); }
+  static AVRF_DI void store(uint32_t *p, const el &v) { fp r; fu_to_packed<Fq>(r.v, v); store_fp(p, r); }
+  static AVRF_DI el load_part(const uint32_t *part, size_t k, int j) { return teu_load_part_coord_raw<S>(part + k * TEU_PART_WORDS, j); }
+};
+#if !defined(AVRF_NO_UNSAT) && !defined(AVRF_NO_UNSAT_QUAD)
+template <class S> using Quad = std::conditional_t<FuAsm<typename S::Fq>::value && !S::SW_NATIVE, QuadUns<S>, QuadSat<S>>;
+#else
+template <class S> using Quad = QuadSat<S>;
+#endif
+
 // sum over the 16 quads of a wave, valid in quad 0
-template <class S> AVRF_DI fp q_wave_sum(fp v, uint32_t q, uint32_t j) {
+template <class S> AVRF_DI typename Quad<S>::el q_wave_sum(typename Quad<S>::el v, uint32_t q, uint32_t j) {
+  using Q = Quad<S>;
 #pragma unroll 1
   for (int off = 8; off >= 1; off >>= 1) {
-    const fp o = fp_shfl_down(v, 4 * off);
-    if ((int)q < off) v = q_add<S>(v, o, j);
+    const typename Q::el o = Q::shfl_down(v, 4 * off);
+    if ((int)q < off) v = Q::add(v, o, j);
   }
   return v;
 }
 // two sums at once: returns sum_q a_q in quad 0 and sum_q b_q in quad 8 (first step folds a into the low quads and b into
 // the high quads, then both halves reduce together)
-template <class S> AVRF_DI fp q_wave_sum2(const fp &a, const fp &b, uint32_t q, uint32_t j) {
+template <class S> AVRF_DI typename Quad<S>::el q_wave_sum2(const typename Quad<S>::el &a, const typename Quad<S>::el &b, uint32_t q, uint32_t j) {
+  using Q = Quad<S>;
   const bool lowq = q < 8;
-  const fp send = fp_sel(lowq, b, a);                              // what the partner quad (q ^ 8) accumulates
-  const fp got = fp_shfl_xor(send, 32);
-  fp v = q_add<S>(fp_sel(lowq, a, b), got, j);
+  const typename Q::el send = Q::sel(lowq, b, a);                     // what the partner quad (q ^ 8) accumulates
+  const typename Q::el got = Q::shfl_xor(send, 32);
+  typename Q::el v = Q::add(Q::sel(lowq, a, b), got, j);
 #pragma unroll 1
   for (int off = 4; off >= 1; off >>= 1) {
-    const fp o = fp_shfl_down(v, 4 * off);
-    if ((int)(q & 7) < off) v = q_add<S>(v, o, j);
+    const typename Q::el o = Q::shfl_down(v, 4 * off);
+    if ((int)(q & 7) < off) v = Q::add(v, o, j);
   }
   return v;
 }
 // suffix sums over the quads of a wave: result_q = sum_{q' >= q} v_q'
-template <class S> AVRF_DI fp q_wave_suffix(fp v, uint32_t q, uint32_t j) {
+template <class S> AVRF_DI typename Quad<S>::el q_wave_suffix(typename Quad<S>::el v, uint32_t q, uint32_t j) {
+  using Q = Quad<S>;
 #pragma unroll 1
   for (int off = 1; off < 16; off <<= 1) {
-    const fp o = fp_shfl_down(v, 4 * off);
-    if ((int)q + off < 16) v = q_add<S>(v, o, j);
+    const typename Q::el o = Q::shfl_down(v, 4 * off);
+    if ((int)q + off < 16) v = Q::add(v, o, j);
   }
   return v;
 }
@@ -172,19 +260,20 @@ k_wsum_q1(const uint32_t *__restrict__ buckets, uint32_t nb, uint32_t m, uint32_
   const uint32_t gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
   if (gw >= nwaves) return;
   const uint32_t v = gw / wpw, wi = gw - v * wpw;
+  using Q = Quad<S>; using el = typename Q::el;
   const uint32_t *B = buckets + (size_t)v * nb * 32;
-  fp Sx = q_identity<S>(j), J = q_identity<S>(j);
+  el Sx = Q::identity(j), J = Q::identity(j);
 #pragma unroll 1
   for (int k = (int)m - 1; k >= 0; k--) {
     const uint32_t b0 = wi * 16 * m + q + 16 * (uint32_t)k;
-    if (b0 < nb) Sx = q_add<S>(Sx, load_fp(B + (size_t)b0 * 32 + j * 8), j);
-    if (k > 0) J = q_add<S>(J, Sx, j);
+    if (b0 < nb) Sx = Q::add(Sx, Q::load(B + (size_t)b0 * 32 + j * 8), j);
+    if (k > 0) J = Q::add(J, Sx, j);
   }
-  const fp A = q_wave_suffix<S>(Sx, q, j);                         // A_0 = Y; sum_q (q + 1) S_q = sum_q A_q
-  const fp V = q_wave_sum2<S>(A, J, q, j);                         // quad 0: V1, quad 8: V2
+  const el A = q_wave_suffix<S>(Sx, q, j);                         // A_0 = Y; sum_q (q + 1) S_q = sum_q A_q
+  const el V = q_wave_sum2<S>(A, J, q, j);                         // quad 0: V1, quad 8: V2
   uint32_t *o = out + (size_t)gw * 3 * 32 + j * 8;
-  if (q == 0) { store_fp(o, V); store_fp(o + 64, A); }
-  if (q == 8) store_fp(o + 32, V);
+  if (q == 0) { Q::store(o, V); Q::store(o + 64, A); }
+  if (q == 8) Q::store(o + 32, V);
 }
 
 // Level 2: one wave per window over the wpw <= 16 triples of level 1:
@@ -194,39 +283,36 @@ template <class S>
 __global__ void __launch_bounds__(64)
 k_wsum_q2(const uint32_t *__restrict__ trip, uint32_t wpw, uint32_t *__restrict__ out) {
   const uint32_t v = blockIdx.x, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
-  fp v1 = q_identity<S>(j), v2 = v1, y = v1;
+  using Q = Quad<S>; using el = typename Q::el;
+  el v1 = Q::identity(j), v2 = v1, y = v1;
   if (q < wpw) {
     const uint32_t *t = trip + ((size_t)v * wpw + q) * 3 * 32 + j * 8;
-    v1 = load_fp(t); v2 = load_fp(t + 32); y = load_fp(t + 64);
+    v1 = Q::load(t); v2 = Q::load(t + 32); y = Q::load(t + 64);
   }
-  const fp P12 = q_wave_sum2<S>(v1, v2, q, j);
-  fp A = q_wave_suffix<S>(y, q, j);                                // sum_q q Y_q = sum_{q >= 1} A_q
-  if (q == 0) A = q_identity<S>(j);
-  const fp P3 = q_wave_sum<S>(A, q, j);
+  const el P12 = q_wave_sum2<S>(v1, v2, q, j);
+  el A = q_wave_suffix<S>(y, q, j);                                // sum_q q Y_q = sum_{q >= 1} A_q
+  if (q == 0) A = Q::identity(j);
+  const el P3 = q_wave_sum<S>(A, q, j);
   uint32_t *o = out + (size_t)v * 3 * 32 + j * 8;
-  if (q == 0) { store_fp(o, P12); store_fp(o + 64, P3); }
-  if (q == 8) store_fp(o + 32, P12);
+  if (q == 0) { Q::store(o, P12); Q::store(o + 64, P3); }
+  if (q == 8) Q::store(o + 32, P12);
 }
 
 // Sum of a heavy bucket's np partials by one workgroup of 64 quads (see k_bucket_sum): quads stride over the partials,
 // each wave folds its 16 quads, the four wave results meet in LDS.
 template <class S> AVRF_DI void q_heavy_sum(const uint32_t *__restrict__ part, size_t p0, uint32_t np, uint32_t *__restrict__ dst, uint32_t *lds) {
   const uint32_t t = threadIdx.x, lane = t & 63, q = lane >> 2, j = lane & 3, gq = t >> 2, wv = t >> 6;
-  fp a = q_identity<S>(j);
+  using Q = Quad<S>; using el = typename Q::el;
+  el a = Q::identity(j);
 #pragma unroll 1
-  for (uint32_t k = gq; k < np; k += 64) {
-    fp c;                                                              // coordinate j of partial k (curves.h: the k_accumulate policy's format)
-    if constexpr (TeCurve<S>::accum::PART_WORDS == 32) c = load_fp(part + (p0 + k) * 32 + j * 8);
-    else c = teu_load_part_coord<S>(part + (p0 + k) * TEU_PART_WORDS, (int)j);
-    a = q_add<S>(a, c, j);
-  }
+  for (uint32_t k = gq; k < np; k += 64) a = Q::add(a, Q::load_part(part, p0 + k, (int)j), j);
   a = q_wave_sum<S>(a, q, j);
-  if (q == 0) store_fp(lds + wv * 32 + j * 8, a);
+  if (q == 0) Q::store(lds + wv * 32 + j * 8, a);
   __syncthreads();
   if (t < 4) {
 #pragma unroll 1
-    for (uint32_t w = 1; w < 4; w++) a = q_add<S>(a, load_fp(lds + w * 32 + j * 8), j);
-    store_fp(dst + j * 8, a);
+    for (uint32_t w = 1; w < 4; w++) a = Q::add(a, Q::load(lds + w * 32 + j * 8), j);
+    Q::store(dst + j * 8, a);
   }
   __syncthreads();
 }

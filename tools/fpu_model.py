@@ -321,6 +321,28 @@ class TEChain:
         self.lim(E, n30, F, n29); self.lim(G, n30, H, n29)
         return self.check_out((f.mul(E, F), f.mul(G, H), f.mul(E, H), f.mul(F, G)))
 
+    def add_gen(self, P, Q):
+        """qu_add of te_quad.h (the four-lanes-per-point general addition of the reduction tails, one coordinate per lane): both
+        operands are running values (domain R, any common scale each); the operand order of every product is the kernel's"""
+        f, te = self.f, self.te
+        n29, n30 = (1 << f.W) + 4, 1 << (f.W + 1)
+        for c in P + Q:
+            assert max(abs(v) for v in c) <= n29, (te.name, "quad operand not normalised")
+        A, B, TT, D = (f.mul(a, b) for a, b in zip(P, Q))
+        sa = [i32(a + b) for a, b in zip(P[0], P[1])]
+        sb = f.carry([i32(a + b) for a, b in zip(Q[0], Q[1])])
+        self.lim(sa, n30, sb, n29)
+        Ep = f.mul(sa, sb)
+        C = f.mul(TT, f.slice(te.d * f.R % f.p, f.SH))
+        E = f.carry([i32(q - a - b) for q, a, b in zip(Ep, A, B)])
+        H = self.hsum(A, B) if te.a_kind != 0 else f.carry([i32(b - a) for a, b in zip(A, B)])
+        if te.a_kind == 2:
+            H = H                                               # hsum carried it
+        G = f.carry([i32(d + c) for d, c in zip(D, C)]); F = f.carry([i32(d - c) for d, c in zip(D, C)])
+        for v in (E, F, G, H):
+            assert max(abs(x) for x in v) <= n29, (te.name, "quad closing operand")
+        return self.check_out((f.mul(E, F), f.mul(H, G), f.mul(E, H), f.mul(F, G)))
+
     def from_ext(self, e):
         return tuple(self.f.slice(v, 0) for v in e)
 
@@ -371,7 +393,21 @@ def check_te_chain(te, rng, n_scalars=4):
             if dgt:
                 acc = ch.add_sat(acc, sat(tab[dgt])); ref = te.add(ref, tab[dgt])
         assert ch.to_affine(acc) == ref, te.name
-    print(f"  {te.name}: doubling chains (teu4_dbl / teu4_add_sat) == affine law; invariant |X|,|Y|,|T|,|Z| < {TEChain.INV} p closed "
+    # the reduction tails' general addition: sums of running points, of freshly loaded (sliced) points, and a tree of them
+    run = []
+    for i in range(6):
+        qa = ch.from_ext(sat(pts[i % len(pts)])); ra = pts[i % len(pts)]
+        for j in range(i + 1):
+            qa = ch.add_gen(qa, ch.from_ext(sat(pts[(i + j) % len(pts)]))); ra = te.add(ra, pts[(i + j) % len(pts)])
+        run.append((qa, ra))
+    while len(run) > 1:
+        (qa, ra), (qb, rb) = run.pop(), run.pop()
+        c = ch.add_gen(qa, qb); assert ch.to_affine(c) == te.add(ra, rb), (te.name, "general addition")
+        c2 = ch.add_gen(c, c); assert ch.to_affine(c2) == te.add(te.add(ra, rb), te.add(ra, rb))          # P + P: the law is complete
+        ident = ch.from_ext(sat((0, 1)))
+        assert ch.to_affine(ch.add_gen(c, ident)) == te.add(ra, rb)
+        run.insert(0, (c, te.add(ra, rb)))
+    print(f"  {te.name}: doubling chains (teu4_dbl / teu4_add_sat) and the reduction tails' general addition (qu_add) == affine law; invariant |X|,|Y|,|T|,|Z| < {TEChain.INV} p closed "
           f"(worst case out: dbl {d[0]:.2f} {d[1]:.2f} {d[2]:.2f} {d[3]:.2f}, add {a[0]:.2f} {a[1]:.2f} {a[2]:.2f} {a[3]:.2f})")
 
 
