@@ -16,7 +16,7 @@ SINGLE="python3 $ROOT/bench.py --gpus 1 --slots 1 --lanes 1 --host-threads 1 --h
 PASSES=("FETCH_SIZE" "WRITE_SIZE" "VALUBusy" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum")
 stats() {   # name, command...: rocprofv3 --kernel-trace --stats, keep the kernel_stats csv
   name=$1; shift; d=$(mktemp -d /tmp/kt.XXXX)
-  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $d -o k -- "$@" > $OUT/${R}_$name.log 2>&1 )
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o k -- "$@" > $OUT/${R}_$name.log 2>&1 )
   f=$(find $d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${R}_${name}_kernel_stats.csv
   python3 $ROOT/tools/kstats.py $d | sort -k4 -n -r -t'|' | head -14; rm -rf $d
 }
