@@ -268,39 +268,75 @@ template <class F> AVRF_DN fp fp_inv_nf(fp a) {
   const fp r2 = fp_const<F>(F::R2);                        // x2 = (a' R)^-1 for a = a' R; times R^3 / R gives a'^-1 R
   return fp_mul_nf<F>(x2, fp_mul_nf<F>(r2, r2));
 }
-// The Jacobi symbol (a / p) = the quadratic character of a (p prime): +1, -1, or 0 for a = 0.  Binary algorithm, ONE fused step per
-// iteration and no branches inside it, so the lanes of a wave walk the same instruction stream (the trip count differs by a few):
-//   a even:          a <- a / 2                      sign *= (2 / n)
-//   a odd, a >= n:   a <- (a - n) / 2                sign *= (2 / n)
-//   a odd, a <  n:   (a, n) <- ((n - a) / 2, a)      sign *= (-1)^((a-1)(n-1)/4) (2 / a)        (quadratic reciprocity)
-// with (2 / n) = -1 iff n = 3, 5 mod 8.  ~1.4 x 255 iterations of ~60 carry / select instructions: ~22 k instructions against the
-// ~50 k of Euler's criterion a^((p-1)/2).  `a` may be given in Montgomery form: R = (2^128)^2 is a square, so (a R / p) = (a / p).
-template <class F> AVRF_DN int fp_jacobi_nf(fp a) {
-  fp n = fp_const<F>(F::P);
-  uint32_t t = 0;                                          // bit 0: the sign so far is -1
-#pragma unroll 1
-  while (!fp_is_zero(a)) {
-    const bool odd = (a.v[0] & 1u) != 0;
-    fp d1, d2;
-    const bool lt = sub8(d1, a, n) != 0;                   // d1 = a - n, d2 = n - a
-    sub8(d2, n, a);
-    const bool sw = odd && lt;
-    t ^= sw ? ((a.v[0] & n.v[0]) >> 1) & 1u : 0u;          // both 3 mod 4
+// The Jacobi symbols (a / p), (b / p) = the quadratic characters of a and b (p prime): +1, -1, or 0 for a = 0.  Exact binary algorithm on
+// (a, n), n odd, in MACRO steps -- one step removes ALL trailing zeros of a (v_ffbl_b32 + a funnel shift per limb), then subtracts:
+//   z = ctz(a) (at most 30 per step):  a <- a / 2^z            sign *= (2 / n)^z,  (2 / n) = -1 iff n = 3, 5 mod 8
+//   a odd, a >= n:                     a <- a - n
+//   a odd, a <  n:                     (a, n) <- (n - a, a)    sign *= (-1)^((a-1)(n-1)/4)            (quadratic reciprocity)
+// ~180 macro steps for a 255-bit modulus (every subtraction leaves two trailing zeros on average) instead of ~360 single-bit steps, and the
+// values shrink by ~1.4 bits each per step, so the wave walks the steps in PHASES of K = 8, 7, .. 1 live limbs (K = the longest value any of
+// its lanes still holds; a phase is left when limb K-1 of every lane's a and n is zero): 6 K + 11 instructions per step and symbol, ~8 k
+// instructions per symbol against the ~22 k of the single-bit form on all eight limbs (tools/scratch/jac_model.py counts both) and the ~50 k of
+// Euler's criterion.  Two symbols share one loop (the subgroup test needs two: glv.h), which also gives every carry chain an independent
+// neighbour.  No branches inside a step; every lane walks the same stream; a lane that is done (a = 0) idles harmlessly: its z is 30 (even:
+// no sign change), it is never odd.  The loop ends on any input: a step with a odd shortens len(a) + len(n), a step with a even shifts.
+// `a` may be given in Montgomery form: R = (2^128)^2 is a square, so (a R / p) = (a / p).
+struct jac_state { uint32_t a[8], n[8], t; };
+template <int K> AVRF_DI void jac_step(jac_state &s) {
+  uint32_t z = s.a[0] ? (uint32_t)__builtin_ctz(s.a[0]) : 32u;
+  z = z < 30u ? z : 30u;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const uint32_t an = odd ? (lt ? d2.v[i] : d1.v[i]) : a.v[i];
-      n.v[i] = sw ? a.v[i] : n.v[i];
-      a.v[i] = an;
-    }
+  for (int i = 0; i + 1 < K; i++) s.a[i] = __builtin_amdgcn_alignbit(s.a[i + 1], s.a[i], z);
+  s.a[K - 1] >>= z;
+  s.t ^= (s.n[0] ^ (s.n[0] >> 1)) & (z << 1);                 // bit 1 of t: the sign so far is -1
+  const bool odd = (s.a[0] & 1u) != 0;
+  uint32_t d[K], e[K];
+  unsigned br = 0, br2 = 0;
 #pragma unroll
-    for (int i = 0; i < 7; i++) a.v[i] = (a.v[i] >> 1) | (a.v[i + 1] << 31);
-    a.v[7] >>= 1;
-    t ^= ((n.v[0] >> 1) ^ (n.v[0] >> 2)) & 1u;             // the halving: (2 / n), n = the modulus of this step
+  for (int i = 0; i < K; i++) d[i] = __builtin_subc(s.a[i], s.n[i], br, &br);      // a - n; borrow: a < n
+#pragma unroll
+  for (int i = 0; i < K; i++) e[i] = __builtin_subc(s.n[i], s.a[i], br2, &br2);    // n - a
+  const bool lt = br != 0, sw = odd && lt;
+  s.t ^= sw ? (s.a[0] & s.n[0]) : 0u;                         // both 3 mod 4
+#pragma unroll
+  for (int i = 0; i < K; i++) {
+    const uint32_t x = lt ? e[i] : d[i];
+    s.n[i] = sw ? s.a[i] : s.n[i];
+    s.a[i] = odd ? x : s.a[i];
   }
-  uint32_t o = n.v[0] ^ 1u;
+}
+// one phase: steps on K limbs until every lane is finished (returns true) or may drop limb K - 1 (false)
+template <int K> AVRF_DI bool jac_phase(jac_state &s1, jac_state &s2, int &budget) {
+#pragma unroll 1
+  for (;;) {
+    uint32_t z1 = 0, z2 = 0;
 #pragma unroll
-  for (int i = 1; i < 8; i++) o |= n.v[i];
-  return o ? 0 : ((t & 1u) ? -1 : 1);                      // gcd = n != 1 only for a = 0 (p prime)
+    for (int i = 0; i < K; i++) { z1 |= s1.a[i]; z2 |= s2.a[i]; }
+    if (__all((z1 | z2) == 0) || budget <= 0) return true;
+    if constexpr (K > 1)
+      if (__all((z1 == 0 || (s1.a[K - 1] | s1.n[K - 1]) == 0) && (z2 == 0 || (s2.a[K - 1] | s2.n[K - 1]) == 0))) return false;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { jac_step<K>(s1); jac_step<K>(s2); }
+    budget -= 4;
+  }
+}
+AVRF_DI int jac_result(const jac_state &s) {
+  uint32_t za = 0, zn = s.n[0] ^ 1u;                          // a = 0 and n = gcd = 1 (a finished lane's n is never touched again)
+#pragma unroll
+  for (int i = 0; i < 8; i++) za |= s.a[i];
+#pragma unroll
+  for (int i = 1; i < 8; i++) zn |= s.n[i];
+  return (za | zn) ? 0 : ((s.t & 2u) ? -1 : 1);
+}
+template <class F> AVRF_DN void fp_jacobi2_nf(fp a, fp b, int *ja, int *jb) {
+  jac_state s1, s2;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { s1.a[i] = a.v[i]; s2.a[i] = b.v[i]; s1.n[i] = s2.n[i] = F::P[i]; }
+  s1.t = s2.t = 0;
+  int budget = 1024;                                           // (at most 2 x 256 shortening steps + the steps a zero low word takes)
+  (void)(jac_phase<8>(s1, s2, budget) || jac_phase<7>(s1, s2, budget) || jac_phase<6>(s1, s2, budget) || jac_phase<5>(s1, s2, budget) ||
+         jac_phase<4>(s1, s2, budget) || jac_phase<3>(s1, s2, budget) || jac_phase<2>(s1, s2, budget) || jac_phase<1>(s1, s2, budget));
+  *ja = jac_result(s1); *jb = jac_result(s2);
 }
 // the fixed power a^(p-2), kept as the cross-check of the two Euclidean forms (tools/ubench.hip)
 template <class F> AVRF_DN fp fp_inv_fermat_nf(fp a) {
@@ -355,12 +391,16 @@ template <class F> AVRF_DN fp fp_pow_nf(fp a, int which) {   // which: 0 -> T_MI
 // classic Tonelli-Shanks loop below runs every lane for the LONGEST of their discrete-log walks -- up to 32 x 32 squarings on a field
 // with 2-adicity 32 -- and the quotient cost a ~45 k-instruction inversion first).  With p - 1 = 2^s t, a = u v, w = a^((t-1)/2):
 //   a w^2 = a^t = g^e (g = ROOT, order 2^s),     1 / sqrt(a) = w g^(-e/2),     sqrt(u / v) = u / sqrt(u v) = u w g^(-e/2);
-// e is read in 4-bit windows from the low end: the window's value is the j with c^(2^(s - 4i - w)) = h^j (16 compares), then
-// c <- c g^(-j 16^i) (tables SQRT_H / SQRT_G / SQRT_GH of consts_gen.h, tools/gen_consts.py).  112 squarings + 16 products for
-// s = 32 after the one fixed exponentiation; the same instruction stream in every lane.  Returns false when u / v is not a square
+// e is read in 8-bit windows from the low end: the window's value j is looked up from d = c^(2^(s - 8i - w)), a 2^w-th root of unity
+// (sqrt_window below: a perfect hash of the 256 roots on the low word of d), then c <- c g^(-j 256^i) (tables SQRT_HIDX / SQRT_G /
+// SQRT_GH of consts_gen.h, tools/gen_consts.py).  48 squarings + 8 products for s = 32 after the one fixed exponentiation (4-bit
+// windows with compare loops took 112 + 16); the same instruction stream in every lane.  Returns false when u / v is not a square
 // (e odd), and checks x^2 v = u.  u = 0 gives x = 0; v = 0 is the caller's case.
+template <class F> AVRF_DI uint32_t sqrt_window(uint32_t d_low, int wd) {        // d = h^(j 2^(hw - wd)) in canonical Montgomery form -> j
+  return (uint32_t)F::SQRT_HIDX[(d_low * F::SQRT_HMUL) >> (32 - F::SQRT_HBITS)] >> (F::SQRT_HW - wd);
+}
 template <class F> AVRF_DN bool fp_sqrt_ratio_nf(fp u, fp v, fp *out) {
-  constexpr int S = F::TWO_ADICITY;
+  constexpr int S = F::TWO_ADICITY, W = F::SQRT_W;
   const fp a = fp_mul_nf<F>(u, v);
   const fp w = fp_pow_nf<F>(a, 0);                                   // a^((t-1)/2)
   fp c = fp_mul_nf<F>(a, fp_mul_nf<F>(w, w));                        // a^t, in the group of 2^s-th roots of unity
@@ -368,18 +408,11 @@ template <class F> AVRF_DN bool fp_sqrt_ratio_nf(fp u, fp v, fp *out) {
   bool odd = false;
 #pragma unroll 1
   for (int i = 0; i < F::SQRT_STEPS; i++) {
-    const int wd = S - 4 * i < 4 ? S - 4 * i : 4;                    // bits of this window
+    const int wd = S - W * i < W ? S - W * i : W;                    // bits of this window
     fp d = c;
 #pragma unroll 1
-    for (int k = 0; k < S - 4 * i - wd; k++) d = fp_mul_nf<F>(d, d);
-    uint32_t j = 0;
-#pragma unroll 1
-    for (uint32_t cand = 1; cand < (1u << wd); cand++) {
-      uint32_t o = 0;
-#pragma unroll
-      for (int l = 0; l < 8; l++) o |= d.v[l] ^ F::SQRT_H[(cand << ((S < 4 ? S : 4) - wd)) & 15][l];   // SQRT_H holds the 2^min(4, s)-th roots
-      j = o == 0 ? cand : j;
-    }
+    for (int k = 0; k < S - W * i - wd; k++) d = fp_mul_nf<F>(d, d);
+    const uint32_t j = sqrt_window<F>(d.v[0], wd);
     if (i == 0 && (j & 1u)) odd = true;
     fp gs, gh;
 #pragma unroll

@@ -1,5 +1,5 @@
 // fpu_sqrt.h -- sqrt(u / v) as fp256.h's fp_sqrt_ratio_nf computes it (x = u w g^(-e/2), w = (u v)^((t-1)/2), the discrete log e of
-// (u v)^t read in 4-bit windows), on the unsaturated limbs of fpu.h: the ~450 field operations of one point decompression are
+// (u v)^t read in 8-bit windows), on the unsaturated limbs of fpu.h: the ~380 field operations of one point decompression are
 // squarings and products by table entries with nothing between them, i.e. exactly the asm blocks of fpu_asm_gen.h (178 / 206
 // vector instructions against ~250 of the saturated multiplier, which also squares by multiplying).  The fixed exponentiation
 // reads its exponent in 4-bit windows (223 squarings + 56 products + 14 for the table, the binary form took 223 + ~111).
@@ -21,7 +21,7 @@ template <class F> AVRF_DI constexpr int fu_top_digit4(const uint32_t (&e)[8]) {
 
 template <class F> AVRF_DN bool fu_sqrt_ratio_nf(fp u, fp v, fp *out) {
   using U = UL<F>;
-  constexpr int S = F::TWO_ADICITY, SH = U::SH;
+  constexpr int S = F::TWO_ADICITY, SH = U::SH, W = F::SQRT_W;
   const fuF<F> to_r = fu_const<F>(U::ONE);                            // R mod p, sliced plainly: fu_mul(x R', to_r) = x R
   const fuF<F> uu = fu_slice<F, SH>(u.v), vv = fu_slice<F, SH>(v.v);
   const fuF<F> a = fu_mul<F>(uu, vv);
@@ -43,19 +43,12 @@ template <class F> AVRF_DN bool fu_sqrt_ratio_nf(fp u, fp v, fp *out) {
   bool odd = false;
 #pragma unroll 1
   for (int i = 0; i < F::SQRT_STEPS; i++) {
-    const int wd = S - 4 * i < 4 ? S - 4 * i : 4;                     // bits of this window
+    const int wd = S - W * i < W ? S - W * i : W;                     // bits of this window
     fuF<F> d = c;
 #pragma unroll 1
-    for (int k = 0; k < S - 4 * i - wd; k++) d = fu_sqr<F>(d);
+    for (int k = 0; k < S - W * i - wd; k++) d = fu_sqr<F>(d);
     fp dc; fu_to_packed<F>(dc.v, fu_mul<F>(d, to_r));                 // canonical, in the tables' domain
-    uint32_t j = 0;
-#pragma unroll 1
-    for (uint32_t cand = 1; cand < (1u << wd); cand++) {
-      uint32_t o = 0;
-#pragma unroll
-      for (int l = 0; l < 8; l++) o |= dc.v[l] ^ F::SQRT_H[(cand << ((S < 4 ? S : 4) - wd)) & 15][l];
-      j = o == 0 ? cand : j;
-    }
+    const uint32_t j = sqrt_window<F>(dc.v[0], wd);                   // (fp256.h: perfect hash of the 2^w-th roots of unity)
     if (i == 0 && (j & 1u)) odd = true;
     fp gs, gh;
 #pragma unroll

@@ -98,7 +98,7 @@ template <class S> AVRF_DI bool te_endo(const te_pre &p, te_ext &r) {
 // B v^2 = u (u - alpha)(u - beta); their product is a square on the curve, so two symbols decide): modulo squares
 //   chi(1 - y^2) = chi(B)   and   chi((c0 + c1 y)(1 - y)) = chi(B),   c0 = 1 - alpha, c1 = 1 + alpha
 // (tools/gen_consts.py two_descent derives the constants and checks the criterion against r P on every coset).  Two Jacobi
-// symbols, ~45 k instructions, instead of the 253-bit scalar multiplication r P (~540 k) that src/lib.rs:410-433's
+// symbols in one loop (fp256.h fp_jacobi2_nf), ~16 k instructions, instead of the 253-bit scalar multiplication r P (~540 k) that src/lib.rs:410-433's
 // is_in_correct_subgroup_assuming_on_curve amounts to.  The identity (y = 1) is in the subgroup; (0, -1) gives chi = 0: rejected.
 template <class S> AVRF_DI bool te_in_subgroup_2descent(const fp &ym) {
   using Fq = typename S::Fq;
@@ -107,7 +107,9 @@ template <class S> AVRF_DI bool te_in_subgroup_2descent(const fp &ym) {
   const fp omy = fp_sub<Fq>(one, ym);
   const fp n1 = fp_mul_nf<Fq>(omy, fp_add<Fq>(one, ym));
   const fp n2 = fp_mul_nf<Fq>(fp_add<Fq>(fp_const<Fq>(S::TD_C0), fp_mul_nf<Fq>(fp_const<Fq>(S::TD_C1), ym)), omy);
-  return fp_jacobi_nf<Fq>(n1) == S::TD_WANT && fp_jacobi_nf<Fq>(n2) == S::TD_WANT;
+  int j1, j2;
+  fp_jacobi2_nf<Fq>(n1, n2, &j1, &j2);
+  return j1 == S::TD_WANT && j2 == S::TD_WANT;
 }
 
 template <class S> AVRF_DI te_ext te_ext_neg(const te_ext &p) {

@@ -35,6 +35,9 @@ def parse():
         for a in re.finditer(r"(?:int|uint32_t|bool) (\w+) = (\w+)u?;", body):
             v = a.group(2)
             d[a.group(1)] = {"true": 1, "false": 0}.get(v, None) if v in ("true", "false") else int(v.rstrip("u"), 0)
+        a = re.search(r"uint8_t SQRT_HIDX\[\d+\] = \{([^}]*)\}", body)
+        if a:
+            d["SQRT_HIDX_tab"] = [int(x) for x in a.group(1).replace("\n", " ").split(",")]
         u = re.search(r"using Fq = (\w+);", body)
         if u:
             d["Fq"] = u.group(1)
@@ -648,25 +651,28 @@ def check_sqrt_chain(f, d, rng, n=6):
         assert val(w) == pow(u0 * v0 % p, e, p)
         c = mul(a, mul(w, w, sqr=True)); r = mul(uu, w)
         odd = False
-        steps = (S + 3) // 4
+        steps = (S + 7) // 8
         for i in range(steps):
-            wd = min(4, S - 4 * i)
+            wd = min(8, S - 8 * i)
             dd = c
-            for _ in range(S - 4 * i - wd):
+            for _ in range(S - 8 * i - wd):
                 dd = mul(dd, dd, sqr=True)
             dc = packed(dd)
             h = pow(g, 1 << (S - wd), p)                           # generator of the 2^wd-th roots
             j = next(j for j in range(1 << wd) if pow(h, j, p) == dc)
             if i == 0 and j & 1:
                 odd = True
-            gs = pow(g, -(j << (4 * i)), p); gh = pow(g, -((j << (4 * i)) >> 1), p) if not (i == 0 and j & 1) else 1
+            hw = min(8, S)                                         # the device finds j by a perfect hash of the 2^hw-th roots (consts_gen.h)
+            lo = (dc * f.R % p) & 0xFFFFFFFF
+            assert d["SQRT_HIDX_tab"][((lo * d["SQRT_HMUL"]) & 0xFFFFFFFF) >> (32 - d["SQRT_HBITS"])] >> (hw - wd) == j
+            gs = pow(g, -(j << (8 * i)), p); gh = pow(g, -((j << (8 * i)) >> 1), p) if not (i == 0 and j & 1) else 1
             c = mul(c, sl(gs * f.R % p)); r = mul(r, sl(gh * f.R % p))
         x = packed(r)
         is_sq = pow(u0 * pow(v0, -1, p) % p, (p - 1) // 2, p) == 1
         assert odd == (not is_sq)
         if is_sq:
             assert x * x % p * v0 % p == u0
-    print(f"  {f.name}: sqrt(u / v) on unsaturated limbs (4-bit-window power, {S}-bit discrete log) on {n} random inputs; largest operand {big:.1f} p (the inputs sliced with the shift)")
+    print(f"  {f.name}: sqrt(u / v) on unsaturated limbs (4-bit-window power, {S}-bit discrete log in 8-bit windows, looked up through the header's hash table) on {n} random inputs; largest operand {big:.1f} p (the inputs sliced with the shift)")
 
 
 class G1Red:
