@@ -33,6 +33,10 @@ template <class F> struct UL {
   static constexpr int SH = W * L - 32 * N;                       // 5 (8 limbs), 8 (12 limbs)
   static constexpr uint32_t MASK = (1u << W) - 1u;
   static constexpr uint32_t NINV = F::NINV & MASK;                // -p^-1 mod 2^W
+  // p = 1 mod 2^W (Bandersnatch's base field): the reduction SUBTRACTS m_k p with m_k = the column's low W bits as they are -- no multiply
+  // and no negation for m_k, and the column's own term m_k p_0 = m_k is what the arithmetic shift drops (floor).  Results differ from the
+  // additive form's by exactly p (|value| < |a b| / 2^(W L) + p either way); tools/fpu_model.py and gen_fpu_asm.py take the same branch.
+  static constexpr bool SUBTRACTIVE = (F::P[0] & MASK) == 1u && NINV == MASK;
   // limbs of K * value(c) (c: N words, K small): limb i = bits [W i, W i + W), the top limb takes what is left
   static constexpr ulimbs<L> slice_const(const uint32_t (&c)[N], uint32_t K) {
     uint32_t w[N + 2] = {};
@@ -160,9 +164,12 @@ template <class F> AVRF_DI fuF<F> fu_mul(const fuF<F> &a, const fuF<F> &b) {
 #pragma unroll
     for (int i = 0; i <= k; i++) acc += (int64_t)a.v[i] * (int64_t)b.v[k - i];
 #pragma unroll
-    for (int i = 0; i < k; i++) acc += (int64_t)m[i] * (int64_t)(int32_t)U::P1.v[k - i];
-    m[k] = (int32_t)(((uint32_t)acc * U::NINV) & U::MASK);
-    acc += (int64_t)m[k] * (int64_t)(int32_t)U::P1.v[0];
+    for (int i = 0; i < k; i++) acc += (int64_t)m[i] * (U::SUBTRACTIVE ? -(int64_t)(int32_t)U::P1.v[k - i] : (int64_t)(int32_t)U::P1.v[k - i]);
+    if constexpr (U::SUBTRACTIVE) m[k] = (int32_t)((uint32_t)acc & U::MASK);
+    else {
+      m[k] = (int32_t)(((uint32_t)acc * U::NINV) & U::MASK);
+      acc += (int64_t)m[k] * (int64_t)(int32_t)U::P1.v[0];
+    }
     acc >>= W;
   }
 #pragma unroll
@@ -170,7 +177,7 @@ template <class F> AVRF_DI fuF<F> fu_mul(const fuF<F> &a, const fuF<F> &b) {
 #pragma unroll
     for (int i = k - L + 1; i < L; i++) acc += (int64_t)a.v[i] * (int64_t)b.v[k - i];
 #pragma unroll
-    for (int i = k - L + 1; i < L; i++) acc += (int64_t)m[i] * (int64_t)(int32_t)U::P1.v[k - i];
+    for (int i = k - L + 1; i < L; i++) acc += (int64_t)m[i] * (U::SUBTRACTIVE ? -(int64_t)(int32_t)U::P1.v[k - i] : (int64_t)(int32_t)U::P1.v[k - i]);
     r.v[k - L] = (int32_t)((uint32_t)acc & U::MASK);
     acc >>= W;
   }
@@ -195,10 +202,13 @@ template <class F> AVRF_DI fuF<F> fu_sqr(const fuF<F> &a) {
 #pragma unroll
     for (int i = i0; 2 * i <= k; i++) acc += (int64_t)a.v[i] * (int64_t)(2 * i == k ? a.v[i] : d[k - i]);
 #pragma unroll
-    for (int i = i0; i < (k < L ? k : L); i++) acc += (int64_t)m[i] * (int64_t)(int32_t)U::P1.v[k - i];
+    for (int i = i0; i < (k < L ? k : L); i++) acc += (int64_t)m[i] * (U::SUBTRACTIVE ? -(int64_t)(int32_t)U::P1.v[k - i] : (int64_t)(int32_t)U::P1.v[k - i]);
     if (k < L) {
-      m[k] = (int32_t)(((uint32_t)acc * U::NINV) & U::MASK);
-      acc += (int64_t)m[k] * (int64_t)(int32_t)U::P1.v[0];
+      if constexpr (U::SUBTRACTIVE) m[k] = (int32_t)((uint32_t)acc & U::MASK);
+      else {
+        m[k] = (int32_t)(((uint32_t)acc * U::NINV) & U::MASK);
+        acc += (int64_t)m[k] * (int64_t)(int32_t)U::P1.v[0];
+      }
     } else r.v[k - L] = (int32_t)((uint32_t)acc & U::MASK);
     acc >>= W;
   }

@@ -57,6 +57,9 @@ class Field:
         self.Ru = 1 << (self.W * self.L)       # unsaturated form
         self.pl = self.slice_pos(self.p)
         self.max_col = 0
+        # p = 1 mod 2^W (Bandersnatch's base field): the reduction SUBTRACTS lo_k p, lo_k = the column's low W bits as they are -- no
+        # negation, no multiply for m_k, and the column's own term lo_k p_0 = lo_k is what the arithmetic shift drops (fpu.h fu_mul)
+        self.p0_one = self.pl[0] == 1 and self.ninv == self.MASK
 
     def slice_pos(self, v):
         """limbs of a non-negative value (top limb takes the rest)"""
@@ -84,8 +87,10 @@ class Field:
             for i in range(lo, hi + 1):
                 acc += a[i] * b[k - i]; self.acc_ok(acc)
             for i in range(lo, min(hi, k - 1) + 1):
-                acc += m[i] * self.pl[k - i]; self.acc_ok(acc)
-            if k < L:
+                acc += (-m[i] if self.p0_one else m[i]) * self.pl[k - i]; self.acc_ok(acc)
+            if k < L and self.p0_one:
+                m[k] = acc & self.MASK                         # (acc - m_k) >> W == acc >> W: the floor of the arithmetic shift
+            elif k < L:
                 m[k] = ((acc & 0xffffffff) * self.ninv) & self.MASK
                 acc += m[k] * self.pl[0]; self.acc_ok(acc)
                 assert acc & self.MASK == 0

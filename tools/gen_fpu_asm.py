@@ -5,7 +5,10 @@ limbs, product scanning with the reduction interleaved) as ONE inline-asm block 
 Why: the compiler's form of the same C++ spends ~100 instructions per product beside the 162 multiply-adds (64-bit adds that join
 column chains it split for latency, moves that build 64-bit addends, two shifts per column: profiles/r5_ubench.txt, 532
 instructions for two products); the stream below is the algorithm as written -- 162 multiply-adds, two instructions for each
-m_k, one 64-bit shift per column, one mask per result limb: 207 instructions (squaring: 126 multiply-adds, 180).  The bucket
+m_k, one 64-bit shift per column, one mask per result limb: 207 instructions (squaring: 126 multiply-adds, 180).  A field with
+p = 1 mod 2^29 (Bandersnatch's base field) takes the subtractive form: m_k is the column's low 29 bits as they are (one v_and_b32), the
+reduction subtracts m_k p through signed products with the negated modulus limbs, the column's own m_k p_0 = m_k is what the arithmetic
+shift drops: 153 multiply-adds in 179 vector instructions (squaring 117 in 151).  The bucket
 accumulation is bound by VALU issue, so instructions are what counts.
 
   column k < 9:   acc += sum_i a_i b_(k-i) + sum_(i<k) m_i p_(k-i);  m_k = (-p^-1 lo(acc)) mod 2^29;  acc += m_k p_0;  acc >>= 29
@@ -31,7 +34,7 @@ import fpu_model  # noqa: E402
 
 OUT = os.path.join(ROOT, "ark_vrf_amd", "csrc", "fpu_asm_gen.h")
 ACC, S0 = 30, 36                 # accumulator pair v[30:31]; modulus limbs from s36
-SM = 52                          # s[52:53] = 2^W - 1 as a 64-bit constant (fields with p = 1 mod 2^W)
+
 M0 = 32                          # 14-limb form: m_k in v[32..45]
 ACCP = f"v[{ACC}:{ACC + 1}]"
 LO = f"v{ACC}"
@@ -80,13 +83,10 @@ def body(f, sqr=False):
     P = lambda j: f"s{S0 + j}"
     p0_one = f.pl[0] == 1 and f.ninv == MASK
     for j in range(L):
-        if not (p0_one and j == 0):
-            ins.append(f"s_mov_b32 {P(j)}, 0x{f.pl[j]:x}")
+        if not (p0_one and j == 0):                          # p = 1 mod 2^W: the limbs are held NEGATED (the reduction subtracts lo_k p)
+            ins.append(f"s_mov_b32 {P(j)}, 0x{((-f.pl[j]) & 0xffffffff) if p0_one else f.pl[j]:x}")
     if not p0_one:
         ins.append(f"s_mov_b32 s{S0 + L}, 0x{f.ninv:x}")
-    else:
-        ins.append(f"s_mov_b32 s{SM}, 0x{MASK:x}")
-        ins.append(f"s_mov_b32 s{SM + 1}, 0")
     if sqr:
         for j in range(1, L):
             ins.append(f"v_lshlrev_b32 {fm.D(j)}, 1, {fm.A(j)}")
@@ -108,13 +108,11 @@ def body(f, sqr=False):
             elif i < j:
                 mad("v_mad_i64_i32", fm.A(i), fm.D(j))
         for i in range(lo, min(hi, k - 1) + 1):
-            mad("v_mad_u64_u32", fm.M(i), P(k - i))
+            mad("v_mad_i64_i32" if p0_one else "v_mad_u64_u32", fm.M(i), P(k - i))
         if k < L:
-            if p0_one:                       # p = 1 mod 2^W: m_k = -lo mod 2^W; acc + m_k p_0 = acc + m_k has its low W bits clear,
-                ins.append(f"v_sub_u32 {fm.M(k)}, 0, {LO}")      # so (acc + m_k) >> W = (acc + 2^W - 1) >> W: a 64-bit add of a
-                ins.append(f"v_and_b32 {fm.M(k)}, 0x{MASK:x}, {fm.M(k)}")   # constant, no multiplier slot
-                ins.append(f"v_lshl_add_u64 {ACCP}, {ACCP}, 0, s[{SM}:{SM + 1}]")
-            else:
+            if p0_one:                       # p = 1 mod 2^W: subtract lo_k p with lo_k = the column's low W bits as they are: lo_k p_0 = lo_k is
+                ins.append(f"v_and_b32 {fm.M(k)}, 0x{MASK:x}, {LO}")        # exactly what the arithmetic shift below drops (floor), and the later
+            else:                                                            # columns take lo_k (-p_j) as signed products: one instruction per m_k
                 ins.append(f"v_mul_lo_u32 {fm.M(k)}, {LO}, s{S0 + L}")
                 ins.append(f"v_and_b32 {fm.M(k)}, 0x{MASK:x}, {fm.M(k)}")
                 ins.append(f"v_mad_u64_u32 {ACCP}, vcc, {fm.M(k)}, {P(0)}, {ACCP}")
@@ -128,7 +126,7 @@ def body(f, sqr=False):
 def clobbers(f, sqr=False):
     L = f.L
     p0_one = f.pl[0] == 1 and f.ninv == f.MASK
-    s = [f"s{S0 + j}" for j in range(L + 1) if not (p0_one and j in (0, L))] + ([f"s{SM}", f"s{SM + 1}"] if p0_one else [])
+    s = [f"s{S0 + j}" for j in range(L + 1) if not (p0_one and j in (0, L))]
     return Form(f, sqr).fixed_vgprs() + s + ["vcc"]
 
 

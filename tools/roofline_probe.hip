@@ -41,12 +41,14 @@ template <int WHICH> __global__ void __launch_bounds__(256) k_stream(uint32_t *o
     clk[2 * (size_t)w] = t1 - t0; clk[2 * (size_t)w + 1] = r1 - r0;
   }
 }
-__global__ void __launch_bounds__(64) k_clock(uint64_t *clk, uint64_t spin_ticks) {
-  const uint64_t t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
-  uint64_t r1 = r0;
-  while (r1 - r0 < spin_ticks) { __builtin_amdgcn_s_sleep(32); r1 = wall_clock64(); }
-  const uint64_t t1 = __builtin_readcyclecounter();
-  if (threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+__global__ void __launch_bounds__(64) k_clock(uint64_t *clk, uint64_t spin_ticks, uint32_t count) {
+  for (uint32_t s = 0; s < count; s++) {
+    const uint64_t t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    uint64_t r1 = r0;
+    while (r1 - r0 < spin_ticks) { __builtin_amdgcn_s_sleep(32); r1 = wall_clock64(); }
+    const uint64_t t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) { clk[2 * (size_t)s] = t1 - t0; clk[2 * (size_t)s + 1] = r1 - r0; }
+  }
 }
 
 static double median_mhz(std::vector<uint64_t> &h, double wall_khz) {
@@ -90,18 +92,25 @@ extern "C" {
 // out[6] = {T lane-ops/s, measured shader MHz, best launch ms, CUs, runtime-reported MHz, lane-ops/clk/CU at the measured clock}
 int avrf_probe_mad_stream(int device, int waves_per_cu, int iters, int reps, double *out) { return run_stream<0>(device, waves_per_cu, iters, reps, out); }
 int avrf_probe_valu_stream(int device, int waves_per_cu, int iters, int reps, double *out) { return run_stream<1>(device, waves_per_cu, iters, reps, out); }
-// one wave on its own (non-blocking) stream for spin_us microseconds; out[2] = {shader MHz, microseconds actually spun}
-int avrf_probe_clock(int device, double spin_us, double *out) {
+// one wave on its own (non-blocking) stream: `count` samples of spin_us microseconds each, back to back; mhz[count] = the shader clock of
+// every sample (the wave sleeps between its reads of the two counters: it takes no issue slots worth mentioning from what runs beside it)
+int avrf_probe_clock_series(int device, double spin_us, uint32_t count, double *mhz) {
   PCK(hipSetDevice(device));
   int wall_khz = 0; PCK(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, device));
   hipStream_t st; PCK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  uint64_t *d_clk; PCK(hipMalloc(&d_clk, 16));
-  hipLaunchKernelGGL(k_clock, dim3(1), dim3(64), 0, st, d_clk, (uint64_t)(spin_us * 1e-3 * wall_khz));
+  uint64_t *d_clk; PCK(hipMalloc(&d_clk, 16 * (size_t)count));
+  hipLaunchKernelGGL(k_clock, dim3(1), dim3(64), 0, st, d_clk, (uint64_t)(spin_us * 1e-3 * wall_khz), count);
   PCK(hipStreamSynchronize(st));
-  uint64_t h[2]; PCK(hipMemcpy(h, d_clk, 16, hipMemcpyDeviceToHost));
-  out[0] = h[1] ? (double)h[0] / (double)h[1] * wall_khz * 1e-3 : 0.0;
-  out[1] = (double)h[1] / wall_khz * 1e3;
+  std::vector<uint64_t> h(2 * (size_t)count);
+  PCK(hipMemcpy(h.data(), d_clk, 16 * (size_t)count, hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < count; i++) mhz[i] = h[2 * i + 1] ? (double)h[2 * i] / (double)h[2 * i + 1] * wall_khz * 1e-3 : 0.0;
   hipFree(d_clk); hipStreamDestroy(st);
   return 0;
+}
+// one sample; out[2] = {shader MHz, microseconds actually spun}
+int avrf_probe_clock(int device, double spin_us, double *out) {
+  int rc = avrf_probe_clock_series(device, spin_us, 1, out);
+  out[1] = spin_us;
+  return rc;
 }
 }
