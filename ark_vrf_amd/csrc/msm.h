@@ -96,6 +96,22 @@ int msm_g1_fixed_device(int curve, const uint32_t *d_table, int table_c, size_t 
                         size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch,
                         const uint32_t *d_base_idx = nullptr, int scalars_mont = 0);
 // (scalars_mont: the scalar vectors hold Montgomery limbs -- 1 = BLS12-381 Fr, 2 = BN254 Fr -- and the digit kernel converts on load)
+// Fixed-base form over a table of ALL multiples (msm.hip "fixed-base MSM over a table of ALL multiples"): for HBM-rich parts.  The table of
+// a KZG SRS is built once per (device, SRS) and shared; a commitment is one gathered point per (coefficient, row), no buckets.
+struct G1DirectTable {
+  uint32_t *d = nullptr;            // affine Montgomery points, 2 * Fq words each; (w, m, i) = (m + 1) 2^(c w) P_i at off[w] + m * n + i
+  int curve = 0, c = 0, rows = 0;   // rows: digit rows + the carry row where the recoding can carry out of the top one
+  size_t n = 0;                     // bases per row
+  uint64_t off[32] = {};            // first point of row w
+  uint32_t mult[32] = {};           // multiples held for row w (1 .. mult[w])
+  uint64_t points = 0, bytes = 0;
+};
+size_t g1_direct_table_shape(int curve, size_t n, int c, G1DirectTable *t);      // fills *t (no allocation), returns the table's bytes
+void build_g1_direct_table(int curve, const uint32_t *d_bases, size_t n, int c, G1DirectTable *t, hipStream_t stream);   // allocates t->d, synchronises
+void free_g1_direct_table(G1DirectTable *t);
+// `batch` vectors of n Montgomery-or-plain scalars (vector b starts at element b * scalar_stride) -> `batch` affine results in out_xy
+int msm_g1_direct_device(const G1DirectTable &t, const uint32_t *d_scalars, size_t n, size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream,
+                         uint8_t *out_xy, size_t batch, int scalars_mont = 0);
 // n compressed G1 points (FQ_BYTES each, ark-serialize) -> canonical x || y little-endian + ok[i] (0 invalid, 1 point, 2 infinity)
 void launch_g1_decompress(int curve, const uint8_t *d_comp, size_t n, uint8_t *d_out_xy, uint8_t *d_ok, hipStream_t stream);
 void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, uint32_t *d_flag, hipStream_t stream);

@@ -341,14 +341,15 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
     };
     const uint32_t cnt = e1 - e0;
     if constexpr (!CV::PREFETCH) acc = AC::identity();
-    uint32_t idx = sorted[e0];
+    uint32_t idx = cnt ? sorted[e0] : 0u;                       // (a lane with an empty share reads nothing and gathers nothing)
     uint32_t idx1 = cnt > 1 ? sorted[e0 + 1] : 0u;
-    issue(idx, 0);
+    if (cnt) issue(idx, 0);
     for (uint32_t k = 0; k < cnt; k++) {                        // k is the same in every lane of the wave (shares start together)
       const uint32_t i = e0 + k, cidx = idx;
       // the DMA of this buffer was issued one iteration ago: the compiler's own wait insertion does not carry an LDS-DMA across
-      // the loop's back edge (it put the ds_reads BEFORE its vmcnt(0)), so the wait is explicit -- and a compiler barrier
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the loop's back edge (it put the ds_reads BEFORE its vmcnt(0)), so the wait is explicit -- and a compiler barrier.
+      // lgkmcnt(0): the ds_reads of the OTHER buffer (last iteration's fetch) have returned before the DMA issued below overwrites it.
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       const base_t cur = fetch(k & 1);
       idx = idx1;
       if (k + 1 < cnt) issue(idx, (k + 1) & 1);
@@ -1383,6 +1384,248 @@ int msm_g1_device(int curve, const uint32_t *d_bases, const uint32_t *d_scalars,
   if (curve == 1) return msm_g1_impl<G1Bn254>(d_bases, d_scalars, n, ws, stream, out_xy, batch, 0, 0, scalar_stride);
   return -1;
 }
+// ---------------------------------------------------------------- fixed-base MSM over a table of ALL multiples (no buckets, no sort)
+//
+// A KZG commitment is an MSM over ONE fixed base set (the SRS), and an MI355X has 288 GB of HBM.  G1DirectTable holds, for every
+// window row w and base i, every multiple m 2^(c w) P_i a signed c-bit digit can ask for (m = 1 .. 2^(c-1)): a commitment is then the
+// plain SUM of one table point per (coefficient, row) -- n * rows mixed additions into per-lane accumulators and a tree over the lanes'
+// partial sums.  No digit sort, no bucket sums, no weighted bucket reduction (the latter two were a quarter of the ring prover's device
+// time), and the window can be as wide as memory allows: c = 15 for the 6 145 powers of a ring-1024 setup = 17 rows instead of the 22 of
+// the 12-bit bucket form (1.71 G points, 164 GB).  The gathers are random 96-byte reads over the whole table: 12.7 G/s measured on a
+// 200 GB table (tools/gather_probe.hip, profiles/r6_gather_probe.txt), four times what 24 k proofs/s ask for, 8 us each -- covered by
+// the LDS-DMA prefetch of k_accumulate, whose addition takes longer than that.
+//   layout: point (w, m, i) = (m + 1) 2^(c w) P_i at t.off[w] + m * n + i (affine Montgomery, (0, 0) = infinity): a build step writes
+//   whole rows of bases at a time.  Rows: R = ceil(bits / c) digit rows; the top one holds only the multiples its digits can reach, and a
+//   carry row (one multiple) follows when the signed recoding can carry out of it.
+template <class C> static void direct_shape(size_t n, int c, G1DirectTable *t) {
+  constexpr int BITS = C::Fr::BITS;
+  const int R = (BITS + c - 1) / c;
+  const uint32_t nb = 1u << (c - 1);
+  // largest digit of the top row: (r - 1) >> (c (R - 1)), plus the carry coming in
+  uint32_t top = 0;
+  { const int bit = c * (R - 1); uint64_t w[9] = {}; for (int k = 0; k < 8; k++) w[k] = C::Fr::P[k];
+    uint64_t borrow = 1; for (int k = 0; k < 8; k++) { const uint64_t d = w[k] - borrow; borrow = w[k] < borrow; w[k] = d & 0xffffffffu; }     // r - 1
+    const int li = bit >> 5, sh = bit & 31; const uint64_t two = w[li] | (w[li + 1] << 32); top = (uint32_t)((two >> sh) & ((1ull << c) - 1)) + 1u; }
+  t->c = c; t->n = n; t->rows = R;
+  uint64_t off = 0;
+  for (int w = 0; w < R; w++) { t->mult[w] = (w + 1 < R) ? nb : (top <= nb ? top : nb); t->off[w] = off; off += (uint64_t)t->mult[w] * n; }
+  if (top > nb) { t->mult[R] = 1; t->off[R] = off; off += n; t->rows = R + 1; }
+  t->points = off; t->bytes = off * 2 * C::Fq::N * 4;
+}
+size_t g1_direct_table_shape(int curve, size_t n, int c, G1DirectTable *t) {
+  G1DirectTable tmp; if (!t) t = &tmp;
+  t->curve = curve;
+  if (curve == 0) direct_shape<G1Bls12381>(n, c, t); else direct_shape<G1Bn254>(n, c, t);
+  return t->bytes;
+}
+
+// One lane per (row, base): the multiples m0 + 1 .. m0 + K of its base, as k_g1_table normalises a lane's rows -- X, Y into the table
+// slot, ZZ, ZZZ and the running product into tmp, ONE inversion per lane and chunk, Montgomery's trick backwards.
+template <class C>
+__global__ void __launch_bounds__(64)
+k_g1_multiples(const uint32_t *__restrict__ rowbase, uint32_t n, uint32_t rows, G1DirectTable t, uint32_t m0, uint32_t K, uint32_t *__restrict__ table,
+               uint32_t *__restrict__ tmp, uint32_t lanes) {
+  using CV = G1Curve<C>; using Fq = typename C::Fq; constexpr int N = Fq::N;
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lane >= lanes) return;
+  const uint32_t w = lane / n, i = lane - w * n;
+  if (m0 >= t.mult[w]) return;
+  const uint32_t kend = m0 + K < t.mult[w] ? m0 + K : t.mult[w];
+  const typename CV::base_t B = CV::load_base(rowbase + ((size_t)w * n + i) * 2 * N);
+  typename CV::acc_t acc = CV::from_affine(B);
+  if (m0) acc = CV::madd(CV::from_affine(CV::load_base(table + (t.off[w] + (uint64_t)(m0 - 1) * n + i) * 2 * N)), B, false);
+  fpn<N> run = fn_one<Fq>();
+#pragma unroll 1
+  for (uint32_t m = m0; m < kend; m++) {
+    uint32_t *o = table + (t.off[w] + (uint64_t)m * n + i) * 2 * N;
+    uint32_t *q = tmp + ((size_t)(m - m0) * lanes + lane) * 3 * N;
+    fn_store<N>(o, acc.x); fn_store<N>(o + N, acc.y);
+    fn_store<N>(q, acc.zz); fn_store<N>(q + N, acc.zzz); fn_store<N>(q + 2 * N, run);
+    if (!CV::is_identity(acc)) run = fn_mul<Fq>(run, fn_mul<Fq>(acc.zz, acc.zzz));
+    if (m + 1 < kend) acc = m == 0 ? CV::dbl(acc) : CV::madd(acc, B, false);
+  }
+  fpn<N> inv = fn_inv<Fq>(run);
+#pragma unroll 1
+  for (uint32_t m = kend; m-- > m0;) {
+    uint32_t *o = table + (t.off[w] + (uint64_t)m * n + i) * 2 * N;
+    const uint32_t *q = tmp + ((size_t)(m - m0) * lanes + lane) * 3 * N;
+    const fpn<N> zz = fn_load<N>(q), zzz = fn_load<N>(q + N);
+    if (fn_is_zero(zz)) { fn_store<N>(o, fn_zero<N>()); fn_store<N>(o + N, fn_zero<N>()); continue; }
+    const fpn<N> dinv = fn_mul<Fq>(inv, fn_load<N>(q + 2 * N));              // 1 / (ZZ ZZZ) of this multiple
+    inv = fn_mul<Fq>(inv, fn_mul<Fq>(zz, zzz));
+    fn_store<N>(o, fn_mul<Fq>(fn_load<N>(o), fn_mul<Fq>(dinv, zzz)));        // X / ZZ
+    fn_store<N>(o + N, fn_mul<Fq>(fn_load<N>(o + N), fn_mul<Fq>(dinv, zz)));  // Y / ZZZ
+  }
+}
+template <class C> static void build_direct_impl(const uint32_t *d_bases, G1DirectTable *t, hipStream_t stream) {
+  constexpr int N = C::Fq::N;
+  const size_t n = t->n; const uint32_t rows = (uint32_t)t->rows;
+  if (t->points >= 0x7fffffffull) throw HipFailure{hipErrorInvalidValue, __FILE__, __LINE__};     // 31-bit entry indices
+  HIP_CHECK(hipMalloc(&t->d, t->bytes));
+  uint32_t *rowbase = nullptr, *tmp = nullptr;
+  HIP_CHECK(hipMalloc(&rowbase, (size_t)rows * n * 2 * N * 4));
+  build_g1_table(t->curve, d_bases, n, t->c, (int)rows, rowbase, stream);
+  const uint32_t lanes = (uint32_t)(rows * n), K = 128;
+  HIP_CHECK(hipMalloc(&tmp, (size_t)K * lanes * 3 * N * 4));
+  uint32_t mmax = 0; for (uint32_t w = 0; w < rows; w++) mmax = t->mult[w] > mmax ? t->mult[w] : mmax;
+  for (uint32_t m0 = 0; m0 < mmax; m0 += K)
+    hipLaunchKernelGGL(k_g1_multiples<C>, dim3((lanes + 63) / 64), dim3(64), 0, stream, (const uint32_t *)rowbase, (uint32_t)n, rows, *t, m0, K, t->d, tmp, lanes);
+  HIP_CHECK(hipStreamSynchronize(stream));
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipFree(tmp)); HIP_CHECK(hipFree(rowbase));
+}
+void build_g1_direct_table(int curve, const uint32_t *d_bases, size_t n, int c, G1DirectTable *t, hipStream_t stream) {
+  g1_direct_table_shape(curve, n, c, t);
+  if (curve == 0) build_direct_impl<G1Bls12381>(d_bases, t, stream); else build_direct_impl<G1Bn254>(d_bases, t, stream);
+}
+void free_g1_direct_table(G1DirectTable *t) { if (t->d) (void)hipFree(t->d); t->d = nullptr; }
+
+constexpr uint32_t DIRECT_ZERO = 0xffffffffu;
+// entry (vector, coefficient i, row w) -> table index | sign << 31 (DIRECT_ZERO for a zero digit); the digits are k_digits' signed recoding
+__global__ void __launch_bounds__(256) k_direct_index(const uint32_t *__restrict__ scalars, uint32_t n, uint32_t stride, G1DirectTable t, uint32_t *__restrict__ idx, int mont) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t bat = blockIdx.y, rows = (uint32_t)t.rows, tn = (uint32_t)t.n;
+  const int c = t.c;
+  uint32_t s[9];
+  const uint4 *p = reinterpret_cast<const uint4 *>(scalars + 8 * ((size_t)bat * stride + i));
+  const uint4 a = p[0], b = p[1];
+  s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; s[8] = 0;
+  if (mont) {
+    fp v;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v.v[k] = s[k];
+    v = mont == 1 ? fp_from_mont<FqBandersnatch>(v) : fp_from_mont<FqBabyJubJub>(v);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = v.v[k];
+  }
+  uint32_t *o = idx + ((size_t)bat * n + i) * rows;
+  const uint32_t nb = 1u << (c - 1), mask = (1u << c) - 1;
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < rows; w++) {
+    const int bit = (int)w * c;
+    uint32_t v = 0;
+    if (bit < 256) {
+      const int li = bit >> 5, sh = bit & 31;
+      const uint64_t two = (uint64_t)s[li] | ((uint64_t)(li + 1 < 9 ? s[li + 1] : 0u) << 32);
+      v = (uint32_t)(two >> sh) & mask;
+    }
+    v += carry;
+    uint32_t m, sign = 0;
+    if (v > nb) { m = (1u << c) - v; sign = 0x80000000u; carry = 1; } else { m = v; carry = 0; }
+    // (a scalar below r never asks a row for more than it holds: direct_shape sized the top row and the carry row from r - 1)
+    o[w] = (m == 0 || m > t.mult[w]) ? DIRECT_ZERO : (uint32_t)(t.off[w] + (uint64_t)(m - 1) * tn + i) | sign;
+  }
+}
+
+// Lane t sums the table points of the entries [e0, e1) of ONE vector (t / lpv); its partial sum goes to part[t].  The gather
+// pipeline is k_accumulate's: the point of entry k + 1 travels HBM -> LDS by DMA while the addition of entry k runs.
+template <class CV>
+__global__ void __launch_bounds__(256, CV::MIN_WAVES)
+k_accumulate_direct(const uint32_t *__restrict__ table, const uint32_t *__restrict__ idx, uint32_t E, uint32_t lpv, uint32_t per, uint32_t batch,
+                    uint32_t *__restrict__ part) {
+  using AC = typename CV::accum; using acc_t = typename AC::acc_t; using base_t = typename CV::base_t;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t vec = t / lpv, r = t - vec * lpv;
+  extern __shared__ uint32_t acc_lds[];
+  constexpr int BW = CV::BASE_WORDS, CH = BW / 4;
+  uint32_t *wbuf = acc_lds + (threadIdx.x >> 6) * (2 * BW * 64);
+  const uint32_t lane = threadIdx.x & 63;
+  const bool live = vec < batch;
+  const size_t v0 = (size_t)(live ? vec : 0) * E;
+  uint32_t cnt = 0; size_t e0 = v0;
+  if (live && (uint64_t)r * per < E) { e0 = v0 + (size_t)r * per; cnt = (uint64_t)r * per + per <= E ? per : (uint32_t)(E - (uint64_t)r * per); }
+  auto issue = [&](uint32_t ix, uint32_t slot) {
+    const uint32_t *src = table + (size_t)(ix == DIRECT_ZERO ? 0u : (ix & 0x7fffffffu)) * BW;
+#pragma unroll
+    for (int c = 0; c < CH; c++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 4 * c),
+                                       (__attribute__((address_space(3))) void *)(wbuf + slot * (BW * 64) + c * 256), 16, 0, 0);
+  };
+  auto fetch = [&](uint32_t slot) {
+    uint32_t w[BW];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(wbuf + slot * (BW * 64) + c * 256 + lane * 4);
+      w[4 * c] = v.x; w[4 * c + 1] = v.y; w[4 * c + 2] = v.z; w[4 * c + 3] = v.w;
+    }
+    return CV::base_from_words(w);
+  };
+  acc_t acc = AC::identity();
+  uint32_t ix = cnt ? idx[e0] : DIRECT_ZERO;
+  uint32_t ix1 = cnt > 1 ? idx[e0 + 1] : DIRECT_ZERO;
+  if (cnt) issue(ix, 0);
+  for (uint32_t k = 0; k < cnt; k++) {
+    const uint32_t cix = ix;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");            // the DMA of this buffer, and the reads of the other one before it is overwritten
+    const base_t cur = fetch(k & 1);
+    ix = ix1;
+    if (k + 1 < cnt) issue(ix, (k + 1) & 1);
+    if (k + 2 < cnt) ix1 = idx[e0 + k + 2];
+    if (cix != DIRECT_ZERO) acc = AC::madd(acc, cur, (cix & 0x80000000u) != 0);
+  }
+  if (t < batch * lpv) AC::store_part(part + (size_t)t * AC::PART_WORDS, acc);
+}
+// one workgroup per vector: the lpv partial sums -> one point (canonical XYZZ for the host, as the bucket form's k_wsum leaves it)
+template <class RV>
+__global__ void __launch_bounds__(256, RV::RED_WAVES)
+k_direct_reduce(const uint32_t *__restrict__ part, uint32_t lpv, uint32_t *__restrict__ out) {
+  using acc_t = typename RV::acc_t;
+  extern __shared__ uint32_t lds[];                                            // 4 accumulators
+  const uint32_t vec = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  acc_t a = RV::identity();
+#pragma unroll 1
+  for (uint32_t k = t; k < lpv; k += 256) a = cv_add<RV>(a, RV::accum::load_part(part + ((size_t)vec * lpv + k) * RV::accum::PART_WORDS));
+  a = wave_sum<RV>(a);
+  if (lane == 0) RV::store_acc(lds + wv * RV::ACC_WORDS, a);
+  __syncthreads();
+  if (t == 0) {
+#pragma unroll 1
+    for (uint32_t w = 1; w < 4; w++) a = cv_add<RV>(a, RV::load_acc(lds + w * RV::ACC_WORDS));
+    RV::store_out(out + (size_t)vec * RV::OUT_WORDS, a);
+  }
+}
+template <class C>
+static int msm_g1_direct_impl(const G1DirectTable &t, const uint32_t *d_scalars, size_t n, size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream,
+                              uint8_t *out_xy, size_t batch, int scalars_mont) {
+  using CV = G1Curve<C>; using RV = typename CV::red; using HG = HostG1<C>;
+  if (!n || !batch) return -1;
+  const size_t rows = (size_t)t.rows, E = n * rows;
+  if (E * batch >= 0xffff0000ull || n > t.n) throw HipFailure{hipErrorInvalidValue, __FILE__, __LINE__};
+  const AccShape shape = accumulate_shape<CV>();
+  size_t lpv = shape.lanes / batch; if (lpv > 1024) lpv = 1024; if (lpv < 1) lpv = 1;
+  const size_t per = (E + lpv - 1) / lpv, lanes = batch * lpv;
+  // workspace: the entry indices take `sorted`, the partial sums `part`, the results `rc` / `bits_host`
+  MsmPlan p; p.c = t.c; p.nwin = 1; p.nb = 1; p.lpb = (int)per;
+  ws.ensure(E, p, (size_t)RV::OUT_WORDS * 4 > (size_t)RV::ACC_WORDS * 4 ? (size_t)RV::OUT_WORDS * 4 : (size_t)RV::ACC_WORDS * 4, batch, lanes + 256,
+            (size_t)CV::accum::PART_WORDS * 4);
+  static std::once_flag once[2];
+  std::call_once(once[t.curve ? 1 : 0], [&]() {
+    if (shape.lds > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate_direct<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape.lds));
+  });
+  hipLaunchKernelGGL(k_direct_index, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, stream, d_scalars, (uint32_t)n, (uint32_t)(scalar_stride ? scalar_stride : n),
+                     t, ws.sorted, scalars_mont);
+  if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
+  HIP_CHECK(hipEventRecord(ws.ev0, stream));
+  hipLaunchKernelGGL(k_accumulate_direct<CV>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), shape.lds, stream, (const uint32_t *)t.d, (const uint32_t *)ws.sorted,
+                     (uint32_t)E, (uint32_t)lpv, (uint32_t)per, (uint32_t)batch, ws.part);
+  HIP_CHECK(hipEventRecord(ws.ev1, stream));
+  hipLaunchKernelGGL(k_direct_reduce<RV>, dim3((unsigned)batch), dim3(256), 4 * (size_t)RV::ACC_WORDS * 4, stream, (const uint32_t *)ws.part, (uint32_t)lpv, ws.rc);
+  HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.rc, batch * (size_t)RV::OUT_WORDS * 4, hipMemcpyDeviceToHost, stream));
+  ws.plan_host[0] = (uint32_t)per;
+  ws.pending_plan = p;
+  msm_wait(ws, stream);
+  std::vector<typename HG::Pt> res(batch);
+  for (size_t b = 0; b < batch; b++) res[b] = HG::from_raw32(ws.bits_host + b * 4 * C::Fq::N);
+  HG::to_affine_bytes_batch(res.data(), batch, out_xy);
+  return 0;
+}
+int msm_g1_direct_device(const G1DirectTable &t, const uint32_t *d_scalars, size_t n, size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream,
+                         uint8_t *out_xy, size_t batch, int scalars_mont) {
+  if (t.curve == 0) return msm_g1_direct_impl<G1Bls12381>(t, d_scalars, n, scalar_stride, ws, stream, out_xy, batch, scalars_mont);
+  return msm_g1_direct_impl<G1Bn254>(t, d_scalars, n, scalar_stride, ws, stream, out_xy, batch, scalars_mont);
+}
+
 int msm_g1_fixed_device(int curve, const uint32_t *d_table, int table_c, size_t table_stride, const uint32_t *d_scalars, size_t n,
                         size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream, uint8_t *out_xy, size_t batch, const uint32_t *d_base_idx,
                         int scalars_mont) {

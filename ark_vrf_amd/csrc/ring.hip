@@ -28,6 +28,7 @@
 #include <sys/random.h>
 #include <algorithm>
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -523,11 +524,22 @@ using namespace avrf;
 // ------------------------------------------------------------------------------------------------
 // handles
 
+// The table of all multiples of an SRS (msm.h G1DirectTable: 164 GB for the 6 145 powers of a ring-1024 setup at c = 15) is a property
+// of (device, SRS): every setup over the same SRS on a device -- the four contexts bench.py proves with, their second lanes --
+// shares ONE through this registry; the last setup to go frees it.
+struct DirectEntry {
+  G1DirectTable t; int device = 0; std::vector<uint8_t> srs_key;
+  ~DirectEntry() { if (t.d) { (void)hipSetDevice(device); free_g1_direct_table(&t); } }
+};
+static std::mutex g_direct_mu;
+static std::vector<std::weak_ptr<DirectEntry>> g_direct;
+
 struct avrf_ring_setup {
   avrf_ctx *ctx; int suite; int curve; hipStream_t stream; int device;   // curve: pairing curve of the suite (0 BLS12-381, 1 BN254)
   size_t N, cap, keyset, L, n_srs;                    // n_srs = 0: verifier-only setup (PcsVerifierParams), no SRS on the device
   uint32_t *d_srs = nullptr;                          // n_srs Montgomery affine points
   uint32_t *d_srs_table = nullptr; int table_c = 0, table_nwin = 0;   // fixed-base window table over the SRS (batched commits)
+  std::shared_ptr<DirectEntry> direct; bool direct_tried = false;     // the table of all multiples (large batches of commitments), built on first use
   int wit_c = 0, wit_nwin = 0;                        // window width of the witness table (sparse MSMs: few entries, small buckets)
   uint32_t *d_wit_table = nullptr;                    // same over [L_i(tau) G, i < N | prefix sums PS_k = sum_{i<k} L_i(tau) G, k <= N] (witness commits)
   void *host_lines = nullptr; void (*host_lines_free)(void *) = nullptr;   // host Miller-loop line tables of (g2, tau g2), built on first use
@@ -973,7 +985,9 @@ template <class S, class G> struct Ring {
     std::vector<uint8_t> xy(batch * 2 * FQB);
     static const bool trace = getenv("AVRF_RING_TRACE") != nullptr;
     struct timespec t0; if (trace) { HIP_CHECK(hipStreamSynchronize(su->stream)); clock_gettime(CLOCK_MONOTONIC, &t0); }
-    msm_g1_fixed_device(su->curve, su->d_srs_table, su->table_c, su->n_srs, d_coeffs_mont, n, stride, su->ws, su->stream, xy.data(), batch, nullptr, mont_id);
+    // many vectors at once and the table of all multiples is there: one gathered point per (coefficient, row), no buckets (msm.hip)
+    if (su->direct && batch >= 32) msm_g1_direct_device(su->direct->t, d_coeffs_mont, n, stride, su->ws, su->stream, xy.data(), batch, mont_id);
+    else msm_g1_fixed_device(su->curve, su->d_srs_table, su->table_c, su->n_srs, d_coeffs_mont, n, stride, su->ws, su->stream, xy.data(), batch, nullptr, mont_id);
     if (trace) { struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
       fprintf(stderr, "    commit n=%zu batch=%zu: %.3f ms wall, accumulate %.3f ms (c=%d seg=%d)\n", n, batch,
               (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6, su->ws.accum_ms_last, su->ws.last_plan.c, su->ws.last_plan.lpb); }
@@ -1744,6 +1758,43 @@ int avrf_ring_vk_builder_finalize(const avrf_ring_vk_builder *b, uint8_t *commit
   return AVRF_OK;
 }
 
+// The table of all multiples of this setup's SRS: found in the registry or built (once per device and SRS, ~2 s), sized to the HBM that
+// is free -- the widest window c <= 16 whose table fits min(AVRF_RING_TABLE_GB (default 200), free - 40 GB); no table when even the
+// bucket form's own width does not fit, when AVRF_RING_DIRECT=0, or when the allocation fails (the bucket form then runs as before).
+static void ensure_direct(avrf_ring_setup *su) {
+  if (su->direct_tried || !su->n_srs) return;
+  su->direct_tried = true;
+  if (const char *e = getenv("AVRF_RING_DIRECT")) if (atoi(e) == 0) return;
+  std::lock_guard<std::mutex> lk(g_direct_mu);
+  for (auto it = g_direct.begin(); it != g_direct.end();) {
+    std::shared_ptr<DirectEntry> e = it->lock();
+    if (!e) { it = g_direct.erase(it); continue; }
+    if (e->device == su->device && e->t.curve == su->curve && e->t.n == su->n_srs && e->srs_key == su->g1_raw) { su->direct = e; break; }
+    ++it;
+  }
+  if (!su->direct) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+    double budget_gb = 200.0;
+    if (const char *e = getenv("AVRF_RING_TABLE_GB")) budget_gb = atof(e);
+    const double reserve = 40e9;
+    double usable = (double)free_b - reserve; if (usable > budget_gb * 1e9) usable = budget_gb * 1e9;
+    int c = 0;
+    for (int cc = 16; cc >= su->table_c && cc >= 8; cc--) {
+      G1DirectTable shape;
+      if ((double)g1_direct_table_shape(su->curve, su->n_srs, cc, &shape) <= usable && shape.points < 0x7fffffffull) { c = cc; break; }
+    }
+    if (!c) return;
+    auto e = std::make_shared<DirectEntry>();
+    e->device = su->device; e->srs_key = su->g1_raw;
+    try { build_g1_direct_table(su->curve, su->d_srs, su->n_srs, c, &e->t, su->stream); }
+    catch (const HipFailure &) { (void)hipGetLastError(); return; }         // (the entry's destructor frees what was allocated)
+    g_direct.push_back(e);
+    su->direct = e;
+  }
+  if (su->lane1) { su->lane1->direct = su->direct; su->lane1->direct_tried = true; }
+}
+
 int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const uint8_t *blindings, int blinding_mode, uint8_t *proofs_out) {
   if (!k || (n && (!key_index || !blindings || !proofs_out))) return AVRF_ERR_BAD_ARG;
   if (avrf_ctx_busy_(k->setup->ctx)) return AVRF_ERR_BAD_ARG;
@@ -1758,6 +1809,7 @@ int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const
   if (n >= 32 && n <= 1024) chunk = (n + 1) / 2;
   if (const char *e = getenv("AVRF_RING_CHUNK")) { long v = atol(e); if (v >= 1 && v <= 4096) chunk = (size_t)v; }   // (test hook: re-read per call)
   avrf_ring_setup *su = k->setup;
+  if (n >= 64) if (int st = guarded([&] { ensure_direct(su); return (int)AVRF_OK; })) return st;
   auto run = [&](avrf_ring_setup *lane, size_t i) {
     const size_t m = n - i < chunk ? n - i : chunk;
     return guarded([&] {
