@@ -532,13 +532,8 @@ int batch_seed(avrf_ctx *c, int kind, uint8_t digest[64]) {
     if (host_stream == 1) { HostShake128 h; run(h); } else { HostSha256 h; run(h); }
     return AVRF_OK;
   }
-#ifdef AVRF_EXPERIMENTS   // timing experiment only (tools/gpu_only_rate.py): wrong weights, wrong verdict; never in the shipped build
-  static const bool skip_hash = getenv("AVRF_EXPERIMENT_SKIP_HASH") != nullptr;
-#else
-  constexpr bool skip_hash = false;
-#endif
   WeightJob job; job.prefix = nullptr; job.prefix_len = 0; job.c16 = nullptr; job.resp = nullptr; job.n = n; job.rsz = 0;
-  job.msg = c->h_msg.as<uint8_t>(); job.msg_len = skip_hash ? c->h_msg_len - (n - 1) * (kind == 1 ? 64 : 96) : c->h_msg_len;
+  job.msg = c->h_msg.as<uint8_t>(); job.msg_len = c->h_msg_len;
   WeightHashService &svc = WeightHashService::get();
   if (svc.enabled()) svc.run(job); else weight_digest_scalar(job);
   memcpy(digest, job.digest, 64);
@@ -1236,10 +1231,18 @@ int avrf_secret_from_seed(avrf_ctx *c, size_t n, const uint8_t *seeds, uint8_t *
   HIP_TRY(hipMemsetAsync(c->d_flags.p, 0, 4, c->stream));
   launch_secret_from_seed(c->suite, c->d_misc.as<uint8_t>(), (uint32_t)n, c->d_sks.as<uint8_t>(), c->d_flags.as<uint32_t>(), c->stream);
   HIP_TRY(hipMemcpyAsync(sks_out, c->d_sks.p, n * 32, hipMemcpyDeviceToHost, c->stream));
+  // the reference zeroizes the seed and the intermediate scalar (src/lib.rs:367-368): the seeds are scrubbed from the scratch buffer
+  // behind the kernel, the scalars behind the copy back (d_misc / d_sks are general scratch that later, non-secret calls reuse and
+  // copy from).  sks_out is the caller's to scrub, as `Secret` is the caller's in the reference.
+  HIP_TRY(hipMemsetAsync(c->d_misc.p, 0, n * 32, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_sks.p, 0, n * 32, c->stream));
   int f = read_flags(c);
   if (f < 0) return AVRF_ERR_NO_DEVICE;
   if (f) return AVRF_INVALID_DATA;
-  return pks_xy_out ? smul_common(c, n, sks_out, nullptr, pks_xy_out) : AVRF_OK;
+  if (!pks_xy_out) return AVRF_OK;
+  const int st = smul_common(c, n, sks_out, nullptr, pks_xy_out);          // (uploads the scalars into d_sks again for the base multiplication)
+  if (hipMemsetAsync(c->d_sks.p, 0, n * 32, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return st ? st : (int)AVRF_ERR_NO_DEVICE; }
+  return st;
 }
 int avrf_points_compress(avrf_ctx *c, size_t n, const uint8_t *in_xy, uint8_t *out) {
   if (!c || (n && (!in_xy || !out))) return AVRF_ERR_BAD_ARG;

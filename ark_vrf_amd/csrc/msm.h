@@ -110,8 +110,9 @@ size_t g1_direct_table_shape(int curve, size_t n, int c, G1DirectTable *t);     
 void build_g1_direct_table(int curve, const uint32_t *d_bases, size_t n, int c, G1DirectTable *t, hipStream_t stream);   // allocates t->d, synchronises
 void free_g1_direct_table(G1DirectTable *t);
 // `batch` vectors of n Montgomery-or-plain scalars (vector b starts at element b * scalar_stride) -> `batch` affine results in out_xy
+// (d_base_idx != nullptr: sparse form, as msm_g1_fixed_device's)
 int msm_g1_direct_device(const G1DirectTable &t, const uint32_t *d_scalars, size_t n, size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream,
-                         uint8_t *out_xy, size_t batch, int scalars_mont = 0);
+                         uint8_t *out_xy, size_t batch, int scalars_mont = 0, const uint32_t *d_base_idx = nullptr);
 // n compressed G1 points (FQ_BYTES each, ark-serialize) -> canonical x || y little-endian + ok[i] (0 invalid, 1 point, 2 infinity)
 void launch_g1_decompress(int curve, const uint8_t *d_comp, size_t n, uint8_t *d_out_xy, uint8_t *d_ok, hipStream_t stream);
 void launch_g1_bases(int curve, const uint8_t *d_xy, size_t n, uint32_t *d_out, uint32_t *d_flag, hipStream_t stream);

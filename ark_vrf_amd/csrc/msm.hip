@@ -312,7 +312,6 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
   uint32_t nxt = (b + 1 < nb) ? ow[b + 1] : 0xffffffffu;      // first entry of the next bucket
   const size_t slot0 = (size_t)t + (size_t)v * nb;
   acc_t acc;
-#ifndef AVRF_NO_LDS_PREFETCH
   {
     // Gather pipeline through LDS: the base of entry k + 1 travels HBM -> LDS by DMA (global_load_lds_dwordx4: lane l's 16-byte
     // chunk c lands at chunk c's row + 16 l of the wave's buffer) while the addition of entry k runs, and costs NO registers until
@@ -365,46 +364,6 @@ k_accumulate(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ so
       acc = AC::madd(acc, cur, (cidx & 0x80000000u) != 0);
     }
   }
-#else
-  if (CV::PREFETCH) {
-    // software-pipelined gather, two stages: the index of entry i + 2 and the base of entry i + 1 are in flight while the
-    // addition of entry i runs (with the index only one ahead every iteration waited out the index load before it could even
-    // issue the gather that depends on it: wait_any 21 % of the wave cycles, profiles/r5a_pmc_thin.json)
-    uint32_t idx = sorted[e0];
-    uint32_t idx1 = e0 + 1 < e1 ? sorted[e0 + 1] : 0u;
-    base_t q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS);
-    {                                                          // first entry of every lane: no addition, just the base
-      const uint32_t cidx = idx; const base_t cur = q;
-      idx = idx1;
-      if (e0 + 1 < e1) q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS);
-      if (e0 + 2 < e1) idx1 = sorted[e0 + 2];
-      acc = AC::from_base(cur, (cidx & 0x80000000u) != 0);
-    }
-    for (uint32_t i = e0 + 1; i < e1; i++) {
-      const uint32_t cidx = idx; const base_t cur = q;
-      idx = idx1;
-      if (i + 1 < e1) q = CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS);
-      if (i + 2 < e1) idx1 = sorted[i + 2];
-      if (i >= nxt) {                                          // bucket boundary inside the lane's range
-        AC::store_part(part + (slot0 + b) * AC::PART_WORDS, acc);
-        acc = AC::identity();
-        do { b++; nxt = (b + 1 < nb) ? ow[b + 1] : 0xffffffffu; } while (i >= nxt);
-      }
-      acc = AC::madd(acc, cur, (cidx & 0x80000000u) != 0);
-    }
-  } else {                                                     // 381-bit points: registers are the scarcer resource
-    acc = AC::identity();
-    for (uint32_t i = e0; i < e1; i++) {
-      if (i >= nxt) {
-        AC::store_part(part + (slot0 + b) * AC::PART_WORDS, acc);
-        acc = AC::identity();
-        do { b++; nxt = (b + 1 < nb) ? ow[b + 1] : 0xffffffffu; } while (i >= nxt);
-      }
-      const uint32_t idx = sorted[i];
-      acc = AC::madd(acc, CV::load_base(bases + (size_t)(idx & 0x7fffffffu) * CV::BASE_WORDS), (idx & 0x80000000u) != 0);
-    }
-  }
-#endif
   AC::store_part(part + (slot0 + b) * AC::PART_WORDS, acc);
 }
 
@@ -713,7 +672,6 @@ template <class CV> static AccShape accumulate_shape() {
         if (lds > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       }
     }
-#ifndef AVRF_NO_LDS_PREFETCH
     {   // the gather pipeline's two buffers per wave (k_accumulate): at least that much dynamic LDS; resident workgroups follow
       const unsigned need = 4u * 2u * CV::BASE_WORDS * 64u * 4u;
       if (lds < need) lds = need;
@@ -722,7 +680,6 @@ template <class CV> static AccShape accumulate_shape() {
       HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blk2, k_accumulate<CV>, 256, lds));
       if (blk2 >= 1 && blk2 < blocks) blocks = blk2;
     }
-#endif
     cache[dev] = AccShape{(size_t)cus * blocks * 256, lds};
   }
   return cache[dev];
@@ -1482,7 +1439,9 @@ void free_g1_direct_table(G1DirectTable *t) { if (t->d) (void)hipFree(t->d); t->
 
 constexpr uint32_t DIRECT_ZERO = 0xffffffffu;
 // entry (vector, coefficient i, row w) -> table index | sign << 31 (DIRECT_ZERO for a zero digit); the digits are k_digits' signed recoding
-__global__ void __launch_bounds__(256) k_direct_index(const uint32_t *__restrict__ scalars, uint32_t n, uint32_t stride, G1DirectTable t, uint32_t *__restrict__ idx, int mont) {
+// (base_idx != nullptr: the sparse form -- entry i of vector b multiplies table base base_idx[b * n + i])
+__global__ void __launch_bounds__(256) k_direct_index(const uint32_t *__restrict__ scalars, uint32_t n, uint32_t stride, G1DirectTable t, uint32_t *__restrict__ idx, int mont,
+                                                      const uint32_t *__restrict__ base_idx) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t bat = blockIdx.y, rows = (uint32_t)t.rows, tn = (uint32_t)t.n;
@@ -1500,6 +1459,7 @@ __global__ void __launch_bounds__(256) k_direct_index(const uint32_t *__restrict
     for (int k = 0; k < 8; k++) s[k] = v.v[k];
   }
   uint32_t *o = idx + ((size_t)bat * n + i) * rows;
+  const uint32_t ib = base_idx ? base_idx[(size_t)bat * n + i] : i;
   const uint32_t nb = 1u << (c - 1), mask = (1u << c) - 1;
   uint32_t carry = 0;
   for (uint32_t w = 0; w < rows; w++) {
@@ -1514,7 +1474,7 @@ __global__ void __launch_bounds__(256) k_direct_index(const uint32_t *__restrict
     uint32_t m, sign = 0;
     if (v > nb) { m = (1u << c) - v; sign = 0x80000000u; carry = 1; } else { m = v; carry = 0; }
     // (a scalar below r never asks a row for more than it holds: direct_shape sized the top row and the carry row from r - 1)
-    o[w] = (m == 0 || m > t.mult[w]) ? DIRECT_ZERO : (uint32_t)(t.off[w] + (uint64_t)(m - 1) * tn + i) | sign;
+    o[w] = (m == 0 || m > t.mult[w] || ib >= tn) ? DIRECT_ZERO : (uint32_t)(t.off[w] + (uint64_t)(m - 1) * tn + ib) | sign;
   }
 }
 
@@ -1566,32 +1526,27 @@ k_accumulate_direct(const uint32_t *__restrict__ table, const uint32_t *__restri
   }
   if (t < batch * lpv) AC::store_part(part + (size_t)t * AC::PART_WORDS, acc);
 }
-// one workgroup per vector: the lpv partial sums -> one point (canonical XYZZ for the host, as the bucket form's k_wsum leaves it)
+// one WAVE per vector: lane t sums the partials t, t + 64, .. of its vector one after the other, then the wave's butterfly -- 64 (lpv / 64 + 5)
+// lane-additions per vector instead of the 7 lpv of a lane per partial (the kernel is latency-bound either way; what it does not issue, the
+// other contexts' accumulations do) -> one point (canonical XYZZ for the host, as the bucket form's k_wsum leaves it)
 template <class RV>
-__global__ void __launch_bounds__(256, RV::RED_WAVES)
+__global__ void __launch_bounds__(64, RV::RED_WAVES)
 k_direct_reduce(const uint32_t *__restrict__ part, uint32_t lpv, uint32_t *__restrict__ out) {
   using acc_t = typename RV::acc_t;
-  extern __shared__ uint32_t lds[];                                            // 4 accumulators
-  const uint32_t vec = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const uint32_t vec = blockIdx.x, t = threadIdx.x;
   acc_t a = RV::identity();
 #pragma unroll 1
-  for (uint32_t k = t; k < lpv; k += 256) a = cv_add<RV>(a, RV::accum::load_part(part + ((size_t)vec * lpv + k) * RV::accum::PART_WORDS));
+  for (uint32_t k = t; k < lpv; k += 64) a = cv_add<RV>(a, RV::accum::load_part(part + ((size_t)vec * lpv + k) * RV::accum::PART_WORDS));
   a = wave_sum<RV>(a);
-  if (lane == 0) RV::store_acc(lds + wv * RV::ACC_WORDS, a);
-  __syncthreads();
-  if (t == 0) {
-#pragma unroll 1
-    for (uint32_t w = 1; w < 4; w++) a = cv_add<RV>(a, RV::load_acc(lds + w * RV::ACC_WORDS));
-    RV::store_out(out + (size_t)vec * RV::OUT_WORDS, a);
-  }
+  if (t == 0) RV::store_out(out + (size_t)vec * RV::OUT_WORDS, a);
 }
 template <class C>
 static int msm_g1_direct_impl(const G1DirectTable &t, const uint32_t *d_scalars, size_t n, size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream,
-                              uint8_t *out_xy, size_t batch, int scalars_mont) {
+                              uint8_t *out_xy, size_t batch, int scalars_mont, const uint32_t *d_base_idx) {
   using CV = G1Curve<C>; using RV = typename CV::red; using HG = HostG1<C>;
   if (!n || !batch) return -1;
   const size_t rows = (size_t)t.rows, E = n * rows;
-  if (E * batch >= 0xffff0000ull || n > t.n) throw HipFailure{hipErrorInvalidValue, __FILE__, __LINE__};
+  if (E * batch >= 0xffff0000ull || (!d_base_idx && n > t.n)) throw HipFailure{hipErrorInvalidValue, __FILE__, __LINE__};
   const AccShape shape = accumulate_shape<CV>();
   size_t lpv = shape.lanes / batch; if (lpv > 1024) lpv = 1024; if (lpv < 1) lpv = 1;
   const size_t per = (E + lpv - 1) / lpv, lanes = batch * lpv;
@@ -1604,13 +1559,13 @@ static int msm_g1_direct_impl(const G1DirectTable &t, const uint32_t *d_scalars,
     if (shape.lds > 48 * 1024) HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate_direct<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shape.lds));
   });
   hipLaunchKernelGGL(k_direct_index, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, stream, d_scalars, (uint32_t)n, (uint32_t)(scalar_stride ? scalar_stride : n),
-                     t, ws.sorted, scalars_mont);
+                     t, ws.sorted, scalars_mont, d_base_idx);
   if (!ws.ev0) { HIP_CHECK(hipEventCreate(&ws.ev0)); HIP_CHECK(hipEventCreate(&ws.ev1)); }
   HIP_CHECK(hipEventRecord(ws.ev0, stream));
   hipLaunchKernelGGL(k_accumulate_direct<CV>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), shape.lds, stream, (const uint32_t *)t.d, (const uint32_t *)ws.sorted,
                      (uint32_t)E, (uint32_t)lpv, (uint32_t)per, (uint32_t)batch, ws.part);
   HIP_CHECK(hipEventRecord(ws.ev1, stream));
-  hipLaunchKernelGGL(k_direct_reduce<RV>, dim3((unsigned)batch), dim3(256), 4 * (size_t)RV::ACC_WORDS * 4, stream, (const uint32_t *)ws.part, (uint32_t)lpv, ws.rc);
+  hipLaunchKernelGGL(k_direct_reduce<RV>, dim3((unsigned)batch), dim3(64), 0, stream, (const uint32_t *)ws.part, (uint32_t)lpv, ws.rc);
   HIP_CHECK(hipMemcpyAsync(ws.bits_host, ws.rc, batch * (size_t)RV::OUT_WORDS * 4, hipMemcpyDeviceToHost, stream));
   ws.plan_host[0] = (uint32_t)per;
   ws.pending_plan = p;
@@ -1621,9 +1576,9 @@ static int msm_g1_direct_impl(const G1DirectTable &t, const uint32_t *d_scalars,
   return 0;
 }
 int msm_g1_direct_device(const G1DirectTable &t, const uint32_t *d_scalars, size_t n, size_t scalar_stride, MsmWorkspace &ws, hipStream_t stream,
-                         uint8_t *out_xy, size_t batch, int scalars_mont) {
-  if (t.curve == 0) return msm_g1_direct_impl<G1Bls12381>(t, d_scalars, n, scalar_stride, ws, stream, out_xy, batch, scalars_mont);
-  return msm_g1_direct_impl<G1Bn254>(t, d_scalars, n, scalar_stride, ws, stream, out_xy, batch, scalars_mont);
+                         uint8_t *out_xy, size_t batch, int scalars_mont, const uint32_t *d_base_idx) {
+  if (t.curve == 0) return msm_g1_direct_impl<G1Bls12381>(t, d_scalars, n, scalar_stride, ws, stream, out_xy, batch, scalars_mont, d_base_idx);
+  return msm_g1_direct_impl<G1Bn254>(t, d_scalars, n, scalar_stride, ws, stream, out_xy, batch, scalars_mont, d_base_idx);
 }
 
 int msm_g1_fixed_device(int curve, const uint32_t *d_table, int table_c, size_t table_stride, const uint32_t *d_scalars, size_t n,

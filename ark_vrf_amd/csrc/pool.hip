@@ -40,6 +40,7 @@ struct Slot {
   bool has_batch = false;         // the buffers hold a staged batch (it can be run again without its host sources)
   bool wire = false; int validate = 0;   // the host sources are serialize_compressed bytes (avrf_pool_submit_wire): decompressed on the device while staging
   bool from_host = false;         // stage from the host sources before the run
+  bool resident_invalid = false;  // the staged bytes did not decode / validate (a wire batch): runs from the resident state answer InvalidData again
   uint64_t ticket = 0;
   int status = 0;
   hipEvent_t ev = nullptr;        // behind the prepare kernel's copies back, then behind the MSM chain
@@ -112,6 +113,9 @@ struct Run {
     } else { S.status = status; S.state = S_DONE; }
     P->cv_done.notify_all();
   }
+  // (a wire batch whose points did not decode leaves no usable staged state -- batch_collect drops it -- but the slot still "holds" that
+  // batch: resubmission and cycle mode from the resident state must give the same verdict, not a bad-argument error)
+  static void latch(Slot &S, int status) { if (S.wire && status == AVRF_INVALID_DATA) S.resident_invalid = true; }
 
   void begin(Slot &S) {
     const double t0 = thread_cpu_us();
@@ -119,7 +123,9 @@ struct Run {
     c->stream = W.ingest;
     c->L = &c->own;
     int st = AVRF_OK;
+    if (!S.from_host && S.resident_invalid) { W.cpu_us[0] += thread_cpu_us() - t0; done(S, AVRF_INVALID_DATA); return; }
     if (S.from_host) {
+      S.resident_invalid = false;
       if (S.wire) st = guarded([&] { return ctx_stage_wire(c, P->kind, S.n, S.pks, S.ios, S.io_counts, S.ads, S.ad_lens, S.proofs, S.validate, /*wait=*/false); });
       else st = guarded([&] { return ctx_stage(c, P->kind, S.n, nullptr, S.pks, S.ios, S.io_counts, S.ads, S.ad_lens, S.proofs, /*wait=*/false); });
       S.has_batch = st == AVRF_OK;
@@ -210,7 +216,7 @@ struct Run {
           const double t0 = thread_cpu_us();
           const int st = guarded([&] { return batch_collect(S.c, P->kind); });
           W.cpu_us[1] += thread_cpu_us() - t0;
-          if (st != AVRF_OK) done(S, st); else { S.state = S_READY; ready.push_back(si); }
+          if (st != AVRF_OK) { latch(S, st); done(S, st); } else { S.state = S_READY; ready.push_back(si); }
           progress = true;
         } else { (void)hipGetLastError(); n_begun++; if (!oldest || S.seq < oldest->seq) oldest = &S; }
       }
@@ -335,7 +341,7 @@ static int pool_submit(avrf_pool *P, size_t n, const uint8_t *pks_xy, const uint
     if (best >= 0) {
       Slot &S = P->slots[best];
       S.n = n; S.pks = pks_xy; S.ios = ios_xy; S.io_counts = io_counts; S.ads = ads; S.ad_lens = ad_lens; S.proofs = proofs;
-      S.from_host = true; S.wire = wire; S.validate = validate; S.ticket = P->next_ticket++; S.status = 0;
+      S.from_host = true; S.wire = wire; S.validate = validate; S.resident_invalid = false; S.ticket = P->next_ticket++; S.status = 0;
       S.state = S_SUBMITTED;
       *ticket = S.ticket;
       P->cv_work.notify_all();

@@ -528,7 +528,7 @@ using namespace avrf;
 // of (device, SRS): every setup over the same SRS on a device -- the four contexts bench.py proves with, their second lanes --
 // shares ONE through this registry; the last setup to go frees it.
 struct DirectEntry {
-  G1DirectTable t; int device = 0; std::vector<uint8_t> srs_key;
+  G1DirectTable t; int device = 0, kind = 0; std::vector<uint8_t> srs_key;   // kind 0: the SRS powers, 1: the witness bases derived from them
   ~DirectEntry() { if (t.d) { (void)hipSetDevice(device); free_g1_direct_table(&t); } }
 };
 static std::mutex g_direct_mu;
@@ -539,7 +539,8 @@ struct avrf_ring_setup {
   size_t N, cap, keyset, L, n_srs;                    // n_srs = 0: verifier-only setup (PcsVerifierParams), no SRS on the device
   uint32_t *d_srs = nullptr;                          // n_srs Montgomery affine points
   uint32_t *d_srs_table = nullptr; int table_c = 0, table_nwin = 0;   // fixed-base window table over the SRS (batched commits)
-  std::shared_ptr<DirectEntry> direct; bool direct_tried = false;     // the table of all multiples (large batches of commitments), built on first use
+  std::shared_ptr<DirectEntry> direct, direct_wit; bool direct_tried = false;   // the tables of all multiples (SRS powers; witness bases), built on first use
+  uint32_t *d_wit_bases = nullptr;                    // the 2N + 1 witness bases the tables are built over
   int wit_c = 0, wit_nwin = 0;                        // window width of the witness table (sparse MSMs: few entries, small buckets)
   uint32_t *d_wit_table = nullptr;                    // same over [L_i(tau) G, i < N | prefix sums PS_k = sum_{i<k} L_i(tau) G, k <= N] (witness commits)
   void *host_lines = nullptr; void (*host_lines_free)(void *) = nullptr;   // host Miller-loop line tables of (g2, tau g2), built on first use
@@ -1038,12 +1039,14 @@ template <class S, class G> struct Ring {
     HIP_CHECK(hipMalloc(&su->d_wit_table, (size_t)su->wit_nwin * nb * 2 * FQB));
     build_g1_table(su->curve, d_bases, nb, su->wit_c, su->wit_nwin, su->d_wit_table, su->stream);
     HIP_CHECK(hipStreamSynchronize(su->stream));
-    HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag)); HIP_CHECK(hipFree(d_bases));
+    HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag));
+    su->d_wit_bases = d_bases;
   }
   // `batch` sparse commits over the witness table: vector b = m (base index, plain scalar) pairs
   static void commit_sparse(avrf_ring_setup *su, const uint32_t *d_scalars_plain, const uint32_t *d_base_idx, size_t m, size_t batch, std::vector<G1Aff> &out) {
     std::vector<uint8_t> xy(batch * 2 * FQB);
-    msm_g1_fixed_device(su->curve, su->d_wit_table, su->wit_c, 2 * su->N + 1, d_scalars_plain, m, m, su->ws, su->stream, xy.data(), batch, d_base_idx);
+    if (su->direct_wit && batch >= 32) msm_g1_direct_device(su->direct_wit->t, d_scalars_plain, m, m, su->ws, su->stream, xy.data(), batch, 0, d_base_idx);
+    else msm_g1_fixed_device(su->curve, su->d_wit_table, su->wit_c, 2 * su->N + 1, d_scalars_plain, m, m, su->ws, su->stream, xy.data(), batch, d_base_idx);
     out.resize(batch);
     for (size_t b = 0; b < batch; b++) {
       memset(&out[b], 0, sizeof(G1Aff)); memcpy(out[b].xy, &xy[b * 2 * FQB], 2 * FQB);
@@ -1691,7 +1694,7 @@ size_t avrf_ring_pcs_domain_size(int suite, size_t ring_size) {       /* pcs_dom
 void avrf_ring_setup_free(avrf_ring_setup *su) {
   if (!su) return;
   (void)hipSetDevice(su->device);
-  void *d[] = {su->d_srs, su->d_tw_n, su->d_tw_n_inv, su->d_tw_4n, su->d_tw_4n_inv, su->d_buf, su->d_l4, su->d_srs_table, su->d_wit_table,
+  void *d[] = {su->d_srs, su->d_tw_n, su->d_tw_n_inv, su->d_tw_4n, su->d_tw_4n_inv, su->d_buf, su->d_l4, su->d_srs_table, su->d_wit_table, su->d_wit_bases,
                su->d_scr[0], su->d_scr[1], su->d_scr[2], su->d_scr[3], su->d_scr[4], su->d_scr[5]};
   for (void *p : d) if (p) (void)hipFree(p);
   su->ws.release();
@@ -1715,6 +1718,9 @@ avrf_ring_setup *avrf_ring_key_setup(const avrf_ring_key *key) { return key ? ke
 int avrf_ring_setup_plan(const avrf_ring_setup *su, int32_t out[4]) {
   if (!su || !out) return AVRF_ERR_BAD_ARG;
   out[0] = su->table_c; out[1] = su->table_nwin; out[2] = su->wit_c; out[3] = su->wit_nwin;   // the witness table is built on first proof
+  // once a batched prove call has built the tables of all multiples, those are what the commitments of a batch run over
+  if (su->direct) { out[0] = su->direct->t.c; out[1] = su->direct->t.rows; }
+  if (su->direct_wit) { out[2] = su->direct_wit->t.c; out[3] = su->direct_wit->t.rows; }
   return AVRF_OK;
 }
 
@@ -1759,40 +1765,49 @@ int avrf_ring_vk_builder_finalize(const avrf_ring_vk_builder *b, uint8_t *commit
 }
 
 // The table of all multiples of this setup's SRS: found in the registry or built (once per device and SRS, ~2 s), sized to the HBM that
-// is free -- the widest window c <= 16 whose table fits min(AVRF_RING_TABLE_GB (default 200), free - 40 GB); no table when even the
+// is free -- the widest window c <= 16 whose table fits min(what is left of AVRF_RING_TABLE_GB (default 232, both tables together), free - 40 GB); no table when even the
 // bucket form's own width does not fit, when AVRF_RING_DIRECT=0, or when the allocation fails (the bucket form then runs as before).
 static void ensure_direct(avrf_ring_setup *su) {
   if (su->direct_tried || !su->n_srs) return;
   su->direct_tried = true;
   if (const char *e = getenv("AVRF_RING_DIRECT")) if (atoi(e) == 0) return;
+  with_ring(su->suite, [&](auto r_) { using R_ = typename decltype(r_)::type; R_::ensure_lagrange(su); return 0; });   // the witness bases
   std::lock_guard<std::mutex> lk(g_direct_mu);
-  for (auto it = g_direct.begin(); it != g_direct.end();) {
-    std::shared_ptr<DirectEntry> e = it->lock();
-    if (!e) { it = g_direct.erase(it); continue; }
-    if (e->device == su->device && e->t.curve == su->curve && e->t.n == su->n_srs && e->srs_key == su->g1_raw) { su->direct = e; break; }
-    ++it;
-  }
-  if (!su->direct) {
+  double budget_gb = 232.0;
+  if (const char *e = getenv("AVRF_RING_TABLE_GB")) budget_gb = atof(e);
+  // kind 0 over the SRS powers, then kind 1 over the witness bases with what is left of the budget
+  for (int kind = 0; kind < 2; kind++) {
+    std::shared_ptr<DirectEntry> &slot = kind ? su->direct_wit : su->direct;
+    const size_t nb = kind ? 2 * su->N + 1 : su->n_srs;
+    const uint32_t *bases = kind ? su->d_wit_bases : su->d_srs;
+    const int c_min = kind ? su->wit_c : su->table_c;
+    if (!bases) continue;
+    if (kind) if (const char *e = getenv("AVRF_RING_DIRECT_WIT")) if (atoi(e) == 0) continue;   // (A/B knob: the witness commits stay on the bucket form)
+    for (auto it = g_direct.begin(); it != g_direct.end();) {
+      std::shared_ptr<DirectEntry> e = it->lock();
+      if (!e) { it = g_direct.erase(it); continue; }
+      if (e->device == su->device && e->kind == kind && e->t.curve == su->curve && e->t.n == nb && e->srs_key == su->g1_raw) { slot = e; break; }
+      ++it;
+    }
+    if (slot) { budget_gb -= slot->t.bytes * 1e-9; continue; }
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
-    double budget_gb = 200.0;
-    if (const char *e = getenv("AVRF_RING_TABLE_GB")) budget_gb = atof(e);
-    const double reserve = 40e9;
-    double usable = (double)free_b - reserve; if (usable > budget_gb * 1e9) usable = budget_gb * 1e9;
+    double usable = (double)free_b - 40e9; if (usable > budget_gb * 1e9) usable = budget_gb * 1e9;
     int c = 0;
-    for (int cc = 16; cc >= su->table_c && cc >= 8; cc--) {
+    for (int cc = 16; cc >= c_min && cc >= 8; cc--) {
       G1DirectTable shape;
-      if ((double)g1_direct_table_shape(su->curve, su->n_srs, cc, &shape) <= usable && shape.points < 0x7fffffffull) { c = cc; break; }
+      if ((double)g1_direct_table_shape(su->curve, nb, cc, &shape) <= usable && shape.points < 0x7fffffffull) { c = cc; break; }
     }
-    if (!c) return;
+    if (!c) continue;
     auto e = std::make_shared<DirectEntry>();
-    e->device = su->device; e->srs_key = su->g1_raw;
-    try { build_g1_direct_table(su->curve, su->d_srs, su->n_srs, c, &e->t, su->stream); }
-    catch (const HipFailure &) { (void)hipGetLastError(); return; }         // (the entry's destructor frees what was allocated)
+    e->device = su->device; e->kind = kind; e->srs_key = su->g1_raw;
+    try { build_g1_direct_table(su->curve, bases, nb, c, &e->t, su->stream); }
+    catch (const HipFailure &) { (void)hipGetLastError(); continue; }       // (the entry's destructor frees what was allocated)
     g_direct.push_back(e);
-    su->direct = e;
+    slot = e;
+    budget_gb -= e->t.bytes * 1e-9;
   }
-  if (su->lane1) { su->lane1->direct = su->direct; su->lane1->direct_tried = true; }
+  if (su->lane1) { su->lane1->direct = su->direct; su->lane1->direct_wit = su->direct_wit; su->lane1->direct_tried = true; su->lane1->d_wit_bases = su->d_wit_bases; }
 }
 
 int avrf_ring_prove(avrf_ring_key *k, size_t n, const uint32_t *key_index, const uint8_t *blindings, int blinding_mode, uint8_t *proofs_out) {

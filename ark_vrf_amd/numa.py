@@ -60,10 +60,14 @@ def gpu_pci_addresses(root="/"):
 
 
 def visible_devices(n_total, env=None):
-    """indices (into the unfiltered enumeration) of the devices HIP will show, in HIP's order"""
+    """indices (into the unfiltered enumeration) of the devices HIP will show, in HIP's order: ROCR_VISIBLE_DEVICES filters first (the
+    runtime below HIP), then exactly ONE of HIP_VISIBLE_DEVICES or -- only when that is unset -- its alias CUDA_VISIBLE_DEVICES (a
+    launcher that sets both to the same list must not see the list applied twice)"""
     env = os.environ if env is None else env
     idx = list(range(n_total))
-    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+    hip = env.get("HIP_VISIBLE_DEVICES")
+    second = "HIP_VISIBLE_DEVICES" if (hip is not None and hip.strip() != "") else "CUDA_VISIBLE_DEVICES"
+    for var in ("ROCR_VISIBLE_DEVICES", second):
         v = env.get(var)
         if v is None or v.strip() == "":
             continue

@@ -344,7 +344,9 @@ size_t avrf_ring_commitment_len(const avrf_ring_setup *setup);  /* 144 / 96 */
 int avrf_ring_setup_suite(const avrf_ring_setup *setup);
 avrf_ring_setup *avrf_ring_key_setup(const avrf_ring_key *key);
 /* how the prover's KZG commitments are laid out as fixed-base MSMs (for op counts in reports): out = { window bits and rows of
- * the SRS window table, window bits and rows of the Lagrange-basis witness table (0 until the first proof builds it) } */
+ * the SRS window table, window bits and rows of the Lagrange-basis witness table (0 until the first proof builds it) }.  A prove call of
+ * 64 or more proofs builds, once per device and SRS, the tables of ALL multiples of both base sets in the HBM that is free (DESIGN.md;
+ * AVRF_RING_TABLE_GB, default 232, AVRF_RING_DIRECT=0 to keep the bucket form); from then on the figures are those tables'. */
 int avrf_ring_setup_plan(const avrf_ring_setup *setup, int32_t out[4]);
 
 /* RingSetup::prover_key / verifier_key -> ring_proof::index (src/ring.rs:399-417): fixed columns of the
@@ -421,7 +423,8 @@ size_t avrf_point_len(int suite);
 int avrf_points_decompress(avrf_ctx *ctx, size_t n, const uint8_t *in, uint8_t *out_xy, int validate, int32_t *status_out);
 /* Output::hash::<N> (src/lib.rs:605-609 -> Suite::point_to_hash, src/utils/common.rs:290-305): the VRF output bytes `beta` of n
  * output points, hash_len = N <= 64 bytes each.  Secret::from_seed (src/lib.rs:346-369) for n 32-byte seeds: the secret scalars
- * (LE32) and, when pks_xy_out is not NULL, their public keys (Secret::from_scalar). */
+ * (LE32) and, when pks_xy_out is not NULL, their public keys (Secret::from_scalar).  The device copies of the seeds and scalars are
+ * zeroed before the call returns (the reference zeroizes seed and sk, src/lib.rs:367-368); sks_out is the caller's to scrub. */
 int avrf_output_hash(avrf_ctx *ctx, size_t n, const uint8_t *points_xy, size_t hash_len, uint8_t *out);
 int avrf_secret_from_seed(avrf_ctx *ctx, size_t n, const uint8_t *seeds, uint8_t *sks_out, uint8_t *pks_xy_out);
 int avrf_points_compress(avrf_ctx *ctx, size_t n, const uint8_t *in_xy, uint8_t *out);

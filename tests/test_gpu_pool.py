@@ -218,6 +218,13 @@ def test_pool_wire_ingest(nat, kind):
         assert got[:4] == [0, 0, 1, 2] and got[4] in (0, 1)
         t2 = [pool.resubmit(t, from_host=True) for t in tk[:3]]                      # staged again from the same wire bytes
         assert [pool.wait(t) for t in t2] == [0, 0, 1]
+        # a wire batch with a point that does not decode, run again from the slot's resident state: InvalidData again (not a bad-argument
+        # error: the slot still holds that batch), and again after staging it from the host bytes once more
+        t3 = pool.resubmit(tk[3], from_host=False)
+        assert pool.wait(t3) == 2
+        t4 = pool.resubmit(t3, from_host=True)
+        assert pool.wait(t4) == 2
+        assert pool.wait(pool.resubmit(t4, from_host=False)) == 2
         # a wire batch and an x || y batch side by side in one pool
         from helpers import nat_batch
         ta, tb = pool.submit_wire(good), pool.submit(nat_batch(b))

@@ -46,6 +46,19 @@ def test_device_to_node_and_cpus(tmp_path):
     assert numa.device_numa(0, root, env=env)[0] == "0000:95:00.0" and numa.device_numa(1, root, env=env)[0] == "0000:85:00.0"
 
 
+def test_hip_and_cuda_visible_devices_set_to_the_same_list(tmp_path):
+    """launchers often export HIP_VISIBLE_DEVICES and CUDA_VISIBLE_DEVICES with the same list: HIP reads the CUDA name only when its own is
+    unset, so the list is applied ONCE (applied twice, "4,5,6,7" selects nothing and "1,0" swaps back)"""
+    assert numa.visible_devices(8, {"HIP_VISIBLE_DEVICES": "4,5,6,7", "CUDA_VISIBLE_DEVICES": "4,5,6,7"}) == [4, 5, 6, 7]
+    assert numa.visible_devices(8, {"HIP_VISIBLE_DEVICES": "1,0", "CUDA_VISIBLE_DEVICES": "1,0"}) == [1, 0]
+    assert numa.visible_devices(8, {"CUDA_VISIBLE_DEVICES": "2,3"}) == [2, 3]                       # the alias alone
+    assert numa.visible_devices(8, {"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": "2,3"}) == [2, 3]
+    assert numa.visible_devices(8, {"ROCR_VISIBLE_DEVICES": "4,5,6,7", "HIP_VISIBLE_DEVICES": "1,0", "CUDA_VISIBLE_DEVICES": "3"}) == [5, 4]
+    root = make_tree(tmp_path)
+    pci, node, cpus = numa.device_numa(0, root, {"HIP_VISIBLE_DEVICES": "4,5,6,7", "CUDA_VISIBLE_DEVICES": "4,5,6,7"})
+    assert node == 1 and pci is not None
+
+
 def test_ranks_split_their_socket(tmp_path):
     root = make_tree(tmp_path)
     allowed = set(range(192))

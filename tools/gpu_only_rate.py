@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Experiment: the headline workload with the host weight hash switched off (AVRF_EXPERIMENT_SKIP_HASH=1: wrong weights, the
 verdicts are ignored) -- what the GPU side alone sustains with S contexts.  Tells how far the host hash is from mattering.
-The switch exists only in an experiment build of the library: `make -C ark_vrf_amd/csrc clean all EXTRA=-DAVRF_EXPERIMENTS`
-(rebuild without EXTRA afterwards); against the shipped build this script measures the ordinary pipeline."""
+The switch is NOT in the product source: apply tools/patches/experiment_skip_hash.patch to a scratch copy of the tree and build that
+(`git apply tools/patches/experiment_skip_hash.patch && make -C ark_vrf_amd/csrc EXTRA=-DAVRF_EXPERIMENTS OUT=/tmp/libavrf_exp.so
+OBJDIR=/tmp/obj_exp && git checkout ark_vrf_amd/csrc/capi.hip`, then AVRF_LIB_PATH=/tmp/libavrf_exp.so); against the shipped build this
+script measures the ordinary pipeline."""
 import os
 import sys
 import threading

@@ -14,10 +14,22 @@ acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 os.environ.setdefault("TMPDIR", "/tmp")
 for k, counters in enumerate(passes):
     d = tempfile.mkdtemp(prefix="pmc", dir="/tmp")
-    r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + cmd,
-                       cwd="/tmp", capture_output=True, text=True)
-    if r.returncode != 0:
-        print("pass", k, "failed:", r.stderr[-800:], file=sys.stderr)
+    # every pass under a timeout, in its own process group: a hung workload is killed with the profiler (it must not outlive the pass and
+    # run into the next one's counters); the program after `--` stays the interpreter itself (no shell, no env hop)
+    import signal
+    pr = subprocess.Popen(["rocprofv3", "--kernel-trace", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + cmd,
+                          cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        _, err = pr.communicate(timeout=float(os.environ.get("AVRF_PMC_TIMEOUT", "900")))
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)                      # the exact group this pass started
+        except ProcessLookupError:
+            pass
+        _, err = pr.communicate()
+        err = (err or "") + "\n(timed out: process group killed)"
+    if pr.returncode != 0:
+        print("pass", k, "failed:", (err or "")[-800:], file=sys.stderr)
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").replace("avrf::", "").strip()

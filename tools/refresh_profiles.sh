@@ -16,7 +16,7 @@ SINGLE="python3 $ROOT/bench.py --gpus 1 --slots 1 --lanes 1 --host-threads 1 --h
 PASSES=("FETCH_SIZE" "WRITE_SIZE" "VALUBusy" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "TCC_HIT_sum TCC_MISS_sum")
 stats() {   # name, command...: rocprofv3 --kernel-trace --stats, keep the kernel_stats csv
   name=$1; shift; d=$(mktemp -d /tmp/kt.XXXX)
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o k -- "$@" > $OUT/${R}_$name.log 2>&1 )
+  ( cd /tmp && timeout -k 20 900 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o k -- "$@" > $OUT/${R}_$name.log 2>&1 )
   f=$(find $d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${R}_${name}_kernel_stats.csv
   python3 $ROOT/tools/kstats.py $d | sort -k4 -n -r -t'|' | head -14; rm -rf $d
 }
@@ -31,7 +31,7 @@ d = {"head": head, "profile_command": cmd, **d}
 json.dump(d, open(p, "w"), indent=1)
 PY
 }
-stamp_txt() { sed -i "1i # head $HEAD -- $2" "$1"; }
+stamp_txt() { if [ -s "$1" ]; then sed -i "1i # head $HEAD -- $2" "$1"; else echo "# head $HEAD -- $2 (no output)" > "$1"; fi; }
 for w in $WHAT; do case $w in
   ubench) bash $ROOT/tools/ubench_report.sh > $OUT/${R}_ubench.txt 2>&1; stamp_txt $OUT/${R}_ubench.txt "bash tools/ubench_report.sh"; cp $OUT/${R}_ubench.txt $ROOT/profiles/; tail -30 $OUT/${R}_ubench.txt;;
   single) stats single_context $SINGLE;;
