@@ -223,6 +223,10 @@ def test_bench_whole_path_on_rccl_world_size_one():
     assert m["split_one_batch"]["value"] > 0, m
     assert m["ring_sharded"]["ring_vrf_proofs_per_sec"] > 0 and m["ring_sharded"]["ranks"] == 1, m
     assert out["additional_metrics"]["ring_vrf_batch_verifications_per_sec"] > 0
+    # what a scaling run is judged by: the ranks RCCL itself counted, every rank's own figures, the weak-scaling ring leg
+    assert m["communicator"]["backend"] == "nccl" and m["communicator"]["ranks_counted_by_an_all_reduce_of_ones"] == 1 and m["communicator"]["world_size_torch"] == 1
+    assert len(m["per_rank"]) == 1 and m["per_rank"][0]["value"] > 0 and m["per_rank"][0]["host_cpu_us_per_step"] > 0
+    assert m["ring_sharded_weak"].get("ring_vrf_proofs_per_sec", 0) > 0 and "weak" in m["ring_sharded_weak"]["scaling"], m["ring_sharded_weak"]
 
 
 def test_bench_two_ranks_rehearsal_on_one_gpu():
@@ -247,3 +251,5 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert m["split_one_batch"]["value"] > 0, m
     assert m["ring_sharded"]["ranks"] == 2 and m["ring_sharded"]["ring_vrf_proofs_per_sec"] > 0, m
     assert m["ring_sharded"]["ring_vrf_batch_verifications_per_sec"] > 0 and m["ring_sharded"]["ring_vrf_independent_verifications_per_sec"] > 0
+    assert m["communicator"]["ranks_counted_by_an_all_reduce_of_ones"] == 2 and sorted(r["rank"] for r in m["per_rank"]) == [0, 1]
+    assert all(r["value"] > 0 for r in m["per_rank"]) and m["ring_sharded_weak"].get("ranks") == 2 and m["ring_sharded_weak"]["ring_vrf_proofs_per_sec"] > 0, m["ring_sharded_weak"]

@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <algorithm>
 #include <vector>
+#include "../ark_vrf_amd/csrc/curves.h"      // the shipped mixed additions (bare loops: what the instruction stream itself sustains)
 
 #define PCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return -(int)e_ - 1000; } while (0)
 
@@ -49,6 +50,67 @@ __global__ void __launch_bounds__(64) k_clock(uint64_t *clk, uint64_t spin_ticks
     const uint64_t t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0) { clk[2 * (size_t)s] = t1 - t0; clk[2 * (size_t)s + 1] = r1 - r0; }
   }
+}
+
+// The bare mixed-addition loops of the shipped arithmetic, no memory traffic: WHICH 0 = teu_madd<Bandersnatch> (k_accumulate<TeCurve>'s
+// policy), 1 / 2 = the G1 accumulation policy on BLS12-381 / BN254.  The G1 bases are pseudo-random field elements, not curve points: the
+// addition's instruction path is the same (its exceptional cases -- P = +-Q, identity -- do not occur either way) and only time is measured.
+template <int WHICH> __global__ void __launch_bounds__(256, 2) k_madd_loop(uint32_t *out, const uint32_t *bases, int iters, uint32_t seed) {
+  using namespace avrf;
+  const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+  if constexpr (WHICH == 0) {
+    using S = SuiteBandersnatch; using Fq = typename S::Fq;
+    te_pre g, b;
+    g.x = fp_const<Fq>(S::G_X); g.y = fp_const<Fq>(S::G_Y); g.k = fp_const<Fq>(S::G_K);
+    b.x = fp_const<Fq>(S::B_X); b.y = fp_const<Fq>(S::B_Y); b.k = fp_const<Fq>(S::B_K);
+    te_acc_u<S> p = teu_identity<S>();
+    for (int i = 0; i < iters; i++) {
+      const bool neg = ((lane * 2654435761u + i * 40503u + seed) >> 13) & 1;
+      const te_pre q = ((lane + i) & 2) ? g : b;
+      p = teu_madd<S>(p, q, neg);
+    }
+    const te_ext r = teu_to_ext<S>(p);
+    uint32_t x = 0;
+    for (int i = 0; i < 8; i++) x ^= r.x.v[i] ^ r.y.v[i] ^ r.t.v[i] ^ r.z.v[i];
+    out[lane] = x;
+  } else {
+    using C = typename std::conditional<WHICH == 1, G1Bls12381, G1Bn254>::type;
+    using CV = G1Curve<C>; using AC = typename CV::accum; constexpr int N = C::Fq::N;
+    // (the bases come from a small table in memory, as in the accumulation kernels: two bases held in registers beside the 256-register
+    // addition spilled and halved the rate)
+    typename AC::acc_t p = AC::from_base(CV::load_base(bases), false);
+    for (int i = 0; i < iters; i++) {
+      const uint32_t h = lane * 2654435761u + i * 40503u + seed;
+      p = AC::madd(p, CV::load_base(bases + (size_t)((h >> 3) & 63u) * 2 * N), (h >> 13) & 1);
+    }
+    alignas(16) uint32_t tmp[AC::PART_WORDS];
+    AC::store_part(tmp, p);
+    uint32_t x = 0;
+    for (int i = 0; i < AC::PART_WORDS; i++) x ^= tmp[i];
+    out[lane] = x;
+  }
+}
+template <int WHICH> static int run_madd_loop(int device, int blocks_per_cu, int iters, int reps, double *out) {
+  PCK(hipSetDevice(device));
+  hipDeviceProp_t prop; PCK(hipGetDeviceProperties(&prop, device));
+  const int cus = prop.multiProcessorCount, blocks = cus * blocks_per_cu;
+  uint32_t *d_out, *d_bases; PCK(hipMalloc(&d_out, (size_t)blocks * 256 * 4));
+  std::vector<uint32_t> hb(64 * 24);                                      // 64 pseudo-random "points": field elements below 2^(32 N - 8)
+  for (size_t i = 0; i < hb.size(); i++) hb[i] = (uint32_t)(0x9e3779b9u * (i + 1) + 0x85ebca6bu * (i >> 3)) & ((i % 12 == 11 || i % 8 == 7) ? 0x00ffffffu : 0xffffffffu);
+  PCK(hipMalloc(&d_bases, hb.size() * 4)); PCK(hipMemcpy(d_bases, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1; PCK(hipEventCreate(&e0)); PCK(hipEventCreate(&e1));
+  double best_ms = 1e30;
+  for (int r = 0; r < reps + 1; r++) {
+    PCK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_madd_loop<WHICH>, dim3(blocks), dim3(256), 0, 0, d_out, (const uint32_t *)d_bases, iters, 777u + r);
+    PCK(hipEventRecord(e1, 0)); PCK(hipEventSynchronize(e1));
+    float ms; PCK(hipEventElapsedTime(&ms, e0, e1));
+    if (r && ms < best_ms) best_ms = ms;
+  }
+  out[0] = (double)blocks * 256.0 * iters / (best_ms * 1e-3) * 1e-9;       // G mixed additions / s
+  out[1] = best_ms; out[2] = blocks_per_cu; out[3] = iters;
+  hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d_out); hipFree(d_bases);
+  return 0;
 }
 
 static double median_mhz(std::vector<uint64_t> &h, double wall_khz) {
@@ -92,6 +154,13 @@ extern "C" {
 // out[6] = {T lane-ops/s, measured shader MHz, best launch ms, CUs, runtime-reported MHz, lane-ops/clk/CU at the measured clock}
 int avrf_probe_mad_stream(int device, int waves_per_cu, int iters, int reps, double *out) { return run_stream<0>(device, waves_per_cu, iters, reps, out); }
 int avrf_probe_valu_stream(int device, int waves_per_cu, int iters, int reps, double *out) { return run_stream<1>(device, waves_per_cu, iters, reps, out); }
+// out[4] = {G mixed additions/s, best launch ms, workgroups of 256 per CU, iterations}; which: 0 twisted Edwards (Bandersnatch), 1 G1 BLS12-381, 2 G1 BN254
+int avrf_probe_madd_loop(int device, int which, int blocks_per_cu, int iters, int reps, double *out) {
+  if (which == 0) return run_madd_loop<0>(device, blocks_per_cu, iters, reps, out);
+  if (which == 1) return run_madd_loop<1>(device, blocks_per_cu, iters, reps, out);
+  if (which == 2) return run_madd_loop<2>(device, blocks_per_cu, iters, reps, out);
+  return -1;
+}
 // one wave on its own (non-blocking) stream: `count` samples of spin_us microseconds each, back to back; mhz[count] = the shader clock of
 // every sample (the wave sleeps between its reads of the two counters: it takes no issue slots worth mentioning from what runs beside it)
 int avrf_probe_clock_series(int device, double spin_us, uint32_t count, double *mhz) {
