@@ -707,7 +707,7 @@ template <class S, class G> struct Ring {
     HIP_CHECK(hipSetDevice(su->device));
     uint8_t *d_le; uint32_t *d_flag; uint32_t flag = 0;
     HIP_CHECK(hipMalloc(&d_le, le.size())); HIP_CHECK(hipMalloc(&d_flag, 4)); HIP_CHECK(hipMalloc(&su->d_srs, pcs * e1));
-    HIP_CHECK(hipMemcpy(d_le, le.data(), le.size(), hipMemcpyHostToDevice)); HIP_CHECK(hipMemset(d_flag, 0, 4));
+    HIP_CHECK(hipMemcpyAsync(d_le, le.data(), le.size(), hipMemcpyHostToDevice, su->stream)); HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream));   // (in stream order with the kernel: the null stream does not order with a non-blocking one)
     launch_g1_bases(su->curve, d_le, pcs, su->d_srs, d_flag, su->stream);
     HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, su->stream)); HIP_CHECK(hipStreamSynchronize(su->stream));
     HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag));
@@ -832,8 +832,8 @@ template <class S, class G> struct Ring {
     uint8_t *d_le; uint32_t *d_flag, *d_base, *d_table, *d_sc; uint32_t flag = 0;
     HIP_CHECK(hipMalloc(&d_le, e1)); HIP_CHECK(hipMalloc(&d_flag, 4)); HIP_CHECK(hipMalloc(&d_base, e1));
     HIP_CHECK(hipMalloc(&d_table, (size_t)nwin * e1)); HIP_CHECK(hipMalloc(&d_sc, n_g1 * 32));
-    HIP_CHECK(hipMemcpy(d_le, le, e1, hipMemcpyHostToDevice)); HIP_CHECK(hipMemset(d_flag, 0, 4));
-    HIP_CHECK(hipMemcpy(d_sc, pw.data(), n_g1 * 32, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpyAsync(d_le, le, e1, hipMemcpyHostToDevice, stream)); HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, stream));   // (stream-ordered with the kernels below)
+    HIP_CHECK(hipMemcpyAsync(d_sc, pw.data(), n_g1 * 32, hipMemcpyHostToDevice, stream));
     launch_g1_bases(pairing_curve_of(S::ID), d_le, 1, d_base, d_flag, stream);
     HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, stream)); HIP_CHECK(hipStreamSynchronize(stream));
     int st = AVRF_OK;
@@ -1031,7 +1031,7 @@ template <class S, class G> struct Ring {
     HG::to_affine_bytes_batch(ps.data(), N + 1, &le[N * 2 * FQB]);
     uint8_t *d_le; uint32_t *d_flag, *d_bases;
     HIP_CHECK(hipMalloc(&d_le, le.size())); HIP_CHECK(hipMalloc(&d_flag, 4)); HIP_CHECK(hipMalloc(&d_bases, nb * 2 * FQB));
-    HIP_CHECK(hipMemcpy(d_le, le.data(), le.size(), hipMemcpyHostToDevice)); HIP_CHECK(hipMemset(d_flag, 0, 4));
+    HIP_CHECK(hipMemcpyAsync(d_le, le.data(), le.size(), hipMemcpyHostToDevice, su->stream)); HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream));
     launch_g1_bases(su->curve, d_le, nb, d_bases, d_flag, su->stream);
     su->wit_c = 7;
     if (const char *e = getenv("AVRF_RING_WIT_C")) { int v = atoi(e); if (v >= 4 && v <= 14) su->wit_c = v; }
