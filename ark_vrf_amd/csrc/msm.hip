@@ -686,11 +686,20 @@ template <class CV> static AccShape accumulate_shape() {
 }
 template <class CV> static size_t accumulate_lanes() { return accumulate_shape<CV>().lanes; }
 
-template <class T> static void grow(T *&p, size_t &cap, size_t need, size_t elem) {
+// AVRF_MSM_POISON=1 (debugging): fresh workspace memory is filled with 0xA5 bytes, so that a kernel that reads what no kernel wrote fails
+// every time instead of depending on what the allocator hands back
+static bool msm_poison() { static const bool on = getenv("AVRF_MSM_POISON") != nullptr; return on; }
+static void poison(void *p, size_t bytes, int which) {
+  if (!msm_poison() || !p) return;
+  if (const char *e = getenv("AVRF_MSM_POISON_SKIP")) { if (atoi(e) == which) return; }
+  HIP_CHECK(hipMemset(p, 0xA5, bytes)); if (!getenv("AVRF_MSM_POISON_NOSYNC")) HIP_CHECK(hipDeviceSynchronize());
+}
+template <class T> static void grow(T *&p, size_t &cap, size_t need, size_t elem, int which = 0) {
   if (need <= cap) return;
   if (p) HIP_CHECK(hipFree(p));
   p = nullptr; cap = 0;
   HIP_CHECK(hipMalloc(&p, need * elem + 64));
+  poison(p, need * elem + 64, which);
   cap = need;
 }
 
@@ -704,15 +713,17 @@ void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t b
     if (sorted) HIP_CHECK(hipFree(sorted));
     keys = nullptr; sorted = nullptr; cap_n = 0;
     HIP_CHECK(hipMalloc(&keys, need_n * 2 + 16)); HIP_CHECK(hipMalloc(&sorted, need_n * 4 + 16));
+    poison(keys, need_n * 2 + 16, 1); poison(sorted, need_n * 4 + 16, 2);
     cap_n = need_n;
   }
-  grow(hist, cap_hist, nbk * ntiles, 4);
+  grow(hist, cap_hist, nbk * ntiles, 4, 3);
   if (nbk > cap_slots) {
     if (cnts) HIP_CHECK(hipFree(cnts));
     if (offsets) HIP_CHECK(hipFree(offsets));
     if (heavy) HIP_CHECK(hipFree(heavy));
     cnts = offsets = heavy = nullptr; cap_slots = 0;
     HIP_CHECK(hipMalloc(&cnts, nbk * 4)); HIP_CHECK(hipMalloc(&offsets, nbk * 4)); HIP_CHECK(hipMalloc(&heavy, nbk * 4));
+    poison(cnts, nbk * 4, 4); poison(offsets, nbk * 4, 5); poison(heavy, nbk * 4, 6);
     cap_slots = nbk;
   }
   if (vwin > cap_vwin) {
@@ -720,6 +731,7 @@ void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t b
     if (lane_base) HIP_CHECK(hipFree(lane_base));
     win_tot = lane_base = nullptr; cap_vwin = 0;
     HIP_CHECK(hipMalloc(&win_tot, (vwin + 64) * 4)); HIP_CHECK(hipMalloc(&lane_base, (vwin + 64) * 4));
+    poison(win_tot, (vwin + 64) * 4, 7); poison(lane_base, (vwin + 64) * 4, 8);
     cap_vwin = vwin;
   }
   if (!plan_dev) { HIP_CHECK(hipMalloc(&plan_dev, 64)); HIP_CHECK(hipHostMalloc(&plan_host, 64)); plan_host[0] = plan_host[1] = 0; }
@@ -729,14 +741,16 @@ void MsmWorkspace::ensure(size_t n, const MsmPlan &p, size_t acc_bytes, size_t b
     buckets = rc = nullptr; cap_buckets = 0;
     HIP_CHECK(hipMalloc(&buckets, nbk * acc_bytes));
     HIP_CHECK(hipMalloc(&rc, nbk * acc_bytes));               // >= nwin * (NR + NC)
+    poison(buckets, nbk * acc_bytes, 9); poison(rc, nbk * acc_bytes, 10);
     cap_buckets = nbk * acc_bytes;
   }
-  grow(part, cap_part, (lanes_max + nbk + 64) * (part_bytes ? part_bytes : acc_bytes), 1);
+  grow(part, cap_part, (lanes_max + nbk + 64) * (part_bytes ? part_bytes : acc_bytes), 1, 11);
   if (nbits * acc_bytes > cap_bits) {
     if (bits) HIP_CHECK(hipFree(bits));
     if (bits_host) HIP_CHECK(hipHostFree(bits_host));
     bits = bits_host = nullptr; cap_bits = 0;
     HIP_CHECK(hipMalloc(&bits, nbits * acc_bytes));
+    poison(bits, nbits * acc_bytes, 12);
     HIP_CHECK(hipHostMalloc(&bits_host, nbits * acc_bytes));
     cap_bits = nbits * acc_bytes;
   }
@@ -1151,14 +1165,18 @@ k_g1_table(const uint32_t *__restrict__ bases, uint32_t n, int c, int nwin, uint
 void build_g1_table(int curve, const uint32_t *d_bases, size_t n, int c, int nwin, uint32_t *d_table, hipStream_t stream) {
   if (!n) return;
   const size_t fqn = curve == 0 ? G1Bls12381::Fq::N : G1Bn254::Fq::N;
-  // scratch from the stream-ordered pool: no device-wide synchronisation (hipFree stalls every other context in flight), and the
-  // build stays asynchronous -- callers synchronise the stream when they need the table
+  // Plain scratch, the stream waited for, then freed: setup-time work.  (Until round 6 the scratch came from the stream-ordered pool --
+  // hipMallocAsync / hipFreeAsync -- so that the build stayed asynchronous.  Next to the synchronous hipMalloc / hipFree of the MSM
+  // workspaces that was a race: after two setups on two streams the first batched commitment of avrf_ring_srs_generate returned the
+  // point at infinity for its first vector, every time, and not with HIP_LAUNCH_BLOCKING=1 or a device synchronisation in between
+  // (tests/test_gpu_ring.py::test_srs_generate caught it once an unrelated null-stream hipMemset, which had been hiding it, went away).)
   uint32_t *tmp = nullptr;
-  HIP_CHECK(hipMallocAsync((void **)&tmp, (size_t)nwin * n * 3 * fqn * 4, stream));
+  HIP_CHECK(hipMalloc((void **)&tmp, (size_t)nwin * n * 3 * fqn * 4));
   dim3 g((unsigned)((n + 63) / 64)), b(64);
   if (curve == 0) hipLaunchKernelGGL(k_g1_table<G1Bls12381>, g, b, 0, stream, d_bases, (uint32_t)n, c, nwin, d_table, tmp);
   else hipLaunchKernelGGL(k_g1_table<G1Bn254>, g, b, 0, stream, d_bases, (uint32_t)n, c, nwin, d_table, tmp);
-  HIP_CHECK(hipFreeAsync(tmp, stream));
+  HIP_CHECK(hipStreamSynchronize(stream));
+  HIP_CHECK(hipFree(tmp));
 }
 
 template <class C>

@@ -20,6 +20,8 @@
 #include "pairing.h"
 #include "suite_dispatch.h"
 #include "host_shake128.h"
+#include "host_sha512.h"
+#include "host_sha256.h"
 #include "host_pool.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -707,7 +709,7 @@ template <class S, class G> struct Ring {
     HIP_CHECK(hipSetDevice(su->device));
     uint8_t *d_le; uint32_t *d_flag; uint32_t flag = 0;
     HIP_CHECK(hipMalloc(&d_le, le.size())); HIP_CHECK(hipMalloc(&d_flag, 4)); HIP_CHECK(hipMalloc(&su->d_srs, pcs * e1));
-    HIP_CHECK(hipMemcpyAsync(d_le, le.data(), le.size(), hipMemcpyHostToDevice, su->stream)); HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream));   // (in stream order with the kernel: the null stream does not order with a non-blocking one)
+    HIP_CHECK(hipMemcpy(d_le, le.data(), le.size(), hipMemcpyHostToDevice)); HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream));   // (the flag reset in stream order with the kernel: the null stream does not order with a non-blocking one)
     launch_g1_bases(su->curve, d_le, pcs, su->d_srs, d_flag, su->stream);
     HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, su->stream)); HIP_CHECK(hipStreamSynchronize(su->stream));
     HIP_CHECK(hipFree(d_le)); HIP_CHECK(hipFree(d_flag));
@@ -810,6 +812,94 @@ template <class S, class G> struct Ring {
     return AVRF_OK;
   }
 
+  // ---- RingSetup::from_seed (src/ring.rs:359-366) as the reference derives it: S::Transcript::new(SUITE_ID), absorb_raw(seed),
+  // to_rng() (src/utils/transcript.rs:61-92: every draw is the next bytes of the squeeze stream), then Kzg::setup(pcs_domain_size - 1,
+  // rng) = w3f-pcs URS::generate: tau = Fr::rand, g1 = G1::rand, g2 = G2::rand, powers tau^i g1 / g2.  **UNPINNED**: the reference holds
+  // no vector of a seeded setup; the draw order and the samplers are restated from the published code of ark-ff
+  // (Fp::rand: N x next_u64 limbs, top limb masked to the modulus' bits, taken AS the Montgomery representation, rejected if >= p;
+  // Fp2: c0 then c1), ark-ec (Projective::rand: x = BaseField::rand, greatest = next_u32's top bit, the larger / smaller root by the
+  // field's Ord, times the cofactor) and rand 0.8, and checked against oracle/ring_py.py srs_from_seed, which restates the same.
+  struct SeedStream {
+    std::vector<uint8_t> buf; size_t pos = 0; uint8_t dig[64]; uint64_t blk = 0;
+    const uint8_t *absorbed; size_t absorbed_len;
+    void more(size_t n) {
+      if constexpr (S::XOF_SHAKE) { HostShake128 h; h.update(absorbed, absorbed_len); buf.resize(pos + n + 4096); h.squeeze_copy(buf.data(), buf.size()); }
+      else if constexpr (S::TR_SHA256) { HostSha256 h; h.update(absorbed, absorbed_len); buf.resize(pos + n + 4096); h.squeeze_copy(buf.data(), buf.size()); }
+      else {                                                           // DigestXof over SHA-512: d = H(absorbed), block_i = H(d || LE64(i))
+        if (!blk && buf.empty()) { HostSha512 h; h.update(absorbed, absorbed_len); h.final(dig); }
+        while (buf.size() < pos + n) { HostSha512 h; h.update(dig, 64); uint8_t c[8]; for (int i = 0; i < 8; i++) c[i] = (uint8_t)(blk >> (8 * i)); h.update(c, 8);
+          uint8_t o[64]; h.final(o); buf.insert(buf.end(), o, o + 64); blk++; }
+      }
+    }
+    void take(uint8_t *out, size_t n) { if (pos + n > buf.size()) more(n); memcpy(out, buf.data() + pos, n); pos += n; }
+    bool boolean() { uint8_t b[4]; take(b, 4); return (b[3] & 0x80) != 0; }                     // (rng.next_u32() as i32) < 0
+    template <int L, int BITS> void field(uint64_t *v, const uint64_t *p) {                     // ark-ff Fp::rand: the limbs ARE the Montgomery form
+      for (;;) {
+        uint8_t b[8 * L]; take(b, sizeof b); memcpy(v, b, sizeof b);
+        constexpr int shave = 64 * L - BITS;
+        if (shave) v[L - 1] &= ~(uint64_t)0 >> shave;
+        bool less = false;
+        for (int i = L - 1; i >= 0; i--) if (v[i] != p[i]) { less = v[i] < p[i]; break; }
+        if (less) return;
+      }
+    }
+  };
+  static int setup_from_seed(avrf_ctx *ctx, const uint8_t seed[32], size_t ring_size, avrf_ring_setup **out) {
+    using HP = HostPairing<G>; using HG = typename T::HG;
+    std::vector<uint8_t> ab(S::SUITE_ID, S::SUITE_ID + S::SUITE_ID_LEN); ab.insert(ab.end(), seed, seed + 32);
+    SeedStream st; st.absorbed = ab.data(); st.absorbed_len = ab.size();
+    // tau = Fr::rand: the drawn limbs are tau's Montgomery form
+    H256 tau_m; { const H256 pr = Fr::P(); st.template field<4, G::Fr::BITS>(tau_m.l, pr.l); }
+    const H256 tau = Fr::from_mont(tau_m);
+    uint8_t tau_le[32]; memcpy(tau_le, tau.l, 32);
+    // g1 = G1::rand: first x with x^3 + b a square, the root picked by `greatest`, times the cofactor
+    std::vector<uint8_t> g1_urs, g2_urs(4 * FQB);
+    for (;;) {
+      const QEl pq = FqN::P(); QEl xm; st.template field<FqN::L, G::Fq::BITS>(xm.l, pq.l);
+      const bool greatest = st.boolean();
+      const QEl rhs = FqN::add(FqN::mul(FqN::sqr(xm), xm), FqN::from32(G::B));
+      static const QEl e = [] { QEl v = FqN::P(), one = FqN::zero(); one.l[0] = 1; FqN::addc(v, v, one);   // (p + 1) / 4
+                                for (int k = 0; k < 2; k++) for (int i = 0; i < FqN::L; i++) v.l[i] = (v.l[i] >> 1) | (i + 1 < FqN::L ? v.l[i + 1] << 63 : 0);
+                                return v; }();
+      QEl y = FqN::one();
+      for (int i = 64 * FqN::L - 1; i >= 0; i--) { y = FqN::sqr(y); if ((e.l[i / 64] >> (i % 64)) & 1) y = FqN::mul(y, rhs); }
+      if (!FqN::eq(FqN::sqr(y), rhs)) continue;
+      QEl t; const QEl yp = FqN::from_mont(y), half = FqN::from32(G::Fq::HALF);
+      const bool is_larger = FqN::subb(t, half, yp) != 0;                                       // y > (p - 1) / 2  <=>  y > -y
+      if (is_larger != greatest) y = FqN::neg(y);
+      typename HG::Pt pt; pt.x = xm; pt.y = y; pt.zz = FqN::one(); pt.zzz = FqN::one();
+      static const uint64_t COF_BLS[2] = {0x8c00aaab0000aaabULL, 0x396c8c005555e156ULL};
+      typename HG::Pt acc = HG::identity();
+      if (FQB == 48) { for (int i = 127; i >= 0; i--) { acc = HG::dbl(acc); if ((COF_BLS[i / 64] >> (i % 64)) & 1) acc = HG::add(acc, pt); } }
+      else acc = pt;                                                                            // BN254: cofactor 1
+      G1Aff a; memset(&a, 0, sizeof a); HG::to_affine_bytes(acc, a.xy); a.inf = false;
+      g1_encode<G>(a, false, g1_urs);
+      break;
+    }
+    // g2 = G2::rand on the twist: x = (c0, c1), the root by the (c1, c0) order, times the cofactor
+    for (;;) {
+      const QEl pq = FqN::P(); typename HP::F2 x; st.template field<FqN::L, G::Fq::BITS>(x.a.l, pq.l); st.template field<FqN::L, G::Fq::BITS>(x.b.l, pq.l);
+      const bool greatest = st.boolean();
+      typename HP::F2 y;
+      if (!HP::f2_sqrt(HP::f2_add(HP::f2_mul(HP::f2_sqr(x), x), HP::twist_b()), &y)) continue;
+      if (HP::f2_is_largest(y) != greatest) y = HP::f2_neg(y);
+      typename HP::G2 q; q.x = x; q.y = y; q.inf = false;
+      static const uint64_t COF2_BLS[8] = {0xcf1c38e31c7238e5ULL, 0x1616ec6e786f0c70ULL, 0x21537e293a6691aeULL, 0xa628f1cb4d9e82efULL,
+                                           0xa68a205b2e5a7ddfULL, 0xcd91de4547085abaULL, 0x091d50792876a202ULL, 0x05d543a95414e7f1ULL};
+      static const uint64_t COF2_BN[4] = {0x345f2299c0f9fa8dULL, 0x06ceecda572a2489ULL, 0xb85045b68181585eULL, 0x30644e72e131a029ULL};
+      const uint64_t *cof = FQB == 48 ? COF2_BLS : COF2_BN; const int cbits = FQB == 48 ? 512 : 256;
+      typename HP::G2 acc; acc.inf = true; acc.x = HP::f2_zero(); acc.y = HP::f2_zero();
+      for (int i = cbits - 1; i >= 0; i--) { acc = HP::g2_dbl(acc); if ((cof[i / 64] >> (i % 64)) & 1) acc = HP::g2_add(acc, q); }
+      HP::g2_encode(acc, g2_urs.data());
+      break;
+    }
+    const size_t n_g1 = avrf_ring_pcs_domain_size(S::ID, ring_size);
+    std::vector<uint8_t> srs(8 + n_g1 * 2 * FQB + 8 + 2 * 4 * FQB);
+    size_t len = 0;
+    if (int e = srs_generate(ctx, tau_le, g1_urs.data(), g2_urs.data(), n_g1, srs.data(), srs.size(), &len)) return e;
+    return setup_load(ctx, srs.data(), len, ring_size, out);
+  }
+
   // ---- Kzg::setup (reached from RingSetup::from_rand / from_seed, src/ring.rs:359-374) with the trapdoor and the two
   // generators given explicitly: writes `URS { powers_in_g1: tau^i g1 (i < n_g1), powers_in_g2: [g2, tau g2] }` in the
   // serialize_uncompressed layout that setup_load reads.  The n_g1 fixed-base multiplications are ONE batched table MSM.
@@ -832,8 +922,8 @@ template <class S, class G> struct Ring {
     uint8_t *d_le; uint32_t *d_flag, *d_base, *d_table, *d_sc; uint32_t flag = 0;
     HIP_CHECK(hipMalloc(&d_le, e1)); HIP_CHECK(hipMalloc(&d_flag, 4)); HIP_CHECK(hipMalloc(&d_base, e1));
     HIP_CHECK(hipMalloc(&d_table, (size_t)nwin * e1)); HIP_CHECK(hipMalloc(&d_sc, n_g1 * 32));
-    HIP_CHECK(hipMemcpyAsync(d_le, le, e1, hipMemcpyHostToDevice, stream)); HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, stream));   // (stream-ordered with the kernels below)
-    HIP_CHECK(hipMemcpyAsync(d_sc, pw.data(), n_g1 * 32, hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemcpy(d_le, le, e1, hipMemcpyHostToDevice)); HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, stream));   // (the flag reset in stream order with the kernel that sets it)
+    HIP_CHECK(hipMemcpy(d_sc, pw.data(), n_g1 * 32, hipMemcpyHostToDevice));
     launch_g1_bases(pairing_curve_of(S::ID), d_le, 1, d_base, d_flag, stream);
     HIP_CHECK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, stream)); HIP_CHECK(hipStreamSynchronize(stream));
     int st = AVRF_OK;
@@ -1031,7 +1121,7 @@ template <class S, class G> struct Ring {
     HG::to_affine_bytes_batch(ps.data(), N + 1, &le[N * 2 * FQB]);
     uint8_t *d_le; uint32_t *d_flag, *d_bases;
     HIP_CHECK(hipMalloc(&d_le, le.size())); HIP_CHECK(hipMalloc(&d_flag, 4)); HIP_CHECK(hipMalloc(&d_bases, nb * 2 * FQB));
-    HIP_CHECK(hipMemcpyAsync(d_le, le.data(), le.size(), hipMemcpyHostToDevice, su->stream)); HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream));
+    HIP_CHECK(hipMemcpy(d_le, le.data(), le.size(), hipMemcpyHostToDevice)); HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, su->stream));
     launch_g1_bases(su->curve, d_le, nb, d_bases, d_flag, su->stream);
     su->wit_c = 7;
     if (const char *e = getenv("AVRF_RING_WIT_C")) { int v = atoi(e); if (v >= 4 && v <= 14) su->wit_c = v; }
@@ -1685,6 +1775,12 @@ int avrf_ring_srs_generate(avrf_ctx *ctx, const uint8_t *tau, const uint8_t *g1,
   if (!ctx || !tau || !g1 || !g2 || !ring_suite(avrf_ctx_suite_(ctx))) return AVRF_ERR_BAD_ARG;
   if (avrf_ctx_busy_(ctx)) return AVRF_ERR_BAD_ARG;
   return guarded([&] { return with_ring(avrf_ctx_suite_(ctx), [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::srs_generate(ctx, tau, g1, g2, n_g1, out, out_cap, out_len); }); });
+}
+int avrf_ring_setup_from_seed(avrf_ctx *ctx, const uint8_t *seed, size_t ring_size, avrf_ring_setup **out) {
+  if (!ctx || !seed || !out || !ring_suite(avrf_ctx_suite_(ctx))) return AVRF_ERR_BAD_ARG;
+  if (avrf_ctx_busy_(ctx)) return AVRF_ERR_BAD_ARG;
+  *out = nullptr;
+  return guarded([&] { return with_ring(avrf_ctx_suite_(ctx), [&](auto r_) { using R_ = typename decltype(r_)::type; return R_::setup_from_seed(ctx, seed, ring_size, out); }); });
 }
 size_t avrf_ring_pcs_domain_size(int suite, size_t ring_size) {       /* pcs_domain_size, src/ring.rs:810-817: 3 * piop_domain + 1 */
   const size_t L = with_suite(suite, [&](auto tag) { using S = typename decltype(tag)::type; return (size_t)S::Fr::BITS; });

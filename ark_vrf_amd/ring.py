@@ -37,16 +37,22 @@ class RingKey:
 
 
 class RingSetup:
-    def __init__(self, ctx, srs_bytes, ring_size, verifier_only=False):
+    def __init__(self, ctx, srs_bytes, ring_size, verifier_only=False, seed=None):
         """srs_bytes: the URS (RingSetup / PcsParams, either ark-serialize mode); with verifier_only=True the serialised
-        PcsVerifierParams (g1, g2, tau g2) instead -- a setup that verifies but holds no SRS (src/ring.rs:466-482)."""
+        PcsVerifierParams (g1, g2, tau g2) instead -- a setup that verifies but holds no SRS (src/ring.rs:466-482);
+        seed (32 bytes, srs_bytes None): RingSetup::from_seed (src/ring.rs:359-366, avrf_ring_setup_from_seed)."""
         L = nat.lib()
         for f in ("avrf_ring_max_ring_size", "avrf_ring_domain_size", "avrf_ring_proof_len", "avrf_ring_commitment_len"):
             getattr(L, f).restype = C.c_size_t
         self.ctx = ctx
         self._h = C.c_void_p()
-        fn = "avrf_ring_verifier_setup_load" if verifier_only else "avrf_ring_setup_load"
-        st = getattr(L, fn)(ctx._h, nat._u8(srs_bytes), C.c_size_t(len(srs_bytes)), C.c_size_t(ring_size), C.byref(self._h))
+        if seed is not None:
+            assert srs_bytes is None and len(seed) == 32
+            fn = "avrf_ring_setup_from_seed"
+            st = L.avrf_ring_setup_from_seed(ctx._h, nat._u8(seed), C.c_size_t(ring_size), C.byref(self._h))
+        else:
+            fn = "avrf_ring_verifier_setup_load" if verifier_only else "avrf_ring_setup_load"
+            st = getattr(L, fn)(ctx._h, nat._u8(srs_bytes), C.c_size_t(len(srs_bytes)), C.c_size_t(ring_size), C.byref(self._h))
         self.status = st
         if st != nat.OK:
             self._h = None
@@ -55,6 +61,10 @@ class RingSetup:
         self.domain_size = L.avrf_ring_domain_size(self._h)
         self.proof_len = L.avrf_ring_proof_len(self._h)
         self.commitment_len = L.avrf_ring_commitment_len(self._h)
+
+    @classmethod
+    def from_seed(cls, ctx, ring_size, seed):
+        return cls(ctx, None, ring_size, seed=seed)
 
     def _ser(self, fn, compress):
         ln = C.c_size_t(0)

@@ -319,6 +319,14 @@ void avrf_ring_setup_free(avrf_ring_setup *setup);
  * Insecure by construction (the caller knows tau) -- exactly like the reference's from_seed; for tests and benches. */
 int avrf_ring_srs_generate(avrf_ctx *ctx, const uint8_t *tau, const uint8_t *g1, const uint8_t *g2, size_t n_g1,
                            uint8_t *out, size_t out_cap, size_t *out_len);
+/* RingSetup::from_seed(ring_size, seed) (src/ring.rs:359-366): the deterministic setup of a 32-byte seed as the reference derives it --
+ * Transcript::new(SUITE_ID), absorb_raw(seed), to_rng() (src/utils/transcript.rs:61-92), then Kzg::setup = URS::generate: tau = Fr::rand,
+ * g1 = G1::rand, g2 = G2::rand from that stream -- so that two parties sharing only the seed hold the same SRS (README.md:181 of the
+ * reference).  PARITY UNPINNED: the reference holds no vector of a seeded setup; the samplers (ark-ff Fp::rand, ark-ec
+ * Projective::rand, rand 0.8 bool, w3f-pcs draw order) are restated from their published code, here and in oracle/ring_py.py
+ * srs_from_seed, and the two restatements are tested against each other.  Insecure by construction (the seed gives tau), like the
+ * reference's. */
+int avrf_ring_setup_from_seed(avrf_ctx *ctx, const uint8_t *seed, size_t ring_size, avrf_ring_setup **out);
 /* (avrf_ring_setup_load also accepts the serialize_compressed form of the same object: G1 / G2 points are decompressed on
  * the host, curve membership checked, no G2 subgroup check -- the SRS is trusted-setup material, src/ring.rs:466-474.)
  * CanonicalSerialize for RingSetup (= its PcsParams, truncated to the 3N+1 powers the setup keeps; src/ring.rs:484-521) and

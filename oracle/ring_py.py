@@ -644,3 +644,128 @@ def verify(prm, srs, fixed_commitments, proof, instance, pairing=None):
         npi = (pi[0], (-pi[1]) % s.p)
         ok &= PP.pairing_product_is_one([(lhs_a, g2), (npi, tg2)])
     return ok
+
+
+# ---------------------------------------------------------------------------------------------
+# RingSetup::from_seed (src/ring.rs:359-374) -- **PARITY UNPINNED**: the reference holds no vector for a seeded setup.
+# Restated from the published code of the crates the reference calls:
+#   from_seed:   t = S::Transcript::new(SUITE_ID); t.absorb_raw(seed); rng = t.to_rng()   (src/utils/transcript.rs:61-92: every draw is the
+#                next bytes of the squeeze stream -- next_u32 4 bytes LE, next_u64 8 bytes LE)
+#   from_rand:   Kzg::setup(pcs_domain_size - 1, rng)  ->  w3f-pcs URS::generate(n1 = pcs_domain_size, n2 = 2, rng):
+#                tau = Fr::rand(rng); g1 = G1::rand(rng); g2 = G2::rand(rng); powers tau^i g1 (i < n1), tau^i g2 (i < 2)
+#   ark-ff  Fp::rand:   loop { N x next_u64 little-endian limbs, the top limb masked to the modulus' bit length, taken AS THE MONTGOMERY
+#                       REPRESENTATION (the element is limbs * R^-1); accept if limbs < p }
+#   ark-ff  Fp2::rand:  c0 = Fp::rand, then c1 = Fp::rand
+#   ark-ec  Projective::rand (short Weierstrass): loop { x = BaseField::rand; greatest = rng.gen::<bool>() (rand 0.8: top bit of
+#                       next_u32); if x^3 + b is a square: y = the larger / smaller root by the field's Ord (Fp: canonical integers;
+#                       Fp2: c1 first, then c0); return (x, y) * COFACTOR }
+
+def seed_stream(s, seed, n):
+    """first n bytes of the squeeze stream of HashTranscript<Sha512>::new(SUITE_ID) after absorb_raw(seed)
+    (DigestXof: d = H(absorbed); block_i = H(d || LE64(i)), src/utils/transcript.rs:227-274)"""
+    import hashlib
+    d = hashlib.sha512(s.suite_id + seed).digest()
+    out, i = b"", 0
+    while len(out) < n:
+        out += hashlib.sha512(d + i.to_bytes(8, "little")).digest(); i += 1
+    return out[:n]
+
+
+class _Draw:
+    def __init__(self, s, seed):
+        self.s, self.seed, self.pos, self.buf = s, seed, 0, b""
+
+    def take(self, n):
+        if self.pos + n > len(self.buf):
+            self.buf = seed_stream(self.s, self.seed, max(4096, 2 * (self.pos + n)))
+        b = self.buf[self.pos: self.pos + n]; self.pos += n
+        return b
+
+    def fp(self, p):
+        """ark-ff Fp::rand"""
+        limbs = (p.bit_length() + 63) // 64
+        shave = 64 * limbs - p.bit_length()
+        while True:
+            v = int.from_bytes(self.take(8 * limbs), "little") & ((1 << (64 * limbs - shave)) - 1)
+            if v < p:
+                return v * pow(1 << (64 * limbs), -1, p) % p          # the limbs are the Montgomery representation
+
+    def boolean(self):
+        return int.from_bytes(self.take(4), "little") >> 31 == 1
+
+
+G1_COFACTOR = {"bls12_381": 0x396c8c005555e1568c00aaab0000aaab, "bn254": 1}
+G2_COFACTOR = {"bls12_381": 0x5d543a95414e7f1091d50792876a202cd91de4547085abaa68a205b2e5a7ddfa628f1cb4d9e82ef21537e293a6691ae1616ec6e786f0c70cf1c38e31c7238e5,
+               "bn254": 0x30644e72e131a029b85045b68181585e06ceecda572a2489345f2299c0f9fa8d}
+
+
+def _f2_sqrt(a, p):
+    """a square root of a = (a0, a1) in Fp[u]/(u^2 + 1), p = 3 mod 4, or None"""
+    a0, a1 = a
+    if a1 == 0:
+        r = sqrt_mod(a0, p)
+        if r is not None:
+            return (r, 0)
+        r = sqrt_mod((-a0) % p, p)
+        return None if r is None else (0, r)
+    n = sqrt_mod((a0 * a0 + a1 * a1) % p, p)
+    if n is None:
+        return None
+    inv2 = pow(2, -1, p)
+    for d in ((a0 + n) * inv2 % p, (a0 - n) * inv2 % p):
+        x0 = sqrt_mod(d, p)
+        if x0 is not None and x0 != 0:
+            x1 = a1 * pow(2 * x0, -1, p) % p
+            if ((x0 * x0 - x1 * x1) % p, 2 * x0 * x1 % p) == (a0 % p, a1 % p):
+                return (x0, x1)
+    return None
+
+
+def srs_params_from_seed(s, seed):
+    """(tau, g1 affine, g2 affine on the twist) of RingSetup::from_seed(_, seed)"""
+    import oracle.pairing_py as pp
+    curve = "bls12_381" if s.fp_bytes == 48 else "bn254"
+    pp.use_curve(curve)
+    p = s.p
+    dr = _Draw(s, seed)
+    tau = dr.fp(s.r)
+    while True:                                                     # G1::rand
+        x = dr.fp(p); greatest = dr.boolean()
+        y = sqrt_mod((x * x * x + s.g1_b) % p, p)
+        if y is None:
+            continue
+        lo, hi = min(y, p - y), max(y, p - y)
+        g1 = g1_affine(p, g1_mul(p, (x, hi if greatest else lo, 1), G1_COFACTOR[curve]))
+        break
+    xi = (pp.XI0, 1)
+    b2 = pp.f2_mul((s.g1_b, 0), xi) if pp.MTWIST else pp.f2_mul((s.g1_b, 0), pp.f2_inv(xi))      # twist coefficient b' = b xi or b / xi
+    while True:                                                     # G2::rand
+        x = (dr.fp(p), dr.fp(p)); greatest = dr.boolean()
+        y = _f2_sqrt(pp.f2_add(pp.f2_mul(pp.f2_mul(x, x), x), b2), p)
+        if y is None:
+            continue
+        neg = ((-y[0]) % p, (-y[1]) % p)
+        larger = y if (y[1], y[0]) > (neg[1], neg[0]) else neg
+        smaller = neg if larger is y else y
+        g2 = pp.g2_mul((x, larger if greatest else smaller), G2_COFACTOR[curve])
+        break
+    return tau, g1, g2
+
+
+def srs_from_seed(s, ring_size, seed, n_g1=None):
+    """serialize_uncompressed(URS) of RingSetup::from_seed(ring_size, seed): n_g1 powers tau^i g1 (default: the setup's pcs domain
+    size 3 N + 1) and the two G2 powers"""
+    import oracle.pairing_py as pp
+    tau, g1, g2 = srs_params_from_seed(s, seed)
+    if n_g1 is None:
+        n = 1 << (ring_size + 4 + s.te_order_bits - 1).bit_length()
+        n_g1 = 3 * n + 1
+    out = n_g1.to_bytes(8, "little")
+    pt, t = (g1[0], g1[1], 1), 1
+    for i in range(n_g1):
+        out += g1_encode(s, g1_affine(s.p, g1_mul(s.p, pt, t)) if t != 1 else g1, False)
+        t = t * tau % s.r
+    out += (2).to_bytes(8, "little")
+    enc = pp.g2_encode_zcash_uncompressed if s.zcash else pp.g2_encode_arkworks_uncompressed
+    out += enc(g2) + enc(pp.g2_mul(g2, tau))
+    return out

@@ -393,6 +393,42 @@ def test_srs_generate(env, suite):
 
 
 @pytest.mark.parametrize("suite", [0, 1])
+def test_setup_from_seed(env, suite):
+    """a13, RingSetup::from_seed (src/ring.rs:359-366) as the reference derives it: Transcript::new(SUITE_ID) | seed -> to_rng ->
+    Kzg::setup (tau = Fr::rand, g1 = G1::rand, g2 = G2::rand).  UNPINNED by any reference vector (SURVEY.md 8c-v): the device-side
+    derivation equals the oracle's independent restatement (oracle/ring_py.py srs_from_seed) byte for byte on both pairing curves,
+    a different seed gives a different SRS, the same seed the same, and a ring proof made over the seeded setup verifies."""
+    import oracle as orc
+    from ark_vrf_amd.ring import RingSetup, ring_batch_verify
+    ctx, _, vs, _ = env[suite]
+    s = R.SUITES[suite]
+    seed = bytes([suite + 1]) + bytes(range(31))
+    setup = RingSetup.from_seed(ctx, 8, seed)
+    got = setup.serialize(compress=False)
+    want = R.srs_from_seed(s, 8, seed, n_g1=40)                            # the first 40 powers of the oracle (Python G1 arithmetic)
+    fq = s.fp_bytes
+    n_g1 = int.from_bytes(got[:8], "little")
+    assert n_g1 == 3 * 512 + 1 and got[8: 8 + 40 * 2 * fq] == want[8: 8 + 40 * 2 * fq]
+    assert got[8 + n_g1 * 2 * fq:] == want[8 + 40 * 2 * fq:]              # count 2 | g2 | tau g2
+    tau, g1, g2 = R.srs_params_from_seed(s, seed)
+    srs = R.Srs(s, got)
+    assert srs.g1[1536] == R.g1_affine(s.p, R.g1_mul(s.p, g1 + (1,), pow(tau, 1536, s.r)))
+    again = RingSetup.from_seed(ctx, 8, seed)
+    assert again.serialize(compress=False) == got
+    other = RingSetup.from_seed(ctx, 8, bytes(32))
+    assert other.serialize(compress=False)[:8 + 2 * fq] != got[:8 + 2 * fq]
+    again.close(); other.close()
+    sks = [orc.from_seed(suite, bytes([9, i]) + bytes(30)) for i in range(4)]
+    key = setup.index([xy(suite, pk) for _, pk in sks])
+    h = orc.hash_to_curve(suite, b"seeded-setup")
+    sk, pk = sks[2]
+    ped, blinding = orc.pedersen_prove(suite, sk, [(h, orc.vrf_output(suite, sk, h))], b"")
+    proof = key.prove([2], [blinding])[0]
+    assert ring_batch_verify(setup, [key.commitment], None, [xy(suite, ped[:32])], [proof]) == 0
+    key.close(); setup.close()
+
+
+@pytest.mark.parametrize("suite", [0, 1])
 def test_setup_serialisation(env, suite):
     """CanonicalSerialize / Deserialize of RingSetup and RingBuilderPcsParams (src/ring.rs:484-542) in both ark-serialize modes:
     uncompressed == the truncated SRS file; compressed == the oracle's encodings of the same points (G1 form pinned by the
