@@ -264,6 +264,12 @@ class RingSetup {
     out->reset();
     return avrf_ring_setup_load(su.ctx(), srs.data(), srs.size(), ring_size, &out->h_);
   }
+  // RingSetup::from_seed (src/ring.rs:359-366): the deterministic setup of a seed, derived as the reference derives it
+  // (avrf_ring_setup_from_seed; unpinned by any reference vector, see include/avrf.h)
+  static Status from_seed(const Suite &su, size_t ring_size, const std::array<uint8_t, 32> &seed, RingSetup *out) {
+    out->reset();
+    return avrf_ring_setup_from_seed(su.ctx(), seed.data(), ring_size, &out->h_);
+  }
   // Kzg::setup with an explicit trapdoor (what from_seed / from_rand reach, src/ring.rs:359-374); g1 / g2: generator
   // entries in the URS encoding
   static std::vector<uint8_t> generate_pcs_params(const Suite &su, int suite_id, size_t ring_size, const Scalar &tau, const std::vector<uint8_t> &g1,
