@@ -34,9 +34,15 @@ n1 = am["configs0_shape"]["n=1"]
 print("n=1 ms:", {k: round(v, 3) for k, v in n1.items()})
 print("validate (bench line):", {k: M(v) for k, v in am["validate_yes"].items() if isinstance(v, float)})
 print("validate_bench:", {k: M(v) for k, v in json.load(open(P("validate_bench.json"))).items() if isinstance(v, (int, float))})
+# (the measurement kernels of libavrf_probe.so -- the clock probe's sleeping wave, the instruction streams, the bare addition loops -- and
+# the once-per-SRS table builds are listed in the CSVs but are not part of a step / a proof: shares below are of the rest)
+SKIP = ("k_clock", "k_stream", "k_madd_loop", "k_g1_multiples", "k_g1_table", "k_fixed_table")
 for f in ("single_context", "per_item", "ring_prove_2048", "ring_bn254_prove_1024"):
-    rows = list(csv.DictReader(open(P(f + "_kernel_stats.csv"))))
-    print(f + ": " + "; ".join(f"{x['Name'].split('<')[0].replace('void avrf::', '').replace('avrf::', '').split('(')[0]} {float(x['AverageNs']) / 1e3:.1f} us ({x['Percentage'][:4]}%)" for x in rows[:10]))
+    rows = [x for x in csv.DictReader(open(P(f + "_kernel_stats.csv"))) if not any(t in x["Name"] for t in SKIP)]
+    tot = sum(int(x["TotalDurationNs"]) for x in rows) or 1
+    nm = lambda x: x["Name"].replace("void avrf::", "").replace("avrf::", "").split("(")[0]
+    short = lambda x: nm(x).split("<")[0] + ("<G1>" if "G1" in nm(x) and "k_accumulate<" in nm(x) else "")
+    print(f + ": " + "; ".join(f"{short(x)} {float(x['AverageNs']) / 1e3:.1f} us x {x['Calls']} ({100.0 * int(x['TotalDurationNs']) / tot:.1f}%)" for x in rows[:12]))
 for name in ("pmc_thin", "pmc_ring"):
     k = json.load(open(P(name + ".json")))["kernels"]
     for n, v in k.items():
