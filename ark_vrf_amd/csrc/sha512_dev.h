@@ -52,6 +52,19 @@ AVRF_DI uint64_t shr64(uint64_t x, int n) {              // 0 < n < 32
   return ((uint64_t)(hi >> n) << 32) | __builtin_amdgcn_alignbit(hi, lo, (uint32_t)n);
 }
 
+// three-input boolean functions of 64-bit words as ONE v_bitop3_b32 per half (gfx950): x ^ y ^ z (truth table 0x96) for the four sigma
+// functions, the majority (0xE8) and the choice (0xCA) -- the compiler's own selection left two v_xor_b32 per xor-of-three and four
+// and / or / bfi per majority: 60 -> 48 vector instructions per round (tools/kernel_counts.py on sha512_compress_nf)
+AVRF_DI uint64_t bitop3_64(uint64_t x, uint64_t y, uint64_t z, const uint32_t tt) {
+  uint32_t lo, hi;
+  if (tt == 0x96) { lo = __builtin_amdgcn_bitop3_b32((uint32_t)x, (uint32_t)y, (uint32_t)z, 0x96); hi = __builtin_amdgcn_bitop3_b32((uint32_t)(x >> 32), (uint32_t)(y >> 32), (uint32_t)(z >> 32), 0x96); }
+  else if (tt == 0xE8) { lo = __builtin_amdgcn_bitop3_b32((uint32_t)x, (uint32_t)y, (uint32_t)z, 0xE8); hi = __builtin_amdgcn_bitop3_b32((uint32_t)(x >> 32), (uint32_t)(y >> 32), (uint32_t)(z >> 32), 0xE8); }
+  else { lo = __builtin_amdgcn_bitop3_b32((uint32_t)x, (uint32_t)y, (uint32_t)z, 0xCA); hi = __builtin_amdgcn_bitop3_b32((uint32_t)(x >> 32), (uint32_t)(y >> 32), (uint32_t)(z >> 32), 0xCA); }
+  typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+  u32x2_ v; v.x = lo; v.y = hi;
+  return __builtin_bit_cast(uint64_t, v);                     // (a register pair, no arithmetic: `hi << 32 | lo` came out as a v_lshl_add_u64)
+}
+
 struct Sha512 {
   uint64_t h[8];
   uint64_t w[16];   // current block, big-endian words
@@ -75,16 +88,15 @@ __device__ __noinline__ static ShaH sha512_compress_nf(ShaH hin, ShaW win) {
     for (int i = 0; i < 16; i++) {
       if (r) {
         uint64_t w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
-        uint64_t s0 = ror64(w15, 1) ^ ror64(w15, 8) ^ shr64(w15, 7);
-        uint64_t s1 = ror64(w2, 19) ^ ror64(w2, 61) ^ shr64(w2, 6);
+        uint64_t s0 = bitop3_64(ror64(w15, 1), ror64(w15, 8), shr64(w15, 7), 0x96);
+        uint64_t s1 = bitop3_64(ror64(w2, 19), ror64(w2, 61), shr64(w2, 6), 0x96);
         w[i] = w[i] + s0 + w[(i + 9) & 15] + s1;
       }
-      uint64_t S1 = ror64(e, 14) ^ ror64(e, 18) ^ ror64(e, 41);
-      uint64_t ch = (e & f) ^ (~e & g);
+      uint64_t S1 = bitop3_64(ror64(e, 14), ror64(e, 18), ror64(e, 41), 0x96);
+      uint64_t ch = bitop3_64(e, f, g, 0xCA);                 // (e & f) | (~e & g)
       uint64_t t1 = hh + S1 + ch + SHA512_K[r + i] + w[i];
-      uint64_t S0 = ror64(a, 28) ^ ror64(a, 34) ^ ror64(a, 39);
-      const uint64_t ab = a ^ b;
-      uint64_t mj = (ab & c) | (~ab & b);                 // majority as one bitfield insert per half
+      uint64_t S0 = bitop3_64(ror64(a, 28), ror64(a, 34), ror64(a, 39), 0x96);
+      uint64_t mj = bitop3_64(a, b, c, 0xE8);                 // majority
       uint64_t t2 = S0 + mj;
       hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
