@@ -2,7 +2,7 @@
 # A/B runs of bench.py on one GPU box: bash tools/ab.sh OUTDIR NAME "ARGS" [NAME "ARGS" ...]
 #   ARGS are appended to `python bench.py --gpus 1 --no-ring --no-cpu-baseline --no-projection --steps 20 --warmup 5 --min-seconds 1`;
 #   a leading `cpus=LIST` in ARGS runs that variant under `taskset -c LIST` (the per-rank CPU share of a multi-GPU node);
-#   a leading `lib=PATH` selects another build of the library (AVRF_LIB_PATH).
+#   a leading `lib=PATH` selects another build of the library (AVRF_LIB_PATH); `env=K=V` sets an environment variable for that variant.
 # One summary line per variant; the JSON lines are kept under OUTDIR.  (Replaces the one-off tools/r2_*.sh / r3_run*.sh scripts.)
 OUT=$1; shift; mkdir -p "$OUT"
 B="python bench.py --gpus 1 --no-ring --no-cpu-baseline --no-projection --steps 20 --warmup 5 --min-seconds 1"
@@ -12,7 +12,8 @@ while [ $# -ge 2 ]; do
   for w in $args; do
     case $w in
       cpus=*) pre="taskset -c ${w#cpus=}"; args=${args#"$w"};;
-      lib=*) envs="AVRF_LIB_PATH=${w#lib=}"; args=${args#"$w"};;
+      lib=*) envs="$envs AVRF_LIB_PATH=${w#lib=}"; args=${args#"$w"};;
+      env=*) envs="$envs ${w#env=}"; args=${args/"$w"/};;
     esac
   done
   env $envs $pre $B $args > "$OUT/$name.json" 2> "$OUT/$name.err"
