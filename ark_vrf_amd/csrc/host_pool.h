@@ -92,22 +92,27 @@ class HostPool {
     }();
     return *p;
   }
-  // fn(i) for every i < n, on the pool and the calling thread; returns when all are done
-  void run(size_t n, const std::function<void(size_t)> &fn) {
+  // fn(i) for every i < n, on the pool and the calling thread; returns when all are done.  `grain` = items worth one worker's
+  // wake-up (a sleeping thread costs tens of microseconds to bring in: a chunk's 512 transcript steps of ~10 us each are work for
+  // a few dozen threads, eight pairing checks of a millisecond each for eight)
+  void run(size_t n, const std::function<void(size_t)> &fn, size_t grain = 1) {
     if (n == 0) return;
     if (n == 1 || workers_.empty()) { for (size_t i = 0; i < n; i++) fn(i); return; }
     auto j = std::make_shared<Job>(); j->fn = &fn; j->n = n;
     { std::lock_guard<std::mutex> lk(mu_); jobs_.push_back(j); }
-    cv_work_.notify_all();
+    if (grain < 1) grain = 1;
+    const size_t wake = (n - 1 + grain - 1) / grain;                 // the caller takes a share too
+    if (wake >= workers_.size()) cv_work_.notify_all();
+    else for (size_t i = 0; i < wake; i++) cv_work_.notify_one();
     drain(*j);
     std::unique_lock<std::mutex> lk(mu_);
     cv_done_.wait(lk, [&] { return j->done.load(std::memory_order_acquire) == j->n; });
   }
 };
 
-template <class Fn> static void parallel_for(size_t n, Fn fn) {
+template <class Fn> static void parallel_for(size_t n, Fn fn, size_t grain = 1) {
   const std::function<void(size_t)> f = [&](size_t i) { fn(i); };
-  HostPool::get().run(n, f);
+  HostPool::get().run(n, f, grain);
 }
 
 }  // namespace avrf

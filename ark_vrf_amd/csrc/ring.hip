@@ -482,11 +482,15 @@ template <class S, class G> struct RingTypes {
 // host-side data parallelism over the proofs of a chunk: parallel_for of host_pool.h (one bounded persistent pool per process)
 
 // int_BE(48 bytes) mod r, Montgomery form
+// (hi 2^256 + lo) R = (hi R) R^2 / R + lo R: three Montgomery products -- sixteen challenges per proof on the prover AND the verifier;
+// the byte-by-byte Horner form this replaces cost 96 products, 3.8 us, i.e. 60 us of a core per proof of the ~80 a proof took)
 template <class F> static H256 fr_from_be48(const uint8_t b[48]) {
   using Fr = HostField<F>;
-  H256 acc = {{0, 0, 0, 0}}, c256 = Fr::to_mont(H256{{256, 0, 0, 0}});
-  for (int i = 0; i < 48; i++) { acc = Fr::mul(acc, c256); acc = Fr::add(acc, Fr::to_mont(H256{{b[i], 0, 0, 0}})); }
-  return acc;
+  H256 hi = {{0, 0, 0, 0}}, lo;
+  for (int i = 0; i < 2; i++) { uint64_t v; memcpy(&v, b + 8 * i, 8); hi.l[1 - i] = __builtin_bswap64(v); }
+  for (int i = 0; i < 4; i++) { uint64_t v; memcpy(&v, b + 16 + 8 * i, 8); lo.l[3 - i] = __builtin_bswap64(v); }
+  static const H256 r2 = Fr::r2();
+  return Fr::add(Fr::mul(Fr::mul(hi, r2), r2), Fr::mul(lo, r2));    // (mul reduces any 256-bit left operand: its result is below 2 p before the final subtraction)
 }
 template <class F> static H256 fr_pow(H256 a, uint64_t e) {
   using Fr = HostField<F>; H256 r = Fr::one();
@@ -1160,8 +1164,9 @@ template <class S, class G> struct Ring {
     const H256 one = Fr::one();
     static const bool trace = getenv("AVRF_RING_TRACE") != nullptr;
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
-    double t_prev = now();
-    auto lap = [&](const char *what) { if (trace) { double t = now(); fprintf(stderr, "  ring_prove[%zu] %-24s %8.3f ms\n", n, what, t - t_prev); t_prev = t; } };
+    auto cpu_now = [] { struct timespec ts; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    double t_prev = now(), c_prev = cpu_now();                         // (trace: wall time and the PROCESS's CPU time of every phase, workers included)
+    auto lap = [&](const char *what) { if (trace) { double t = now(), c = cpu_now(); fprintf(stderr, "  ring_prove[%zu] %-32s %8.3f ms wall %8.3f ms cpu\n", n, what, t - t_prev, c - c_prev); t_prev = t; c_prev = c; } };
     for (size_t i = 0; i < n; i++) if (key_index[i] >= k->n_keys) return AVRF_ERR_BAD_ARG;
     std::vector<ProofState> st(n);
     const H256 w_last = fr_pow<F>(su->w, cap - 1);
@@ -1217,7 +1222,8 @@ template <class S, class G> struct Ring {
       { std::vector<uint8_t> b; push_le32(b, ps.instx); push_le32(b, ps.insty); ps.t.label("instance"); ps.t.append(b); }
       { std::vector<uint8_t> b; for (int i = 0; i < 4; i++) g1_encode<G>(ps.C[i], false, b); ps.t.label("committed_cols"); ps.t.append(b); }
       for (int i = 0; i < 7; i++) ps.al[i] = challenge(ps.t, "constraints_aggregation");
-    });
+    }, 16);
+    lap("transcript: alphas");
     // per-chunk parameter block on the device: RingConsts[n] | zeta[n] | nu[8n] | ev[7n] | lin_zw[n]
     const size_t qlen = 3 * N + 1, olen = 3 * N;
     const size_t rc_bytes = (n * sizeof(RingConsts) + 31) / 32 * 32;
@@ -1256,7 +1262,7 @@ template <class S, class G> struct Ring {
         ProofState &ps = st[p];
         std::vector<uint8_t> b; g1_encode<G>(ps.Cq, false, b); ps.t.label("quotient"); ps.t.append(b);
         ps.zeta = challenge(ps.t, "evaluation_point"); zs[p] = ps.zeta;
-      });
+      }, 32);
       HIP_CHECK(hipMemcpyAsync(d_zeta, zs.data(), n * 32, hipMemcpyHostToDevice, su->stream));
     }
     uint32_t *d_lin = dev_scratch(su, 5, n * N * 32);
@@ -1277,7 +1283,7 @@ template <class S, class G> struct Ring {
         { std::vector<uint8_t> b; for (int i = 0; i < 7; i++) push_le32(b, ps.ev[i]); ps.t.label("register_evaluations"); ps.t.append(b); }
         { std::vector<uint8_t> bb; push_le32(bb, ps.lin_zw); ps.t.label("shifted_linearization_evaluation"); ps.t.append(bb); }
         for (int i = 0; i < 8; i++) { ps.nu[i] = challenge(ps.t, "kzg_aggregation"); nus[p * 8 + i] = ps.nu[i]; }
-      });
+      }, 16);
       HIP_CHECK(hipMemcpyAsync(d_nu, nus.data(), n * 8 * 32, hipMemcpyHostToDevice, su->stream));
       HIP_CHECK(hipStreamSynchronize(su->stream));                     // nus goes out of scope
     }
@@ -1320,6 +1326,7 @@ template <class S, class G> struct Ring {
       if (pr.size() != plen) return AVRF_ERR_BAD_ARG;
       memcpy(out + plen * p, pr.data(), plen);
     }
+    lap("proof bytes");
     return AVRF_OK;
   }
 
@@ -1602,6 +1609,15 @@ template <class S, class G> struct Ring {
       if (ok && host_subgroup) ok = g1_in_subgroup_host(dec[k]);
       dec_ok[k] = ok;
     });
+    // the transcript up to the verifier key is the same for every proof checked against one ring: absorbed once per ring
+    std::vector<ArkTranscript> t_ring(n_rings);
+    for (size_t r = 0; r < n_rings; r++) {
+      ArkTranscript &t = t_ring[r];
+      t.label(S::SUITE_ID, S::SUITE_ID_LEN); t.label("vk");
+      std::vector<uint8_t> vk; g1_encode<G>(su->g1_0, false, vk); vk.insert(vk.end(), su->g2_raw.begin(), su->g2_raw.end());
+      for (int i = 0; i < 3; i++) g1_encode<G>(fixed[3 * r + i], false, vk);
+      t.append(vk);
+    }
     parallel_for(n, [&](size_t it) {
       const uint8_t *pr = proofs + plen * it;
       const uint32_t ring = ring_of_item ? ring_of_item[it] : 0;
@@ -1620,10 +1636,7 @@ template <class S, class G> struct Ring {
       if (Fr::geq_p(ix) || Fr::geq_p(iy)) { fail(it, AVRF_INVALID_DATA); return; }
       H256 ixm = Fr::to_mont(ix), iym = Fr::to_mont(iy);
       // transcript replay
-      ArkTranscript t;
-      t.label(S::SUITE_ID, S::SUITE_ID_LEN); t.label("vk");
-      { std::vector<uint8_t> vk; g1_encode<G>(su->g1_0, false, vk); vk.insert(vk.end(), su->g2_raw.begin(), su->g2_raw.end());
-        for (int i = 0; i < 3; i++) g1_encode<G>(fx[i], false, vk); t.append(vk); }
+      ArkTranscript t = t_ring[ring];
       { std::vector<uint8_t> b(instances_xy + 64 * it, instances_xy + 64 * it + 64); t.label("instance"); t.append(b); }
       { std::vector<uint8_t> b; for (int i = 0; i < 4; i++) g1_encode<G>(C[i], false, b); t.label("committed_cols"); t.append(b); }
       H256 al[7]; for (int i = 0; i < 7; i++) al[i] = challenge(t, "constraints_aggregation");
@@ -1638,11 +1651,22 @@ template <class S, class G> struct Ring {
       H256 zn = zeta; for (size_t k = 1; k < N; k <<= 1) zn = Fr::sqr(zn);
       const H256 zn1 = Fr::sub(zn, one);
       if (Fr::is_zero(zn1)) { fail(it, AVRF_VERIFICATION_FAILURE); return; }
-      auto lag = [&](size_t i) { H256 wi = fr_pow<F>(su->w, i); return Fr::mul(Fr::mul(Fr::mul(wi, zn1), ninv), Fr::inv(Fr::sub(zeta, wi))); };
-      const H256 lf = lag(0), ll = lag(cap - 1);
       HostExt sd; sd.x = seedx; sd.y = seedy; sd.t = Fr::mul(seedx, seedy); sd.z = one;
       HostExt in; in.x = ixm; in.y = iym; in.t = Fr::mul(ixm, iym); in.z = one;
-      HostExt rs = Te::add(sd, in); H256 rzi = Fr::inv(rs.z); const H256 resx = Fr::mul(rs.x, rzi), resy = Fr::mul(rs.y, rzi);
+      HostExt rs = Te::add(sd, in);
+      // the item's four inversions -- 1 / (zeta - 1), 1 / (zeta - w^(cap-1)) of the two Lagrange values, 1 / z of seed + instance,
+      // 1 / (zeta^N - 1) -- as ONE (Montgomery's trick; a fixed-exponent inversion is 380 products, 13 us).  zeta^N != 1 was checked, so
+      // the first, second and fourth are non-zero; z = 0 (an instance off the curve) keeps the old meaning: 1 / 0 = 0
+      const bool z_zero = Fr::is_zero(rs.z);
+      const H256 v0 = Fr::sub(zeta, one), v1 = nl, v2 = z_zero ? one : rs.z, v3 = zn1;
+      const H256 p01 = Fr::mul(v0, v1), p012 = Fr::mul(p01, v2);
+      H256 tinv = Fr::inv(Fr::mul(p012, v3));
+      const H256 i3 = Fr::mul(tinv, p012); tinv = Fr::mul(tinv, v3);
+      const H256 i2 = Fr::mul(tinv, p01); tinv = Fr::mul(tinv, v2);
+      const H256 i1 = Fr::mul(tinv, v0), i0 = Fr::mul(tinv, v1);
+      const H256 zn1n = Fr::mul(zn1, ninv);
+      const H256 lf = Fr::mul(zn1n, i0), ll = Fr::mul(Fr::mul(w_last, zn1n), i1);      // L_i(zeta) = w^i (zeta^N - 1) / (N (zeta - w^i))
+      const H256 rzi = z_zero ? H256{{0, 0, 0, 0}} : i2; const H256 resx = Fr::mul(rs.x, rzi), resy = Fr::mul(rs.y, rzi);
       const H256 x1y1 = Fr::mul(x1, y1), x2y2 = Fr::mul(x2, y2);
       H256 rest[7];
       rest[0] = Fr::mul(Fr::neg(Fr::add(ip, Fr::mul(sel, b))), nl);
@@ -1654,7 +1678,7 @@ template <class S, class G> struct Ring {
       rest[6] = Fr::add(Fr::mul(lf, ip), Fr::mul(ll, Fr::sub(ip, one)));
       H256 aggz = lin_zw; for (int i = 0; i < 7; i++) aggz = Fr::add(aggz, Fr::mul(al[i], rest[i]));
       H256 zk = one; for (int j = 0; j < 3; j++) zk = Fr::mul(zk, Fr::sub(zeta, wz[j]));
-      const H256 qz = Fr::mul(Fr::mul(aggz, zk), Fr::inv(zn1));
+      const H256 qz = Fr::mul(Fr::mul(aggz, zk), i3);
       H256 vagg = Fr::mul(nu[7], qz); for (int i = 0; i < 7; i++) vagg = Fr::add(vagg, Fr::mul(nu[i], ev[i]));
       const H256 a_coef = S::A_KIND == 1 ? Fr::neg(fr_small<F>(5)) : S::A_KIND == 2 ? Fr::neg(one) : one;
       const H256 k1 = Fr::add(Fr::mul(b, Fr::add(Fr::mul(y1, y2), Fr::mul(a_coef, Fr::mul(x1, x2)))), omb);
@@ -1674,7 +1698,7 @@ template <class S, class G> struct Ring {
       put(b1, s1, o + 8, pi1, Fr::mul(r1, zeta)); put(b1, s1, o + 9, pi2, Fr::mul(r2, zw));
       gsc[it] = Fr::add(Fr::mul(r1, vagg), Fr::mul(r2, lin_zw));
       put(b2, s2, 2 * it, pi1, Fr::neg(r1)); put(b2, s2, 2 * it + 1, pi2, Fr::neg(r2));
-    });
+    }, 4);
     if (status != AVRF_OK) return status;
     lap("decode + transcripts (host)");
     // ONE independent verification is a batch of one: its two 11- / 2-term sums go through the MSM engine and the pairing

@@ -55,10 +55,12 @@ if len(sys.argv) > 3:
     pool = ThreadPoolExecutor(nctx)
     list(pool.map(work, range(nctx)))                        # warm (scratch allocation)
     import gc
-    dts = []
+    dts = []; cpu = []
     for _ in range(int(os.environ.get("RING_BENCH_PASSES", "5"))):
         gc.collect(); gc.disable()
+        c0 = time.process_time()
         t = time.perf_counter(); res = list(pool.map(work, range(nctx))); dts.append(time.perf_counter() - t)
+        cpu.append(time.process_time() - c0)
         gc.enable()
     assert res[0][0] == proofs[0]
-    print(f"  {nctx} contexts x {per} proofs: best {per * nctx / min(dts):.1f} proofs/s ({min(dts) * 1e3:.1f} ms), mean {per * nctx * len(dts) / sum(dts):.1f}; passes ms {[round(x * 1e3, 1) for x in dts]}")
+    print(f"  {nctx} contexts x {per} proofs: best {per * nctx / min(dts):.1f} proofs/s ({min(dts) * 1e3:.1f} ms), mean {per * nctx * len(dts) / sum(dts):.1f}; passes ms {[round(x * 1e3, 1) for x in dts]}; host CPU ms per pass {[round(x * 1e3, 1) for x in cpu]}")
