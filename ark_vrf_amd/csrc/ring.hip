@@ -1222,7 +1222,7 @@ template <class S, class G> struct Ring {
       { std::vector<uint8_t> b; push_le32(b, ps.instx); push_le32(b, ps.insty); ps.t.label("instance"); ps.t.append(b); }
       { std::vector<uint8_t> b; for (int i = 0; i < 4; i++) g1_encode<G>(ps.C[i], false, b); ps.t.label("committed_cols"); ps.t.append(b); }
       for (int i = 0; i < 7; i++) ps.al[i] = challenge(ps.t, "constraints_aggregation");
-    }, 16);
+    }, 64);                                                            // (3 us per proof on one thread: a worker is worth waking for ~200 us)
     lap("transcript: alphas");
     // per-chunk parameter block on the device: RingConsts[n] | zeta[n] | nu[8n] | ev[7n] | lin_zw[n]
     const size_t qlen = 3 * N + 1, olen = 3 * N;
@@ -1262,7 +1262,7 @@ template <class S, class G> struct Ring {
         ProofState &ps = st[p];
         std::vector<uint8_t> b; g1_encode<G>(ps.Cq, false, b); ps.t.label("quotient"); ps.t.append(b);
         ps.zeta = challenge(ps.t, "evaluation_point"); zs[p] = ps.zeta;
-      }, 32);
+      }, 256);
       HIP_CHECK(hipMemcpyAsync(d_zeta, zs.data(), n * 32, hipMemcpyHostToDevice, su->stream));
     }
     uint32_t *d_lin = dev_scratch(su, 5, n * N * 32);
@@ -1283,7 +1283,7 @@ template <class S, class G> struct Ring {
         { std::vector<uint8_t> b; for (int i = 0; i < 7; i++) push_le32(b, ps.ev[i]); ps.t.label("register_evaluations"); ps.t.append(b); }
         { std::vector<uint8_t> bb; push_le32(bb, ps.lin_zw); ps.t.label("shifted_linearization_evaluation"); ps.t.append(bb); }
         for (int i = 0; i < 8; i++) { ps.nu[i] = challenge(ps.t, "kzg_aggregation"); nus[p * 8 + i] = ps.nu[i]; }
-      }, 16);
+      }, 64);
       HIP_CHECK(hipMemcpyAsync(d_nu, nus.data(), n * 8 * 32, hipMemcpyHostToDevice, su->stream));
       HIP_CHECK(hipStreamSynchronize(su->stream));                     // nus goes out of scope
     }
