@@ -166,3 +166,30 @@ def test_host_sha512_long_message_path(tmp_path):
     n = (4 << 20) + 28
     d = bytes((((i * 2654435761) & 0xffffffff) >> 13) & 0xff for i in range(0, n))
     assert out.stdout.strip().split()[-1] == hashlib.sha512(d).hexdigest()[:8]
+
+
+def test_host_shake128_and_challenge_reduction(tmp_path):
+    """host_shake128.h (the ark-transcript of the ring proof, the SHAKE128 suite's weight transcript): XOF output == hashlib.shake_128 for
+    messages around the 168-byte rate, absorbed in one piece and in odd pieces, squeezed past one block.  ring.hip's reduction of a
+    challenge's 48 big-endian bytes (hi 2^256 + lo with three Montgomery products) == the integer mod r, on both scalar fields of the
+    KZG commitments, including all-ones bytes."""
+    import hashlib
+    import os
+    import random
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "hk")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(ROOT, "tests", "cpp", "host_shake_check.cpp"), "-o", exe])
+    rng = random.Random(11)
+    for n in (0, 1, 167, 168, 169, 335, 336, 337, 1000):
+        m = bytes(rng.randrange(256) for _ in range(n))
+        for cut, outn in ((max(n, 1), 48), (7, 200), (168, 400)):
+            got = subprocess.run([exe, "shake", m.hex() or "", str(outn), str(cut)], capture_output=True, text=True).stdout.strip()
+            assert got == hashlib.shake_128(m).hexdigest(outn), (n, cut, outn)
+    R = (0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,      # Fr(BLS12-381) = Fq(Bandersnatch)
+         0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001)      # Fr(BN254) = Fq(Baby-JubJub)
+    cases = [bytes(48), b"\xff" * 48, bytes(16) + b"\xff" * 32, b"\xff" * 16 + bytes(32)] + [bytes(rng.randrange(256) for _ in range(48)) for _ in range(40)]
+    for f in (0, 1):
+        for b in cases + [(R[f] - 1).to_bytes(48, "big"), R[f].to_bytes(48, "big"), ((R[f] << 128) + 5).to_bytes(48, "big")]:
+            got = subprocess.run([exe, "be48", str(f), b.hex()], capture_output=True, text=True).stdout.strip()
+            assert int(got, 16) == int.from_bytes(b, "big") % R[f], (f, b.hex())
