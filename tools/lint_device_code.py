@@ -13,7 +13,9 @@ function holds at most a few generic multiplications (the short-Weierstrass law 
 the code that ships: it unbundles the gfx950 code objects of libavrf.so (clang offload bundles in .hip_fatbin), disassembles
 them and counts, per NON-KERNEL function, the v_mad_u64_u32 whose carry goes to an SGPR pair.  The largest such function that
 is known good has 720 (f12_sqr of pairing.hip, exercised by every pairing test); the build fails above LIMIT = 1024, a fifth
-of the count that faulted.
+of the count that faulted.  tools/sgpr_carry_repro.hip is the stand-alone reduction of that shape (40 / 80 inlined generic multiplications
+in one non-kernel function, no product headers): it does NOT fault, with or without interprocedural register allocation -- the count alone is
+not the cause; the limit fences the one shape known bad.
 
     python tools/lint_device_code.py [path/to/libavrf.so]      exit status 1 on a violation
 """
