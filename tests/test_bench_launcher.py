@@ -57,17 +57,17 @@ def test_host_plan_follows_the_quota():
     sys.path.insert(0, ROOT)
     import bench
     p = bench.host_plan(16, 1)
-    assert (p["slots"], p["lanes"], p["threads"], p["group"], p["cores"]) == (240, 10, 10, 8, 16.0)   # ten threads, three groups of eight transcripts each
+    assert (p["slots"], p["lanes"], p["threads"], p["group"], p["cores"]) == (144, 12, 6, 8, 16.0)   # six threads, three groups of eight transcripts each, twelve lanes (round 6 sweeps)
     p = bench.host_plan(16, 8)                                    # 2 cores per rank: sixteen transcripts hashed together (two interleaved groups), three groups per thread
     assert (p["threads"], p["group"], p["cores"]) == (2, 16, 2.0) and p["slots"] == 96 and p["lanes"] == 12
-    assert bench.host_plan(256, 8)["threads"] == 10 and bench.host_plan(256, 8)["group"] == 8
+    assert bench.host_plan(256, 8)["threads"] == 6 and bench.host_plan(256, 8)["group"] == 8
     assert bench.host_plan(16, 2)["threads"] == 6 and bench.host_plan(8, 2)["threads"] == 4 and bench.host_plan(8, 2)["slots"] == 96
     p = bench.host_plan(16, 4)                                    # 4 cores per rank: multi-buffer hashing on four threads
     assert (p["slots"], p["threads"], p["group"], p["lanes"]) == (96, 4, 8, 12)
     p = bench.host_plan(16, 1, group_arg=1)                       # --hash-group 1: scalar chains, four slots and two lanes per thread
     assert (p["slots"], p["lanes"], p["threads"], p["group"]) == (24, 12, 6, 1)
     p = bench.host_plan(16, 1, slots_arg=12)                      # --slots overrides
-    assert (p["slots"], p["threads"], p["lanes"]) == (12, 10, 10)
+    assert (p["slots"], p["threads"], p["lanes"]) == (12, 6, 12)
     p = bench.host_plan(16, 1, slots_arg=20, threads_arg=20)
     assert (p["slots"], p["threads"]) == (20, 20)
     p = bench.host_plan(2, 1, group_arg=16)
