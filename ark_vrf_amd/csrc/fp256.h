@@ -276,7 +276,7 @@ template <class F> AVRF_DN fp fp_inv_nf(fp a) {
 // ~180 macro steps for a 255-bit modulus (every subtraction leaves two trailing zeros on average) instead of ~360 single-bit steps, and the
 // values shrink by ~1.4 bits each per step, so the wave walks the steps in PHASES of K = 8, 7, .. 1 live limbs (K = the longest value any of
 // its lanes still holds; a phase is left when limb K-1 of every lane's a and n is zero): 6 K + 11 instructions per step and symbol, ~8 k
-// instructions per symbol against the ~22 k of the single-bit form on all eight limbs (tools/scratch/jac_model.py counts both) and the ~50 k of
+// instructions per symbol against the ~22 k of the single-bit form on all eight limbs (tools/jac_model.py counts both) and the ~50 k of
 // Euler's criterion.  Two symbols share one loop (the subgroup test needs two: glv.h), which also gives every carry chain an independent
 // neighbour.  No branches inside a step; every lane walks the same stream; a lane that is done (a = 0) idles harmlessly: its z is 30 (even:
 // no sign change), it is never odd.  The loop ends on any input: a step with a odd shortens len(a) + len(n), a step with a even shifts.

@@ -725,7 +725,7 @@ template <class S, class G> struct Ring {
       // c = 12 / 11 / 10 / 9 -> 11.1 / 11.4 / 11.6 / 10.8 k proofs/s -- its latency-bound reductions sit on the critical path),
       // FOUR contexts sharing the chip, as bench.py and a loaded server run it, hide each other's reductions and pay for
       // additions only: c = 11 / 12 / 13 -> 13.8 / 14.4 / 13.8 k; BN254 ring 4096 (N = 8192): c = 12 / 13 -> 7.39 / 7.56 k
-      // (tools/ring4_bench.py, tools/scratch/r5_ringsweep*.sh).  The loaded regime decides: c = log2(3N + 1) rounded down
+      // (tools/ring4_bench.py with AVRF_RING_TABLE_C swept).  The loaded regime decides: c = log2(3N + 1) rounded down
       // (381-bit curve), one less on the 254-bit curve whose additions are cheaper relative to its reductions.
       { int lg = 0; while (((size_t)2 << lg) <= pcs) lg++;                    // floor(log2(3N + 1)) = log2(N) + 1
         su->table_c = G::Fq::N > 8 ? lg : lg - 1;
